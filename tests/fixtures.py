@@ -1,0 +1,34 @@
+"""Helpers shared by the tests: load a golden fixture and rebuild its weights (test infrastructure)."""
+import os
+
+import torch
+
+from fixture_weights import synth_weights          # oracle/
+import bbdm_oracle as O                            # oracle/
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx")
+
+
+def load_case(name):
+    rec = torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)
+    unet_sd = synth_weights(rec["unet_shapes"], rec["weight_seed"])
+    sd = {"denoise_fn." + k: v for k, v in unet_sd.items()}
+    sd.update(rec["buffers"])
+    rec["state_dict"] = sd
+    return rec
+
+
+def oracle_model(rec):
+    spec = O.UNetSpec(**rec["unet_params"])
+    bb = rec["bb_params"]
+    return O.OracleBBDM(rec["state_dict"], spec, num_timesteps=bb["num_timesteps"], mt_type=bb["mt_type"],
+                        max_var=bb.get("max_var", 1), eta=bb.get("eta", 1), skip_sample=bb["skip_sample"],
+                        sample_type=bb["sample_type"], sample_step=bb["sample_step"], loss_type=bb["loss_type"],
+                        objective=bb["objective"])
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b|  (SURVEY.md §8c per-step parity metric)."""
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
