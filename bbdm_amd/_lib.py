@@ -1,0 +1,79 @@
+"""ctypes binding of libbbdm_hip.so (the C-ABI declared in include/bbdm_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails, the product path raises.
+Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C bbdm_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbbdm_hip.so")
+ABI_VERSION = 1
+
+_P = c_void_p
+# name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "bbdm_version": (c_int, []),
+    "bbdm_last_error": (c_char_p, []),
+    "bbdm_nchw_to_nhwc_f32": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_nhwc_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_conv_packed_floats": (c_size_t, [c_int, c_int, c_int]),
+    "bbdm_conv_pack_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_conv2d_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_groupnorm_stats_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_groupnorm_apply_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_float, c_int, c_int, _P]),
+    "bbdm_attention_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_timestep_embedding_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
+    "bbdm_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_bb_q_sample_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "bbdm_bb_p_sample_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int,
+                                          _P, _P, c_int, c_int, _P]),
+    "bbdm_bb_predict_x0_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "bbdm_bb_loss_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+}
+
+_lib = None
+
+
+class BBDMHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BBDMHipError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `make -C bbdm_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "bbdm_amd has no CPU/PyTorch fallback by design.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.bbdm_version()
+    if v != ABI_VERSION:
+        raise BBDMHipError(f"libbbdm_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().bbdm_last_error()
+        raise BBDMHipError(f"{what or 'bbdm call'} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point and raise on a non-zero code."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)

@@ -1,0 +1,44 @@
+// Shared helpers for the libbbdm_hip.so kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/bbdm_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BBDM_WAVE 64
+
+void bbdm_set_error(const char* fmt, ...);
+
+#define BBDM_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            bbdm_set_error(__VA_ARGS__);   \
+            return BBDM_E_BADARG;          \
+        }                                  \
+    } while (0)
+
+#define BBDM_CHECK_LAUNCH(what)                                                        \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            bbdm_set_error("%s: launch failed: %s", what, hipGetErrorString(e__));     \
+            return BBDM_E_LAUNCH;                                                      \
+        }                                                                              \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int ceil_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+static inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }

@@ -1,0 +1,348 @@
+// conv_igemm.hip -- fp32 NHWC convolution (3x3 pad 1 / 1x1, stride 1) as an implicit GEMM on the CDNA4
+// f32-input matrix core (v_mfma_f32_32x32x2_f32, exact fp32 = an fmaf chain).
+//
+// Replaces the reference's nn.Conv2d / nn.Conv1d(k=1) call sites: openaimodel.py:207,233,244,307,315,524,690.
+//
+// GEMM view:  out[m, co] = sum_{tap, ci} x[pixel(m) + tap, ci] * W[tap, ci, co],   m = (n, h, w)
+//
+// Work decomposition (one workgroup = 4 or 8 waves = BM output pixels x BN output channels):
+//   * the BM pixels are IMGS whole-or-partial images x a TH x TW spatial tile (all powers of two), so that the
+//     input needed by all 9 taps is ONE halo patch (TH+2) x (TW+2) per image, staged into LDS once per
+//     16-channel chunk and re-used by the 9 taps (9x fewer L2/HBM reads than a materialised im2col).
+//   * K is walked chunk-major, tap-minor ("phase" = (chunk, tap)); per phase the [BN x 16] weight slab is
+//     staged (the packed layout makes it one contiguous 8 KB run), double-buffered; the patch is
+//     double-buffered per chunk.  Global loads for phase p+1 are issued before phase p's MFMAs and written to
+//     the other LDS buffer after them: one __syncthreads per phase, HBM/L2 latency hidden under 4096 cycles
+//     of MFMA per wave.
+//   * LDS rows are [pixel][16 ch + 4 pad] and [cout][16 ch + 4 pad]: a lane fetches 4 consecutive k with one
+//     ds_read_b128 (lanes 0-31: k0..k0+3, lanes 32-63: k0+4..k0+7, matching the 32x32x2 operand map where
+//     lanes>=32 carry the second k) and the 20-float pitch makes every 16-lane b128 group hit 16 distinct
+//     16-byte slots -> conflict-free.
+//   * every wave owns a 64x64 output tile (4 accumulators of 16 VGPRs); the 256x128 block runs 8 waves and two
+//     blocks share a CU (<=75 KB LDS, <=128 VGPR each): 4 waves per SIMD cover each other's barriers.
+#include "common.h"
+
+namespace {
+
+constexpr int KC = 16;   // input channels per chunk (also the packed-weight inner dimension)
+constexpr int KP = 20;   // LDS pitch of one pixel / one cout row (16 + 4 pad floats)
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* out;
+    int ldx, ldr, ldo, out_nchw;
+    int N, H, W, Cin, Cout, CoutPad;
+    int taps, nchunks, pad;
+    int TWl, THl, IMl;          // log2 of tile width / height / images per block
+    int PW, PH, patchPix;       // patch geometry (incl. halo), pixels per block patch
+    int tilesX, tilesY, tilesN;
+};
+
+template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC>
+__global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
+conv_igemm_f32(const ConvArgs a) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int MT = BM / WM / 32;     // 32-row MFMA tiles per wave (M)
+    constexpr int NTL = BN / WN / 32;    // 32-col MFMA tiles per wave (N)
+    constexpr int WSLOTS = (BN * KC / 4) / NTHR;
+    static_assert((BN * KC / 4) % NTHR == 0, "weight slab must divide evenly");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int patchFloats = a.patchPix * KP;
+    float* pbuf = smem;                          // [2][patchPix][KP]
+    float* wbuf = smem + 2 * patchFloats;        // [2][BN][KP]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- block -> tile ------------------------------------------------------------------------------
+    int bid = blockIdx.x;
+    const int n_tile = bid % a.tilesN;
+    bid /= a.tilesN;
+    const int tile_x = bid % a.tilesX;
+    bid /= a.tilesX;
+    const int tile_y = bid % a.tilesY;
+    const int ig = bid / a.tilesY;
+    const int TW = 1 << a.TWl, TH = 1 << a.THl;
+    const int img0 = ig << a.IMl;
+    const int h0 = tile_y * TH - a.pad, w0 = tile_x * TW - a.pad;
+    const int cout0 = n_tile * BN;
+
+    // ---- per-thread patch staging slots (same pixels for every chunk) ---------------------------------
+    uint32_t goff[PSLOTS];
+    uint32_t pvalid = 0;
+    const int nPatchVec = a.patchPix * (KC / 4);
+#pragma unroll
+    for (int s = 0; s < PSLOTS; ++s) {
+        const int f = tid + s * NTHR;
+        goff[s] = 0;
+        if (f < nPatchVec) {
+            const int pp = f >> 2, c4 = f & 3;
+            const int img_l = pp / (a.PH * a.PW);
+            const int rem = pp - img_l * (a.PH * a.PW);
+            const int py = rem / a.PW, px = rem - py * a.PW;
+            const int n = img0 + img_l, h = h0 + py, w = w0 + px;
+            if (n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W) {
+                goff[s] = (uint32_t)(((n * a.H + h) * a.W + w)) * (uint32_t)a.ldx + c4 * 4;
+                pvalid |= 1u << s;
+            }
+        }
+    }
+
+    // ---- per-lane fragment bases --------------------------------------------------------------------
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = wm * (BM / WM) + mt * 32 + (lane & 31);
+        const int img_l = m >> (a.THl + a.TWl);
+        const int ph = (m >> a.TWl) & (TH - 1);
+        const int pw = m & (TW - 1);
+        abase[mt] = (img_l * a.PH * a.PW + ph * a.PW + pw) * KP + (lane >> 5) * 4;
+    }
+    int bbase[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) bbase[nt] = (wn * (BN / WN) + nt * 32 + (lane & 31)) * KP + (lane >> 5) * 4;
+
+    f32x16 acc[MT][NTL];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const size_t wPhaseStride = (size_t)a.CoutPad * KC;
+    const float* wsrc = a.w + (size_t)cout0 * KC + tid * 4;   // + phase * wPhaseStride + s * NTHR * 4
+
+    float4 preg[PSLOTS];
+    float4 wreg[WSLOTS];
+
+    auto load_patch = [&](int chunk) {
+        const int cbase = chunk * KC;
+#pragma unroll
+        for (int s = 0; s < PSLOTS; ++s) {
+            const int c = cbase + ((tid + s * NTHR) & 3) * 4;
+            if (((pvalid >> s) & 1u) && c < a.Cin)
+                preg[s] = *reinterpret_cast<const float4*>(a.x + goff[s] + cbase);
+            else
+                preg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&](float* dst) {
+#pragma unroll
+        for (int s = 0; s < PSLOTS; ++s) {
+            const int f = tid + s * NTHR;
+            if (f < nPatchVec) *reinterpret_cast<float4*>(dst + (f >> 2) * KP + (f & 3) * 4) = preg[s];
+        }
+    };
+    auto load_w = [&](int phase) {
+        // packed order is [tap][chunk][CoutPad][KC]; phase = chunk * taps + tap
+        const int chunk = phase / a.taps, tap = phase - chunk * a.taps;
+        const float* src = wsrc + (size_t)(tap * a.nchunks + chunk) * wPhaseStride;
+#pragma unroll
+        for (int s = 0; s < WSLOTS; ++s) wreg[s] = *reinterpret_cast<const float4*>(src + s * NTHR * 4);
+    };
+    auto store_w = [&](float* dst) {
+#pragma unroll
+        for (int s = 0; s < WSLOTS; ++s) {
+            const int f = tid + s * NTHR;
+            *reinterpret_cast<float4*>(dst + (f >> 2) * KP + (f & 3) * 4) = wreg[s];
+        }
+    };
+
+    // ---- prologue ------------------------------------------------------------------------------------
+    load_patch(0);
+    load_w(0);
+    store_patch(pbuf);
+    store_w(wbuf);
+    __syncthreads();
+
+    const int nphase = a.nchunks * a.taps;
+    int chunk = 0, tap = 0;
+    for (int phase = 0; phase < nphase; ++phase) {
+        const bool has_next = phase + 1 < nphase;
+        const bool last_tap = tap == a.taps - 1;
+        if (has_next) load_w(phase + 1);
+        if (last_tap && has_next) load_patch(chunk + 1);
+
+        const int r = tap / 3, s = tap - r * 3;
+        const float* P = pbuf + (chunk & 1) * patchFloats + (a.taps == 1 ? 0 : (r * a.PW + s) * KP);
+        const float* Wb = wbuf + (phase & 1) * (BN * KP);
+#pragma unroll
+        for (int kg = 0; kg < KC / 8; ++kg) {
+            float4 af[MT], bf[NTL];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(P + abase[mt] + kg * 8);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) bf[nt] = *reinterpret_cast<const float4*>(Wb + bbase[nt] + kg * 8);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].x, bf[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].y, bf[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].z, bf[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].w, bf[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+
+        if (has_next) store_w(wbuf + ((phase + 1) & 1) * (BN * KP));
+        if (last_tap && has_next) store_patch(pbuf + ((chunk + 1) & 1) * patchFloats);
+        __syncthreads();
+        if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
+    }
+
+    // ---- epilogue: + bias (+ residual) -> global --------------------------------------------------------
+    const int hbase = tile_y * TH, wbase = tile_x * TW;
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int co = cout0 + wn * (BN / WN) + nt * 32 + (lane & 31);
+        const bool cok = co < a.Cout;
+        const float bv = (cok && a.bias) ? a.bias[co] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = img0 + (m >> (a.THl + a.TWl));
+                const int h = hbase + ((m >> a.TWl) & (TH - 1));
+                const int w = wbase + (m & (TW - 1));
+                if (cok && n < a.N && h < a.H && w < a.W) {
+                    const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+                    float v = acc[mt][nt][r] + bv;
+                    if (a.res) v += a.res[pix * a.ldr + co];
+                    if (a.out_nchw)
+                        a.out[((size_t)(n * a.Cout + co) * a.H + h) * a.W + w] = v;
+                    else
+                        a.out[pix * a.ldo + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- OIHW -> packed [tap][chunk][CoutPad][16] -------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int CinPad,
+                                   int ks, int CoutPad, int nchunks) {
+    const size_t total = (size_t)ks * ks * nchunks * CoutPad * KC;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = i % KC;
+        size_t t = i / KC;
+        const int co = t % CoutPad;
+        t /= CoutPad;
+        const int chunk = t % nchunks;
+        const int tap = t / nchunks;
+        const int ci = chunk * KC + k;
+        float v = 0.0f;
+        if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * ks * ks + tap];
+        p[i] = v;
+    }
+}
+
+template <typename K>
+int set_lds_limit(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes) == hipSuccess
+               ? 0
+               : -1;
+}
+
+template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC>
+int launch_conv(ConvArgs& a, hipStream_t stream) {
+    const int TWc = ceil_pow2(a.W) < 32 ? ceil_pow2(a.W) : 32;
+    int THc = BM / TWc;
+    if (THc > ceil_pow2(a.H)) THc = ceil_pow2(a.H);
+    const int IM = BM / (TWc * THc);
+    a.TWl = ilog2(TWc);
+    a.THl = ilog2(THc);
+    a.IMl = ilog2(IM);
+    a.PW = TWc + 2 * a.pad;
+    a.PH = THc + 2 * a.pad;
+    a.patchPix = IM * a.PW * a.PH;
+    a.tilesX = cdiv(a.W, TWc);
+    a.tilesY = cdiv(a.H, THc);
+    a.tilesN = cdiv(a.Cout, BN);
+    if (a.patchPix * (KC / 4) > PSLOTS * WM * WN * 64) return 1;   // does not fit this instantiation
+    const size_t lds = ((size_t)2 * a.patchPix * KP + 2 * BN * KP) * sizeof(float);
+    if (lds > 160 * 1024) return 1;
+    auto kern = conv_igemm_f32<BM, BN, WM, WN, PSLOTS, OCC>;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (set_lds_limit(kern, lds) != 0) {
+            bbdm_set_error("conv: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        lds_set = lds;
+    }
+    const long long blocks = (long long)a.tilesN * a.tilesX * a.tilesY * cdiv(a.N, IM);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t bbdm_conv_packed_floats(int Cout, int CinPad, int ks) {
+    const int CoutPad = cdiv(Cout, 128) * 128;
+    const int nchunks = cdiv(CinPad, KC);
+    return (size_t)ks * ks * nchunks * CoutPad * KC;
+}
+
+extern "C" int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int CinPad, int ks,
+                                         void* stream) {
+    BBDM_REQUIRE(w_oihw && packed, "conv_pack: null pointer");
+    BBDM_REQUIRE((ks == 1 || ks == 3) && Cout > 0 && Cin > 0 && CinPad >= Cin && CinPad % 4 == 0,
+                 "conv_pack: bad shape Cout=%d Cin=%d CinPad=%d ks=%d", Cout, Cin, CinPad, ks);
+    const int CoutPad = cdiv(Cout, 128) * 128;
+    const int nchunks = cdiv(CinPad, KC);
+    const size_t total = bbdm_conv_packed_floats(Cout, CinPad, ks);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin,
+                       CinPad, ks, CoutPad, nchunks);
+    BBDM_CHECK_LAUNCH("conv_pack");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
+                                    const float* residual, int ldr, float* out, int ldo, int out_nchw, int N, int H,
+                                    int W, int CinPad, int Cout, int ks, void* stream) {
+    BBDM_REQUIRE(x && packed_w && out, "conv2d: null pointer");
+    BBDM_REQUIRE(ks == 1 || ks == 3, "conv2d: ks=%d unsupported (1 or 3)", ks);
+    BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && CinPad > 0, "conv2d: bad shape");
+    BBDM_REQUIRE(CinPad % 4 == 0 && ldx % 4 == 0 && ldx >= CinPad, "conv2d: CinPad=%d ldx=%d must be multiples of 4",
+                 CinPad, ldx);
+    BBDM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv2d: x / w must be 16-byte aligned");
+    BBDM_REQUIRE((size_t)N * H * W * (size_t)ldx < (1ull << 32), "conv2d: input exceeds 2^32 elements");
+    BBDM_REQUIRE(out_nchw || ldo >= Cout, "conv2d: ldo < Cout");
+    BBDM_REQUIRE(!residual || ldr >= Cout, "conv2d: ldr < Cout");
+    ConvArgs a;
+    a.x = x; a.w = packed_w; a.bias = bias; a.res = residual; a.out = out;
+    a.ldx = ldx; a.ldr = ldr; a.ldo = ldo; a.out_nchw = out_nchw;
+    a.N = N; a.H = H; a.W = W; a.Cin = CinPad; a.Cout = Cout;
+    a.CoutPad = cdiv(Cout, 128) * 128;
+    a.taps = ks * ks; a.nchunks = cdiv(CinPad, KC); a.pad = ks / 2;
+    hipStream_t st = (hipStream_t)stream;
+    const long long M = (long long)N * H * W;
+    int rc;
+    // Tile choice: 256x128 when it still yields >= 2 blocks per CU, else 128x128.
+    const long long blocks256 = ((M + 255) / 256) * cdiv(Cout, 128);
+    if (blocks256 >= 512) {
+        rc = launch_conv<256, 128, 4, 2, 3, 2>(a, st);
+        if (rc == 1) rc = launch_conv<256, 128, 4, 2, 5, 2>(a, st);
+    } else {
+        rc = launch_conv<128, 128, 2, 2, 4, 2>(a, st);
+        if (rc == 1) rc = launch_conv<128, 128, 2, 2, 6, 2>(a, st);
+    }
+    if (rc == 1) {
+        bbdm_set_error("conv2d: no tile configuration fits N=%d H=%d W=%d", N, H, W);
+        return BBDM_E_BADARG;
+    }
+    if (rc < 0) return rc;
+    BBDM_CHECK_LAUNCH("conv2d");
+    return BBDM_OK;
+}

@@ -1,0 +1,233 @@
+// groupnorm.hip -- GroupNorm(32 groups) on fp32 NHWC tensors, split into
+//   (1) a statistics pass (per (n, group) sum / sum-of-squares, accumulated in fp64) and
+//   (2) a fused apply pass:  GN affine -> [FiLM (1+scale), shift] -> [SiLU] -> [2x2 avg-pool | nearest x2].
+//
+// Replaces util.py:199-216 (GroupNorm32) at openaimodel.py:205,229,306,688, the FiLM arithmetic at
+// openaimodel.py:270-273, nn.SiLU, Downsample/Upsample without conv (openaimodel.py:118,159) at :259-264.
+//
+// Both passes are HBM-bound streaming kernels: 16-byte (float4) accesses along the contiguous channel
+// axis, one wave covers 1 KiB of consecutive bytes, many small blocks so that all 256 CUs stream.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// stats: grid = (pixel splits, N).  Thread t owns channel-quads c4 = t % C4 (+ k*256 when C4 > 256) and walks
+// pixels with stride PP = 256 / C4; its accumulators therefore always belong to one group per quad.
+// ---------------------------------------------------------------------------------------------------------
+template <int JMAX>
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int ldx, double* __restrict__ stats,
+                                                       int HW, int C, int G, int pix_per_block) {
+    __shared__ double lsum[64 * 2];      // G <= 64
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int C4 = C >> 2;
+    const int cpg = C / G;
+    if (tid < 2 * G) lsum[tid] = 0.0;
+    __syncthreads();
+
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    const float* xb = x + (size_t)n * HW * ldx;
+
+    int PP, prow, c4base;
+    bool active;
+    if (C4 <= 256) {
+        PP = 256 / C4;
+        prow = tid / C4;
+        c4base = tid - prow * C4;
+        active = prow < PP;
+    } else {
+        PP = 1;
+        prow = 0;
+        c4base = tid;
+        active = true;
+    }
+    double s[JMAX], ss[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) s[j] = ss[j] = 0.0;
+    if (active) {
+        for (int p = p0 + prow; p < p1; p += PP) {
+            const float* row = xb + (size_t)p * ldx;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                const int c4 = c4base + j * 256;
+                if (c4 < C4) {
+                    const float4 v = *reinterpret_cast<const float4*>(row + c4 * 4);
+                    s[j] += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+                    ss[j] += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int c4 = c4base + j * 256;
+            if (c4 < C4) {
+                const int g = (c4 * 4) / cpg;     // cpg % 4 == 0 -> a quad never straddles two groups
+                atomicAdd(&lsum[2 * g], s[j]);
+                atomicAdd(&lsum[2 * g + 1], ss[j]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * G) atomicAdd(&stats[(size_t)n * G * 2 + tid], lsum[tid]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// apply
+// ---------------------------------------------------------------------------------------------------------
+struct ApplyArgs {
+    const float* x;
+    const double* stats;
+    const float* gamma;
+    const float* beta;
+    const float* film;
+    float* y;
+    int ldx, ldy, film_ld;
+    int H, W, C, G;
+    float eps;
+    int silu, resample, norm;
+};
+
+__device__ __forceinline__ float4 gn_xform(const ApplyArgs& a, float4 v, float4 sc, float4 bi) {
+    if (a.norm) {
+        v.x = v.x * sc.x + bi.x;
+        v.y = v.y * sc.y + bi.y;
+        v.z = v.z * sc.z + bi.z;
+        v.w = v.w * sc.w + bi.w;
+    }
+    if (a.silu) {
+        v.x = silu_f(v.x);
+        v.y = silu_f(v.y);
+        v.z = silu_f(v.z);
+        v.w = silu_f(v.w);
+    }
+    return v;
+}
+
+// grid = (blocks over out-units, N).  A "unit" is one float4 of one INPUT pixel (resample 0, 2) or of one OUTPUT
+// pixel (resample 1).
+__global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
+    const int n = blockIdx.y;
+    const int C4 = a.C >> 2;
+    const int Hu = a.resample == 1 ? a.H >> 1 : a.H;
+    const int Wu = a.resample == 1 ? a.W >> 1 : a.W;
+    const long long units = (long long)Hu * Wu * C4;
+    const int cpg = a.C / a.G;
+    const double cnt = (double)a.H * a.W * cpg;
+    const int Ho = a.resample == 1 ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
+    const int Wo = a.resample == 1 ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
+    const float* xb = a.x + (size_t)n * a.H * a.W * a.ldx;
+    float* yb = a.y + (size_t)n * Ho * Wo * a.ldy;
+
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+        const int c4 = (int)(u % C4);
+        const int pu = (int)(u / C4);
+        const int c = c4 * 4;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.norm) {
+            const int g = c / cpg;
+            const double s = a.stats[((size_t)n * a.G + g) * 2], ss = a.stats[((size_t)n * a.G + g) * 2 + 1];
+            const double mean = s / cnt;
+            double var = ss / cnt - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            const float fmean = (float)mean;
+            const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+            // y = (x - mean) * rstd * gamma + beta  ==  x * sc + bi
+            sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
+            bi = make_float4(be.x - fmean * sc.x, be.y - fmean * sc.y, be.z - fmean * sc.z, be.w - fmean * sc.w);
+            if (a.film) {
+                // h = GN(h) * (1 + scale) + shift     (openaimodel.py:272-273)
+                const float4 fs = *reinterpret_cast<const float4*>(a.film + (size_t)n * a.film_ld + c);
+                const float4 fb = *reinterpret_cast<const float4*>(a.film + (size_t)n * a.film_ld + a.C + c);
+                sc = make_float4(sc.x * (1.f + fs.x), sc.y * (1.f + fs.y), sc.z * (1.f + fs.z), sc.w * (1.f + fs.w));
+                bi = make_float4(bi.x * (1.f + fs.x) + fb.x, bi.y * (1.f + fs.y) + fb.y, bi.z * (1.f + fs.z) + fb.z,
+                                 bi.w * (1.f + fs.w) + fb.w);
+            }
+        }
+        if (a.resample == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)pu * a.ldx + c);
+            *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = gn_xform(a, v, sc, bi);
+        } else if (a.resample == 1) {
+            const int ho = pu / Wu, wo = pu - ho * Wu;
+            const float* r0 = xb + ((size_t)(2 * ho) * a.W + 2 * wo) * a.ldx + c;
+            const float* r1 = r0 + (size_t)a.W * a.ldx;
+            const float4 v00 = gn_xform(a, *reinterpret_cast<const float4*>(r0), sc, bi);
+            const float4 v01 = gn_xform(a, *reinterpret_cast<const float4*>(r0 + a.ldx), sc, bi);
+            const float4 v10 = gn_xform(a, *reinterpret_cast<const float4*>(r1), sc, bi);
+            const float4 v11 = gn_xform(a, *reinterpret_cast<const float4*>(r1 + a.ldx), sc, bi);
+            float4 o;
+            o.x = (((v00.x + v01.x) + v10.x) + v11.x) * 0.25f;
+            o.y = (((v00.y + v01.y) + v10.y) + v11.y) * 0.25f;
+            o.z = (((v00.z + v01.z) + v10.z) + v11.z) * 0.25f;
+            o.w = (((v00.w + v01.w) + v10.w) + v11.w) * 0.25f;
+            *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = o;
+        } else {
+            const int h = pu / a.W, w = pu - h * a.W;
+            const float4 v = gn_xform(a, *reinterpret_cast<const float4*>(xb + (size_t)pu * a.ldx + c), sc, bi);
+            float* o0 = yb + ((size_t)(2 * h) * Wo + 2 * w) * a.ldy + c;
+            float* o1 = o0 + (size_t)Wo * a.ldy;
+            *reinterpret_cast<float4*>(o0) = v;
+            *reinterpret_cast<float4*>(o0 + a.ldy) = v;
+            *reinterpret_cast<float4*>(o1) = v;
+            *reinterpret_cast<float4*>(o1 + a.ldy) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int HW, int C, int G,
+                                        void* stream) {
+    BBDM_REQUIRE(x && stats, "gn_stats: null pointer");
+    BBDM_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= 64 && C % G == 0, "gn_stats: bad shape C=%d G=%d", C, G);
+    BBDM_REQUIRE((C / G) % 4 == 0 && ldx % 4 == 0 && ldx >= C && ((uintptr_t)x & 15) == 0,
+                 "gn_stats: channels per group (%d) and ldx (%d) must be multiples of 4", C / G, ldx);
+    const int C4 = C / 4;
+    BBDM_REQUIRE(C4 <= 1024, "gn_stats: C=%d > 4096 unsupported", C);
+    // ~2048 blocks in total, but at least 8 pixel-rows of work per thread row
+    const int PP = C4 <= 256 ? 256 / C4 : 1;
+    int splits = cdiv(2048, N);
+    int ppb = cdiv(HW, splits);
+    if (ppb < PP * 8) ppb = PP * 8;
+    splits = cdiv(HW, ppb);
+    dim3 grid(splits, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (C4 <= 256)
+        hipLaunchKernelGGL(gn_stats_kernel<1>, grid, dim3(256), 0, st, x, ldx, stats, HW, C, G, ppb);
+    else if (C4 <= 512)
+        hipLaunchKernelGGL(gn_stats_kernel<2>, grid, dim3(256), 0, st, x, ldx, stats, HW, C, G, ppb);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<4>, grid, dim3(256), 0, st, x, ldx, stats, HW, C, G, ppb);
+    BBDM_CHECK_LAUNCH("gn_stats");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const float* gamma,
+                                        const float* beta, const float* film, int film_ld, float* y, int ldy, int N,
+                                        int H, int W, int C, int G, float eps, int silu, int resample, void* stream) {
+    BBDM_REQUIRE(x && y, "gn_apply: null pointer");
+    const int norm = gamma != nullptr;
+    BBDM_REQUIRE(!norm || (stats && beta), "gn_apply: gamma given without stats/beta");
+    BBDM_REQUIRE(norm || !film, "gn_apply: film without norm");
+    BBDM_REQUIRE(resample >= 0 && resample <= 2, "gn_apply: resample=%d", resample);
+    BBDM_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avg-pool needs even H, W");
+    BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
+                 "gn_apply: bad shape / pitch");
+    BBDM_REQUIRE(!norm || (G > 0 && C % G == 0 && (C / G) % 4 == 0), "gn_apply: bad groups");
+    BBDM_REQUIRE(!film || film_ld % 4 == 0, "gn_apply: film_ld %% 4");
+    BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "gn_apply: x / y must be 16-byte aligned");
+    ApplyArgs a;
+    a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.y = y;
+    a.ldx = ldx; a.ldy = ldy; a.film_ld = film_ld;
+    a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample; a.norm = norm;
+    const long long units = (long long)(resample == 1 ? (H / 2) * (W / 2) : H * W) * (C / 4);
+    long long blocks = (units + 255) / 256;
+    const long long cap = cdiv(8192, N) > 1 ? cdiv(8192, N) : 1;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, a);
+    BBDM_CHECK_LAUNCH("gn_apply");
+    return BBDM_OK;
+}

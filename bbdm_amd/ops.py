@@ -1,0 +1,132 @@
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/bbdm_hip.h).
+
+They allocate outputs with torch, pass raw device pointers + the current HIP stream, and raise on error.  Used by
+the kernel unit tests and the training path; the inference path (unet._Plan) calls the library directly with
+pre-resolved pointers.  NHWC tensors here are plain contiguous ``[N, H, W, C]`` torch tensors (pitch = C) unless a
+wider buffer + channel slice is passed explicitly via ``ld`` arguments.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def _st(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.BBDMHipError(f"bbdm_amd ops need GPU tensors (no CPU fallback); got {t.device}")
+        if t.dtype not in (torch.float32, torch.float64, torch.int64):
+            raise TypeError(f"unsupported dtype {t.dtype}")
+        if not t.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+
+
+def nchw_to_nhwc(a: torch.Tensor, b: Optional[torch.Tensor] = None, cpad: Optional[int] = None) -> torch.Tensor:
+    _chk(a, b)
+    N, Ca, H, W = a.shape
+    Cb = 0 if b is None else b.shape[1]
+    cpad = cpad or (Ca + Cb + 3) // 4 * 4
+    out = torch.empty(N, H, W, cpad, dtype=torch.float32, device=a.device)
+    _lib.call("bbdm_nchw_to_nhwc_f32", a.data_ptr(), Ca, None if b is None else b.data_ptr(), Cb, out.data_ptr(),
+              cpad, cpad, N, H, W, _st(a))
+    return out
+
+
+def nhwc_to_nchw(x: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
+    _chk(x)
+    N, H, W, ld = x.shape
+    C = C or ld
+    out = torch.empty(N, C, H, W, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_nhwc_to_nchw_f32", x.data_ptr(), ld, out.data_ptr(), N, H, W, C, _st(x))
+    return out
+
+
+def pack_conv_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    """OIHW (or [O, I, 1] conv1d) fp32 -> packed buffer for :func:`conv2d_nhwc`."""
+    _chk(w)
+    cout, cin = w.shape[0], w.shape[1]
+    ks = w.shape[2] if w.dim() == 4 else 1
+    cin_pad = cin_pad or (cin + 3) // 4 * 4
+    n = _lib.load().bbdm_conv_packed_floats(cout, cin_pad, ks)
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), packed.data_ptr(), cout, cin, cin_pad, ks, _st(w))
+    return packed
+
+
+def conv2d_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ks: int,
+                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                out_nchw: bool = False) -> torch.Tensor:
+    """x: [N, H, W, CinPad] -> [N, H, W, cout] (or NCHW).  ``residual`` [N, H, W, cout] is added in the epilogue."""
+    _chk(x, packed_w, bias, residual, out)
+    N, H, W, cin_pad = x.shape
+    if out is None:
+        shape = (N, cout, H, W) if out_nchw else (N, H, W, cout)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv2d_nhwc_f32", x.data_ptr(), cin_pad, packed_w.data_ptr(),
+              None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
+              0 if residual is None else residual.shape[-1], out.data_ptr(), 0 if out_nchw else out.shape[-1],
+              1 if out_nchw else 0, N, H, W, cin_pad, cout, ks, _st(x))
+    return out
+
+
+def groupnorm_stats(x: torch.Tensor, groups: int = 32) -> torch.Tensor:
+    _chk(x)
+    N, H, W, C = x.shape
+    stats = torch.zeros(N, groups, 2, dtype=torch.float64, device=x.device)
+    _lib.call("bbdm_groupnorm_stats_f32", x.data_ptr(), C, stats.data_ptr(), N, H * W, C, groups, _st(x))
+    return stats
+
+
+def groupnorm_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
+                    beta: Optional[torch.Tensor], film: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                    silu: bool = False, resample: int = 0, groups: int = 32) -> torch.Tensor:
+    """film: [N, 2C] (scale | shift).  resample: 0 none, 1 avg-pool 2x2, 2 nearest x2."""
+    _chk(x, stats, gamma, beta, film)
+    N, H, W, C = x.shape
+    Ho, Wo = (H // 2, W // 2) if resample == 1 else ((2 * H, 2 * W) if resample == 2 else (H, W))
+    y = torch.empty(N, Ho, Wo, C, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_groupnorm_apply_f32", x.data_ptr(), C, None if stats is None else stats.data_ptr(),
+              None if gamma is None else gamma.data_ptr(), None if beta is None else beta.data_ptr(),
+              None if film is None else film.data_ptr(), 0 if film is None else film.shape[1], y.data_ptr(), C,
+              N, H, W, C, groups, float(eps), 1 if silu else 0, resample, _st(x))
+    return y
+
+
+def attention(qkv: torch.Tensor, heads: int, new_order: bool = False) -> torch.Tensor:
+    """qkv: [N, T, 3*heads*ch] -> [N, T, heads*ch]."""
+    _chk(qkv)
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    out = torch.empty(N, T, C, dtype=torch.float32, device=qkv.device)
+    _lib.call("bbdm_attention_f32", qkv.data_ptr(), C3, out.data_ptr(), C, N, T, heads, C // heads,
+              1 if new_order else 0, _st(qkv))
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, freqs: torch.Tensor, dim: int) -> torch.Tensor:
+    _chk(t, freqs)
+    emb = torch.empty(t.shape[0], dim, dtype=torch.float32, device=t.device)
+    _lib.call("bbdm_timestep_embedding_f32", t.data_ptr(), freqs.data_ptr(), emb.data_ptr(), t.shape[0], dim, _st(t))
+    return emb
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act_in: bool = False,
+           act_out: bool = False) -> torch.Tensor:
+    _chk(x, w, b)
+    N, In = x.shape
+    Out = w.shape[0]
+    y = torch.empty(N, Out, dtype=torch.float32, device=x.device)
+    for r0 in range(0, N, 64):
+        r = min(64, N - r0)
+        _lib.call("bbdm_linear_f32", x.data_ptr() + 4 * r0 * In, w.data_ptr(), None if b is None else b.data_ptr(),
+                  y.data_ptr() + 4 * r0 * Out, r, In, Out, 1 if act_in else 0, 1 if act_out else 0, _st(x))
+    return y

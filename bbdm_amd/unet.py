@@ -1,0 +1,668 @@
+"""UNetModel -- the BBDM denoiser executed by hand-written HIP kernels (libbbdm_hip.so).
+
+Mirror of the reference's ``UNetModel`` (model/BrownianBridge/base/modules/diffusionmodules/openaimodel.py:416-759):
+same constructor keywords (``UNetModel(**vars(UNetParams))``, BrownianBridgeModel.py:40), same sub-module tree and
+therefore the same ``state_dict()`` keys / shapes / dtypes and the same parameter-initialisation order under a
+given seed, same ``forward(x, timesteps, context)`` contract (NCHW fp32 in, NCHW fp32 out).
+
+The ``nn.Conv2d`` / ``nn.Linear`` / ``GroupNorm32`` children are *parameter holders* (so the runner's
+``weights_init`` -- runners/utils.py:35-45, which dispatches on class names -- EMA, the optimizer, DDP and
+``load_state_dict`` behave exactly as with the reference); their own ``forward`` is never used.  ``forward`` here
+compiles, per input shape, a static list of C-ABI calls over pre-allocated NHWC fp32 buffers and replays it.
+
+There is no PyTorch fallback: without the HIP library, or on a non-GPU tensor, ``forward`` raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ["UNetModel"]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# parameter-holder modules (names follow the reference so that class-name based init hooks match)
+# --------------------------------------------------------------------------------------------------------------
+class GroupNorm32(nn.GroupNorm):
+    """util.py:214-216."""
+
+
+def _zero_(module: nn.Module) -> nn.Module:
+    """util.py:174-180 (zero_module)."""
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def _no_forward(self, *a, **k):
+    raise RuntimeError(f"{type(self).__name__} is a parameter holder of bbdm_amd.UNetModel; call the UNetModel")
+
+
+class TimestepEmbedSequential(nn.Sequential):
+    """openaimodel.py:75-90 (container only)."""
+    forward = _no_forward
+
+
+class Upsample(nn.Module):
+    """openaimodel.py:93-121."""
+
+    def __init__(self, channels, use_conv, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=1)
+
+    forward = _no_forward
+
+
+class Downsample(nn.Module):
+    """openaimodel.py:137-163."""
+
+    def __init__(self, channels, use_conv, out_channels=None):
+        super().__init__()
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=1)
+        else:
+            assert self.channels == self.out_channels
+            self.op = nn.AvgPool2d(kernel_size=2, stride=2)
+
+    forward = _no_forward
+
+
+class ResBlock(nn.Module):
+    """openaimodel.py:166-278."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_scale_shift_norm=False,
+                 up=False, down=False):
+        super().__init__()
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.up, self.down = up, down
+        self.in_layers = nn.Sequential(GroupNorm32(32, channels), nn.SiLU(),
+                                       nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        if up:
+            self.h_upd, self.x_upd = Upsample(channels, False), Upsample(channels, False)
+        elif down:
+            self.h_upd, self.x_upd = Downsample(channels, False), Downsample(channels, False)
+        else:
+            self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(
+            nn.SiLU(), nn.Linear(emb_channels, 2 * self.out_channels if use_scale_shift_norm else self.out_channels))
+        self.out_layers = nn.Sequential(GroupNorm32(32, self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        _zero_(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+
+    forward = _no_forward
+
+
+class AttentionBlock(nn.Module):
+    """openaimodel.py:281-327."""
+
+    def __init__(self, channels, num_heads=1, num_head_channels=-1, use_new_attention_order=False):
+        super().__init__()
+        self.channels = channels
+        if num_head_channels == -1:
+            self.num_heads = num_heads
+        else:
+            assert channels % num_head_channels == 0, \
+                f"q,k,v channels {channels} is not divisible by num_head_channels {num_head_channels}"
+            self.num_heads = channels // num_head_channels
+        self.use_new_attention_order = use_new_attention_order
+        self.norm = GroupNorm32(32, channels)
+        self.qkv = nn.Conv1d(channels, channels * 3, 1)
+        self.proj_out = _zero_(nn.Conv1d(channels, channels, 1))
+
+    forward = _no_forward
+
+
+# --------------------------------------------------------------------------------------------------------------
+# small helpers for the executor
+# --------------------------------------------------------------------------------------------------------------
+class _Buf:
+    """A device allocation whose size is only known once the whole plan has been emitted."""
+    __slots__ = ("numel", "tensor")
+
+    def __init__(self, numel=0):
+        self.numel, self.tensor = numel, None
+
+
+class _View:
+    """An NHWC fp32 activation: (owning buffer, element offset, pitch, N, H, W, C).  Resolves to a device pointer."""
+    __slots__ = ("buf", "off", "ld", "N", "H", "W", "C")
+
+    def __init__(self, buf, off, ld, N, H, W, C):
+        self.buf, self.off, self.ld, self.N, self.H, self.W, self.C = buf, off, ld, N, H, W, C
+
+    def resolve(self):
+        return self.buf.tensor.data_ptr() + 4 * self.off
+
+
+class _TensorRef:
+    """Pointer into a tensor owned by the plan (+ byte offset)."""
+    __slots__ = ("t", "byte_off")
+
+    def __init__(self, t, byte_off=0):
+        self.t, self.byte_off = t, byte_off
+
+    def resolve(self):
+        return self.t.data_ptr() + self.byte_off
+
+
+class _ParamRef:
+    """Pointer to a model parameter, re-resolved whenever any parameter storage moves (EMA swaps ``param.data``,
+    runners/base/EMA.py:31-43; ``load_state_dict`` copies in place and keeps pointers)."""
+    __slots__ = ("p",)
+
+    def __init__(self, p):
+        self.p = p
+
+    def resolve(self):
+        p = self.p
+        if p.dtype != torch.float32 or not p.is_contiguous():
+            raise RuntimeError("bbdm_amd: parameters must be contiguous fp32")
+        return p.data_ptr()
+
+
+def _round4(c):
+    return (c + 3) // 4 * 4
+
+
+class _PackedConv:
+    """Packed copy of one conv weight, refreshed when the parameter storage or version changes
+    (EMA swaps ``param.data`` without bumping ``_version`` -- runners/base/EMA.py:31-43 -- so both are keyed)."""
+
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], cin_pad: int):
+        self.weight, self.bias = weight, bias
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.ks = weight.shape[2] if weight.dim() == 4 else 1      # Conv1d k=1: [O, I, 1] == [O, I, 1, 1] in memory
+        self.cin_pad = cin_pad
+        n = _lib.load().bbdm_conv_packed_floats(self.cout, cin_pad, self.ks)
+        self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        self.key = None
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
+                      self.cin_pad, self.ks, stream)
+            self.key = key
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------------------------------
+class UNetModel(nn.Module):
+    """Drop-in for the reference ``UNetModel`` (openaimodel.py:416-759); see the module docstring."""
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True,
+                 condition_key="concat"):
+        super().__init__()
+        # --- argument checks, same messages / conditions as openaimodel.py:474-491 ------------------------------
+        if use_spatial_transformer:
+            assert context_dim is not None, \
+                'Fool!! You forgot to include the dimension of your cross-attention conditioning...'
+        if context_dim is not None:
+            assert use_spatial_transformer, \
+                'Fool!! You forgot to use the spatial transformer for your cross-attention conditioning...'
+        if num_heads_upsample == -1:
+            num_heads_upsample = num_heads
+        if num_heads == -1:
+            assert num_head_channels != -1, 'Either num_heads or num_head_channels has to be set'
+        if num_head_channels == -1:
+            assert num_heads != -1, 'Either num_heads or num_head_channels has to be set'
+        # --- hot-path scope: everything the four reference templates use -------------------------
+        unsupported = []
+        if dims != 2:
+            unsupported.append(f"dims={dims}")
+        if num_classes is not None:
+            unsupported.append("num_classes")
+        if use_spatial_transformer:
+            unsupported.append("use_spatial_transformer (SURVEY.md §8f 'next')")
+        if n_embed is not None:
+            unsupported.append("n_embed")
+        if dropout:
+            unsupported.append(f"dropout={dropout}")
+        if unsupported:
+            raise NotImplementedError("bbdm_amd.UNetModel does not implement: " + ", ".join(unsupported))
+
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.num_classes = num_classes
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float32          # use_fp16 is a no-op in the reference too (openaimodel.py:25-29)
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads_upsample
+        self.predict_codebook_ids = False
+        self.condition_key = condition_key
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.use_new_attention_order = use_new_attention_order
+
+        mc = model_channels
+        ted = mc * 4
+        self.time_embed = nn.Sequential(nn.Linear(mc, ted), nn.SiLU(), nn.Linear(ted, ted))
+
+        def res(ch, out_ch, up=False, down=False):
+            return ResBlock(ch, ted, dropout, out_channels=out_ch, use_scale_shift_norm=use_scale_shift_norm,
+                            up=up, down=down)
+
+        def attn(ch, heads):
+            return AttentionBlock(ch, num_heads=heads, num_head_channels=num_head_channels,
+                                  use_new_attention_order=use_new_attention_order)
+
+        # construction order == openaimodel.py:518-691 (keeps RNG consumption, hence seeded init, identical)
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, mc, 3, padding=1))])
+        input_block_chans = [mc]
+        ch, ds = mc, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, mult * mc)]
+                ch = mult * mc
+                if ds in attention_resolutions:
+                    layers.append(attn(ch, num_heads))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(
+                    res(ch, ch, down=True) if resblock_updown else Downsample(ch, conv_resample, out_channels=ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepEmbedSequential(res(ch, ch), attn(ch, num_heads), res(ch, ch))
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = input_block_chans.pop()
+                layers = [res(ch + ich, mc * mult)]
+                ch = mc * mult
+                if ds in attention_resolutions:
+                    layers.append(attn(ch, num_heads_upsample))
+                if level and i == num_res_blocks:
+                    layers.append(res(ch, ch, up=True) if resblock_updown
+                                  else Upsample(ch, conv_resample, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+        self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), _zero_(nn.Conv2d(mc, out_channels, 3, padding=1)))
+
+        self._plans: Dict[tuple, "_Plan"] = {}
+        self._freqs: Optional[torch.Tensor] = None
+
+    # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
+    def convert_to_fp16(self):
+        pass
+
+    def convert_to_fp32(self):
+        pass
+
+    # ----------------------------------------------------------------------------------------------------------
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """openaimodel.py:721-759.  x: [N, C, H, W] fp32 on the GPU; returns [N, out_channels, H, W] fp32."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import unet_apply          # training path (autograd.Function over the same kernels)
+            return unet_apply(self, x, timesteps, context)
+        return self.infer(x, timesteps, context)
+
+    @torch.no_grad()
+    def infer(self, x, timesteps, context=None, out: Optional[torch.Tensor] = None):
+        if not x.is_cuda:
+            raise _lib.BBDMHipError("bbdm_amd.UNetModel runs on the GPU only (no CPU fallback by design); "
+                                    f"got a tensor on {x.device}")
+        if x.dtype != torch.float32:
+            raise TypeError(f"bbdm_amd.UNetModel computes in fp32 like the reference; got {x.dtype}")
+        ctx = None
+        if self.condition_key != "nocond":
+            if context is None:
+                raise ValueError("context is required unless condition_key == 'nocond' (openaimodel.py:741-742)")
+            ctx = context.contiguous().float()
+        x = x.contiguous()
+        cin = x.shape[1] + (ctx.shape[1] if ctx is not None else 0)
+        if cin != self.in_channels:
+            raise RuntimeError(f"expected {self.in_channels} input channels (x + context), got {cin}")
+        N, _, H, W = x.shape
+        key = (N, H, W, x.device.index, x.shape[1])
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, N, H, W, x.device, x.shape[1])
+            self._plans[key] = plan
+        t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
+        return plan.run(x, t, ctx, out)
+
+    def _apply(self, fn, *a, **k):
+        # .to(device) / .cuda() / .float(): drop compiled plans, they hold device pointers
+        self._plans = {}
+        self._freqs = None
+        return super()._apply(fn, *a, **k)
+
+    def freqs(self, device):
+        """util.py:160-163: evaluated on the CPU in fp32, then moved to the device."""
+        if self._freqs is None or self._freqs.device != device:
+            half = self.model_channels // 2
+            f = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+            self._freqs = f.to(device)
+        return self._freqs
+
+
+# --------------------------------------------------------------------------------------------------------------
+# shape-specialised execution plan
+# --------------------------------------------------------------------------------------------------------------
+class _Plan:
+    """Static schedule of C-ABI calls for one (N, H, W): buffers are allocated once, every call has fixed arguments.
+
+    Data layout in HBM: all activations fp32 NHWC.  Each ``th.cat([h, hs.pop()], 1)`` of the
+    reference (openaimodel.py:752) is a pre-allocated buffer whose two channel slices are written directly by the
+    producers of ``h`` and of the skip (pitch = total channels), so no concat copy exists.  Block-local
+    temporaries (normalised activations, conv intermediates, qkv) are five role buffers shared by all blocks.
+    """
+
+    GROUPS = 32
+
+    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int):
+        self.m, self.N, self.H, self.W, self.device, self.cx = m, N, H, W, device, cx
+        self.ops: List[tuple] = []          # (fn_name, args with unresolved refs)
+        self.convs: List[_PackedConv] = []
+        self.bufs: List[_Buf] = []
+        self._scratch: Dict[str, _Buf] = {}
+        self._gn_count = 0
+        self._params: List[nn.Parameter] = []
+        self.lib = _lib.load()
+        mc = m.model_channels
+        ted = 4 * mc
+        f32 = dict(dtype=torch.float32, device=device)
+
+        # ---- embedding path buffers -------------------------------------------------------------------------------
+        self.t_buf = torch.zeros(N, dtype=torch.int64, device=device)
+        self.e0 = torch.empty(N, mc, **f32)
+        self.e1 = torch.empty(N, ted, **f32)
+        self.emb = torch.empty(N, ted, **f32)
+        self.resblocks = [mod for mod in m.modules() if isinstance(mod, ResBlock)]
+        self.film_off = {}
+        off = 0
+        for rb in self.resblocks:
+            self.film_off[id(rb)] = off
+            off += rb.emb_layers[1].out_features
+        self.film_total = off
+        self.film = torch.empty(N, off, **f32)
+        self.film_w = torch.empty(off, ted, **f32)        # concatenation of every emb_layers.1 weight / bias
+        self.film_b = torch.empty(off, **f32)
+        self._film_key = None
+
+        # ---- input / output --------------------------------------------------------------------------------------
+        cin = m.in_channels
+        cpad = _round4(cin)
+        self.x_in = torch.empty(N, cx, H, W, **f32)
+        self.ctx_in = torch.empty(N, cin - cx, H, W, **f32) if cin > cx else None
+        self.out_nchw = torch.empty(N, m.out_channels, H, W, **f32)
+        x0 = self._new(N, H, W, cpad)
+        self._op("bbdm_nchw_to_nhwc_f32", _TensorRef(self.x_in), cx,
+                 _TensorRef(self.ctx_in) if self.ctx_in is not None else None, cin - cx, x0, x0.ld, cpad, N, H, W)
+
+        # ---- walk the graph (openaimodel.py:744-759) ---------------------------------------------------------------
+        # pass 1: channels / resolution of every input-block output, to size the concat buffers of the output blocks
+        in_shapes = []
+        h_c, hh, ww = None, H, W
+        for blk in m.input_blocks:
+            for layer in blk:
+                if isinstance(layer, nn.Conv2d):
+                    h_c = layer.out_channels
+                elif isinstance(layer, ResBlock):
+                    h_c = layer.out_channels
+                    if layer.down:
+                        hh, ww = hh // 2, ww // 2
+                elif isinstance(layer, Downsample):
+                    hh, ww = hh // 2, ww // 2
+            in_shapes.append((h_c, hh, ww))
+        mid_c = in_shapes[-1][0]
+        cat_bufs: List[_View] = []
+        hc, hh, ww = mid_c, in_shapes[-1][1], in_shapes[-1][2]
+        for blk, (sc, sh, sw) in zip(m.output_blocks, in_shapes[::-1]):
+            if (sh, sw) != (hh, ww):
+                raise RuntimeError(f"bbdm_amd: input {H}x{W} is not divisible by the UNet's down-sampling factor")
+            cat_bufs.append(self._new(N, hh, ww, hc + sc))
+            for layer in blk:
+                if isinstance(layer, ResBlock):
+                    hc = layer.out_channels
+                    if layer.up:
+                        hh, ww = hh * 2, ww * 2
+                elif isinstance(layer, Upsample):
+                    hc = layer.out_channels
+                    hh, ww = hh * 2, ww * 2
+        n_in = len(m.input_blocks)
+
+        def skip_dest(i):       # the skip of input block i is the tail slice of cat buffer (n_in - 1 - i)
+            cb = cat_bufs[n_in - 1 - i]
+            sc = in_shapes[i][0]
+            return _View(cb.buf, cb.C - sc, cb.ld, cb.N, cb.H, cb.W, sc)
+
+        def h_dest(j, c):       # the h entering output block j is the head slice of cat buffer j
+            cb = cat_bufs[j]
+            return _View(cb.buf, 0, cb.ld, cb.N, cb.H, cb.W, c)
+
+        # pass 2: emit ops
+        h = x0
+        for i, blk in enumerate(m.input_blocks):
+            h = self._emit_block(blk, h, skip_dest(i))
+        h = self._emit_block(m.middle_block, h, h_dest(0, mid_c))
+        for j, blk in enumerate(m.output_blocks):
+            cb = cat_bufs[j]
+            assert h.buf is cb.buf and h.off == 0
+            dest = None
+            if j + 1 < len(m.output_blocks):
+                oc = [l.out_channels for l in blk if isinstance(l, (ResBlock, Upsample))][-1]
+                dest = h_dest(j + 1, oc)
+            h = self._emit_block(blk, cb, dest)
+        # head: GN -> SiLU -> conv3x3 -> NCHW  (openaimodel.py:687-691,759)
+        a = self._gn_apply(h, m.out[0], None, silu=1, resample=0, name="A")
+        pc = self._conv(m.out[2], a.C)
+        self._op("bbdm_conv2d_nhwc_f32", a, a.ld, _TensorRef(pc.packed), self._pref(pc.bias), None, 0,
+                 _TensorRef(self.out_nchw), 0, 1, N, a.H, a.W, a.C, pc.cout, 3)
+
+        # ---- allocate -----------------------------------------------------------------------------------------------
+        for b in self.bufs:
+            b.tensor = torch.empty(max(1, b.numel), **f32)
+        self.stats = torch.zeros(max(1, self._gn_count) * N * self.GROUPS * 2, dtype=torch.float64, device=device)
+        self._param_key = None
+        self._bound: List[tuple] = []
+
+    def activation_bytes(self):
+        return sum(b.tensor.numel() * 4 for b in self.bufs)
+
+    # ---- buffer helpers ---------------------------------------------------------------------------------------
+    def _new(self, N, H, W, C) -> _View:
+        b = _Buf(N * H * W * C)
+        self.bufs.append(b)
+        return _View(b, 0, C, N, H, W, C)
+
+    def _tmp(self, name, N, H, W, C) -> _View:
+        """Block-local temporary: one buffer per role, sized for the largest user (blocks run sequentially)."""
+        b = self._scratch.get(name)
+        if b is None:
+            b = _Buf(0)
+            self._scratch[name] = b
+            self.bufs.append(b)
+        b.numel = max(b.numel, N * H * W * C)
+        return _View(b, 0, C, N, H, W, C)
+
+    class _StatsRef:
+        __slots__ = ("plan", "slot")
+
+        def __init__(self, plan, slot):
+            self.plan, self.slot = plan, slot
+
+        def resolve(self):
+            p = self.plan
+            return p.stats.data_ptr() + 8 * self.slot * p.N * p.GROUPS * 2
+
+    def _pref(self, p):
+        if p is None:
+            return None
+        self._params.append(p)
+        return _ParamRef(p)
+
+    def _op(self, name, *args):
+        self.ops.append((name, args))
+
+    def _conv(self, mod, cin_pad) -> _PackedConv:
+        pc = _PackedConv(mod.weight, mod.bias, cin_pad)
+        self.convs.append(pc)
+        return pc
+
+    # ---- op emitters --------------------------------------------------------------------------------------------
+    def _gn_apply(self, x: _View, gn: Optional[nn.GroupNorm], film_off: Optional[int], silu: int, resample: int,
+                  name: str) -> _View:
+        N = self.N
+        Ho = x.H // 2 if resample == 1 else (x.H * 2 if resample == 2 else x.H)
+        Wo = x.W // 2 if resample == 1 else (x.W * 2 if resample == 2 else x.W)
+        y = self._tmp(name, N, Ho, Wo, x.C)
+        if gn is not None:
+            ref = _Plan._StatsRef(self, self._gn_count)
+            self._gn_count += 1
+            self._op("bbdm_groupnorm_stats_f32", x, x.ld, ref, N, x.H * x.W, x.C, self.GROUPS)
+            film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
+            self._op("bbdm_groupnorm_apply_f32", x, x.ld, ref, self._pref(gn.weight), self._pref(gn.bias),
+                     film, self.film_total, y, y.ld, N, x.H, x.W, x.C, self.GROUPS, float(gn.eps), silu, resample)
+        else:
+            self._op("bbdm_groupnorm_apply_f32", x, x.ld, None, None, None, None, 0, y, y.ld, N, x.H, x.W,
+                     x.C, 1, 0.0, 0, resample)
+        return y
+
+    def _emit_conv(self, x: _View, mod, residual: Optional[_View], dest: _View):
+        pc = self._conv(mod, x.C)
+        assert dest.C == pc.cout and (residual is None or residual.C == pc.cout), (dest.C, pc.cout)
+        self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias),
+                 residual, residual.ld if residual is not None else 0,
+                 dest, dest.ld, 0, self.N, x.H, x.W, x.C, pc.cout, pc.ks)
+
+    def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
+        """ResBlock._forward (openaimodel.py:258-278)."""
+        if not rb.use_scale_shift_norm:
+            raise NotImplementedError("bbdm_amd: use_scale_shift_norm=False is not implemented yet "
+                                      "(all reference templates use True)")
+        N = self.N
+        rs = 2 if rb.up else (1 if rb.down else 0)
+        a = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A")
+        xr = x if rs == 0 else self._gn_apply(x, None, None, 0, rs, name="XR")
+        h1 = self._tmp("H1", N, a.H, a.W, rb.out_channels)
+        self._emit_conv(a, rb.in_layers[2], None, h1)
+        a2 = self._gn_apply(h1, rb.out_layers[0], self.film_off[id(rb)], silu=1, resample=0, name="A2")
+        out = dest if dest is not None else self._new(N, a.H, a.W, rb.out_channels)
+        if isinstance(rb.skip_connection, nn.Conv2d):
+            self._emit_conv(xr, rb.skip_connection, None, out)
+            self._emit_conv(a2, rb.out_layers[3], out, out)
+        else:
+            self._emit_conv(a2, rb.out_layers[3], xr, out)
+        return out
+
+    def _emit_attn(self, ab: AttentionBlock, x: _View, dest: Optional[_View]) -> _View:
+        """AttentionBlock._forward (openaimodel.py:321-327)."""
+        N, T, C = self.N, x.H * x.W, x.C
+        ch = C // ab.num_heads
+        a = self._gn_apply(x, ab.norm, None, silu=0, resample=0, name="A")
+        qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
+        self._emit_conv(a, ab.qkv, None, qkv)
+        at = self._tmp("AT", N, x.H, x.W, C)
+        self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, N, T, ab.num_heads, ch,
+                 1 if ab.use_new_attention_order else 0)
+        out = dest if dest is not None else self._new(N, x.H, x.W, C)
+        self._emit_conv(at, ab.proj_out, x, out)
+        return out
+
+    def _emit_block(self, blk, h: _View, dest: Optional[_View]) -> _View:
+        layers = list(blk)
+        for k, layer in enumerate(layers):
+            d = dest if k == len(layers) - 1 else None
+            if isinstance(layer, nn.Conv2d):
+                out = d if d is not None else self._new(self.N, h.H, h.W, layer.out_channels)
+                self._emit_conv(h, layer, None, out)
+                h = out
+            elif isinstance(layer, ResBlock):
+                h = self._emit_res(layer, h, d)
+            elif isinstance(layer, AttentionBlock):
+                h = self._emit_attn(layer, h, d)
+            else:
+                raise NotImplementedError(
+                    f"bbdm_amd: {type(layer).__name__} (resblock_updown=False) is not implemented yet; "
+                    "all reference templates use resblock_updown=True")
+        return h
+
+    # ---- execution ------------------------------------------------------------------------------------------------
+    def _bind(self):
+        lib = self.lib
+        self._bound = [(getattr(lib, name), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
+                       for name, args in self.ops]
+
+    def _refresh_weights(self, stream):
+        key = tuple(p.data_ptr() for p in self._params)
+        if key != self._param_key:
+            self._bind()
+            self._param_key = key
+        for pc in self.convs:
+            pc.refresh(stream)
+        fkey = tuple((rb.emb_layers[1].weight.data_ptr(), rb.emb_layers[1].weight._version,
+                      rb.emb_layers[1].bias.data_ptr(), rb.emb_layers[1].bias._version) for rb in self.resblocks)
+        if fkey != self._film_key:
+            off = 0
+            for rb in self.resblocks:
+                lin = rb.emb_layers[1]
+                n = lin.out_features
+                self.film_w[off:off + n].copy_(lin.weight.detach())
+                self.film_b[off:off + n].copy_(lin.bias.detach())
+                off += n
+            self._film_key = fkey
+
+    def run(self, x, t, ctx, out=None):
+        m, N = self.m, self.N
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._refresh_weights(stream)
+        self.x_in.copy_(x)
+        if self.ctx_in is not None:
+            self.ctx_in.copy_(ctx)
+        self.t_buf.copy_(t)
+        self.stats.zero_()
+        mc, ted = m.model_channels, 4 * m.model_channels
+        call = _lib.call
+        te0, te2 = m.time_embed[0], m.time_embed[2]
+        call("bbdm_timestep_embedding_f32", self.t_buf.data_ptr(), m.freqs(self.device).data_ptr(),
+             self.e0.data_ptr(), N, mc, stream)
+        for r0 in range(0, N, 64):          # bbdm_linear_f32 handles <= 64 rows per call
+            r = min(64, N - r0)
+            call("bbdm_linear_f32", self.e0.data_ptr() + 4 * r0 * mc, te0.weight.data_ptr(), te0.bias.data_ptr(),
+                 self.e1.data_ptr() + 4 * r0 * ted, r, mc, ted, 0, 1, stream)
+            call("bbdm_linear_f32", self.e1.data_ptr() + 4 * r0 * ted, te2.weight.data_ptr(), te2.bias.data_ptr(),
+                 self.emb.data_ptr() + 4 * r0 * ted, r, ted, ted, 0, 0, stream)
+            call("bbdm_linear_f32", self.emb.data_ptr() + 4 * r0 * ted, self.film_w.data_ptr(),
+                 self.film_b.data_ptr(), self.film.data_ptr() + 4 * r0 * self.film_total, r, ted, self.film_total,
+                 1, 0, stream)
+        check = _lib.check
+        for fn, args in self._bound:
+            rc = fn(*args, stream)
+            if rc != 0:
+                check(rc, fn.__name__)
+        if out is None:
+            return self.out_nchw.clone()
+        out.copy_(self.out_nchw)
+        return out

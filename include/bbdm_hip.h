@@ -1,0 +1,120 @@
+/*
+ * bbdm_hip.h  --  C-ABI of libbbdm_hip.so: the MI355X (gfx950) hot path of xuekt98/BBDM.
+ *
+ * The reference has no FFI / operator registry (it is pure PyTorch); the seam is the Python model object the
+ * runner constructs (runners/DiffusionBasedModelRunners/BBDMRunner.py:21-29).  bbdm_amd/ mirrors that object
+ * and calls the entry points below through ctypes.  Every entry point replaces one ATen call site (or a fused
+ * run of them) of the reference; the file:line it replaces is cited on each declaration (paths relative to the
+ * reference root; "openaimodel.py" = model/BrownianBridge/base/modules/diffusionmodules/openaimodel.py,
+ * "util.py" = .../diffusionmodules/util.py, "BBM.py" = model/BrownianBridge/BrownianBridgeModel.py).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, floats, a hipStream_t passed as void*.  No torch types.
+ *   - the library never allocates, frees or synchronises; kernels are enqueued on `stream`; all outputs and
+ *     workspaces are caller-owned (torch.empty on the Python side).  Stateless and re-entrant.
+ *   - return value: 0 = enqueued; <0 = BBDM_E_* (nothing was launched).  The Python shim raises RuntimeError.
+ *   - activations are fp32 NHWC: element (n, h, w, c) of a tensor with row pitch `ld` (floats per pixel,
+ *     ld >= C) lives at  base[((n*H + h)*W + w)*ld + c].  A pitch larger than C addresses a channel slice of a
+ *     wider buffer, which is how th.cat((h, skip), dim=1) (openaimodel.py:742,752) is made copy-free.
+ *   - all arithmetic is fp32 (the reference's precision; SURVEY.md §5 "Mixed precision: absent").
+ */
+#ifndef BBDM_HIP_H
+#define BBDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BBDM_OK 0
+#define BBDM_E_BADARG (-1)   /* unsupported shape / misaligned pointer / bad enum */
+#define BBDM_E_LAUNCH (-2)   /* hipLaunchKernel reported an error             */
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int bbdm_version(void);                       /* ABI version, bumped on any signature change           */
+const char* bbdm_last_error(void);            /* text of the last error on the calling thread          */
+
+/* ---- layout ------------------------------------------------------------------------------------------ */
+/* NCHW [N,Ca,H,W] (+ optional second NCHW [N,Cb,H,W]) -> NHWC [N,H,W,ldo], channels >= Ca+Cb zero-filled up to
+ * Cpad.  Replaces th.cat([x, context], dim=1) + the implicit NCHW read of the first conv
+ * (openaimodel.py:741-745).  b may be NULL (Cb = 0). */
+int bbdm_nchw_to_nhwc_f32(const float* a, int Ca, const float* b, int Cb, float* out, int ldo, int Cpad,
+                          int N, int H, int W, void* stream);
+/* NHWC (pitch ldx) -> NCHW contiguous.  The UNet output returns to the reference's layout (openaimodel.py:759). */
+int bbdm_nhwc_to_nchw_f32(const float* x, int ldx, float* out, int N, int H, int W, int C, void* stream);
+
+/* ---- convolution (openaimodel.py:207,233,244,524,690; conv1d k=1 at :307,315 is the ks=1 case) ------- */
+/* Number of floats of the packed weight buffer for a [Cout, Cin, ks, ks] filter whose input tensor carries
+ * CinPad >= Cin channels (CinPad % 4 == 0). */
+size_t bbdm_conv_packed_floats(int Cout, int CinPad, int ks);
+/* OIHW fp32 (the reference's state_dict layout) -> packed [tap][Cin-chunk][CoutPad][16] with zero padding.
+ * Runs on `stream`; call again whenever the weight changes (optimizer step, EMA swap, load_state_dict). */
+int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int CinPad, int ks,
+                              void* stream);
+/* out = conv_ks(x) + bias (+ residual).  ks in {1,3}; stride 1, padding ks/2 (F.conv2d semantics).
+ * x: NHWC pitch ldx with CinPad channels; residual (may be NULL): NHWC pitch ldr, Cout channels, may alias out;
+ * out: NHWC pitch ldo, or NCHW contiguous when out_nchw != 0.  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
+int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
+                         const float* residual, int ldr, float* out, int ldo, int out_nchw,
+                         int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
+
+/* ---- GroupNorm (util.py:199-216; sites openaimodel.py:205,229,306,688) -------------------------------- */
+/* Accumulate per-(n, group) sum and sum-of-squares of x into stats[N][G][2] (fp64, must be zeroed by the
+ * caller, e.g. one hipMemsetAsync per forward for all GroupNorms). */
+int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int HW, int C, int G, void* stream);
+/* y = resample( act( GN(x) [* (1 + scale) + shift] ) )  --  the fused run
+ *   GroupNorm32 -> [FiLM: openaimodel.py:270-273] -> SiLU -> [avg-pool 2x2 :159 | nearest x2 :118].
+ * stats: as produced above (may be NULL with gamma == NULL: pure resample of x, the x_upd path :263).
+ * film: [N][film_ld] with scale at [n][c] and shift at [n][C + c] (the emb_layers output :267-272), or NULL.
+ * silu: 0/1.  resample: 0 none, 1 avg-pool 2x2 (H, W even), 2 nearest x2.  H, W are INPUT dims. */
+int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
+                             const float* film, int film_ld, float* y, int ldy, int N, int H, int W, int C, int G,
+                             float eps, int silu, int resample, void* stream);
+
+/* ---- attention (openaimodel.py:359-375 legacy order, :398-413 new order) ------------------------------ */
+/* qkv: NHWC [N, T, 3*heads*ch] pitch ldq.  Channel of (head h, part p in {q,k,v}, c):
+ *   legacy (new_order = 0): h*3*ch + p*ch + c        new order: p*heads*ch + h*ch + c
+ * out: NHWC [N, T, heads*ch] pitch ldo, channel h*ch + c.  softmax((q*s)^T (k*s)) v with s = ch^-1/4,
+ * streamed over keys (no T x T tensor is ever materialised).  ch in {16, 32, 64}. */
+int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, int N, int T, int heads, int ch,
+                       int new_order, void* stream);
+
+/* ---- timestep embedding + small dense layers (util.py:151-171; openaimodel.py:511-516,735; :221-227,267) */
+/* emb[n][:] = [cos(t_n f_0..f_{half-1}), sin(t_n f_0..)] (+ one zero column if dim is odd).  t: int64[N];
+ * freqs: fp32[dim/2] = exp(-ln(1e4) i / half), computed by the HOST exactly as the reference does (util.py:160-163
+ * builds it on the CPU and moves it to the device). */
+int bbdm_timestep_embedding_f32(const int64_t* t, const float* freqs, float* emb, int N, int dim, void* stream);
+/* y[n][o] = act_out( sum_i act_in(x[n][i]) * w[o][i] + b[o] ), w row-major [Out][In] (nn.Linear layout).
+ * act_*: 0 none, 1 SiLU.  For the M = batch GEMMs of the embedding path (N <= 64 rows). */
+int bbdm_linear_f32(const float* x, const float* w, const float* b, float* y, int N, int In, int Out,
+                    int act_in, int act_out, void* stream);
+
+/* ---- Brownian-Bridge scheduler arithmetic (BBM.py) ---------------------------------------------------- */
+/* objective ids: 0 'grad', 1 'noise', 2 'ysubx' (BBM.py:134-141,148-160). */
+/* q_sample (BBM.py:128-146): x_t = (1-m)x0 + m y + sqrt(var) eps ; target per objective.  t: int64[N];
+ * m_t / variance_t: the registered fp32 buffers [T].  per_sample = C*H*W. */
+int bbdm_bb_q_sample_f32(const float* x0, const float* y, const float* noise, const int64_t* t,
+                         const float* m_t, const float* variance_t, float* x_t, float* target,
+                         int N, int per_sample, int objective, void* stream);
+/* One reverse step after the UNet call (BBM.py:186-201, and the steps[i]==0 branch :174-180):
+ * x0_recon = predict_x0(x_t, y, t, pred) [clamped to +-1 if clip]; if last: x_next = x0_recon, else the
+ * posterior mean + sigma_t * noise.  t / t_next are the scalar table indices steps[i], steps[i+1]. */
+int bbdm_bb_p_sample_step_f32(const float* x_t, const float* y, const float* pred, const float* noise,
+                              const float* m_t, const float* variance_t, int t, int t_next, int is_last,
+                              float eta, int clip, int objective, float* x_next, float* x0_recon,
+                              int N, int per_sample, void* stream);
+/* predict_x0_from_objective alone (BBM.py:148-160), per-sample t (used by p_losses :121). */
+int bbdm_bb_predict_x0_f32(const float* x_t, const float* y, const float* pred, const int64_t* t,
+                           const float* m_t, const float* variance_t, float* x0_recon,
+                           int N, int per_sample, int objective, void* stream);
+/* loss (BBM.py:114-117): loss_type 0 'l1' mean|a-b|, 1 'l2' mean (a-b)^2.  partial: fp64[1] zeroed by caller;
+ * out[0] = float(partial / count) is written by a tail kernel on the same stream. */
+int bbdm_bb_loss_f32(const float* a, const float* b, double* partial, float* out, size_t count, int loss_type,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BBDM_HIP_H */

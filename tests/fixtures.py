@@ -13,8 +13,8 @@ CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx")
 def load_case(name):
     rec = torch.load(os.path.join(GOLDEN, f"{name}.pt"), weights_only=False)
     unet_sd = synth_weights(rec["unet_shapes"], rec["weight_seed"])
-    sd = {"denoise_fn." + k: v for k, v in unet_sd.items()}
-    sd.update(rec["buffers"])
+    sd = dict(rec["buffers"])                       # reference order: schedule buffers first, then the UNet
+    sd.update({"denoise_fn." + k: v for k, v in unet_sd.items()})
     rec["state_dict"] = sd
     return rec
 

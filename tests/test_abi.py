@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/bbdm_hip.h
+declares (no compute calls here -- there is no GPU in this tier), and the product path refuses to run on the CPU."""
+import argparse
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "bbdm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bbdm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from bbdm_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "libbbdm_hip.so missing: run __graft_entry__.build()"
+    lib = _lib.load()
+    declared = _header_symbols()
+    assert len(declared) >= 16
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/bbdm_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in bbdm_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == declared
+    assert lib.bbdm_version() == _lib.ABI_VERSION
+    # pure host helper (no GPU needed): packed size of a 3x3 1024->1024 filter
+    assert lib.bbdm_conv_packed_floats(1024, 1024, 3) == 9 * 64 * 1024 * 16
+    assert lib.bbdm_conv_packed_floats(3, 128, 3) == 9 * 8 * 128 * 16
+
+
+def _ns(c):
+    ns = argparse.Namespace()
+    for k, v in c.items():
+        setattr(ns, k, _ns(v) if isinstance(v, dict) else v)
+    return ns
+
+
+def test_product_path_has_no_cpu_fallback():
+    import bbdm_amd
+    from fixtures import load_case
+    rec = load_case("tiny_concat")
+    m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(rec["bb_params"], UNetParams=rec["unet_params"])}}))
+    m.load_state_dict(rec["state_dict"], strict=True)
+    with pytest.raises(bbdm_amd._lib.BBDMHipError):
+        m.p_sample(rec["p_x_t"], rec["y"], rec["y"], 0)
+    with pytest.raises(bbdm_amd._lib.BBDMHipError):
+        m.q_sample(rec["x0"], rec["y"], rec["t"], rec["noise"])
+
+
+def test_state_dict_layout_matches_reference_fixture():
+    """Same keys / shapes as the reference state_dict recorded in the golden fixture (SURVEY.md §5 checkpoint row)."""
+    import bbdm_amd
+    from fixtures import CASES, load_case
+    for name in CASES:
+        rec = load_case(name)
+        up = rec["unet_params"]
+        if not up.get("resblock_updown", True):
+            continue
+        m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(rec["bb_params"], UNetParams=up)}}))
+        ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        ref = {k: tuple(v.shape) for k, v in rec["state_dict"].items()}
+        assert ours == ref
+        assert list(m.state_dict().keys()) == list(rec["state_dict"].keys())
+        assert torch.equal(m.steps, rec["steps"])
+        for k, v in rec["buffers"].items():
+            assert torch.equal(m.state_dict()[k], v), k
+
+
+def test_fresh_init_matches_reference_under_seed():
+    """Same construction order => same RNG consumption => identical seeded initial weights."""
+    if not os.path.isdir("/root/reference/model"):
+        pytest.skip("/root/reference not mounted")
+    import sys
+    sys.path.insert(0, "/root/reference")
+    from model.BrownianBridge.BrownianBridgeModel import BrownianBridgeModel as Ref
+    import bbdm_amd
+    from fixtures import load_case
+    rec = load_case("tiny_concat")
+    cfg = _ns({"BB": {"params": dict(rec["bb_params"], UNetParams=rec["unet_params"])}})
+    torch.manual_seed(7)
+    a = Ref(cfg)
+    torch.manual_seed(7)
+    b = bbdm_amd.BrownianBridgeModel(cfg)
+    sa, sb = a.state_dict(), b.state_dict()
+    assert list(sa.keys()) == list(sb.keys())
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k

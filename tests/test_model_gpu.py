@@ -1,0 +1,139 @@
+"""Model-level parity (GPU): bbdm_amd.BrownianBridgeModel against the oracle and against the golden vectors that the
+real reference produced (tests/golden/), through the reference's own API (forward-free inference path:
+denoise_fn / q_sample / p_sample / p_sample_loop).  Bar: 1e-3 relative per sampling step (BASELINE.json north_star);
+observed errors are ~1e-6 and the asserts use 1e-4 to catch regressions early."""
+import argparse
+
+import pytest
+import torch
+
+from fixtures import CASES, load_case, oracle_model, rel_err
+
+pytestmark = pytest.mark.gpu
+STEP_TOL = 1e-4
+
+
+def _ns(c):
+    ns = argparse.Namespace()
+    for k, v in c.items():
+        setattr(ns, k, _ns(v) if isinstance(v, dict) else v)
+    return ns
+
+
+def build(rec, dev):
+    import bbdm_amd
+    m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(rec["bb_params"], UNetParams=rec["unet_params"])}}))
+    m.load_state_dict(rec["state_dict"], strict=True)
+    return m.to(dev).eval()
+
+
+SUPPORTED = [c for c in CASES if c != "tiny_ysubx"]     # tiny_ysubx: resblock_updown=False / no FiLM (not yet)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_unet_forward_matches_reference_golden(dev, name):
+    rec = load_case(name)
+    m = build(rec, dev)
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"].to(dev)
+    with torch.no_grad():
+        out = m.denoise_fn(rec["x0"].to(dev), timesteps=rec["t"].to(dev), context=ctx)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), rec["unet_out"]) < STEP_TOL
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_p_sample_matches_reference_golden(dev, name):
+    rec = load_case(name)
+    m = build(rec, dev)
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"].to(dev)
+    eps = rec["p_eps"].to(dev)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps
+    try:
+        for clip, i, a_ref, b_ref in rec["p_out"]:
+            a, b = m.p_sample(rec["p_x_t"].to(dev), rec["y"].to(dev), ctx, i, clip_denoised=clip)
+            torch.cuda.synchronize()
+            assert rel_err(a.cpu(), a_ref) < STEP_TOL and rel_err(b.cpu(), b_ref) < STEP_TOL, (clip, i)
+        out = m.p_sample_loop(rec["y"].to(dev), None, clip_denoised=True)
+        assert rel_err(out.cpu(), rec["loop_out"]) < 1e-3
+        imgs, one = m.sample(rec["y"].to(dev), None, clip_denoised=True, sample_mid_step=True)
+        assert len(imgs) == len(m.steps) + 1 and len(one) == len(m.steps)
+        assert rel_err(imgs[-1].cpu(), rec["loop_out"]) < 1e-3
+    finally:
+        torch.randn_like = orig
+
+
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_eval_loss_matches_reference_golden(dev, name):
+    """p_losses under no_grad (the validation path, runners/BaseRunner.py:226-246)."""
+    rec = load_case(name)
+    m = build(rec, dev)
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"].to(dev)
+    with torch.no_grad():
+        loss, log = m.p_losses(rec["x0"].to(dev), rec["y"].to(dev), ctx, rec["t"].to(dev), rec["noise"].to(dev))
+    assert abs(float(loss) - float(rec["loss"])) < STEP_TOL * max(1.0, abs(float(rec["loss"])))
+    assert rel_err(log["x0_recon"].cpu(), rec["x0_recon"]) < STEP_TOL
+    assert "loss" in log
+
+
+def test_weight_updates_and_ema_swaps_are_seen(dev):
+    """Packed-weight caches must follow in-place updates (optimizer) and ``param.data`` swaps (EMA.apply_shadow)."""
+    rec = load_case("tiny_concat")
+    m = build(rec, dev)
+    x, t, ctx = rec["x0"].to(dev), rec["t"].to(dev), rec["y"].to(dev)
+    with torch.no_grad():
+        base = m.denoise_fn(x, timesteps=t, context=ctx).clone()
+        p = m.denoise_fn.input_blocks[1][0].in_layers[2].weight
+        saved = p.data.clone()
+        p.mul_(1.5)                                          # in-place: bumps _version
+        changed = m.denoise_fn(x, timesteps=t, context=ctx).clone()
+        assert rel_err(changed.cpu(), base.cpu()) > 1e-3
+        p.data = saved                                       # storage swap: new data_ptr, same _version semantics as EMA
+        back = m.denoise_fn(x, timesteps=t, context=ctx)
+        assert rel_err(back.cpu(), base.cpu()) < 1e-6
+        gn = m.denoise_fn.out[0].weight
+        gn.data = gn.data.clone() * 2.0                      # GroupNorm affine pointer baked into the plan
+        assert rel_err(m.denoise_fn(x, timesteps=t, context=ctx).cpu(), base.cpu()) > 1e-3
+
+
+def test_full_size_template_step_matches_oracle(dev):
+    """The real Template-BBDM UNet (237 M parameters, 64x64, N=2): one p_sample step, HIP vs the CPU oracle."""
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    import bbdm_amd
+    up = dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2,
+              attention_resolutions=(32, 16, 8), channel_mult=(1, 4, 8), conv_resample=True, dims=2, num_heads=8,
+              num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True, use_spatial_transformer=False,
+              context_dim=None, condition_key="SpatialRescaler")
+    bb = dict(mt_type="linear", objective="grad", loss_type="l1", skip_sample=True, sample_type="linear",
+              sample_step=200, num_timesteps=1000, eta=1.0, max_var=1.0)
+    m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(bb, UNetParams=up)}}))
+    shapes = [(k, tuple(v.shape)) for k, v in m.denoise_fn.state_dict().items()]
+    sd = synth_weights(shapes, 777, w_std=0.02)
+    m.denoise_fn.load_state_dict(sd, strict=True)
+    assert sum(v.numel() for v in sd.values()) == 237094787
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(1234)
+    N = 2
+    y = torch.randn(N, 3, 64, 64, generator=g).clamp(-1, 1)
+    x_t = torch.randn(N, 3, 64, 64, generator=g).clamp(-1, 1)
+    eps = torch.randn(N, 3, 64, 64, generator=g)
+    ora = O.OracleBBDM({"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), **bb)
+    i = 57
+    a_ref, b_ref = ora.p_sample(x_t, y, y, i, clip_denoised=False, noise=eps)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps.to(dev)
+    try:
+        a, b = m.p_sample(x_t.to(dev), y.to(dev), y.to(dev), i, clip_denoised=False)
+    finally:
+        torch.randn_like = orig
+    torch.cuda.synchronize()
+    ea, eb = rel_err(a.cpu(), a_ref), rel_err(b.cpu(), b_ref)
+    print(f"full-size step: rel err {ea:.2e} {eb:.2e}")
+    assert ea < 1e-3 and eb < 1e-3
