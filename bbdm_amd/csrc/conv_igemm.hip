@@ -36,7 +36,7 @@ struct ConvArgs {
     int ldx, ldr, ldo, out_nchw;
     int N, H, W, Cin, Cout, CoutPad;
     int taps, nchunks, pad;
-    int TWl, THl, IMl;          // log2 of tile width / height / images per block
+    int TWl, THl, imgs;         // log2 of tile width / height; images per block (<= BM / (TH*TW))
     int PW, PH, patchPix;       // patch geometry (incl. halo), pixels per block patch
     int tilesX, tilesY, tilesN;
 };
@@ -69,7 +69,7 @@ conv_igemm_f32(const ConvArgs a) {
     const int tile_y = bid % a.tilesY;
     const int ig = bid / a.tilesY;
     const int TW = 1 << a.TWl, TH = 1 << a.THl;
-    const int img0 = ig << a.IMl;
+    const int img0 = ig * a.imgs;
     const int h0 = tile_y * TH - a.pad, w0 = tile_x * TW - a.pad;
     const int cout0 = n_tile * BN;
 
@@ -99,7 +99,8 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = wm * (BM / WM) + mt * 32 + (lane & 31);
-        const int img_l = m >> (a.THl + a.TWl);
+        int img_l = m >> (a.THl + a.TWl);
+        if (img_l >= a.imgs) img_l = 0;      // padding rows of the M tile: read something valid, discarded later
         const int ph = (m >> a.TWl) & (TH - 1);
         const int pw = m & (TW - 1);
         abase[mt] = (img_l * a.PH * a.PW + ph * a.PW + pw) * KP + (lane >> 5) * 4;
@@ -209,10 +210,11 @@ conv_igemm_f32(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = img0 + (m >> (a.THl + a.TWl));
+                const int img_l = m >> (a.THl + a.TWl);
+                const int n = img0 + img_l;
                 const int h = hbase + ((m >> a.TWl) & (TH - 1));
                 const int w = wbase + (m & (TW - 1));
-                if (cok && n < a.N && h < a.H && w < a.W) {
+                if (cok && img_l < a.imgs && n < a.N && h < a.H && w < a.W) {
                     const size_t pix = (size_t)(n * a.H + h) * a.W + w;
                     float v = acc[mt][nt][r] + bv;
                     if (a.res) v += a.res[pix * a.ldr + co];
@@ -257,12 +259,18 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
     const int TWc = ceil_pow2(a.W) < 32 ? ceil_pow2(a.W) : 32;
     int THc = BM / TWc;
     if (THc > ceil_pow2(a.H)) THc = ceil_pow2(a.H);
-    const int IM = BM / (TWc * THc);
+    int IM = BM / (TWc * THc);
     a.TWl = ilog2(TWc);
     a.THl = ilog2(THc);
-    a.IMl = ilog2(IM);
     a.PW = TWc + 2 * a.pad;
     a.PH = THc + 2 * a.pad;
+    // tiny images: cap the images per block so that the halo patch fits the staging slots (the remaining rows of
+    // the M tile are padding)
+    const int maxIm = (PSLOTS * WM * WN * 64 / (KC / 4)) / (a.PW * a.PH);
+    if (IM > maxIm) IM = maxIm;
+    if (IM > a.N) IM = a.N;
+    if (IM < 1) return 1;
+    a.imgs = IM;
     a.patchPix = IM * a.PW * a.PH;
     a.tilesX = cdiv(a.W, TWc);
     a.tilesY = cdiv(a.H, THc);

@@ -73,6 +73,31 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
     if (tid < 2 * G) atomicAdd(&stats[(size_t)n * G * 2 + tid], lsum[tid]);
 }
 
+// Scalar variant for channels-per-group not a multiple of 4 (e.g. C = 32, 96, 192 with 32 groups: only the tiny
+// test configurations; every reference template has cpg % 4 == 0).  One thread per element, LDS fp64 atomics per group.
+__global__ void __launch_bounds__(256) gn_stats_scalar_kernel(const float* __restrict__ x, int ldx,
+                                                              double* __restrict__ stats, int HW, int C, int G,
+                                                              int pix_per_block) {
+    __shared__ double lsum[64 * 2];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.y;
+    const int cpg = C / G;
+    if (tid < 2 * G) lsum[tid] = 0.0;
+    __syncthreads();
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    const float* xb = x + (size_t)n * HW * ldx;
+    const long long total = (long long)(p1 - p0) * C;
+    for (long long i = tid; i < total; i += 256) {
+        const int p = p0 + (int)(i / C), c = (int)(i % C);
+        const double v = xb[(size_t)p * ldx + c];
+        atomicAdd(&lsum[2 * (c / cpg)], v);
+        atomicAdd(&lsum[2 * (c / cpg) + 1], v * v);
+    }
+    __syncthreads();
+    if (tid < 2 * G) atomicAdd(&stats[(size_t)n * G * 2 + tid], lsum[tid]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // apply
 // ---------------------------------------------------------------------------------------------------------
@@ -126,18 +151,23 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
         const int c = c4 * 4;
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.norm) {
-            const int g = c / cpg;
-            const double s = a.stats[((size_t)n * a.G + g) * 2], ss = a.stats[((size_t)n * a.G + g) * 2 + 1];
-            const double mean = s / cnt;
-            double var = ss / cnt - mean * mean;
-            var = var > 0.0 ? var : 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-            const float fmean = (float)mean;
+            float rs[4], mu[4];
+            const int ng = (cpg & 3) ? 4 : 1;      // a quad may span several groups unless cpg % 4 == 0
+            for (int e = 0; e < ng; ++e) {
+                const int g = (c + e) / cpg;
+                const double s = a.stats[((size_t)n * a.G + g) * 2], ss = a.stats[((size_t)n * a.G + g) * 2 + 1];
+                const double mean = s / cnt;
+                double var = ss / cnt - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                rs[e] = (float)(1.0 / sqrt(var + (double)a.eps));
+                mu[e] = (float)mean;
+            }
+            if (ng == 1) { rs[1] = rs[2] = rs[3] = rs[0]; mu[1] = mu[2] = mu[3] = mu[0]; }
             const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
             const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
             // y = (x - mean) * rstd * gamma + beta  ==  x * sc + bi
-            sc = make_float4(rstd * ga.x, rstd * ga.y, rstd * ga.z, rstd * ga.w);
-            bi = make_float4(be.x - fmean * sc.x, be.y - fmean * sc.y, be.z - fmean * sc.z, be.w - fmean * sc.w);
+            sc = make_float4(rs[0] * ga.x, rs[1] * ga.y, rs[2] * ga.z, rs[3] * ga.w);
+            bi = make_float4(be.x - mu[0] * sc.x, be.y - mu[1] * sc.y, be.z - mu[2] * sc.z, be.w - mu[3] * sc.w);
             if (a.film) {
                 // h = GN(h) * (1 + scale) + shift     (openaimodel.py:272-273)
                 const float4 fs = *reinterpret_cast<const float4*>(a.film + (size_t)n * a.film_ld + c);
@@ -183,8 +213,18 @@ extern "C" int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, 
                                         void* stream) {
     BBDM_REQUIRE(x && stats, "gn_stats: null pointer");
     BBDM_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= 64 && C % G == 0, "gn_stats: bad shape C=%d G=%d", C, G);
-    BBDM_REQUIRE((C / G) % 4 == 0 && ldx % 4 == 0 && ldx >= C && ((uintptr_t)x & 15) == 0,
-                 "gn_stats: channels per group (%d) and ldx (%d) must be multiples of 4", C / G, ldx);
+    BBDM_REQUIRE(ldx >= C, "gn_stats: ldx < C");
+    if ((C / G) % 4 != 0) {
+        int splits = cdiv(1024, N);
+        int ppb = cdiv(HW, splits);
+        if (ppb < 16) ppb = 16;
+        hipLaunchKernelGGL(gn_stats_scalar_kernel, dim3(cdiv(HW, ppb), N), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                           stats, HW, C, G, ppb);
+        BBDM_CHECK_LAUNCH("gn_stats");
+        return BBDM_OK;
+    }
+    BBDM_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "gn_stats: ldx (%d) must be a multiple of 4, x 16-B aligned",
+                 ldx);
     const int C4 = C / 4;
     BBDM_REQUIRE(C4 <= 1024, "gn_stats: C=%d > 4096 unsupported", C);
     // ~2048 blocks in total, but at least 8 pixel-rows of work per thread row
@@ -216,7 +256,7 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     BBDM_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avg-pool needs even H, W");
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
                  "gn_apply: bad shape / pitch");
-    BBDM_REQUIRE(!norm || (G > 0 && C % G == 0 && (C / G) % 4 == 0), "gn_apply: bad groups");
+    BBDM_REQUIRE(!norm || (G > 0 && C % G == 0), "gn_apply: C %% G != 0");
     BBDM_REQUIRE(!film || film_ld % 4 == 0, "gn_apply: film_ld %% 4");
     BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "gn_apply: x / y must be 16-byte aligned");
     ApplyArgs a;

@@ -42,6 +42,9 @@ CONV_CASES = [
     (4, 2, 2, 64, 192, 1, False),
     (1, 32, 32, 6, 128, 3, False),       # first conv: Cin = 6 (padded to 8 by the layout kernel)
     (16, 32, 32, 128, 128, 3, True),     # >= 512 blocks -> 256x128 tile path
+    (3, 2, 2, 64, 64, 3, True),          # 2x2 images: images-per-block capped by the patch slots
+    (70, 1, 1, 32, 32, 3, False),        # 1x1 images
+    (40, 4, 4, 128, 1024, 3, False),     # 4x4 latents (LBBDM-f16 bottom level)
 ]
 
 
@@ -125,7 +128,7 @@ def test_conv2d_linearity_at_full_size(dev):
         assert float((got - acc).abs().max() / acc.abs().max()) < 2e-5
 
 
-GN_CASES = [(2, 16, 16, 128), (1, 8, 8, 640), (3, 4, 4, 1536), (2, 6, 10, 2048), (1, 32, 32, 32), (4, 64, 64, 256)]
+GN_CASES = [(2, 8, 8, 96), (1, 4, 4, 192), (2, 16, 16, 128), (1, 8, 8, 640), (3, 4, 4, 1536), (2, 6, 10, 2048), (1, 32, 32, 32), (4, 64, 64, 256)]
 
 
 @pytest.mark.parametrize("N,H,W,C", GN_CASES)

@@ -89,7 +89,7 @@ def test_weight_updates_and_ema_swaps_are_seen(dev):
     x, t, ctx = rec["x0"].to(dev), rec["t"].to(dev), rec["y"].to(dev)
     with torch.no_grad():
         base = m.denoise_fn(x, timesteps=t, context=ctx).clone()
-        p = m.denoise_fn.input_blocks[1][0].in_layers[2].weight
+        p = m.denoise_fn.input_blocks[1][0].out_layers[3].weight      # not followed by a GroupNorm
         saved = p.data.clone()
         p.mul_(1.5)                                          # in-place: bumps _version
         changed = m.denoise_fn(x, timesteps=t, context=ctx).clone()
