@@ -188,6 +188,7 @@ class _PackedConv:
         self.cin_pad = cin_pad
         n = _lib.load().bbdm_conv_packed_floats(self.cout, cin_pad, self.ks)
         self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        self.packed.cin_true = self.cin          # algorithmic (unpadded) input channels, for flop accounting
         self.key = None
 
     def refresh(self, stream):
@@ -309,6 +310,7 @@ class UNetModel(nn.Module):
 
         self._plans: Dict[tuple, "_Plan"] = {}
         self._freqs: Optional[torch.Tensor] = None
+        self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -487,6 +489,19 @@ class _Plan:
         self.stats = torch.zeros(max(1, self._gn_count) * N * self.GROUPS * 2, dtype=torch.float64, device=device)
         self._param_key = None
         self._bound: List[tuple] = []
+        self.op_flops = [self._algorithmic_flops(name, args) for name, args in self.ops]
+
+    @staticmethod
+    def _algorithmic_flops(name, args):
+        """2*MACs of the contraction an op performs (conv / linear / attention matmuls only)."""
+        if name == "bbdm_conv2d_nhwc_f32":
+            N, H, W, cin_pad, cout, ks = args[9:15]
+            cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
+            return 2.0 * N * H * W * cout * cin * ks * ks
+        if name == "bbdm_attention_f32":
+            N, T, heads, ch = args[4:8]
+            return 2.0 * 2.0 * N * heads * T * T * ch
+        return 0.0
 
     def activation_bytes(self):
         return sum(b.tensor.numel() * 4 for b in self.bufs)
@@ -658,10 +673,22 @@ class _Plan:
                  self.film_b.data_ptr(), self.film.data_ptr() + 4 * r0 * self.film_total, r, ted, self.film_total,
                  1, 0, stream)
         check = _lib.check
-        for fn, args in self._bound:
-            rc = fn(*args, stream)
-            if rc != 0:
-                check(rc, fn.__name__)
+        prof = m.op_profile
+        if prof is None:
+            for fn, args in self._bound:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    check(rc, fn.__name__)
+        else:
+            # per-op HIP events on the launch stream (bench.py's roofline leg); (name, start, stop, flops)
+            for (fn, args), fl in zip(self._bound, self.op_flops):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, stream)
+                e1.record()
+                if rc != 0:
+                    check(rc, fn.__name__)
+                prof.append((fn.__name__, e0, e1, fl))
         if out is None:
             return self.out_nchw.clone()
         out.copy_(self.out_nchw)

@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's headline metric on MI355X: denoise-UNet sampling steps/s at 256x256 pixel-space BBDM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c5] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One *step* = one ``BrownianBridgeModel.p_sample`` = one UNet forward on the local batch + the fused bridge update
+(+ ``torch.randn_like`` for the step noise), exactly what the reference's sampling loop executes per iteration
+(BrownianBridgeModel.py:171-201).  Inputs are synthetic (seed 1234, x,y = randn.clamp(-1,1); weights N(0,0.02) with
+the zero-initialised modules randomised) and already resident in HBM when the timed region starts.
+
+Multi-GPU: one process per GPU, image pairs shard naturally: every rank runs its own batch with no
+data-path collective ("weak" scaling); the timed region is bracketed by barrier + synchronize on both sides and the
+MAX over ranks is taken; value = steps all ranks completed / that time.
+
+Rank 0 prints ONE JSON line with, besides the contract fields,
+  roofline     : the dominant kernel (conv_igemm_f32, fp32 MFMA) -- algorithmic conv FLOPs per launch / average
+                 launch duration measured with HIP events on the launch stream inside the timed region, against
+                 the 157.3 TFLOP/s dense fp32-MFMA peak (MI355X_MICROARCH.md);
+  cpu_baseline : the oracle (kind "port": oracle/bbdm_oracle.py, the validated restatement of the reference's CPU
+                 path) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
+
+# BASELINE.json configs (UNetParams per configs/Template-*.yaml)
+_UNET_PIXEL = dict(in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(32, 16, 8),
+                   channel_mult=(1, 4, 8), conv_resample=True, dims=2, num_heads=8, num_head_channels=64,
+                   use_scale_shift_norm=True, resblock_updown=True, use_spatial_transformer=False, context_dim=None,
+                   condition_key="SpatialRescaler")
+WORKLOADS = {
+    # name: (description, UNetParams, latent/pixel channels, size, batch, skip_sample, sample_step)
+    "c2": ("pixel-space BBDM 256x256, batch 16, 1000-step schedule (BASELINE.json configs[1])",
+           dict(_UNET_PIXEL, image_size=256), 3, 256, 16, False, 1000),
+    "c1": ("pixel-space BBDM 64x64, batch 4, 1000-step schedule (BASELINE.json configs[0])",
+           dict(_UNET_PIXEL, image_size=64), 3, 64, 4, False, 1000),
+    "c3": ("LBBDM-f4 latent 3x64x64, batch 32, 200 steps, UNet-only (BASELINE.json configs[2])",
+           dict(_UNET_PIXEL, image_size=64, in_channels=3, condition_key="nocond"), 3, 64, 32, True, 200),
+    "c5": ("LBBDM-f16 latent 8x16x16, batch 32, 200 steps, UNet-only (BASELINE.json configs[4], one GPU's shard)",
+           dict(_UNET_PIXEL, image_size=16, in_channels=8, out_channels=8, attention_resolutions=(16, 8, 4),
+                condition_key="nocond"), 8, 16, 32, True, 200),
+}
+BB = dict(mt_type="linear", objective="grad", loss_type="l1", sample_type="linear", num_timesteps=1000, eta=1.0,
+          max_var=1.0)
+
+
+def _ns(c):
+    ns = argparse.Namespace()
+    for k, v in c.items():
+        setattr(ns, k, _ns(v) if isinstance(v, dict) else v)
+    return ns
+
+
+def synth_state(model_unet, seed=777):
+    from fixture_weights import synth_weights          # deterministic N(0, 0.02)-style weights (oracle/)
+    shapes = [(k, tuple(v.shape)) for k, v in model_unet.state_dict().items()]
+    return synth_weights(shapes, seed, w_std=0.02)
+
+
+def make_inputs(batch, ch, size, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn(batch, ch, size, size, generator=g).clamp(-1, 1)
+    x_t = torch.randn(batch, ch, size, size, generator=g).clamp(-1, 1)
+    return x_t, y
+
+
+def cpu_baseline(workload, sd, budget_s=25.0):
+    """Oracle p_sample on the host cores.  Bounded sample: batch 1 of the workload's shape, 1 warm-up + as many timed
+    steps as fit ~budget (>= 1); reported in the metric's unit (batch-B steps/s = per-image rate / B)."""
+    import bbdm_oracle as O
+    desc, up, ch, size, batch, skip, sstep = WORKLOADS[workload]
+    ora = O.OracleBBDM({"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), skip_sample=skip,
+                       sample_step=sstep, **BB)
+    x_t, y = make_inputs(1, ch, size)
+    ctx = None if up["condition_key"] == "nocond" else y
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    ora.p_sample(x_t, y, ctx, 0, clip_denoised=False)
+    warm = time.perf_counter() - t0
+    n, spent = 0, 0.0
+    while n < 1 or (spent + spent / max(n, 1) < budget_s - warm and n < 20):
+        t0 = time.perf_counter()
+        ora.p_sample(x_t, y, ctx, n + 1, clip_denoised=False)
+        spent += time.perf_counter() - t0
+        n += 1
+    per_img_step = spent / n
+    return {"value": 1.0 / (per_img_step * batch), "unit": "steps/s", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"oracle p_sample, batch 1 of the {batch}-image batch at {size}x{size}, 1 warm-up + {n} timed "
+                      f"steps ({per_img_step:.2f} s per image-step), scaled by 1/{batch} to batch-{batch} steps/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-budget", type=float, default=25.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import bbdm_amd
+    desc, up, ch, size, batch, skip, sstep = WORKLOADS[args.workload]
+    cfg = _ns({"BB": {"params": dict(BB, skip_sample=skip, sample_step=sstep, UNetParams=up)}})
+    model = bbdm_amd.BrownianBridgeModel(cfg)
+    sd = synth_state(model.denoise_fn)
+    model.denoise_fn.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    nparams = sum(p.numel() for p in model.denoise_fn.parameters())
+
+    x_t, y = make_inputs(batch, ch, size, seed=1234 + rank)
+    x_t, y = x_t.to(dev), y.to(dev)
+    ctx = None if up["condition_key"] == "nocond" else y
+    torch.manual_seed(1234 + rank)
+    nsteps_table = len(model.steps)
+
+    def step(i, img):
+        out, _ = model.p_sample(img, y, ctx, i % (nsteps_table - 1), clip_denoised=False)
+        return out
+
+    img = x_t
+    for i in range(args.warmup):
+        img = step(i, img)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    prof = []
+    model.denoise_fn.op_profile = prof
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        img = step(args.warmup + i, img)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    model.denoise_fn.op_profile = None
+    if not bool(torch.isfinite(img).all()):
+        raise RuntimeError("non-finite sample")
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel accounting from the HIP events recorded inside the timed region -------------------------
+    by = {}
+    for name, e0, e1, fl in prof:
+        d = by.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)            # ms
+        d[2] += fl
+    conv = by.get("bbdm_conv2d_nhwc_f32", [0, 0.0, 0.0])
+    total_flops_per_step = sum(v[2] for v in by.values()) / max(1, args.steps)
+    conv_launches = conv[0]
+    conv_ms = conv[1]
+    flops_per_launch = conv[2] / max(1, conv_launches)
+    avg_launch_ms = conv_ms / max(1, conv_launches)
+    achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
+    ms_per_step = elapsed * 1e3 / args.steps
+    steps_per_s_job = world * args.steps / elapsed
+
+    if rank == 0:
+        line = {
+            "metric": "denoise-UNet sampling steps/sec (one step = p_sample of the whole local batch: UNet forward + "
+                      "Brownian-Bridge update) at 256x256 pixel-space BBDM" if args.workload == "c2" else
+                      f"denoise-UNet sampling steps/sec ({args.workload})",
+            "value": steps_per_s_job, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
+            "config": {"workload": desc, "batch_per_gpu": batch, "image_size": size, "unet_params_M": nparams / 1e6,
+                       "schedule_steps": nsteps_table, "parallelism": f"dp{world} (independent image-pair shards)"},
+            "steps_per_sec_per_gpu": args.steps / elapsed,
+            "img_steps_per_sec": steps_per_s_job * batch,
+            "imgs_per_sec_whole_job": steps_per_s_job * batch / nsteps_table,
+            "tflops_algorithmic": total_flops_per_step / (ms_per_step * 1e-3) / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "launches_per_step": conv_launches / max(1, args.steps),
+                         "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
+                         "conv_share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None},
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
+        }
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.workload, sd, args.cpu_budget)
+            line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
