@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +181,31 @@ def main():
         d[0] += 1
         d[1] += e0.elapsed_time(e1)            # ms
         d[2] += fl
+    if args.dump_ops and rank == 0:
+        plan = next(iter(model.denoise_fn._plans.values()))
+        nops = len(plan.ops)
+        agg = {}
+        for j, (name, e0, e1, fl) in enumerate(prof):
+            k = j % nops
+            a = agg.setdefault(k, [name, 0.0, fl])
+            a[1] += e0.elapsed_time(e1) / args.steps
+        with open(args.dump_ops, "w") as f:
+            f.write("| # | op | shape | ms | TFLOP/s |\n|---|---|---|---|---|\n")
+            for k in sorted(agg):
+                name, ms, fl = agg[k]
+                oargs = plan.ops[k][1]
+                if name == "bbdm_conv2d_nhwc_f32":
+                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[9:15])
+                elif name == "bbdm_attention_f32":
+                    shp = "N{} T{} heads{} ch{}".format(*oargs[4:8])
+                elif name == "bbdm_groupnorm_apply_f32":
+                    shp = "N{} {}x{} C{} silu{} rs{}".format(oargs[9], oargs[10], oargs[11], oargs[12], oargs[15], oargs[16])
+                elif name == "bbdm_groupnorm_stats_f32":
+                    shp = "N{} HW{} C{}".format(oargs[3], oargs[4], oargs[5])
+                else:
+                    shp = ""
+                tf = fl / (ms * 1e-3) / 1e12 if ms > 0 and fl else 0.0
+                f.write(f"| {k} | {name.replace('bbdm_', '')} | {shp} | {ms:.3f} | {tf:.1f} |\n")
     conv = by.get("bbdm_conv2d_nhwc_f32", [0, 0.0, 0.0])
     total_flops_per_step = sum(v[2] for v in by.values()) / max(1, args.steps)
     conv_launches = conv[0]
@@ -187,6 +213,20 @@ def main():
     flops_per_launch = conv[2] / max(1, conv_launches)
     avg_launch_ms = conv_ms / max(1, conv_launches)
     achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
+    # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
+    # rocprofv3 PMC passes of this same command (profiles/*_pmc_<workload>_traffic.json), per launch, or null.
+    traffic = None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
+        if cands:
+            pm = json.load(open(cands[-1]))
+            for k, v in pm["kernels"].items():
+                if k.startswith("conv_igemm_f32"):
+                    traffic = {"bytes_per_launch": v["fabric_bytes_per_launch_corrected"], "source": os.path.basename(cands[-1]),
+                               "note": "L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included"}
+    except Exception:
+        traffic = None
     ms_per_step = elapsed * 1e3 / args.steps
     steps_per_s_job = world * args.steps / elapsed
 
@@ -206,7 +246,7 @@ def main():
             "tflops_algorithmic": total_flops_per_step / (ms_per_step * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None, "launches_per_step": conv_launches / max(1, args.steps),
+                         "traffic": traffic, "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
                          "conv_share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
