@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -24,10 +24,23 @@ SIGNATURES = {
     "bbdm_conv_pack_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_conv2d_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_conv_packed_dgrad_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "bbdm_conv_pack_weight_dgrad_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_conv_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "bbdm_conv_wgrad_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_colsum_f32": (c_int, [_P, c_int, _P, _P, ctypes.c_longlong, c_int, _P]),
     "bbdm_groupnorm_stats_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_groupnorm_apply_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_int, c_int, _P]),
-    "bbdm_attention_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_attention_f32": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_attention_bwd_f32": (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, _P]),
+    "bbdm_linear_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "bbdm_linear_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_bb_loss_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_groupnorm_bwd_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
+    "bbdm_groupnorm_bwd_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P, _P,
+                                       _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "bbdm_timestep_embedding_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "bbdm_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_bb_q_sample_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),

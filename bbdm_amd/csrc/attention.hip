@@ -21,7 +21,8 @@ constexpr int QB = 128;       // queries per block
 
 template <int CH>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out,
-                                                       int ldo, int T, int heads, int new_order, float scale) {
+                                                       int ldo, float* __restrict__ lse, int T, int heads, int new_order,
+                                                       float scale) {
     constexpr int KPITCH = CH + 4;                 // K tile pitch: b128 reads by 32 keys conflict-free
     constexpr int VPITCH = CH < 32 ? 32 : CH;      // V tile pitch (lanes sweep channels)
     constexpr int CT = (CH + 31) / 32;             // 32-row channel tiles of O^T
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     float* obuf = smem;                                    // 128 * (CH+1) floats <= the K/V buffers for CH >= 16
     static_assert(QB * OPITCH <= 2 * KT * KPITCH + 2 * KT * VPITCH, "epilogue staging does not fit");
     const float inv = 1.0f / l_run;
+    if (lse && hi == 0 && q < T) lse[((size_t)n * heads + h) * T + q] = m_run + logf(l_run);   // for the backward pass
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -185,8 +187,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 
 }  // namespace
 
-extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, int N, int T, int heads, int ch,
-                                  int new_order, void* stream) {
+extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads,
+                                  int ch, int new_order, void* stream) {
     BBDM_REQUIRE(qkv && out, "attention: null pointer");
     BBDM_REQUIRE(N > 0 && T > 0 && heads > 0, "attention: bad shape");
     BBDM_REQUIRE(ch == 16 || ch == 32 || ch == 64, "attention: head channels %d unsupported (16, 32, 64)", ch);
@@ -197,11 +199,14 @@ extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo
     const dim3 grid((unsigned)((long long)N * heads * qblocks));
     hipStream_t st = (hipStream_t)stream;
     if (ch == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, T, heads, new_order, scale);
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, lse, T, heads, new_order,
+                           scale);
     else if (ch == 32)
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, T, heads, new_order, scale);
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, lse, T, heads, new_order,
+                           scale);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, T, heads, new_order, scale);
+        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, lse, T, heads, new_order,
+                           scale);
     BBDM_CHECK_LAUNCH("attention");
     return BBDM_OK;
 }

@@ -1,0 +1,315 @@
+// conv_wgrad.hip -- weight / bias gradients of the fp32 NHWC convolutions (training path) and the weight packer
+// for the data-gradient pass.
+//
+// Reference: autograd of nn.Conv2d / nn.Conv1d(k=1) at openaimodel.py:207,233,244,307,315,524,690 (the reference
+// relies on ATen's cudnn/MIOpen backward; here it is explicit).
+//
+//   dW[co][ci][r][s] = sum_{n,h,w} dY[n,h,w,co] * X[n,h+r-pad,w+s-pad,ci]        (this file, MFMA fp32)
+//   db[co]           = sum_{n,h,w} dY[n,h,w,co]                                   (this file, HBM-bound)
+//   dX               = conv(dY, W^T flipped)   -> the forward kernel (conv_igemm.hip) with the weights packed by
+//                                                bbdm_conv_pack_weight_dgrad_f32 below.
+//
+// wgrad is a GEMM whose K dimension is the pixel index: C_tap[ci][co] = sum_m Xtap[m][ci] * dY[m][co].  One
+// workgroup (4 waves, 2x2) owns a 64(ci) x 64(co) tile for ALL taps (9 accumulators of 32x32 per wave) and walks
+// 8x8-pixel tiles: the X halo patch (10x10 pixels) and the dY tile are staged in LDS once per pixel tile and shared
+// by the 9 taps, the dY fragment is read once per pixel pair and feeds 9 MFMAs.  The pixel loop is split over
+// gridDim.z; partial tiles go to a workspace and a second kernel sums the splits in a fixed order (deterministic)
+// while transposing to the parameter's OIHW layout.
+#include "common.h"
+
+namespace {
+
+constexpr int CT = 64;           // channels per tile (both ci and co)
+constexpr int CP = CT + 4;       // LDS pitch
+constexpr int PTH = 8, PTW = 8;  // pixel tile
+
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* ws;                   // [splits][taps][CinT*64][CoutT*64] partial tiles (padded dims)
+    int ldx, ldy;
+    int N, H, W, Cin, Cout;
+    int taps, pad;
+    int tilesX, tilesY;          // pixel tiles per image
+    int ptiles;                  // N * tilesX * tilesY
+    int tiles_per_split;
+    int CinP, CoutP;             // Cin, Cout rounded up to 64
+};
+
+template <int TAPS>
+__global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int PW = PTW + 2 * PAD, PH = PTH + 2 * PAD;
+    constexpr int XPIX = PW * PH;                    // 100 or 64
+    constexpr int XSLOTS = (XPIX * CT / 4 + 255) / 256;
+    constexpr int YSLOTS = (PTH * PTW * CT / 4) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XPIX][CP] + [2][64][CP]
+    float* xbuf = smem;
+    float* ybuf = smem + 2 * XPIX * CP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wo = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int ci0 = blockIdx.x * CT, co0 = blockIdx.y * CT;
+    const int t_begin = blockIdx.z * a.tiles_per_split;
+    const int t_end = min(a.ptiles, t_begin + a.tiles_per_split);
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float4 xreg[XSLOTS], yreg[YSLOTS];
+    auto load_tile = [&](int t) {
+        const int n = t / (a.tilesX * a.tilesY);
+        const int rem = t - n * (a.tilesX * a.tilesY);
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        const int h0 = ty * PTH, w0 = tx * PTW;
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = tid + s * 256;
+            const int pp = f / (CT / 4), c = (f % (CT / 4)) * 4;
+            const int py = pp / PW, px = pp - py * PW;
+            const int h = h0 + py - PAD, w = w0 + px - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < XPIX * CT / 4 && h >= 0 && h < a.H && w >= 0 && w < a.W && ci0 + c < a.Cin)
+                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + ci0 + c);
+            xreg[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < YSLOTS; ++s) {
+            const int f = tid + s * 256;
+            const int pp = f / (CT / 4), c = (f % (CT / 4)) * 4;
+            const int py = pp / PTW, px = pp - py * PTW;
+            const int h = h0 + py, w = w0 + px;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h < a.H && w < a.W && co0 + c < a.Cout) {
+                const float* p = a.dy + ((size_t)(n * a.H + h) * a.W + w) * a.ldy + co0 + c;
+                if (co0 + c + 3 < a.Cout) {
+                    v = *reinterpret_cast<const float4*>(p);
+                } else {                                   // ragged Cout (e.g. the 3-channel head)
+                    v.x = p[0];
+                    if (co0 + c + 1 < a.Cout) v.y = p[1];
+                    if (co0 + c + 2 < a.Cout) v.z = p[2];
+                }
+            }
+            yreg[s] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < XSLOTS; ++s) {
+            const int f = tid + s * 256;
+            if (f < XPIX * CT / 4)
+                *reinterpret_cast<float4*>(xbuf + buf * XPIX * CP + (f / (CT / 4)) * CP + (f % (CT / 4)) * 4) = xreg[s];
+        }
+#pragma unroll
+        for (int s = 0; s < YSLOTS; ++s) {
+            const int f = tid + s * 256;
+            *reinterpret_cast<float4*>(ybuf + buf * PTH * PTW * CP + (f / (CT / 4)) * CP + (f % (CT / 4)) * 4) = yreg[s];
+        }
+    };
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) load_tile(t + 1);
+        const float* xb = xbuf + buf * XPIX * CP + wi * 32 + l31;
+        const float* yb = ybuf + buf * PTH * PTW * CP + wo * 32 + l31;
+        // k runs over pixel pairs (px, px+1): lanes < 32 carry the even pixel, lanes >= 32 the odd one
+#pragma unroll 2
+        for (int py = 0; py < PTH; ++py) {
+#pragma unroll
+            for (int pxp = 0; pxp < PTW / 2; ++pxp) {
+                const int px = 2 * pxp + hi;
+                const float b = yb[(py * PTW + px) * CP];
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int r = tap / 3, s = tap - 3 * r;
+                    const float av = xb[((py + (TAPS == 9 ? r : 0)) * PW + px + (TAPS == 9 ? s : 0)) * CP];
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tap], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < t_end) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial tile -> workspace [split][tap][ci][co]
+    float* wsb = a.ws + (size_t)blockIdx.z * TAPS * a.CinP * a.CoutP;
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int co = co0 + wo * 32 + l31;
+            wsb[((size_t)tap * a.CinP + ci) * a.CoutP + co] = acc[tap][r];
+        }
+}
+
+// dW[co][ci][tap] = sum_splits ws[s][tap][ci][co]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int taps, int Cin,
+                                    int Cout, int CinP, int CoutP) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    const size_t stride = (size_t)taps * CinP * CoutP;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        // iterate with co fastest so that workspace reads are coalesced
+        const int co = (int)(i % Cout);
+        const size_t t = i / Cout;
+        const int ci = (int)(t % Cin);
+        const int tap = (int)(t / Cin);
+        const float* p = ws + ((size_t)tap * CinP + ci) * CoutP + co;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += p[k * stride];
+        dw[((size_t)co * Cin + ci) * taps + tap] = s;
+    }
+}
+
+// db[c] = sum over rows of dy[M][ld]; fp64 per-thread accumulation + fp64 atomics (order-independent to fp32 rounding)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc,
+                                                     long long M, int C, int rows_per_block) {
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    // thread -> column c = tid % Cb, row lane = tid / Cb
+    const int Cb = C < 256 ? C : 256;
+    const int RL = 256 / Cb;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int c = cbase + tid % Cb;
+        const int rl = tid / Cb;
+        if (c < C && rl < RL) {
+            double s = 0.0;
+            for (long long r = r0 + rl; r < r1; r += RL) s += (double)dy[(size_t)r * ld + c];
+            atomicAdd(&acc[c], s);
+        }
+    }
+}
+
+__global__ void colsum_final_kernel(const double* __restrict__ acc, float* __restrict__ db, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) db[c] = (float)acc[c];
+}
+
+// packed weights for the data-gradient conv: Wd[ci_out][co_in][r][s] = W[co_in][ci_out][K-1-r][K-1-s]
+__global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int CoutIn,
+                                         int ks, int CinPad128, int nchunks) {
+    const int KC = 16;
+    const size_t total = (size_t)ks * ks * nchunks * CinPad128 * KC;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = i % KC;
+        size_t t = i / KC;
+        const int ci = t % CinPad128;          // output channel of the dgrad conv
+        t /= CinPad128;
+        const int chunk = t % nchunks;
+        const int tap = t / nchunks;
+        const int co = chunk * KC + k;         // input channel of the dgrad conv
+        float v = 0.f;
+        if (ci < Cin && co < Cout) v = w[((size_t)co * Cin + ci) * ks * ks + (ks * ks - 1 - tap)];
+        p[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
+    const int CinP = cdiv(Cin, CT) * CT, CoutP = cdiv(Cout, CT) * CT;
+    const int ptiles = N * cdiv(H, PTH) * cdiv(W, PTW);
+    const int tiles = (CinP / CT) * (CoutP / CT);
+    int splits = cdiv(768, tiles);
+    if (splits > ptiles) splits = ptiles;
+    if (splits < 1) splits = 1;
+    const int tps = cdiv(ptiles, splits);
+    splits = cdiv(ptiles, tps);
+    return (size_t)splits * ks * ks * CinP * CoutP;
+}
+
+extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* ws,
+                                   int N, int H, int W, int Cin, int Cout, int ks, void* stream) {
+    BBDM_REQUIRE(x && dy && dw_oihw && ws, "conv_wgrad: null pointer");
+    BBDM_REQUIRE(ks == 1 || ks == 3, "conv_wgrad: ks=%d", ks);
+    BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
+    BBDM_REQUIRE(ldx % 4 == 0 && ldx >= Cin && ((uintptr_t)x & 15) == 0, "conv_wgrad: x pitch/alignment (ldx=%d)", ldx);
+    BBDM_REQUIRE(ldy >= Cout && (Cout % 4 != 0 || (ldy % 4 == 0 && ((uintptr_t)dy & 15) == 0)),
+                 "conv_wgrad: dy pitch/alignment (ldy=%d)", ldy);
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.ws = ws; a.ldx = ldx; a.ldy = ldy;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.taps = ks * ks; a.pad = ks / 2;
+    a.tilesX = cdiv(W, PTW); a.tilesY = cdiv(H, PTH);
+    a.ptiles = N * a.tilesX * a.tilesY;
+    a.CinP = cdiv(Cin, CT) * CT; a.CoutP = cdiv(Cout, CT) * CT;
+    const int tiles = (a.CinP / CT) * (a.CoutP / CT);
+    int splits = cdiv(768, tiles);
+    if (splits > a.ptiles) splits = a.ptiles;
+    if (splits < 1) splits = 1;
+    a.tiles_per_split = cdiv(a.ptiles, splits);
+    splits = cdiv(a.ptiles, a.tiles_per_split);
+    BBDM_REQUIRE(Cin % 4 == 0, "conv_wgrad: Cin=%d must be a multiple of 4 (pad the input tensor)", Cin);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(a.CinP / CT, a.CoutP / CT, splits);
+    const int xpix = ks == 3 ? (PTW + 2) * (PTH + 2) : PTW * PTH;
+    const size_t lds = ((size_t)2 * xpix * CP + 2 * PTH * PTW * CP) * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[ks == 3]) {
+        const void* f = ks == 3 ? reinterpret_cast<const void*>(conv_wgrad_f32<9>)
+                                : reinterpret_cast<const void*>(conv_wgrad_f32<1>);
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            bbdm_set_error("conv_wgrad: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        attr_set[ks == 3] = true;
+    }
+    if (ks == 3)
+        hipLaunchKernelGGL(conv_wgrad_f32<9>, grid, dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL(conv_wgrad_f32<1>, grid, dim3(256), lds, st, a);
+    const size_t total = (size_t)Cout * Cin * ks * ks;
+    int rb = (int)((total + 255) / 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, splits, ks * ks, Cin, Cout, a.CinP,
+                       a.CoutP);
+    BBDM_CHECK_LAUNCH("conv_wgrad");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream) {
+    BBDM_REQUIRE(dy && acc && out && M > 0 && C > 0 && ld >= C, "colsum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(acc, 0, sizeof(double) * C, st);
+    long long blocks = (M + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const int rpb = (int)((M + blocks - 1) / blocks);
+    blocks = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ld, acc, M, C, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, acc, out, C);
+    BBDM_CHECK_LAUNCH("colsum");
+    return BBDM_OK;
+}
+
+extern "C" size_t bbdm_conv_packed_dgrad_floats(int Cout, int Cin, int CoutIn, int ks) {
+    (void)Cout;
+    const int CinPad128 = cdiv(Cin, 128) * 128;
+    const int nchunks = cdiv(CoutIn, 16);
+    return (size_t)ks * ks * nchunks * CinPad128 * 16;
+}
+
+extern "C" int bbdm_conv_pack_weight_dgrad_f32(const float* w_oihw, float* packed, int Cout, int Cin, int CoutIn, int ks,
+                                               void* stream) {
+    BBDM_REQUIRE(w_oihw && packed, "conv_pack_dgrad: null pointer");
+    BBDM_REQUIRE((ks == 1 || ks == 3) && Cout > 0 && Cin > 0 && CoutIn >= Cout && CoutIn % 4 == 0,
+                 "conv_pack_dgrad: bad shape Cout=%d Cin=%d CoutIn=%d ks=%d", Cout, Cin, CoutIn, ks);
+    const int CinPad128 = cdiv(Cin, 128) * 128;
+    const int nchunks = cdiv(CoutIn, 16);
+    const size_t total = (size_t)ks * ks * nchunks * CinPad128 * 16;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin,
+                       CoutIn, ks, CinPad128, nchunks);
+    BBDM_CHECK_LAUNCH("conv_pack_dgrad");
+    return BBDM_OK;
+}

@@ -66,7 +66,111 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
     y[(size_t)n * Out + o] = acc;
 }
 
+// ---- backward of linear_kernel (training path; M = batch, so these are tiny) ---------------------------------------
+// dx_pre[n][i] = act_in'(x[n][i]) * sum_o dy[n][o] w[o][i].  grid = (In/256, o-chunks); each thread owns one input
+// column i for ALL rows n (<= 64 accumulators), so every weight element is read exactly once; the o-chunks write
+// partials that a second kernel sums in a fixed order (deterministic).
+constexpr int LB_OCH = 256;      // outputs per chunk
+
+__global__ void __launch_bounds__(256) linear_bwd_x_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                   float* __restrict__ part, int N, int In, int Out) {
+    __shared__ float dys[64 * LB_OCH];           // [n][o in chunk]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int o0 = blockIdx.y * LB_OCH;
+    const int on = min(LB_OCH, Out - o0);
+    for (int k = threadIdx.x; k < N * LB_OCH; k += 256) {
+        const int n = k / LB_OCH, o = k - n * LB_OCH;
+        dys[k] = o < on ? dy[(size_t)n * Out + o0 + o] : 0.f;
+    }
+    __syncthreads();
+    if (i >= In) return;
+    float acc[64];
+#pragma unroll
+    for (int n = 0; n < 64; ++n) acc[n] = 0.f;
+    for (int o = 0; o < on; ++o) {
+        const float wv = w[(size_t)(o0 + o) * In + i];
+#pragma unroll
+        for (int n = 0; n < 64; ++n)
+            if (n < N) acc[n] = fmaf(dys[n * LB_OCH + o], wv, acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < 64; ++n)
+        if (n < N) part[((size_t)blockIdx.y * N + n) * In + i] = acc[n];
+}
+
+__global__ void linear_bwd_x_final_kernel(const float* __restrict__ part, const float* __restrict__ x_pre,
+                                          float* __restrict__ dx, int chunks, int N, int In, int act_in) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * In) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N * In + idx];
+    if (act_in) {
+        const float v = x_pre[idx];
+        const float sg = 1.0f / (1.0f + expf(-v));
+        s *= sg * (1.0f + v * (1.0f - sg));
+    }
+    dx[idx] = s;
+}
+
+// dw[o][i] = sum_n dy[n][o] act_in(x[n][i]),  db[o] = sum_n dy[n][o].  Block = 8 outputs x all inputs; x staged in LDS.
+__global__ void __launch_bounds__(256) linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dw, float* __restrict__ db, int N, int In,
+                                                           int Out, int act_in) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [N][In]
+    for (int k = threadIdx.x; k < N * In; k += 256) {
+        float v = x[k];
+        if (act_in) v = silu_f(v);
+        xs[k] = v;
+    }
+    __syncthreads();
+    const int o0 = blockIdx.x * 8;
+    for (int oo = 0; oo < 8; ++oo) {
+        const int o = o0 + oo;
+        if (o >= Out) break;
+        for (int i = threadIdx.x; i < In; i += 256) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s = fmaf(dy[(size_t)n * Out + o], xs[n * In + i], s);
+            dw[(size_t)o * In + i] = s;
+        }
+        if (db && threadIdx.x == 0) {
+            float s = 0.f;
+            for (int n = 0; n < N; ++n) s += dy[(size_t)n * Out + o];
+            db[o] = s;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" size_t bbdm_linear_bwd_workspace_floats(int N, int In, int Out) {
+    return (size_t)cdiv(Out, LB_OCH) * N * In;
+}
+
+extern "C" int bbdm_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                   float* ws, int N, int In, int Out, int act_in, void* stream) {
+    BBDM_REQUIRE(dy && x && w && dw && ws && N > 0 && N <= 64 && In > 0 && Out > 0, "linear_bwd: bad args (N <= 64)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)N * In * sizeof(float);
+    BBDM_REQUIRE(lds <= 160 * 1024, "linear_bwd: N*In too large for LDS staging");
+    static size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            bbdm_set_error("linear_bwd: hipFuncSetAttribute failed");
+            return BBDM_E_LAUNCH;
+        }
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(Out, 8)), dim3(256), lds, st, dy, x, dw, db, N, In, Out, act_in);
+    if (dx) {
+        const int chunks = cdiv(Out, LB_OCH);
+        hipLaunchKernelGGL(linear_bwd_x_partial_kernel, dim3(cdiv(In, 256), chunks), dim3(256), 0, st, dy, w, ws, N, In, Out);
+        hipLaunchKernelGGL(linear_bwd_x_final_kernel, dim3(cdiv(N * In, 256)), dim3(256), 0, st, ws, x, dx, chunks, N, In,
+                           act_in);
+    }
+    BBDM_CHECK_LAUNCH("linear_bwd");
+    return BBDM_OK;
+}
 
 extern "C" int bbdm_timestep_embedding_f32(const int64_t* t, const float* freqs, float* emb, int N, int dim,
                                            void* stream) {

@@ -1,0 +1,274 @@
+// groupnorm_bwd.hip -- backward of the fused GroupNorm -> [FiLM] -> [SiLU] -> [avg-pool | nearest x2] pass
+// (training path; the reference gets it from autograd through util.py:214-216 / openaimodel.py:259-274).
+//
+// Forward (groupnorm.hip):  xh = (x - mu) r,  y = xh g + b,  v = y (1 + sc) + sh,  z = silu(v),  a = R(z)
+// Given dA (gradient of a), with dz = R^T(dA) and dv = dz * silu'(v):
+//   P[n,c] = sum_hw dv xh,   Q[n,c] = sum_hw dv                                   (kernel 1: reduce, fp64 sums)
+//   dgamma[c] = sum_n (1+sc) P,  dbeta[c] = sum_n (1+sc) Q,  dsc[n,c] = g P + b Q,  dsh[n,c] = Q,
+//   S1[n,G] = sum_{c in G} g (1+sc) Q,  S2[n,G] = sum_{c in G} g (1+sc) P          (kernel 2: finalize, tiny)
+//   dx = r ( g (1+sc) dv - S1/cnt - xh S2/cnt )  [+ R^T(dAdd)]  [+ dx]             (kernel 3: apply)
+// dAdd carries the gradient of the skip path (x_upd / identity), which shares the same resampling.
+// All three are HBM-bound streaming kernels with float4 accesses along the channel axis.
+#include "common.h"
+
+namespace {
+
+struct BwdArgs {
+    const float* x;
+    const double* stats;
+    const float* gamma;
+    const float* beta;
+    const float* film;
+    const float* da;
+    const float* dadd;
+    const double* sg;
+    double* pq;
+    float* dx;
+    int ldx, ldda, ldadd, lddx, film_ld;
+    int H, W, C, G;
+    float eps;
+    int silu, resample, accumulate;
+};
+
+__device__ __forceinline__ float dsilu(float v) {
+    const float s = 1.0f / (1.0f + expf(-v));
+    return s * (1.0f + v * (1.0f - s));
+}
+
+// gradient arriving at input pixel (h, w), channel quad c, from tensor `g` (pitch ld) living at the OUTPUT resolution
+__device__ __forceinline__ float4 gather_grad(const float* __restrict__ g, int ld, int resample, int h, int w, int H,
+                                              int W, int c) {
+    if (resample == 0) return *reinterpret_cast<const float4*>(g + ((size_t)h * W + w) * ld + c);
+    if (resample == 1) {
+        const int Wo = W >> 1;
+        float4 v = *reinterpret_cast<const float4*>(g + ((size_t)(h >> 1) * Wo + (w >> 1)) * ld + c);
+        return make_float4(v.x * 0.25f, v.y * 0.25f, v.z * 0.25f, v.w * 0.25f);
+    }
+    const int Wo = W * 2;
+    const float* p0 = g + ((size_t)(2 * h) * Wo + 2 * w) * ld + c;
+    const float* p1 = p0 + (size_t)Wo * ld;
+    const float4 a = *reinterpret_cast<const float4*>(p0), b = *reinterpret_cast<const float4*>(p0 + ld);
+    const float4 cc = *reinterpret_cast<const float4*>(p1), d = *reinterpret_cast<const float4*>(p1 + ld);
+    return make_float4((a.x + b.x) + (cc.x + d.x), (a.y + b.y) + (cc.y + d.y), (a.z + b.z) + (cc.z + d.z),
+                       (a.w + b.w) + (cc.w + d.w));
+}
+
+struct Norm4 {
+    float rs[4], mu[4];
+};
+
+__device__ __forceinline__ Norm4 load_norm(const BwdArgs& a, int n, int c, int cpg, double cnt) {
+    Norm4 o;
+    const int ng = (cpg & 3) ? 4 : 1;
+    for (int e = 0; e < ng; ++e) {
+        const int g = (c + e) / cpg;
+        const double s = a.stats[((size_t)n * a.G + g) * 2], ss = a.stats[((size_t)n * a.G + g) * 2 + 1];
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        o.rs[e] = (float)(1.0 / sqrt(var + (double)a.eps));
+        o.mu[e] = (float)mean;
+    }
+    if (ng == 1) { o.rs[1] = o.rs[2] = o.rs[3] = o.rs[0]; o.mu[1] = o.mu[2] = o.mu[3] = o.mu[0]; }
+    return o;
+}
+
+// xh (normalised input) and dv for one quad
+__device__ __forceinline__ void quad_dv(const BwdArgs& a, int n, int c, const Norm4& nm, float4 xv, float4 dz,
+                                        float xh[4], float dv[4]) {
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float dzs[4] = {dz.x, dz.y, dz.z, dz.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = (xs[e] - nm.mu[e]) * nm.rs[e];
+        float v = xh[e] * a.gamma[c + e] + a.beta[c + e];
+        if (a.film) v = v * (1.f + a.film[(size_t)n * a.film_ld + c + e]) + a.film[(size_t)n * a.film_ld + a.C + c + e];
+        dv[e] = a.silu ? dzs[e] * dsilu(v) : dzs[e];
+    }
+}
+
+// ---- kernel 1: P, Q ----------------------------------------------------------------------------------------------
+template <int JMAX>
+__global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int pix_per_block) {
+    extern __shared__ double lacc[];          // [C][2]
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int C4 = a.C >> 2, cpg = a.C / a.G, HW = a.H * a.W;
+    const double cnt = (double)HW * cpg;
+    for (int i = tid; i < 2 * a.C; i += 256) lacc[i] = 0.0;
+    __syncthreads();
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    const int Ho = a.resample == 1 ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
+    const int Wo = a.resample == 1 ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
+    const float* xb = a.x + (size_t)n * HW * a.ldx;
+    const float* dab = a.da + (size_t)n * Ho * Wo * a.ldda;
+    int PP, prow, c4base;
+    bool active;
+    if (C4 <= 256) { PP = 256 / C4; prow = tid / C4; c4base = tid - prow * C4; active = prow < PP; }
+    else { PP = 1; prow = 0; c4base = tid; active = true; }
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            const int c4 = c4base + j * 256;
+            if (c4 >= C4) continue;
+            const int c = c4 * 4;
+            const Norm4 nm = load_norm(a, n, c, cpg, cnt);
+            double P[4] = {0, 0, 0, 0}, Q[4] = {0, 0, 0, 0};
+            for (int p = p0 + prow; p < p1; p += PP) {
+                const int h = p / a.W, w = p - h * a.W;
+                const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * a.ldx + c);
+                const float4 dz = gather_grad(dab, a.ldda, a.resample, h, w, a.H, a.W, c);
+                float xh[4], dv[4];
+                quad_dv(a, n, c, nm, xv, dz, xh, dv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { P[e] += (double)dv[e] * xh[e]; Q[e] += (double)dv[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&lacc[2 * (c + e)], P[e]);
+                atomicAdd(&lacc[2 * (c + e) + 1], Q[e]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * a.C; i += 256) atomicAdd(&a.pq[(size_t)n * a.C * 2 + i], lacc[i]);
+}
+
+// ---- kernel 2: finalize (one block per image) --------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __restrict__ pq, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ film,
+                                                              int film_ld, double* __restrict__ sg, double* __restrict__ dgb,
+                                                              float* __restrict__ dfilm, int dfilm_ld, int C, int G) {
+    // grid = N; dgb: fp64 [C][2] accumulators (zeroed by the launcher) for dgamma / dbeta over n
+    __shared__ double s12[64 * 2];
+    const int n = blockIdx.x, tid = threadIdx.x, cpg = C / G;
+    if (tid < 2 * G) s12[tid] = 0.0;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const double P = pq[((size_t)n * C + c) * 2], Q = pq[((size_t)n * C + c) * 2 + 1];
+        const double g = gamma[c], b = beta[c];
+        const double one_sc = film ? 1.0 + (double)film[(size_t)n * film_ld + c] : 1.0;
+        atomicAdd(&dgb[2 * c], one_sc * P);
+        atomicAdd(&dgb[2 * c + 1], one_sc * Q);
+        if (dfilm) {
+            dfilm[(size_t)n * dfilm_ld + c] = (float)(g * P + b * Q);       // d scale
+            dfilm[(size_t)n * dfilm_ld + C + c] = (float)Q;                 // d shift
+        }
+        atomicAdd(&s12[2 * (c / cpg)], g * one_sc * Q);
+        atomicAdd(&s12[2 * (c / cpg) + 1], g * one_sc * P);
+    }
+    __syncthreads();
+    if (tid < 2 * G) sg[(size_t)n * G * 2 + tid] = s12[tid];
+}
+
+__global__ void gn_bwd_params_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        dgamma[c] = (float)dgb[2 * c];
+        dbeta[c] = (float)dgb[2 * c + 1];
+    }
+}
+
+// ---- kernel 3: dx ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a) {
+    const int n = blockIdx.y;
+    const int C4 = a.C >> 2, HW = a.H * a.W;
+    const long long units = (long long)HW * C4;
+    const int cpg = a.G > 0 ? a.C / a.G : a.C;
+    const double cnt = (double)HW * cpg;
+    const int Ho = a.resample == 1 ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
+    const int Wo = a.resample == 1 ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
+    const float* xb = a.x ? a.x + (size_t)n * HW * a.ldx : nullptr;
+    const float* dab = a.da ? a.da + (size_t)n * Ho * Wo * a.ldda : nullptr;
+    const float* addb = a.dadd ? a.dadd + (size_t)n * Ho * Wo * a.ldadd : nullptr;
+    float* dxb = a.dx + (size_t)n * HW * a.lddx;
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
+        const int c4 = (int)(u % C4), p = (int)(u / C4), c = c4 * 4;
+        const int h = p / a.W, w = p - h * a.W;
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.gamma) {
+            const Norm4 nm = load_norm(a, n, c, cpg, cnt);
+            const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * a.ldx + c);
+            const float4 dz = gather_grad(dab, a.ldda, a.resample, h, w, a.H, a.W, c);
+            float xh[4], dv[4];
+            quad_dv(a, n, c, nm, xv, dz, xh, dv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int g = (c + e) / cpg;
+                const float s1 = (float)(a.sg[((size_t)n * a.G + g) * 2] / cnt);
+                const float s2 = (float)(a.sg[((size_t)n * a.G + g) * 2 + 1] / cnt);
+                float gs = a.gamma[c + e];
+                if (a.film) gs *= 1.f + a.film[(size_t)n * a.film_ld + c + e];
+                out[e] = nm.rs[e] * (gs * dv[e] - s1 - xh[e] * s2);
+            }
+        }
+        if (addb) {
+            const float4 ad = gather_grad(addb, a.ldadd, a.resample, h, w, a.H, a.W, c);
+            out[0] += ad.x; out[1] += ad.y; out[2] += ad.z; out[3] += ad.w;
+        }
+        float* o = dxb + (size_t)p * a.lddx + c;
+        if (a.accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(o);
+            out[0] += old.x; out[1] += old.y; out[2] += old.z; out[3] += old.w;
+        }
+        *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+}  // namespace
+
+// Workspace (fp64 elements): pq [N][C][2] + sg [N][G][2] + dgb [C][2]
+extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
+    return (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2;
+}
+
+extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
+                                      const float* film, int film_ld, const float* da, int ldda, const float* dadd,
+                                      int ldadd, float* dx, int lddx, int accumulate, float* dgamma, float* dbeta,
+                                      float* dfilm, int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps,
+                                      int silu, int resample, void* stream) {
+    BBDM_REQUIRE(dx, "gn_bwd: null dx");
+    const int norm = gamma != nullptr;
+    BBDM_REQUIRE(norm || dadd, "gn_bwd: nothing to do (no norm, no dadd)");
+    BBDM_REQUIRE(!norm || (x && stats && beta && da && dgamma && dbeta && ws), "gn_bwd: missing pointer for the norm path");
+    BBDM_REQUIRE(resample >= 0 && resample <= 2 && (resample != 1 || (H % 2 == 0 && W % 2 == 0)), "gn_bwd: resample");
+    BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && lddx % 4 == 0 && lddx >= C, "gn_bwd: shape/pitch");
+    BBDM_REQUIRE(!norm || (ldx % 4 == 0 && ldda % 4 == 0 && G > 0 && G <= 64 && C % G == 0 && C <= 4096), "gn_bwd: norm args");
+    BBDM_REQUIRE(!dadd || ldadd % 4 == 0, "gn_bwd: ldadd");
+    BBDM_REQUIRE(!film || film_ld % 4 == 0, "gn_bwd: film_ld");
+    hipStream_t st = (hipStream_t)stream;
+    BwdArgs a;
+    a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.da = da; a.dadd = dadd; a.dx = dx;
+    a.ldx = ldx; a.ldda = ldda; a.ldadd = ldadd; a.lddx = lddx; a.film_ld = film_ld;
+    a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample;
+    a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr;
+    const int HW = H * W;
+    if (norm) {
+        double* pq = ws;
+        double* sg = ws + (size_t)N * C * 2;
+        double* dgb = sg + (size_t)N * G * 2;
+        (void)hipMemsetAsync(ws, 0, sizeof(double) * bbdm_groupnorm_bwd_workspace_doubles(N, C, G), st);
+        a.pq = pq; a.sg = sg;
+        const int C4 = C / 4;
+        const int PP = C4 <= 256 ? 256 / C4 : 1;
+        int splits = cdiv(1024, N);
+        int ppb = cdiv(HW, splits);
+        if (ppb < PP * 8) ppb = PP * 8;
+        splits = cdiv(HW, ppb);
+        const size_t lds = sizeof(double) * 2 * C;
+        const dim3 grid(splits, N);
+        if (C4 <= 256) hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, grid, dim3(256), lds, st, a, ppb);
+        else if (C4 <= 512) hipLaunchKernelGGL(gn_bwd_reduce_kernel<2>, grid, dim3(256), lds, st, a, ppb);
+        else hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, grid, dim3(256), lds, st, a, ppb);
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, pq, gamma, beta, film, film_ld, sg, dgb, dfilm,
+                           dfilm_ld, C, G);
+        hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dgb, dgamma, dbeta, C);
+    }
+    const long long units = (long long)HW * (C / 4);
+    long long blocks = (units + 255) / 256;
+    const long long cap = cdiv(8192, N) > 1 ? cdiv(8192, N) : 1;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, a);
+    BBDM_CHECK_LAUNCH("gn_bwd");
+    return BBDM_OK;
+}

@@ -101,15 +101,27 @@ def groupnorm_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma: Optio
     return y
 
 
-def attention(qkv: torch.Tensor, heads: int, new_order: bool = False) -> torch.Tensor:
-    """qkv: [N, T, 3*heads*ch] -> [N, T, heads*ch]."""
+def attention(qkv: torch.Tensor, heads: int, new_order: bool = False, return_lse: bool = False):
+    """qkv: [N, T, 3*heads*ch] -> [N, T, heads*ch] (and the per-query log-sum-exp [N, heads, T] if asked)."""
     _chk(qkv)
     N, T, C3 = qkv.shape
     C = C3 // 3
     out = torch.empty(N, T, C, dtype=torch.float32, device=qkv.device)
-    _lib.call("bbdm_attention_f32", qkv.data_ptr(), C3, out.data_ptr(), C, N, T, heads, C // heads,
-              1 if new_order else 0, _st(qkv))
-    return out
+    lse = torch.empty(N, heads, T, dtype=torch.float32, device=qkv.device) if return_lse else None
+    _lib.call("bbdm_attention_f32", qkv.data_ptr(), C3, out.data_ptr(), C, None if lse is None else lse.data_ptr(),
+              N, T, heads, C // heads, 1 if new_order else 0, _st(qkv))
+    return (out, lse) if return_lse else out
+
+
+def attention_bwd(qkv, out, dout, lse, heads: int, new_order: bool = False) -> torch.Tensor:
+    _chk(qkv, out, dout, lse)
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    dqkv = torch.empty_like(qkv)
+    work = torch.empty(N * heads * T, dtype=torch.float32, device=qkv.device)
+    _lib.call("bbdm_attention_bwd_f32", qkv.data_ptr(), C3, out.data_ptr(), C, dout.data_ptr(), C, lse.data_ptr(),
+              work.data_ptr(), dqkv.data_ptr(), C3, N, T, heads, C // heads, 1 if new_order else 0, _st(qkv))
+    return dqkv
 
 
 def timestep_embedding(t: torch.Tensor, freqs: torch.Tensor, dim: int) -> torch.Tensor:
@@ -130,3 +142,79 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act_in: 
         _lib.call("bbdm_linear_f32", x.data_ptr() + 4 * r0 * In, w.data_ptr(), None if b is None else b.data_ptr(),
                   y.data_ptr() + 4 * r0 * Out, r, In, Out, 1 if act_in else 0, 1 if act_out else 0, _st(x))
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backward (training path)
+# ---------------------------------------------------------------------------------------------------------------
+def pack_conv_weight_dgrad(w: torch.Tensor, cout_in: Optional[int] = None) -> torch.Tensor:
+    """Packed transposed + flipped weights: conv2d_nhwc(dY, packed, None, cout=Cin, ks) is the data gradient."""
+    _chk(w)
+    cout, cin = w.shape[0], w.shape[1]
+    ks = w.shape[2] if w.dim() == 4 else 1
+    cout_in = cout_in or (cout + 3) // 4 * 4
+    n = _lib.load().bbdm_conv_packed_dgrad_floats(cout, cin, cout_in, ks)
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), packed.data_ptr(), cout, cin, cout_in, ks, _st(w))
+    return packed
+
+
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, cin: int, cout: int, ks: int) -> torch.Tensor:
+    """x: [N,H,W,CinPad], dy: [N,H,W,>=cout] -> dW [cout, cin, ks, ks] (cin = true, unpadded input channels)."""
+    _chk(x, dy)
+    N, H, W, cin_pad = x.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.bbdm_conv_wgrad_workspace_floats(N, H, W, cin_pad, cout, ks), dtype=torch.float32, device=x.device)
+    dw = torch.empty(cout, cin_pad, ks, ks, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv_wgrad_f32", x.data_ptr(), cin_pad, dy.data_ptr(), dy.shape[-1], dw.data_ptr(), ws.data_ptr(),
+              N, H, W, cin_pad, cout, ks, _st(x))
+    return dw if cin == cin_pad else dw[:, :cin].contiguous()
+
+
+def colsum(dy: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
+    _chk(dy)
+    ld = dy.shape[-1]
+    C = C or ld
+    M = dy.numel() // ld
+    acc = torch.empty(C, dtype=torch.float64, device=dy.device)
+    out = torch.empty(C, dtype=torch.float32, device=dy.device)
+    _lib.call("bbdm_colsum_f32", dy.data_ptr(), ld, acc.data_ptr(), out.data_ptr(), M, C, _st(dy))
+    return out
+
+
+def groupnorm_bwd(x, stats, gamma, beta, da, film=None, dadd=None, eps=1e-5, silu=False, resample=0, groups=32,
+                  dx=None, accumulate=False):
+    """Returns (dx, dgamma, dbeta, dfilm[N, 2C] or None)."""
+    _chk(x, stats, gamma, beta, da, film, dadd, dx)
+    N, H, W, C = x.shape
+    if dx is None:
+        dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+    dfilm = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device) if film is not None else None
+    lib = _lib.load()
+    ws = torch.empty(lib.bbdm_groupnorm_bwd_workspace_doubles(N, C, groups), dtype=torch.float64, device=x.device)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.call("bbdm_groupnorm_bwd_f32", x.data_ptr(), C, p(stats), p(gamma), p(beta), p(film),
+              0 if film is None else film.shape[1], p(da), 0 if da is None else da.shape[-1], p(dadd),
+              0 if dadd is None else dadd.shape[-1], dx.data_ptr(), dx.shape[-1], 1 if accumulate else 0, p(dgamma),
+              p(dbeta), p(dfilm), 0 if dfilm is None else 2 * C, ws.data_ptr(), N, H, W, C, groups, float(eps),
+              1 if silu else 0, resample, _st(x))
+    return dx, dgamma, dbeta, dfilm
+
+
+def linear_bwd(dy, x, w, act_in=False, need_dx=True, need_db=True):
+    """Backward of :func:`linear` (x = its pre-activation input).  Returns (dx or None, dw, db or None)."""
+    _chk(dy, x, w)
+    N, In = x.shape
+    Out = w.shape[0]
+    lib = _lib.load()
+    dw = torch.empty_like(w)
+    db = torch.empty(Out, dtype=torch.float32, device=x.device) if need_db else None
+    dx = torch.empty_like(x) if need_dx else None
+    ws = torch.empty(max(1, lib.bbdm_linear_bwd_workspace_floats(min(N, 64), In, Out)), dtype=torch.float32, device=x.device)
+    if N > 64:
+        raise ValueError("linear_bwd: N <= 64 rows per call")
+    _lib.call("bbdm_linear_bwd_f32", dy.data_ptr(), x.data_ptr(), w.data_ptr(), None if dx is None else dx.data_ptr(),
+              dw.data_ptr(), None if db is None else db.data_ptr(), ws.data_ptr(), N, In, Out, 1 if act_in else 0, _st(x))
+    return dx, dw, db

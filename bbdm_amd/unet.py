@@ -499,7 +499,7 @@ class _Plan:
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
             return 2.0 * N * H * W * cout * cin * ks * ks
         if name == "bbdm_attention_f32":
-            N, T, heads, ch = args[4:8]
+            N, T, heads, ch = args[5:9]
             return 2.0 * 2.0 * N * heads * T * T * ch
         return 0.0
 
@@ -600,7 +600,7 @@ class _Plan:
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
         self._emit_conv(a, ab.qkv, None, qkv)
         at = self._tmp("AT", N, x.H, x.W, C)
-        self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, N, T, ab.num_heads, ch,
+        self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, None, N, T, ab.num_heads, ch,
                  1 if ab.use_new_attention_order else 0)
         out = dest if dest is not None else self._new(N, x.H, x.W, C)
         self._emit_conv(at, ab.proj_out, x, out)

@@ -197,7 +197,7 @@ def main():
                 if name == "bbdm_conv2d_nhwc_f32":
                     shp = "N{} {}x{} {}->{} k{}".format(*oargs[9:15])
                 elif name == "bbdm_attention_f32":
-                    shp = "N{} T{} heads{} ch{}".format(*oargs[4:8])
+                    shp = "N{} T{} heads{} ch{}".format(*oargs[5:9])
                 elif name == "bbdm_groupnorm_apply_f32":
                     shp = "N{} {}x{} C{} silu{} rs{}".format(oargs[9], oargs[10], oargs[11], oargs[12], oargs[15], oargs[16])
                 elif name == "bbdm_groupnorm_stats_f32":

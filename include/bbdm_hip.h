@@ -60,6 +60,22 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
                          const float* residual, int ldr, float* out, int ldo, int out_nchw,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
+/* ---- convolution backward (training: autograd of the call sites above; the reference uses ATen's) -------- */
+/* Data gradient = the forward kernel run on dY with transposed + spatially flipped weights: pack them with this
+ * (dY carries CoutIn >= Cout channels, CoutIn % 4 == 0), then call bbdm_conv2d_nhwc_f32(dY, ..., CinPad = CoutIn,
+ * Cout = Cin, ks).  The packed size is bbdm_conv_packed_dgrad_floats(). */
+size_t bbdm_conv_packed_dgrad_floats(int Cout, int Cin, int CoutIn, int ks);
+int bbdm_conv_pack_weight_dgrad_f32(const float* w_oihw, float* packed, int Cout, int Cin, int CoutIn, int ks,
+                                    void* stream);
+/* Weight gradient dW[co][ci][r][s] = sum_{n,h,w} dY[n,h,w,co] X[n,h+r-p,w+s-p,ci], written in OIHW (overwrite).
+ * x: NHWC pitch ldx (Cin % 4 == 0); dy: NHWC pitch ldy; ws: bbdm_conv_wgrad_workspace_floats() floats of scratch
+ * (split-K partials, reduced in a fixed order: deterministic). */
+size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks);
+int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* ws,
+                        int N, int H, int W, int Cin, int Cout, int ks, void* stream);
+/* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: fp64[C] scratch. */
+int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream);
+
 /* ---- GroupNorm (util.py:199-216; sites openaimodel.py:205,229,306,688) -------------------------------- */
 /* Accumulate per-(n, group) sum and sum-of-squares of x into stats[N][G][2] (fp64, must be zeroed by the
  * caller, e.g. one hipMemsetAsync per forward for all GroupNorms). */
@@ -77,9 +93,16 @@ int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const
 /* qkv: NHWC [N, T, 3*heads*ch] pitch ldq.  Channel of (head h, part p in {q,k,v}, c):
  *   legacy (new_order = 0): h*3*ch + p*ch + c        new order: p*heads*ch + h*ch + c
  * out: NHWC [N, T, heads*ch] pitch ldo, channel h*ch + c.  softmax((q*s)^T (k*s)) v with s = ch^-1/4,
- * streamed over keys (no T x T tensor is ever materialised).  ch in {16, 32, 64}. */
-int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, int N, int T, int heads, int ch,
+ * streamed over keys (no T x T tensor is ever materialised).  ch in {16, 32, 64}.
+ * lse (may be NULL): fp32 [N][heads][T] log-sum-exp of every query's score row, kept for the backward pass. */
+int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch,
                        int new_order, void* stream);
+/* Backward of the above (training; the reference re-runs the block under CheckpointFunction, util.py:119-148):
+ * dqkv (same layout / pitch convention as qkv, pitch lddq) from dout [N,T,heads*ch] (pitch lddo), the forward's
+ * qkv, out and lse.  Two streaming kernels (dQ per query block; dK,dV per key block), no T x T tensor. */
+int bbdm_attention_bwd_f32(const float* qkv, int ldq, const float* out, int ldo, const float* dout, int lddo,
+                           const float* lse, float* dwork /* N*heads*T floats */, float* dqkv, int lddq,
+                           int N, int T, int heads, int ch, int new_order, void* stream);
 
 /* ---- timestep embedding + small dense layers (util.py:151-171; openaimodel.py:511-516,735; :221-227,267) */
 /* emb[n][:] = [cos(t_n f_0..f_{half-1}), sin(t_n f_0..)] (+ one zero column if dim is odd).  t: int64[N];
@@ -90,6 +113,13 @@ int bbdm_timestep_embedding_f32(const int64_t* t, const float* freqs, float* emb
  * act_*: 0 none, 1 SiLU.  For the M = batch GEMMs of the embedding path (N <= 64 rows). */
 int bbdm_linear_f32(const float* x, const float* w, const float* b, float* y, int N, int In, int Out,
                     int act_in, int act_out, void* stream);
+
+/* Backward of bbdm_linear_f32 (training): dw[o][i] = sum_n dy[n][o] act_in(x[n][i]); db[o] = sum_n dy[n][o] (db may be
+ * NULL); dx[n][i] = act_in'(x[n][i]) sum_o dy[n][o] w[o][i] (dx may be NULL).  x is the PRE-activation input.
+ * ws: bbdm_linear_bwd_workspace_floats() floats.  N <= 64. */
+size_t bbdm_linear_bwd_workspace_floats(int N, int In, int Out);
+int bbdm_linear_bwd_f32(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, float* ws,
+                        int N, int In, int Out, int act_in, void* stream);
 
 /* ---- Brownian-Bridge scheduler arithmetic (BBM.py) ---------------------------------------------------- */
 /* objective ids: 0 'grad', 1 'noise', 2 'ysubx' (BBM.py:134-141,148-160). */
@@ -113,6 +143,27 @@ int bbdm_bb_predict_x0_f32(const float* x_t, const float* y, const float* pred, 
  * out[0] = float(partial / count) is written by a tail kernel on the same stream. */
 int bbdm_bb_loss_f32(const float* a, const float* b, double* partial, float* out, size_t count, int loss_type,
                      void* stream);
+
+/* d loss / d pred of bbdm_bb_loss_f32, scaled by the upstream scalar gradient gscale[0] (device), written as NHWC
+ * [N,H,W,Cpad] (channels >= C zero) -- the layout the head conv's backward reads.  pred / target are NCHW. */
+int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gscale, float* dpred_nhwc,
+                         int N, int C, int H, int W, int Cpad, int loss_type, void* stream);
+
+/* ---- GroupNorm backward (training) -------------------------------------------------------------------- */
+/* Backward of bbdm_groupnorm_apply_f32 (same x / stats / gamma / beta / film / silu / resample as the forward):
+ *   da   : gradient of the forward's output y (at the OUTPUT resolution), pitch ldda
+ *   dadd : optional second gradient at the output resolution, passed through the same resampling transpose and
+ *          added (the skip path h_upd/x_upd share the resampler, openaimodel.py:262-263); with gamma == NULL only
+ *          this term is produced (pure resample backward)
+ *   dx   : result, pitch lddx; accumulate != 0 adds to what is there (a tensor feeding two consumers)
+ *   dgamma / dbeta [C] are overwritten; dfilm (may be NULL) receives [N][dfilm_ld] d scale at [c], d shift at [C+c]
+ *   ws   : bbdm_groupnorm_bwd_workspace_doubles() fp64 elements of scratch. */
+size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G);
+int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
+                           const float* film, int film_ld, const float* da, int ldda, const float* dadd, int ldadd,
+                           float* dx, int lddx, int accumulate, float* dgamma, float* dbeta, float* dfilm,
+                           int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
+                           int resample, void* stream);
 
 #ifdef __cplusplus
 }

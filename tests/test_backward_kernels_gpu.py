@@ -1,0 +1,160 @@
+"""Backward kernels (training path) against torch.autograd of the same op in fp32 on the CPU."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from fixtures import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_BWD = [(2, 16, 16, 32, 64, 3), (1, 24, 40, 64, 128, 3), (3, 8, 8, 128, 96, 3), (4, 4, 4, 256, 64, 3),
+            (2, 16, 16, 64, 192, 1), (1, 13, 9, 8, 3, 3), (8, 32, 32, 128, 128, 3), (2, 8, 8, 4, 32, 3)]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks", CONV_BWD)
+def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(N + H + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) * 0.05).requires_grad_()
+    b = torch.randn(Cout, generator=g).requires_grad_()
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    F.conv2d(x, w, b, padding=ks // 2).backward(dy)
+    cpad = (Cout + 3) // 4 * 4
+    dyg = torch.zeros(N, H, W, cpad)
+    dyg[..., :Cout] = _nhwc(dy)
+    dyg = dyg.to(dev)
+    xg = _nhwc(x.detach()).to(dev)
+    # data gradient
+    pwd = ops.pack_conv_weight_dgrad(w.detach().to(dev), cout_in=cpad)
+    dx = ops.conv2d_nhwc(dyg, pwd, None, Cin, ks)
+    assert rel_err(_nchw(dx.cpu()), x.grad) < TOL
+    # weight / bias gradient
+    dw = ops.conv_wgrad(xg, dyg, Cin, Cout, ks)
+    db = ops.colsum(dyg, Cout)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    assert rel_err(db.cpu(), b.grad) < TOL
+
+
+GN_BWD = [(2, 16, 16, 128), (1, 8, 8, 640), (2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32), (2, 32, 32, 256)]
+
+
+@pytest.mark.parametrize("N,H,W,C", GN_BWD)
+@pytest.mark.parametrize("mode", ["plain", "film_silu", "silu_pool", "silu_up", "silu_add_acc"])
+def test_groupnorm_backward(dev, N, H, W, C, mode):
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(C + H + len(mode))
+    x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).requires_grad_()
+    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_()
+    film = (0.3 * torch.randn(N, 2 * C, generator=g)).requires_grad_()
+    y = F.group_norm(x, 32, gamma, beta, 1e-5)
+    resample, silu, use_film = 0, mode != "plain", mode == "film_silu"
+    if use_film:
+        y = y * (1 + film[:, :C, None, None]) + film[:, C:, None, None]
+    if silu:
+        y = F.silu(y)
+    if mode == "silu_pool":
+        y, resample = F.avg_pool2d(y, 2, 2), 1
+    elif mode == "silu_up":
+        y, resample = F.interpolate(y, scale_factor=2, mode="nearest"), 2
+    da = torch.randn(y.shape, generator=g)
+    dadd = torch.randn(y.shape, generator=g) if mode in ("silu_add_acc", "silu_pool", "silu_up") else None
+    extra = x
+    if mode == "silu_pool":
+        extra = F.avg_pool2d(x, 2, 2)
+    elif mode == "silu_up":
+        extra = F.interpolate(x, scale_factor=2, mode="nearest")
+    loss = (y * da).sum() + ((extra * dadd).sum() if dadd is not None else 0.0)
+    loss.backward()
+    xg = _nhwc(x.detach()).to(dev)
+    stats = ops.groupnorm_stats(xg)
+    init = torch.randn(N, H, W, C, generator=g) if mode == "silu_add_acc" else None
+    dx0 = init.clone().to(dev) if init is not None else None
+    dx, dg, dbt, dfilm = ops.groupnorm_bwd(xg, stats, gamma.detach().to(dev), beta.detach().to(dev), _nhwc(da).to(dev),
+                                           film=film.detach().to(dev) if use_film else None,
+                                           dadd=_nhwc(dadd).to(dev) if dadd is not None else None, silu=silu,
+                                           resample=resample, dx=dx0, accumulate=init is not None)
+    torch.cuda.synchronize()
+    want = x.grad + (_nchw(init) if init is not None else 0.0)
+    assert rel_err(_nchw(dx.cpu()), want) < TOL
+    assert rel_err(dg.cpu(), gamma.grad) < TOL and rel_err(dbt.cpu(), beta.grad) < TOL
+    if use_film:
+        assert rel_err(dfilm.cpu(), film.grad) < TOL
+
+
+def test_resample_only_backward(dev):
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 8, 12, generator=g, requires_grad=True)
+    for rs, fn in ((1, lambda t: F.avg_pool2d(t, 2, 2)), (2, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))):
+        x.grad = None
+        y = fn(x)
+        d = torch.randn(y.shape, generator=g)
+        y.backward(d)
+        dx, _, _, _ = ops.groupnorm_bwd(_nhwc(x.detach()).to(dev), None, None, None, None, dadd=_nhwc(d).to(dev),
+                                        resample=rs)
+        torch.cuda.synchronize()
+        assert rel_err(_nchw(dx.cpu()), x.grad) < 1e-6
+
+
+ATTN_BWD = [(2, 16, 4, 64), (1, 256, 2, 64), (2, 100, 3, 32), (3, 16, 2, 16), (1, 300, 1, 64)]
+
+
+@pytest.mark.parametrize("N,T,heads,ch", ATTN_BWD)
+@pytest.mark.parametrize("new_order", [False, True])
+def test_attention_backward(dev, N, T, heads, ch, new_order):
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(T + heads + ch)
+    C = heads * ch
+    qkv = (torch.randn(N, 3 * C, T, generator=g) * 1.2).requires_grad_()
+    if new_order:
+        q, k, v = qkv.chunk(3, dim=1)
+        q, k, v = (z.reshape(N * heads, ch, T) for z in (q, k, v))
+    else:
+        q, k, v = qkv.reshape(N * heads, 3 * ch, T).split(ch, dim=1)
+    s = 1 / math.sqrt(math.sqrt(ch))
+    wgt = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), dim=-1)
+    ref = torch.einsum("bts,bcs->bct", wgt, v).reshape(N, C, T)
+    do = torch.randn(N, C, T, generator=g)
+    ref.backward(do)
+    qg = qkv.detach().permute(0, 2, 1).contiguous().to(dev)
+    out, lse = ops.attention(qg, heads, new_order, return_lse=True)
+    dqkv = ops.attention_bwd(qg, out, do.permute(0, 2, 1).contiguous().to(dev), lse, heads, new_order)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().permute(0, 2, 1), ref.detach()) < TOL
+    assert rel_err(dqkv.cpu().permute(0, 2, 1), qkv.grad) < TOL
+
+
+@pytest.mark.parametrize("N,In,Out,act", [(4, 128, 512, False), (16, 512, 1000, True), (33, 96, 70, True),
+                                           (64, 512, 2048, True)])
+def test_linear_backward(dev, N, In, Out, act):
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(N + In)
+    x = torch.randn(N, In, generator=g, requires_grad=True)
+    w = (torch.randn(Out, In, generator=g) * 0.05).requires_grad_()
+    b = torch.randn(Out, generator=g).requires_grad_()
+    dy = torch.randn(N, Out, generator=g)
+    F.linear(F.silu(x) if act else x, w, b).backward(dy)
+    dx, dw, db = ops.linear_bwd(dy.to(dev), x.detach().to(dev), w.detach().to(dev), act_in=act)
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu(), x.grad) < TOL and rel_err(dw.cpu(), w.grad) < TOL and rel_err(db.cpu(), b.grad) < TOL
