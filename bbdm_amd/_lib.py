@@ -37,7 +37,7 @@ SIGNATURES = {
                                        c_int, _P]),
     "bbdm_linear_bwd_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_linear_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "bbdm_bb_loss_bwd_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_bb_loss_bwd_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
     "bbdm_groupnorm_bwd_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_groupnorm_bwd_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P, _P,
                                        _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),

@@ -96,22 +96,15 @@ __global__ void loss_final_kernel(const double* __restrict__ partial, float* __r
     out[0] = (float)(partial[0] * inv_count);
 }
 
-// d loss / d pred, written directly in the NHWC (channels padded to Cpad) layout the head conv's backward consumes.
-// l1: sign(pred - target) / count ; l2: 2 (pred - target) / count ; times the upstream scalar gradient *gscale.
+// d loss / d pred (same NCHW layout as pred):  l1: sign(pred - target) / count ; l2: 2 (pred - target) / count ;
+// times the upstream scalar gradient gscale[0] (read on the device: no host sync).
 __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
-                                const float* __restrict__ gscale, float* __restrict__ dpred, int C, int Cpad, int HW,
-                                size_t total, float inv_count, int loss_type) {
+                                const float* __restrict__ gscale, float* __restrict__ dpred, size_t total,
+                                float inv_count, int loss_type) {
     const float g = gscale[0] * inv_count;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cpad);
-        const size_t pix = i / Cpad;
-        float v = 0.f;
-        if (c < C) {
-            const size_t n = pix / HW, p = pix - n * HW;
-            const float d = pred[(n * C + c) * HW + p] - target[(n * C + c) * HW + p];
-            v = loss_type == 0 ? (d > 0.f ? g : (d < 0.f ? -g : 0.f)) : 2.f * d * g;
-        }
-        dpred[i] = v;
+        const float d = pred[i] - target[i];
+        dpred[i] = loss_type == 0 ? (d > 0.f ? g : (d < 0.f ? -g : 0.f)) : 2.f * d * g;
     }
 }
 
@@ -198,13 +191,12 @@ extern "C" int bbdm_bb_loss_f32(const float* a, const float* b, double* partial,
     return BBDM_OK;
 }
 
-extern "C" int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gscale, float* dpred_nhwc,
-                                    int N, int C, int H, int W, int Cpad, int loss_type, void* stream) {
-    BBDM_REQUIRE(pred && target && gscale && dpred_nhwc && N > 0 && C > 0 && Cpad >= C && (loss_type == 0 || loss_type == 1),
+extern "C" int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gscale, float* dpred,
+                                    size_t count, int loss_type, void* stream) {
+    BBDM_REQUIRE(pred && target && gscale && dpred && count > 0 && (loss_type == 0 || loss_type == 1),
                  "loss_bwd: bad args");
-    const size_t total = (size_t)N * H * W * Cpad;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, pred, target, gscale,
-                       dpred_nhwc, C, Cpad, H * W, total, 1.0f / (float)((size_t)N * C * H * W), loss_type);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(ew_blocks(count)), dim3(256), 0, (hipStream_t)stream, pred, target, gscale,
+                       dpred, count, 1.0f / (float)count, loss_type);
     BBDM_CHECK_LAUNCH("loss_bwd");
     return BBDM_OK;
 }

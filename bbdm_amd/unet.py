@@ -173,6 +173,17 @@ class _ParamRef:
         return p.data_ptr()
 
 
+class _LateTensor:
+    """A workspace whose size is only known after emission; ``t`` is assigned before the first bind."""
+    __slots__ = ("t",)
+
+    def __init__(self):
+        self.t = None
+
+    def resolve(self):
+        return self.t.data_ptr()
+
+
 def _round4(c):
     return (c + 3) // 4 * 4
 
@@ -199,6 +210,27 @@ class _PackedConv:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
             _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
                       self.cin_pad, self.ks, stream)
+            self.key = key
+
+
+class _PackedDgrad:
+    """Packed transposed + flipped copy of a conv weight: the forward kernel run with it computes the data gradient."""
+
+    def __init__(self, weight: nn.Parameter, cout_in: int):
+        self.weight = weight
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.ks = weight.shape[2] if weight.dim() == 4 else 1
+        self.cout_in = cout_in
+        n = _lib.load().bbdm_conv_packed_dgrad_floats(self.cout, self.cin, cout_in, self.ks)
+        self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        self.key = None
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
+                      self.cout_in, self.ks, stream)
             self.key = key
 
 
@@ -329,8 +361,7 @@ class UNetModel(nn.Module):
             return unet_apply(self, x, timesteps, context)
         return self.infer(x, timesteps, context)
 
-    @torch.no_grad()
-    def infer(self, x, timesteps, context=None, out: Optional[torch.Tensor] = None):
+    def _check_inputs(self, x, context):
         if not x.is_cuda:
             raise _lib.BBDMHipError("bbdm_amd.UNetModel runs on the GPU only (no CPU fallback by design); "
                                     f"got a tensor on {x.device}")
@@ -345,14 +376,23 @@ class UNetModel(nn.Module):
         cin = x.shape[1] + (ctx.shape[1] if ctx is not None else 0)
         if cin != self.in_channels:
             raise RuntimeError(f"expected {self.in_channels} input channels (x + context), got {cin}")
-        N, _, H, W = x.shape
-        key = (N, H, W, x.device.index, x.shape[1])
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = _Plan(self, N, H, W, x.device, x.shape[1])
-            self._plans[key] = plan
+        return x, ctx
+
+    @torch.no_grad()
+    def infer(self, x, timesteps, context=None, out: Optional[torch.Tensor] = None):
+        x, ctx = self._check_inputs(x, context)
+        plan = self._plan_for(x, training=False)
         t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
         return plan.run(x, t, ctx, out)
+
+    def _plan_for(self, x, training: bool) -> "_Plan":
+        N, _, H, W = x.shape
+        key = (N, H, W, x.device.index, x.shape[1], training)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
+            self._plans[key] = plan
+        return plan
 
     def _apply(self, fn, *a, **k):
         # .to(device) / .cuda() / .float(): drop compiled plans, they hold device pointers
@@ -383,8 +423,13 @@ class _Plan:
 
     GROUPS = 32
 
-    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int):
+    SAVED_ROLES = ("A", "H1", "A2", "XR", "QKV", "AT")     # activations the backward pass re-reads
+
+    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int, training: bool = False):
         self.m, self.N, self.H, self.W, self.device, self.cx = m, N, H, W, device, cx
+        self.training = training
+        self.tape: List[tuple] = []         # training: one record per layer, replayed in reverse by _emit_backward
+        self.bops: List[tuple] = []         # training: backward op list
         self.ops: List[tuple] = []          # (fn_name, args with unresolved refs)
         self.convs: List[_PackedConv] = []
         self.bufs: List[_Buf] = []
@@ -478,10 +523,14 @@ class _Plan:
                 dest = h_dest(j + 1, oc)
             h = self._emit_block(blk, cb, dest)
         # head: GN -> SiLU -> conv3x3 -> NCHW  (openaimodel.py:687-691,759)
+        head_stats = self._gn_count
         a = self._gn_apply(h, m.out[0], None, silu=1, resample=0, name="A")
         pc = self._conv(m.out[2], a.C)
         self._op("bbdm_conv2d_nhwc_f32", a, a.ld, _TensorRef(pc.packed), self._pref(pc.bias), None, 0,
                  _TensorRef(self.out_nchw), 0, 1, N, a.H, a.W, a.C, pc.cout, 3)
+        if training:
+            self.tape.append(("head", m.out, h, a, head_stats))
+            self._emit_backward(x0)
 
         # ---- allocate -----------------------------------------------------------------------------------------------
         for b in self.bufs:
@@ -513,7 +562,10 @@ class _Plan:
         return _View(b, 0, C, N, H, W, C)
 
     def _tmp(self, name, N, H, W, C) -> _View:
-        """Block-local temporary: one buffer per role, sized for the largest user (blocks run sequentially)."""
+        """Block-local temporary: one buffer per role, sized for the largest user (blocks run sequentially).
+        In a training plan the roles the backward pass re-reads get their own buffer per use instead."""
+        if self.training and name in self.SAVED_ROLES:
+            return self._new(N, H, W, C)
         b = self._scratch.get(name)
         if b is None:
             b = _Buf(0)
@@ -579,10 +631,12 @@ class _Plan:
                                       "(all reference templates use True)")
         N = self.N
         rs = 2 if rb.up else (1 if rb.down else 0)
+        s1 = self._gn_count
         a = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A")
         xr = x if rs == 0 else self._gn_apply(x, None, None, 0, rs, name="XR")
         h1 = self._tmp("H1", N, a.H, a.W, rb.out_channels)
         self._emit_conv(a, rb.in_layers[2], None, h1)
+        s2 = self._gn_count
         a2 = self._gn_apply(h1, rb.out_layers[0], self.film_off[id(rb)], silu=1, resample=0, name="A2")
         out = dest if dest is not None else self._new(N, a.H, a.W, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
@@ -590,20 +644,28 @@ class _Plan:
             self._emit_conv(a2, rb.out_layers[3], out, out)
         else:
             self._emit_conv(a2, rb.out_layers[3], xr, out)
+        if self.training:
+            self.tape.append(("res", rb, x, a, xr, h1, a2, out, s1, s2, rs))
         return out
 
     def _emit_attn(self, ab: AttentionBlock, x: _View, dest: Optional[_View]) -> _View:
         """AttentionBlock._forward (openaimodel.py:321-327)."""
         N, T, C = self.N, x.H * x.W, x.C
         ch = C // ab.num_heads
+        s0 = self._gn_count
         a = self._gn_apply(x, ab.norm, None, silu=0, resample=0, name="A")
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
         self._emit_conv(a, ab.qkv, None, qkv)
         at = self._tmp("AT", N, x.H, x.W, C)
-        self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, None, N, T, ab.num_heads, ch,
+        lse = None
+        if self.training:
+            lse = _TensorRef(torch.empty(N * ab.num_heads * T, dtype=torch.float32, device=self.device))
+        self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, lse, N, T, ab.num_heads, ch,
                  1 if ab.use_new_attention_order else 0)
         out = dest if dest is not None else self._new(N, x.H, x.W, C)
         self._emit_conv(at, ab.proj_out, x, out)
+        if self.training:
+            self.tape.append(("attn", ab, x, a, qkv, at, lse, out, s0))
         return out
 
     def _emit_block(self, blk, h: _View, dest: Optional[_View]) -> _View:
@@ -613,6 +675,8 @@ class _Plan:
             if isinstance(layer, nn.Conv2d):
                 out = d if d is not None else self._new(self.N, h.H, h.W, layer.out_channels)
                 self._emit_conv(h, layer, None, out)
+                if self.training:
+                    self.tape.append(("stem", layer, h, out))
                 h = out
             elif isinstance(layer, ResBlock):
                 h = self._emit_res(layer, h, d)
@@ -623,6 +687,231 @@ class _Plan:
                     f"bbdm_amd: {type(layer).__name__} (resblock_updown=False) is not implemented yet; "
                     "all reference templates use resblock_updown=True")
         return h
+
+    # ---- backward plan (training) ----------------------------------------------------------------------------------
+    class _GradRef:
+        """Pointer into the flat parameter-gradient buffer of the current backward call (+ element offset)."""
+        __slots__ = ("plan", "off")
+
+        def __init__(self, plan, off):
+            self.plan, self.off = plan, off
+
+        def resolve(self):
+            return self.plan._flat_grad.data_ptr() + 4 * self.off
+
+    def _bop(self, name, *args):
+        self.bops.append((name, args))
+
+    def _emit_backward(self, x0: _View):
+        """Walk the tape in reverse and emit the gradient ops.
+
+        Every persistent activation buffer gets a gradient twin of the same geometry.  A tensor consumed by two
+        layers (block input = GN path + skip path is handled inside one kernel; an input-block output feeds the next
+        block AND an output block through the concat) receives its first gradient by overwrite and later ones by
+        accumulation -- the concat consumer always runs first in reverse order and writes the whole buffer.
+        """
+        m, N, lib, dev = self.m, self.N, self.lib, self.device
+        G = self.GROUPS
+        # parameter -> offset in the flat gradient buffer (order of m.parameters())
+        self.param_list = list(m.parameters())
+        self.grad_off, off = {}, 0
+        for p in self.param_list:
+            self.grad_off[id(p)] = off
+            off += p.numel()
+        self.grad_total = off
+        self._flat_grad = None
+        gref = lambda p: _Plan._GradRef(self, self.grad_off[id(p)])
+
+        gbufs: Dict[int, _Buf] = {}
+        written = set()
+
+        def gview(v: _View) -> _View:
+            b = gbufs.get(id(v.buf))
+            if b is None:
+                b = _Buf(v.buf.numel)
+                gbufs[id(v.buf)] = b
+                self.bufs.append(b)
+            return _View(b, v.off, v.ld, v.N, v.H, v.W, v.C)
+
+        def first_write(v: _View) -> int:
+            """0 = overwrite (first gradient reaching this buffer), 1 = accumulate."""
+            k = id(v.buf)
+            acc = 1 if k in written else 0
+            written.add(k)
+            return acc
+
+        ws_floats, ws_doubles, colsum_c = [1], [1], [1]
+
+        def sstat(slot):
+            return _Plan._StatsRef(self, slot)
+
+        def conv_bwd(mod, x_in: _View, dy: _View, need_dx: bool, dx_name: str, cin_true=None):
+            """wgrad + bias grad (+ dgrad into a scratch view).  dy: gradient of the conv output (pitch >= Cout)."""
+            w = mod.weight
+            cout, cin = w.shape[0], w.shape[1]
+            ks = w.shape[2] if w.dim() == 4 else 1
+            ws_floats[0] = max(ws_floats[0], lib.bbdm_conv_wgrad_workspace_floats(N, x_in.H, x_in.W, x_in.C, cout, ks))
+            if x_in.C == cin:
+                dw_dst = gref(w)
+            else:                                   # padded stem input: gradient of the padding channels is dropped
+                t = torch.empty(cout, x_in.C, ks, ks, dtype=torch.float32, device=dev)
+                self._padded_wgrads.append((w, t))
+                dw_dst = _TensorRef(t)
+            self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, self._ws_f, N, x_in.H, x_in.W, x_in.C,
+                      cout, ks)
+            if mod.bias is not None:
+                colsum_c[0] = max(colsum_c[0], cout)
+                self._bop("bbdm_colsum_f32", dy, dy.ld, self._ws_d, gref(mod.bias), N * x_in.H * x_in.W, cout)
+            if not need_dx:
+                return None
+            pk = _PackedDgrad(w, dy.C)
+            self.dconvs.append(pk)
+            dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
+            self._bop("bbdm_conv2d_nhwc_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, 0, N, x_in.H,
+                      x_in.W, dy.C, x_in.C, ks)
+            return dx
+
+        def gn_bwd(gn, x: _View, slot, film_off, da: _View, dadd: Optional[_View], silu, rs, dx: _View, acc: int):
+            ws_doubles[0] = max(ws_doubles[0], lib.bbdm_groupnorm_bwd_workspace_doubles(N, x.C, G))
+            film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
+            dfilm = None if film_off is None else _TensorRef(self.dfilm, 4 * film_off)
+            self._bop("bbdm_groupnorm_bwd_f32", x, x.ld, sstat(slot), self._pref(gn.weight), self._pref(gn.bias), film,
+                      self.film_total, da, da.ld, dadd, dadd.ld if dadd is not None else 0, dx, dx.ld, acc,
+                      gref(gn.weight), gref(gn.bias), dfilm, self.film_total, self._ws_d2, N, x.H, x.W, x.C, G,
+                      float(gn.eps), silu, rs)
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.dfilm = torch.zeros(N, self.film_total, **f32)
+        self.dconvs: List[_PackedDgrad] = []
+        self._padded_wgrads: List[tuple] = []
+        self._ws_f = _LateTensor()
+        self._ws_d = _LateTensor()
+        self._ws_d2 = _LateTensor()
+        self.dout_nchw = torch.empty_like(self.out_nchw)
+        self.need_input_grad = False
+
+        for rec in reversed(self.tape):
+            kind = rec[0]
+            if kind == "head":
+                _, seq, h, a, slot = rec
+                cpad = _round4(m.out_channels)
+                dy = self._tmp("DOUT", N, a.H, a.W, cpad)
+                self._bop("bbdm_nchw_to_nhwc_f32", _TensorRef(self.dout_nchw), m.out_channels, None, 0, dy, dy.ld, cpad,
+                          N, a.H, a.W)
+                dyv = _View(dy.buf, 0, dy.ld, N, a.H, a.W, cpad)
+                da = conv_bwd(seq[2], a, dyv, True, "DA")
+                dh = gview(h)
+                gn_bwd(seq[0], h, slot, None, da, None, 1, 0, dh, first_write(h))
+            elif kind == "res":
+                _, rb, x, a, xr, h1, a2, out, s1, s2, rs = rec
+                dout = gview(out)
+                if isinstance(rb.skip_connection, nn.Conv2d):
+                    dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR")
+                else:
+                    dxr = dout
+                da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2")
+                dh1 = self._tmp("DH1", N, h1.H, h1.W, h1.C)
+                gn_bwd(rb.out_layers[0], h1, s2, self.film_off[id(rb)], da2, None, 1, 0, dh1, 0)
+                da = conv_bwd(rb.in_layers[2], a, dh1, True, "DA")
+                dx = gview(x)
+                gn_bwd(rb.in_layers[0], x, s1, None, da, dxr, 1, rs, dx, first_write(x))
+            elif kind == "attn":
+                _, ab, x, a, qkv, at, lse, out, s0 = rec
+                T, C = x.H * x.W, x.C
+                dout = gview(out)
+                dat = conv_bwd(ab.proj_out, at, dout, True, "DAT")
+                dqkv = self._tmp("DQKV", N, x.H, x.W, 3 * C)
+                dwork = _TensorRef(torch.empty(N * ab.num_heads * T, **f32))
+                self._bop("bbdm_attention_bwd_f32", qkv, qkv.ld, at, at.ld, dat, dat.ld, lse, dwork, dqkv, dqkv.ld, N, T,
+                          ab.num_heads, C // ab.num_heads, 1 if ab.use_new_attention_order else 0)
+                da = conv_bwd(ab.qkv, a, dqkv, True, "DA")
+                dx = gview(x)
+                gn_bwd(ab.norm, x, s0, None, da, dout, 0, 0, dx, first_write(x))
+            elif kind == "stem":
+                _, conv, x, out = rec
+                dout = gview(out)
+                conv_bwd(conv, x, dout, False, "DX0")
+                # d input (only when x / context require grad, e.g. a trainable SpatialRescaler context): own op list
+                main, self.bops = self.bops, []
+                pk = _PackedDgrad(conv.weight, dout.C)
+                self.dconvs.append(pk)
+                self.dx0 = self._tmp("DX0", N, x.H, x.W, x.C)
+                self._bop("bbdm_conv2d_nhwc_f32", dout, dout.ld, _TensorRef(pk.packed), None, None, 0, self.dx0,
+                          self.dx0.ld, 0, N, x.H, x.W, dout.C, x.C, 3)
+                self.bops_x0, self.bops = self.bops, main
+        self._ws_f.t = torch.empty(ws_floats[0], **f32)
+        self._ws_d.t = torch.empty(colsum_c[0], dtype=torch.float64, device=dev)
+        self._ws_d2.t = torch.empty(ws_doubles[0], dtype=torch.float64, device=dev)
+        # embedding-path backward scratch
+        ted = 4 * m.model_channels
+        self.dfilm_w = torch.empty(self.film_total, ted, **f32)
+        self.dfilm_b = torch.empty(self.film_total, **f32)
+        self.d_emb = torch.empty(N, ted, **f32)
+        self.d_e1 = torch.empty(N, ted, **f32)
+        self._lin_ws = torch.empty(max(lib.bbdm_linear_bwd_workspace_floats(min(N, 64), ted, self.film_total),
+                                       lib.bbdm_linear_bwd_workspace_floats(min(N, 64), ted, ted), 1), **f32)
+        self._bbound: List[tuple] = []
+
+    def run_backward(self, dout: torch.Tensor, need_dx: bool):
+        """Gradient of everything w.r.t. ``dout`` (NCHW).  Returns (flat parameter gradient, d input NHWC view or None)."""
+        m, N = self.m, self.N
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self._flat_grad = torch.zeros(self.grad_total, **f32)      # fresh per call: autograd may keep views of it
+        self.dout_nchw.copy_(dout)
+        for pk in self.dconvs:
+            pk.refresh(stream)
+        lib = self.lib
+        bound = [(getattr(lib, name), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
+                 for name, args in (self.bops + (self.bops_x0 if need_dx else []))]
+        check = _lib.check
+        for fn, args in bound:
+            rc = fn(*args, stream)
+            if rc != 0:
+                check(rc, fn.__name__)
+        flat = self._flat_grad
+        gslice = lambda p: flat[self.grad_off[id(p)]: self.grad_off[id(p)] + p.numel()].view_as(p)
+        for w, t in self._padded_wgrads:
+            gslice(w).copy_(t[:, : w.shape[1]])
+        # ---- embedding path: film projections -> time_embed.2 -> time_embed.0 ------------------------------------
+        mc, ted = m.model_channels, 4 * m.model_channels
+        call = _lib.call
+        te0, te2 = m.time_embed[0], m.time_embed[2]
+        first = True
+        for r0 in range(0, N, 64):
+            r = min(64, N - r0)
+            tgt_w = self.dfilm_w if first else torch.empty_like(self.dfilm_w)
+            tgt_b = self.dfilm_b if first else torch.empty_like(self.dfilm_b)
+            call("bbdm_linear_bwd_f32", self.dfilm.data_ptr() + 4 * r0 * self.film_total,
+                 self.emb.data_ptr() + 4 * r0 * ted, self.film_w.data_ptr(), self.d_emb.data_ptr() + 4 * r0 * ted,
+                 tgt_w.data_ptr(), tgt_b.data_ptr(), self._lin_ws.data_ptr(), r, ted, self.film_total, 1, stream)
+            g2w = gslice(te2.weight) if first else torch.empty_like(te2.weight)
+            g2b = gslice(te2.bias) if first else torch.empty_like(te2.bias)
+            call("bbdm_linear_bwd_f32", self.d_emb.data_ptr() + 4 * r0 * ted, self.e1.data_ptr() + 4 * r0 * ted,
+                 te2.weight.data_ptr(), self.d_e1.data_ptr() + 4 * r0 * ted, g2w.data_ptr(), g2b.data_ptr(),
+                 self._lin_ws.data_ptr(), r, ted, ted, 1, stream)
+            g0w = gslice(te0.weight) if first else torch.empty_like(te0.weight)
+            g0b = gslice(te0.bias) if first else torch.empty_like(te0.bias)
+            call("bbdm_linear_bwd_f32", self.d_e1.data_ptr() + 4 * r0 * ted, self.e0.data_ptr() + 4 * r0 * mc,
+                 te0.weight.data_ptr(), None, g0w.data_ptr(), g0b.data_ptr(), self._lin_ws.data_ptr(), r, mc, ted, 0,
+                 stream)
+            if not first:                      # batch > 64: sum the per-chunk weight gradients
+                self.dfilm_w += tgt_w; self.dfilm_b += tgt_b
+                gslice(te2.weight).add_(g2w); gslice(te2.bias).add_(g2b)
+                gslice(te0.weight).add_(g0w); gslice(te0.bias).add_(g0b)
+            first = False
+        off = 0
+        for rb in self.resblocks:
+            lin = rb.emb_layers[1]
+            n = lin.out_features
+            gslice(lin.weight).copy_(self.dfilm_w[off:off + n])
+            gslice(lin.bias).copy_(self.dfilm_b[off:off + n])
+            off += n
+        dx_in = None
+        if need_dx:
+            v = self.dx0
+            dx_in = v.buf.tensor[: v.N * v.H * v.W * v.ld].view(v.N, v.H, v.W, v.ld)
+        return flat, dx_in
 
     # ---- execution ------------------------------------------------------------------------------------------------
     def _bind(self):
@@ -651,6 +940,7 @@ class _Plan:
 
     def run(self, x, t, ctx, out=None):
         m, N = self.m, self.N
+        self.generation = getattr(self, "generation", 0) + 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self._refresh_weights(stream)
         self.x_in.copy_(x)
@@ -665,10 +955,11 @@ class _Plan:
              self.e0.data_ptr(), N, mc, stream)
         for r0 in range(0, N, 64):          # bbdm_linear_f32 handles <= 64 rows per call
             r = min(64, N - r0)
+            # e1 holds the PRE-activation of time_embed.0; its SiLU is applied as the next layer's act_in
             call("bbdm_linear_f32", self.e0.data_ptr() + 4 * r0 * mc, te0.weight.data_ptr(), te0.bias.data_ptr(),
-                 self.e1.data_ptr() + 4 * r0 * ted, r, mc, ted, 0, 1, stream)
+                 self.e1.data_ptr() + 4 * r0 * ted, r, mc, ted, 0, 0, stream)
             call("bbdm_linear_f32", self.e1.data_ptr() + 4 * r0 * ted, te2.weight.data_ptr(), te2.bias.data_ptr(),
-                 self.emb.data_ptr() + 4 * r0 * ted, r, ted, ted, 0, 0, stream)
+                 self.emb.data_ptr() + 4 * r0 * ted, r, ted, ted, 1, 0, stream)
             call("bbdm_linear_f32", self.emb.data_ptr() + 4 * r0 * ted, self.film_w.data_ptr(),
                  self.film_b.data_ptr(), self.film.data_ptr() + 4 * r0 * self.film_total, r, ted, self.film_total,
                  1, 0, stream)

@@ -144,10 +144,11 @@ int bbdm_bb_predict_x0_f32(const float* x_t, const float* y, const float* pred, 
 int bbdm_bb_loss_f32(const float* a, const float* b, double* partial, float* out, size_t count, int loss_type,
                      void* stream);
 
-/* d loss / d pred of bbdm_bb_loss_f32, scaled by the upstream scalar gradient gscale[0] (device), written as NHWC
- * [N,H,W,Cpad] (channels >= C zero) -- the layout the head conv's backward reads.  pred / target are NCHW. */
-int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gscale, float* dpred_nhwc,
-                         int N, int C, int H, int W, int Cpad, int loss_type, void* stream);
+/* d loss / d pred of bbdm_bb_loss_f32 (BBM.py:114-117 under autograd), same layout as pred, scaled by the upstream
+ * scalar gradient gscale[0] (device memory: no host sync).  pred is the second argument of the loss (a - b = target - pred
+ * in the reference; the sign convention here is d/d pred). */
+int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gscale, float* dpred, size_t count,
+                         int loss_type, void* stream);
 
 /* ---- GroupNorm backward (training) -------------------------------------------------------------------- */
 /* Backward of bbdm_groupnorm_apply_f32 (same x / stats / gamma / beta / film / silu / resample as the forward):
