@@ -27,6 +27,7 @@ struct WgradArgs {
     const float* x;
     const float* dy;
     float* ws;                   // [splits][taps][CinT*64][CoutT*64] partial tiles (padded dims)
+    float* wsb;                  // [splits][CoutP] partial bias gradients (column sums of dY), or nullptr
     int ldx, ldy;
     int N, H, W, Cin, Cout;
     int taps, pad;
@@ -59,6 +60,12 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // bias gradient = column sums of dY: one extra MFMA per pixel pair with an all-ones A operand (every row of the
+    // result is the column sum), only in the waves that own ci-rows 0..31 of ci-tile 0 -- no extra memory traffic.
+    const bool do_bias = a.wsb != nullptr && blockIdx.x == 0 && wi == 0;
+    f32x16 accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
 
     float4 xreg[XSLOTS], yreg[YSLOTS];
     auto load_tile = [&](int t) {
@@ -128,6 +135,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
             for (int pxp = 0; pxp < PTW / 2; ++pxp) {
                 const int px = 2 * pxp + hi;
                 const float b = yb[(py * PTW + px) * CP];
+                if (do_bias) accb = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, b, accb, 0, 0, 0);
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const int r = tap / 3, s = tap - 3 * r;
@@ -150,13 +158,21 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
             const int co = co0 + wo * 32 + l31;
             wsb[((size_t)tap * a.CinP + ci) * a.CoutP + co] = acc[tap][r];
         }
+    if (do_bias && hi == 0) a.wsb[(size_t)blockIdx.z * a.CoutP + co0 + wo * 32 + l31] = accb[0];   // row 0 of the tile
 }
 
 // dW[co][ci][tap] = sum_splits ws[s][tap][ci][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int taps, int Cin,
-                                    int Cout, int CinP, int CoutP) {
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, const float* __restrict__ wsb,
+                                    float* __restrict__ db, int splits, int taps, int Cin, int Cout, int CinP, int CoutP) {
     const size_t total = (size_t)Cout * Cin * taps;
     const size_t stride = (size_t)taps * CinP * CoutP;
+    if (db && blockIdx.x == 0) {
+        for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += wsb[(size_t)k * CoutP + co];
+            db[co] = s;
+        }
+    }
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         // iterate with co fastest so that workspace reads are coalesced
         const int co = (int)(i % Cout);
@@ -225,11 +241,11 @@ extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin,
     if (splits < 1) splits = 1;
     const int tps = cdiv(ptiles, splits);
     splits = cdiv(ptiles, tps);
-    return (size_t)splits * ks * ks * CinP * CoutP;
+    return (size_t)splits * ks * ks * CinP * CoutP + (size_t)splits * CoutP;
 }
 
-extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* ws,
-                                   int N, int H, int W, int Cin, int Cout, int ks, void* stream) {
+extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                                   float* ws, int N, int H, int W, int Cin, int Cout, int ks, void* stream) {
     BBDM_REQUIRE(x && dy && dw_oihw && ws, "conv_wgrad: null pointer");
     BBDM_REQUIRE(ks == 1 || ks == 3, "conv_wgrad: ks=%d", ks);
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
@@ -249,6 +265,7 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     if (splits < 1) splits = 1;
     a.tiles_per_split = cdiv(a.ptiles, splits);
     splits = cdiv(a.ptiles, a.tiles_per_split);
+    a.wsb = dbias ? ws + (size_t)splits * ks * ks * a.CinP * a.CoutP : nullptr;
     BBDM_REQUIRE(Cin % 4 == 0, "conv_wgrad: Cin=%d must be a multiple of 4 (pad the input tensor)", Cin);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(a.CinP / CT, a.CoutP / CT, splits);
@@ -271,8 +288,8 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     const size_t total = (size_t)Cout * Cin * ks * ks;
     int rb = (int)((total + 255) / 256);
     if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, splits, ks * ks, Cin, Cout, a.CinP,
-                       a.CoutP);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, a.wsb, dbias, splits, ks * ks, Cin,
+                       Cout, a.CinP, a.CoutP);
     BBDM_CHECK_LAUNCH("conv_wgrad");
     return BBDM_OK;
 }

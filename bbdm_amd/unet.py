@@ -757,11 +757,8 @@ class _Plan:
                 t = torch.empty(cout, x_in.C, ks, ks, dtype=torch.float32, device=dev)
                 self._padded_wgrads.append((w, t))
                 dw_dst = _TensorRef(t)
-            self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, self._ws_f, N, x_in.H, x_in.W, x_in.C,
-                      cout, ks)
-            if mod.bias is not None:
-                colsum_c[0] = max(colsum_c[0], cout)
-                self._bop("bbdm_colsum_f32", dy, dy.ld, self._ws_d, gref(mod.bias), N * x_in.H * x_in.W, cout)
+            self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst,
+                      gref(mod.bias) if mod.bias is not None else None, self._ws_f, N, x_in.H, x_in.W, x_in.C, cout, ks)
             if not need_dx:
                 return None
             pk = _PackedDgrad(w, dy.C)

@@ -55,6 +55,9 @@ WORKLOADS = {
            dict(_UNET_PIXEL, image_size=16, in_channels=8, out_channels=8, attention_resolutions=(16, 8, 4),
                 condition_key="nocond"), 8, 16, 32, True, 200),
 }
+WORKLOADS["c4"] = ("LBBDM-f4 training step (forward + backward + Adam), latent 3x64x64, batch 32 per GPU, DDP gradient "
+                   "all-reduce when --gpus > 1 (BASELINE.json configs[3])",
+                   dict(_UNET_PIXEL, image_size=64, in_channels=3, condition_key="nocond"), 3, 64, 32, True, 200)
 BB = dict(mt_type="linear", objective="grad", loss_type="l1", sample_type="linear", num_timesteps=1000, eta=1.0,
           max_var=1.0)
 
@@ -145,10 +148,27 @@ def main():
     ctx = None if up["condition_key"] == "nocond" else y
     torch.manual_seed(1234 + rank)
     nsteps_table = len(model.steps)
+    training = args.workload == "c4"
 
-    def step(i, img):
-        out, _ = model.p_sample(img, y, ctx, i % (nsteps_table - 1), clip_denoised=False)
-        return out
+    if training:
+        # the reference's training step (runners/BaseRunner.py:398-417, BBDMRunner.py:164-176): net(x, x_cond) ->
+        # loss.backward() -> Adam step; DDP (BaseRunner.py:76) all-reduces the UNet gradients over RCCL/xGMI.
+        model.train()
+        net = model
+        if dist is not None:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank)
+        opt = torch.optim.Adam(model.get_parameters(), lr=1e-4, betas=(0.9, 0.999))
+
+        def step(i, img):
+            opt.zero_grad(set_to_none=True)
+            loss, _ = net(x_t, y)
+            loss.backward()
+            opt.step()
+            return loss.detach().reshape(1)
+    else:
+        def step(i, img):
+            out, _ = model.p_sample(img, y, ctx, i % (nsteps_table - 1), clip_denoised=False)
+            return out
 
     img = x_t
     for i in range(args.warmup):
@@ -157,7 +177,7 @@ def main():
     if dist is not None:
         dist.barrier()
     prof = []
-    model.denoise_fn.op_profile = prof
+    model.denoise_fn.op_profile = None if training else prof
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -234,7 +254,8 @@ def main():
         line = {
             "metric": "denoise-UNet sampling steps/sec (one step = p_sample of the whole local batch: UNet forward + "
                       "Brownian-Bridge update) at 256x256 pixel-space BBDM" if args.workload == "c2" else
-                      f"denoise-UNet sampling steps/sec ({args.workload})",
+                      ("training steps/sec (c4: forward + backward + Adam)" if training else
+                       f"denoise-UNet sampling steps/sec ({args.workload})"),
             "value": steps_per_s_job, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",

@@ -67,11 +67,12 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
 size_t bbdm_conv_packed_dgrad_floats(int Cout, int Cin, int CoutIn, int ks);
 int bbdm_conv_pack_weight_dgrad_f32(const float* w_oihw, float* packed, int Cout, int Cin, int CoutIn, int ks,
                                     void* stream);
-/* Weight gradient dW[co][ci][r][s] = sum_{n,h,w} dY[n,h,w,co] X[n,h+r-p,w+s-p,ci], written in OIHW (overwrite).
+/* Weight gradient dW[co][ci][r][s] = sum_{n,h,w} dY[n,h,w,co] X[n,h+r-p,w+s-p,ci], written in OIHW (overwrite), and
+ * (dbias != NULL) the bias gradient dbias[co] = sum_{n,h,w} dY[n,h,w,co] from the same pass over dY.
  * x: NHWC pitch ldx (Cin % 4 == 0); dy: NHWC pitch ldy; ws: bbdm_conv_wgrad_workspace_floats() floats of scratch
  * (split-K partials, reduced in a fixed order: deterministic). */
 size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks);
-int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* ws,
+int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* ws,
                         int N, int H, int W, int Cin, int Cout, int ks, void* stream);
 /* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: fp64[C] scratch. */
 int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream);

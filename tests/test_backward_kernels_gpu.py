@@ -48,11 +48,11 @@ def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
     dx = ops.conv2d_nhwc(dyg, pwd, None, Cin, ks)
     assert rel_err(_nchw(dx.cpu()), x.grad) < TOL
     # weight / bias gradient
-    dw = ops.conv_wgrad(xg, dyg, Cin, Cout, ks)
+    dw, db2 = ops.conv_wgrad(xg, dyg, Cin, Cout, ks, with_bias=True)
     db = ops.colsum(dyg, Cout)
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), w.grad) < TOL
-    assert rel_err(db.cpu(), b.grad) < TOL
+    assert rel_err(db.cpu(), b.grad) < TOL and rel_err(db2.cpu(), b.grad) < TOL
 
 
 GN_BWD = [(2, 16, 16, 128), (1, 8, 8, 640), (2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32), (2, 32, 32, 256)]
