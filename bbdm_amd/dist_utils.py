@@ -1,0 +1,69 @@
+"""One-process-per-GPU helpers shared by bench.py and the sampling driver.
+
+The path shards by image pair: every rank owns a contiguous slice of the batch / dataset and runs
+the whole sampling loop on it; there is NO data-path collective.  The only exchanges are the control-plane ones the
+reference also has (runners/BaseRunner.py:419,536: a scalar reduce for logging, a barrier per epoch) plus, for
+training, DDP's gradient all-reduce which ``torch.nn.parallel.DistributedDataParallel`` issues itself.
+Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` for the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Callable, Optional, Tuple
+
+import torch
+
+
+def env_rank() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun / torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: Optional[str] = None):
+    """Initialise the default process group when WORLD_SIZE > 1; returns torch.distributed or None."""
+    rank, _, world = env_rank()
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank,
+                                world_size=world)
+    return dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, disjoint, exhaustive [begin, end) split of ``total`` units over ``world`` ranks (sizes differ by
+    at most one)."""
+    base, rem = divmod(total, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def timed_region(fn: Callable[[], None], dist=None, device: Optional[torch.device] = None) -> float:
+    """Run ``fn`` bracketed by barrier + device synchronize on both sides; return the MAX elapsed seconds over ranks."""
+    def fence():
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+
+    fence()
+    t0 = time.perf_counter()
+    fn()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def aggregate_throughput(units_per_rank: int, elapsed_max: float, world: int) -> float:
+    """Whole-job units/s for weak scaling: every rank processed ``units_per_rank`` in the (max-over-ranks) time."""
+    return world * units_per_rank / elapsed_max

@@ -119,22 +119,16 @@ def main():
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import bbdm_amd
+    from bbdm_amd import dist_utils
+    rank, local_rank, world = dist_utils.env_rank()
     if world != args.gpus and not (world == 1 and args.gpus == 1):
         if rank == 0:
             print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = dist_utils.init(backend="nccl")      # RCCL over xGMI; None when single-process
 
-    import bbdm_amd
     desc, up, ch, size, batch, skip, sstep = WORKLOADS[args.workload]
     cfg = _ns({"BB": {"params": dict(BB, skip_sample=skip, sample_step=sstep, UNetParams=up)}})
     model = bbdm_amd.BrownianBridgeModel(cfg)
@@ -170,29 +164,22 @@ def main():
             out, _ = model.p_sample(img, y, ctx, i % (nsteps_table - 1), clip_denoised=False)
             return out
 
-    img = x_t
+    state = {"img": x_t}
     for i in range(args.warmup):
-        img = step(i, img)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
+        state["img"] = step(i, state["img"])
     prof = []
     model.denoise_fn.op_profile = None if training else prof
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        img = step(args.warmup + i, img)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed():
+        for i in range(args.steps):
+            state["img"] = step(args.warmup + i, state["img"])
+
+    # barrier + synchronize on both sides, MAX over ranks (bbdm_amd/dist_utils.py)
+    elapsed = dist_utils.timed_region(timed, dist, dev)
     model.denoise_fn.op_profile = None
+    img = state["img"]
     if not bool(torch.isfinite(img).all()):
         raise RuntimeError("non-finite sample")
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     # ---- per-kernel accounting from the HIP events recorded inside the timed region -------------------------
     by = {}
@@ -248,7 +235,7 @@ def main():
     except Exception:
         traffic = None
     ms_per_step = elapsed * 1e3 / args.steps
-    steps_per_s_job = world * args.steps / elapsed
+    steps_per_s_job = dist_utils.aggregate_throughput(args.steps, elapsed, world)
 
     if rank == 0:
         line = {
