@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -29,6 +29,7 @@ SIGNATURES = {
     "bbdm_conv_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbdm_conv_wgrad_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_colsum_f32": (c_int, [_P, c_int, _P, _P, ctypes.c_longlong, c_int, _P]),
+    "bbdm_colsum_batched_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, ctypes.c_longlong, c_int, _P]),
     "bbdm_groupnorm_stats_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_groupnorm_apply_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_int, c_int, _P]),

@@ -217,8 +217,8 @@ conv_igemm_f32(const ConvArgs a) {
                 if (cok && img_l < a.imgs && n < a.N && h < a.H && w < a.W) {
                     const size_t pix = (size_t)(n * a.H + h) * a.W + w;
                     float v = acc[mt][nt][r] + bv;
-                    if (a.res) v += a.res[pix * a.ldr + co];
-                    if (a.out_nchw)
+                    if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co] : a.res[pix * a.ldr + co];
+                    if (a.out_nchw & 1)
                         a.out[((size_t)(n * a.Cout + co) * a.H + h) * a.W + w] = v;
                     else
                         a.out[pix * a.ldo + co] = v;
@@ -326,7 +326,8 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
                  CinPad, ldx);
     BBDM_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)packed_w & 15) == 0, "conv2d: x / w must be 16-byte aligned");
     BBDM_REQUIRE((size_t)N * H * W * (size_t)ldx < (1ull << 32), "conv2d: input exceeds 2^32 elements");
-    BBDM_REQUIRE(out_nchw || ldo >= Cout, "conv2d: ldo < Cout");
+    BBDM_REQUIRE((out_nchw & 1) || ldo >= Cout, "conv2d: ldo < Cout");
+    BBDM_REQUIRE((out_nchw & ~3) == 0, "conv2d: unknown flag bits 0x%x", out_nchw);
     BBDM_REQUIRE(!residual || ldr >= Cout, "conv2d: ldr < Cout");
     ConvArgs a;
     a.x = x; a.w = packed_w; a.bias = bias; a.res = residual; a.out = out;

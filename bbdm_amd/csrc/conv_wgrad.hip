@@ -206,6 +206,30 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
     }
 }
 
+// per-image variant: grid.y = image
+__global__ void __launch_bounds__(256) colsum_batched_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc,
+                                                             long long M, int C, int rows_per_block) {
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    const float* base = dy + (size_t)n * M * ld;
+    const int Cb = C < 256 ? C : 256;
+    const int RL = 256 / Cb;
+    for (int cbase = 0; cbase < C; cbase += 256) {
+        const int c = cbase + tid % Cb, rl = tid / Cb;
+        if (c < C && rl < RL) {
+            double s = 0.0;
+            for (long long r = r0 + rl; r < r1; r += RL) s += (double)base[(size_t)r * ld + c];
+            atomicAdd(&acc[(size_t)n * C + c], s);
+        }
+    }
+}
+
+__global__ void colsum_batched_final_kernel(const double* __restrict__ acc, float* __restrict__ out, int ldo, int N, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N * C) out[(size_t)(i / C) * ldo + i % C] = (float)acc[i];
+}
+
 __global__ void colsum_final_kernel(const double* __restrict__ acc, float* __restrict__ db, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) db[c] = (float)acc[c];
@@ -305,6 +329,22 @@ extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out,
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ld, acc, M, C, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, acc, out, C);
     BBDM_CHECK_LAUNCH("colsum");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, float* out, int ldo, int N, long long M, int C,
+                                       void* stream) {
+    BBDM_REQUIRE(dy && acc && out && N > 0 && M > 0 && C > 0 && ld >= C && ldo >= C, "colsum_batched: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(acc, 0, sizeof(double) * N * C, st);
+    long long blocks = (M + 255) / 256;
+    const long long cap = cdiv(1024, N) > 1 ? cdiv(1024, N) : 1;
+    if (blocks > cap) blocks = cap;
+    const int rpb = (int)((M + blocks - 1) / blocks);
+    blocks = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_batched_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, dy, ld, acc, M, C, rpb);
+    hipLaunchKernelGGL(colsum_batched_final_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, st, acc, out, ldo, N, C);
+    BBDM_CHECK_LAUNCH("colsum_batched");
     return BBDM_OK;
 }
 

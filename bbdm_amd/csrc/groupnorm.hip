@@ -135,13 +135,14 @@ __device__ __forceinline__ float4 gn_xform(const ApplyArgs& a, float4 v, float4 
 __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
     const int n = blockIdx.y;
     const int C4 = a.C >> 2;
-    const int Hu = a.resample == 1 ? a.H >> 1 : a.H;
-    const int Wu = a.resample == 1 ? a.W >> 1 : a.W;
+    const bool halve = a.resample == 1 || a.resample == 3;
+    const int Hu = halve ? a.H >> 1 : a.H;
+    const int Wu = halve ? a.W >> 1 : a.W;
     const long long units = (long long)Hu * Wu * C4;
     const int cpg = a.C / a.G;
     const double cnt = (double)a.H * a.W * cpg;
-    const int Ho = a.resample == 1 ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
-    const int Wo = a.resample == 1 ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
+    const int Ho = halve ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
+    const int Wo = halve ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
     const float* xb = a.x + (size_t)n * a.H * a.W * a.ldx;
     float* yb = a.y + (size_t)n * Ho * Wo * a.ldy;
 
@@ -179,6 +180,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
         }
         if (a.resample == 0) {
             const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)pu * a.ldx + c);
+            *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = gn_xform(a, v, sc, bi);
+        } else if (a.resample == 3) {
+            const int ho = pu / Wu, wo = pu - ho * Wu;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)(2 * ho) * a.W + 2 * wo) * a.ldx + c);
             *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = gn_xform(a, v, sc, bi);
         } else if (a.resample == 1) {
             const int ho = pu / Wu, wo = pu - ho * Wu;
@@ -252,8 +257,8 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     const int norm = gamma != nullptr;
     BBDM_REQUIRE(!norm || (stats && beta), "gn_apply: gamma given without stats/beta");
     BBDM_REQUIRE(norm || !film, "gn_apply: film without norm");
-    BBDM_REQUIRE(resample >= 0 && resample <= 2, "gn_apply: resample=%d", resample);
-    BBDM_REQUIRE(resample != 1 || (H % 2 == 0 && W % 2 == 0), "gn_apply: avg-pool needs even H, W");
+    BBDM_REQUIRE(resample >= 0 && resample <= 3, "gn_apply: resample=%d", resample);
+    BBDM_REQUIRE((resample != 1 && resample != 3) || (H % 2 == 0 && W % 2 == 0), "gn_apply: down-sampling needs even H, W");
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
                  "gn_apply: bad shape / pitch");
     BBDM_REQUIRE(!norm || (G > 0 && C % G == 0), "gn_apply: C %% G != 0");
@@ -263,7 +268,7 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.y = y;
     a.ldx = ldx; a.ldy = ldy; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample; a.norm = norm;
-    const long long units = (long long)(resample == 1 ? (H / 2) * (W / 2) : H * W) * (C / 4);
+    const long long units = (long long)((resample == 1 || resample == 3) ? (H / 2) * (W / 2) : H * W) * (C / 4);
     long long blocks = (units + 255) / 256;
     const long long cap = cdiv(8192, N) > 1 ? cdiv(8192, N) : 1;
     if (blocks > cap) blocks = cap;

@@ -44,6 +44,10 @@ __device__ __forceinline__ float4 gather_grad(const float* __restrict__ g, int l
         float4 v = *reinterpret_cast<const float4*>(g + ((size_t)(h >> 1) * Wo + (w >> 1)) * ld + c);
         return make_float4(v.x * 0.25f, v.y * 0.25f, v.z * 0.25f, v.w * 0.25f);
     }
+    if (resample == 3) {                      // forward kept pixel (2ho, 2wo): only those receive a gradient
+        if ((h | w) & 1) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return *reinterpret_cast<const float4*>(g + ((size_t)(h >> 1) * (W >> 1) + (w >> 1)) * ld + c);
+    }
     const int Wo = W * 2;
     const float* p0 = g + ((size_t)(2 * h) * Wo + 2 * w) * ld + c;
     const float* p1 = p0 + (size_t)Wo * ld;
@@ -97,8 +101,8 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
     for (int i = tid; i < 2 * a.C; i += 256) lacc[i] = 0.0;
     __syncthreads();
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
-    const int Ho = a.resample == 1 ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
-    const int Wo = a.resample == 1 ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
+    const int Ho = (a.resample == 1 || a.resample == 3) ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
+    const int Wo = (a.resample == 1 || a.resample == 3) ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
     const float* xb = a.x + (size_t)n * HW * a.ldx;
     const float* dab = a.da + (size_t)n * Ho * Wo * a.ldda;
     int PP, prow, c4base;
@@ -176,8 +180,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a) {
     const long long units = (long long)HW * C4;
     const int cpg = a.G > 0 ? a.C / a.G : a.C;
     const double cnt = (double)HW * cpg;
-    const int Ho = a.resample == 1 ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
-    const int Wo = a.resample == 1 ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
+    const int Ho = (a.resample == 1 || a.resample == 3) ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
+    const int Wo = (a.resample == 1 || a.resample == 3) ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
     const float* xb = a.x ? a.x + (size_t)n * HW * a.ldx : nullptr;
     const float* dab = a.da ? a.da + (size_t)n * Ho * Wo * a.ldda : nullptr;
     const float* addb = a.dadd ? a.dadd + (size_t)n * Ho * Wo * a.ldadd : nullptr;
@@ -231,7 +235,8 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
     const int norm = gamma != nullptr;
     BBDM_REQUIRE(norm || dadd, "gn_bwd: nothing to do (no norm, no dadd)");
     BBDM_REQUIRE(!norm || (x && stats && beta && da && dgamma && dbeta && ws), "gn_bwd: missing pointer for the norm path");
-    BBDM_REQUIRE(resample >= 0 && resample <= 2 && (resample != 1 || (H % 2 == 0 && W % 2 == 0)), "gn_bwd: resample");
+    BBDM_REQUIRE(resample >= 0 && resample <= 3 && ((resample != 1 && resample != 3) || (H % 2 == 0 && W % 2 == 0)),
+                 "gn_bwd: resample");
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && lddx % 4 == 0 && lddx >= C, "gn_bwd: shape/pitch");
     BBDM_REQUIRE(!norm || (ldx % 4 == 0 && ldda % 4 == 0 && G > 0 && G <= 64 && C % G == 0 && C <= 4096), "gn_bwd: norm args");
     BBDM_REQUIRE(!dadd || ldadd % 4 == 0, "gn_bwd: ldadd");

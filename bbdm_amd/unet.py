@@ -260,7 +260,7 @@ class UNetModel(nn.Module):
             assert num_head_channels != -1, 'Either num_heads or num_head_channels has to be set'
         if num_head_channels == -1:
             assert num_heads != -1, 'Either num_heads or num_head_channels has to be set'
-        # --- hot-path scope: everything the four reference templates use -------------------------
+        # --- hot-path scope: the four reference templates + both ResBlock / resampling variants ------
         unsupported = []
         if dims != 2:
             unsupported.append(f"dims={dims}")
@@ -617,27 +617,33 @@ class _Plan:
                      x.C, 1, 0.0, 0, resample)
         return y
 
-    def _emit_conv(self, x: _View, mod, residual: Optional[_View], dest: _View):
+    def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0):
+        """``residual`` is an NHWC view, or (with flags & 2) a per-image [N][res_ld] tensor reference."""
         pc = self._conv(mod, x.C)
-        assert dest.C == pc.cout and (residual is None or residual.C == pc.cout), (dest.C, pc.cout)
-        self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias),
-                 residual, residual.ld if residual is not None else 0,
-                 dest, dest.ld, 0, self.N, x.H, x.W, x.C, pc.cout, pc.ks)
+        assert dest.C == pc.cout, (dest.C, pc.cout)
+        if res_ld is None:
+            assert residual is None or residual.C == pc.cout
+            res_ld = residual.ld if residual is not None else 0
+        self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias), residual, res_ld,
+                 dest, dest.ld, flags, self.N, x.H, x.W, x.C, pc.cout, pc.ks)
 
     def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
         """ResBlock._forward (openaimodel.py:258-278)."""
-        if not rb.use_scale_shift_norm:
-            raise NotImplementedError("bbdm_amd: use_scale_shift_norm=False is not implemented yet "
-                                      "(all reference templates use True)")
         N = self.N
+        film = rb.use_scale_shift_norm
         rs = 2 if rb.up else (1 if rb.down else 0)
         s1 = self._gn_count
         a = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A")
         xr = x if rs == 0 else self._gn_apply(x, None, None, 0, rs, name="XR")
         h1 = self._tmp("H1", N, a.H, a.W, rb.out_channels)
-        self._emit_conv(a, rb.in_layers[2], None, h1)
+        if film:
+            self._emit_conv(a, rb.in_layers[2], None, h1)
+        else:       # h = h + emb_out[..., None, None] (openaimodel.py:275): per-image row added in the conv epilogue
+            self._emit_conv(a, rb.in_layers[2], _TensorRef(self.film, 4 * self.film_off[id(rb)]), h1,
+                            res_ld=self.film_total, flags=2)
         s2 = self._gn_count
-        a2 = self._gn_apply(h1, rb.out_layers[0], self.film_off[id(rb)], silu=1, resample=0, name="A2")
+        a2 = self._gn_apply(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, resample=0,
+                            name="A2")
         out = dest if dest is not None else self._new(N, a.H, a.W, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
             self._emit_conv(xr, rb.skip_connection, None, out)
@@ -682,11 +688,45 @@ class _Plan:
                 h = self._emit_res(layer, h, d)
             elif isinstance(layer, AttentionBlock):
                 h = self._emit_attn(layer, h, d)
+            elif isinstance(layer, Downsample):
+                h = self._emit_down(layer, h, d)
+            elif isinstance(layer, Upsample):
+                h = self._emit_up(layer, h, d)
             else:
-                raise NotImplementedError(
-                    f"bbdm_amd: {type(layer).__name__} (resblock_updown=False) is not implemented yet; "
-                    "all reference templates use resblock_updown=True")
+                raise NotImplementedError(f"bbdm_amd: unsupported layer {type(layer).__name__}")
         return h
+
+    def _emit_down(self, ds: Downsample, x: _View, dest: Optional[_View]) -> _View:
+        """Downsample.forward (openaimodel.py:161-163): stride-2 3x3 conv = stride-1 conv + keep every 2nd pixel
+        (4x the minimal FLOPs on 2 layers of a configuration no reference template uses), or a 2x2 average pool."""
+        N = self.N
+        out = dest if dest is not None else self._new(N, x.H // 2, x.W // 2, ds.out_channels)
+        if ds.use_conv:
+            full = self._tmp("DSF", N, x.H, x.W, ds.out_channels)
+            self._emit_conv(x, ds.op, None, full)
+            self._op("bbdm_groupnorm_apply_f32", full, full.ld, None, None, None, None, 0, out, out.ld, N, x.H, x.W,
+                     full.C, 1, 0.0, 0, 3)
+        else:
+            self._op("bbdm_groupnorm_apply_f32", x, x.ld, None, None, None, None, 0, out, out.ld, N, x.H, x.W, x.C, 1,
+                     0.0, 0, 1)
+        if self.training:
+            self.tape.append(("down", ds, x, out))
+        return out
+
+    def _emit_up(self, us: Upsample, x: _View, dest: Optional[_View]) -> _View:
+        """Upsample.forward (openaimodel.py:111-121): nearest x2, then an optional 3x3 conv."""
+        N = self.N
+        out = dest if dest is not None else self._new(N, x.H * 2, x.W * 2, us.out_channels)
+        if us.use_conv:
+            u = self._gn_apply(x, None, None, 0, 2, name="XR")
+            self._emit_conv(u, us.conv, None, out)
+        else:
+            u = None
+            self._op("bbdm_groupnorm_apply_f32", x, x.ld, None, None, None, None, 0, out, out.ld, N, x.H, x.W, x.C, 1,
+                     0.0, 0, 2)
+        if self.training:
+            self.tape.append(("up", us, x, u, out))
+        return out
 
     # ---- backward plan (training) ----------------------------------------------------------------------------------
     class _GradRef:
@@ -808,7 +848,13 @@ class _Plan:
                     dxr = dout
                 da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2")
                 dh1 = self._tmp("DH1", N, h1.H, h1.W, h1.C)
-                gn_bwd(rb.out_layers[0], h1, s2, self.film_off[id(rb)], da2, None, 1, 0, dh1, 0)
+                if rb.use_scale_shift_norm:
+                    gn_bwd(rb.out_layers[0], h1, s2, self.film_off[id(rb)], da2, None, 1, 0, dh1, 0)
+                else:           # d emb_out[n, c] = sum_hw d(h + emb_out)
+                    gn_bwd(rb.out_layers[0], h1, s2, None, da2, None, 1, 0, dh1, 0)
+                    colsum_c[0] = max(colsum_c[0], N * h1.C)
+                    self._bop("bbdm_colsum_batched_f32", dh1, dh1.ld, self._ws_d,
+                              _TensorRef(self.dfilm, 4 * self.film_off[id(rb)]), self.film_total, N, h1.H * h1.W, h1.C)
                 da = conv_bwd(rb.in_layers[2], a, dh1, True, "DA")
                 dx = gview(x)
                 gn_bwd(rb.in_layers[0], x, s1, None, da, dxr, 1, rs, dx, first_write(x))
@@ -824,6 +870,27 @@ class _Plan:
                 da = conv_bwd(ab.qkv, a, dqkv, True, "DA")
                 dx = gview(x)
                 gn_bwd(ab.norm, x, s0, None, da, dout, 0, 0, dx, first_write(x))
+            elif kind == "down":
+                _, ds, x, out = rec
+                dout = gview(out)
+                dx = gview(x)
+                if ds.use_conv:
+                    dfull = self._tmp("DDSF", N, x.H, x.W, ds.out_channels)
+                    self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, dout, dout.ld, dfull,
+                              dfull.ld, 0, None, None, None, 0, None, N, x.H, x.W, dfull.C, 1, 0.0, 0, 3)
+                    dxs = conv_bwd(ds.op, x, dfull, True, "DA")
+                    self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, dxs, dxs.ld, dx, dx.ld,
+                              first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 0)
+                else:
+                    self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, dout, dout.ld, dx, dx.ld,
+                              first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 1)
+            elif kind == "up":
+                _, us, x, u, out = rec
+                dout = gview(out)
+                dx = gview(x)
+                du = conv_bwd(us.conv, u, dout, True, "DA") if us.use_conv else dout
+                self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, du, du.ld, dx, dx.ld,
+                          first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 2)
             elif kind == "stem":
                 _, conv, x, out = rec
                 dout = gview(out)

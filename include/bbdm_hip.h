@@ -55,9 +55,13 @@ int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int 
                               void* stream);
 /* out = conv_ks(x) + bias (+ residual).  ks in {1,3}; stride 1, padding ks/2 (F.conv2d semantics).
  * x: NHWC pitch ldx with CinPad channels; residual (may be NULL): NHWC pitch ldr, Cout channels, may alias out;
- * out: NHWC pitch ldo, or NCHW contiguous when out_nchw != 0.  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
+ * out: NHWC pitch ldo.  flags: BBDM_CONV_OUT_NCHW = write NCHW contiguous instead (the UNet head);
+ * BBDM_CONV_RES_PER_IMAGE = residual is [N][ldr], one row per image broadcast over its pixels (h + emb_out[..., None,
+ * None] of the use_scale_shift_norm=False ResBlock, openaimodel.py:275).  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
+#define BBDM_CONV_OUT_NCHW 1
+#define BBDM_CONV_RES_PER_IMAGE 2
 int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
-                         const float* residual, int ldr, float* out, int ldo, int out_nchw,
+                         const float* residual, int ldr, float* out, int ldo, int flags,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
 /* ---- convolution backward (training: autograd of the call sites above; the reference uses ATen's) -------- */
@@ -76,6 +80,10 @@ int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float
                         int N, int H, int W, int Cin, int Cout, int ks, void* stream);
 /* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: fp64[C] scratch. */
 int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream);
+/* Per-image column sums out[n*ldo + c] = sum_{m < M} dy[(n*M + m)*ld + c] (gradient of a per-image broadcast add).
+ * acc: fp64[N*C] scratch. */
+int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, float* out, int ldo, int N, long long M, int C,
+                            void* stream);
 
 /* ---- GroupNorm (util.py:199-216; sites openaimodel.py:205,229,306,688) -------------------------------- */
 /* Accumulate per-(n, group) sum and sum-of-squares of x into stats[N][G][2] (fp64, must be zeroed by the
@@ -85,7 +93,8 @@ int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int 
  *   GroupNorm32 -> [FiLM: openaimodel.py:270-273] -> SiLU -> [avg-pool 2x2 :159 | nearest x2 :118].
  * stats: as produced above (may be NULL with gamma == NULL: pure resample of x, the x_upd path :263).
  * film: [N][film_ld] with scale at [n][c] and shift at [n][C + c] (the emb_layers output :267-272), or NULL.
- * silu: 0/1.  resample: 0 none, 1 avg-pool 2x2 (H, W even), 2 nearest x2.  H, W are INPUT dims. */
+ * silu: 0/1.  resample: 0 none, 1 avg-pool 2x2 (H, W even), 2 nearest x2, 3 keep every second pixel (turns a stride-1
+ * conv output into the stride-2 conv of Downsample(use_conv=True), openaimodel.py:153-156).  H, W are INPUT dims. */
 int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
                              const float* film, int film_ld, float* y, int ldy, int N, int H, int W, int C, int G,
                              float eps, int silu, int resample, void* stream);

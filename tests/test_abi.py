@@ -58,8 +58,6 @@ def test_state_dict_layout_matches_reference_fixture():
     for name in CASES:
         rec = load_case(name)
         up = rec["unet_params"]
-        if not up.get("resblock_updown", True):
-            continue
         m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(rec["bb_params"], UNetParams=up)}}))
         ours = {k: tuple(v.shape) for k, v in m.state_dict().items()}
         ref = {k: tuple(v.shape) for k, v in rec["state_dict"].items()}

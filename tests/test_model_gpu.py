@@ -27,7 +27,7 @@ def build(rec, dev):
     return m.to(dev).eval()
 
 
-SUPPORTED = [c for c in CASES if c != "tiny_ysubx"]     # tiny_ysubx: resblock_updown=False / no FiLM (not yet)
+SUPPORTED = list(CASES)
 
 
 @pytest.fixture(scope="module")

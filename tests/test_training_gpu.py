@@ -11,7 +11,7 @@ from fixtures import load_case, oracle_model, rel_err
 
 pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-3          # per-parameter: max|g - g_ref| / max|g_ref|
-CASES = ("tiny_concat", "tiny_nocond")
+CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx")
 
 
 def _ns(c):
