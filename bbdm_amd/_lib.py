@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -22,7 +22,8 @@ SIGNATURES = {
     "bbdm_nhwc_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_conv_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_conv_pack_weight_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
-    "bbdm_conv2d_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int,
+    "bbdm_conv_splitk_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "bbdm_conv2d_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t,
                                      c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_conv_packed_dgrad_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "bbdm_conv_pack_weight_dgrad_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -39,6 +39,10 @@ struct ConvArgs {
     int TWl, THl, imgs;         // log2 of tile width / height; images per block (<= BM / (TH*TW))
     int PW, PH, patchPix;       // patch geometry (incl. halo), pixels per block patch
     int tilesX, tilesY, tilesN;
+    int splits, chunks_per_split;   // split-K over the Cin chunks (gridDim.y); partial sums go to ws
+    float* ws;                      // [splits][N*H*W][ldw]
+    size_t ws_cap;                  // capacity of ws in floats
+    int ldw;
 };
 
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC>
@@ -157,15 +161,18 @@ conv_igemm_f32(const ConvArgs a) {
     };
 
     // ---- prologue ------------------------------------------------------------------------------------
-    load_patch(0);
-    load_w(0);
-    store_patch(pbuf);
-    store_w(wbuf);
+    const int chunk_begin = blockIdx.y * a.chunks_per_split;
+    const int chunk_end = min(a.nchunks, chunk_begin + a.chunks_per_split);
+    const int phase_begin = chunk_begin * a.taps;
+    load_patch(chunk_begin);
+    load_w(phase_begin);
+    store_patch(pbuf + (chunk_begin & 1) * patchFloats);
+    store_w(wbuf + (phase_begin & 1) * (BN * KP));
     __syncthreads();
 
-    const int nphase = a.nchunks * a.taps;
-    int chunk = 0, tap = 0;
-    for (int phase = 0; phase < nphase; ++phase) {
+    const int nphase = chunk_end * a.taps;
+    int chunk = chunk_begin, tap = 0;
+    for (int phase = phase_begin; phase < nphase; ++phase) {
         const bool has_next = phase + 1 < nphase;
         const bool last_tap = tap == a.taps - 1;
         if (has_next) load_w(phase + 1);
@@ -216,6 +223,10 @@ conv_igemm_f32(const ConvArgs a) {
                 const int w = wbase + (m & (TW - 1));
                 if (cok && img_l < a.imgs && n < a.N && h < a.H && w < a.W) {
                     const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+                    if (a.splits > 1) {          // raw partial sum; bias / residual are applied by the reduce kernel
+                        a.ws[((size_t)blockIdx.y * a.N * a.H * a.W + pix) * a.ldw + co] = acc[mt][nt][r];
+                        continue;
+                    }
                     float v = acc[mt][nt][r] + bv;
                     if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co] : a.res[pix * a.ldr + co];
                     if (a.out_nchw & 1)
@@ -243,6 +254,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
         float v = 0.0f;
         if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * ks * ks + tap];
         p[i] = v;
+    }
+}
+
+// out = sum_s ws[s] + bias (+ residual): fixed summation order -> deterministic
+__global__ void conv_splitk_reduce_kernel(const ConvArgs a) {
+    const size_t M = (size_t)a.N * a.H * a.W;
+    const size_t total = M * a.Cout;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % a.Cout);
+        const size_t pix = i / a.Cout;
+        float v = 0.f;
+        for (int s = 0; s < a.splits; ++s) v += a.ws[((size_t)s * M + pix) * a.ldw + co];
+        if (a.bias) v += a.bias[co];
+        const size_t n = pix / ((size_t)a.H * a.W);
+        if (a.res) v += (a.out_nchw & 2) ? a.res[n * a.ldr + co] : a.res[pix * a.ldr + co];
+        if (a.out_nchw & 1) {
+            const size_t hw = pix - n * (size_t)a.H * a.W;
+            a.out[(n * a.Cout + co) * (size_t)a.H * a.W + hw] = v;
+        } else {
+            a.out[pix * a.ldo + co] = v;
+        }
     }
 }
 
@@ -288,7 +320,26 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
         lds_set = lds;
     }
     const long long blocks = (long long)a.tilesN * a.tilesX * a.tilesY * cdiv(a.N, IM);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WM * WN * 64), lds, stream, a);
+    // split-K: when the output tiles alone cannot fill the 256 CUs, spread the Cin chunks over gridDim.y
+    a.splits = 1;
+    a.chunks_per_split = a.nchunks;
+    if (a.ws && blocks < 256 && a.nchunks >= 4) {
+        int want = (int)cdiv(512, (int)blocks);
+        if (want > a.nchunks / 2) want = a.nchunks / 2;
+        if (want > 32) want = 32;
+        if ((size_t)want * a.N * a.H * a.W * a.ldw > a.ws_cap) want = (int)(a.ws_cap / ((size_t)a.N * a.H * a.W * a.ldw));
+        if (want > 1) {
+            a.chunks_per_split = cdiv(a.nchunks, want);
+            a.splits = cdiv(a.nchunks, a.chunks_per_split);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits), dim3(WM * WN * 64), lds, stream, a);
+    if (a.splits > 1) {
+        const size_t total = (size_t)a.N * a.H * a.W * a.Cout;
+        size_t rb = (total + 255) / 256;
+        if (rb > 4096) rb = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, a);
+    }
     return 0;
 }
 
@@ -316,9 +367,21 @@ extern "C" int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int
     return BBDM_OK;
 }
 
+extern "C" size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int CinPad, int Cout, int ks) {
+    // enough for 32 splits of a problem small enough to want them (< 256 output tiles of 128x128), else nothing
+    const long long M = (long long)N * H * W;
+    const long long blocks = ((M + 127) / 128) * cdiv(Cout, 128);
+    (void)ks;
+    if (blocks >= 256 || cdiv(CinPad, KC) < 4) return 0;
+    int want = (int)cdiv(512, (int)blocks);
+    if (want > cdiv(CinPad, KC) / 2) want = cdiv(CinPad, KC) / 2;
+    if (want > 32) want = 32;
+    return want > 1 ? (size_t)want * M * ((Cout + 3) & ~3) : 0;
+}
+
 extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
-                                    const float* residual, int ldr, float* out, int ldo, int out_nchw, int N, int H,
-                                    int W, int CinPad, int Cout, int ks, void* stream) {
+                                    const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
+                                    size_t ws_floats, int N, int H, int W, int CinPad, int Cout, int ks, void* stream) {
     BBDM_REQUIRE(x && packed_w && out, "conv2d: null pointer");
     BBDM_REQUIRE(ks == 1 || ks == 3, "conv2d: ks=%d unsupported (1 or 3)", ks);
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && CinPad > 0, "conv2d: bad shape");
@@ -335,6 +398,7 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     a.N = N; a.H = H; a.W = W; a.Cin = CinPad; a.Cout = Cout;
     a.CoutPad = cdiv(Cout, 128) * 128;
     a.taps = ks * ks; a.nchunks = cdiv(CinPad, KC); a.pad = ks / 2;
+    a.ws = ws; a.ws_cap = ws ? ws_floats : 0; a.ldw = (Cout + 3) & ~3;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     int rc;

@@ -64,17 +64,19 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Te
 
 def conv2d_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ks: int,
                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                out_nchw: bool = False) -> torch.Tensor:
+                out_nchw: bool = False, split_k: bool = True) -> torch.Tensor:
     """x: [N, H, W, CinPad] -> [N, H, W, cout] (or NCHW).  ``residual`` [N, H, W, cout] is added in the epilogue."""
     _chk(x, packed_w, bias, residual, out)
     N, H, W, cin_pad = x.shape
     if out is None:
         shape = (N, cout, H, W) if out_nchw else (N, H, W, cout)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    nws = _lib.load().bbdm_conv_splitk_workspace_floats(N, H, W, cin_pad, cout, ks) if split_k else 0
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     _lib.call("bbdm_conv2d_nhwc_f32", x.data_ptr(), cin_pad, packed_w.data_ptr(),
               None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
               0 if residual is None else residual.shape[-1], out.data_ptr(), 0 if out_nchw else out.shape[-1],
-              1 if out_nchw else 0, N, H, W, cin_pad, cout, ks, _st(x))
+              1 if out_nchw else 0, None if ws is None else ws.data_ptr(), nws, N, H, W, cin_pad, cout, ks, _st(x))
     return out
 
 

@@ -184,6 +184,16 @@ class _LateTensor:
         return self.t.data_ptr()
 
 
+class _LateInt:
+    __slots__ = ("v",)
+
+    def __init__(self):
+        self.v = 0
+
+    def resolve(self):
+        return self.v
+
+
 def _round4(c):
     return (c + 3) // 4 * 4
 
@@ -437,6 +447,9 @@ class _Plan:
         self._gn_count = 0
         self._params: List[nn.Parameter] = []
         self.lib = _lib.load()
+        self._conv_ws_need = 0
+        self._conv_ws = _LateTensor()             # split-K scratch shared by every conv of the plan
+        self._conv_ws_floats = _LateInt()
         mc = m.model_channels
         ted = 4 * mc
         f32 = dict(dtype=torch.float32, device=device)
@@ -527,12 +540,14 @@ class _Plan:
         a = self._gn_apply(h, m.out[0], None, silu=1, resample=0, name="A")
         pc = self._conv(m.out[2], a.C)
         self._op("bbdm_conv2d_nhwc_f32", a, a.ld, _TensorRef(pc.packed), self._pref(pc.bias), None, 0,
-                 _TensorRef(self.out_nchw), 0, 1, N, a.H, a.W, a.C, pc.cout, 3)
+                 _TensorRef(self.out_nchw), 0, 1, None, 0, N, a.H, a.W, a.C, pc.cout, 3)
         if training:
             self.tape.append(("head", m.out, h, a, head_stats))
             self._emit_backward(x0)
 
         # ---- allocate -----------------------------------------------------------------------------------------------
+        self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
+        self._conv_ws_floats.v = self._conv_ws_need
         for b in self.bufs:
             b.tensor = torch.empty(max(1, b.numel), **f32)
         self.stats = torch.zeros(max(1, self._gn_count) * N * self.GROUPS * 2, dtype=torch.float64, device=device)
@@ -544,7 +559,7 @@ class _Plan:
     def _algorithmic_flops(name, args):
         """2*MACs of the contraction an op performs (conv / linear / attention matmuls only)."""
         if name == "bbdm_conv2d_nhwc_f32":
-            N, H, W, cin_pad, cout, ks = args[9:15]
+            N, H, W, cin_pad, cout, ks = args[11:17]
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
             return 2.0 * N * H * W * cout * cin * ks * ks
         if name == "bbdm_attention_f32":
@@ -624,8 +639,10 @@ class _Plan:
         if res_ld is None:
             assert residual is None or residual.C == pc.cout
             res_ld = residual.ld if residual is not None else 0
+        self._conv_ws_need = max(self._conv_ws_need,
+                                 self.lib.bbdm_conv_splitk_workspace_floats(self.N, x.H, x.W, x.C, pc.cout, pc.ks))
         self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias), residual, res_ld,
-                 dest, dest.ld, flags, self.N, x.H, x.W, x.C, pc.cout, pc.ks)
+                 dest, dest.ld, flags, self._conv_ws, self._conv_ws_floats, self.N, x.H, x.W, x.C, pc.cout, pc.ks)
 
     def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
         """ResBlock._forward (openaimodel.py:258-278)."""
@@ -804,8 +821,10 @@ class _Plan:
             pk = _PackedDgrad(w, dy.C)
             self.dconvs.append(pk)
             dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
-            self._bop("bbdm_conv2d_nhwc_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, 0, N, x_in.H,
-                      x_in.W, dy.C, x_in.C, ks)
+            self._conv_ws_need = max(self._conv_ws_need,
+                                     lib.bbdm_conv_splitk_workspace_floats(N, x_in.H, x_in.W, dy.C, x_in.C, ks))
+            self._bop("bbdm_conv2d_nhwc_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, 0,
+                      self._conv_ws, self._conv_ws_floats, N, x_in.H, x_in.W, dy.C, x_in.C, ks)
             return dx
 
         def gn_bwd(gn, x: _View, slot, film_off, da: _View, dadd: Optional[_View], silu, rs, dx: _View, acc: int):
@@ -901,7 +920,7 @@ class _Plan:
                 self.dconvs.append(pk)
                 self.dx0 = self._tmp("DX0", N, x.H, x.W, x.C)
                 self._bop("bbdm_conv2d_nhwc_f32", dout, dout.ld, _TensorRef(pk.packed), None, None, 0, self.dx0,
-                          self.dx0.ld, 0, N, x.H, x.W, dout.C, x.C, 3)
+                          self.dx0.ld, 0, None, 0, N, x.H, x.W, dout.C, x.C, 3)
                 self.bops_x0, self.bops = self.bops, main
         self._ws_f.t = torch.empty(ws_floats[0], **f32)
         self._ws_d.t = torch.empty(colsum_c[0], dtype=torch.float64, device=dev)

@@ -202,7 +202,7 @@ def main():
                 name, ms, fl = agg[k]
                 oargs = plan.ops[k][1]
                 if name == "bbdm_conv2d_nhwc_f32":
-                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[9:15])
+                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[11:17])
                 elif name == "bbdm_attention_f32":
                     shp = "N{} T{} heads{} ch{}".format(*oargs[5:9])
                 elif name == "bbdm_groupnorm_apply_f32":

@@ -60,8 +60,13 @@ int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int 
  * None] of the use_scale_shift_norm=False ResBlock, openaimodel.py:275).  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
 #define BBDM_CONV_OUT_NCHW 1
 #define BBDM_CONV_RES_PER_IMAGE 2
+/* ws (may be NULL) / ws_floats: scratch for split-K.  When the output tiles alone cannot fill the 256 CUs (small
+ * latents: LBBDM-f16 runs the 1024-channel layers on 4x4 images) the Cin reduction is spread over extra workgroups
+ * whose partial sums are added in a fixed order by a second kernel (deterministic).  Size it with
+ * bbdm_conv_splitk_workspace_floats() (0 = this shape never splits). */
+size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int CinPad, int Cout, int ks);
 int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
-                         const float* residual, int ldr, float* out, int ldo, int flags,
+                         const float* residual, int ldr, float* out, int ldo, int flags, float* ws, size_t ws_floats,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
 /* ---- convolution backward (training: autograd of the call sites above; the reference uses ATen's) -------- */

@@ -45,6 +45,9 @@ CONV_CASES = [
     (3, 2, 2, 64, 64, 3, True),          # 2x2 images: images-per-block capped by the patch slots
     (70, 1, 1, 32, 32, 3, False),        # 1x1 images
     (40, 4, 4, 128, 1024, 3, False),     # 4x4 latents (LBBDM-f16 bottom level)
+    (32, 4, 4, 1024, 1024, 3, True),     # split-K: 32 output tiles, 64 chunks
+    (4, 16, 16, 2048, 512, 1, True),     # split-K on a 1x1
+    (2, 8, 8, 640, 96, 3, False),        # split-K with ragged Cout
 ]
 
 
@@ -89,7 +92,7 @@ def test_conv2d_channel_slices(dev):
     st = torch.cuda.current_stream().cuda_stream
     bg = b.to(dev)
     _lib.call("bbdm_conv2d_nhwc_f32", wide_in.data_ptr() + 4 * 48, 80, pw.data_ptr(), bg.data_ptr(), None, 0,
-              wide_out.data_ptr() + 4 * 64, 320, 0, N, H, W, Cin, Cout, 3, st)
+              wide_out.data_ptr() + 4 * 64, 320, 0, None, 0, N, H, W, Cin, Cout, 3, st)
     torch.cuda.synchronize()
     ref = F.conv2d(_nchw(wide_in.cpu()[..., 48:80]), w, b, padding=1)
     got = wide_out.cpu()

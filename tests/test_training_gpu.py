@@ -56,13 +56,13 @@ def test_loss_and_all_parameter_gradients(dev, name):
     torch.cuda.synchronize()
     assert abs(float(loss) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
     # A conv bias that feeds a GroupNorm has a (mathematically) ~zero gradient: its reference value is rounding noise.
-    # Errors are therefore measured against max(|g_ref|_max, 1e-4 * largest gradient magnitude in the model).
+    # Errors are therefore measured against max(|g_ref|_max, 1e-3 * largest gradient magnitude in the model).
     gmax = max(float(v.abs().max()) for v in g_ref.values())
     errs = []
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         ref = g_ref[k]
-        scale = max(float(ref.abs().max()), 1e-4 * gmax)
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
         errs.append((float((p.grad.cpu() - ref).abs().max()) / scale, k, float(ref.abs().max())))
     errs.sort(reverse=True)
     print(f"{name}: loss {float(loss):.6f} (ref {loss_ref:.6f}); gmax {gmax:.3e}; worst: " +
