@@ -353,6 +353,7 @@ class UNetModel(nn.Module):
         self._plans: Dict[tuple, "_Plan"] = {}
         self._freqs: Optional[torch.Tensor] = None
         self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
+        self.hip_graph: Optional[bool] = None       # None = automatic (small latents), True / False = force
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -553,6 +554,7 @@ class _Plan:
         self.stats = torch.zeros(max(1, self._gn_count) * N * self.GROUPS * 2, dtype=torch.float64, device=device)
         self._param_key = None
         self._bound: List[tuple] = []
+        self._graph, self._graph_key = None, None
         self.op_flops = [self._algorithmic_flops(name, args) for name, args in self.ops]
 
     @staticmethod
@@ -1021,15 +1023,9 @@ class _Plan:
                 off += n
             self._film_key = fkey
 
-    def run(self, x, t, ctx, out=None):
+    def _launch_forward(self, stream, prof=None):
+        """Enqueue one forward (statistics reset, embedding path, the op list) on ``stream``."""
         m, N = self.m, self.N
-        self.generation = getattr(self, "generation", 0) + 1
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self._refresh_weights(stream)
-        self.x_in.copy_(x)
-        if self.ctx_in is not None:
-            self.ctx_in.copy_(ctx)
-        self.t_buf.copy_(t)
         self.stats.zero_()
         mc, ted = m.model_channels, 4 * m.model_channels
         call = _lib.call
@@ -1047,7 +1043,6 @@ class _Plan:
                  self.film_b.data_ptr(), self.film.data_ptr() + 4 * r0 * self.film_total, r, ted, self.film_total,
                  1, 0, stream)
         check = _lib.check
-        prof = m.op_profile
         if prof is None:
             for fn, args in self._bound:
                 rc = fn(*args, stream)
@@ -1063,6 +1058,38 @@ class _Plan:
                 if rc != 0:
                     check(rc, fn.__name__)
                 prof.append((fn.__name__, e0, e1, fl))
+
+    def _want_graph(self) -> bool:
+        """hipGraph replay of the ~200-launch forward pays only when the launches are short (small latents); at the
+        256^2 pixel config one launch is milliseconds.  ``UNetModel.hip_graph`` = True / False overrides."""
+        pref = self.m.hip_graph
+        if pref is not None:
+            return bool(pref)
+        return not self.training and self.N * self.H * self.W <= 32 * 64 * 64
+
+    def run(self, x, t, ctx, out=None):
+        m = self.m
+        self.generation = getattr(self, "generation", 0) + 1
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self._refresh_weights(stream)
+        self.x_in.copy_(x)
+        if self.ctx_in is not None:
+            self.ctx_in.copy_(ctx)
+        self.t_buf.copy_(t)
+        prof = m.op_profile
+        if prof is None and self._want_graph():
+            # weights / parameter pointers are checked above on every call; a change re-captures
+            gkey = (self._param_key,) + tuple(p.data_ptr() for p in m.time_embed.parameters())
+            if self._graph is None or self._graph_key != gkey:
+                self._launch_forward(stream)                     # eager warm-up (sets kernel attributes, fills caches)
+                torch.cuda.current_stream(self.device).synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch_forward(torch.cuda.current_stream(self.device).cuda_stream)
+                self._graph, self._graph_key = g, gkey
+            self._graph.replay()
+        else:
+            self._launch_forward(stream, prof)
         if out is None:
             return self.out_nchw.clone()
         out.copy_(self.out_nchw)
