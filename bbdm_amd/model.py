@@ -281,14 +281,15 @@ class LatentBrownianBridgeModel(BrownianBridgeModel):
 
     Only the wrapper API lives here (constructor, ``forward``, ``encode``/``decode``, ``sample``, the externally
     assigned ``ori_latent_mean/std`` and ``cond_latent_mean/std`` attributes -- BBDMRunner.py:41-44).  The first stage
-    is any module exposing ``encoder / quant_conv / quantize / decode`` (the reference ``VQModel``); pass one as
-    ``vqgan=`` or let it be built from ``model_config.VQGAN.params``.
+    is any module exposing ``encoder / quant_conv / quantize / decode``: by default ``bbdm_amd.first_stage.VQModel``
+    built from ``model_config.VQGAN.params`` (plain PyTorch-ROCm, loads the reference's VQGAN checkpoints), or whatever
+    is passed as ``vqgan=`` (e.g. the checkout's own ``model.VQGAN.vqgan.VQModel``).
     """
 
     def __init__(self, model_config, vqgan: nn.Module = None):
         super().__init__(model_config)
         if vqgan is None:
-            VQModel = _reference_class("model.VQGAN.vqgan", "VQModel", "LatentBrownianBridgeModel")
+            from .first_stage import VQModel       # PyTorch-ROCm first stage, state_dict-compatible with the reference's
             vqgan = VQModel(**vars(model_config.VQGAN.params))
         self.vqgan = vqgan.eval()
         self.vqgan.train = disabled_train

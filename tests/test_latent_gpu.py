@@ -89,3 +89,30 @@ def test_latent_wrapper_sample_and_train(normalize):
     loss.backward()
     assert all(p.grad is not None for p in m.denoise_fn.parameters())
     assert all(p.grad is None for p in m.vqgan.parameters())
+
+
+def test_latent_with_builtin_first_stage():
+    """No ``vqgan=``: the first stage is built from ``model_config.VQGAN.params`` by bbdm_amd.first_stage.VQModel
+    (same schema as configs/Template-LBBDM-f4.yaml, shrunk)."""
+    import bbdm_amd
+    dev = torch.device("cuda:0")
+    rec = load_case("tiny_nocond")
+    dd = dict(double_z=False, z_channels=8, resolution=32, in_channels=3, out_ch=3, ch=32, ch_mult=(1, 2, 2),
+              num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+    cfg = _ns({"BB": {"params": dict(rec["bb_params"], UNetParams=rec["unet_params"])},
+               "VQGAN": {"params": {"ckpt_path": None, "embed_dim": 8, "n_embed": 128, "ddconfig": dd,
+                                    "lossconfig": {"target": "torch.nn.Identity"}}},
+               "normalize_latent": False, "latent_before_quant_conv": False})
+    torch.manual_seed(4)
+    m = bbdm_amd.LatentBrownianBridgeModel(cfg).to(dev)
+    m.denoise_fn.load_state_dict({k[len("denoise_fn."):]: v for k, v in rec["state_dict"].items()
+                                  if k.startswith("denoise_fn.")})
+    assert any(k.startswith("vqgan.encoder.down.0.block.0.norm1") for k in m.state_dict())
+    x_cond = torch.randn(2, 3, 32, 32).clamp(-1, 1).to(dev)
+    assert m.encode(x_cond).shape == (2, 8, 8, 8)
+    out = m.sample(x_cond, clip_denoised=False)
+    assert out.shape == (2, 3, 32, 32) and bool(torch.isfinite(out).all())
+    m.train()
+    loss, _ = m(x_cond, x_cond.flip(0))
+    loss.backward()
+    assert all(p.grad is not None for p in m.get_parameters())
