@@ -43,6 +43,11 @@ struct ConvArgs {
     float* ws;                      // [splits][N*H*W][ldw]
     size_t ws_cap;                  // capacity of ws in floats
     int ldw;
+    // optional fused producer: x is replaced by act(x * pre_sc[n][c] + pre_bi[n][c]) while it is staged (the
+    // GroupNorm affine [+ FiLM] [+ SiLU] of the reference, with per-image coefficients from bbdm_groupnorm_coeffs_f32)
+    const float* pre_sc;
+    const float* pre_bi;
+    int pre_ld, pre_silu;
 };
 
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC>
@@ -80,6 +85,7 @@ conv_igemm_f32(const ConvArgs a) {
     // ---- per-thread patch staging slots (same pixels for every chunk) ---------------------------------
     uint32_t goff[PSLOTS];
     uint32_t pvalid = 0;
+    uint32_t pimg = 0;                 // 5 bits per slot: image (relative to img0) the slot's pixel belongs to
     const int nPatchVec = a.patchPix * (KC / 4);
 #pragma unroll
     for (int s = 0; s < PSLOTS; ++s) {
@@ -94,6 +100,7 @@ conv_igemm_f32(const ConvArgs a) {
             if (n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W) {
                 goff[s] = (uint32_t)(((n * a.H + h) * a.W + w)) * (uint32_t)a.ldx + c4 * 4;
                 pvalid |= 1u << s;
+                pimg |= (uint32_t)(img_l & 31) << (5 * s);
             }
         }
     }
@@ -138,7 +145,24 @@ conv_igemm_f32(const ConvArgs a) {
                 preg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_patch = [&](float* dst) {
+    auto store_patch = [&](float* dst, int chunk) {
+        if (a.pre_sc) {
+            // fused GroupNorm affine (+ FiLM) (+ SiLU) on the valid elements; padding stays exactly zero
+            const int cbase = chunk * KC;
+#pragma unroll
+            for (int s = 0; s < PSLOTS; ++s) {
+                const int c = cbase + ((tid + s * NTHR) & 3) * 4;
+                if (((pvalid >> s) & 1u) && c < a.Cin) {
+                    const size_t o = (size_t)(img0 + ((pimg >> (5 * s)) & 31u)) * a.pre_ld + c;
+                    const float4 sc = *reinterpret_cast<const float4*>(a.pre_sc + o);
+                    const float4 bi = *reinterpret_cast<const float4*>(a.pre_bi + o);
+                    float4 v = preg[s];
+                    v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+                    if (a.pre_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    preg[s] = v;
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < PSLOTS; ++s) {
             const int f = tid + s * NTHR;
@@ -166,7 +190,7 @@ conv_igemm_f32(const ConvArgs a) {
     const int phase_begin = chunk_begin * a.taps;
     load_patch(chunk_begin);
     load_w(phase_begin);
-    store_patch(pbuf + (chunk_begin & 1) * patchFloats);
+    store_patch(pbuf + (chunk_begin & 1) * patchFloats, chunk_begin);
     store_w(wbuf + (phase_begin & 1) * (BN * KP));
     __syncthreads();
 
@@ -200,7 +224,7 @@ conv_igemm_f32(const ConvArgs a) {
         }
 
         if (has_next) store_w(wbuf + ((phase + 1) & 1) * (BN * KP));
-        if (last_tap && has_next) store_patch(pbuf + ((chunk + 1) & 1) * patchFloats);
+        if (last_tap && has_next) store_patch(pbuf + ((chunk + 1) & 1) * patchFloats, chunk + 1);
         __syncthreads();
         if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
     }
@@ -298,7 +322,8 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
     a.PH = THc + 2 * a.pad;
     // tiny images: cap the images per block so that the halo patch fits the staging slots (the remaining rows of
     // the M tile are padding)
-    const int maxIm = (PSLOTS * WM * WN * 64 / (KC / 4)) / (a.PW * a.PH);
+    int maxIm = (PSLOTS * WM * WN * 64 / (KC / 4)) / (a.PW * a.PH);
+    if (maxIm > 32) maxIm = 32;          // the per-slot image index is kept in 5 bits
     if (IM > maxIm) IM = maxIm;
     if (IM > a.N) IM = a.N;
     if (IM < 1) return 1;
@@ -381,7 +406,8 @@ extern "C" size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int Cin
 
 extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
                                     const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
-                                    size_t ws_floats, int N, int H, int W, int CinPad, int Cout, int ks, void* stream) {
+                                    size_t ws_floats, const float* pre_scale, const float* pre_bias, int pre_ld,
+                                    int pre_silu, int N, int H, int W, int CinPad, int Cout, int ks, void* stream) {
     BBDM_REQUIRE(x && packed_w && out, "conv2d: null pointer");
     BBDM_REQUIRE(ks == 1 || ks == 3, "conv2d: ks=%d unsupported (1 or 3)", ks);
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && CinPad > 0, "conv2d: bad shape");
@@ -399,6 +425,10 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     a.CoutPad = cdiv(Cout, 128) * 128;
     a.taps = ks * ks; a.nchunks = cdiv(CinPad, KC); a.pad = ks / 2;
     a.ws = ws; a.ws_cap = ws ? ws_floats : 0; a.ldw = (Cout + 3) & ~3;
+    BBDM_REQUIRE((pre_scale == nullptr) == (pre_bias == nullptr), "conv2d: pre_scale / pre_bias must come together");
+    BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
+                 "conv2d: pre_ld / alignment of the fused-producer coefficients");
+    a.pre_sc = pre_scale; a.pre_bi = pre_bias; a.pre_ld = pre_ld; a.pre_silu = pre_silu;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     int rc;

@@ -212,7 +212,46 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
     }
 }
 
+// Per-image, per-channel coefficients of the fused apply:  GN(x)[*(1+scale)+shift] == x * sc[n][c] + bi[n][c].
+// Same expressions (and therefore the same roundings) as gn_apply_kernel.
+__global__ void gn_coeffs_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, const float* __restrict__ film, int film_ld,
+                                 float* __restrict__ sc_out, float* __restrict__ bi_out, int ld, int N, int HW, int C, int G,
+                                 float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const int cpg = C / G, g = c / cpg;
+    const double cnt = (double)HW * cpg;
+    const double s = stats[((size_t)n * G + g) * 2], ss = stats[((size_t)n * G + g) * 2 + 1];
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float fmean = (float)mean;
+    float sc = rstd * gamma[c];
+    float bi = beta[c] - fmean * sc;
+    if (film) {
+        const float fs = film[(size_t)n * film_ld + c], fb = film[(size_t)n * film_ld + C + c];
+        sc = sc * (1.f + fs);
+        bi = bi * (1.f + fs) + fb;
+    }
+    sc_out[(size_t)n * ld + c] = sc;
+    bi_out[(size_t)n * ld + c] = bi;
+}
+
 }  // namespace
+
+extern "C" int bbdm_groupnorm_coeffs_f32(const double* stats, const float* gamma, const float* beta, const float* film,
+                                         int film_ld, float* scale_out, float* bias_out, int ld, int N, int HW, int C, int G,
+                                         float eps, void* stream) {
+    BBDM_REQUIRE(stats && gamma && beta && scale_out && bias_out, "gn_coeffs: null pointer");
+    BBDM_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && ld >= C, "gn_coeffs: bad shape");
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, film,
+                       film_ld, scale_out, bias_out, ld, N, HW, C, G, eps);
+    BBDM_CHECK_LAUNCH("gn_coeffs");
+    return BBDM_OK;
+}
 
 extern "C" int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int HW, int C, int G,
                                         void* stream) {

@@ -64,7 +64,8 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Te
 
 def conv2d_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int, ks: int,
                 residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                out_nchw: bool = False, split_k: bool = True) -> torch.Tensor:
+                out_nchw: bool = False, split_k: bool = True, pre_scale: Optional[torch.Tensor] = None,
+                pre_bias: Optional[torch.Tensor] = None, pre_silu: bool = False) -> torch.Tensor:
     """x: [N, H, W, CinPad] -> [N, H, W, cout] (or NCHW).  ``residual`` [N, H, W, cout] is added in the epilogue."""
     _chk(x, packed_w, bias, residual, out)
     N, H, W, cin_pad = x.shape
@@ -76,8 +77,23 @@ def conv2d_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
     _lib.call("bbdm_conv2d_nhwc_f32", x.data_ptr(), cin_pad, packed_w.data_ptr(),
               None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
               0 if residual is None else residual.shape[-1], out.data_ptr(), 0 if out_nchw else out.shape[-1],
-              1 if out_nchw else 0, None if ws is None else ws.data_ptr(), nws, N, H, W, cin_pad, cout, ks, _st(x))
+              1 if out_nchw else 0, None if ws is None else ws.data_ptr(), nws,
+              None if pre_scale is None else pre_scale.data_ptr(), None if pre_bias is None else pre_bias.data_ptr(),
+              0 if pre_scale is None else pre_scale.shape[-1], 1 if pre_silu else 0, N, H, W, cin_pad, cout, ks, _st(x))
     return out
+
+
+def groupnorm_coeffs(stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, hw: int,
+                     film: Optional[torch.Tensor] = None, eps: float = 1e-5, groups: int = 32):
+    """(scale, bias) [N, C] such that GN(x)[*(1+fs)+fb] == x * scale + bias per image and channel."""
+    _chk(stats, gamma, beta, film)
+    N, C = stats.shape[0], gamma.shape[0]
+    sc = torch.empty(N, C, dtype=torch.float32, device=gamma.device)
+    bi = torch.empty(N, C, dtype=torch.float32, device=gamma.device)
+    _lib.call("bbdm_groupnorm_coeffs_f32", stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+              None if film is None else film.data_ptr(), 0 if film is None else film.shape[1], sc.data_ptr(), bi.data_ptr(),
+              C, N, hw, C, groups, float(eps), _st(gamma))
+    return sc, bi
 
 
 def groupnorm_stats(x: torch.Tensor, groups: int = 32) -> torch.Tensor:

@@ -155,7 +155,8 @@ class _TensorRef:
         self.t, self.byte_off = t, byte_off
 
     def resolve(self):
-        return self.t.data_ptr() + self.byte_off
+        t = self.t.t if isinstance(self.t, _LateTensor) else self.t
+        return t.data_ptr() + self.byte_off
 
 
 class _ParamRef:
@@ -354,6 +355,10 @@ class UNetModel(nn.Module):
         self._freqs: Optional[torch.Tensor] = None
         self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
         self.hip_graph: Optional[bool] = None       # None = automatic (small latents), True / False = force
+        # Fold GroupNorm/FiLM/SiLU into the consuming conv's LDS staging (inference).  Measured on MI355X it trades a
+        # 2.5 % streaming pass for ~5 % more time in the MFMA-bound conv at 256^2 (VALU + coefficient loads on the
+        # staging path), so it is off by default; kept for the small-latent regime and as a tested kernel feature.
+        self.fuse_groupnorm: bool = False
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -448,6 +453,8 @@ class _Plan:
         self._gn_count = 0
         self._params: List[nn.Parameter] = []
         self.lib = _lib.load()
+        self._n_coeffs, self._coeff_need = 0, 1
+        self._coeff_bufs = [(_LateTensor(), _LateTensor()), (_LateTensor(), _LateTensor())]
         self._conv_ws_need = 0
         self._conv_ws = _LateTensor()             # split-K scratch shared by every conv of the plan
         self._conv_ws_floats = _LateInt()
@@ -538,15 +545,18 @@ class _Plan:
             h = self._emit_block(blk, cb, dest)
         # head: GN -> SiLU -> conv3x3 -> NCHW  (openaimodel.py:687-691,759)
         head_stats = self._gn_count
-        a = self._gn_apply(h, m.out[0], None, silu=1, resample=0, name="A")
+        a, pre = self._gn_input(h, m.out[0], None, silu=1, name="A")
         pc = self._conv(m.out[2], a.C)
         self._op("bbdm_conv2d_nhwc_f32", a, a.ld, _TensorRef(pc.packed), self._pref(pc.bias), None, 0,
-                 _TensorRef(self.out_nchw), 0, 1, None, 0, N, a.H, a.W, a.C, pc.cout, 3)
+                 _TensorRef(self.out_nchw), 0, 1, None, 0, *pre, N, a.H, a.W, a.C, pc.cout, 3)
         if training:
             self.tape.append(("head", m.out, h, a, head_stats))
             self._emit_backward(x0)
 
         # ---- allocate -----------------------------------------------------------------------------------------------
+        for pair in self._coeff_bufs:
+            for lt in pair:
+                lt.t = torch.empty(self._coeff_need, **f32)
         self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
         self._conv_ws_floats.v = self._conv_ws_need
         for b in self.bufs:
@@ -561,7 +571,7 @@ class _Plan:
     def _algorithmic_flops(name, args):
         """2*MACs of the contraction an op performs (conv / linear / attention matmuls only)."""
         if name == "bbdm_conv2d_nhwc_f32":
-            N, H, W, cin_pad, cout, ks = args[11:17]
+            N, H, W, cin_pad, cout, ks = args[15:21]
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
             return 2.0 * N * H * W * cout * cin * ks * ks
         if name == "bbdm_attention_f32":
@@ -634,7 +644,32 @@ class _Plan:
                      x.C, 1, 0.0, 0, resample)
         return y
 
-    def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0):
+    NO_PRE = (None, None, 0, 0)
+
+    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str):
+        """Input of a conv that follows GroupNorm [-> FiLM] [-> SiLU] at the same resolution.
+
+        Inference plans do not materialise the normalised tensor: they emit the statistics + a tiny per-(image, channel)
+        coefficient kernel and return (x itself, the fused-producer arguments of bbdm_conv2d_nhwc_f32).  Training plans
+        keep the explicit apply pass (the backward re-reads its output for the weight gradient)."""
+        if self.training or not self.m.fuse_groupnorm:
+            return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
+        N = self.N
+        ref = _Plan._StatsRef(self, self._gn_count)
+        self._gn_count += 1
+        self._op("bbdm_groupnorm_stats_f32", x, x.ld, ref, N, x.H * x.W, x.C, self.GROUPS)
+        k = self._n_coeffs
+        self._n_coeffs += 1
+        self._coeff_need = max(self._coeff_need, N * x.C)
+        sc = _TensorRef(self._coeff_bufs[k % 2][0])
+        bi = _TensorRef(self._coeff_bufs[k % 2][1])
+        film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
+        self._op("bbdm_groupnorm_coeffs_f32", ref, self._pref(gn.weight), self._pref(gn.bias), film, self.film_total, sc, bi,
+                 x.C, N, x.H * x.W, x.C, self.GROUPS, float(gn.eps))
+        return x, (sc, bi, x.C, silu)
+
+    def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0,
+                   pre=None):
         """``residual`` is an NHWC view, or (with flags & 2) a per-image [N][res_ld] tensor reference."""
         pc = self._conv(mod, x.C)
         assert dest.C == pc.cout, (dest.C, pc.cout)
@@ -644,7 +679,8 @@ class _Plan:
         self._conv_ws_need = max(self._conv_ws_need,
                                  self.lib.bbdm_conv_splitk_workspace_floats(self.N, x.H, x.W, x.C, pc.cout, pc.ks))
         self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias), residual, res_ld,
-                 dest, dest.ld, flags, self._conv_ws, self._conv_ws_floats, self.N, x.H, x.W, x.C, pc.cout, pc.ks)
+                 dest, dest.ld, flags, self._conv_ws, self._conv_ws_floats, *(pre or self.NO_PRE), self.N, x.H, x.W, x.C,
+                 pc.cout, pc.ks)
 
     def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
         """ResBlock._forward (openaimodel.py:258-278)."""
@@ -652,23 +688,25 @@ class _Plan:
         film = rb.use_scale_shift_norm
         rs = 2 if rb.up else (1 if rb.down else 0)
         s1 = self._gn_count
-        a = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A")
+        if rs == 0:
+            a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A")
+        else:       # up / down blocks resample between the activation and the conv: explicit apply pass
+            a, pre1 = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A"), None
         xr = x if rs == 0 else self._gn_apply(x, None, None, 0, rs, name="XR")
         h1 = self._tmp("H1", N, a.H, a.W, rb.out_channels)
         if film:
-            self._emit_conv(a, rb.in_layers[2], None, h1)
+            self._emit_conv(a, rb.in_layers[2], None, h1, pre=pre1)
         else:       # h = h + emb_out[..., None, None] (openaimodel.py:275): per-image row added in the conv epilogue
             self._emit_conv(a, rb.in_layers[2], _TensorRef(self.film, 4 * self.film_off[id(rb)]), h1,
-                            res_ld=self.film_total, flags=2)
+                            res_ld=self.film_total, flags=2, pre=pre1)
         s2 = self._gn_count
-        a2 = self._gn_apply(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, resample=0,
-                            name="A2")
+        a2, pre2 = self._gn_input(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, name="A2")
         out = dest if dest is not None else self._new(N, a.H, a.W, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
             self._emit_conv(xr, rb.skip_connection, None, out)
-            self._emit_conv(a2, rb.out_layers[3], out, out)
+            self._emit_conv(a2, rb.out_layers[3], out, out, pre=pre2)
         else:
-            self._emit_conv(a2, rb.out_layers[3], xr, out)
+            self._emit_conv(a2, rb.out_layers[3], xr, out, pre=pre2)
         if self.training:
             self.tape.append(("res", rb, x, a, xr, h1, a2, out, s1, s2, rs))
         return out
@@ -678,9 +716,9 @@ class _Plan:
         N, T, C = self.N, x.H * x.W, x.C
         ch = C // ab.num_heads
         s0 = self._gn_count
-        a = self._gn_apply(x, ab.norm, None, silu=0, resample=0, name="A")
+        a, pre = self._gn_input(x, ab.norm, None, silu=0, name="A")
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
-        self._emit_conv(a, ab.qkv, None, qkv)
+        self._emit_conv(a, ab.qkv, None, qkv, pre=pre)
         at = self._tmp("AT", N, x.H, x.W, C)
         lse = None
         if self.training:
@@ -826,7 +864,7 @@ class _Plan:
             self._conv_ws_need = max(self._conv_ws_need,
                                      lib.bbdm_conv_splitk_workspace_floats(N, x_in.H, x_in.W, dy.C, x_in.C, ks))
             self._bop("bbdm_conv2d_nhwc_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, 0,
-                      self._conv_ws, self._conv_ws_floats, N, x_in.H, x_in.W, dy.C, x_in.C, ks)
+                      self._conv_ws, self._conv_ws_floats, None, None, 0, 0, N, x_in.H, x_in.W, dy.C, x_in.C, ks)
             return dx
 
         def gn_bwd(gn, x: _View, slot, film_off, da: _View, dadd: Optional[_View], silu, rs, dx: _View, acc: int):
@@ -922,7 +960,7 @@ class _Plan:
                 self.dconvs.append(pk)
                 self.dx0 = self._tmp("DX0", N, x.H, x.W, x.C)
                 self._bop("bbdm_conv2d_nhwc_f32", dout, dout.ld, _TensorRef(pk.packed), None, None, 0, self.dx0,
-                          self.dx0.ld, 0, None, 0, N, x.H, x.W, dout.C, x.C, 3)
+                          self.dx0.ld, 0, None, 0, None, None, 0, 0, N, x.H, x.W, dout.C, x.C, 3)
                 self.bops_x0, self.bops = self.bops, main
         self._ws_f.t = torch.empty(ws_floats[0], **f32)
         self._ws_d.t = torch.empty(colsum_c[0], dtype=torch.float64, device=dev)

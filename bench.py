@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
+    ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
     args = ap.parse_args()
 
     import bbdm_amd
@@ -134,6 +135,7 @@ def main():
     model = bbdm_amd.BrownianBridgeModel(cfg)
     sd = synth_state(model.denoise_fn)
     model.denoise_fn.load_state_dict(sd, strict=True)
+    model.denoise_fn.fuse_groupnorm = bool(args.fuse_gn)
     model = model.to(dev).eval()
     nparams = sum(p.numel() for p in model.denoise_fn.parameters())
 
@@ -210,7 +212,7 @@ def main():
                 name, ms, fl = agg[k]
                 oargs = plan.ops[k][1]
                 if name == "bbdm_conv2d_nhwc_f32":
-                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[11:17])
+                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[15:21])
                 elif name == "bbdm_attention_f32":
                     shp = "N{} T{} heads{} ch{}".format(*oargs[5:9])
                 elif name == "bbdm_groupnorm_apply_f32":

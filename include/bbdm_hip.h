@@ -65,8 +65,14 @@ int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int 
  * whose partial sums are added in a fixed order by a second kernel (deterministic).  Size it with
  * bbdm_conv_splitk_workspace_floats() (0 = this shape never splits). */
 size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int CinPad, int Cout, int ks);
+/* pre_scale / pre_bias (both NULL or both set): fp32 [N][pre_ld] per-image, per-input-channel coefficients of a fused
+ * producer: the kernel convolves act(x * pre_scale[n][c] + pre_bias[n][c]) (act = SiLU when pre_silu) instead of x,
+ * applying the transform while the input patch is staged into LDS.  With the coefficients from
+ * bbdm_groupnorm_coeffs_f32 this is GroupNorm32 -> [FiLM] -> [SiLU] -> conv (openaimodel.py:205-207,229-233,306-307,
+ * 688-690) without writing the normalised tensor to HBM; zero padding applies to the activated tensor, as in F.conv2d. */
 int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
                          const float* residual, int ldr, float* out, int ldo, int flags, float* ws, size_t ws_floats,
+                         const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
 /* ---- convolution backward (training: autograd of the call sites above; the reference uses ATen's) -------- */
@@ -94,6 +100,11 @@ int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, float* out, in
 /* Accumulate per-(n, group) sum and sum-of-squares of x into stats[N][G][2] (fp64, must be zeroed by the
  * caller, e.g. one hipMemsetAsync per forward for all GroupNorms). */
 int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int HW, int C, int G, void* stream);
+/* scale_out / bias_out [N][ld]: GN(x)[n,:,:,c] [* (1 + film scale) + film shift] == x * scale_out[n][c] + bias_out[n][c],
+ * from the statistics above -- the coefficients bbdm_conv2d_nhwc_f32 applies on the fly (pre_scale / pre_bias). */
+int bbdm_groupnorm_coeffs_f32(const double* stats, const float* gamma, const float* beta, const float* film, int film_ld,
+                              float* scale_out, float* bias_out, int ld, int N, int HW, int C, int G, float eps,
+                              void* stream);
 /* y = resample( act( GN(x) [* (1 + scale) + shift] ) )  --  the fused run
  *   GroupNorm32 -> [FiLM: openaimodel.py:270-273] -> SiLU -> [avg-pool 2x2 :159 | nearest x2 :118].
  * stats: as produced above (may be NULL with gamma == NULL: pure resample of x, the x_upd path :263).

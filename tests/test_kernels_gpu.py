@@ -92,7 +92,7 @@ def test_conv2d_channel_slices(dev):
     st = torch.cuda.current_stream().cuda_stream
     bg = b.to(dev)
     _lib.call("bbdm_conv2d_nhwc_f32", wide_in.data_ptr() + 4 * 48, 80, pw.data_ptr(), bg.data_ptr(), None, 0,
-              wide_out.data_ptr() + 4 * 64, 320, 0, None, 0, N, H, W, Cin, Cout, 3, st)
+              wide_out.data_ptr() + 4 * 64, 320, 0, None, 0, None, None, 0, 0, N, H, W, Cin, Cout, 3, st)
     torch.cuda.synchronize()
     ref = F.conv2d(_nchw(wide_in.cpu()[..., 48:80]), w, b, padding=1)
     got = wide_out.cpu()
@@ -292,3 +292,30 @@ def test_layout_roundtrip(dev):
     assert torch.equal(x.cpu().permute(0, 3, 1, 2), ref)
     back = ops.nhwc_to_nchw(x, 6)
     assert torch.equal(back.cpu(), ref[:, :6])
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout,ks,film,silu", [(2, 16, 16, 128, 64, 3, True, True), (3, 8, 8, 96, 128, 3, False, True),
+                                                        (1, 32, 32, 256, 128, 1, False, False), (20, 4, 4, 640, 256, 3, True, True)])
+def test_conv_with_fused_groupnorm_producer(dev, N, H, W, C, Cout, ks, film, silu):
+    """GroupNorm -> [FiLM] -> [SiLU] -> conv with the normalisation applied while the patch is staged."""
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(C + Cout + ks)
+    x = torch.randn(N, C, H, W, generator=g) * 1.7 + 0.4
+    gamma = 1.0 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    fl = 0.3 * torch.randn(N, 2 * C, generator=g) if film else None
+    w = torch.randn(Cout, C, ks, ks, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g) * 0.1
+    y = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if film:
+        y = y * (1 + fl[:, :C, None, None]) + fl[:, C:, None, None]
+    if silu:
+        y = F.silu(y)
+    ref = F.conv2d(y, w, b, padding=ks // 2)
+    xg = _nhwc(x).to(dev)
+    stats = ops.groupnorm_stats(xg)
+    sc, bi = ops.groupnorm_coeffs(stats, gamma.to(dev), beta.to(dev), H * W, film=fl.to(dev) if film else None)
+    out = ops.conv2d_nhwc(xg, ops.pack_conv_weight(w.to(dev)), b.to(dev), Cout, ks, pre_scale=sc, pre_bias=bi,
+                          pre_silu=silu)
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out.cpu()), ref) < TOL
