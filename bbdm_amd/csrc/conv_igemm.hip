@@ -345,17 +345,18 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
         lds_set = lds;
     }
     const long long blocks = (long long)a.tilesN * a.tilesX * a.tilesY * cdiv(a.N, IM);
-    // split-K: when the output tiles alone cannot fill the 256 CUs, spread the Cin chunks over gridDim.y
-    a.splits = 1;
-    a.chunks_per_split = a.nchunks;
-    if (a.ws && blocks < 256 && a.nchunks >= 4) {
-        int want = (int)cdiv(512, (int)blocks);
-        if (want > a.nchunks / 2) want = a.nchunks / 2;
-        if (want > 32) want = 32;
-        if ((size_t)want * a.N * a.H * a.W * a.ldw > a.ws_cap) want = (int)(a.ws_cap / ((size_t)a.N * a.H * a.W * a.ldw));
-        if (want > 1) {
-            a.chunks_per_split = cdiv(a.nchunks, want);
-            a.splits = cdiv(a.nchunks, a.chunks_per_split);
+    // split-K (a.splits chosen by conv_plan): spread the Cin chunks over gridDim.y, bounded by the workspace
+    {
+        int want = a.splits;
+        a.splits = 1;
+        a.chunks_per_split = a.nchunks;
+        if (a.ws && want > 1) {
+            const size_t per = (size_t)a.N * a.H * a.W * a.ldw;
+            if ((size_t)want * per > a.ws_cap) want = (int)(a.ws_cap / per);
+            if (want > 1) {
+                a.chunks_per_split = cdiv(a.nchunks, want);
+                a.splits = cdiv(a.nchunks, a.chunks_per_split);
+            }
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits), dim3(WM * WN * 64), lds, stream, a);
@@ -392,16 +393,39 @@ extern "C" int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int
     return BBDM_OK;
 }
 
+// Tile / split-K choice.  The 256x128 tile (8 waves, 2 blocks per CU) is the efficient one; it needs >= 512 blocks to
+// fill the chip, so problems with fewer output tiles get the Cin reduction split over 2..32 extra workgroups each
+// (partials summed in a fixed order by conv_splitk_reduce_kernel).
+struct ConvPlan {
+    bool big;
+    int splits;
+};
+static ConvPlan conv_plan(long long M, int Cout, int nchunks) {
+    ConvPlan p;
+    const long long b256 = ((M + 255) / 256) * cdiv(Cout, 128);
+    const long long b128 = ((M + 127) / 128) * cdiv(Cout, 128);
+    if (b256 >= 512) { p.big = true; p.splits = 1; return p; }
+    if (b256 >= 128 && nchunks >= 8) {            // 2..4-way split of the big tile
+        p.big = true;
+        p.splits = (int)cdiv(512, (int)b256);
+        return p;
+    }
+    p.big = false;
+    p.splits = 1;
+    if (b128 < 256 && nchunks >= 4) {
+        int want = (int)cdiv(512, (int)b128);
+        if (want > nchunks / 2) want = nchunks / 2;
+        if (want > 32) want = 32;
+        p.splits = want > 1 ? want : 1;
+    }
+    return p;
+}
+
 extern "C" size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int CinPad, int Cout, int ks) {
-    // enough for 32 splits of a problem small enough to want them (< 256 output tiles of 128x128), else nothing
-    const long long M = (long long)N * H * W;
-    const long long blocks = ((M + 127) / 128) * cdiv(Cout, 128);
     (void)ks;
-    if (blocks >= 256 || cdiv(CinPad, KC) < 4) return 0;
-    int want = (int)cdiv(512, (int)blocks);
-    if (want > cdiv(CinPad, KC) / 2) want = cdiv(CinPad, KC) / 2;
-    if (want > 32) want = 32;
-    return want > 1 ? (size_t)want * M * ((Cout + 3) & ~3) : 0;
+    const long long M = (long long)N * H * W;
+    const ConvPlan p = conv_plan(M, Cout, cdiv(CinPad, KC));
+    return p.splits > 1 ? (size_t)p.splits * M * ((Cout + 3) & ~3) : 0;
 }
 
 extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
@@ -431,15 +455,16 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     a.pre_sc = pre_scale; a.pre_bi = pre_bias; a.pre_ld = pre_ld; a.pre_silu = pre_silu;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
+    const ConvPlan plan = conv_plan(M, Cout, a.nchunks);
+    a.splits = plan.splits;
     int rc;
-    // Tile choice: 256x128 when it still yields >= 2 blocks per CU, else 128x128.
-    const long long blocks256 = ((M + 255) / 256) * cdiv(Cout, 128);
-    if (blocks256 >= 512) {
+    if (plan.big) {
         rc = launch_conv<256, 128, 4, 2, 3, 2>(a, st);
-        if (rc == 1) rc = launch_conv<256, 128, 4, 2, 5, 2>(a, st);
+        if (rc == 1) { a.splits = plan.splits; rc = launch_conv<256, 128, 4, 2, 5, 2>(a, st); }
     } else {
-        rc = launch_conv<128, 128, 2, 2, 4, 2>(a, st);
-        if (rc == 1) rc = launch_conv<128, 128, 2, 2, 6, 2>(a, st);
+        rc = launch_conv<128, 128, 4, 2, 2, 2>(a, st);            // 8 waves of 32x64: 16 waves per CU like the big tile
+        if (rc == 1) { a.splits = plan.splits; rc = launch_conv<128, 128, 4, 2, 3, 2>(a, st); }
+        if (rc == 1) { a.splits = plan.splits; rc = launch_conv<128, 128, 2, 2, 6, 2>(a, st); }
     }
     if (rc == 1) {
         bbdm_set_error("conv2d: no tile configuration fits N=%d H=%d W=%d", N, H, W);
