@@ -34,24 +34,27 @@ struct WgradArgs {
     int tilesX, tilesY;          // pixel tiles per image
     int ptiles;                  // N * tilesX * tilesY
     int tiles_per_split;
-    int CinP, CoutP;             // Cin, Cout rounded up to 64
+    int CinP, CoutP;             // Cin rounded up to the ci tile (64 or 128), Cout rounded up to 64
 };
 
-template <int TAPS>
-__global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
+template <int TAPS, int WI>
+__global__ void __launch_bounds__(WI * 128, 1) conv_wgrad_f32(const WgradArgs a) {
+    constexpr int NT = WI * 128;                     // threads: WI ci-waves x 2 co-waves
+    constexpr int CTI = WI * 32;                     // ci channels per block
+    constexpr int CPI = CTI + 4;                     // LDS pitch of the X patch
     constexpr int PAD = TAPS == 9 ? 1 : 0;
     constexpr int PW = PTW + 2 * PAD, PH = PTH + 2 * PAD;
     constexpr int XPIX = PW * PH;                    // 100 or 64
-    constexpr int XSLOTS = (XPIX * CT / 4 + 255) / 256;
-    constexpr int YSLOTS = (PTH * PTW * CT / 4) / 256;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XPIX][CP] + [2][64][CP]
+    constexpr int XSLOTS = (XPIX * CTI / 4 + NT - 1) / NT;
+    constexpr int YSLOTS = (PTH * PTW * CT / 4 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][XPIX][CPI] + [2][64][CP]
     float* xbuf = smem;
-    float* ybuf = smem + 2 * XPIX * CP;
+    float* ybuf = smem + 2 * XPIX * CPI;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wo = wave & 1;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int ci0 = blockIdx.x * CT, co0 = blockIdx.y * CT;
+    const int ci0 = blockIdx.x * CTI, co0 = blockIdx.y * CT;
     const int t_begin = blockIdx.z * a.tiles_per_split;
     const int t_end = min(a.ptiles, t_begin + a.tiles_per_split);
 
@@ -75,23 +78,23 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
         const int h0 = ty * PTH, w0 = tx * PTW;
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
-            const int f = tid + s * 256;
-            const int pp = f / (CT / 4), c = (f % (CT / 4)) * 4;
+            const int f = tid + s * NT;
+            const int pp = f / (CTI / 4), c = (f % (CTI / 4)) * 4;
             const int py = pp / PW, px = pp - py * PW;
             const int h = h0 + py - PAD, w = w0 + px - PAD;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < XPIX * CT / 4 && h >= 0 && h < a.H && w >= 0 && w < a.W && ci0 + c < a.Cin)
+            if (f < XPIX * CTI / 4 && h >= 0 && h < a.H && w >= 0 && w < a.W && ci0 + c < a.Cin)
                 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + ci0 + c);
             xreg[s] = v;
         }
 #pragma unroll
         for (int s = 0; s < YSLOTS; ++s) {
-            const int f = tid + s * 256;
+            const int f = tid + s * NT;
             const int pp = f / (CT / 4), c = (f % (CT / 4)) * 4;
             const int py = pp / PTW, px = pp - py * PTW;
             const int h = h0 + py, w = w0 + px;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (h < a.H && w < a.W && co0 + c < a.Cout) {
+            if (f < PTH * PTW * CT / 4 && h < a.H && w < a.W && co0 + c < a.Cout) {
                 const float* p = a.dy + ((size_t)(n * a.H + h) * a.W + w) * a.ldy + co0 + c;
                 if (co0 + c + 3 < a.Cout) {
                     v = *reinterpret_cast<const float4*>(p);
@@ -107,14 +110,15 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < XSLOTS; ++s) {
-            const int f = tid + s * 256;
-            if (f < XPIX * CT / 4)
-                *reinterpret_cast<float4*>(xbuf + buf * XPIX * CP + (f / (CT / 4)) * CP + (f % (CT / 4)) * 4) = xreg[s];
+            const int f = tid + s * NT;
+            if (f < XPIX * CTI / 4)
+                *reinterpret_cast<float4*>(xbuf + buf * XPIX * CPI + (f / (CTI / 4)) * CPI + (f % (CTI / 4)) * 4) = xreg[s];
         }
 #pragma unroll
         for (int s = 0; s < YSLOTS; ++s) {
-            const int f = tid + s * 256;
-            *reinterpret_cast<float4*>(ybuf + buf * PTH * PTW * CP + (f / (CT / 4)) * CP + (f % (CT / 4)) * 4) = yreg[s];
+            const int f = tid + s * NT;
+            if (f < PTH * PTW * CT / 4)
+                *reinterpret_cast<float4*>(ybuf + buf * PTH * PTW * CP + (f / (CT / 4)) * CP + (f % (CT / 4)) * 4) = yreg[s];
         }
     };
 
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         if (t + 1 < t_end) load_tile(t + 1);
-        const float* xb = xbuf + buf * XPIX * CP + wi * 32 + l31;
+        const float* xb = xbuf + buf * XPIX * CPI + wi * 32 + l31;
         const float* yb = ybuf + buf * PTH * PTW * CP + wo * 32 + l31;
         // k runs over pixel pairs (px, px+1): lanes < 32 carry the even pixel, lanes >= 32 the odd one
 #pragma unroll 2
@@ -139,7 +143,7 @@ __global__ void __launch_bounds__(256, 1) conv_wgrad_f32(const WgradArgs a) {
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const int r = tap / 3, s = tap - 3 * r;
-                    const float av = xb[((py + (TAPS == 9 ? r : 0)) * PW + px + (TAPS == 9 ? s : 0)) * CP];
+                    const float av = xb[((py + (TAPS == 9 ? r : 0)) * PW + px + (TAPS == 9 ? s : 0)) * CPI];
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[tap], 0, 0, 0);
                 }
             }
@@ -256,16 +260,46 @@ __global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, float* __r
 
 }  // namespace
 
-extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
-    const int CinP = cdiv(Cin, CT) * CT, CoutP = cdiv(Cout, CT) * CT;
-    const int ptiles = N * cdiv(H, PTH) * cdiv(W, PTW);
-    const int tiles = (CinP / CT) * (CoutP / CT);
-    int splits = cdiv(768, tiles);
-    if (splits > ptiles) splits = ptiles;
+// geometry shared by the workspace query and the launcher: ci tile 128 (8 waves) when Cin >= 128, else 64 (4 waves)
+struct WgradGeom {
+    int cti, CinP, CoutP, ptiles, splits, tiles_per_split;
+};
+static WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout) {
+    WgradGeom g;
+    g.cti = Cin >= 128 ? 128 : 64;
+    g.CinP = cdiv(Cin, g.cti) * g.cti;
+    g.CoutP = cdiv(Cout, CT) * CT;
+    g.ptiles = N * cdiv(H, PTH) * cdiv(W, PTW);
+    const int tiles = (g.CinP / g.cti) * (g.CoutP / CT);
+    int splits = cdiv(g.cti == 128 ? 512 : 768, tiles);
+    if (splits > g.ptiles) splits = g.ptiles;
     if (splits < 1) splits = 1;
-    const int tps = cdiv(ptiles, splits);
-    splits = cdiv(ptiles, tps);
-    return (size_t)splits * ks * ks * CinP * CoutP + (size_t)splits * CoutP;
+    g.tiles_per_split = cdiv(g.ptiles, splits);
+    g.splits = cdiv(g.ptiles, g.tiles_per_split);
+    return g;
+}
+
+extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
+    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout);
+    return (size_t)g.splits * ks * ks * g.CinP * g.CoutP + (size_t)g.splits * g.CoutP;
+}
+
+template <int TAPS, int WI>
+static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int XPIX = (PTW + 2 * PAD) * (PTH + 2 * PAD);
+    constexpr size_t lds = ((size_t)2 * XPIX * (WI * 32 + 4) + 2 * PTH * PTW * CP) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<TAPS, WI>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            bbdm_set_error("conv_wgrad: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_f32<TAPS, WI>), grid, dim3(WI * 128), lds, st, a);
+    return 0;
 }
 
 extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias,
@@ -276,39 +310,24 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     BBDM_REQUIRE(ldx % 4 == 0 && ldx >= Cin && ((uintptr_t)x & 15) == 0, "conv_wgrad: x pitch/alignment (ldx=%d)", ldx);
     BBDM_REQUIRE(ldy >= Cout && (Cout % 4 != 0 || (ldy % 4 == 0 && ((uintptr_t)dy & 15) == 0)),
                  "conv_wgrad: dy pitch/alignment (ldy=%d)", ldy);
+    BBDM_REQUIRE(Cin % 4 == 0, "conv_wgrad: Cin=%d must be a multiple of 4 (pad the input tensor)", Cin);
+    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout);
     WgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.ldx = ldx; a.ldy = ldy;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.taps = ks * ks; a.pad = ks / 2;
     a.tilesX = cdiv(W, PTW); a.tilesY = cdiv(H, PTH);
-    a.ptiles = N * a.tilesX * a.tilesY;
-    a.CinP = cdiv(Cin, CT) * CT; a.CoutP = cdiv(Cout, CT) * CT;
-    const int tiles = (a.CinP / CT) * (a.CoutP / CT);
-    int splits = cdiv(768, tiles);
-    if (splits > a.ptiles) splits = a.ptiles;
-    if (splits < 1) splits = 1;
-    a.tiles_per_split = cdiv(a.ptiles, splits);
-    splits = cdiv(a.ptiles, a.tiles_per_split);
+    a.ptiles = g.ptiles;
+    a.CinP = g.CinP; a.CoutP = g.CoutP;
+    a.tiles_per_split = g.tiles_per_split;
+    const int splits = g.splits;
     a.wsb = dbias ? ws + (size_t)splits * ks * ks * a.CinP * a.CoutP : nullptr;
-    BBDM_REQUIRE(Cin % 4 == 0, "conv_wgrad: Cin=%d must be a multiple of 4 (pad the input tensor)", Cin);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(a.CinP / CT, a.CoutP / CT, splits);
-    const int xpix = ks == 3 ? (PTW + 2) * (PTH + 2) : PTW * PTH;
-    const size_t lds = ((size_t)2 * xpix * CP + 2 * PTH * PTW * CP) * sizeof(float);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[ks == 3]) {
-        const void* f = ks == 3 ? reinterpret_cast<const void*>(conv_wgrad_f32<9>)
-                                : reinterpret_cast<const void*>(conv_wgrad_f32<1>);
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            bbdm_set_error("conv_wgrad: hipFuncSetAttribute(%zu B LDS) failed", lds);
-            return BBDM_E_LAUNCH;
-        }
-        attr_set[ks == 3] = true;
-    }
-    if (ks == 3)
-        hipLaunchKernelGGL(conv_wgrad_f32<9>, grid, dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL(conv_wgrad_f32<1>, grid, dim3(256), lds, st, a);
+    const dim3 grid(a.CinP / g.cti, a.CoutP / CT, splits);
+    int rc;
+    if (ks == 3) rc = g.cti == 128 ? launch_wgrad<9, 4>(a, grid, st) : launch_wgrad<9, 2>(a, grid, st);
+    else rc = g.cti == 128 ? launch_wgrad<1, 4>(a, grid, st) : launch_wgrad<1, 2>(a, grid, st);
+    if (rc != 0) return rc;
     const size_t total = (size_t)Cout * Cin * ks * ks;
     int rb = (int)((total + 255) / 256);
     if (rb > 4096) rb = 4096;
