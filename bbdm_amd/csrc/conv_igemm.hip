@@ -50,9 +50,12 @@ struct ConvArgs {
     int pre_ld, pre_silu;
 };
 
-template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC>
+// VAR bit 0: fused producer (pre_sc / pre_bi) present; bit 1: split-K epilogue (raw partial sums to the workspace).
+// The common case (VAR = 0) carries neither branch, so its register allocation is that of the plain kernel.
+template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
 __global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
 conv_igemm_f32(const ConvArgs a) {
+    constexpr bool PRE = (VAR & 1) != 0, SPLIT = (VAR & 2) != 0;
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 32;     // 32-row MFMA tiles per wave (M)
     constexpr int NTL = BN / WN / 32;    // 32-col MFMA tiles per wave (N)
@@ -100,7 +103,7 @@ conv_igemm_f32(const ConvArgs a) {
             if (n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W) {
                 goff[s] = (uint32_t)(((n * a.H + h) * a.W + w)) * (uint32_t)a.ldx + c4 * 4;
                 pvalid |= 1u << s;
-                pimg |= (uint32_t)(img_l & 31) << (5 * s);
+                if (PRE) pimg |= (uint32_t)(img_l & 31) << (5 * s);
             }
         }
     }
@@ -146,7 +149,7 @@ conv_igemm_f32(const ConvArgs a) {
         }
     };
     auto store_patch = [&](float* dst, int chunk) {
-        if (a.pre_sc) {
+        if (PRE) {
             // fused GroupNorm affine (+ FiLM) (+ SiLU) on the valid elements; padding stays exactly zero
             const int cbase = chunk * KC;
 #pragma unroll
@@ -247,7 +250,7 @@ conv_igemm_f32(const ConvArgs a) {
                 const int w = wbase + (m & (TW - 1));
                 if (cok && img_l < a.imgs && n < a.N && h < a.H && w < a.W) {
                     const size_t pix = (size_t)(n * a.H + h) * a.W + w;
-                    if (a.splits > 1) {          // raw partial sum; bias / residual are applied by the reduce kernel
+                    if (SPLIT) {                 // raw partial sum; bias / residual are applied by the reduce kernel
                         a.ws[((size_t)blockIdx.y * a.N * a.H * a.W + pix) * a.ldw + co] = acc[mt][nt][r];
                         continue;
                     }
@@ -310,6 +313,21 @@ int set_lds_limit(K kernel, size_t bytes) {
                : -1;
 }
 
+template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
+int launch_variant(const ConvArgs& a, size_t lds, long long blocks, hipStream_t stream) {
+    auto kern = conv_igemm_f32<BM, BN, WM, WN, PSLOTS, OCC, VAR>;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (set_lds_limit(kern, lds) != 0) {
+            bbdm_set_error("conv: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits), dim3(WM * WN * 64), lds, stream, a);
+    return 0;
+}
+
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC>
 int launch_conv(ConvArgs& a, hipStream_t stream) {
     const int TWc = ceil_pow2(a.W) < 32 ? ceil_pow2(a.W) : 32;
@@ -335,15 +353,6 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
     if (a.patchPix * (KC / 4) > PSLOTS * WM * WN * 64) return 1;   // does not fit this instantiation
     const size_t lds = ((size_t)2 * a.patchPix * KP + 2 * BN * KP) * sizeof(float);
     if (lds > 160 * 1024) return 1;
-    auto kern = conv_igemm_f32<BM, BN, WM, WN, PSLOTS, OCC>;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (set_lds_limit(kern, lds) != 0) {
-            bbdm_set_error("conv: hipFuncSetAttribute(%zu B LDS) failed", lds);
-            return BBDM_E_LAUNCH;
-        }
-        lds_set = lds;
-    }
     const long long blocks = (long long)a.tilesN * a.tilesX * a.tilesY * cdiv(a.N, IM);
     // split-K (a.splits chosen by conv_plan): spread the Cin chunks over gridDim.y, bounded by the workspace
     {
@@ -359,7 +368,15 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
             }
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits), dim3(WM * WN * 64), lds, stream, a);
+    const int var = (a.pre_sc ? 1 : 0) | (a.splits > 1 ? 2 : 0);
+    int lrc;
+    switch (var) {
+        case 0: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 0>(a, lds, blocks, stream); break;
+        case 1: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 1>(a, lds, blocks, stream); break;
+        case 2: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 2>(a, lds, blocks, stream); break;
+        default: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 3>(a, lds, blocks, stream); break;
+    }
+    if (lrc != 0) return lrc;
     if (a.splits > 1) {
         const size_t total = (size_t)a.N * a.H * a.W * a.Cout;
         size_t rb = (total + 255) / 256;
