@@ -319,3 +319,17 @@ def test_conv_with_fused_groupnorm_producer(dev, N, H, W, C, Cout, ks, film, sil
                           pre_silu=silu)
     torch.cuda.synchronize()
     assert rel_err(_nchw(out.cpu()), ref) < TOL
+
+
+def test_conv_lds_dma_variant_in_subprocess():
+    """The opt-in LDS-DMA conv kernel (BBDM_CONV_GLDS=1: global_load_lds + counted vmcnt + XOR-swizzled LDS images) must
+    give the same results; the switch is read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BBDM_CONV_GLDS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x",
+                        "-k", "test_conv2d or test_conv2d_channel_slices"], env=env, cwd=root, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
