@@ -41,4 +41,8 @@ static inline int ilog2(int v) {
     return l;
 }
 
+// conv_igemm.hip: `batch` independent GEMMs [H*W x CinPad] x [CinPad x Cout] (packed 1x1 weights) in one launch
+int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed_w, size_t wz, float* out, int ldo, size_t oz,
+                         int batch, int H, int W, int CinPad, int Cout, hipStream_t st);
+
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }

@@ -49,6 +49,10 @@ struct ConvArgs {
     const float* pre_sc;
     const float* pre_bi;
     int pre_ld, pre_silu;
+    // batched GEMM mode (gridDim.z = batch): per-batch element offsets of x / packed weights / out.  Used by the
+    // Winograd path (16 transformed-domain GEMMs in one launch); bias, residual and split-K are off in this mode.
+    int batch;
+    size_t xz, wz, oz;
 };
 
 template <int BM, int BN, int WM, int WN, bool SPLIT>
@@ -112,8 +116,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // The common case (VAR = 0) carries neither branch, so its register allocation is that of the plain kernel.
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
 __global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
-conv_igemm_f32(const ConvArgs a) {
+conv_igemm_f32(const ConvArgs a_in) {
     constexpr bool PRE = (VAR & 1) != 0, SPLIT = (VAR & 2) != 0;
+    ConvArgs a = a_in;
+    a.x += (size_t)blockIdx.z * a.xz;
+    a.w += (size_t)blockIdx.z * a.wz;
+    a.out += (size_t)blockIdx.z * a.oz;
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 32;     // 32-row MFMA tiles per wave (M)
     constexpr int NTL = BN / WN / 32;    // 32-col MFMA tiles per wave (N)
@@ -319,7 +327,11 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) 
 
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, bool SPLIT>
 __global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
-conv_igemm_glds_f32(const ConvArgs a) {
+conv_igemm_glds_f32(const ConvArgs a_in) {
+    ConvArgs a = a_in;
+    a.x += (size_t)blockIdx.z * a.xz;
+    a.w += (size_t)blockIdx.z * a.wz;
+    a.out += (size_t)blockIdx.z * a.oz;
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 32;
     constexpr int NTL = BN / WN / 32;
@@ -546,7 +558,7 @@ int launch_variant(const ConvArgs& a, size_t lds, long long blocks, hipStream_t 
         }
         lds_set = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits, a.batch), dim3(WM * WN * 64), lds, stream, a);
     return 0;
 }
 
@@ -561,7 +573,7 @@ int launch_glds(const ConvArgs& a, size_t lds, long long blocks, hipStream_t str
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits), dim3(WM * WN * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits, a.batch), dim3(WM * WN * 64), lds, stream, a);
     return 0;
 }
 
@@ -694,6 +706,28 @@ extern "C" size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int Cin
     return p.splits > 1 ? (size_t)p.splits * M * ((Cout + 3) & ~3) : 0;
 }
 
+// Batched 1x1 "convolution" = `batch` independent GEMMs [pixels x CinPad] x [CinPad x Cout] in one launch (used by the
+// Winograd path; declared in common.h).  x / packed_w / out advance by xz / wz / oz floats per batch element.
+int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed_w, size_t wz, float* out, int ldo, size_t oz,
+                         int batch, int H, int W, int CinPad, int Cout, hipStream_t st) {
+    ConvArgs a;
+    a.x = x; a.w = packed_w; a.bias = nullptr; a.res = nullptr; a.out = out;
+    a.ldx = ldx; a.ldr = 0; a.ldo = ldo; a.out_nchw = 0;
+    a.N = 1; a.H = H; a.W = W; a.Cin = CinPad; a.Cout = Cout;
+    a.CoutPad = cdiv(Cout, 128) * 128;
+    a.taps = 1; a.nchunks = cdiv(CinPad, KC); a.pad = 0;
+    a.ws = nullptr; a.ws_cap = 0; a.ldw = (Cout + 3) & ~3;
+    a.pre_sc = nullptr; a.pre_bi = nullptr; a.pre_ld = 0; a.pre_silu = 0;
+    a.batch = batch; a.xz = xz; a.wz = wz; a.oz = oz;
+    a.splits = 1;
+    int rc = launch_conv<256, 128, 4, 2, 3, 2>(a, st);
+    if (rc == 1) {
+        bbdm_set_error("conv1x1_batched: tile configuration does not fit H=%d W=%d", H, W);
+        return BBDM_E_BADARG;
+    }
+    return rc;
+}
+
 extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
                                     const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
                                     size_t ws_floats, const float* pre_scale, const float* pre_bias, int pre_ld,
@@ -719,6 +753,7 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
                  "conv2d: pre_ld / alignment of the fused-producer coefficients");
     a.pre_sc = pre_scale; a.pre_bi = pre_bias; a.pre_ld = pre_ld; a.pre_silu = pre_silu;
+    a.batch = 1; a.xz = a.wz = a.oz = 0;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     const ConvPlan plan = conv_plan(M, Cout, a.nchunks);

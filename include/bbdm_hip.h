@@ -75,6 +75,25 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
                          const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
+/* ---- 3x3 convolution through Winograd F(2x2,3x3) (same call sites, wide layers) ---------------------------- */
+/* Y = A^T[(G g G^T) (.) (B^T d B)]A: 16 multiplies per 2x2 outputs instead of 36 (2.25x fewer MFMA FLOP), the choice
+ * cuDNN / MIOpen make for the reference's wide 3x3 layers (openaimodel.py:207,233,524).  stride 1, padding 1, H and W
+ * even, CinPad % 4 == 0, Cout % 4 == 0.  Three launches: input transform -> 16 batched GEMMs on the fp32 MFMA
+ * (conv_igemm_f32 in 1x1 mode) -> output transform (+ bias, + residual).  fp32 throughout; the transforms only use
+ * 0, +-1, +-1/2 so the result agrees with the direct kernel to ~1e-6 relative.
+ * packed_wino: bbdm_winograd_packed_floats() floats filled by bbdm_winograd_pack_weight_f32 (dgrad != 0 packs the
+ * data-gradient convolution Cout -> Cin of the same filter: transposed + flipped; then InPad is the channel count of
+ * dY and the forward entry is called with CinPad = InPad, Cout = Cin).
+ * ws: bbdm_winograd_workspace_floats() floats (transformed input V[16][tiles][CinPad] + products M[16][tiles][Cout]).
+ * flags: only BBDM_CONV_RES_PER_IMAGE. */
+size_t bbdm_winograd_packed_floats(int Cout, int CinPad);
+int bbdm_winograd_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
+                                  void* stream);
+size_t bbdm_winograd_workspace_floats(int N, int H, int W, int CinPad, int Cout);
+int bbdm_conv3x3_winograd_f32(const float* x, int ldx, const float* packed_wino, const float* bias,
+                              const float* residual, int ldr, float* out, int ldo, int flags, float* ws,
+                              int N, int H, int W, int CinPad, int Cout, void* stream);
+
 /* ---- convolution backward (training: autograd of the call sites above; the reference uses ATen's) -------- */
 /* Data gradient = the forward kernel run on dY with transposed + spatially flipped weights: pack them with this
  * (dY carries CoutIn >= Cout channels, CoutIn % 4 == 0), then call bbdm_conv2d_nhwc_f32(dY, ..., CinPad = CoutIn,

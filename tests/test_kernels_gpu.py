@@ -79,6 +79,84 @@ def test_conv2d(dev, N, H, W, Cin, Cout, ks, res):
         assert rel_err(_nchw(buf.cpu()), ref) < TOL
 
 
+WINO_CASES = [
+    # N, H, W, Cin, Cout, residual (0 none, 1 per pixel, 2 per image)
+    (2, 16, 16, 64, 128, 0),
+    (1, 32, 32, 256, 256, 1),
+    (3, 8, 12, 48, 72, 1),            # ragged tile count (padded to whole GEMM tiles), Cin not a multiple of 16
+    (2, 64, 64, 320, 384, 2),
+    (1, 2, 2, 16, 8, 0),              # a single tile
+    (5, 6, 4, 132, 260, 1),
+]
+WINO_TOL = 5e-5      # F(2x2,3x3) in fp32: transforms use 0, +-1, +-1/2 only
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res", WINO_CASES)
+def test_conv3x3_winograd(dev, N, H, W, Cin, Cout, res):
+    from bbdm_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    rg = None
+    if res == 1:
+        r = torch.randn(N, Cout, H, W, generator=g)
+        ref = ref + r
+        rg = _nhwc(r).to(dev)
+    elif res == 2:
+        r = torch.randn(N, Cout, generator=g)
+        ref = ref + r[:, :, None, None]
+        rg = r.to(dev)
+    xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
+    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cin)
+    out = ops.conv3x3_winograd(xg, pw, b.to(dev), Cout, residual=rg, res_per_image=(res == 2))
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL
+    # and it agrees with the direct implicit-GEMM kernel on the same input
+    direct = ops.conv2d_nhwc(xg, ops.pack_conv_weight(w.to(dev), cin_pad=Cin), b.to(dev), Cout, 3)
+    if res == 1:
+        direct = direct + rg
+    elif res == 2:
+        direct = direct + rg[:, None, None, :]
+    assert rel_err(out.cpu(), direct.cpu()) < WINO_TOL
+    if res == 1:                      # in place: out aliases the residual
+        buf = rg.clone()
+        ops.conv3x3_winograd(xg, pw, b.to(dev), Cout, residual=buf, out=buf)
+        assert rel_err(_nchw(buf.cpu()), ref.float()) < WINO_TOL
+
+
+def test_conv3x3_winograd_dgrad_and_slices(dev):
+    """Data gradient through the dgrad packing; input / output as channel slices of wider buffers."""
+    from bbdm_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cin, Cout = 2, 16, 16, 96, 160
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()          # dX of conv2d(x, w, padding=1)
+    wide_in = torch.zeros(N, H, W, 200, device=dev)
+    wide_in[..., 40:200] = _nhwc(dy).to(dev)
+    wide_out = torch.zeros(N, H, W, 128, device=dev)
+    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cout, dgrad=True)
+    lib = _lib.load()
+    ws = torch.empty(lib.bbdm_winograd_workspace_floats(N, H, W, Cout, Cin), device=dev)
+    _lib.call("bbdm_conv3x3_winograd_f32", wide_in.data_ptr() + 4 * 40, 200, pw.data_ptr(), None, None, 0,
+              wide_out.data_ptr() + 4 * 16, 128, 0, ws.data_ptr(), N, H, W, Cout, Cin,
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = wide_out.cpu()
+    assert rel_err(_nchw(got[..., 16:112]), ref) < WINO_TOL
+    assert float(got[..., :16].abs().max()) == 0 and float(got[..., 112:].abs().max()) == 0
+
+
+def test_conv3x3_winograd_rejects_odd(dev):
+    from bbdm_amd import _lib, ops
+    x = torch.zeros(1, 5, 4, 16, device=dev)
+    pw = ops.pack_winograd_weight(torch.zeros(16, 16, 3, 3, device=dev))
+    with pytest.raises(_lib.BBDMHipError, match="even"):
+        ops.conv3x3_winograd(x, pw, None, 16)
+
+
 def test_conv2d_channel_slices(dev):
     """Reading from / writing into channel slices of wider buffers (the copy-free th.cat)."""
     from bbdm_amd import _lib, ops
