@@ -114,6 +114,23 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 
 // VAR bit 0: fused producer (pre_sc / pre_bi) present; bit 1: split-K epilogue (raw partial sums to the workspace).
 // The common case (VAR = 0) carries neither branch, so its register allocation is that of the plain kernel.
+// Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2) in linear launch order.  Give every XCD a
+// CONTIGUOUS range of the (n_tile fastest) tile order instead, so that the Cout tiles of one pixel tile -- which read the
+// same input rows -- run on the same XCD and share them through its L2 rather than each fetching them over the fabric.
+__device__ __forceinline__ int xcd_swizzled_block() {
+    const int nblk = (int)gridDim.x, x = (int)blockIdx.x;
+    if (nblk < 64) return x;
+    const int off = (int)(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (size_t)nblk % 8);   // linear id of x = 0, mod 8
+    const int c = (off + x) & 7;                 // the XCD this workgroup lands on
+    int start = 0;
+    for (int cc = 0; cc < 8; ++cc) {
+        if (cc == c) break;
+        const int first = (cc - off) & 7;        // smallest x on XCD cc
+        start += (nblk - first + 7) >> 3;
+    }
+    return start + ((x - ((c - off) & 7)) >> 3);
+}
+
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
 __global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
 conv_igemm_f32(const ConvArgs a_in) {
@@ -139,7 +156,7 @@ conv_igemm_f32(const ConvArgs a_in) {
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- block -> tile ------------------------------------------------------------------------------
-    int bid = blockIdx.x;
+    int bid = xcd_swizzled_block();
     const int n_tile = bid % a.tilesN;
     bid /= a.tilesN;
     const int tile_x = bid % a.tilesX;
@@ -350,7 +367,7 @@ conv_igemm_glds_f32(const ConvArgs a_in) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    int bid = blockIdx.x;
+    int bid = xcd_swizzled_block();
     const int n_tile = bid % a.tilesN;
     bid /= a.tilesN;
     const int tile_x = bid % a.tilesX;

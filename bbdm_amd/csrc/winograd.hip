@@ -1,31 +1,91 @@
-// winograd.hip -- 3x3 stride-1 convolution through Winograd F(2x2, 3x3) on the fp32 matrix core.
+// winograd.hip -- 3x3 stride-1 convolution through Winograd F(m x m, 3x3), m = 2 or 4, on the fp32 matrix core.
 //
-// Same call sites as conv_igemm.hip (openaimodel.py:207,233,524,690 with >= 256 input channels); the reference's
-// cuDNN/MIOpen back ends make the same algorithmic choice for 3x3 convolutions.
+// Same call sites as conv_igemm.hip (openaimodel.py:207,233,524,690 on the wide layers); the reference's cuDNN / MIOpen
+// back ends make the same algorithmic choice for 3x3 convolutions (fp32 "Winograd non-fused" is F(4x4,3x3)).
 //
-//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 4x4 input tile d -> 2x2 output tile Y, summed over channels
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A     per (m+2)x(m+2) input tile d -> m x m output tile Y, summed over channels
 //
-// 16 multiplies per 2x2 outputs instead of 36: the contraction drops from 18 M Cin Cout to 8 M Cin Cout FLOP (2.25x).
-// Three launches:
-//   (1) winograd_input_kernel : x NHWC -> V[16][T][Cin], T = N (H/2)(W/2) tiles       (HBM-bound, adds only)
-//   (2) conv_igemm_f32 in batched 1x1 mode: 16 GEMMs  M_xi = V_xi [T x Cin] . U_xi [Cin x Cout]   (MFMA-bound)
-//   (3) winograd_output_kernel: M[16][T][Cout] -> y NHWC (+ bias, + residual)         (HBM-bound, adds only)
+// (m+2)^2 multiplies per m^2 outputs instead of 9 m^2: the contraction drops from 18 P Cin Cout FLOP (P pixels) to
+// 8 P Cin Cout (m = 2, 2.25x fewer) or 4.5 P Cin Cout (m = 4, 4x fewer).  Three launches:
+//   (1) winograd_input_kernel : x NHWC -> V[(m+2)^2][tiles][Cin]                           (HBM-bound, adds only)
+//   (2) conv_igemm_f32 in batched 1x1 mode: (m+2)^2 GEMMs  M_xi = V_xi [tiles x Cin] . U_xi [Cin x Cout]  (MFMA-bound)
+//   (3) winograd_output_kernel: M[(m+2)^2][tiles][Cout] -> y NHWC (+ bias, + residual)     (HBM-bound, adds only)
 // U_xi = G g G^T is precomputed once per weight update in the packed layout the GEMM wants.
-// fp32 throughout; F(2x2,3x3) keeps the error at the 1e-6 level (the transforms only use 0, +-1, +-1/2).
+// fp32 throughout.  Rounding error relative to an fp64 convolution (rms / max, Cin = 512, unit-variance activations):
+// direct 2e-7 / 3e-7, m = 2: 5e-7 / 6e-7, m = 4: 3e-6 / 1e-5 -- all far inside the 1e-3 per-step bar.
 #include "common.h"
 
 namespace {
 
 constexpr int KC = 16;
 
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// one thread = one (tile, channel quad)
+// ---- the 1-D transforms -------------------------------------------------------------------------------------------
+// t = B^T d.  m = 2: points {0, 1, -1, inf}; m = 4: points {0, 1, -1, 2, -2, inf} (Lavin & Gray, arXiv:1509.09308).
+template <int MO, typename T>
+__device__ __forceinline__ void bt_transform(const T (&d)[MO + 2], T (&t)[MO + 2]) {
+    if constexpr (MO == 2) {
+        t[0] = d[0] - d[2];
+        t[1] = d[1] + d[2];
+        t[2] = d[2] - d[1];
+        t[3] = d[1] - d[3];
+    } else {
+        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        t[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
+        t[2] = 4.f * (d[1] - d[2]) + (d[4] - d[3]);
+        t[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
+        t[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
+        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+}
+// s = A^T m
+template <int MO, typename T>
+__device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&s)[MO]) {
+    if constexpr (MO == 2) {
+        s[0] = m[0] + m[1] + m[2];
+        s[1] = m[1] - m[2] - m[3];
+    } else {
+        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
+        s[0] = m[0] + p12 + p34;
+        s[1] = m12 + 2.f * m34;
+        s[2] = p12 + 4.f * p34;
+        s[3] = m12 + 8.f * m34 + m[5];
+    }
+}
+// u = G g
+template <int MO>
+__device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
+    if constexpr (MO == 2) {
+        u[0] = g[0];
+        u[1] = 0.5f * (g[0] + g[1] + g[2]);
+        u[2] = 0.5f * (g[0] - g[1] + g[2]);
+        u[3] = g[2];
+    } else {
+        u[0] = 0.25f * g[0];
+        u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
+        u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
+        u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+        u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+        u[5] = g[2];
+    }
+}
+
+// ---- (1) input transform: one thread = one (tile, channel quad) ------------------------------------------------------
+// PRE: the tensor being convolved is act(x * sc[n][c] + bi[n][c]) (GroupNorm [+FiLM] [+SiLU] folded into per-image,
+//      per-channel coefficients by bbdm_groupnorm_coeffs_f32); zero padding applies to the activated tensor.
+// UP : x is [N, H/2, W/2] and is nearest-upsampled x2 on the fly (Upsample.forward, openaimodel.py:111-121).
+template <int MO, bool PRE, bool UP>
 __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
-                                                             int N, int H, int W, int C, size_t plane) {
+                                                             const float* __restrict__ sc, const float* __restrict__ bi,
+                                                             int pre_ld, int pre_silu, int N, int H, int W, int C,
+                                                             size_t plane) {
+    constexpr int AL = MO + 2;
     const int C4 = C >> 2;
-    const int TH = H >> 1, TW = W >> 1;
+    const int TH = H / MO, TW = W / MO;
     const long long total = (long long)N * TH * TW * C4;
     for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
         const int c = (int)(u % C4) * 4;
@@ -33,45 +93,57 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
         const int tw = (int)(tile % TW);
         const long long r = tile / TW;
         const int th = (int)(r % TH), n = (int)(r / TH);
-        float4 d[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int h = 2 * th - 1 + i;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int w = 2 * tw - 1 + j;
-                d[i][j] = (h >= 0 && h < H && w >= 0 && w < W)
-                              ? *reinterpret_cast<const float4*>(x + ((size_t)(n * H + h) * W + w) * ldx + c)
-                              : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+        float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = f4zero();
+        if (PRE) {
+            s4 = *reinterpret_cast<const float4*>(sc + (size_t)n * pre_ld + c);
+            b4 = *reinterpret_cast<const float4*>(bi + (size_t)n * pre_ld + c);
         }
-        // t = B^T d   (B^T rows: [1,0,-1,0], [0,1,1,0], [0,-1,1,0], [0,1,0,-1])
-        float4 t[4][4];
+        const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
+        float4 t[AL][AL];                 // t[i][j] = (B^T d)[i][j]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t[0][j] = f4sub(d[0][j], d[2][j]);
-            t[1][j] = f4add(d[1][j], d[2][j]);
-            t[2][j] = f4sub(d[2][j], d[1][j]);
-            t[3][j] = f4sub(d[1][j], d[3][j]);
+        for (int j = 0; j < AL; ++j) {    // column j of the tile, transformed down the rows as soon as it is loaded
+            const int w = MO * tw - 1 + j;
+            float4 d[AL], col[AL];
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int h = MO * th - 1 + i;
+                float4 v = f4zero();
+                if (h >= 0 && h < H && w >= 0 && w < W) {
+                    const int hs = UP ? h >> 1 : h, wsrc = UP ? w >> 1 : w;
+                    v = *reinterpret_cast<const float4*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+                    if (PRE) {
+                        v.x = v.x * s4.x + b4.x; v.y = v.y * s4.y + b4.y;
+                        v.z = v.z * s4.z + b4.z; v.w = v.w * s4.w + b4.w;
+                        if (pre_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    }
+                }
+                d[i] = v;
+            }
+            bt_transform<MO>(d, col);
+#pragma unroll
+            for (int i = 0; i < AL; ++i) t[i][j] = col[i];
         }
         float* o = V + (size_t)tile * C + c;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(o + (size_t)(i * 4 + 0) * plane) = f4sub(t[i][0], t[i][2]);
-            *reinterpret_cast<float4*>(o + (size_t)(i * 4 + 1) * plane) = f4add(t[i][1], t[i][2]);
-            *reinterpret_cast<float4*>(o + (size_t)(i * 4 + 2) * plane) = f4sub(t[i][2], t[i][1]);
-            *reinterpret_cast<float4*>(o + (size_t)(i * 4 + 3) * plane) = f4sub(t[i][1], t[i][3]);
+        for (int i = 0; i < AL; ++i) {
+            float4 row[AL];
+            bt_transform<MO>(t[i], row);  // (B^T d B)[i][.] = B^T applied along the row
+#pragma unroll
+            for (int j = 0; j < AL; ++j) *reinterpret_cast<float4*>(o + (size_t)(i * AL + j) * plane) = row[j];
         }
     }
 }
 
-// one thread = one (tile, output-channel quad): y[2th+a][2tw+b] = (A^T m A)[a][b] + bias (+ residual)
+// ---- (3) output transform: one thread = one (tile, output-channel quad) ---------------------------------------------
+// y[MO*th + a][MO*tw + b] = (A^T m A)[a][b] + bias (+ residual)
+template <int MO>
 __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int ldr, int res_per_image,
                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout) {
+    constexpr int AL = MO + 2;
     const int C4 = Cout >> 2;
-    const int TH = H >> 1, TW = W >> 1;
+    const int TH = H / MO, TW = W / MO;
     const long long total = (long long)N * TH * TW * C4;
     for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
         const int c = (int)(u % C4) * 4;
@@ -80,31 +152,28 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
         const long long r = tile / TW;
         const int th = (int)(r % TH), n = (int)(r / TH);
         const float* m = M + (size_t)tile * ldm + c;
-        float4 v[4][4];
+        float4 s[MO][AL];                 // s = A^T m, built one column of m at a time
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < AL; ++j) {
+            float4 v[AL], sj[MO];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = *reinterpret_cast<const float4*>(m + (size_t)(i * 4 + j) * plane);
-        // s = A^T m  (A^T rows: [1,1,1,0], [0,1,-1,-1])
-        float4 s[2][4];
+            for (int i = 0; i < AL; ++i) v[i] = *reinterpret_cast<const float4*>(m + (size_t)(i * AL + j) * plane);
+            at_transform<MO>(v, sj);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[0][j] = f4add(f4add(v[0][j], v[1][j]), v[2][j]);
-            s[1][j] = f4sub(f4sub(v[1][j], v[2][j]), v[3][j]);
+            for (int a = 0; a < MO; ++a) s[a][j] = sj[a];
         }
-        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c) : f4zero();
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float4 o[2];
-            o[0] = f4add(f4add(s[a][0], s[a][1]), s[a][2]);
-            o[1] = f4sub(f4sub(s[a][1], s[a][2]), s[a][3]);
+        for (int a = 0; a < MO; ++a) {
+            float4 o[MO];
+            at_transform<MO>(s[a], o);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const size_t pix = (size_t)(n * H + 2 * th + a) * W + 2 * tw + b;
-                float4 val = f4add(o[b], b4);
+            for (int b = 0; b < MO; ++b) {
+                const size_t pix = (size_t)(n * H + MO * th + a) * W + MO * tw + b;
+                float4 val = o[b] + b4;
                 if (res) {
                     const float* rp = res_per_image ? res + (size_t)n * ldr + c : res + pix * ldr + c;
-                    val = f4add(val, *reinterpret_cast<const float4*>(rp));
+                    val = val + *reinterpret_cast<const float4*>(rp);
                 }
                 *reinterpret_cast<float4*>(y + pix * ldy + c) = val;
             }
@@ -112,12 +181,13 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
     }
 }
 
-// U_xi[co][ci] = (G g G^T)[i][j] written in the packed 1x1 layout [xi][chunk][CoutPad][16].
+// ---- weights: U_xi[co][ci] = (G g G^T)[i][j] in the packed 1x1 layout [xi][chunk][CoutPad][16] -----------------------
 // dgrad != 0: the weights of the data-gradient convolution, g'[ci][co][r][s] = g[co][ci][2-r][2-s].
-__global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int CinPad,
-                                       int CoutPad, int nchunks, int dgrad) {
-    // logical conv: O output channels, I input channels
-    const int O = dgrad ? Cin : Cout, I = dgrad ? Cout : Cin;
+template <int MO>
+__global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int CoutPad,
+                                       int nchunks, int dgrad) {
+    constexpr int AL = MO + 2;
+    const int O = dgrad ? Cin : Cout, I = dgrad ? Cout : Cin;     // logical conv: O output, I input channels
     const size_t per = (size_t)nchunks * CoutPad * KC;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
         const int k = idx % KC;
@@ -125,56 +195,53 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
         const int o = t % CoutPad;
         const int chunk = t / CoutPad;
         const int i = chunk * KC + k;
-        float g[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                float v = 0.f;
-                if (o < O && i < I) {
-                    v = dgrad ? w[((size_t)i * Cin + o) * 9 + (2 - r) * 3 + (2 - s)]     // w[co = i][ci = o]
-                              : w[((size_t)o * Cin + i) * 9 + r * 3 + s];
-                }
-                g[r][s] = v;
-            }
-        // Gg (4x3), G rows: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
-        float a[4][3];
+        float a[AL][3];                   // a = G g   (rows of g transformed)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            a[0][s] = g[0][s];
-            a[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-            a[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-            a[3][s] = g[2][s];
+            float g[3], u[AL];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float v = 0.f;
+                if (o < O && i < I)
+                    v = dgrad ? w[((size_t)i * Cin + o) * 9 + (2 - r) * 3 + (2 - s)]      // w[co = i][ci = o]
+                              : w[((size_t)o * Cin + i) * 9 + r * 3 + s];
+                g[r] = v;
+            }
+            g_transform<MO>(g, u);
+#pragma unroll
+            for (int r = 0; r < AL; ++r) a[r][s] = u[r];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float u0 = a[r][0];
-            const float u1 = 0.5f * (a[r][0] + a[r][1] + a[r][2]);
-            const float u2 = 0.5f * (a[r][0] - a[r][1] + a[r][2]);
-            const float u3 = a[r][2];
-            p[(size_t)(r * 4 + 0) * per + idx] = u0;
-            p[(size_t)(r * 4 + 1) * per + idx] = u1;
-            p[(size_t)(r * 4 + 2) * per + idx] = u2;
-            p[(size_t)(r * 4 + 3) * per + idx] = u3;
+        for (int r = 0; r < AL; ++r) {
+            float u[AL];
+            g_transform<MO>(a[r], u);
+#pragma unroll
+            for (int s = 0; s < AL; ++s) p[(size_t)(r * AL + s) * per + idx] = u[s];
         }
     }
 }
 
-inline size_t tiles_padded(int N, int H, int W) {
-    const size_t T = (size_t)N * (H / 2) * (W / 2);
+inline size_t tiles_padded(int N, int H, int W, int m) {
+    const size_t T = (size_t)N * (H / m) * (W / m);
     return (T + 255) / 256 * 256;      // whole 8x32 GEMM tiles
 }
+inline int planes(int m) { return (m + 2) * (m + 2); }
 
 }  // namespace
 
-extern "C" size_t bbdm_winograd_packed_floats(int Cout, int CinPad) {
-    return (size_t)16 * cdiv(CinPad, KC) * (cdiv(Cout, 128) * 128) * KC;
+#define BBDM_WINO_M(m) BBDM_REQUIRE((m) == 2 || (m) == 4, "winograd: output tile m=%d unsupported (2 or 4)", (m))
+#define BBDM_WINO_HW(m, H, W) \
+    BBDM_REQUIRE((H) > 0 && (W) > 0 && (H) % (m) == 0 && (W) % (m) == 0, "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)
+
+extern "C" size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad) {
+    return (size_t)planes(m) * cdiv(CinPad, KC) * (cdiv(Cout, 128) * 128) * KC;
 }
 
-extern "C" int bbdm_winograd_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
-                                             void* stream) {
+extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* packed, int Cout, int Cin, int InPad,
+                                             int dgrad, void* stream) {
     // forward: conv Cin -> Cout, input tensor carries InPad >= Cin channels.
     // dgrad  : conv Cout -> Cin, its input (dY) carries InPad >= Cout channels.
+    BBDM_WINO_M(m);
     BBDM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && InPad % 4 == 0, "winograd_pack: bad args");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack: InPad too small");
     const int O = dgrad ? Cin : Cout;
@@ -182,48 +249,108 @@ extern "C" int bbdm_winograd_pack_weight_f32(const float* w_oihw, float* packed,
     const size_t per = (size_t)nchunks * CoutPad * KC;
     int blocks = (int)((per + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(winograd_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin,
-                       InPad, CoutPad, nchunks, dgrad);
+    if (m == 2)
+        hipLaunchKernelGGL(winograd_weight_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
+                           Cin, CoutPad, nchunks, dgrad);
+    else
+        hipLaunchKernelGGL(winograd_weight_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
+                           Cin, CoutPad, nchunks, dgrad);
     BBDM_CHECK_LAUNCH("winograd_pack");
     return BBDM_OK;
 }
 
-extern "C" size_t bbdm_winograd_workspace_floats(int N, int H, int W, int CinPad, int Cout) {
-    return (size_t)16 * tiles_padded(N, H, W) * ((size_t)CinPad + (size_t)Cout);
+extern "C" size_t bbdm_winograd_tiles(int m, int N, int H, int W) {
+    return (m == 2 || m == 4) ? tiles_padded(N, H, W, m) : 0;
 }
 
-extern "C" int bbdm_conv3x3_winograd_f32(const float* x, int ldx, const float* packed_wino, const float* bias,
+extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int CinPad, int Cout) {
+    if (m != 2 && m != 4) return 0;
+    return (size_t)planes(m) * tiles_padded(N, H, W, m) * ((size_t)CinPad + (size_t)Cout);
+}
+
+extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale,
+                                       const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
+                                       int CinPad, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(x && V && N > 0, "winograd_input: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    BBDM_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "winograd_input: upsample needs even H, W");
+    BBDM_REQUIRE(CinPad > 0 && CinPad % 4 == 0 && ldx % 4 == 0 && ldx >= CinPad, "winograd_input: CinPad=%d ldx=%d", CinPad, ldx);
+    BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)V) & 15) == 0, "winograd_input: 16-byte alignment");
+    BBDM_REQUIRE((pre_scale == nullptr) == (pre_bias == nullptr), "winograd_input: pre_scale / pre_bias must come together");
+    BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
+                 "winograd_input: pre_ld / alignment of the fused-producer coefficients");
+    const size_t T = (size_t)N * (H / m) * (W / m), Tp = tiles_padded(N, H, W, m);
+    const size_t vplane = Tp * (size_t)CinPad;
+    const long long units = (long long)T * (CinPad / 4);
+    long long blocks = (units + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t st = (hipStream_t)stream;
+#define BBDM_WINO_IN(MO, PRE, UP)                                                                                         \
+    hipLaunchKernelGGL((winograd_input_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, V, pre_scale, pre_bias, pre_ld, pre_silu, \
+                       N, H, W, CinPad, vplane)
+#define BBDM_WINO_IN_M(MO)                                                                      \
+    do {                                                                                        \
+        if (pre_scale) { if (upsample) BBDM_WINO_IN(MO, true, true); else BBDM_WINO_IN(MO, true, false); }   \
+        else           { if (upsample) BBDM_WINO_IN(MO, false, true); else BBDM_WINO_IN(MO, false, false); } \
+    } while (0)
+    if (m == 2) BBDM_WINO_IN_M(2); else BBDM_WINO_IN_M(4);
+#undef BBDM_WINO_IN_M
+#undef BBDM_WINO_IN
+    BBDM_CHECK_LAUNCH("winograd_input");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed_wino, float* M, int N, int H, int W,
+                                      int CinPad, int Cout, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(V && packed_wino && M && N > 0, "winograd_gemm: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    BBDM_REQUIRE(CinPad > 0 && CinPad % 4 == 0 && Cout % 4 == 0 && Cout > 0, "winograd_gemm: bad channel counts");
+    BBDM_REQUIRE((((uintptr_t)V | (uintptr_t)M | (uintptr_t)packed_wino) & 15) == 0, "winograd_gemm: 16-byte alignment");
+    const size_t Tp = tiles_padded(N, H, W, m);
+    BBDM_REQUIRE(Tp * (size_t)CinPad < (1ull << 32), "winograd_gemm: one transformed plane exceeds 2^32 elements");
+    const size_t wz = bbdm_winograd_packed_floats(m, Cout, CinPad) / planes(m);
+    return bbdm_conv1x1_batched(V, CinPad, Tp * (size_t)CinPad, packed_wino, wz, M, Cout, Tp * (size_t)Cout, planes(m),
+                                (int)(Tp / 32), 32, CinPad, Cout, (hipStream_t)stream);
+}
+
+extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
+                                        float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    BBDM_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldo % 4 == 0 && ldo >= Cout, "winograd_output: Cout=%d ldo=%d", Cout, ldo);
+    BBDM_REQUIRE((flags & ~BBDM_CONV_RES_PER_IMAGE) == 0, "winograd_output: unsupported flags 0x%x", flags);
+    BBDM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= Cout && ((uintptr_t)residual & 15) == 0), "winograd_output: ldr=%d", ldr);
+    BBDM_REQUIRE(!bias || ((uintptr_t)bias & 15) == 0, "winograd_output: bias alignment");
+    BBDM_REQUIRE((((uintptr_t)M | (uintptr_t)out) & 15) == 0, "winograd_output: 16-byte alignment");
+    const size_t T = (size_t)N * (H / m) * (W / m), Tp = tiles_padded(N, H, W, m);
+    const long long units = (long long)T * (Cout / 4);
+    long long blocks = (units + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0;
+    if (m == 2)
+        hipLaunchKernelGGL(winograd_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
+                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+    else
+        hipLaunchKernelGGL(winograd_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
+                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+    BBDM_CHECK_LAUNCH("winograd_output");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packed_wino, const float* bias,
                                          const float* residual, int ldr, float* out, int ldo, int flags, float* ws, int N,
                                          int H, int W, int CinPad, int Cout, void* stream) {
-    BBDM_REQUIRE(x && packed_wino && out && ws, "winograd: null pointer");
-    BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "winograd: H, W must be even (H=%d W=%d)", H, W);
-    BBDM_REQUIRE(CinPad % 4 == 0 && Cout % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= CinPad && ldo >= Cout,
-                 "winograd: channel counts / pitches must be multiples of 4");
-    BBDM_REQUIRE((flags & ~BBDM_CONV_RES_PER_IMAGE) == 0, "winograd: unsupported flags 0x%x", flags);
-    BBDM_REQUIRE(!residual || ldr % 4 == 0, "winograd: ldr");
-    BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)ws) & 15) == 0, "winograd: 16-byte alignment");
-    hipStream_t st = (hipStream_t)stream;
-    const size_t T = (size_t)N * (H / 2) * (W / 2), Tp = tiles_padded(N, H, W);
-    float* V = ws;                                   // [16][Tp][CinPad]
-    float* M = ws + (size_t)16 * Tp * CinPad;        // [16][Tp][Cout]
-    const size_t vplane = Tp * (size_t)CinPad, mplane = Tp * (size_t)Cout;
-    {
-        const long long units = (long long)T * (CinPad / 4);
-        long long blocks = (units + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, ldx, V, N, H, W, CinPad, vplane);
-    }
-    const size_t wz = bbdm_winograd_packed_floats(Cout, CinPad) / 16;
-    const int rc = bbdm_conv1x1_batched(V, CinPad, vplane, packed_wino, wz, M, Cout, mplane, 16, (int)(Tp / 32), 32, CinPad,
-                                        Cout, st);
-    if (rc != 0) return rc;
-    {
-        const long long units = (long long)T * (Cout / 4);
-        long long blocks = (units + 255) / 256;
-        if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)blocks), dim3(256), 0, st, M, mplane, Cout, bias, residual,
-                           ldr, (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0, out, ldo, N, H, W, Cout);
-    }
-    BBDM_CHECK_LAUNCH("winograd");
-    return BBDM_OK;
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(ws, "winograd: null workspace");
+    BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && CinPad > 0, "winograd: bad shape");
+    float* V = ws;                                                                    // [(m+2)^2][tiles][CinPad]
+    float* M = ws + (size_t)planes(m) * tiles_padded(N, H, W, m) * CinPad;            // [(m+2)^2][tiles][Cout]
+    int rc = bbdm_winograd_input_f32(m, x, ldx, V, nullptr, nullptr, 0, 0, 0, N, H, W, CinPad, stream);
+    if (rc == BBDM_OK) rc = bbdm_winograd_gemm_f32(m, V, packed_wino, M, N, H, W, CinPad, Cout, stream);
+    if (rc == BBDM_OK) rc = bbdm_winograd_output_f32(m, M, bias, residual, ldr, out, ldo, flags, N, H, W, Cout, stream);
+    return rc;
 }

@@ -83,30 +83,31 @@ def conv2d_nhwc(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
-def pack_winograd_weight(w: torch.Tensor, in_pad: Optional[int] = None, dgrad: bool = False) -> torch.Tensor:
-    """OIHW 3x3 fp32 -> G g G^T in the packed layout of :func:`conv3x3_winograd` (``dgrad``: the Cout -> Cin conv)."""
+def pack_winograd_weight(w: torch.Tensor, in_pad: Optional[int] = None, dgrad: bool = False, m: int = 2) -> torch.Tensor:
+    """OIHW 3x3 fp32 -> G g G^T of F(m x m, 3x3) in the packed layout of :func:`conv3x3_winograd` (``dgrad``: the
+    Cout -> Cin conv)."""
     _chk(w)
     cout, cin = w.shape[0], w.shape[1]
     src = cout if dgrad else cin
     in_pad = in_pad or (src + 3) // 4 * 4
-    n = _lib.load().bbdm_winograd_packed_floats(cin if dgrad else cout, in_pad)
+    n = _lib.load().bbdm_winograd_packed_floats(m, cin if dgrad else cout, in_pad)
     packed = torch.empty(n, dtype=torch.float32, device=w.device)
-    _lib.call("bbdm_winograd_pack_weight_f32", w.data_ptr(), packed.data_ptr(), cout, cin, in_pad, 1 if dgrad else 0,
+    _lib.call("bbdm_winograd_pack_weight_f32", m, w.data_ptr(), packed.data_ptr(), cout, cin, in_pad, 1 if dgrad else 0,
               _st(w))
     return packed
 
 
 def conv3x3_winograd(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                      residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                     res_per_image: bool = False) -> torch.Tensor:
-    """3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3): x [N, H, W, CinPad] -> [N, H, W, cout]."""
+                     res_per_image: bool = False, m: int = 2) -> torch.Tensor:
+    """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [N, H, W, CinPad] -> [N, H, W, cout]."""
     _chk(x, packed_w, bias, residual, out)
     N, H, W, cin_pad = x.shape
     if out is None:
         out = torch.empty(N, H, W, cout, dtype=torch.float32, device=x.device)
-    nws = _lib.load().bbdm_winograd_workspace_floats(N, H, W, cin_pad, cout)
-    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-    _lib.call("bbdm_conv3x3_winograd_f32", x.data_ptr(), cin_pad, packed_w.data_ptr(),
+    nws = _lib.load().bbdm_winograd_workspace_floats(m, N, H, W, cin_pad, cout)
+    ws = torch.empty(max(1, nws), dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv3x3_winograd_f32", m, x.data_ptr(), cin_pad, packed_w.data_ptr(),
               None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
               0 if residual is None else residual.shape[-1], out.data_ptr(), out.shape[-1], 2 if res_per_image else 0,
               ws.data_ptr(), N, H, W, cin_pad, cout, _st(x))

@@ -15,6 +15,7 @@ There is no PyTorch fallback: without the HIP library, or on a non-GPU tensor, `
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -245,6 +246,45 @@ class _PackedDgrad:
             self.key = key
 
 
+class _PackedWinograd:
+    """G g G^T of one 3x3 conv weight in the batched-GEMM layout (``dgrad``: of the data-gradient convolution)."""
+
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], in_pad: int, m: int, dgrad: bool = False):
+        self.weight, self.bias, self.dgrad, self.m = weight, bias, dgrad, m
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.ks, self.in_pad = 3, in_pad
+        n = _lib.load().bbdm_winograd_packed_floats(m, self.cin if dgrad else self.cout, in_pad)
+        self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        self.packed.cin_true = self.cout if dgrad else self.cin
+        self.key = None
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
+                      self.in_pad, 1 if self.dgrad else 0, stream)
+            self.key = key
+
+
+def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 4) -> int:
+    """Output tile m of the Winograd F(m x m, 3x3) path for this layer, or 0 = direct implicit GEMM.
+
+    Measured on MI355X (tools/wino_bench.py): the 2.25x (m = 2) / 4x (m = 4) cut in MFMA work must
+    outweigh the HBM passes of the two transforms -- (m+2)^2/m^2 x the input plus the same for the output -- which
+    needs wide layers (harmonic width cin*cout/(cin+cout)) and enough tiles to fill the chip with 256-row GEMM tiles."""
+    if cin % 4 or cout % 4 or cout < 128:
+        return 0
+    hw = cin * cout / (cin + cout)
+    if max_m >= 4 and H % 4 == 0 and W % 4 == 0 and cin >= 128 and hw >= 64 and N * (H // 4) * (W // 4) >= 256:
+        return 4
+    if max_m >= 2 and H % 2 == 0 and W % 2 == 0 and cin >= 256 and hw >= 100 and N * (H // 2) * (W // 2) >= 1024:
+        return 2
+    return 0
+
+
 # --------------------------------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------------------------------
@@ -359,6 +399,11 @@ class UNetModel(nn.Module):
         # 2.5 % streaming pass for ~5 % more time in the MFMA-bound conv at 256^2 (VALU + coefficient loads on the
         # staging path), so it is off by default; kept for the small-latent regime and as a tested kernel feature.
         self.fuse_groupnorm: bool = False
+        # 3x3 convolutions of wide layers through Winograd F(4x4,3x3) / F(2x2,3x3) (csrc/winograd.hip; `winograd_tile`
+        # picks per layer).  Plans are cached per setting, so this can be changed between calls (A/B runs).
+        # BBDM_WINOGRAD: largest output tile allowed, 4 (default), 2, or 0 = off.
+        self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "4"))
+        self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -403,7 +448,8 @@ class UNetModel(nn.Module):
 
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
-        key = (N, H, W, x.device.index, x.shape[1], training)
+        key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
+               self.winograd_fuse_groupnorm)
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
@@ -458,6 +504,8 @@ class _Plan:
         self._conv_ws_need = 0
         self._conv_ws = _LateTensor()             # split-K scratch shared by every conv of the plan
         self._conv_ws_floats = _LateInt()
+        self._wino_v, self._wino_m = _LateTensor(), _LateTensor()      # Winograd V / M planes shared by every layer
+        self._wino_v_need = self._wino_m_need = 0
         mc = m.model_channels
         ted = 4 * mc
         f32 = dict(dtype=torch.float32, device=device)
@@ -559,6 +607,8 @@ class _Plan:
                 lt.t = torch.empty(self._coeff_need, **f32)
         self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
         self._conv_ws_floats.v = self._conv_ws_need
+        self._wino_v.t = torch.empty(max(1, self._wino_v_need), **f32)
+        self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
         for b in self.bufs:
             b.tensor = torch.empty(max(1, b.numel), **f32)
         self.stats = torch.zeros(max(1, self._gn_count) * N * self.GROUPS * 2, dtype=torch.float64, device=device)
@@ -574,6 +624,10 @@ class _Plan:
             N, H, W, cin_pad, cout, ks = args[15:21]
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
             return 2.0 * N * H * W * cout * cin * ks * ks
+        if name == "bbdm_winograd_gemm_f32":        # the (m+2)^2 GEMMs actually executed: 2 (m+2)^2 tiles Cin Cout
+            wm, N, H, W, cin_pad, cout = args[0], *args[4:9]
+            cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
+            return 2.0 * (wm + 2) ** 2 * N * (H // wm) * (W // wm) * cin * cout
         if name == "bbdm_attention_f32":
             N, T, heads, ch = args[5:9]
             return 2.0 * 2.0 * N * heads * T * T * ch
@@ -646,13 +700,18 @@ class _Plan:
 
     NO_PRE = (None, None, 0, 0)
 
-    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str):
+    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None):
         """Input of a conv that follows GroupNorm [-> FiLM] [-> SiLU] at the same resolution.
 
         Inference plans do not materialise the normalised tensor: they emit the statistics + a tiny per-(image, channel)
         coefficient kernel and return (x itself, the fused-producer arguments of bbdm_conv2d_nhwc_f32).  Training plans
-        keep the explicit apply pass (the backward re-reads its output for the weight gradient)."""
-        if self.training or not self.m.fuse_groupnorm:
+        keep the explicit apply pass (the backward re-reads its output for the weight gradient).  The producer is folded
+        into the direct conv kernel only on request (``fuse_groupnorm``: it costs more MFMA stalls than the pass it
+        removes) but always into the HBM-bound Winograd input transform of ``consumer``, where it is
+        free."""
+        fuse = self.m.fuse_groupnorm or (consumer is not None and self.m.winograd_fuse_groupnorm
+                                         and self._winograd_ok(consumer, x.H, x.W, x.C))
+        if self.training or not fuse:
             return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
         N = self.N
         ref = _Plan._StatsRef(self, self._gn_count)
@@ -668,14 +727,45 @@ class _Plan:
                  x.C, N, x.H * x.W, x.C, self.GROUPS, float(gn.eps))
         return x, (sc, bi, x.C, silu)
 
+    def _winograd_ok(self, mod, H, W, cin_pad, flags=0) -> int:
+        """Winograd output tile for this conv (0 = direct kernel)."""
+        w = mod.weight
+        if not self.m.winograd or w.dim() != 4 or w.shape[2] != 3 or (flags & ~2) != 0:
+            return 0
+        return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd)
+
+    def _emit_winograd(self, x, cin_pad, pw, pre, upsample, H, W, residual, res_ld, dest, flags, bwd=False):
+        """input transform -> 16 batched GEMMs -> output transform (csrc/winograd.hip)."""
+        emit = self._bop if bwd else self._op
+        N, cout, wm = self.N, dest.C, pw.m
+        tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
+        self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad)
+        self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
+        emit("bbdm_winograd_input_f32", wm, x, x.ld, self._wino_v, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W,
+             cin_pad)
+        emit("bbdm_winograd_gemm_f32", wm, self._wino_v, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
+        emit("bbdm_winograd_output_f32", wm, self._wino_m,
+             self._pref(pw.bias) if pw.bias is not None and not bwd else None, residual, res_ld, dest, dest.ld, flags,
+             N, H, W, cout)
+
     def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0,
-                   pre=None):
-        """``residual`` is an NHWC view, or (with flags & 2) a per-image [N][res_ld] tensor reference."""
-        pc = self._conv(mod, x.C)
-        assert dest.C == pc.cout, (dest.C, pc.cout)
+                   pre=None, upsample: bool = False):
+        """``residual`` is an NHWC view, or (with flags & 2) a per-image [N][res_ld] tensor reference.
+        ``upsample``: the convolved tensor is the nearest x2 upsampling of ``x`` (Winograd path only)."""
+        cout = mod.weight.shape[0]
+        assert dest.C == cout, (dest.C, cout)
         if res_ld is None:
-            assert residual is None or residual.C == pc.cout
+            assert residual is None or residual.C == cout
             res_ld = residual.ld if residual is not None else 0
+        H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+        wm = self._winograd_ok(mod, H, W, x.C, flags)
+        if wm:
+            pw = _PackedWinograd(mod.weight, mod.bias, x.C, wm)
+            self.convs.append(pw)
+            self._emit_winograd(x, x.C, pw, pre, upsample, H, W, residual, res_ld, dest, flags)
+            return
+        assert not upsample
+        pc = self._conv(mod, x.C)
         self._conv_ws_need = max(self._conv_ws_need,
                                  self.lib.bbdm_conv_splitk_workspace_floats(self.N, x.H, x.W, x.C, pc.cout, pc.ks))
         self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias), residual, res_ld,
@@ -689,7 +779,7 @@ class _Plan:
         rs = 2 if rb.up else (1 if rb.down else 0)
         s1 = self._gn_count
         if rs == 0:
-            a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A")
+            a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A", consumer=rb.in_layers[2])
         else:       # up / down blocks resample between the activation and the conv: explicit apply pass
             a, pre1 = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A"), None
         xr = x if rs == 0 else self._gn_apply(x, None, None, 0, rs, name="XR")
@@ -700,7 +790,8 @@ class _Plan:
             self._emit_conv(a, rb.in_layers[2], _TensorRef(self.film, 4 * self.film_off[id(rb)]), h1,
                             res_ld=self.film_total, flags=2, pre=pre1)
         s2 = self._gn_count
-        a2, pre2 = self._gn_input(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, name="A2")
+        a2, pre2 = self._gn_input(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, name="A2",
+                                  consumer=rb.out_layers[3])
         out = dest if dest is not None else self._new(N, a.H, a.W, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
             self._emit_conv(xr, rb.skip_connection, None, out)
@@ -774,7 +865,10 @@ class _Plan:
         """Upsample.forward (openaimodel.py:111-121): nearest x2, then an optional 3x3 conv."""
         N = self.N
         out = dest if dest is not None else self._new(N, x.H * 2, x.W * 2, us.out_channels)
-        if us.use_conv:
+        if us.use_conv and not self.training and self._winograd_ok(us.conv, 2 * x.H, 2 * x.W, x.C):
+            u = None                 # nearest x2 folded into the Winograd input transform: the 4x tensor never exists
+            self._emit_conv(x, us.conv, None, out, upsample=True)
+        elif us.use_conv:
             u = self._gn_apply(x, None, None, 0, 2, name="XR")
             self._emit_conv(u, us.conv, None, out)
         else:
@@ -858,9 +952,16 @@ class _Plan:
                       gref(mod.bias) if mod.bias is not None else None, self._ws_f, N, x_in.H, x_in.W, x_in.C, cout, ks)
             if not need_dx:
                 return None
+            dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
+            wm = (winograd_tile(N, x_in.H, x_in.W, dy.C, x_in.C, m.winograd)
+                  if (m.winograd and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
+            if wm:
+                pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True)
+                self.dconvs.append(pk)
+                self._emit_winograd(dy, dy.C, pk, None, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
+                return dx
             pk = _PackedDgrad(w, dy.C)
             self.dconvs.append(pk)
-            dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
             self._conv_ws_need = max(self._conv_ws_need,
                                      lib.bbdm_conv_splitk_workspace_floats(N, x_in.H, x_in.W, dy.C, x_in.C, ks))
             self._bop("bbdm_conv2d_nhwc_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, 0,

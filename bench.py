@@ -213,6 +213,13 @@ def main():
                 oargs = plan.ops[k][1]
                 if name == "bbdm_conv2d_nhwc_f32":
                     shp = "N{} {}x{} {}->{} k{}".format(*oargs[15:21])
+                elif name == "bbdm_winograd_gemm_f32":
+                    shp = "N{} {}x{} {}->{} F({m}x{m},3x3) {p} GEMMs".format(*oargs[4:9], m=oargs[0], p=(oargs[0] + 2) ** 2)
+                elif name == "bbdm_winograd_input_f32":
+                    shp = "F{} N{} {}x{} C{} up{} fusedGN{}".format(oargs[0], oargs[9], oargs[10], oargs[11], oargs[12],
+                                                                    oargs[8], int(oargs[4] is not None))
+                elif name == "bbdm_winograd_output_f32":
+                    shp = "F{} N{} {}x{} C{}".format(oargs[0], *oargs[8:12])
                 elif name == "bbdm_attention_f32":
                     shp = "N{} T{} heads{} ch{}".format(*oargs[5:9])
                 elif name == "bbdm_groupnorm_apply_f32":
@@ -223,8 +230,17 @@ def main():
                     shp = ""
                 tf = fl / (ms * 1e-3) / 1e12 if ms > 0 and fl else 0.0
                 f.write(f"| {k} | {name.replace('bbdm_', '')} | {shp} | {ms:.3f} | {tf:.1f} |\n")
-    conv = by.get("bbdm_conv2d_nhwc_f32", [0, 0.0, 0.0])
-    total_flops_per_step = sum(v[2] for v in by.values()) / max(1, args.steps)
+    # conv_igemm_f32 is launched by the direct convolutions and by the 16-GEMM stage of the Winograd layers; the
+    # roofline counts the FLOPs the kernel EXECUTES (for a Winograd layer 4/9 of the direct-convolution FLOPs).
+    direct = by.get("bbdm_conv2d_nhwc_f32", [0, 0.0, 0.0])
+    wino = by.get("bbdm_winograd_gemm_f32", [0, 0.0, 0.0])
+    conv = [direct[0] + wino[0], direct[1] + wino[1], direct[2] + wino[2]]
+    executed_flops_per_step = sum(v[2] for v in by.values()) / max(1, args.steps)
+    # SURVEY.md §8d's algorithmic figure is the direct-convolution count: a Winograd GEMM stands for 2.25x its FLOPs
+    plan0 = next(iter(model.denoise_fn._plans.values()))
+    extra = sum(fl * (9.0 * oa[0] ** 2 / (oa[0] + 2) ** 2 - 1.0) for (nm, oa), fl in zip(plan0.ops, plan0.op_flops)
+                if nm == "bbdm_winograd_gemm_f32")              # per forward pass: direct count - executed count
+    total_flops_per_step = executed_flops_per_step + (extra if not training else 0.0)
     conv_launches = conv[0]
     conv_ms = conv[1]
     flops_per_launch = conv[2] / max(1, conv_launches)
@@ -263,11 +279,16 @@ def main():
             "img_steps_per_sec": steps_per_s_job * batch,
             "imgs_per_sec_whole_job": steps_per_s_job * batch / nsteps_table,
             "tflops_algorithmic": total_flops_per_step / (ms_per_step * 1e-3) / 1e12,
+            "tflops_executed": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic, "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
-                         "conv_share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None},
+                         "conv_share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,
+                         "flops_counted": "executed on the MFMA (Winograd layers: (m+2)^2 tile GEMMs = 4/9 (m=2) or 1/4 (m=4) of the direct count)",
+                         "winograd_gemm_launches_per_step": wino[0] / max(1, args.steps),
+                         "winograd_gemm_tflops": (wino[2] / (wino[1] * 1e-3) / 1e12) if wino[1] > 0 else None,
+                         "direct_conv_tflops": (direct[2] / (direct[1] * 1e-3) / 1e12) if direct[1] > 0 else None},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
         }
         if not args.no_cpu and world == 1:

@@ -75,24 +75,40 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
                          const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
-/* ---- 3x3 convolution through Winograd F(2x2,3x3) (same call sites, wide layers) ---------------------------- */
-/* Y = A^T[(G g G^T) (.) (B^T d B)]A: 16 multiplies per 2x2 outputs instead of 36 (2.25x fewer MFMA FLOP), the choice
- * cuDNN / MIOpen make for the reference's wide 3x3 layers (openaimodel.py:207,233,524).  stride 1, padding 1, H and W
- * even, CinPad % 4 == 0, Cout % 4 == 0.  Three launches: input transform -> 16 batched GEMMs on the fp32 MFMA
- * (conv_igemm_f32 in 1x1 mode) -> output transform (+ bias, + residual).  fp32 throughout; the transforms only use
- * 0, +-1, +-1/2 so the result agrees with the direct kernel to ~1e-6 relative.
+/* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2 or 4 (same call sites, wide layers) ------------- */
+/* Y = A^T[(G g G^T) (.) (B^T d B)]A: (m+2)^2 multiplies per m^2 outputs instead of 9 m^2 -- 2.25x (m = 2) or 4x (m = 4)
+ * fewer MFMA FLOP; the choice cuDNN / MIOpen make for the reference's wide 3x3 layers (openaimodel.py:207,233,524;
+ * their fp32 "Winograd non-fused" is m = 4).  stride 1, padding 1, H and W multiples of m, CinPad % 4 == 0,
+ * Cout % 4 == 0.  Three launches: input transform -> (m+2)^2 batched GEMMs on the fp32 MFMA (conv_igemm_f32 in 1x1
+ * mode) -> output transform (+ bias, + residual).  fp32 throughout; rounding error vs an fp64 convolution (rms / max,
+ * Cin = 512): direct 2e-7 / 3e-7, m = 2: 5e-7 / 6e-7, m = 4: 3e-6 / 1e-5.
  * packed_wino: bbdm_winograd_packed_floats() floats filled by bbdm_winograd_pack_weight_f32 (dgrad != 0 packs the
  * data-gradient convolution Cout -> Cin of the same filter: transposed + flipped; then InPad is the channel count of
  * dY and the forward entry is called with CinPad = InPad, Cout = Cin).
- * ws: bbdm_winograd_workspace_floats() floats (transformed input V[16][tiles][CinPad] + products M[16][tiles][Cout]).
- * flags: only BBDM_CONV_RES_PER_IMAGE. */
-size_t bbdm_winograd_packed_floats(int Cout, int CinPad);
-int bbdm_winograd_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
+ * ws: bbdm_winograd_workspace_floats() floats (transformed input V[(m+2)^2][tiles][CinPad] + products
+ * M[(m+2)^2][tiles][Cout]).  flags: only BBDM_CONV_RES_PER_IMAGE. */
+size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad);
+int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
                                   void* stream);
-size_t bbdm_winograd_workspace_floats(int N, int H, int W, int CinPad, int Cout);
-int bbdm_conv3x3_winograd_f32(const float* x, int ldx, const float* packed_wino, const float* bias,
+size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int CinPad, int Cout);
+int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packed_wino, const float* bias,
                               const float* residual, int ldr, float* out, int ldo, int flags, float* ws,
                               int N, int H, int W, int CinPad, int Cout, void* stream);
+/* The three stages on their own (what bbdm_conv3x3_winograd_f32 chains; a static plan calls them directly so that it
+ * can share V / M across layers, time each stage and fold the producer of the convolved tensor into stage 1).
+ * tiles = bbdm_winograd_tiles(m, N, H, W) = N (H/m)(W/m) rounded up to whole 256-row GEMM tiles.
+ *   input : x -> V[(m+2)^2][tiles][CinPad].  pre_scale / pre_bias / pre_ld / pre_silu: same fused GroupNorm [-> FiLM]
+ *           [-> SiLU] producer as bbdm_conv2d_nhwc_f32.  upsample != 0: x is [N, H/2, W/2, ldx] and the convolved tensor
+ *           is its nearest x2 upsampling (Upsample.forward, openaimodel.py:111-121) -- never materialised.
+ *   gemm  : M[xi] = V[xi] . U[xi] for the (m+2)^2 transform points, one launch.
+ *   output: M[(m+2)^2][tiles][Cout] -> out NHWC (+ bias, + residual; flags: BBDM_CONV_RES_PER_IMAGE). */
+size_t bbdm_winograd_tiles(int m, int N, int H, int W);
+int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale, const float* pre_bias,
+                            int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
+int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed_wino, float* M, int N, int H, int W, int CinPad,
+                           int Cout, void* stream);
+int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
+                             int ldo, int flags, int N, int H, int W, int Cout, void* stream);
 
 /* ---- convolution backward (training: autograd of the call sites above; the reference uses ATen's) -------- */
 /* Data gradient = the forward kernel run on dY with transposed + spatially flipped weights: pack them with this

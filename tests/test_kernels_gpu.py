@@ -80,19 +80,28 @@ def test_conv2d(dev, N, H, W, Cin, Cout, ks, res):
 
 
 WINO_CASES = [
-    # N, H, W, Cin, Cout, residual (0 none, 1 per pixel, 2 per image)
-    (2, 16, 16, 64, 128, 0),
-    (1, 32, 32, 256, 256, 1),
-    (3, 8, 12, 48, 72, 1),            # ragged tile count (padded to whole GEMM tiles), Cin not a multiple of 16
-    (2, 64, 64, 320, 384, 2),
-    (1, 2, 2, 16, 8, 0),              # a single tile
-    (5, 6, 4, 132, 260, 1),
+    # m, N, H, W, Cin, Cout, residual (0 none, 1 per pixel, 2 per image)
+    (2, 2, 16, 16, 64, 128, 0),
+    (2, 1, 32, 32, 256, 256, 1),
+    (2, 3, 8, 12, 48, 72, 1),            # ragged tile count (padded to whole GEMM tiles), Cin not a multiple of 16
+    (2, 2, 64, 64, 320, 384, 2),
+    (2, 1, 2, 2, 16, 8, 0),              # a single tile
+    (2, 5, 6, 4, 132, 260, 1),
+    (4, 2, 16, 16, 64, 128, 0),
+    (4, 1, 32, 32, 256, 256, 1),
+    (4, 3, 8, 12, 48, 72, 1),
+    (4, 2, 64, 64, 320, 384, 2),
+    (4, 1, 4, 4, 16, 8, 0),
+    (4, 5, 12, 4, 132, 260, 1),
+    (4, 1, 32, 32, 1024, 512, 1),        # long reduction: rounding error grows with sqrt(Cin)
 ]
-WINO_TOL = 5e-5      # F(2x2,3x3) in fp32: transforms use 0, +-1, +-1/2 only
+# rel_err is max|diff| / max|ref|.  F(2x2,3x3) transforms use 0, +-1, +-1/2 only; F(4x4,3x3) uses up to 8 (+ 1/24 in
+# the weights) and is ~10x noisier (csrc/winograd.hip header) -- both orders of magnitude inside the 1e-3 step bar.
+WINO_TOL = {2: 2e-5, 4: 1e-4}
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,res", WINO_CASES)
-def test_conv3x3_winograd(dev, N, H, W, Cin, Cout, res):
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,res", WINO_CASES)
+def test_conv3x3_winograd(dev, m, N, H, W, Cin, Cout, res):
     from bbdm_amd import ops
     g = torch.Generator().manual_seed(N * 1000 + H * 10 + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -109,24 +118,25 @@ def test_conv3x3_winograd(dev, N, H, W, Cin, Cout, res):
         ref = ref + r[:, :, None, None]
         rg = r.to(dev)
     xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
-    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cin)
-    out = ops.conv3x3_winograd(xg, pw, b.to(dev), Cout, residual=rg, res_per_image=(res == 2))
+    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cin, m=m)
+    out = ops.conv3x3_winograd(xg, pw, b.to(dev), Cout, residual=rg, res_per_image=(res == 2), m=m)
     torch.cuda.synchronize()
-    assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL
+    assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL[m]
     # and it agrees with the direct implicit-GEMM kernel on the same input
     direct = ops.conv2d_nhwc(xg, ops.pack_conv_weight(w.to(dev), cin_pad=Cin), b.to(dev), Cout, 3)
     if res == 1:
         direct = direct + rg
     elif res == 2:
         direct = direct + rg[:, None, None, :]
-    assert rel_err(out.cpu(), direct.cpu()) < WINO_TOL
+    assert rel_err(out.cpu(), direct.cpu()) < WINO_TOL[m]
     if res == 1:                      # in place: out aliases the residual
         buf = rg.clone()
-        ops.conv3x3_winograd(xg, pw, b.to(dev), Cout, residual=buf, out=buf)
-        assert rel_err(_nchw(buf.cpu()), ref.float()) < WINO_TOL
+        ops.conv3x3_winograd(xg, pw, b.to(dev), Cout, residual=buf, out=buf, m=m)
+        assert rel_err(_nchw(buf.cpu()), ref.float()) < WINO_TOL[m]
 
 
-def test_conv3x3_winograd_dgrad_and_slices(dev):
+@pytest.mark.parametrize("m", [2, 4])
+def test_conv3x3_winograd_dgrad_and_slices(dev, m):
     """Data gradient through the dgrad packing; input / output as channel slices of wider buffers."""
     from bbdm_amd import _lib, ops
     g = torch.Generator().manual_seed(11)
@@ -137,24 +147,64 @@ def test_conv3x3_winograd_dgrad_and_slices(dev):
     wide_in = torch.zeros(N, H, W, 200, device=dev)
     wide_in[..., 40:200] = _nhwc(dy).to(dev)
     wide_out = torch.zeros(N, H, W, 128, device=dev)
-    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cout, dgrad=True)
+    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cout, dgrad=True, m=m)
     lib = _lib.load()
-    ws = torch.empty(lib.bbdm_winograd_workspace_floats(N, H, W, Cout, Cin), device=dev)
-    _lib.call("bbdm_conv3x3_winograd_f32", wide_in.data_ptr() + 4 * 40, 200, pw.data_ptr(), None, None, 0,
+    ws = torch.empty(lib.bbdm_winograd_workspace_floats(m, N, H, W, Cout, Cin), device=dev)
+    _lib.call("bbdm_conv3x3_winograd_f32", m, wide_in.data_ptr() + 4 * 40, 200, pw.data_ptr(), None, None, 0,
               wide_out.data_ptr() + 4 * 16, 128, 0, ws.data_ptr(), N, H, W, Cout, Cin,
               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = wide_out.cpu()
-    assert rel_err(_nchw(got[..., 16:112]), ref) < WINO_TOL
+    assert rel_err(_nchw(got[..., 16:112]), ref) < WINO_TOL[m]
     assert float(got[..., :16].abs().max()) == 0 and float(got[..., 112:].abs().max()) == 0
 
 
-def test_conv3x3_winograd_rejects_odd(dev):
+@pytest.mark.parametrize("m,up,silu", [(2, 0, 1), (2, 1, 0), (2, 1, 1), (2, 0, 0), (4, 0, 1), (4, 1, 1), (4, 1, 0)])
+def test_winograd_stages_fused_producer(dev, m, up, silu):
+    """The three stages called separately, with the GroupNorm/FiLM/SiLU producer and the nearest x2 upsampling folded
+    into the input transform (zero padding applies to the activated, upsampled tensor)."""
     from bbdm_amd import _lib, ops
-    x = torch.zeros(1, 5, 4, 16, device=dev)
+    g = torch.Generator().manual_seed(21 + 2 * up + silu)
+    N, H, W, Cin, Cout = 3, 16, 24, 64, 96                    # conv resolution; the source is H/2 x W/2 when up
+    hs, ws_ = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(N, Cin, hs, ws_, generator=g)
+    sc = torch.randn(N, Cin, generator=g)
+    bi = torch.randn(N, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    a = x.double() * sc.double()[:, :, None, None] + bi.double()[:, :, None, None]
+    if silu:
+        a = F.silu(a)
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    ref = F.conv2d(a, w.double(), b.double(), padding=1).float()
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    xg, scg, big, bg = _nhwc(x).to(dev), sc.to(dev), bi.to(dev), b.to(dev)
+    pw = ops.pack_winograd_weight(w.to(dev), m=m)
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    assert tiles % 256 == 0 and tiles >= N * (H // m) * (W // m)
+    P = (m + 2) ** 2
+    V = torch.empty(P * tiles * Cin, device=dev)
+    M = torch.empty(P * tiles * Cout, device=dev)
+    out = torch.empty(N, H, W, Cout, device=dev)
+    _lib.call("bbdm_winograd_input_f32", m, xg.data_ptr(), Cin, V.data_ptr(), scg.data_ptr(), big.data_ptr(), Cin, silu, up,
+              N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_f32", m, V.data_ptr(), pw.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, st)
+    _lib.call("bbdm_winograd_output_f32", m, M.data_ptr(), bg.data_ptr(), None, 0, out.data_ptr(), Cout, 0, N, H, W, Cout, st)
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out.cpu()), ref) < WINO_TOL[m]
+
+
+def test_conv3x3_winograd_rejects_bad_shapes(dev):
+    from bbdm_amd import _lib, ops
     pw = ops.pack_winograd_weight(torch.zeros(16, 16, 3, 3, device=dev))
-    with pytest.raises(_lib.BBDMHipError, match="even"):
-        ops.conv3x3_winograd(x, pw, None, 16)
+    with pytest.raises(_lib.BBDMHipError, match="multiples of m"):
+        ops.conv3x3_winograd(torch.zeros(1, 5, 4, 16, device=dev), pw, None, 16)
+    with pytest.raises(_lib.BBDMHipError, match="multiples of m"):
+        ops.conv3x3_winograd(torch.zeros(1, 6, 8, 16, device=dev), pw, None, 16, m=4)
+    with pytest.raises(_lib.BBDMHipError, match="unsupported"):
+        ops.conv3x3_winograd(torch.zeros(1, 6, 6, 16, device=dev), pw, None, 16, m=3)
 
 
 def test_conv2d_channel_slices(dev):

@@ -137,3 +137,48 @@ def test_full_size_template_step_matches_oracle(dev):
     ea, eb = rel_err(a.cpu(), a_ref), rel_err(b.cpu(), b_ref)
     print(f"full-size step: rel err {ea:.2e} {eb:.2e}")
     assert ea < 1e-3 and eb < 1e-3
+
+
+def test_full_size_step_batch16_direct_and_winograd(dev):
+    """Same 237 M-parameter UNet at batch 16, where the wide layers of every level are large enough for the Winograd
+    path (bbdm_amd.unet.winograd_tile): one p_sample step against the CPU oracle (computed once) with the direct kernel
+    only (winograd = 0), F(2x2,3x3) and F(4x4,3x3).  The bar is the north star's 1e-3; the measured errors are printed
+    (MI355X: 3.2e-6 direct, 2.6e-6 F(2x2), 9.6e-6 F(4x4))."""
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    import bbdm_amd
+    up = dict(image_size=64, in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2,
+              attention_resolutions=(32, 16, 8), channel_mult=(1, 4, 8), conv_resample=True, dims=2, num_heads=8,
+              num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True, use_spatial_transformer=False,
+              context_dim=None, condition_key="SpatialRescaler")
+    bb = dict(mt_type="linear", objective="grad", loss_type="l1", skip_sample=True, sample_type="linear",
+              sample_step=200, num_timesteps=1000, eta=1.0, max_var=1.0)
+    m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(bb, UNetParams=up)}}))
+    shapes = [(k, tuple(v.shape)) for k, v in m.denoise_fn.state_dict().items()]
+    sd = synth_weights(shapes, 778, w_std=0.02)
+    m.denoise_fn.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    g = torch.Generator().manual_seed(4321)
+    N = 16
+    y = torch.randn(N, 3, 64, 64, generator=g).clamp(-1, 1)
+    x_t = torch.randn(N, 3, 64, 64, generator=g).clamp(-1, 1)
+    eps = torch.randn(N, 3, 64, 64, generator=g)
+    ora = O.OracleBBDM({"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), **bb)
+    i = 120
+    a_ref, b_ref = ora.p_sample(x_t, y, y, i, clip_denoised=False, noise=eps)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps.to(dev)
+    try:
+        for wino in (0, 2, 4):
+            m.denoise_fn.winograd = wino
+            a, b = m.p_sample(x_t.to(dev), y.to(dev), y.to(dev), i, clip_denoised=False)
+            torch.cuda.synchronize()
+            plan = m.denoise_fn._plan_for(torch.empty(N, 6, 64, 64, device=dev), False)
+            tiles = sorted({args[0] for name, args in plan.ops if name == "bbdm_winograd_gemm_f32"})
+            n_wino = sum(name == "bbdm_winograd_gemm_f32" for name, _ in plan.ops)
+            ea, eb = rel_err(a.cpu(), a_ref), rel_err(b.cpu(), b_ref)
+            print(f"batch-16 step, winograd={wino}: {n_wino} Winograd layers (tiles {tiles}); rel err {ea:.2e} {eb:.2e}")
+            assert (n_wino == 0) == (wino == 0) and (not tiles or max(tiles) == wino)
+            assert ea < 1e-3 and eb < 1e-3
+    finally:
+        torch.randn_like = orig

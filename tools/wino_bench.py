@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Direct implicit-GEMM 3x3 vs Winograd F(2x2,3x3) on the wide layers of the 256^2 / batch-16 step.
+"""Direct implicit-GEMM 3x3 vs Winograd F(2x2,3x3) / F(4x4,3x3) on the wide layers of the 256^2 / batch-16 step.
 
     python tools/wino_bench.py [--reps 5]
 Prints ms per shape for both paths (HIP events on the launch stream) and the max relative difference."""
@@ -27,6 +27,15 @@ SHAPES = [  # N, H, W, Cin, Cout
     (8, 32, 32, 512, 512),
     (8, 16, 16, 512, 512),
     (8, 64, 64, 256, 256),
+    (32, 64, 64, 128, 128),       # c3 / c4 (LBBDM-f4 latent, batch 32)
+    (32, 32, 32, 512, 512),
+    (32, 32, 32, 1024, 512),
+    (32, 16, 16, 1024, 1024),
+    (32, 16, 16, 2048, 1024),
+    (4, 32, 32, 512, 512),        # c1 (64^2 pixels, batch 4)
+    (4, 16, 16, 1024, 1024),
+    (32, 8, 8, 512, 512),         # c5 (LBBDM-f16 latent)
+    (32, 4, 4, 1024, 1024),
 ]
 
 
@@ -54,21 +63,29 @@ def main():
         x = torch.randn(N, H, W, Cin, device=dev)
         w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02
         b = torch.randn(Cout, device=dev)
-        pd, pw = ops.pack_conv_weight(w), ops.pack_winograd_weight(w)
+        pd = ops.pack_conv_weight(w)
         o1 = torch.empty(N, H, W, Cout, device=dev)
         o2 = torch.empty(N, H, W, Cout, device=dev)
-        ws = torch.empty(lib.bbdm_winograd_workspace_floats(N, H, W, Cin, Cout), device=dev)
         ms_d = _time(lambda: ops.conv2d_nhwc(x, pd, b, Cout, 3, out=o1), args.reps)
-        ms_w = _time(lambda: _lib.call("bbdm_conv3x3_winograd_f32", x.data_ptr(), Cin, pw.data_ptr(), b.data_ptr(), None,
-                                       0, o2.data_ptr(), Cout, 0, ws.data_ptr(), N, H, W, Cin, Cout, st), args.reps)
-        err = float((o1 - o2).abs().max() / o1.abs().max())
         fl = 18.0 * N * H * W * Cout * Cin
         td += ms_d
-        tw += ms_w
-        print(f"N{N} {H}x{W} {Cin}->{Cout}: direct {ms_d:8.3f} ms ({fl / ms_d / 1e9:6.1f} TF)  winograd {ms_w:8.3f} ms "
-              f"({fl / ms_w / 1e9:6.1f} TF-equivalent)  x{ms_d / ms_w:5.2f}  maxdiff {err:.2e}", flush=True)
-        del x, w, o1, o2, ws
-    print(f"total: direct {td:.2f} ms  winograd {tw:.2f} ms")
+        line = f"N{N} {H}x{W} {Cin}->{Cout}: direct {ms_d:8.3f} ms ({fl / ms_d / 1e9:6.1f} TF)"
+        best = ms_d
+        for m in (2, 4):
+            if H % m or W % m:
+                continue
+            pw = ops.pack_winograd_weight(w, m=m)
+            ws = torch.empty(lib.bbdm_winograd_workspace_floats(m, N, H, W, Cin, Cout), device=dev)
+            ms_w = _time(lambda: _lib.call("bbdm_conv3x3_winograd_f32", m, x.data_ptr(), Cin, pw.data_ptr(), b.data_ptr(),
+                                           None, 0, o2.data_ptr(), Cout, 0, ws.data_ptr(), N, H, W, Cin, Cout, st), args.reps)
+            err = float((o1 - o2).abs().max() / o1.abs().max())
+            line += f" | F{m}: {ms_w:8.3f} ms x{ms_d / ms_w:5.2f} maxdiff {err:.1e}"
+            best = min(best, ms_w)
+            del ws, pw
+        tw += best
+        print(line, flush=True)
+        del x, w, o1, o2
+    print(f"total: direct {td:.2f} ms  best-of(direct, F2, F4) {tw:.2f} ms")
 
 
 if __name__ == "__main__":
