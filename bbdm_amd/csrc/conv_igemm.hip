@@ -61,35 +61,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     constexpr int MT = BM / WM / 32, NTL = BN / WN / 32;
     const int TW = 1 << a.TWl, TH = 1 << a.THl;
     // ---- epilogue: + bias (+ residual) -> global --------------------------------------------------------
+    // Row loop outside, column tiles inside: the pixel index of a row is computed once and consumed at once.  (With the
+    // column tile outermost the compiler kept all MT*16 row addresses live across it and spilled accumulators to
+    // scratch -- ~190 scratch accesses per wave, a fixed ~35 us per tile that short-K GEMM tiles could not amortise.)
     const int hbase = tile_y * TH, wbase = tile_x * TW;
+    int co[NTL];
+    bool cok[NTL];
+    float bv[NTL];
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt) {
-        const int co = cout0 + wn * (BN / WN) + nt * 32 + (lane & 31);
-        const bool cok = co < a.Cout;
-        const float bv = (cok && a.bias) ? a.bias[co] : 0.0f;
+        co[nt] = cout0 + wn * (BN / WN) + nt * 32 + (lane & 31);
+        cok[nt] = co[nt] < a.Cout;
+        bv[nt] = (cok[nt] && a.bias) ? a.bias[co[nt]] : 0.0f;
+    }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int img_l = m >> (a.THl + a.TWl);
-                const int n = img0 + img_l;
-                const int h = hbase + ((m >> a.TWl) & (TH - 1));
-                const int w = wbase + (m & (TW - 1));
-                if (cok && img_l < a.imgs && n < a.N && h < a.H && w < a.W) {
-                    const size_t pix = (size_t)(n * a.H + h) * a.W + w;
-                    if (SPLIT) {                 // raw partial sum; bias / residual are applied by the reduce kernel
-                        a.ws[((size_t)blockIdx.y * a.N * a.H * a.W + pix) * a.ldw + co] = acc[mt][nt][r];
-                        continue;
-                    }
-                    float v = acc[mt][nt][r] + bv;
-                    if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co] : a.res[pix * a.ldr + co];
-                    if (a.out_nchw & 1)
-                        a.out[((size_t)(n * a.Cout + co) * a.H + h) * a.W + w] = v;
-                    else
-                        a.out[pix * a.ldo + co] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int m = wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int img_l = m >> (a.THl + a.TWl);
+            const int n = img0 + img_l;
+            const int h = hbase + ((m >> a.TWl) & (TH - 1));
+            const int w = wbase + (m & (TW - 1));
+            if (!(img_l < a.imgs && n < a.N && h < a.H && w < a.W)) continue;
+            const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                if (!cok[nt]) continue;
+                if (SPLIT) {                 // raw partial sum; bias / residual are applied by the reduce kernel
+                    a.ws[((size_t)blockIdx.y * a.N * a.H * a.W + pix) * a.ldw + co[nt]] = acc[mt][nt][r];
+                    continue;
                 }
+                float v = acc[mt][nt][r] + bv[nt];
+                if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co[nt]] : a.res[pix * a.ldr + co[nt]];
+                if (a.out_nchw & 1)
+                    a.out[((size_t)(n * a.Cout + co[nt]) * a.H + h) * a.W + w] = v;
+                else
+                    a.out[pix * a.ldo + co[nt]] = v;
             }
+            __builtin_amdgcn_sched_barrier(0);      // keep the rows sequential: no batching of address math
         }
     }
 }

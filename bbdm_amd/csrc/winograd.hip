@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
                     if (PRE) {
                         v.x = v.x * s4.x + b4.x; v.y = v.y * s4.y + b4.y;
                         v.z = v.z * s4.z + b4.z; v.w = v.w * s4.w + b4.w;
-                        if (pre_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                        if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
                     }
                 }
                 d[i] = v;

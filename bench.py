@@ -254,10 +254,12 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
-            for k, v in pm["kernels"].items():
-                if k.startswith("conv_igemm_f32"):
-                    traffic = {"bytes_per_launch": v["fabric_bytes_per_launch_corrected"], "source": os.path.basename(cands[-1]),
-                               "note": "L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included"}
+            hits = [v for k, v in pm["kernels"].items() if k.startswith("conv_igemm_f32")]
+            if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
+                nl = sum(v["launches"] for v in hits)
+                traffic = {"bytes_per_launch": sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in hits) / nl,
+                           "source": os.path.basename(cands[-1]),
+                           "note": "L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included"}
     except Exception:
         traffic = None
     ms_per_step = elapsed * 1e3 / args.steps
