@@ -262,6 +262,20 @@ def main():
                            "note": "L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included"}
     except Exception:
         traffic = None
+    # algorithmic HBM bytes of the dominant kernel per launch: operands read once + result written once
+    alg_bytes, alg_n = 0.0, 0
+    for nm, oa in plan0.ops:
+        if nm == "bbdm_winograd_gemm_f32":
+            wm, gN, gH, gW, gci, gco = oa[0], *oa[4:9]
+            P, T = (wm + 2) ** 2, gN * (gH // wm) * (gW // wm)
+            alg_bytes += 4.0 * (P * T * (gci + gco) + P * gci * gco)
+            alg_n += 1
+        elif nm == "bbdm_conv2d_nhwc_f32":
+            gN, gH, gW, gci, gco, gks = oa[15:21]
+            alg_bytes += 4.0 * (gN * gH * gW * (gci + gco) + gks * gks * gci * gco)
+            alg_n += 1
+    if traffic is not None and alg_n:
+        traffic["algorithmic_bytes_per_launch"] = alg_bytes / alg_n
     ms_per_step = elapsed * 1e3 / args.steps
     steps_per_s_job = dist_utils.aggregate_throughput(args.steps, elapsed, world)
 
