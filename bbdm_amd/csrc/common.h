@@ -46,6 +46,6 @@ int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed
                          int batch, int H, int W, int CinPad, int Cout, hipStream_t st);
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
-// hardware exp2 + reciprocal (~2 ulp): for kernels where the exact-division form above would make an HBM-bound pass
+// hardware v_exp_f32 + v_rcp_f32 (~2 ulp; __frcp_rn would expand to the full IEEE division sequence): for kernels where the exact-division form above would make an HBM-bound pass
 // ALU-bound (the Winograd input transform evaluates each activation (m+2)^2/m^2 times)
-__device__ __forceinline__ float silu_fast(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

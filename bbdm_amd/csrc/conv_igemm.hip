@@ -52,18 +52,25 @@ struct ConvArgs {
     // batched GEMM mode (gridDim.z = batch): per-batch element offsets of x / packed weights / out.  Used by the
     // Winograd path (16 transformed-domain GEMMs in one launch); bias, residual and split-K are off in this mode.
     int batch;
+    long long* dbg;
     size_t xz, wz, oz;
 };
 
-template <int BM, int BN, int WM, int WN, bool SPLIT>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tile_x,
-                                              int tile_y, int img0, int cout0, int wm, int wn, int lane) {
+// ---- epilogue: + bias (+ residual) -> global ----------------------------------------------------------------------
+// MODE 0: NHWC, no residual   1: NHWC + per-pixel residual   2: NHWC + per-image residual row   3: NCHW (the head)
+// 4: split-K partial sums.  The mode is a compile-time parameter because gfx9 counts loads AND stores in the one
+// in-order vmcnt: with a run-time `if (residual)` inside the row loop the compiler waits vmcnt(0) in front of every
+// element, i.e. for the previous store to complete -- 64 serialised stores = 38 us per tile (measured with per-workgroup
+// timestamps), 12 % of a K = 1024 tile.  Mode 0 issues nothing but stores; the residual modes fetch the residuals of
+// 8 rows, wait once, then store.
+// Row loop outside, column tiles inside: the pixel index of a row is computed once and consumed at once (with the column
+// tile outermost all MT*16 row addresses stayed live and accumulators were spilled to scratch).
+template <int BM, int BN, int WM, int WN, int MODE>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tile_x,
+                                                   int tile_y, int img0, int cout0, int wm, int wn, int lane) {
     constexpr int MT = BM / WM / 32, NTL = BN / WN / 32;
+    constexpr int RG = 8;                        // rows per residual batch
     const int TW = 1 << a.TWl, TH = 1 << a.THl;
-    // ---- epilogue: + bias (+ residual) -> global --------------------------------------------------------
-    // Row loop outside, column tiles inside: the pixel index of a row is computed once and consumed at once.  (With the
-    // column tile outermost the compiler kept all MT*16 row addresses live across it and spilled accumulators to
-    // scratch -- ~190 scratch accesses per wave, a fixed ~35 us per tile that short-K GEMM tiles could not amortise.)
     const int hbase = tile_y * TH, wbase = tile_x * TW;
     int co[NTL];
     bool cok[NTL];
@@ -72,36 +79,73 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     for (int nt = 0; nt < NTL; ++nt) {
         co[nt] = cout0 + wn * (BN / WN) + nt * 32 + (lane & 31);
         cok[nt] = co[nt] < a.Cout;
-        bv[nt] = (cok[nt] && a.bias) ? a.bias[co[nt]] : 0.0f;
+        bv[nt] = (MODE != 4 && cok[nt] && a.bias) ? a.bias[co[nt]] : 0.0f;
     }
+    // One explicit wait on the path that dominates every store: without it the waitcnt pass, unable to prove across the
+    // per-row branches that the bias load has landed, re-inserts vmcnt(0) in front of each store.
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) as a real S_WAITCNT the waitcnt pass accounts for
+    auto row_of = [&](int mt, int r, int& n, int& h, int& w) -> bool {
+        const int m = wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int img_l = m >> (a.THl + a.TWl);
+        n = img0 + img_l;
+        h = hbase + ((m >> a.TWl) & (TH - 1));
+        w = wbase + (m & (TW - 1));
+        return img_l < a.imgs && n < a.N && h < a.H && w < a.W;
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = wm * (BM / WM) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int img_l = m >> (a.THl + a.TWl);
-            const int n = img0 + img_l;
-            const int h = hbase + ((m >> a.TWl) & (TH - 1));
-            const int w = wbase + (m & (TW - 1));
-            if (!(img_l < a.imgs && n < a.N && h < a.H && w < a.W)) continue;
-            const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+        for (int r0 = 0; r0 < 16; r0 += RG) {
+            float rv[RG][NTL];
+            if (MODE == 1 || MODE == 2) {
 #pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) {
-                if (!cok[nt]) continue;
-                if (SPLIT) {                 // raw partial sum; bias / residual are applied by the reduce kernel
-                    a.ws[((size_t)blockIdx.y * a.N * a.H * a.W + pix) * a.ldw + co[nt]] = acc[mt][nt][r];
-                    continue;
+                for (int rr = 0; rr < RG; ++rr) {
+                    int n, h, w;
+                    const bool ok = row_of(mt, r0 + rr, n, h, w);
+                    const size_t roff = MODE == 2 ? (size_t)n * a.ldr : ((size_t)(n * a.H + h) * a.W + w) * a.ldr;
+#pragma unroll
+                    for (int nt = 0; nt < NTL; ++nt) rv[rr][nt] = (ok && cok[nt]) ? a.res[roff + co[nt]] : 0.0f;
                 }
-                float v = acc[mt][nt][r] + bv[nt];
-                if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co[nt]] : a.res[pix * a.ldr + co[nt]];
-                if (a.out_nchw & 1)
-                    a.out[((size_t)(n * a.Cout + co[nt]) * a.H + h) * a.W + w] = v;
-                else
-                    a.out[pix * a.ldo + co[nt]] = v;
+                __builtin_amdgcn_s_waitcnt(0x0F70);      // the batch has landed (same reason as above)
             }
-            __builtin_amdgcn_sched_barrier(0);      // keep the rows sequential: no batching of address math
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                const int r = r0 + rr;
+                int n, h, w;
+                if (!row_of(mt, r, n, h, w)) continue;
+                const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) {
+                    if (!cok[nt]) continue;
+                    float v = acc[mt][nt][r] + bv[nt];
+                    if (MODE == 1 || MODE == 2) v += rv[rr][nt];
+                    if (MODE == 4)          // raw partial sum; bias / residual are applied by the reduce kernel
+                        a.ws[((size_t)blockIdx.y * a.N * a.H * a.W + pix) * a.ldw + co[nt]] = acc[mt][nt][r];
+                    else if (MODE == 3) {
+                        if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co[nt]] : a.res[pix * a.ldr + co[nt]];
+                        a.out[((size_t)(n * a.Cout + co[nt]) * a.H + h) * a.W + w] = v;
+                    } else
+                        a.out[pix * a.ldo + co[nt]] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the row groups sequential: no batching of address math
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, bool SPLIT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tile_x,
+                                              int tile_y, int img0, int cout0, int wm, int wn, int lane) {
+    if (SPLIT)
+        conv_epilogue_rows<BM, BN, WM, WN, 4>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
+    else if (a.out_nchw & 1)
+        conv_epilogue_rows<BM, BN, WM, WN, 3>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
+    else if (!a.res)
+        conv_epilogue_rows<BM, BN, WM, WN, 0>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
+    else if (a.out_nchw & 2)
+        conv_epilogue_rows<BM, BN, WM, WN, 2>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
+    else
+        conv_epilogue_rows<BM, BN, WM, WN, 1>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
 }
 
 // ---- OIHW -> packed [tap][chunk][CoutPad][16] -------------------------------------------------------------
@@ -144,11 +188,13 @@ __device__ __forceinline__ int xcd_swizzled_block() {
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
 __global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
 conv_igemm_f32(const ConvArgs a_in) {
-    constexpr bool PRE = (VAR & 1) != 0, SPLIT = (VAR & 2) != 0;
+    constexpr bool PRE = (VAR & 1) != 0, SPLIT = (VAR & 2) != 0, GEMM = (VAR & 4) != 0;
     ConvArgs a = a_in;
     a.x += (size_t)blockIdx.z * a.xz;
     a.w += (size_t)blockIdx.z * a.wz;
     a.out += (size_t)blockIdx.z * a.oz;
+    long long tdbg0 = 0, tdbg1 = 0, tdbg2 = 0;
+    if (a.dbg) tdbg0 = wall_clock64();
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 32;     // 32-row MFMA tiles per wave (M)
     constexpr int NTL = BN / WN / 32;    // 32-col MFMA tiles per wave (N)
@@ -230,7 +276,7 @@ conv_igemm_f32(const ConvArgs a_in) {
     float4 preg[PSLOTS];
     float4 wreg[WSLOTS];
 
-    auto load_patch = [&](int chunk) {
+    auto load_patch_to = [&](float4 (&preg)[PSLOTS], int chunk) {
         const int cbase = chunk * KC;
 #pragma unroll
         for (int s = 0; s < PSLOTS; ++s) {
@@ -241,6 +287,14 @@ conv_igemm_f32(const ConvArgs a_in) {
                 preg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    auto store_patch_from = [&](float4 (&preg)[PSLOTS], float* dst) {
+#pragma unroll
+        for (int s = 0; s < PSLOTS; ++s) {
+            const int f = tid + s * NTHR;
+            if (f < nPatchVec) *reinterpret_cast<float4*>(dst + (f >> 2) * KP + (f & 3) * 4) = preg[s];
+        }
+    };
+    auto load_patch = [&](int chunk) { load_patch_to(preg, chunk); };
     auto store_patch = [&](float* dst, int chunk) {
         if (PRE) {
             // fused GroupNorm affine (+ FiLM) (+ SiLU) on the valid elements; padding stays exactly zero
@@ -292,6 +346,49 @@ conv_igemm_f32(const ConvArgs a_in) {
 
     const int nphase = chunk_end * a.taps;
     int chunk = chunk_begin, tap = 0;
+    if (a.dbg) tdbg1 = wall_clock64();
+    auto mfma_phase = [&](const float* P, const float* Wb) {
+#pragma unroll
+        for (int kg = 0; kg < KC / 8; ++kg) {
+            float4 af[MT], bf[NTL];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(P + abase[mt] + kg * 8);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) bf[nt] = *reinterpret_cast<const float4*>(Wb + bbase[nt] + kg * 8);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].x, bf[nt].x, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].y, bf[nt].y, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].z, bf[nt].z, acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt].w, bf[nt].w, acc[mt][nt], 0, 0, 0);
+                }
+        }
+    };
+    if constexpr (GEMM) {
+        // One tap per chunk (plain GEMM, the Winograd tile GEMMs): every phase needs a fresh activation tile straight
+        // from HBM, and one phase of compute (~3.4 us with two workgroups per CU) does not cover that latency under
+        // load -- measured 4.6 us per phase.  The activation tile is therefore requested TWO phases ahead (two register
+        // sets, loop unrolled by two so that they keep static names); the weight slab (L2-resident) stays one ahead.
+        float4 preg2[PSLOTS];
+        auto gemm_phase = [&](int phase, float4 (&cur)[PSLOTS], float4 (&nxt)[PSLOTS]) {
+            // cur holds chunk phase+1 (requested during the previous phase); nxt receives chunk phase+2
+            if (phase + 1 < nphase) load_w(phase + 1);
+            if (phase + 2 < nphase) load_patch_to(nxt, phase + 2);
+            mfma_phase(pbuf + (phase & 1) * patchFloats, wbuf + (phase & 1) * (BN * KP));
+            if (phase + 1 < nphase) {
+                store_w(wbuf + ((phase + 1) & 1) * (BN * KP));
+                store_patch_from(cur, pbuf + ((phase + 1) & 1) * patchFloats);
+            }
+            __syncthreads();
+        };
+        if (phase_begin + 1 < nphase) load_patch_to(preg, phase_begin + 1);
+        for (int phase = phase_begin; phase < nphase; phase += 2) {
+            gemm_phase(phase, preg, preg2);
+            if (phase + 1 < nphase) gemm_phase(phase + 1, preg2, preg);
+        }
+    } else
     for (int phase = phase_begin; phase < nphase; ++phase) {
         const bool has_next = phase + 1 < nphase;
         const bool last_tap = tap == a.taps - 1;
@@ -325,7 +422,16 @@ conv_igemm_f32(const ConvArgs a_in) {
         if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
     }
 
+    if (a.dbg) tdbg2 = wall_clock64();
     conv_epilogue<BM, BN, WM, WN, SPLIT>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
+    if (a.dbg && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        long long* d = a.dbg + (size_t)lin * 8;
+        d[0] = tdbg0; d[1] = tdbg1; d[2] = tdbg2; d[3] = wall_clock64();
+        d[4] = __builtin_amdgcn_s_getreg(63492);     // HW_ID
+        d[5] = __builtin_amdgcn_s_getreg(63508);     // XCC_ID
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -657,6 +763,13 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
             goto launched;
         }
     }
+    if constexpr (BM == 256 && PSLOTS == 2) {        // the batched tile-GEMM instantiation (bbdm_conv1x1_batched)
+        if (var == 0 && a.taps == 1) {
+            lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 4>(a, lds, blocks, stream);
+            if (lrc != 0) return lrc;
+            goto launched;
+        }
+    }
     switch (var) {
         case 0: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 0>(a, lds, blocks, stream); break;
         case 1: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 1>(a, lds, blocks, stream); break;
@@ -735,6 +848,9 @@ extern "C" size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int Cin
 
 // Batched 1x1 "convolution" = `batch` independent GEMMs [pixels x CinPad] x [CinPad x Cout] in one launch (used by the
 // Winograd path; declared in common.h).  x / packed_w / out advance by xz / wz / oz floats per batch element.
+static long long* g_conv_trace = nullptr;
+extern "C" void bbdm_debug_conv_trace(long long* p) { g_conv_trace = p; }
+
 int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed_w, size_t wz, float* out, int ldo, size_t oz,
                          int batch, int H, int W, int CinPad, int Cout, hipStream_t st) {
     ConvArgs a;
@@ -746,8 +862,9 @@ int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed
     a.ws = nullptr; a.ws_cap = 0; a.ldw = (Cout + 3) & ~3;
     a.pre_sc = nullptr; a.pre_bi = nullptr; a.pre_ld = 0; a.pre_silu = 0;
     a.batch = batch; a.xz = xz; a.wz = wz; a.oz = oz;
+    a.dbg = g_conv_trace;
     a.splits = 1;
-    int rc = launch_conv<256, 128, 4, 2, 3, 2>(a, st);
+    int rc = launch_conv<256, 128, 4, 2, 2, 2>(a, st);
     if (rc == 1) {
         bbdm_set_error("conv1x1_batched: tile configuration does not fit H=%d W=%d", H, W);
         return BBDM_E_BADARG;
@@ -780,7 +897,7 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
                  "conv2d: pre_ld / alignment of the fused-producer coefficients");
     a.pre_sc = pre_scale; a.pre_bi = pre_bias; a.pre_ld = pre_ld; a.pre_silu = pre_silu;
-    a.batch = 1; a.xz = a.wz = a.oz = 0;
+    a.batch = 1; a.xz = a.wz = a.oz = 0; a.dbg = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     const ConvPlan plan = conv_plan(M, Cout, a.nchunks);
