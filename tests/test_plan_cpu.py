@@ -1,0 +1,93 @@
+"""Host logic of the execution plan (no GPU): the per-layer Winograd / direct choice, the consistency of the emitted
+op list and the FLOP accounting bench.py reports.  Plans are built on CPU tensors -- construction only queries the
+C-ABI's host-side size functions and allocates buffers; nothing is launched."""
+import collections
+
+import pytest
+import torch
+
+import bench
+from bbdm_amd import _lib, unet
+
+
+def _plan(workload, batch=None, training=False, winograd=4):
+    desc, up, ch, size, n, *_ = bench.WORKLOADS[workload]
+    m = unet.UNetModel(**up)
+    m.winograd = winograd
+    x = torch.zeros(batch or n, up["in_channels"], size, size)
+    return m, m._plan_for(x, training)
+
+
+def test_winograd_tile_choice_follows_the_measured_crossovers():
+    wt = unet.winograd_tile
+    # profiles/r01_wino_bench.txt (MI355X): F(4x4) wins on every wide layer with >= 256 tiles ...
+    assert wt(16, 64, 64, 1024, 1024) == 4
+    assert wt(16, 256, 256, 128, 128) == 4          # 1.27x
+    assert wt(16, 128, 128, 128, 512) == 4          # 1.46x
+    assert wt(4, 32, 32, 512, 512) == 4             # 256 tiles: 1.50x
+    # ... loses below that (padded GEMM tiles, launch-bound), where F(2x2) does not pay either
+    assert wt(4, 16, 16, 1024, 1024) == 0           # 0.55x / 0.98x
+    assert wt(32, 4, 4, 1024, 1024) == 0
+    assert wt(32, 8, 8, 512, 512) == 0
+    # the stem / head / narrow outputs stay on the direct kernel
+    assert wt(16, 256, 256, 8, 128) == 0 and wt(16, 256, 256, 128, 3) == 0 and wt(16, 64, 64, 64, 64) == 0
+    # H, W not multiples of 4 -> F(2x2) if the layer is wide and large enough, else direct
+    assert wt(16, 66, 66, 512, 512) == 2 and wt(16, 66, 66, 128, 128) == 0 and wt(16, 33, 33, 512, 512) == 0
+    # the cap (UNetModel.winograd / BBDM_WINOGRAD)
+    assert wt(16, 64, 64, 1024, 1024, 2) == 2 and wt(16, 64, 64, 1024, 1024, 0) == 0
+
+
+@pytest.mark.parametrize("workload,batch,training", [("c1", 4, False), ("c1", 16, False), ("c1", 16, True), ("c5", 32, False)])
+def test_plan_ops_are_consistent(workload, batch, training):
+    lib = _lib.load()
+    m, plan = _plan(workload, batch, training)
+    ops = list(plan.ops) + (list(plan.bops) if training else [])
+    names = collections.Counter(n for n, _ in ops)
+    assert names["bbdm_winograd_input_f32"] == names["bbdm_winograd_gemm_f32"] == names["bbdm_winograd_output_f32"]
+    for k, (name, a) in enumerate(ops):
+        if name != "bbdm_winograd_input_f32":
+            continue
+        (n1, i), (n2, g), (n3, o) = ops[k], ops[k + 1], ops[k + 2]
+        assert (n2, n3) == ("bbdm_winograd_gemm_f32", "bbdm_winograd_output_f32")       # emitted as a triple
+        wm = i[0]
+        N, H, W, cin = i[9:13]
+        assert wm in (2, 4) and g[0] == wm and o[0] == wm
+        assert H % wm == 0 and W % wm == 0 and cin % 4 == 0
+        assert tuple(g[4:8]) == (N, H, W, cin) and tuple(o[8:11]) == (N, H, W) and o[11] == g[8]
+        cout = g[8]
+        up = i[8]
+        src = i[1]                                            # the view being convolved
+        assert (src.H, src.W) == ((H // 2, W // 2) if up else (H, W)) and src.C == cin
+        tiles = lib.bbdm_winograd_tiles(wm, N, H, W)
+        P = (wm + 2) ** 2
+        assert tiles % 256 == 0 and tiles >= N * (H // wm) * (W // wm)
+        assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
+        assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
+        assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) == wm
+    if training:
+        assert names["bbdm_conv_wgrad_f32"] > 0
+        fwd_wino = sum(n == "bbdm_winograd_gemm_f32" for n, _ in plan.ops)
+        bwd_wino = sum(n == "bbdm_winograd_gemm_f32" for n, _ in plan.bops)
+        assert fwd_wino > 0 and bwd_wino > 0                  # forward and data-gradient convolutions both take it
+
+
+def test_flop_accounting_direct_equivalent_matches_the_direct_plan():
+    """bench.py reports `tflops_executed` (what the MFMA runs) and `tflops_algorithmic` (SURVEY.md §8d's direct
+    count): a Winograd GEMM executing F FLOP stands for F * 9 m^2 / (m+2)^2 FLOP of direct convolution."""
+    _, direct = _plan("c1", 16, winograd=0)
+    assert not any(n.startswith("bbdm_winograd") for n, _ in direct.ops)
+    want = sum(direct.op_flops)
+    for cap in (2, 4):
+        _, plan = _plan("c1", 16, winograd=cap)
+        executed = sum(plan.op_flops)
+        equiv = sum(f * (9.0 * a[0] ** 2 / (a[0] + 2) ** 2 if n == "bbdm_winograd_gemm_f32" else 1.0)
+                    for (n, a), f in zip(plan.ops, plan.op_flops))
+        assert executed < want and abs(equiv - want) < 1e-6 * want
+
+
+def test_fused_producers_only_in_inference_plans():
+    _, inf = _plan("c1", 16)
+    _, trn = _plan("c1", 16, training=True)
+    fused = lambda p: sum(n == "bbdm_winograd_input_f32" and a[4] is not None for n, a in p.ops)
+    assert fused(inf) > 0 and fused(trn) == 0        # training keeps the normalised tensor for the weight gradient
+    assert sum(n == "bbdm_groupnorm_coeffs_f32" for n, _ in trn.ops) == 0
