@@ -176,3 +176,56 @@ def test_batch_larger_than_64(dev):
         out = m.denoise_fn(x0.to(dev), timesteps=t.to(dev), context=None)
         ref_out = ora.denoise(x0, t, None)
     assert rel_err(out.cpu(), ref_out.detach()) < 1e-4
+
+
+def test_gradients_through_winograd_layers(dev):
+    """A UNet wide and large enough (128 / 256 channels, batch 16, 32x32) for the forward AND the data-gradient
+    convolutions to take the Winograd F(4x4,3x3) path (bbdm_amd.unet.winograd_tile): loss and every parameter gradient
+    against autograd on the CPU oracle, with the Winograd path and -- same weights, same batch -- with the direct kernel
+    only.  (The golden-fixture models above are too narrow for the Winograd path.)  Kept last in the file on purpose."""
+    import bbdm_amd
+    from fixture_weights import synth_weights
+    up = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=1,
+              attention_resolutions=(2,), channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=8,
+              num_head_channels=64, use_scale_shift_norm=True, resblock_updown=True, use_spatial_transformer=False,
+              context_dim=None, condition_key="nocond")
+    bb = dict(mt_type="linear", objective="grad", loss_type="l1", skip_sample=True, sample_type="linear",
+              sample_step=50, num_timesteps=1000, eta=1.0, max_var=1.0)
+    m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(bb, UNetParams=up)}}))
+    shapes = [(k, tuple(v.shape)) for k, v in m.denoise_fn.state_dict().items()]
+    sd = synth_weights(shapes, 4242, w_std=0.02)
+    m.denoise_fn.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(99)
+    N = 16
+    x0 = torch.randn(N, 3, 32, 32, generator=g).clamp(-1, 1)
+    y = torch.randn(N, 3, 32, 32, generator=g).clamp(-1, 1)
+    t = torch.randint(0, 1000, (N,), generator=g)
+    nz = torch.randn(N, 3, 32, 32, generator=g)
+    # oracle
+    osd = {"denoise_fn." + k: v.clone().requires_grad_() for k, v in sd.items()}
+    ora = O.OracleBBDM(osd, O.UNetSpec(**up), **bb)
+    lo, _ = ora.p_losses(x0, y, None, t, nz)
+    lo.backward()
+    g_ref = {k[len("denoise_fn."):]: v.grad for k, v in osd.items()}
+    gmax = max(float(v.abs().max()) for v in g_ref.values())
+    m = m.to(dev).train()
+    for wino in (4, 0):
+        m.denoise_fn.winograd = wino
+        m.zero_grad(set_to_none=True)
+        loss, _ = m.p_losses(x0.to(dev), y.to(dev), None, t.to(dev), nz.to(dev))
+        loss.backward()
+        torch.cuda.synchronize()
+        plan = m.denoise_fn._plan_for(x0.to(dev), True)
+        fw = sum(n == "bbdm_winograd_gemm_f32" for n, _ in plan.ops)
+        bw = sum(n == "bbdm_winograd_gemm_f32" for n, _ in plan.bops)
+        assert (fw > 0 and bw > 0) if wino else (fw == 0 and bw == 0)
+        errs = []
+        for k, p in m.denoise_fn.named_parameters():
+            ref = g_ref[k]
+            scale = max(float(ref.abs().max()), 1e-3 * gmax)
+            errs.append((float((p.grad.cpu() - ref).abs().max()) / scale, k))
+        errs.sort(reverse=True)
+        print(f"winograd={wino}: {fw} forward + {bw} data-gradient Winograd layers; loss {float(loss.detach()):.6f} "
+              f"(ref {float(lo.detach()):.6f}); worst gradient errors: " + "; ".join(f"{k} {e:.2e}" for e, k in errs[:3]))
+        assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5 * max(1.0, abs(float(lo.detach())))
+        assert errs[0][0] < GRAD_TOL, errs[0]
