@@ -229,3 +229,40 @@ def test_gradients_through_winograd_layers(dev):
               f"(ref {float(lo.detach()):.6f}); worst gradient errors: " + "; ".join(f"{k} {e:.2e}" for e, k in errs[:3]))
         assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5 * max(1.0, abs(float(lo.detach())))
         assert errs[0][0] < GRAD_TOL, errs[0]
+
+
+def test_upsample_conv_folded_into_the_winograd_input_transform(dev):
+    """`resblock_updown=False` models resample with `Upsample` (nearest x2 + 3x3 conv) / `Downsample` (stride-2 conv):
+    in inference plans the nearest x2 is folded into the Winograd input transform of the conv (the 4x tensor is never
+    written).  Forward parity against the CPU oracle, Winograd path and direct-only, on a model wide enough to take it."""
+    import bbdm_amd
+    from fixture_weights import synth_weights
+    up = dict(image_size=32, in_channels=3, model_channels=128, out_channels=3, num_res_blocks=1,
+              attention_resolutions=(2,), channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=8,
+              num_head_channels=64, use_scale_shift_norm=True, resblock_updown=False, use_spatial_transformer=False,
+              context_dim=None, condition_key="nocond")
+    bb = dict(mt_type="linear", objective="grad", loss_type="l1", skip_sample=True, sample_type="linear",
+              sample_step=50, num_timesteps=1000, eta=1.0, max_var=1.0)
+    m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(bb, UNetParams=up)}}))
+    shapes = [(k, tuple(v.shape)) for k, v in m.denoise_fn.state_dict().items()]
+    sd = synth_weights(shapes, 515, w_std=0.02)
+    m.denoise_fn.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(17)
+    N = 16
+    x = torch.randn(N, 3, 32, 32, generator=g).clamp(-1, 1)
+    t = torch.randint(0, 1000, (N,), generator=g)
+    ora = O.OracleBBDM({"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), **bb)
+    with torch.no_grad():
+        ref = ora.denoise(x, t, None)
+    m = m.to(dev).eval()
+    for wino in (4, 0):
+        m.denoise_fn.winograd = wino
+        with torch.no_grad():
+            out = m.denoise_fn(x.to(dev), timesteps=t.to(dev), context=None)
+        torch.cuda.synchronize()
+        plan = m.denoise_fn._plan_for(x.to(dev), False)
+        folded = sum(n == "bbdm_winograd_input_f32" and a[8] == 1 for n, a in plan.ops)
+        assert folded == (1 if wino else 0)
+        e = rel_err(out.cpu(), ref)
+        print(f"winograd={wino}: {folded} upsample conv folded; UNet forward rel err {e:.2e}")
+        assert e < 1e-4
