@@ -1,0 +1,59 @@
+"""The Winograd F(m x m, 3x3) algebra used by csrc/winograd.hip, restated with explicit matrices (CPU, no GPU):
+B^T, G, A^T below are the matrices the HIP kernels hard-code as adds / multiplies (bt_transform, g_transform,
+at_transform).  Checks that they reproduce a 3x3 'same' convolution exactly in fp64, that the data-gradient variant
+(transposed + flipped filter) is the transposed convolution, and the fp32 rounding levels DESIGN.md §4.5 quotes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+MATS = {
+    2: (torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1.]], dtype=torch.float64),
+        torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1.]], dtype=torch.float64),
+        torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1.]], dtype=torch.float64)),
+    4: (torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                      [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1.]], dtype=torch.float64),
+        torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+                      [1 / 24, -1 / 12, 1 / 6], [0, 0, 1.]], dtype=torch.float64),
+        torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1.]],
+                     dtype=torch.float64)),
+}
+
+
+def winograd_conv(x, w, m, dtype):
+    """x [N,C,H,W], w [K,C,3,3] -> [N,K,H,W]; every stage in `dtype` (the HIP path: fp32)."""
+    BT, G, AT = (t.to(dtype) for t in MATS[m])
+    x, w = x.to(dtype), w.to(dtype)
+    a = m + 2
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    tiles = F.pad(x, (1, 1, 1, 1)).unfold(2, a, m).unfold(3, a, m)            # N, C, th, tw, a, a
+    V = torch.einsum("ij,nctwjk,lk->nctwil", BT, tiles, BT)                  # input transform  B^T d B
+    U = torch.einsum("ij,kcjl,ml->kcim", G, w, G)                            # filter transform G g G^T
+    M = torch.einsum("nctwil,kcil->nktwil", V, U)                            # (m+2)^2 independent GEMMs over c
+    Y = torch.einsum("ij,nktwjl,ml->nktwim", AT, M, AT)                      # output transform A^T m A
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, K, H, W)
+
+
+@pytest.mark.parametrize("m", [2, 4])
+def test_exact_in_fp64(m):
+    g = torch.Generator().manual_seed(m)
+    x = torch.randn(2, 5, 8, 12, generator=g, dtype=torch.float64)
+    w = torch.randn(7, 5, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, padding=1)
+    assert float((winograd_conv(x, w, m, torch.float64) - ref).abs().max()) < 1e-12
+    # data gradient = the same algorithm on the transposed, spatially flipped filter (winograd_weight_kernel, dgrad)
+    dy = torch.randn(2, 7, 8, 12, generator=g, dtype=torch.float64)
+    wd = w.transpose(0, 1).flip(2, 3)
+    assert float((winograd_conv(dy, wd, m, torch.float64) - F.conv_transpose2d(dy, w, padding=1)).abs().max()) < 1e-12
+
+
+def test_fp32_rounding_levels():
+    """rms error relative to the rms of the fp64 result, Cin = 512, unit-variance post-SiLU-like activations."""
+    g = torch.Generator().manual_seed(0)
+    x = F.silu(torch.randn(1, 512, 16, 16, generator=g))
+    w = torch.randn(64, 512, 3, 3, generator=g) * 0.02
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    rms = lambda y: float(((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+    e_direct, e2, e4 = rms(F.conv2d(x, w, padding=1)), rms(winograd_conv(x, w, 2, torch.float32)), rms(winograd_conv(x, w, 4, torch.float32))
+    assert e_direct < 1e-6 and e2 < 2e-6 and e4 < 1e-5          # measured: 2e-7, 5e-7, 3e-6
+    assert e2 < e4                                              # F(4x4) is the noisier one, by about an order of magnitude
