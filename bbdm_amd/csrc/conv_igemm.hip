@@ -372,6 +372,48 @@ conv_igemm_f32(const ConvArgs a_in) {
         // load -- measured 4.6 us per phase.  The activation tile is therefore requested TWO phases ahead (two register
         // sets, loop unrolled by two so that they keep static names); the weight slab (L2-resident) stays one ahead.
         float4 preg2[PSLOTS];
+        constexpr bool STRAIGHT = (VAR & 8) != 0;
+        if constexpr (STRAIGHT) {
+            // EXPERIMENTAL (opt-in: BBDM_GEMM_PREFETCH2=1; written at the end of round 1 without GPU time left to run
+            // it -- not part of any measured number).  In the loop below the tail conditions and the per-slot validity
+            // tests are branches, and across branches the waitcnt pass falls back to vmcnt(0): the wait in front of the
+            // LDS stores then also covers the activation tile requested for phase+2, so the two-phase distance is only
+            // nominal.  This variant is straight-line: the host guarantees a full tile (every slot valid, Cin % 16 == 0),
+            // loads past the end are clamped to the last chunk (redundant, never consumed) and the stores of the last
+            // phase go to the idle buffer -- so the compiler can count: vmcnt(PSLOTS) before the weight slab is stored.
+            const int last = nphase - 1;
+            auto load_patch_nc = [&](float4 (&dst)[PSLOTS], int chunk) {
+#pragma unroll
+                for (int s = 0; s < PSLOTS; ++s) dst[s] = *reinterpret_cast<const float4*>(a.x + goff[s] + chunk * KC);
+            };
+            auto load_w_nc = [&](int phase) {
+                const float* src = wsrc + (size_t)phase * wPhaseStride;
+#pragma unroll
+                for (int s = 0; s < WSLOTS; ++s) wreg[s] = *reinterpret_cast<const float4*>(src + s * NTHR * 4);
+            };
+            auto store_patch_nc = [&](float4 (&src)[PSLOTS], float* dst) {
+#pragma unroll
+                for (int s = 0; s < PSLOTS; ++s) {
+                    const int f = tid + s * NTHR;
+                    *reinterpret_cast<float4*>(dst + (f >> 2) * KP + (f & 3) * 4) = src[s];
+                }
+            };
+            auto phase_nc = [&](int phase, float4 (&cur)[PSLOTS], float4 (&nxt)[PSLOTS]) {
+                load_w_nc(min(phase + 1, last));
+                load_patch_nc(nxt, min(phase + 2, last));
+                mfma_phase(pbuf + (phase & 1) * patchFloats, wbuf + (phase & 1) * (BN * KP));
+                store_w(wbuf + ((phase + 1) & 1) * (BN * KP));
+                store_patch_nc(cur, pbuf + ((phase + 1) & 1) * patchFloats);
+                __syncthreads();
+            };
+            load_patch_nc(preg, min(phase_begin + 1, last));
+            int phase = phase_begin;
+            for (; phase + 1 < nphase; phase += 2) {
+                phase_nc(phase, preg, preg2);
+                phase_nc(phase + 1, preg2, preg);
+            }
+            if (phase < nphase) phase_nc(phase, preg, preg2);
+        } else {
         auto gemm_phase = [&](int phase, float4 (&cur)[PSLOTS], float4 (&nxt)[PSLOTS]) {
             // cur holds chunk phase+1 (requested during the previous phase); nxt receives chunk phase+2
             if (phase + 1 < nphase) load_w(phase + 1);
@@ -387,6 +429,7 @@ conv_igemm_f32(const ConvArgs a_in) {
         for (int phase = phase_begin; phase < nphase; phase += 2) {
             gemm_phase(phase, preg, preg2);
             if (phase + 1 < nphase) gemm_phase(phase + 1, preg2, preg);
+        }
         }
     } else
     for (int phase = phase_begin; phase < nphase; ++phase) {
@@ -765,7 +808,11 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
     }
     if constexpr (BM == 256 && PSLOTS == 2) {        // the batched tile-GEMM instantiation (bbdm_conv1x1_batched)
         if (var == 0 && a.taps == 1) {
-            lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 4>(a, lds, blocks, stream);
+            static const bool straight = []() { const char* e = getenv("BBDM_GEMM_PREFETCH2"); return e && e[0] == '1'; }();
+            const bool full_tiles = a.Cin % KC == 0 && a.W == TWc && a.H % THc == 0 && IM == 1 &&
+                                    a.patchPix * (KC / 4) == PSLOTS * WM * WN * 64;
+            lrc = (straight && full_tiles) ? launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 12>(a, lds, blocks, stream)
+                                           : launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 4>(a, lds, blocks, stream);
             if (lrc != 0) return lrc;
             goto launched;
         }
