@@ -1,4 +1,4 @@
-// winograd.hip -- 3x3 stride-1 convolution through Winograd F(m x m, 3x3), m = 2 or 4, on the fp32 matrix core.
+// winograd.hip -- 3x3 stride-1 convolution through Winograd F(m x m, 3x3), m = 2, 4 (or, opt-in, 6), on the fp32 matrix core.
 //
 // Same call sites as conv_igemm.hip (openaimodel.py:207,233,524,690 on the wide layers); the reference's cuDNN / MIOpen
 // back ends make the same algorithmic choice for 3x3 convolutions (fp32 "Winograd non-fused" is F(4x4,3x3)).
@@ -13,6 +13,10 @@
 // U_xi = G g G^T is precomputed once per weight update in the packed layout the GEMM wants.
 // fp32 throughout.  Rounding error relative to an fp64 convolution (rms / max, Cin = 512, unit-variance activations):
 // direct 2e-7 / 3e-7, m = 2: 5e-7 / 6e-7, m = 4: 3e-6 / 1e-5 -- all far inside the 1e-3 per-step bar.
+// m = 6 (8x8 tiles, 64 transform points, 1.78 multiplies per output instead of 2.25; 6e-6 / 1.4e-5 in the same test,
+// tests/test_winograd_math_cpu.py) is EXPERIMENTAL: written at the end of round 1 after the GPU budget was spent, never
+// run on hardware, not reachable unless UNetModel.winograd / BBDM_WINOGRAD is raised to 6.  H, W need not be multiples
+// of 6: edge tiles read zeros beyond the image and their out-of-image outputs are not written.
 #include "common.h"
 
 namespace {
@@ -23,54 +27,87 @@ __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_fl
 __device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
 
-// ---- the 1-D transforms -------------------------------------------------------------------------------------------
+// ---- the 1-D transforms (host + device: bbdm_debug_winograd_transform_1d runs the same code on the CPU for the tests) ---
 // t = B^T d.  m = 2: points {0, 1, -1, inf}; m = 4: points {0, 1, -1, 2, -2, inf} (Lavin & Gray, arXiv:1509.09308).
 template <int MO, typename T>
-__device__ __forceinline__ void bt_transform(const T (&d)[MO + 2], T (&t)[MO + 2]) {
+__host__ __device__ __forceinline__ void bt_transform(const T (&d)[MO + 2], T (&t)[MO + 2]) {
     if constexpr (MO == 2) {
         t[0] = d[0] - d[2];
         t[1] = d[1] + d[2];
         t[2] = d[2] - d[1];
         t[3] = d[1] - d[3];
-    } else {
+    } else if constexpr (MO == 4) {
         t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
         t[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
         t[2] = 4.f * (d[1] - d[2]) + (d[4] - d[3]);
         t[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
         t[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
         t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    } else {        // m = 6: points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (the 8x8 transform of NNPACK / wincnn)
+        const T e0 = (d[2] + d[6]) - 4.25f * d[4], o0 = (d[1] + d[5]) - 4.25f * d[3];
+        const T e1 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], o1 = (0.5f * d[1] + 2.f * d[5]) - 2.5f * d[3];
+        const T e2 = (d[6] + 4.f * d[2]) - 5.f * d[4], o2 = (2.f * d[1] + 0.5f * d[5]) - 2.5f * d[3];
+        t[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
+        t[1] = e0 + o0;
+        t[2] = e0 - o0;
+        t[3] = e1 + o1;
+        t[4] = e1 - o1;
+        t[5] = e2 + o2;
+        t[6] = e2 - o2;
+        t[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
     }
 }
 // s = A^T m
 template <int MO, typename T>
-__device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&s)[MO]) {
+__host__ __device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&s)[MO]) {
     if constexpr (MO == 2) {
         s[0] = m[0] + m[1] + m[2];
         s[1] = m[1] - m[2] - m[3];
-    } else {
+    } else if constexpr (MO == 4) {
         const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
         s[0] = m[0] + p12 + p34;
         s[1] = m12 + 2.f * m34;
         s[2] = p12 + 4.f * p34;
         s[3] = m12 + 8.f * m34 + m[5];
+    } else {
+        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4], p56 = m[5] + m[6],
+                m56 = m[5] - m[6];
+        s[0] = m[0] + p12 + p34 + p56;
+        s[1] = m12 + 2.f * m34 + 0.5f * m56;
+        s[2] = p12 + 4.f * p34 + 0.25f * p56;
+        s[3] = m12 + 8.f * m34 + 0.125f * m56;
+        s[4] = p12 + 16.f * p34 + 0.0625f * p56;
+        s[5] = m12 + 32.f * m34 + 0.03125f * m56 + m[7];
     }
 }
 // u = G g
 template <int MO>
-__device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
+__host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
     if constexpr (MO == 2) {
         u[0] = g[0];
         u[1] = 0.5f * (g[0] + g[1] + g[2]);
         u[2] = 0.5f * (g[0] - g[1] + g[2]);
         u[3] = g[2];
-    } else {
+    } else if constexpr (MO == 4) {
         u[0] = 0.25f * g[0];
         u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
         u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
         u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
         u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
         u[5] = g[2];
+    } else {
+        u[0] = g[0];
+        u[1] = (-2.f / 9.f) * (g[0] + g[1] + g[2]);
+        u[2] = (-2.f / 9.f) * (g[0] - g[1] + g[2]);
+        u[3] = (1.f / 90.f) * g[0] + (1.f / 45.f) * g[1] + (2.f / 45.f) * g[2];
+        u[4] = (1.f / 90.f) * g[0] - (1.f / 45.f) * g[1] + (2.f / 45.f) * g[2];
+        u[5] = (32.f / 45.f) * g[0] + (16.f / 45.f) * g[1] + (8.f / 45.f) * g[2];
+        u[6] = (32.f / 45.f) * g[0] - (16.f / 45.f) * g[1] + (8.f / 45.f) * g[2];
+        u[7] = g[2];
     }
 }
 
@@ -181,6 +218,111 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
     }
 }
 
+// ---- m = 6 (experimental, see the header): 8x8 tiles, one thread = one (tile, channel PAIR) so that the 64 values of
+// a tile stay in registers; TH / TW are rounded up and edge tiles are masked.
+template <bool PRE, bool UP>
+__global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
+                                                              const float* __restrict__ sc, const float* __restrict__ bi,
+                                                              int pre_ld, int pre_silu, int N, int H, int W, int C,
+                                                              size_t plane) {
+    constexpr int MO = 6, AL = 8;
+    const int C2 = C >> 1;
+    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const long long total = (long long)N * TH * TW * C2;
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
+        const int c = (int)(u % C2) * 2;
+        const long long tile = u / C2;
+        const int tw = (int)(tile % TW);
+        const long long r = tile / TW;
+        const int th = (int)(r % TH), n = (int)(r / TH);
+        float2 s2 = make_float2(1.f, 1.f), b2 = make_float2(0.f, 0.f);
+        if (PRE) {
+            s2 = *reinterpret_cast<const float2*>(sc + (size_t)n * pre_ld + c);
+            b2 = *reinterpret_cast<const float2*>(bi + (size_t)n * pre_ld + c);
+        }
+        const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
+        float2 t[AL][AL];
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const int w = MO * tw - 1 + j;
+            float2 d[AL], col[AL];
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int h = MO * th - 1 + i;
+                float2 v = make_float2(0.f, 0.f);
+                if (h >= 0 && h < H && w >= 0 && w < W) {
+                    const int hs = UP ? h >> 1 : h, wsrc = UP ? w >> 1 : w;
+                    v = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+                    if (PRE) {
+                        v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
+                        if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
+                    }
+                }
+                d[i] = v;
+            }
+            bt_transform<MO>(d, col);
+#pragma unroll
+            for (int i = 0; i < AL; ++i) t[i][j] = col[i];
+        }
+        float* o = V + (size_t)tile * C + c;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            float2 row[AL];
+            bt_transform<MO>(t[i], row);
+#pragma unroll
+            for (int j = 0; j < AL; ++j) *reinterpret_cast<float2*>(o + (size_t)(i * AL + j) * plane) = row[j];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __restrict__ M, size_t plane, int ldm,
+                                                               const float* __restrict__ bias,
+                                                               const float* __restrict__ res, int ldr, int res_per_image,
+                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout) {
+    constexpr int MO = 6, AL = 8;
+    const int C2 = Cout >> 1;
+    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const long long total = (long long)N * TH * TW * C2;
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
+        const int c = (int)(u % C2) * 2;
+        const long long tile = u / C2;
+        const int tw = (int)(tile % TW);
+        const long long r = tile / TW;
+        const int th = (int)(r % TH), n = (int)(r / TH);
+        const float* m = M + (size_t)tile * ldm + c;
+        float2 s[MO][AL];
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            float2 v[AL], sj[MO];
+#pragma unroll
+            for (int i = 0; i < AL; ++i) v[i] = *reinterpret_cast<const float2*>(m + (size_t)(i * AL + j) * plane);
+            at_transform<MO>(v, sj);
+#pragma unroll
+            for (int a = 0; a < MO; ++a) s[a][j] = sj[a];
+        }
+        const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < MO; ++a) {
+            float2 o[MO];
+            at_transform<MO>(s[a], o);
+            const int oh = MO * th + a;
+#pragma unroll
+            for (int b = 0; b < MO; ++b) {
+                const int ow = MO * tw + b;
+                if (oh < H && ow < W) {
+                    const size_t pix = (size_t)(n * H + oh) * W + ow;
+                    float2 val = o[b] + b2;
+                    if (res) {
+                        const float* rp = res_per_image ? res + (size_t)n * ldr + c : res + pix * ldr + c;
+                        val = val + *reinterpret_cast<const float2*>(rp);
+                    }
+                    *reinterpret_cast<float2*>(y + pix * ldy + c) = val;
+                }
+            }
+        }
+    }
+}
+
 // ---- weights: U_xi[co][ci] = (G g G^T)[i][j] in the packed 1x1 layout [xi][chunk][CoutPad][16] -----------------------
 // dgrad != 0: the weights of the data-gradient convolution, g'[ci][co][r][s] = g[co][ci][2-r][2-s].
 template <int MO>
@@ -221,17 +363,19 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
     }
 }
 
+inline size_t tiles_raw(int N, int H, int W, int m) { return (size_t)N * cdiv(H, m) * cdiv(W, m); }
 inline size_t tiles_padded(int N, int H, int W, int m) {
-    const size_t T = (size_t)N * (H / m) * (W / m);
-    return (T + 255) / 256 * 256;      // whole 8x32 GEMM tiles
+    return (tiles_raw(N, H, W, m) + 255) / 256 * 256;      // whole 8x32 GEMM tiles
 }
 inline int planes(int m) { return (m + 2) * (m + 2); }
 
 }  // namespace
 
-#define BBDM_WINO_M(m) BBDM_REQUIRE((m) == 2 || (m) == 4, "winograd: output tile m=%d unsupported (2 or 4)", (m))
-#define BBDM_WINO_HW(m, H, W) \
-    BBDM_REQUIRE((H) > 0 && (W) > 0 && (H) % (m) == 0 && (W) % (m) == 0, "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)
+#define BBDM_WINO_M(m) \
+    BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6, "winograd: output tile m=%d unsupported (2, 4 or 6)", (m))
+#define BBDM_WINO_HW(m, H, W)                                                                                          \
+    BBDM_REQUIRE((H) > 0 && (W) > 0 && ((m) == 6 || ((H) % (m) == 0 && (W) % (m) == 0)),                                \
+                 "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)
 
 extern "C" size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad) {
     return (size_t)planes(m) * cdiv(CinPad, KC) * (cdiv(Cout, 128) * 128) * KC;
@@ -252,19 +396,22 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
     if (m == 2)
         hipLaunchKernelGGL(winograd_weight_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
                            Cin, CoutPad, nchunks, dgrad);
-    else
+    else if (m == 4)
         hipLaunchKernelGGL(winograd_weight_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
+                           Cin, CoutPad, nchunks, dgrad);
+    else
+        hipLaunchKernelGGL(winograd_weight_kernel<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
                            Cin, CoutPad, nchunks, dgrad);
     BBDM_CHECK_LAUNCH("winograd_pack");
     return BBDM_OK;
 }
 
 extern "C" size_t bbdm_winograd_tiles(int m, int N, int H, int W) {
-    return (m == 2 || m == 4) ? tiles_padded(N, H, W, m) : 0;
+    return (m == 2 || m == 4 || m == 6) ? tiles_padded(N, H, W, m) : 0;
 }
 
 extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int CinPad, int Cout) {
-    if (m != 2 && m != 4) return 0;
+    if (m != 2 && m != 4 && m != 6) return 0;
     return (size_t)planes(m) * tiles_padded(N, H, W, m) * ((size_t)CinPad + (size_t)Cout);
 }
 
@@ -280,13 +427,23 @@ extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V,
     BBDM_REQUIRE((pre_scale == nullptr) == (pre_bias == nullptr), "winograd_input: pre_scale / pre_bias must come together");
     BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
                  "winograd_input: pre_ld / alignment of the fused-producer coefficients");
-    const size_t T = (size_t)N * (H / m) * (W / m), Tp = tiles_padded(N, H, W, m);
+    const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const size_t vplane = Tp * (size_t)CinPad;
-    const long long units = (long long)T * (CinPad / 4);
+    const long long units = (long long)T * (CinPad / (m == 6 ? 2 : 4));
     long long blocks = (units + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     const dim3 g((unsigned)blocks), b(256);
     hipStream_t st = (hipStream_t)stream;
+    if (m == 6) {
+#define BBDM_WINO_IN6(PRE, UP)                                                                                            \
+    hipLaunchKernelGGL((winograd_input6_kernel<PRE, UP>), g, b, 0, st, x, ldx, V, pre_scale, pre_bias, pre_ld, pre_silu, N, \
+                       H, W, CinPad, vplane)
+        if (pre_scale) { if (upsample) BBDM_WINO_IN6(true, true); else BBDM_WINO_IN6(true, false); }
+        else           { if (upsample) BBDM_WINO_IN6(false, true); else BBDM_WINO_IN6(false, false); }
+#undef BBDM_WINO_IN6
+        BBDM_CHECK_LAUNCH("winograd_input");
+        return BBDM_OK;
+    }
 #define BBDM_WINO_IN(MO, PRE, UP)                                                                                         \
     hipLaunchKernelGGL((winograd_input_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, V, pre_scale, pre_bias, pre_ld, pre_silu, \
                        N, H, W, CinPad, vplane)
@@ -326,12 +483,15 @@ extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias
     BBDM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= Cout && ((uintptr_t)residual & 15) == 0), "winograd_output: ldr=%d", ldr);
     BBDM_REQUIRE(!bias || ((uintptr_t)bias & 15) == 0, "winograd_output: bias alignment");
     BBDM_REQUIRE((((uintptr_t)M | (uintptr_t)out) & 15) == 0, "winograd_output: 16-byte alignment");
-    const size_t T = (size_t)N * (H / m) * (W / m), Tp = tiles_padded(N, H, W, m);
-    const long long units = (long long)T * (Cout / 4);
+    const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
+    const long long units = (long long)T * (Cout / (m == 6 ? 2 : 4));
     long long blocks = (units + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0;
-    if (m == 2)
+    if (m == 6)
+        hipLaunchKernelGGL(winograd_output6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
+                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+    else if (m == 2)
         hipLaunchKernelGGL(winograd_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
                            Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
     else
@@ -353,4 +513,34 @@ extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const f
     if (rc == BBDM_OK) rc = bbdm_winograd_gemm_f32(m, V, packed_wino, M, N, H, W, CinPad, Cout, stream);
     if (rc == BBDM_OK) rc = bbdm_winograd_output_f32(m, M, bias, residual, ldr, out, ldo, flags, N, H, W, Cout, stream);
     return rc;
+}
+
+// Test hook (exported, not part of the public header): the 1-D transforms above evaluated on the HOST, so that the CPU
+// test-suite can check the hand-factored formulas against the transform matrices (tests/test_winograd_math_cpu.py).
+// which: 0 = B^T (m+2 -> m+2), 1 = A^T (m+2 -> m), 2 = G (3 -> m+2).
+extern "C" int bbdm_debug_winograd_transform_1d(int m, int which, const float* in, float* out) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(in && out && which >= 0 && which <= 2, "winograd_transform_1d: bad args");
+#define BBDM_WINO_1D(MO)                                                             \
+    do {                                                                             \
+        if (which == 0) {                                                            \
+            float d[MO + 2], t[MO + 2];                                              \
+            for (int i = 0; i < MO + 2; ++i) d[i] = in[i];                           \
+            bt_transform<MO>(d, t);                                                  \
+            for (int i = 0; i < MO + 2; ++i) out[i] = t[i];                          \
+        } else if (which == 1) {                                                     \
+            float v[MO + 2], r[MO];                                                  \
+            for (int i = 0; i < MO + 2; ++i) v[i] = in[i];                           \
+            at_transform<MO>(v, r);                                                  \
+            for (int i = 0; i < MO; ++i) out[i] = r[i];                              \
+        } else {                                                                     \
+            float g[3], u[MO + 2];                                                   \
+            for (int i = 0; i < 3; ++i) g[i] = in[i];                                \
+            g_transform<MO>(g, u);                                                   \
+            for (int i = 0; i < MO + 2; ++i) out[i] = u[i];                          \
+        }                                                                            \
+    } while (0)
+    if (m == 2) BBDM_WINO_1D(2); else if (m == 4) BBDM_WINO_1D(4); else BBDM_WINO_1D(6);
+#undef BBDM_WINO_1D
+    return BBDM_OK;
 }

@@ -278,6 +278,10 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 4) -
     if cin % 4 or cout % 4 or cout < 128:
         return 0
     hw = cin * cout / (cin + cout)
+    # m = 6 (64 transform points, 1.78 multiplies per output): EXPERIMENTAL, never the default (max_m defaults to 4);
+    # thresholds are placeholders until it has been measured.  H, W need not be multiples of 6 (masked edge tiles).
+    if max_m >= 6 and H >= 12 and W >= 12 and cin >= 128 and hw >= 64 and N * -(-H // 6) * -(-W // 6) >= 256:
+        return 6
     if max_m >= 4 and H % 4 == 0 and W % 4 == 0 and cin >= 128 and hw >= 64 and N * (H // 4) * (W // 4) >= 256:
         return 4
     if max_m >= 2 and H % 2 == 0 and W % 2 == 0 and cin >= 256 and hw >= 100 and N * (H // 2) * (W // 2) >= 1024:
@@ -401,7 +405,7 @@ class UNetModel(nn.Module):
         self.fuse_groupnorm: bool = False
         # 3x3 convolutions of wide layers through Winograd F(4x4,3x3) / F(2x2,3x3) (csrc/winograd.hip; `winograd_tile`
         # picks per layer).  Plans are cached per setting, so this can be changed between calls (A/B runs).
-        # BBDM_WINOGRAD: largest output tile allowed, 4 (default), 2, or 0 = off.
+        # BBDM_WINOGRAD: largest output tile allowed, 4 (default), 2, or 0 = off (6: experimental, see winograd_tile).
         self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "4"))
         self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
 
@@ -627,7 +631,7 @@ class _Plan:
         if name == "bbdm_winograd_gemm_f32":        # the (m+2)^2 GEMMs actually executed: 2 (m+2)^2 tiles Cin Cout
             wm, N, H, W, cin_pad, cout = args[0], *args[4:9]
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
-            return 2.0 * (wm + 2) ** 2 * N * (H // wm) * (W // wm) * cin * cout
+            return 2.0 * (wm + 2) ** 2 * N * -(-H // wm) * -(-W // wm) * cin * cout
         if name == "bbdm_attention_f32":
             N, T, heads, ch = args[5:9]
             return 2.0 * 2.0 * N * heads * T * T * ch

@@ -238,7 +238,10 @@ def main():
     executed_flops_per_step = sum(v[2] for v in by.values()) / max(1, args.steps)
     # SURVEY.md §8d's algorithmic figure is the direct-convolution count: a Winograd GEMM stands for 2.25x its FLOPs
     plan0 = next(iter(model.denoise_fn._plans.values()))
-    extra = sum(fl * (9.0 * oa[0] ** 2 / (oa[0] + 2) ** 2 - 1.0) for (nm, oa), fl in zip(plan0.ops, plan0.op_flops)
+    def _direct_flops(oa):          # 2 * 9 * N * H * W * Cin * Cout of the layer a Winograd GEMM stands for
+        cin = getattr(oa[2].t, "cin_true", oa[7])
+        return 18.0 * oa[4] * oa[5] * oa[6] * cin * oa[8]
+    extra = sum(_direct_flops(oa) - fl for (nm, oa), fl in zip(plan0.ops, plan0.op_flops)
                 if nm == "bbdm_winograd_gemm_f32")              # per forward pass: direct count - executed count
     total_flops_per_step = executed_flops_per_step + (extra if not training else 0.0)
     conv_launches = conv[0]

@@ -75,7 +75,7 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
                          const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
-/* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2 or 4 (same call sites, wide layers) ------------- */
+/* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2 or 4 [6: experimental] (same call sites, wide layers) */
 /* Y = A^T[(G g G^T) (.) (B^T d B)]A: (m+2)^2 multiplies per m^2 outputs instead of 9 m^2 -- 2.25x (m = 2) or 4x (m = 4)
  * fewer MFMA FLOP; the choice cuDNN / MIOpen make for the reference's wide 3x3 layers (openaimodel.py:207,233,524;
  * their fp32 "Winograd non-fused" is m = 4).  stride 1, padding 1, H and W multiples of m, CinPad % 4 == 0,
@@ -86,7 +86,9 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
  * data-gradient convolution Cout -> Cin of the same filter: transposed + flipped; then InPad is the channel count of
  * dY and the forward entry is called with CinPad = InPad, Cout = Cin).
  * ws: bbdm_winograd_workspace_floats() floats (transformed input V[(m+2)^2][tiles][CinPad] + products
- * M[(m+2)^2][tiles][Cout]).  flags: only BBDM_CONV_RES_PER_IMAGE. */
+ * M[(m+2)^2][tiles][Cout]).  flags: only BBDM_CONV_RES_PER_IMAGE.
+ * m = 6 (8x8 tiles, 64 transform points; H, W arbitrary -- edge tiles are masked; CinPad, Cout multiples of 4) is accepted
+ * by every entry below but is EXPERIMENTAL: written after round 1's GPU budget was spent, not yet run on hardware. */
 size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad);
 int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
                                   void* stream);
@@ -96,7 +98,7 @@ int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packe
                               int N, int H, int W, int CinPad, int Cout, void* stream);
 /* The three stages on their own (what bbdm_conv3x3_winograd_f32 chains; a static plan calls them directly so that it
  * can share V / M across layers, time each stage and fold the producer of the convolved tensor into stage 1).
- * tiles = bbdm_winograd_tiles(m, N, H, W) = N (H/m)(W/m) rounded up to whole 256-row GEMM tiles.
+ * tiles = bbdm_winograd_tiles(m, N, H, W) = N ceil(H/m) ceil(W/m) rounded up to whole 256-row GEMM tiles.
  *   input : x -> V[(m+2)^2][tiles][CinPad].  pre_scale / pre_bias / pre_ld / pre_silu: same fused GroupNorm [-> FiLM]
  *           [-> SiLU] producer as bbdm_conv2d_nhwc_f32.  upsample != 0: x is [N, H/2, W/2, ldx] and the convolved tensor
  *           is its nearest x2 upsampling (Upsample.forward, openaimodel.py:111-121) -- never materialised.

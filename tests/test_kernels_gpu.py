@@ -97,7 +97,7 @@ WINO_CASES = [
 ]
 # rel_err is max|diff| / max|ref|.  F(2x2,3x3) transforms use 0, +-1, +-1/2 only; F(4x4,3x3) uses up to 8 (+ 1/24 in
 # the weights) and is ~10x noisier (csrc/winograd.hip header) -- both orders of magnitude inside the 1e-3 step bar.
-WINO_TOL = {2: 2e-5, 4: 1e-4}
+WINO_TOL = {2: 2e-5, 4: 1e-4, 6: 2e-4}
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout,res", WINO_CASES)
@@ -194,6 +194,30 @@ def test_winograd_stages_fused_producer(dev, m, up, silu):
     _lib.call("bbdm_winograd_output_f32", m, M.data_ptr(), bg.data_ptr(), None, 0, out.data_ptr(), Cout, 0, N, H, W, Cout, st)
     torch.cuda.synchronize()
     assert rel_err(_nchw(out.cpu()), ref) < WINO_TOL[m]
+
+
+EXPERIMENTAL = pytest.mark.skipif(__import__("os").environ.get("BBDM_TEST_EXPERIMENTAL") != "1",
+                                  reason="m = 6 Winograd path: written after round 1's GPU budget was spent, not yet run "
+                                         "on hardware; set BBDM_TEST_EXPERIMENTAL=1 to run")
+
+
+@EXPERIMENTAL
+@pytest.mark.parametrize("N,H,W,Cin,Cout,res", [
+    (2, 12, 12, 64, 128, 0), (1, 24, 36, 256, 256, 1), (2, 64, 64, 320, 384, 2),      # 64 is not a multiple of 6
+    (3, 16, 20, 48, 72, 1), (1, 6, 6, 16, 8, 0), (1, 32, 32, 1024, 512, 1), (5, 7, 9, 132, 260, 1)])
+def test_conv3x3_winograd_m6(dev, N, H, W, Cin, Cout, res):
+    test_conv3x3_winograd(dev, 6, N, H, W, Cin, Cout, res)
+
+
+@EXPERIMENTAL
+@pytest.mark.parametrize("up,silu", [(0, 1), (1, 1), (1, 0)])
+def test_winograd_stages_fused_producer_m6(dev, up, silu):
+    test_winograd_stages_fused_producer(dev, 6, up, silu)
+
+
+@EXPERIMENTAL
+def test_conv3x3_winograd_dgrad_and_slices_m6(dev):
+    test_conv3x3_winograd_dgrad_and_slices(dev, 6)
 
 
 def test_conv3x3_winograd_rejects_bad_shapes(dev):

@@ -18,6 +18,10 @@ def _plan(workload, batch=None, training=False, winograd=4):
     return m, m._plan_for(x, training)
 
 
+def lib_tiles(m, N, H, W):
+    return _lib.load().bbdm_winograd_tiles(m, N, H, W)
+
+
 def test_winograd_tile_choice_follows_the_measured_crossovers():
     wt = unet.winograd_tile
     # profiles/r01_wino_bench.txt (MI355X): F(4x4) wins on every wide layer with >= 256 tiles ...
@@ -33,14 +37,20 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert wt(16, 256, 256, 8, 128) == 0 and wt(16, 256, 256, 128, 3) == 0 and wt(16, 64, 64, 64, 64) == 0
     # H, W not multiples of 4 -> F(2x2) if the layer is wide and large enough, else direct
     assert wt(16, 66, 66, 512, 512) == 2 and wt(16, 66, 66, 128, 128) == 0 and wt(16, 33, 33, 512, 512) == 0
-    # the cap (UNetModel.winograd / BBDM_WINOGRAD)
+    # the cap (UNetModel.winograd / BBDM_WINOGRAD); 6 is the experimental 8x8-tile path and never the default
     assert wt(16, 64, 64, 1024, 1024, 2) == 2 and wt(16, 64, 64, 1024, 1024, 0) == 0
+    assert wt(16, 64, 64, 1024, 1024, 6) == 6 and wt(16, 8, 8, 1024, 1024, 6) == 0
+    tiny = unet.UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
+                          attention_resolutions=(), channel_mult=(1,), num_head_channels=32, condition_key="nocond")
+    assert tiny.winograd == int(__import__("os").environ.get("BBDM_WINOGRAD", "4"))      # the default cap is 4
+    assert lib_tiles(6, 16, 64, 64) == 2048 and lib_tiles(4, 16, 64, 64) == 4096 and lib_tiles(2, 3, 8, 12) == 256
 
 
-@pytest.mark.parametrize("workload,batch,training", [("c1", 4, False), ("c1", 16, False), ("c1", 16, True), ("c5", 32, False)])
-def test_plan_ops_are_consistent(workload, batch, training):
+@pytest.mark.parametrize("workload,batch,training,cap", [("c1", 4, False, 4), ("c1", 16, False, 4), ("c1", 16, True, 4),
+                                                         ("c5", 32, False, 4), ("c1", 16, False, 6)])
+def test_plan_ops_are_consistent(workload, batch, training, cap):
     lib = _lib.load()
-    m, plan = _plan(workload, batch, training)
+    m, plan = _plan(workload, batch, training, winograd=cap)
     ops = list(plan.ops) + (list(plan.bops) if training else [])
     names = collections.Counter(n for n, _ in ops)
     assert names["bbdm_winograd_input_f32"] == names["bbdm_winograd_gemm_f32"] == names["bbdm_winograd_output_f32"]
@@ -51,8 +61,8 @@ def test_plan_ops_are_consistent(workload, batch, training):
         assert (n2, n3) == ("bbdm_winograd_gemm_f32", "bbdm_winograd_output_f32")       # emitted as a triple
         wm = i[0]
         N, H, W, cin = i[9:13]
-        assert wm in (2, 4) and g[0] == wm and o[0] == wm
-        assert H % wm == 0 and W % wm == 0 and cin % 4 == 0
+        assert wm in (2, 4, 6) and g[0] == wm and o[0] == wm
+        assert (wm == 6 or (H % wm == 0 and W % wm == 0)) and cin % 4 == 0
         assert tuple(g[4:8]) == (N, H, W, cin) and tuple(o[8:11]) == (N, H, W) and o[11] == g[8]
         cout = g[8]
         up = i[8]
@@ -60,7 +70,7 @@ def test_plan_ops_are_consistent(workload, batch, training):
         assert (src.H, src.W) == ((H // 2, W // 2) if up else (H, W)) and src.C == cin
         tiles = lib.bbdm_winograd_tiles(wm, N, H, W)
         P = (wm + 2) ** 2
-        assert tiles % 256 == 0 and tiles >= N * (H // wm) * (W // wm)
+        assert tiles % 256 == 0 and tiles >= N * -(-H // wm) * -(-W // wm)
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
         assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
         assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) == wm
@@ -77,10 +87,10 @@ def test_flop_accounting_direct_equivalent_matches_the_direct_plan():
     _, direct = _plan("c1", 16, winograd=0)
     assert not any(n.startswith("bbdm_winograd") for n, _ in direct.ops)
     want = sum(direct.op_flops)
-    for cap in (2, 4):
+    for cap in (2, 4, 6):                                     # 6 = the experimental 8x8-tile path (masked edge tiles)
         _, plan = _plan("c1", 16, winograd=cap)
         executed = sum(plan.op_flops)
-        equiv = sum(f * (9.0 * a[0] ** 2 / (a[0] + 2) ** 2 if n == "bbdm_winograd_gemm_f32" else 1.0)
+        equiv = sum(18.0 * a[4] * a[5] * a[6] * getattr(a[2].t, "cin_true", a[7]) * a[8] if n == "bbdm_winograd_gemm_f32" else f
                     for (n, a), f in zip(plan.ops, plan.op_flops))
         assert executed < want and abs(equiv - want) < 1e-6 * want
 

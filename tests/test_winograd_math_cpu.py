@@ -1,6 +1,6 @@
 """The Winograd F(m x m, 3x3) algebra used by csrc/winograd.hip, restated with explicit matrices (CPU, no GPU):
 B^T, G, A^T below are the matrices the HIP kernels hard-code as adds / multiplies (bt_transform, g_transform,
-at_transform).  Checks that they reproduce a 3x3 'same' convolution exactly in fp64, that the data-gradient variant
+at_transform; m = 6 is the experimental 8x8-tile path).  Checks that they reproduce a 3x3 'same' convolution exactly in fp64, that the data-gradient variant
 (transposed + flipped filter) is the transposed convolution, and the fp32 rounding levels DESIGN.md §4.5 quotes."""
 import pytest
 import torch
@@ -16,6 +16,17 @@ MATS = {
                       [1 / 24, -1 / 12, 1 / 6], [0, 0, 1.]], dtype=torch.float64),
         torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1.]],
                      dtype=torch.float64)),
+    # m = 6 (experimental path): the 8x8 transform with points {0, +-1, +-2, +-1/2, inf}
+    6: (torch.tensor([[1, 0, -21 / 4, 0, 21 / 4, 0, -1, 0], [0, 1, 1, -17 / 4, -17 / 4, 1, 1, 0],
+                      [0, -1, 1, 17 / 4, -17 / 4, -1, 1, 0], [0, 1 / 2, 1 / 4, -5 / 2, -5 / 4, 2, 1, 0],
+                      [0, -1 / 2, 1 / 4, 5 / 2, -5 / 4, -2, 1, 0], [0, 2, 4, -5 / 2, -5, 1 / 2, 1, 0],
+                      [0, -2, 4, 5 / 2, -5, -1 / 2, 1, 0], [0, -1, 0, 21 / 4, 0, -21 / 4, 0, 1.]], dtype=torch.float64),
+        torch.tensor([[1, 0, 0], [-2 / 9, -2 / 9, -2 / 9], [-2 / 9, 2 / 9, -2 / 9], [1 / 90, 1 / 45, 2 / 45],
+                      [1 / 90, -1 / 45, 2 / 45], [32 / 45, 16 / 45, 8 / 45], [32 / 45, -16 / 45, 8 / 45], [0, 0, 1.]],
+                     dtype=torch.float64),
+        torch.tensor([[1, 1, 1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 1 / 2, -1 / 2, 0], [0, 1, 1, 4, 4, 1 / 4, 1 / 4, 0],
+                      [0, 1, -1, 8, -8, 1 / 8, -1 / 8, 0], [0, 1, 1, 16, 16, 1 / 16, 1 / 16, 0],
+                      [0, 1, -1, 32, -32, 1 / 32, -1 / 32, 1.]], dtype=torch.float64)),
 }
 
 
@@ -34,15 +45,15 @@ def winograd_conv(x, w, m, dtype):
     return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, K, H, W)
 
 
-@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("m", [2, 4, 6])
 def test_exact_in_fp64(m):
     g = torch.Generator().manual_seed(m)
-    x = torch.randn(2, 5, 8, 12, generator=g, dtype=torch.float64)
+    x = torch.randn(2, 5, 12, 24, generator=g, dtype=torch.float64)
     w = torch.randn(7, 5, 3, 3, generator=g, dtype=torch.float64)
     ref = F.conv2d(x, w, padding=1)
     assert float((winograd_conv(x, w, m, torch.float64) - ref).abs().max()) < 1e-12
     # data gradient = the same algorithm on the transposed, spatially flipped filter (winograd_weight_kernel, dgrad)
-    dy = torch.randn(2, 7, 8, 12, generator=g, dtype=torch.float64)
+    dy = torch.randn(2, 7, 12, 24, generator=g, dtype=torch.float64)
     wd = w.transpose(0, 1).flip(2, 3)
     assert float((winograd_conv(dy, wd, m, torch.float64) - F.conv_transpose2d(dy, w, padding=1)).abs().max()) < 1e-12
 
@@ -50,10 +61,36 @@ def test_exact_in_fp64(m):
 def test_fp32_rounding_levels():
     """rms error relative to the rms of the fp64 result, Cin = 512, unit-variance post-SiLU-like activations."""
     g = torch.Generator().manual_seed(0)
-    x = F.silu(torch.randn(1, 512, 16, 16, generator=g))
+    x = F.silu(torch.randn(1, 512, 24, 24, generator=g))
     w = torch.randn(64, 512, 3, 3, generator=g) * 0.02
     ref = F.conv2d(x.double(), w.double(), padding=1)
     rms = lambda y: float(((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
-    e_direct, e2, e4 = rms(F.conv2d(x, w, padding=1)), rms(winograd_conv(x, w, 2, torch.float32)), rms(winograd_conv(x, w, 4, torch.float32))
-    assert e_direct < 1e-6 and e2 < 2e-6 and e4 < 1e-5          # measured: 2e-7, 5e-7, 3e-6
-    assert e2 < e4                                              # F(4x4) is the noisier one, by about an order of magnitude
+    e_direct = rms(F.conv2d(x, w, padding=1))
+    e2, e4, e6 = (rms(winograd_conv(x, w, m, torch.float32)) for m in (2, 4, 6))
+    assert e_direct < 1e-6 and e2 < 2e-6 and e4 < 1e-5 and e6 < 2e-5          # measured: 2e-7, 5e-7, 3e-6, 6e-6
+    assert e2 < e4 < e6                            # each step up in tile size costs accuracy: ~10x, then ~2x
+
+
+@pytest.mark.parametrize("m", [2, 4, 6])
+def test_hip_source_transforms_match_the_matrices(m):
+    """csrc/winograd.hip evaluates B^T, A^T and G as hand-factored adds / multiplies; the same template code compiled
+    for the host (bbdm_debug_winograd_transform_1d, an exported test hook) must agree with the matrices above on random
+    vectors and on every unit vector (= every matrix column)."""
+    import ctypes
+    import numpy as np
+    from bbdm_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    fn = lib.bbdm_debug_winograd_transform_1d
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    BT, G, AT = (t.numpy() for t in MATS[m])
+    rng = np.random.RandomState(m)
+    for which, mat in ((0, BT), (1, AT), (2, G)):
+        rows, cols = mat.shape
+        vecs = [rng.randn(cols).astype(np.float32) for _ in range(8)] + list(np.eye(cols, dtype=np.float32))
+        for v in vecs:
+            v = np.ascontiguousarray(v)
+            out = np.zeros(rows, dtype=np.float32)
+            assert fn(m, which, v.ctypes.data, out.ctypes.data) == 0
+            want = mat @ v.astype(np.float64)
+            assert np.abs(out - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), (m, which, v, out, want)

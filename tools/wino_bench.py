@@ -39,6 +39,10 @@ SHAPES = [  # N, H, W, Cin, Cout
 ]
 
 
+# m = 6 is the experimental 8x8-tile path (never run on hardware as of round 1): only with BBDM_TEST_EXPERIMENTAL=1
+MS = (2, 4, 6) if os.environ.get("BBDM_TEST_EXPERIMENTAL") == "1" else (2, 4)
+
+
 def _time(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -71,8 +75,8 @@ def main():
         td += ms_d
         line = f"N{N} {H}x{W} {Cin}->{Cout}: direct {ms_d:8.3f} ms ({fl / ms_d / 1e9:6.1f} TF)"
         best = ms_d
-        for m in (2, 4):
-            if H % m or W % m:
+        for m in MS:
+            if m != 6 and (H % m or W % m):
                 continue
             pw = ops.pack_winograd_weight(w, m=m)
             ws = torch.empty(lib.bbdm_winograd_workspace_floats(m, N, H, W, Cin, Cout), device=dev)
@@ -85,7 +89,7 @@ def main():
         tw += best
         print(line, flush=True)
         del x, w, o1, o2
-    print(f"total: direct {td:.2f} ms  best-of(direct, F2, F4) {tw:.2f} ms")
+    print(f"total: direct {td:.2f} ms  best-of(direct, F2, F4[, F6]) {tw:.2f} ms")
 
 
 if __name__ == "__main__":
