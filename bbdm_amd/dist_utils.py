@@ -67,3 +67,42 @@ def timed_region(fn: Callable[[], None], dist=None, device: Optional[torch.devic
 def aggregate_throughput(units_per_rank: int, elapsed_max: float, world: int) -> float:
     """Whole-job units/s for weak scaling: every rank processed ``units_per_rank`` in the (max-over-ranks) time."""
     return world * units_per_rank / elapsed_max
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_procs: int, script_argv, python: Optional[str] = None) -> int:
+    """Re-exec ``script_argv`` as ``n_procs`` ranks of one node under ``torch.distributed.run`` (one process per GPU;
+    rendezvous on 127.0.0.1: the container hostname may not resolve).  The reference starts its ranks itself as well
+    (main.py:100-104, ``mp.spawn``).  Returns the launcher's exit code."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n_procs))))
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + list(script_argv)
+    return subprocess.call(cmd, env=env)
+
+
+def gather_device_info(dist=None, device: Optional[torch.device] = None):
+    """[{rank, device, name}] for every rank (+ the RCCL version on GPUs), gathered to all ranks; control plane only."""
+    rank, local_rank, world = env_rank()
+    mine = {"rank": rank, "device": str(device) if device is not None else "cpu"}
+    if device is not None and device.type == "cuda":
+        mine["name"] = torch.cuda.get_device_name(device)
+    if dist is None:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    if device is not None and device.type == "cuda":
+        try:
+            out[0]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                   # pragma: no cover
+            pass
+    return out

@@ -82,30 +82,109 @@ def make_inputs(batch, ch, size, seed=1234):
     return x_t, y
 
 
-def cpu_baseline(workload, sd, budget_s=25.0):
-    """Oracle p_sample on the host cores.  Bounded sample: batch 1 of the workload's shape, 1 warm-up + as many timed
-    steps as fit ~budget (>= 1); reported in the metric's unit (batch-B steps/s = per-image rate / B)."""
-    import bbdm_oracle as O
-    desc, up, ch, size, batch, skip, sstep = WORKLOADS[workload]
-    ora = O.OracleBBDM({"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), skip_sample=skip,
-                       sample_step=sstep, **BB)
-    x_t, y = make_inputs(1, ch, size)
-    ctx = None if up["condition_key"] == "nocond" else y
-    threads = torch.get_num_threads()
-    t0 = time.perf_counter()
-    ora.p_sample(x_t, y, ctx, 0, clip_denoised=False)
-    warm = time.perf_counter() - t0
-    n, spent = 0, 0.0
-    while n < 1 or (spent + spent / max(n, 1) < budget_s - warm and n < 20):
+def _reference_model(up, skip, sstep, sd):
+    """The reference's own BrownianBridgeModel (CPU) with our state_dict, when /root/reference is mounted (the build
+    container); None on the GPU box.  Never part of the product path: bench.py's cpu_baseline leg only."""
+    ref_root = os.environ.get("BBDM_REFERENCE_ROOT", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "model", "BrownianBridge")):
+        return None
+    try:
+        if ref_root not in sys.path:
+            sys.path.insert(0, ref_root)
+        from model.BrownianBridge.BrownianBridgeModel import BrownianBridgeModel as RefModel
+        m = RefModel(_ns({"BB": {"params": dict(BB, skip_sample=skip, sample_step=sstep, UNetParams=up)}}))
+        m.denoise_fn.load_state_dict(sd, strict=True)
+        return m.eval()
+    except Exception as e:                      # pragma: no cover
+        print(f"cpu_baseline: reference import failed ({e!r}); using the oracle port", file=sys.stderr)
+        return None
+
+
+class _CpuPath:
+    """p_sample of the reference (kind 'reference') or of oracle/bbdm_oracle.py (kind 'port') on the host cores."""
+
+    def __init__(self, up, skip, sstep, sd):
+        import bbdm_oracle as O
+        self.ref = _reference_model(up, skip, sstep, sd)
+        self.kind = "reference" if self.ref is not None else "port"
+        self.ora = None if self.ref is not None else O.OracleBBDM(
+            {"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), skip_sample=skip, sample_step=sstep, **BB)
+
+    @torch.no_grad()
+    def p_sample(self, x_t, y, ctx, i, noise):
+        if self.ref is None:
+            return self.ora.p_sample(x_t, y, ctx, i, clip_denoised=False, noise=noise)
+        import model.BrownianBridge.BrownianBridgeModel as RM       # inject the step noise (SURVEY.md §8c protocol)
+        orig = RM.torch.randn_like
+        RM.torch.randn_like = lambda t, **k: noise
+        try:
+            return self.ref.p_sample(x_t=x_t, y=y, context=ctx, i=i, clip_denoised=False)
+        finally:
+            RM.torch.randn_like = orig
+
+
+def _time_cpu_steps(path, x_t, y, ctx, eps, n_timed, i0=1):
+    ts = []
+    for k in range(n_timed):
         t0 = time.perf_counter()
-        ora.p_sample(x_t, y, ctx, n + 1, clip_denoised=False)
-        spent += time.perf_counter() - t0
-        n += 1
-    per_img_step = spent / n
-    return {"value": 1.0 / (per_img_step * batch), "unit": "steps/s", "cores": threads, "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"oracle p_sample, batch 1 of the {batch}-image batch at {size}x{size}, 1 warm-up + {n} timed "
-                      f"steps ({per_img_step:.2f} s per image-step), scaled by 1/{batch} to batch-{batch} steps/s"}
+        path.p_sample(x_t, y, ctx, i0 + k, eps)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts
+
+
+def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
+    """the reference's CPU path (imported from /root/reference when mounted -> kind "reference", else
+    the validated restatement oracle/bbdm_oracle.py -> kind "port") timed on this box's host cores.
+
+    Bounded sample of the workload: ONE image of the batch at the workload's resolution (a 256x256 batch-16 CPU step
+    would need ~35 GB of attention scores), 1 warm-up + >= 3 timed p_sample steps (median), reported in the metric's
+    unit (batch-B steps/s = per-image rate / B).  For c2 additionally C1 exactly as BASELINE.json names it (64x64,
+    batch 4, 1 warm-up + 5 timed steps, median).  The warm-up step doubles as the parity sample: when
+    ``parity_inputs`` = (x_t, y, i, eps, gpu_x_next_row0, gpu_x0_recon_row0) is given, its output for image 0 is compared
+    with row 0 of the GPU's step on the same batch."""
+    desc, up, ch, size, batch, skip, sstep = WORKLOADS[workload]
+    path = _CpuPath(up, skip, sstep, sd)
+    threads = torch.get_num_threads()
+    parity = None
+    if parity_inputs is not None:
+        x_t, y, i_par, eps, g_a, g_b = parity_inputs
+        x_t, y, eps = x_t[:1].cpu(), y[:1].cpu(), eps[:1].cpu()
+    else:
+        x_t, y = make_inputs(1, ch, size)
+        eps = torch.randn(x_t.shape, generator=torch.Generator().manual_seed(99))
+        i_par = 0
+    ctx = None if up["condition_key"] == "nocond" else y
+    t0 = time.perf_counter()
+    a_ref, b_ref = path.p_sample(x_t, y, ctx, i_par, eps)
+    warm = time.perf_counter() - t0
+    if parity_inputs is not None:
+        def rel(a, b):
+            a, b = a.double().cpu(), b.double()
+            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        parity = {"rel_err_x_tminus": rel(g_a, a_ref[0]), "rel_err_x0_recon": rel(g_b, b_ref[0]), "bar": 1e-3,
+                  "metric": "max|gpu - cpu| / max|cpu| on image 0 of the benchmarked batch, one p_sample step "
+                            f"(schedule index {i_par}), same weights / inputs / step noise",
+                  "against": path.kind}
+    n_timed = max(3, min(20, int((budget_s - warm) / max(warm, 1e-3))))
+    med, ts = _time_cpu_steps(path, x_t, y, ctx, eps, n_timed)
+    out = {"value": 1.0 / (med * batch), "unit": "steps/s", "cores": threads, "kind": path.kind,
+           "host_cpus": os.cpu_count(),
+           "sample": f"{path.kind} p_sample, image 0 of the {batch}-image batch at {size}x{size}, 1 warm-up + {n_timed} "
+                     f"timed steps (median {med:.2f} s per image-step, min {ts[0]:.2f}, max {ts[-1]:.2f}), scaled by "
+                     f"1/{batch} to batch-{batch} steps/s",
+           "s_per_image_step": med}
+    if workload == "c2":
+        d1, up1, ch1, size1, batch1, skip1, sstep1 = WORKLOADS["c1"]
+        p1 = _CpuPath(up1, skip1, sstep1, sd)                   # same 237 M weights (the UNet is resolution-agnostic)
+        x1, y1 = make_inputs(batch1, ch1, size1)
+        e1 = torch.randn(x1.shape, generator=torch.Generator().manual_seed(98))
+        p1.p_sample(x1, y1, y1, 0, e1)
+        med1, ts1 = _time_cpu_steps(p1, x1, y1, y1, e1, 5)
+        out["c1_exact"] = {"config": d1, "s_per_step_median": med1, "steps_per_s": 1.0 / med1,
+                           "img_steps_per_s": batch1 / med1, "full_1000_step_sample_min": 1000 * med1 / 60.0,
+                           "timed_steps": 5, "warmup": 1, "kind": p1.kind}
+    return out, parity
 
 
 def main():
@@ -115,17 +194,32 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
     args = ap.parse_args()
 
+    if args.cpu_only:                      # build-container check of the cpu_baseline leg (no GPU needed)
+        import bbdm_amd
+        desc, up, ch, size, batch, skip, sstep = WORKLOADS[args.workload]
+        model = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(BB, skip_sample=skip, sample_step=sstep,
+                                                                        UNetParams=up)}}))
+        cb, _ = cpu_baseline(args.workload, synth_state(model.denoise_fn), args.cpu_budget)
+        print(json.dumps({"cpu_baseline": cb}))
+        return
+
     import bbdm_amd
     from bbdm_amd import dist_utils
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` launches its own ranks (the reference spawns them itself too: main.py:100-104,
+        # mp.spawn): re-exec under torch.distributed.run, one process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1.
+        sys.exit(dist_utils.self_launch(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = dist_utils.env_rank()
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, but only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = dist_utils.init(backend="nccl")      # RCCL over xGMI; None when single-process
@@ -280,6 +374,7 @@ def main():
     if traffic is not None and alg_n:
         traffic["algorithmic_bytes_per_launch"] = alg_bytes / alg_n
     ms_per_step = elapsed * 1e3 / args.steps
+    devices = dist_utils.gather_device_info(dist, dev)          # per-rank device ids (+ RCCL version when world > 1)
     steps_per_s_job = dist_utils.aggregate_throughput(args.steps, elapsed, world)
 
     if rank == 0:
@@ -293,6 +388,7 @@ def main():
             "dtype": "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
             "config": {"workload": desc, "batch_per_gpu": batch, "image_size": size, "unet_params_M": nparams / 1e6,
                        "schedule_steps": nsteps_table, "parallelism": f"dp{world} (independent image-pair shards)"},
+            "devices": devices,
             "hip_graph": bool(plan_graph),
             "steps_per_sec_per_gpu": args.steps / elapsed,
             "img_steps_per_sec": steps_per_s_job * batch,
@@ -301,6 +397,8 @@ def main():
             "tflops_executed": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "frac_step": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         "frac_step_note": "whole step: FLOPs executed on the MFMA by every kernel / step time / peak",
                          "traffic": traffic, "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
                          "conv_share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,
@@ -311,10 +409,28 @@ def main():
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
         }
         if not args.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.workload, sd, args.cpu_budget)
+            # parity sample: one more p_sample of the SAME batch with known step noise (untimed), image 0 of which the
+            # CPU path recomputes in its warm-up step
+            par_in = None
+            if not training:
+                i_par = 431 % (nsteps_table - 1)
+                eps = torch.randn(x_t.shape, generator=torch.Generator().manual_seed(4321)).to(dev)
+                orig_rl = torch.randn_like
+                torch.randn_like = lambda t, **k: eps
+                try:
+                    g_a, g_b = model.p_sample(x_t, y, ctx, i_par, clip_denoised=False)
+                finally:
+                    torch.randn_like = orig_rl
+                torch.cuda.synchronize(dev)
+                par_in = (x_t, y, i_par, eps, g_a[0].cpu(), g_b[0].cpu())
+            line["cpu_baseline"], line["parity"] = cpu_baseline(args.workload, sd, args.cpu_budget, par_in)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+            if line["parity"] is not None and not (line["parity"]["rel_err_x_tminus"] < 1e-3
+                                                   and line["parity"]["rel_err_x0_recon"] < 1e-3):
+                raise RuntimeError(f"bench parity check failed: {line['parity']}")
         else:
             line["cpu_baseline"] = None
+            line["parity"] = None
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()
