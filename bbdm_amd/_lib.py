@@ -70,6 +70,19 @@ class BBDMHipError(RuntimeError):
     pass
 
 
+def bind(path: str):
+    """dlopen ``path`` and bind every declared symbol (raises if one is missing or the ABI version differs)."""
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.bbdm_version()
+    if v != ABI_VERSION:
+        raise BBDMHipError(f"{path}: ABI version {v} != expected {ABI_VERSION}; rebuild it")
+    return lib
+
+
 def load():
     """Load the shared library (once) and bind every declared symbol.  Raises if anything is missing."""
     global _lib
@@ -80,16 +93,33 @@ def load():
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run `make -C bbdm_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "bbdm_amd has no CPU/PyTorch fallback by design.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
-        fn.restype = res
-        fn.argtypes = args
-    v = lib.bbdm_version()
-    if v != ABI_VERSION:
-        raise BBDMHipError(f"libbbdm_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild it")
-    _lib = lib
-    return lib
+    _lib = bind(LIB_PATH)
+    return _lib
+
+
+# ---- the three places the package touches the HIP runtime through torch (device memory / streams are torch's) ---------
+def require_gpu(*tensors):
+    """No CPU fallback by design: every tensor handed to the kernels must live on a GPU."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise BBDMHipError("bbdm_amd runs on the GPU only (no CPU fallback by design); "
+                               f"got a tensor on {t.device}")
+
+
+def current_stream(device) -> int:
+    """Raw ``hipStream_t`` of torch's current stream on ``device`` (the kernels are enqueued there)."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def device_guard(device):
+    """Context manager making ``device`` the current HIP device for the calls inside it.
+
+    torch's default stream handle is 0 -- the NULL stream, which HIP binds to the *current* device, not to the device
+    of the pointers passed: without this guard a model living on cuda:1 in a process that never called ``set_device``
+    (the reference's ``main.py --gpu_ids 1``) would launch on device 0 with device-1 pointers."""
+    import torch
+    return torch.cuda.device(device)
 
 
 def check(rc: int, what: str = ""):

@@ -62,9 +62,9 @@ class _LossFn(torch.autograd.Function):
         t, p = target.contiguous().float(), pred.contiguous().float()
         partial = torch.zeros(1, dtype=torch.float64, device=p.device)
         out = torch.empty(1, dtype=torch.float32, device=p.device)
-        st = torch.cuda.current_stream(p.device).cuda_stream
-        _lib.call("bbdm_bb_loss_f32", t.data_ptr(), p.data_ptr(), partial.data_ptr(), out.data_ptr(), p.numel(),
-                  loss_type, st)
+        with _lib.device_guard(p.device):
+            _lib.call("bbdm_bb_loss_f32", t.data_ptr(), p.data_ptr(), partial.data_ptr(), out.data_ptr(), p.numel(),
+                      loss_type, _lib.current_stream(p.device))
         ctx.save_for_backward(t, p)
         ctx.loss_type = loss_type
         return out[0]
@@ -74,15 +74,14 @@ class _LossFn(torch.autograd.Function):
         t, p = ctx.saved_tensors
         gs = g.reshape(1).contiguous().float()
         dp = torch.empty_like(p)
-        st = torch.cuda.current_stream(p.device).cuda_stream
-        _lib.call("bbdm_bb_loss_bwd_f32", p.data_ptr(), t.data_ptr(), gs.data_ptr(), dp.data_ptr(), p.numel(),
-                  ctx.loss_type, st)
+        with _lib.device_guard(p.device):
+            _lib.call("bbdm_bb_loss_bwd_f32", p.data_ptr(), t.data_ptr(), gs.data_ptr(), dp.data_ptr(), p.numel(),
+                      ctx.loss_type, _lib.current_stream(p.device))
         return None, dp, None
 
 
 def bb_loss(target, pred, loss_type: str):
     """mean|target - pred| ('l1') or mean (target - pred)^2 ('l2'), differentiable w.r.t. ``pred``
     (BrownianBridgeModel.py:114-117)."""
-    if not pred.is_cuda:
-        raise _lib.BBDMHipError("bbdm_amd runs on the GPU only (no CPU fallback by design)")
+    _lib.require_gpu(pred, target)
     return _LossFn.apply(target, pred, {"l1": 0, "l2": 1}[loss_type])

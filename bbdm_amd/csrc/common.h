@@ -29,6 +29,15 @@ void bbdm_set_error(const char* fmt, ...);
         }                                                                              \
     } while (0)
 
+// hipFuncSetAttribute applies to the CURRENT device: the "already raised the LDS limit" caches are kept per device
+// (a process may drive several GPUs: the reference's `main.py --gpu_ids 1` runs on cuda:1 without set_device).
+constexpr int BBDM_MAX_DEVICES = 64;
+static inline int bbdm_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BBDM_MAX_DEVICES) d = 0;
+    return d;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int ceil_pow2(int v) {
     int p = 1;

@@ -372,48 +372,6 @@ conv_igemm_f32(const ConvArgs a_in) {
         // load -- measured 4.6 us per phase.  The activation tile is therefore requested TWO phases ahead (two register
         // sets, loop unrolled by two so that they keep static names); the weight slab (L2-resident) stays one ahead.
         float4 preg2[PSLOTS];
-        constexpr bool STRAIGHT = (VAR & 8) != 0;
-        if constexpr (STRAIGHT) {
-            // EXPERIMENTAL (opt-in: BBDM_GEMM_PREFETCH2=1; written at the end of round 1 without GPU time left to run
-            // it -- not part of any measured number).  In the loop below the tail conditions and the per-slot validity
-            // tests are branches, and across branches the waitcnt pass falls back to vmcnt(0): the wait in front of the
-            // LDS stores then also covers the activation tile requested for phase+2, so the two-phase distance is only
-            // nominal.  This variant is straight-line: the host guarantees a full tile (every slot valid, Cin % 16 == 0),
-            // loads past the end are clamped to the last chunk (redundant, never consumed) and the stores of the last
-            // phase go to the idle buffer -- so the compiler can count: vmcnt(PSLOTS) before the weight slab is stored.
-            const int last = nphase - 1;
-            auto load_patch_nc = [&](float4 (&dst)[PSLOTS], int chunk) {
-#pragma unroll
-                for (int s = 0; s < PSLOTS; ++s) dst[s] = *reinterpret_cast<const float4*>(a.x + goff[s] + chunk * KC);
-            };
-            auto load_w_nc = [&](int phase) {
-                const float* src = wsrc + (size_t)phase * wPhaseStride;
-#pragma unroll
-                for (int s = 0; s < WSLOTS; ++s) wreg[s] = *reinterpret_cast<const float4*>(src + s * NTHR * 4);
-            };
-            auto store_patch_nc = [&](float4 (&src)[PSLOTS], float* dst) {
-#pragma unroll
-                for (int s = 0; s < PSLOTS; ++s) {
-                    const int f = tid + s * NTHR;
-                    *reinterpret_cast<float4*>(dst + (f >> 2) * KP + (f & 3) * 4) = src[s];
-                }
-            };
-            auto phase_nc = [&](int phase, float4 (&cur)[PSLOTS], float4 (&nxt)[PSLOTS]) {
-                load_w_nc(min(phase + 1, last));
-                load_patch_nc(nxt, min(phase + 2, last));
-                mfma_phase(pbuf + (phase & 1) * patchFloats, wbuf + (phase & 1) * (BN * KP));
-                store_w(wbuf + ((phase + 1) & 1) * (BN * KP));
-                store_patch_nc(cur, pbuf + ((phase + 1) & 1) * patchFloats);
-                __syncthreads();
-            };
-            load_patch_nc(preg, min(phase_begin + 1, last));
-            int phase = phase_begin;
-            for (; phase + 1 < nphase; phase += 2) {
-                phase_nc(phase, preg, preg2);
-                phase_nc(phase + 1, preg2, preg);
-            }
-            if (phase < nphase) phase_nc(phase, preg, preg2);
-        } else {
         auto gemm_phase = [&](int phase, float4 (&cur)[PSLOTS], float4 (&nxt)[PSLOTS]) {
             // cur holds chunk phase+1 (requested during the previous phase); nxt receives chunk phase+2
             if (phase + 1 < nphase) load_w(phase + 1);
@@ -429,7 +387,6 @@ conv_igemm_f32(const ConvArgs a_in) {
         for (int phase = phase_begin; phase < nphase; phase += 2) {
             gemm_phase(phase, preg, preg2);
             if (phase + 1 < nphase) gemm_phase(phase + 1, preg2, preg);
-        }
         }
     } else
     for (int phase = phase_begin; phase < nphase; ++phase) {
@@ -477,223 +434,6 @@ conv_igemm_f32(const ConvArgs a_in) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (opt-in with BBDM_CONV_GLDS=1): the same tiling, but both operands reach LDS with global_load_lds_dwordx4 (no staging
-// registers, no ds_write pass) and run further ahead of the MFMAs:
-//   * weights: 3-slot ring, the slab of phase p+2 is requested at the start of phase p;
-//   * patch  : 2 buffers, the next chunk's patch is requested 4 taps before the chunk boundary;
-//   * completion by COUNTED s_waitcnt vmcnt(N) (only the slab needed next must have landed) + a raw s_barrier.
-// An LDS-DMA writes wave-uniform-base + lane*16 B, so the LDS images are linear ([pixel][16] / [cout][16]) and the
-// bank-conflict fix moves from padding to an XOR swizzle applied to the per-lane SOURCE address and to the reads:
-// 16-byte slot q of row r lives at physical slot q ^ ((r >> 2) & 3)  ->  every 16-lane ds_read_b128 group still hits
-// 16 distinct slots.  Out-of-image / channel-tail lanes read a zero page instead (the DMA cannot write constants).
-// Measured against the register-staged kernel above (tools/conv_bench.py): see DESIGN.md §4.1.
-// ------------------------------------------------------------------------------------------------------------------
-__device__ float g_zero_page[64];      // zero-initialised device memory: source of padding for the LDS-DMA loads
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, bool SPLIT>
-__global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
-conv_igemm_glds_f32(const ConvArgs a_in) {
-    ConvArgs a = a_in;
-    a.x += (size_t)blockIdx.z * a.xz;
-    a.w += (size_t)blockIdx.z * a.wz;
-    a.out += (size_t)blockIdx.z * a.oz;
-    constexpr int NTHR = WM * WN * 64;
-    constexpr int MT = BM / WM / 32;
-    constexpr int NTL = BN / WN / 32;
-    constexpr int WSLOTS = (BN * KC / 4) / NTHR;
-    constexpr int PBUF = PSLOTS * NTHR * 4;          // floats per patch buffer (>= patchPix * 16, tail = padding)
-    constexpr int WBUF = BN * KC;                    // floats per weight slab
-    static_assert((BN * KC / 4) % NTHR == 0, "weight slab must divide evenly");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* pbuf = smem;                  // [2][PBUF]
-    float* wbuf = smem + 2 * PBUF;       // [3][WBUF]
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)smem;   // LDS byte address
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    int bid = xcd_swizzled_block();
-    const int n_tile = bid % a.tilesN;
-    bid /= a.tilesN;
-    const int tile_x = bid % a.tilesX;
-    bid /= a.tilesX;
-    const int tile_y = bid % a.tilesY;
-    const int ig = bid / a.tilesY;
-    const int TW = 1 << a.TWl, TH = 1 << a.THl;
-    const int img0 = ig * a.imgs;
-    const int h0 = tile_y * TH - a.pad, w0 = tile_x * TW - a.pad;
-    const int cout0 = n_tile * BN;
-
-    // ---- per-thread DMA sources: slot s of this lane is 16-byte unit L = tid + s*NTHR of the linear LDS image ------
-    const float* psrc[PSLOTS];           // nullptr-equivalent = zero page
-    uint32_t pq = 0;                     // logical 16-B slot (0..3) of each patch slot, 2 bits each
-    const int nPatchVec = a.patchPix * (KC / 4);
-#pragma unroll
-    for (int s = 0; s < PSLOTS; ++s) {
-        const int L = tid + s * NTHR;
-        psrc[s] = g_zero_page;
-        if (L < nPatchVec) {
-            const int pp = L >> 2;
-            const int q = (L & 3) ^ ((pp >> 2) & 3);
-            const int img_l = pp / (a.PH * a.PW);
-            const int rem = pp - img_l * (a.PH * a.PW);
-            const int py = rem / a.PW, px = rem - py * a.PW;
-            const int n = img0 + img_l, h = h0 + py, w = w0 + px;
-            pq |= (uint32_t)q << (2 * s);
-            if (n < a.N && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                psrc[s] = a.x + (size_t)((n * a.H + h) * a.W + w) * a.ldx + q * 4;
-        }
-    }
-    const float* wsrc[WSLOTS];
-    const size_t wPhaseStride = (size_t)a.CoutPad * KC;
-#pragma unroll
-    for (int s = 0; s < WSLOTS; ++s) {
-        const int L = tid + s * NTHR;
-        const int n = L >> 2;
-        const int q = (L & 3) ^ ((n >> 2) & 3);
-        wsrc[s] = a.w + (size_t)cout0 * KC + n * KC + q * 4;
-    }
-
-    // ---- per-lane fragment coordinates ------------------------------------------------------------------------
-    const int hi = lane >> 5;
-    int apix[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = wm * (BM / WM) + mt * 32 + (lane & 31);
-        int img_l = m >> (a.THl + a.TWl);
-        if (img_l >= a.imgs) img_l = 0;
-        apix[mt] = img_l * a.PH * a.PW + ((m >> a.TWl) & (TH - 1)) * a.PW + (m & (TW - 1));
-    }
-    int boff[NTL][KC / 8];
-#pragma unroll
-    for (int nt = 0; nt < NTL; ++nt) {
-        const int n = wn * (BN / WN) + nt * 32 + (lane & 31);
-#pragma unroll
-        for (int kg = 0; kg < KC / 8; ++kg) boff[nt][kg] = n * KC + (((kg * 2 + hi) ^ ((n >> 2) & 3)) << 2);
-    }
-
-    f32x16 acc[MT][NTL];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NTL; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-
-    auto dma_patch = [&](int chunk, float* dst) {
-        const int cbase = chunk * KC;
-#pragma unroll
-        for (int s = 0; s < PSLOTS; ++s) {
-            const int q = (pq >> (2 * s)) & 3;
-            const float* src = (cbase + q * 4 < a.Cin) ? psrc[s] + cbase : g_zero_page;
-            if (psrc[s] == g_zero_page) src = g_zero_page;
-            glds16(src, dst + (s * NTHR + wave * 64) * 4);
-        }
-    };
-    auto dma_w = [&](int phase, float* dst) {
-        const int chunk = phase / a.taps, tap = phase - chunk * a.taps;
-        const size_t o = (size_t)(tap * a.nchunks + chunk) * wPhaseStride;
-#pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) glds16(wsrc[s] + o, dst + (s * NTHR + wave * 64) * 4);
-    };
-
-    const int chunk_begin = blockIdx.y * a.chunks_per_split;
-    const int chunk_end = min(a.nchunks, chunk_begin + a.chunks_per_split);
-    const int phase_begin = chunk_begin * a.taps;
-    const int nphase = chunk_end * a.taps;
-    const int plead_tap = a.taps >= 6 ? a.taps - 5 : 0;      // 3x3: request the next patch at tap 4
-
-    // ---- prologue: patch(chunk_begin), W(p0), W(p0+1) -------------------------------------------------------------
-    dma_patch(chunk_begin, pbuf + (chunk_begin & 1) * PBUF);
-    dma_w(phase_begin, wbuf + (phase_begin % 3) * WBUF);
-    if (phase_begin + 1 < nphase) {
-        dma_w(phase_begin + 1, wbuf + ((phase_begin + 1) % 3) * WBUF);
-        wait_vmcnt<WSLOTS>();
-    } else {
-        wait_vmcnt<0>();
-    }
-    asm volatile("s_barrier" ::: "memory");
-
-    int chunk = chunk_begin, tap = 0;
-    for (int phase = phase_begin; phase < nphase; ++phase) {
-        const bool last_tap = tap == a.taps - 1;
-        const bool req_patch = tap == plead_tap && chunk + 1 < chunk_end;
-        const bool req_w = phase + 2 < nphase;
-        // order matters for the counted wait below: patch first, then the weight slab
-        if (req_patch) dma_patch(chunk + 1, pbuf + ((chunk + 1) & 1) * PBUF);
-        if (req_w) dma_w(phase + 2, wbuf + ((phase + 2) % 3) * WBUF);
-
-        const int r = tap / 3, sft = tap - r * 3;
-        const int tapoff = a.taps == 1 ? 0 : r * a.PW + sft;
-        // Fragment reads are inline asm: for a compiler-visible LDS load hipcc drains EVERY outstanding LDS-DMA first
-        // (s_waitcnt vmcnt(0) before the first ds_read), which would serialise the pipeline.  The buffers read here
-        // were completed by the counted wait + barrier that ended the previous phase.
-        const uint32_t pa = lds_base + (uint32_t)((chunk & 1) * PBUF) * 4u;
-        const uint32_t wa = lds_base + (uint32_t)(2 * PBUF + (phase % 3) * WBUF) * 4u;
-        f32x4 fa[4], fb[4];                    // [kg * 2 + tile]; native vectors so that they can be asm operands
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = fb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kg = 0; kg < KC / 8; ++kg) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int pp = apix[mt] + tapoff;
-                const uint32_t ad = pa + (uint32_t)(pp * KC + (((kg * 2 + hi) ^ ((pp >> 2) & 3)) << 2)) * 4u;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fa[kg * 2 + mt]) : "v"(ad));
-            }
-#pragma unroll
-            for (int nt = 0; nt < NTL; ++nt) {
-                const uint32_t ad = wa + (uint32_t)boff[nt][kg] * 4u;
-                asm volatile("ds_read_b128 %0, %1" : "=v"(fb[kg * 2 + nt]) : "v"(ad));
-            }
-        }
-        static_assert(KC / 8 == 2 && MT <= 2 && NTL <= 2, "fragment registers are indexed [kg * 2 + tile]");
-        {
-            f32x4 &a0 = fa[0], &a1 = fa[1], &a2 = fa[2], &a3 = fa[3], &b0 = fb[0], &b1 = fb[1], &b2 = fb[2], &b3 = fb[3];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kg = 0; kg < KC / 8; ++kg)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) {
-                    const f32x4 av = fa[kg * 2 + mt], bv = fb[kg * 2 + nt];
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[mt][nt], 0, 0, 0);
-                }
-
-        // W(phase+1) must have landed; the slab requested in this phase (and a patch requested in this phase that
-        // is not needed before the next chunk) may stay in flight.  Loads complete in issue order.
-        const bool patch_may_fly = req_patch && !last_tap;
-        if (req_w) {
-            if (patch_may_fly) wait_vmcnt<PSLOTS + WSLOTS>(); else wait_vmcnt<WSLOTS>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        asm volatile("s_barrier" ::: "memory");
-        if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
-    }
-    conv_epilogue<BM, BN, WM, WN, SPLIT>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
-}
-
 // out = sum_s ws[s] + bias (+ residual): fixed summation order -> deterministic
 __global__ void conv_splitk_reduce_kernel(const ConvArgs a) {
     const size_t M = (size_t)a.N * a.H * a.W;
@@ -726,28 +466,14 @@ int set_lds_limit(K kernel, size_t bytes) {
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
 int launch_variant(const ConvArgs& a, size_t lds, long long blocks, hipStream_t stream) {
     auto kern = conv_igemm_f32<BM, BN, WM, WN, PSLOTS, OCC, VAR>;
-    static size_t lds_set = 0;
+    static size_t lds_set_dev[BBDM_MAX_DEVICES] = {};
+    size_t& lds_set = lds_set_dev[bbdm_device_slot()];
     if (lds > lds_set) {
         if (set_lds_limit(kern, lds) != 0) {
             bbdm_set_error("conv: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
         }
         lds_set = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits, a.batch), dim3(WM * WN * 64), lds, stream, a);
-    return 0;
-}
-
-template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, bool SPLIT>
-int launch_glds(const ConvArgs& a, size_t lds, long long blocks, hipStream_t stream) {
-    auto kern = conv_igemm_glds_f32<BM, BN, WM, WN, PSLOTS, OCC, SPLIT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (set_lds_limit(kern, lds) != 0) {
-            bbdm_set_error("conv(glds): hipFuncSetAttribute(%zu B LDS) failed", lds);
-            return BBDM_E_LAUNCH;
-        }
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, a.splits, a.batch), dim3(WM * WN * 64), lds, stream, a);
     return 0;
@@ -794,37 +520,21 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
         }
     }
     const int var = (a.pre_sc ? 1 : 0) | (a.splits > 1 ? 2 : 0);
-    int lrc;
-    // opt-in (BBDM_CONV_GLDS=1): measured equal-to-slightly-slower than the register-staged kernel
-    static const bool use_glds = []() { const char* e = getenv("BBDM_CONV_GLDS"); return e && e[0] == '1'; }();
-    if (use_glds && !a.pre_sc) {
-        const size_t lds2 = ((size_t)2 * PSLOTS * WM * WN * 64 * 4 + 3 * BN * KC) * sizeof(float);
-        if (a.patchPix * (KC / 4) <= PSLOTS * WM * WN * 64 && lds2 <= 160 * 1024) {
-            lrc = a.splits > 1 ? launch_glds<BM, BN, WM, WN, PSLOTS, OCC, true>(a, lds2, blocks, stream)
-                               : launch_glds<BM, BN, WM, WN, PSLOTS, OCC, false>(a, lds2, blocks, stream);
-            if (lrc != 0) return lrc;
-            goto launched;
+    int lrc = 0;
+    bool tile_gemm = false;
+    if constexpr (BM == 256 && PSLOTS == 2)          // the batched tile-GEMM instantiation (bbdm_conv1x1_batched)
+        tile_gemm = var == 0 && a.taps == 1;
+    if (tile_gemm) {
+        if constexpr (BM == 256 && PSLOTS == 2) lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 4>(a, lds, blocks, stream);
+    } else {
+        switch (var) {
+            case 0: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 0>(a, lds, blocks, stream); break;
+            case 1: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 1>(a, lds, blocks, stream); break;
+            case 2: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 2>(a, lds, blocks, stream); break;
+            default: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 3>(a, lds, blocks, stream); break;
         }
-    }
-    if constexpr (BM == 256 && PSLOTS == 2) {        // the batched tile-GEMM instantiation (bbdm_conv1x1_batched)
-        if (var == 0 && a.taps == 1) {
-            static const bool straight = []() { const char* e = getenv("BBDM_GEMM_PREFETCH2"); return e && e[0] == '1'; }();
-            const bool full_tiles = a.Cin % KC == 0 && a.W == TWc && a.H % THc == 0 && IM == 1 &&
-                                    a.patchPix * (KC / 4) == PSLOTS * WM * WN * 64;
-            lrc = (straight && full_tiles) ? launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 12>(a, lds, blocks, stream)
-                                           : launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 4>(a, lds, blocks, stream);
-            if (lrc != 0) return lrc;
-            goto launched;
-        }
-    }
-    switch (var) {
-        case 0: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 0>(a, lds, blocks, stream); break;
-        case 1: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 1>(a, lds, blocks, stream); break;
-        case 2: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 2>(a, lds, blocks, stream); break;
-        default: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 3>(a, lds, blocks, stream); break;
     }
     if (lrc != 0) return lrc;
-launched:
     if (a.splits > 1) {
         const size_t total = (size_t)a.N * a.H * a.W * a.Cout;
         size_t rb = (total + 255) / 256;

@@ -289,7 +289,8 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
     constexpr int PAD = TAPS == 9 ? 1 : 0;
     constexpr int XPIX = (PTW + 2 * PAD) * (PTH + 2 * PAD);
     constexpr size_t lds = ((size_t)2 * XPIX * (WI * 32 + 4) + 2 * PTH * PTW * CP) * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[bbdm_device_slot()];
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_f32<TAPS, WI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -152,7 +152,8 @@ extern "C" int bbdm_linear_bwd_f32(const float* dy, const float* x, const float*
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)N * In * sizeof(float);
     BBDM_REQUIRE(lds <= 160 * 1024, "linear_bwd: N*In too large for LDS staging");
-    static size_t lds_set = 0;
+    static size_t lds_set_dev[BBDM_MAX_DEVICES] = {};
+    size_t& lds_set = lds_set_dev[bbdm_device_slot()];
     if (lds > 64 * 1024 && lds > lds_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
@@ -191,7 +192,8 @@ extern "C" int bbdm_linear_f32(const float* x, const float* w, const float* b, f
     const int outs_per_block = 256 >> NBl;
     const bool vec = (In % 4 == 0) && (((uintptr_t)w & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
-    static size_t lds_set[2] = {0, 0};
+    static size_t lds_set_dev[BBDM_MAX_DEVICES][2] = {};
+    size_t (&lds_set)[2] = lds_set_dev[bbdm_device_slot()];
     if (lds > 64 * 1024 && lds > lds_set[vec]) {
         const void* f = vec ? reinterpret_cast<const void*>(linear_kernel<1>) : reinterpret_cast<const void*>(linear_kernel<0>);
         if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

@@ -1,4 +1,4 @@
-// winograd.hip -- 3x3 stride-1 convolution through Winograd F(m x m, 3x3), m = 2, 4 (or, opt-in, 6), on the fp32 matrix core.
+// winograd.hip -- 3x3 stride-1 convolution through Winograd F(m x m, 3x3), m = 2, 4, 6, on the fp32 matrix core.
 //
 // Same call sites as conv_igemm.hip (openaimodel.py:207,233,524,690 on the wide layers); the reference's cuDNN / MIOpen
 // back ends make the same algorithmic choice for 3x3 convolutions (fp32 "Winograd non-fused" is F(4x4,3x3)).
@@ -14,9 +14,10 @@
 // fp32 throughout.  Rounding error relative to an fp64 convolution (rms / max, Cin = 512, unit-variance activations):
 // direct 2e-7 / 3e-7, m = 2: 5e-7 / 6e-7, m = 4: 3e-6 / 1e-5 -- all far inside the 1e-3 per-step bar.
 // m = 6 (8x8 tiles, 64 transform points, 1.78 multiplies per output instead of 2.25; 6e-6 / 1.4e-5 in the same test,
-// tests/test_winograd_math_cpu.py) is EXPERIMENTAL: written at the end of round 1 after the GPU budget was spent, never
-// run on hardware, not reachable unless UNetModel.winograd / BBDM_WINOGRAD is raised to 6.  H, W need not be multiples
-// of 6: edge tiles read zeros beyond the image and their out-of-image outputs are not written.
+// tests/test_winograd_math_cpu.py): H, W need not be multiples of 6 -- edge tiles read zeros beyond the image and their
+// out-of-image outputs are not written.  Measured on MI355X (round 2, profiles/r02_wino_bench.txt): 1.1-1.25x faster
+// than m = 4 per layer where the image is >= 64 pixels a side (little edge waste) and there are >= ~1000 tiles; slower
+// on 16x16 / 32x32 latents, where m = 4 stays (bbdm_amd/unet.py: winograd_tile).
 #include "common.h"
 
 namespace {
@@ -115,11 +116,7 @@ __host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float 
 // PRE: the tensor being convolved is act(x * sc[n][c] + bi[n][c]) (GroupNorm [+FiLM] [+SiLU] folded into per-image,
 //      per-channel coefficients by bbdm_groupnorm_coeffs_f32); zero padding applies to the activated tensor.
 // UP : x is [N, H/2, W/2] and is nearest-upsampled x2 on the fly (Upsample.forward, openaimodel.py:111-121).
-// BL  : EXPERIMENTAL branch-free load path (opt-in: BBDM_WINO_BL=1; written after round 1's GPU budget was spent, not yet
-//       run).  In the default path every tap sits in a bounds-check branch, across which the waitcnt pass falls back to
-//       vmcnt(0): the ISA shows the 36 loads of a tile fully serialised (load, wait, load, wait ...).  Here out-of-image
-//       taps load a clamped (valid) address and are zeroed by a select afterwards, so a column's loads issue together.
-template <int MO, bool PRE, bool UP, bool BL = false>
+template <int MO, bool PRE, bool UP>
 __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
                                                              const float* __restrict__ sc, const float* __restrict__ bi,
                                                              int pre_ld, int pre_silu, int N, int H, int W, int C,
@@ -149,19 +146,6 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
             for (int i = 0; i < AL; ++i) {
                 const int h = MO * th - 1 + i;
                 float4 v = f4zero();
-                if constexpr (BL) {
-                    const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
-                    const int hs = UP ? hc >> 1 : hc, wsrc = UP ? wc >> 1 : wc;
-                    v = *reinterpret_cast<const float4*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
-                    if (PRE) {
-                        v.x = v.x * s4.x + b4.x; v.y = v.y * s4.y + b4.y;
-                        v.z = v.z * s4.z + b4.z; v.w = v.w * s4.w + b4.w;
-                        const float4 a4 = make_float4(silu_fast(v.x), silu_fast(v.y), silu_fast(v.z), silu_fast(v.w));
-                        v = pre_silu ? a4 : v;
-                    }
-                    // zero by multiplication, not by select: a select lets the compiler sink the load back into a branch
-                    v = ((h >= 0 && h < H && w >= 0 && w < W) ? 1.f : 0.f) * v;
-                } else
                 if (h >= 0 && h < H && w >= 0 && w < W) {
                     const int hs = UP ? h >> 1 : h, wsrc = UP ? w >> 1 : w;
                     v = *reinterpret_cast<const float4*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
@@ -190,10 +174,7 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 
 // ---- (3) output transform: one thread = one (tile, output-channel quad) ---------------------------------------------
 // y[MO*th + a][MO*tw + b] = (A^T m A)[a][b] + bias (+ residual)
-// BL (experimental, BBDM_WINO_BL=1, see the input kernel): the default path adds the residual pixel by pixel -- load,
-// vmcnt(0) (which on gfx9 also waits for the previous pixel's store), store: m^2 serialised round trips per thread.  The
-// BL path fetches the residuals of one output row together, then stores the row.
-template <int MO, bool BL = false>
+template <int MO>
 __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int ldr, int res_per_image,
@@ -224,21 +205,6 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
         for (int a = 0; a < MO; ++a) {
             float4 o[MO];
             at_transform<MO>(s[a], o);
-            if constexpr (BL) {
-                const size_t pix0 = (size_t)(n * H + MO * th + a) * W + MO * tw;
-                float4 rv[MO];
-#pragma unroll
-                for (int b = 0; b < MO; ++b) rv[b] = f4zero();
-                if (res) {
-#pragma unroll
-                    for (int b = 0; b < MO; ++b)
-                        rv[b] = *reinterpret_cast<const float4*>(res_per_image ? res + (size_t)n * ldr + c
-                                                                               : res + (pix0 + b) * ldr + c);
-                }
-#pragma unroll
-                for (int b = 0; b < MO; ++b) *reinterpret_cast<float4*>(y + (pix0 + b) * ldy + c) = (o[b] + b4) + rv[b];
-                continue;
-            }
 #pragma unroll
             for (int b = 0; b < MO; ++b) {
                 const size_t pix = (size_t)(n * H + MO * th + a) * W + MO * tw + b;
@@ -253,7 +219,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
     }
 }
 
-// ---- m = 6 (experimental, see the header): 8x8 tiles, one thread = one (tile, channel PAIR) so that the 64 values of
+// ---- m = 6 (see the header): 8x8 tiles, one thread = one (tile, channel PAIR) so that the 64 values of
 // a tile stay in registers; TH / TW are rounded up and edge tiles are masked.
 template <bool PRE, bool UP>
 __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __restrict__ x, int ldx, float* __restrict__ V,
@@ -403,10 +369,6 @@ inline size_t tiles_padded(int N, int H, int W, int m) {
     return (tiles_raw(N, H, W, m) + 255) / 256 * 256;      // whole 8x32 GEMM tiles
 }
 inline int planes(int m) { return (m + 2) * (m + 2); }
-inline bool branch_free_out() {
-    static const bool on = []() { const char* e = getenv("BBDM_WINO_BL"); return e && e[0] == '1'; }();
-    return on;
-}
 
 }  // namespace
 
@@ -483,16 +445,9 @@ extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V,
         BBDM_CHECK_LAUNCH("winograd_input");
         return BBDM_OK;
     }
-    static const bool branch_free = []() { const char* e = getenv("BBDM_WINO_BL"); return e && e[0] == '1'; }();
 #define BBDM_WINO_IN(MO, PRE, UP)                                                                                         \
-    do {                                                                                                                  \
-        if (branch_free)                                                                                                  \
-            hipLaunchKernelGGL((winograd_input_kernel<MO, PRE, UP, true>), g, b, 0, st, x, ldx, V, pre_scale, pre_bias,     \
-                               pre_ld, pre_silu, N, H, W, CinPad, vplane);                                                \
-        else                                                                                                              \
-            hipLaunchKernelGGL((winograd_input_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, V, pre_scale, pre_bias, pre_ld,  \
-                               pre_silu, N, H, W, CinPad, vplane);                                                        \
-    } while (0)
+    hipLaunchKernelGGL((winograd_input_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, V, pre_scale, pre_bias, pre_ld, pre_silu, \
+                       N, H, W, CinPad, vplane)
 #define BBDM_WINO_IN_M(MO)                                                                      \
     do {                                                                                        \
         if (pre_scale) { if (upsample) BBDM_WINO_IN(MO, true, true); else BBDM_WINO_IN(MO, true, false); }   \
@@ -539,9 +494,6 @@ extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias
                            Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
     else if (m == 2)
         hipLaunchKernelGGL(winograd_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
-                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
-    else if (branch_free_out())
-        hipLaunchKernelGGL((winograd_output_kernel<4, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
                            Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
     else
         hipLaunchKernelGGL(winograd_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,

@@ -31,15 +31,14 @@ _OBJECTIVES = {"grad": 0, "noise": 1, "ysubx": 2}
 _LOSSES = {"l1": 0, "l2": 1}
 
 
-def _stream(t: torch.Tensor):
-    return torch.cuda.current_stream(t.device).cuda_stream
-
-
 def _need_gpu(*ts):
-    for t in ts:
-        if t is not None and not t.is_cuda:
-            raise _lib.BBDMHipError("bbdm_amd runs on the GPU only (no CPU fallback by design); "
-                                    f"got a tensor on {t.device}")
+    _lib.require_gpu(*ts)
+
+
+def _launch(t: torch.Tensor, name: str, *args):
+    """One C-ABI call on ``t``'s device and torch's current stream there."""
+    with _lib.device_guard(t.device):
+        _lib.call(name, *args, _lib.current_stream(t.device))
 
 
 def _f32c(t):
@@ -166,8 +165,8 @@ class BrownianBridgeModel(nn.Module):
         a, b = _f32c(a), _f32c(b)
         partial_ = torch.zeros(1, dtype=torch.float64, device=a.device)
         out = torch.empty(1, dtype=torch.float32, device=a.device)
-        _lib.call("bbdm_bb_loss_f32", a.data_ptr(), b.data_ptr(), partial_.data_ptr(), out.data_ptr(), a.numel(),
-                  _LOSSES[self.loss_type], _stream(a))
+        _launch(a, "bbdm_bb_loss_f32", a.data_ptr(), b.data_ptr(), partial_.data_ptr(), out.data_ptr(), a.numel(),
+                  _LOSSES[self.loss_type])
         return out[0]
 
     def q_sample(self, x0, y, t, noise=None):
@@ -179,9 +178,9 @@ class BrownianBridgeModel(nn.Module):
         x0c, yc, nc = _f32c(x0), _f32c(y), _f32c(noise)
         tc = t.to(torch.int64).contiguous()
         x_t, target = torch.empty_like(x0c), torch.empty_like(x0c)
-        _lib.call("bbdm_bb_q_sample_f32", x0c.data_ptr(), yc.data_ptr(), nc.data_ptr(), tc.data_ptr(),
+        _launch(x0c, "bbdm_bb_q_sample_f32", x0c.data_ptr(), yc.data_ptr(), nc.data_ptr(), tc.data_ptr(),
                   self.m_t.data_ptr(), self.variance_t.data_ptr(), x_t.data_ptr(), target.data_ptr(),
-                  x0c.shape[0], x0c[0].numel(), _OBJECTIVES[self.objective], _stream(x0c))
+                  x0c.shape[0], x0c[0].numel(), _OBJECTIVES[self.objective])
         return x_t, target
 
     def predict_x0_from_objective(self, x_t, y, t, objective_recon):
@@ -192,9 +191,9 @@ class BrownianBridgeModel(nn.Module):
         a, b, p = _f32c(x_t), _f32c(y), _f32c(objective_recon)
         tc = t.to(torch.int64).contiguous()
         out = torch.empty_like(a)
-        _lib.call("bbdm_bb_predict_x0_f32", a.data_ptr(), b.data_ptr(), p.data_ptr(), tc.data_ptr(),
+        _launch(a, "bbdm_bb_predict_x0_f32", a.data_ptr(), b.data_ptr(), p.data_ptr(), tc.data_ptr(),
                   self.m_t.data_ptr(), self.variance_t.data_ptr(), out.data_ptr(), a.shape[0], a[0].numel(),
-                  _OBJECTIVES[self.objective], _stream(a))
+                  _OBJECTIVES[self.objective])
         return out
 
     @torch.no_grad()
@@ -216,17 +215,22 @@ class BrownianBridgeModel(nn.Module):
         _need_gpu(x_t, y)
         steps = self._steps_host()
         step = steps[i]
+        nxt = 0 if step == 0 else steps[i + 1]
+        if not (0 <= step < self.num_timesteps and 0 <= nxt < self.num_timesteps):
+            # the reference gathers m_t[t] and fails there (sample_type 'cosine' starts at t = num_timesteps:
+            # BrownianBridgeModel.py:74-77); the kernels read the tables unchecked, so the check lives here
+            raise IndexError(f"timestep {max(step, nxt)} is out of range for the {self.num_timesteps}-entry schedule")
         x_t, y = _f32c(x_t), _f32c(y)
         t = torch.full((x_t.shape[0],), step, device=x_t.device, dtype=torch.long)
         objective_recon = self.denoise_fn(x_t, timesteps=t, context=context)
         is_last = step == 0
         noise = None if is_last else torch.randn_like(x_t)
         x_next, x0_recon = torch.empty_like(x_t), torch.empty_like(x_t)
-        _lib.call("bbdm_bb_p_sample_step_f32", x_t.data_ptr(), y.data_ptr(), objective_recon.data_ptr(),
+        _launch(x_t, "bbdm_bb_p_sample_step_f32", x_t.data_ptr(), y.data_ptr(), objective_recon.data_ptr(),
                   None if noise is None else noise.data_ptr(), self.m_t.data_ptr(), self.variance_t.data_ptr(),
                   step, 0 if is_last else steps[i + 1], 1 if is_last else 0, float(self.eta),
                   1 if clip_denoised else 0, _OBJECTIVES[self.objective], x_next.data_ptr(), x0_recon.data_ptr(),
-                  x_t.shape[0], x_t[0].numel(), _stream(x_t))
+                  x_t.shape[0], x_t[0].numel())
         if is_last:
             return x0_recon, x0_recon
         return x_next, x0_recon

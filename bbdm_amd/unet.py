@@ -269,18 +269,20 @@ class _PackedWinograd:
             self.key = key
 
 
-def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 4) -> int:
+def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6) -> int:
     """Output tile m of the Winograd F(m x m, 3x3) path for this layer, or 0 = direct implicit GEMM.
 
-    Measured on MI355X (tools/wino_bench.py): the 2.25x (m = 2) / 4x (m = 4) cut in MFMA work must
-    outweigh the HBM passes of the two transforms -- (m+2)^2/m^2 x the input plus the same for the output -- which
-    needs wide layers (harmonic width cin*cout/(cin+cout)) and enough tiles to fill the chip with 256-row GEMM tiles."""
+    Measured on MI355X (tools/wino_bench.py -> profiles/r02_wino_bench.txt): the 2.25x (m = 2) / 4x
+    (m = 4) / 5.06x (m = 6) cut in MFMA work must outweigh the HBM passes of the two transforms -- (m+2)^2/m^2 x the input
+    plus the same for the output -- which needs wide layers (harmonic width cin*cout/(cin+cout)) and enough tiles to fill
+    the chip with 256-row GEMM tiles.  m = 6 beats m = 4 by 1.1-1.25x once there are >= ~900 8x8 tiles and the masked edge
+    tiles waste <= 10 % (H, W need not be multiples of 6); on 32x32 / 16x16 latents (27 % edge waste) m = 4 stays."""
     if cin % 4 or cout % 4 or cout < 128:
         return 0
     hw = cin * cout / (cin + cout)
-    # m = 6 (64 transform points, 1.78 multiplies per output): EXPERIMENTAL, never the default (max_m defaults to 4);
-    # thresholds are placeholders until it has been measured.  H, W need not be multiples of 6 (masked edge tiles).
-    if max_m >= 6 and H >= 12 and W >= 12 and cin >= 128 and hw >= 64 and N * -(-H // 6) * -(-W // 6) >= 256:
+    t6h, t6w = -(-H // 6), -(-W // 6)
+    if (max_m >= 6 and cin >= 128 and hw >= 64 and N * t6h * t6w >= 900
+            and (6 * t6h) * (6 * t6w) <= 1.10 * H * W):
         return 6
     if max_m >= 4 and H % 4 == 0 and W % 4 == 0 and cin >= 128 and hw >= 64 and N * (H // 4) * (W // 4) >= 256:
         return 4
@@ -405,8 +407,8 @@ class UNetModel(nn.Module):
         self.fuse_groupnorm: bool = False
         # 3x3 convolutions of wide layers through Winograd F(4x4,3x3) / F(2x2,3x3) (csrc/winograd.hip; `winograd_tile`
         # picks per layer).  Plans are cached per setting, so this can be changed between calls (A/B runs).
-        # BBDM_WINOGRAD: largest output tile allowed, 4 (default), 2, or 0 = off (6: experimental, see winograd_tile).
-        self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "4"))
+        # BBDM_WINOGRAD: largest output tile allowed: 6 (default), 4, 2, or 0 = direct kernel everywhere.
+        self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "6"))
         self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
@@ -427,9 +429,7 @@ class UNetModel(nn.Module):
         return self.infer(x, timesteps, context)
 
     def _check_inputs(self, x, context):
-        if not x.is_cuda:
-            raise _lib.BBDMHipError("bbdm_amd.UNetModel runs on the GPU only (no CPU fallback by design); "
-                                    f"got a tensor on {x.device}")
+        _lib.require_gpu(x, context)
         if x.dtype != torch.float32:
             raise TypeError(f"bbdm_amd.UNetModel computes in fp32 like the reference; got {x.dtype}")
         ctx = None
@@ -515,6 +515,9 @@ class _Plan:
         f32 = dict(dtype=torch.float32, device=device)
 
         # ---- embedding path buffers -------------------------------------------------------------------------------
+        # rows per bbdm_linear_f32 / bbdm_linear_bwd_f32 call: both stage [rows x In] (+4 pad) floats in the 160 KB LDS and
+        # take <= 64 rows; In = 4 * model_channels, so wide models (model_channels >= 160) get fewer rows per call
+        self.emb_rows = max(1, min(64, (160 * 1024) // (4 * (ted + 4))))
         self.t_buf = torch.zeros(N, dtype=torch.int64, device=device)
         self.e0 = torch.empty(N, mc, **f32)
         self.e1 = torch.empty(N, ted, **f32)
@@ -1076,14 +1079,18 @@ class _Plan:
         self.dfilm_b = torch.empty(self.film_total, **f32)
         self.d_emb = torch.empty(N, ted, **f32)
         self.d_e1 = torch.empty(N, ted, **f32)
-        self._lin_ws = torch.empty(max(lib.bbdm_linear_bwd_workspace_floats(min(N, 64), ted, self.film_total),
-                                       lib.bbdm_linear_bwd_workspace_floats(min(N, 64), ted, ted), 1), **f32)
+        self._lin_ws = torch.empty(max(lib.bbdm_linear_bwd_workspace_floats(min(N, self.emb_rows), ted, self.film_total),
+                                       lib.bbdm_linear_bwd_workspace_floats(min(N, self.emb_rows), ted, ted), 1), **f32)
         self._bbound: List[tuple] = []
 
     def run_backward(self, dout: torch.Tensor, need_dx: bool):
         """Gradient of everything w.r.t. ``dout`` (NCHW).  Returns (flat parameter gradient, d input NHWC view or None)."""
+        with _lib.device_guard(self.device):
+            return self._run_backward(dout, need_dx)
+
+    def _run_backward(self, dout: torch.Tensor, need_dx: bool):
         m, N = self.m, self.N
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = _lib.current_stream(self.device)
         f32 = dict(dtype=torch.float32, device=self.device)
         self._flat_grad = torch.zeros(self.grad_total, **f32)      # fresh per call: autograd may keep views of it
         self.dout_nchw.copy_(dout)
@@ -1106,8 +1113,9 @@ class _Plan:
         call = _lib.call
         te0, te2 = m.time_embed[0], m.time_embed[2]
         first = True
-        for r0 in range(0, N, 64):
-            r = min(64, N - r0)
+        R = self.emb_rows
+        for r0 in range(0, N, R):
+            r = min(R, N - r0)
             tgt_w = self.dfilm_w if first else torch.empty_like(self.dfilm_w)
             tgt_b = self.dfilm_b if first else torch.empty_like(self.dfilm_b)
             call("bbdm_linear_bwd_f32", self.dfilm.data_ptr() + 4 * r0 * self.film_total,
@@ -1175,8 +1183,9 @@ class _Plan:
         te0, te2 = m.time_embed[0], m.time_embed[2]
         call("bbdm_timestep_embedding_f32", self.t_buf.data_ptr(), m.freqs(self.device).data_ptr(),
              self.e0.data_ptr(), N, mc, stream)
-        for r0 in range(0, N, 64):          # bbdm_linear_f32 handles <= 64 rows per call
-            r = min(64, N - r0)
+        R = self.emb_rows
+        for r0 in range(0, N, R):           # bbdm_linear_f32 stages its rows in LDS: <= emb_rows per call
+            r = min(R, N - r0)
             # e1 holds the PRE-activation of time_embed.0; its SiLU is applied as the next layer's act_in
             call("bbdm_linear_f32", self.e0.data_ptr() + 4 * r0 * mc, te0.weight.data_ptr(), te0.bias.data_ptr(),
                  self.e1.data_ptr() + 4 * r0 * ted, r, mc, ted, 0, 0, stream)
@@ -1211,9 +1220,13 @@ class _Plan:
         return not self.training and self.N * self.H * self.W <= 32 * 64 * 64
 
     def run(self, x, t, ctx, out=None):
+        with _lib.device_guard(self.device):        # NULL-stream launches follow the current device (see _lib.device_guard)
+            return self._run(x, t, ctx, out)
+
+    def _run(self, x, t, ctx, out=None):
         m = self.m
         self.generation = getattr(self, "generation", 0) + 1
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        stream = _lib.current_stream(self.device)
         self._refresh_weights(stream)
         self.x_in.copy_(x)
         if self.ctx_in is not None:
@@ -1228,7 +1241,7 @@ class _Plan:
                 torch.cuda.current_stream(self.device).synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._launch_forward(torch.cuda.current_stream(self.device).cuda_stream)
+                    self._launch_forward(_lib.current_stream(self.device))
                 self._graph, self._graph_key = g, gkey
             self._graph.replay()
         else:

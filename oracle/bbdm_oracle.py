@@ -163,7 +163,8 @@ def timestep_embedding(t: Tensor, dim: int, max_period: float = 10000.0) -> Tens
 
 def _gn(sd: StateDict, key: str, x: Tensor, eps: float = 1e-5) -> Tensor:
     """GroupNorm32(32, C): util.py:199-216."""
-    return F.group_norm(x.float(), 32, sd[key + ".weight"], sd[key + ".bias"], eps).type(x.dtype)
+    w = sd[key + ".weight"]          # fp32 weights: x.float() as in the reference; fp64 weights (test probe): stay in fp64
+    return F.group_norm(x.to(w.dtype), 32, w, sd[key + ".bias"], eps).type(x.dtype)
 
 
 def _conv(sd: StateDict, key: str, x: Tensor, padding: int = 0, stride: int = 1) -> Tensor:
@@ -314,6 +315,7 @@ def unet_forward(sd: StateDict, spec: UNetSpec, x: Tensor, timesteps: Tensor,
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     inp, mid, out = spec.layout()
     emb = timestep_embedding(timesteps, spec.model_channels)
+    emb = emb.to(sd["time_embed.0.weight"].dtype)     # no-op in fp32; lets the tests run the oracle in fp64 as a conditioning probe
     emb = _lin(sd, "time_embed.2", F.silu(_lin(sd, "time_embed.0", emb)))
     if spec.condition_key != "nocond":
         x = torch.cat([x, context], dim=1)

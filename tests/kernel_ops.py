@@ -1,20 +1,63 @@
-"""Tensor-level wrappers over the C-ABI (one function per entry point of include/bbdm_hip.h).
+"""Tensor-level wrappers over the C-ABI (one function per entry point of include/bbdm_hip.h) -- TEST SCAFFOLDING.
 
-They allocate outputs with torch, pass raw device pointers + the current HIP stream, and raise on error.  Used by
-the kernel unit tests and the training path; the inference path (unet._Plan) calls the library directly with
-pre-resolved pointers.  NHWC tensors here are plain contiguous ``[N, H, W, C]`` torch tensors (pitch = C) unless a
-wider buffer + channel slice is passed explicitly via ``ld`` arguments.
+They allocate outputs with torch, pass raw pointers + the current HIP stream, and raise on error.  Used by the kernel
+unit tests and the tools/ benchmarks only; the product path (bbdm_amd/unet.py, model.py) calls the library directly with
+pre-resolved pointers.  NHWC tensors here are plain contiguous ``[N, H, W, C]`` torch tensors (pitch = C) unless a wider
+buffer + channel slice is passed explicitly via ``ld`` arguments.
+
+Two back ends: the real library (GPU tensors; the default), or -- after ``use_emulator()`` -- the host build of the same
+kernel sources running on tools/hipemu's CPU emulation of the HIP device model (CPU tensors; tests/test_emu_*.py).
 """
 from __future__ import annotations
 
+import os
+import sys
 from typing import Optional
 
 import torch
 
-from . import _lib
+from bbdm_amd import _lib as _real
+
+_EMU = None          # ctypes handle of tools/hipemu/_build/libbbdm_emu.so once use_emulator() has been called
+
+
+class _Lib:
+    """The subset of bbdm_amd._lib the wrappers use, routed to the selected back end."""
+    BBDMHipError = _real.BBDMHipError
+
+    @staticmethod
+    def load():
+        return _EMU if _EMU is not None else _real.load()
+
+    @staticmethod
+    def call(name, *args):
+        lib = _Lib.load()
+        rc = getattr(lib, name)(*args)
+        if rc != 0:
+            msg = lib.bbdm_last_error()
+            raise _real.BBDMHipError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+_lib = _Lib
+
+
+def use_emulator(on: bool = True):
+    """Route every wrapper to the CPU-emulated host build (built on demand by tools/hipemu/build.py)."""
+    global _EMU
+    if not on:
+        _EMU = None
+        return None
+    if _EMU is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "tools", "hipemu"))
+        import build as hipemu_build
+        _EMU = _real.bind(hipemu_build.build())
+    return _EMU
 
 
 def _st(t):
+    if not t.is_cuda:
+        return None          # the emulator ignores the stream
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -22,8 +65,8 @@ def _chk(*ts):
     for t in ts:
         if t is None:
             continue
-        if not t.is_cuda:
-            raise _lib.BBDMHipError(f"bbdm_amd ops need GPU tensors (no CPU fallback); got {t.device}")
+        if t.is_cuda == (_EMU is not None):
+            raise _real.BBDMHipError(f"kernel_ops: back end / tensor device mismatch ({t.device}, emulator={_EMU is not None})")
         if t.dtype not in (torch.float32, torch.float64, torch.int64):
             raise TypeError(f"unsupported dtype {t.dtype}")
         if not t.is_contiguous():

@@ -31,7 +31,7 @@ CONV_BWD = [(2, 16, 16, 32, 64, 3), (1, 24, 40, 64, 128, 3), (3, 8, 8, 128, 96, 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks", CONV_BWD)
 def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
-    from bbdm_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(N + H + Cin + Cout)
     x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
     w = (torch.randn(Cout, Cin, ks, ks, generator=g) * 0.05).requires_grad_()
@@ -61,7 +61,7 @@ GN_BWD = [(2, 16, 16, 128), (1, 8, 8, 640), (2, 4, 4, 1536), (2, 8, 8, 96), (3, 
 @pytest.mark.parametrize("N,H,W,C", GN_BWD)
 @pytest.mark.parametrize("mode", ["plain", "film_silu", "silu_pool", "silu_up", "silu_add_acc"])
 def test_groupnorm_backward(dev, N, H, W, C, mode):
-    from bbdm_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(C + H + len(mode))
     x = (torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3).requires_grad_()
     gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).requires_grad_()
@@ -103,7 +103,7 @@ def test_groupnorm_backward(dev, N, H, W, C, mode):
 
 
 def test_resample_only_backward(dev):
-    from bbdm_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 64, 8, 12, generator=g, requires_grad=True)
     for rs, fn in ((1, lambda t: F.avg_pool2d(t, 2, 2)), (2, lambda t: F.interpolate(t, scale_factor=2, mode="nearest"))):
@@ -123,7 +123,7 @@ ATTN_BWD = [(2, 16, 4, 64), (1, 256, 2, 64), (2, 100, 3, 32), (3, 16, 2, 16), (1
 @pytest.mark.parametrize("N,T,heads,ch", ATTN_BWD)
 @pytest.mark.parametrize("new_order", [False, True])
 def test_attention_backward(dev, N, T, heads, ch, new_order):
-    from bbdm_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(T + heads + ch)
     C = heads * ch
     qkv = (torch.randn(N, 3 * C, T, generator=g) * 1.2).requires_grad_()
@@ -148,7 +148,7 @@ def test_attention_backward(dev, N, T, heads, ch, new_order):
 @pytest.mark.parametrize("N,In,Out,act", [(4, 128, 512, False), (16, 512, 1000, True), (33, 96, 70, True),
                                            (64, 512, 2048, True)])
 def test_linear_backward(dev, N, In, Out, act):
-    from bbdm_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(N + In)
     x = torch.randn(N, In, generator=g, requires_grad=True)
     w = (torch.randn(Out, In, generator=g) * 0.05).requires_grad_()

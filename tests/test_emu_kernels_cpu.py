@@ -1,0 +1,117 @@
+"""The kernel parity tests of test_kernels_gpu.py / test_backward_kernels_gpu.py, run on the CPU (no GPU needed).
+
+The SAME kernel sources (bbdm_amd/csrc/*.hip) are compiled for the host against tools/hipemu -- a fiber-based emulation
+of the HIP device model (64-lane wavefronts, __syncthreads, LDS, __shfl, the v_mfma_f32_32x32x2_f32 lane maps,
+atomics) -- and driven through the same C-ABI by the same test bodies, on the smaller parameter sets.  This is how a
+kernel change gets its first correctness check in the build container before GPU minutes are spent; it says nothing
+about performance, and the `-m gpu` tests remain the parity tests proper."""
+import pytest
+import torch
+
+import test_backward_kernels_gpu as BK
+import test_kernels_gpu as K
+from emu_backend import emulated_backend
+
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator():
+    with emulated_backend() as emu:
+        yield emu
+
+
+SMALL_CONV = [c for c in K.CONV_CASES if c[0] * c[1] * c[2] * c[3] * c[4] * c[5] ** 2 <= 3e7]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,res", SMALL_CONV)
+def test_conv2d(N, H, W, Cin, Cout, ks, res):
+    K.test_conv2d(CPU, N, H, W, Cin, Cout, ks, res)
+
+
+SMALL_WINO = [c for c in K.WINO_CASES if c[1] * c[2] * c[3] * c[4] * c[5] <= 3e6]
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,res", SMALL_WINO + [(6, 2, 12, 12, 64, 128, 0), (6, 1, 6, 6, 16, 8, 0),
+                                                                (6, 3, 16, 20, 48, 72, 1)])
+def test_conv3x3_winograd(m, N, H, W, Cin, Cout, res):
+    K.test_conv3x3_winograd(CPU, m, N, H, W, Cin, Cout, res)
+
+
+@pytest.mark.parametrize("m", [2, 4, 6])
+def test_conv3x3_winograd_dgrad_and_slices(m):
+    K.test_conv3x3_winograd_dgrad_and_slices(CPU, m)
+
+
+@pytest.mark.parametrize("m,up,silu", [(2, 1, 1), (4, 0, 1), (4, 1, 0), (6, 1, 1)])
+def test_winograd_stages_fused_producer(m, up, silu):
+    K.test_winograd_stages_fused_producer(CPU, m, up, silu)
+
+
+def test_conv_rejections_and_slices():
+    K.test_conv3x3_winograd_rejects_bad_shapes(CPU)
+    K.test_conv2d_channel_slices(CPU)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 96), (1, 4, 4, 192), (3, 4, 4, 1536), (1, 32, 32, 32)])
+@pytest.mark.parametrize("mode", ["plain", "film_silu", "silu_pool", "silu_up"])
+def test_groupnorm(N, H, W, C, mode):
+    K.test_groupnorm(CPU, N, H, W, C, mode)
+
+
+def test_resample_and_layout():
+    K.test_resample_only(CPU)
+    K.test_layout_roundtrip(CPU)
+
+
+@pytest.mark.parametrize("N,T,heads,ch", [(2, 16, 4, 64), (2, 100, 3, 32), (3, 16, 2, 16), (2, 37, 1, 64), (1, 256, 2, 64)])
+@pytest.mark.parametrize("new_order", [False, True])
+def test_attention(N, T, heads, ch, new_order):
+    K.test_attention(CPU, N, T, heads, ch, new_order)
+
+
+def test_attention_forces_rescale():
+    K.test_attention_forces_rescale(CPU)
+
+
+@pytest.mark.parametrize("N", [1, 4, 33])
+def test_embedding_path(N):
+    K.test_embedding_path(CPU, N)
+
+
+@pytest.mark.parametrize("objective", ["grad", "noise", "ysubx"])
+def test_bridge_arithmetic(objective):
+    K.test_bridge_arithmetic(CPU, objective)
+
+
+@pytest.mark.parametrize("N,H,W,C,Cout,ks,film,silu", [(2, 16, 16, 128, 64, 3, True, True), (3, 8, 8, 96, 128, 3, False, True)])
+def test_conv_with_fused_groupnorm_producer(N, H, W, C, Cout, ks, film, silu):
+    K.test_conv_with_fused_groupnorm_producer(CPU, N, H, W, C, Cout, ks, film, silu)
+
+
+# ---- backward kernels -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks", [(2, 16, 16, 32, 64, 3), (3, 8, 8, 128, 96, 3), (2, 16, 16, 64, 192, 1),
+                                               (1, 13, 9, 8, 3, 3), (2, 8, 8, 4, 32, 3)])
+def test_conv_backward(N, H, W, Cin, Cout, ks):
+    BK.test_conv_backward(CPU, N, H, W, Cin, Cout, ks)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32)])
+@pytest.mark.parametrize("mode", ["plain", "film_silu", "silu_pool", "silu_up", "silu_add_acc"])
+def test_groupnorm_backward(N, H, W, C, mode):
+    BK.test_groupnorm_backward(CPU, N, H, W, C, mode)
+
+
+def test_resample_only_backward():
+    BK.test_resample_only_backward(CPU)
+
+
+@pytest.mark.parametrize("N,T,heads,ch", [(2, 16, 4, 64), (2, 100, 3, 32), (3, 16, 2, 16)])
+@pytest.mark.parametrize("new_order", [False, True])
+def test_attention_backward(N, T, heads, ch, new_order):
+    BK.test_attention_backward(CPU, N, T, heads, ch, new_order)
+
+
+@pytest.mark.parametrize("N,In,Out,act", [(4, 128, 512, False), (33, 96, 70, True)])
+def test_linear_backward(N, In, Out, act):
+    BK.test_linear_backward(CPU, N, In, Out, act)

@@ -1,0 +1,57 @@
+"""Model-level paths on the CPU-emulated kernels (tools/hipemu): the execution plan, the fused bridge update, the
+autograd node and its backward plan run end to end on the golden fixtures of the real reference -- the same assertions
+as tests/test_model_gpu.py / test_training_gpu.py, before any GPU time is spent.  Not a performance path."""
+import pytest
+import torch
+
+import test_model_gpu as M
+import test_training_gpu as T
+from emu_backend import emulated_backend
+from fixtures import load_case, rel_err
+
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulator():
+    with emulated_backend() as emu:
+        yield emu
+
+
+def _build(rec, train=False):
+    m = T.build(rec, CPU)
+    m.denoise_fn.hip_graph = False            # hipGraph capture needs a real device
+    return m.train() if train else m.eval()
+
+
+@pytest.mark.parametrize("name", ["tiny_concat", "tiny_ysubx"])
+def test_unet_forward_and_p_sample_match_reference_golden(name):
+    rec = load_case(name)
+    m = _build(rec)
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"]
+    with torch.no_grad():
+        out = m.denoise_fn(rec["x0"], timesteps=rec["t"], context=ctx)
+    assert rel_err(out, rec["unet_out"]) < M.STEP_TOL
+    eps = rec["p_eps"]
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps
+    try:
+        for clip, i, a_ref, b_ref in rec["p_out"][:2]:
+            a, b = m.p_sample(rec["p_x_t"], rec["y"], ctx, i, clip_denoised=clip)
+            assert rel_err(a, a_ref) < M.STEP_TOL and rel_err(b, b_ref) < M.STEP_TOL, (clip, i)
+    finally:
+        torch.randn_like = orig
+
+
+def test_loss_and_all_parameter_gradients():
+    rec = load_case("tiny_nocond")
+    loss_ref, g_ref = T._oracle_grads(rec)
+    m = _build(rec, train=True)
+    loss, log = m.p_losses(rec["x0"], rec["y"], None, rec["t"], rec["noise"])
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
+    gmax = max(float(v.abs().max()) for v in g_ref.values())
+    for k, p in m.named_parameters():
+        ref = g_ref[k]
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
+        assert float((p.grad - ref).abs().max()) / scale < T.GRAD_TOL, k

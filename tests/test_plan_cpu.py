@@ -25,29 +25,40 @@ def lib_tiles(m, N, H, W):
 def test_winograd_tile_choice_follows_the_measured_crossovers():
     wt = unet.winograd_tile
     # profiles/r01_wino_bench.txt (MI355X): F(4x4) wins on every wide layer with >= 256 tiles ...
-    assert wt(16, 64, 64, 1024, 1024) == 4
-    assert wt(16, 256, 256, 128, 128) == 4          # 1.27x
-    assert wt(16, 128, 128, 128, 512) == 4          # 1.46x
-    assert wt(4, 32, 32, 512, 512) == 4             # 256 tiles: 1.50x
+    assert wt(16, 64, 64, 1024, 1024, 4) == 4
+    assert wt(16, 256, 256, 128, 128, 4) == 4          # 1.27x
+    assert wt(16, 128, 128, 128, 512, 4) == 4          # 1.46x
+    assert wt(4, 32, 32, 512, 512) == 4                # 256 tiles: 1.50x
     # ... loses below that (padded GEMM tiles, launch-bound), where F(2x2) does not pay either
-    assert wt(4, 16, 16, 1024, 1024) == 0           # 0.55x / 0.98x
+    assert wt(4, 16, 16, 1024, 1024) == 0              # 0.55x / 0.98x
     assert wt(32, 4, 4, 1024, 1024) == 0
     assert wt(32, 8, 8, 512, 512) == 0
     # the stem / head / narrow outputs stay on the direct kernel
     assert wt(16, 256, 256, 8, 128) == 0 and wt(16, 256, 256, 128, 3) == 0 and wt(16, 64, 64, 64, 64) == 0
     # H, W not multiples of 4 -> F(2x2) if the layer is wide and large enough, else direct
-    assert wt(16, 66, 66, 512, 512) == 2 and wt(16, 66, 66, 128, 128) == 0 and wt(16, 33, 33, 512, 512) == 0
-    # the cap (UNetModel.winograd / BBDM_WINOGRAD); 6 is the experimental 8x8-tile path and never the default
+    assert wt(16, 66, 66, 512, 512, 4) == 2 and wt(16, 66, 66, 128, 128, 4) == 0 and wt(16, 33, 33, 512, 512) == 0
+    # profiles/r02_wino_bench.txt: F(6x6) beats F(4x4) by 1.1-1.25x with >= ~900 8x8 tiles and <= 10 % edge waste ...
+    assert wt(16, 64, 64, 1024, 1024) == 6             # 2.63 vs 3.28 ms
+    assert wt(16, 256, 256, 128, 128) == 6             # 1.23 vs 1.50 ms
+    assert wt(8, 64, 64, 256, 256) == 6                # 968 tiles: 0.124 vs 0.166 ms
+    assert wt(32, 64, 64, 128, 128) == 6
+    assert wt(16, 66, 66, 512, 512) == 6               # H, W need not be multiples of 6
+    # ... and loses on 32x32 / 16x16 latents (27 % of the 8x8 tiles' outputs fall outside the image)
+    assert wt(32, 32, 32, 512, 512) == 4               # 0.475 vs 0.472 ms
+    assert wt(32, 16, 16, 1024, 1024) == 4             # 0.640 vs 0.486 ms
+    assert wt(8, 32, 32, 512, 512) == 4
+    # the cap (UNetModel.winograd / BBDM_WINOGRAD)
     assert wt(16, 64, 64, 1024, 1024, 2) == 2 and wt(16, 64, 64, 1024, 1024, 0) == 0
-    assert wt(16, 64, 64, 1024, 1024, 6) == 6 and wt(16, 8, 8, 1024, 1024, 6) == 0
+    assert wt(16, 8, 8, 1024, 1024, 6) == 0
     tiny = unet.UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
                           attention_resolutions=(), channel_mult=(1,), num_head_channels=32, condition_key="nocond")
-    assert tiny.winograd == int(__import__("os").environ.get("BBDM_WINOGRAD", "4"))      # the default cap is 4
+    assert tiny.winograd == int(__import__("os").environ.get("BBDM_WINOGRAD", "6"))      # the default cap
     assert lib_tiles(6, 16, 64, 64) == 2048 and lib_tiles(4, 16, 64, 64) == 4096 and lib_tiles(2, 3, 8, 12) == 256
 
 
 @pytest.mark.parametrize("workload,batch,training,cap", [("c1", 4, False, 4), ("c1", 16, False, 4), ("c1", 16, True, 4),
-                                                         ("c5", 32, False, 4), ("c1", 16, False, 6)])
+                                                         ("c5", 32, False, 4), ("c1", 16, False, 6), ("c2", 2, False, 6),
+                                                         ("c3", 32, True, 6)])
 def test_plan_ops_are_consistent(workload, batch, training, cap):
     lib = _lib.load()
     m, plan = _plan(workload, batch, training, winograd=cap)
@@ -87,7 +98,7 @@ def test_flop_accounting_direct_equivalent_matches_the_direct_plan():
     _, direct = _plan("c1", 16, winograd=0)
     assert not any(n.startswith("bbdm_winograd") for n, _ in direct.ops)
     want = sum(direct.op_flops)
-    for cap in (2, 4, 6):                                     # 6 = the experimental 8x8-tile path (masked edge tiles)
+    for cap in (2, 4, 6):                                     # 6: masked edge tiles (64 is not a multiple of 6)
         _, plan = _plan("c1", 16, winograd=cap)
         executed = sum(plan.op_flops)
         equiv = sum(18.0 * a[4] * a[5] * a[6] * getattr(a[2].t, "cin_true", a[7]) * a[8] if n == "bbdm_winograd_gemm_f32" else f

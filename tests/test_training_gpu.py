@@ -209,7 +209,7 @@ def test_gradients_through_winograd_layers(dev):
     g_ref = {k[len("denoise_fn."):]: v.grad for k, v in osd.items()}
     gmax = max(float(v.abs().max()) for v in g_ref.values())
     m = m.to(dev).train()
-    for wino in (4, 0):
+    for wino in (6, 4, 0):
         m.denoise_fn.winograd = wino
         m.zero_grad(set_to_none=True)
         loss, _ = m.p_losses(x0.to(dev), y.to(dev), None, t.to(dev), nz.to(dev))

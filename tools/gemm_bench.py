@@ -9,8 +9,10 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bbdm_amd import _lib, ops  # noqa: E402
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]      # kernel_ops lives with the tests
+from bbdm_amd import _lib
+import kernel_ops as ops  # noqa: E402
 
 SHAPES = [  # N, H, W, Cin, Cout
     (16, 64, 64, 1024, 1024),

@@ -7,8 +7,10 @@ from collections import defaultdict
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bbdm_amd import _lib, ops  # noqa: E402
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]      # kernel_ops lives with the tests
+from bbdm_amd import _lib
+import kernel_ops as ops  # noqa: E402
 
 
 def main():

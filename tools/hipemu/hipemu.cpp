@@ -1,0 +1,172 @@
+// hipemu runtime: runs the blocks of a launch one after the other; the threads of a block are fibers (hand-rolled
+// x86-64 context switch) scheduled round-robin between synchronisation points.  TEST INFRASTRUCTURE ONLY.
+#include <stdio.h>
+#include <sys/mman.h>
+#include <vector>
+#include "hip/hip_runtime.h"
+
+extern "C" void hipemu_switch(void** save_sp, void* new_sp);
+extern "C" void hipemu_fiber_entry();
+
+namespace hipemu {
+void fiber_main_export();
+
+dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+int g_lane = 0;
+
+namespace {
+enum State { RUNNABLE = 0, AT_WAVE = 1, AT_BLOCK = 2, DONE = 3 };
+constexpr size_t STACK = 512 * 1024;
+struct Fiber {
+    void* sp = nullptr;
+    char* stack = nullptr;
+    int state = DONE;
+};
+std::vector<Fiber> g_fibers;
+void* g_sched_sp = nullptr;
+int g_cur = -1;
+body_fn g_fn = nullptr;
+void* g_ctx = nullptr;
+std::vector<char> g_smem;
+const void* g_wave_slots[64][64];        // [wave][lane] -- up to 4096 threads per block
+
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
+void yield_to_scheduler(int state) {
+    Fiber& f = g_fibers[g_cur];
+    f.state = state;
+    hipemu_switch(&f.sp, g_sched_sp);
+}
+
+void fiber_main() {
+    g_fn(g_ctx);
+    g_wave_slots[g_cur >> 6][g_cur & 63] = nullptr;
+    yield_to_scheduler(DONE);
+    fprintf(stderr, "hipemu: resumed a finished fiber\n");
+    abort();
+}
+
+void prepare(Fiber& f) {
+    if (!f.stack) {
+        f.stack = (char*)mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (f.stack == MAP_FAILED) { perror("hipemu: mmap"); abort(); }
+    }
+    uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+    void** p = (void**)(top - 16);                 // return-address slot (16-byte aligned -> rsp % 16 == 8 at entry)
+    p[0] = (void*)&hipemu_fiber_entry;
+    p[1] = nullptr;
+    void** sp = p - 6;                             // r15 r14 r13 r12 rbx rbp
+    for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+    f.sp = sp;
+    f.state = RUNNABLE;
+}
+
+void set_ids(int t) {
+    const unsigned bx = g_blockDim.x, by = g_blockDim.y;
+    g_threadIdx.x = t % bx;
+    g_threadIdx.y = (t / bx) % by;
+    g_threadIdx.z = t / (bx * by);
+    g_lane = t & 63;
+    g_cur = t;
+}
+
+void run_block(int nthr) {
+    const int nwaves = (nthr + 63) / 64;
+    for (int t = 0; t < nthr; ++t) prepare(g_fibers[t]);
+    for (int w = 0; w < nwaves; ++w)
+        for (int l = 0; l < 64; ++l) g_wave_slots[w][l] = nullptr;
+    for (;;) {
+        bool ran = false;
+        for (int t = 0; t < nthr; ++t) {
+            Fiber& f = g_fibers[t];
+            if (f.state != RUNNABLE) continue;
+            set_ids(t);
+            hipemu_switch(&g_sched_sp, f.sp);
+            ran = true;
+        }
+        // every fiber is now DONE, AT_WAVE or AT_BLOCK
+        bool released = false, all_done = true, all_block = true;
+        for (int w = 0; w < nwaves; ++w) {
+            int n_wave = 0, n_block = 0;
+            const int t0 = w * 64, t1 = t0 + 64 < nthr ? t0 + 64 : nthr;
+            for (int t = t0; t < t1; ++t) {
+                n_wave += g_fibers[t].state == AT_WAVE;
+                n_block += g_fibers[t].state == AT_BLOCK;
+            }
+            if (n_wave && n_block) {
+                fprintf(stderr, "hipemu: wave %d diverged: %d lanes at a cross-lane op, %d at __syncthreads\n", w, n_wave, n_block);
+                abort();
+            }
+            if (n_wave) {
+                for (int t = t0; t < t1; ++t)
+                    if (g_fibers[t].state == AT_WAVE) g_fibers[t].state = RUNNABLE;
+                released = true;
+                all_done = all_block = false;
+            } else if (n_block) {
+                all_done = false;
+            }
+        }
+        if (released) continue;
+        if (all_done) break;
+        if (all_block) {                                        // every live thread reached the barrier
+            for (int t = 0; t < nthr; ++t)
+                if (g_fibers[t].state == AT_BLOCK) g_fibers[t].state = RUNNABLE;
+            continue;
+        }
+        if (!ran) { fprintf(stderr, "hipemu: deadlock\n"); abort(); }
+    }
+}
+}  // namespace
+void fiber_main_export() { fiber_main(); }
+
+void* dyn_smem() { return g_smem.data(); }
+void block_sync() { yield_to_scheduler(AT_BLOCK); }
+const void* const* wave_publish(const void* mine) {
+    g_wave_slots[g_cur >> 6][g_cur & 63] = mine;
+    yield_to_scheduler(AT_WAVE);
+    return g_wave_slots[g_cur >> 6];
+}
+void wave_release() { yield_to_scheduler(AT_WAVE); }
+
+void launch(dim3 grid, dim3 block, size_t shmem, body_fn fn, void* ctx) {
+    const int nthr = (int)(block.x * block.y * block.z);
+    if (nthr <= 0 || nthr > 4096) { fprintf(stderr, "hipemu: bad block size %d\n", nthr); abort(); }
+    if ((int)g_fibers.size() < nthr) g_fibers.resize(nthr);
+    g_smem.assign(shmem + 64, (char)0xFF);                      // NaN-poisoned: reads of unwritten LDS show up
+    g_fn = fn;
+    g_ctx = ctx;
+    g_blockDim = block;
+    g_gridDim = grid;
+    for (unsigned z = 0; z < grid.z; ++z)
+        for (unsigned y = 0; y < grid.y; ++y)
+            for (unsigned x = 0; x < grid.x; ++x) {
+                g_blockIdx = dim3(x, y, z);
+                if (shmem) memset(g_smem.data(), 0xFF, shmem);
+                run_block(nthr);
+            }
+}
+
+}  // namespace hipemu
+
+extern "C" void hipemu_fiber_entry() { hipemu::fiber_main_export(); }

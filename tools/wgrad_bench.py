@@ -5,8 +5,9 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bbdm_amd import ops  # noqa: E402
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [_ROOT, os.path.join(_ROOT, "tests")]      # kernel_ops lives with the tests
+import kernel_ops as ops  # noqa: E402
 
 SHAPES = [(32, 16, 16, 1024, 1024, 3), (32, 32, 32, 512, 512, 3), (32, 64, 64, 128, 128, 3), (32, 16, 16, 2048, 1024, 3),
           (32, 64, 64, 512, 512, 3), (32, 32, 32, 1024, 512, 1)]
