@@ -61,6 +61,9 @@ SIGNATURES = {
                                           _P, _P, c_int, c_int, _P]),
     "bbdm_bb_predict_x0_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "bbdm_bb_loss_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+    "bbdm_opt_chunk_elems": (c_int, []),
+    "bbdm_adam_ema_step_f32": (c_int, [_P, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
+                                       ctypes.c_longlong, c_int, c_double, _P]),
 }
 
 _lib = None

@@ -1,10 +1,12 @@
 """Training path: ``torch.autograd.Function`` wrappers over the HIP forward and backward plans.
 
-``UNetModel.forward`` routes here when gradients are enabled.  The whole UNet is ONE autograd node: its forward runs
-the training plan (same kernels as inference, activations kept), its backward runs the emitted gradient plan
-(conv dgrad/wgrad on the fp32 matrix core, GroupNorm/FiLM/SiLU/resample, attention, embedding MLP -- DESIGN.md §4.4)
-and returns a gradient for every parameter, so ``loss.backward()``, ``torch.optim.Adam`` and DDP's reducer hooks
-(runners/BaseRunner.py:76,412-417) work as with the reference.  The reference's gradient checkpointing of the
+``UNetModel.forward`` routes here when gradients are enabled.  The UNet is a short CHAIN of autograd nodes (one per
+backward segment of the plan, ``unet._Plan.N_SEGMENTS``): the forward runs the training plan once (same kernels as
+inference, activations kept); each node's backward runs its run of the emitted gradient plan (conv dgrad/wgrad on the fp32
+matrix core, GroupNorm/FiLM/SiLU/resample, attention, embedding MLP -- DESIGN.md §4.4) and returns the gradients of the
+parameters that run completed, so ``loss.backward()``, the optimizer and DDP's reducer hooks (runners/BaseRunner.py:76,
+412-417) work as with the reference -- and DDP's bucketed all-reduce of the late layers overlaps the backward of the early
+ones.  The reference's gradient checkpointing of the
 attention block (util.py:119-148) has no numerical effect and is replaced by recomputing the attention
 probabilities from the saved log-sum-exp.
 """
@@ -15,31 +17,40 @@ import torch
 from . import _lib
 
 
-class _UNetFn(torch.autograd.Function):
+class _UNetSeg(torch.autograd.Function):
+    """One link of the UNet's autograd chain.  Link 0 (created first) runs the whole forward plan; links 1..K-1 only pass a
+    token along; the last link returns the UNet output.  In backward the engine visits the links in reverse: link K-1 runs
+    backward segment 0 (head side) of the plan and returns ITS parameters' gradients -- which the engine accumulates (DDP:
+    reduces) at once -- then link K-2 runs segment 1, ... link 0 runs the last segment (+ the embedding path, + d input)."""
+
     @staticmethod
-    def forward(ctx, model, x, t, context, *params):
-        plan = model._plan_for(x, training=True)
-        out = plan.run(x, t, context)
-        ctx.plan, ctx.generation = plan, plan.generation
-        ctx.cx = x.shape[1]
-        ctx.cctx = 0 if context is None else context.shape[1]
-        return out
+    def forward(ctx, model, plan, link, x, t, context, token, *params):
+        K = len(plan.bsegs)
+        ctx.plan, ctx.link, ctx.K = plan, link, K
+        if link == 0:
+            out = plan.run(x, t, context)
+            plan._fwd_out = out
+            ctx.cx = x.shape[1]
+            ctx.cctx = 0 if context is None else context.shape[1]
+        ctx.generation = plan.generation
+        if link == K - 1:
+            out, plan._fwd_out = plan._fwd_out, None
+            return out
+        return torch.zeros(1, dtype=torch.float32, device=plan.device)
 
     @staticmethod
     def backward(ctx, dout):
-        plan = ctx.plan
+        plan, link, K = ctx.plan, ctx.link, ctx.K
         if plan.generation != ctx.generation:
             raise RuntimeError("bbdm_amd: the UNet was run again (same shape, training mode) before this backward; the "
                                "training plan keeps one set of saved activations per shape")
-        need_x, need_ctx = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
-        flat, dx_in = plan.run_backward(dout.contiguous().float(), need_x or need_ctx)
-        grads = []
-        for i, p in enumerate(plan.param_list):
-            if ctx.needs_input_grad[4 + i]:
-                off = plan.grad_off[id(p)]
-                grads.append(flat[off:off + p.numel()].view_as(p))
-            else:
-                grads.append(None)
+        seg = K - 1 - link
+        if seg == 0:
+            plan.backward_begin(dout.contiguous().float())
+        need_x = link == 0 and ctx.needs_input_grad[3]
+        need_ctx = link == 0 and ctx.needs_input_grad[5]
+        dx_in = plan.backward_segment(seg, need_x or need_ctx)
+        grads = [plan.grad_view(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(plan.bsegs[seg][2])]
         dx = dctx = None
         if dx_in is not None:
             nchw = dx_in.permute(0, 3, 1, 2)
@@ -47,13 +58,21 @@ class _UNetFn(torch.autograd.Function):
                 dx = nchw[:, :ctx.cx].contiguous()
             if need_ctx:
                 dctx = nchw[:, ctx.cx:ctx.cx + ctx.cctx].contiguous()
-        return (None, dx, None, dctx, *grads)
+        dtoken = None if link == 0 else torch.zeros(1, dtype=torch.float32, device=plan.device)
+        return (None, None, None, dx, None, dctx, dtoken, *grads)
 
 
 def unet_apply(model, x, timesteps, context):
     x, ctx = model._check_inputs(x, context)
     t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
-    return _UNetFn.apply(model, x, t, ctx, *model.parameters())
+    plan = model._plan_for(x, training=True)
+    K = len(plan.bsegs)
+    token = None
+    for link in range(K):                       # link j owns the parameters of backward segment K-1-j
+        params = plan.bsegs[K - 1 - link][2]
+        token = _UNetSeg.apply(model, plan, link, x if link == 0 else None, t if link == 0 else None,
+                               ctx if link == 0 else None, token, *params)
+    return token
 
 
 class _LossFn(torch.autograd.Function):

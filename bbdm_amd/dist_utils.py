@@ -106,3 +106,18 @@ def gather_device_info(dist=None, device: Optional[torch.device] = None):
         except Exception:                                   # pragma: no cover
             pass
     return out
+
+
+def accumulation_sync(net, micro_step: int, accumulate_grad_batches: int):
+    """Context manager for one micro-step of gradient accumulation under DDP.
+
+    The reference all-reduces the full 948 MB gradient on EVERY micro-step (runners/BaseRunner.py:412-417: ``loss.backward()``
+    with no ``no_sync()``) although the optimizer only steps every ``accumulate_grad_batches``-th one.  Skipping the
+    collective on the non-boundary micro-steps (``net.no_sync()``) and reducing the locally accumulated sum on the boundary
+    step gives the same averaged gradient -- a sum of means is the mean of sums -- with 1/accumulate_grad_batches of the
+    RCCL traffic.  ``micro_step`` is the runner's 1-based ``global_step``; non-DDP modules get a null context."""
+    import contextlib
+    boundary = accumulate_grad_batches <= 1 or micro_step % accumulate_grad_batches == 0
+    if boundary or not hasattr(net, "no_sync"):
+        return contextlib.nullcontext()
+    return net.no_sync()

@@ -994,6 +994,7 @@ class _Plan:
         self.dout_nchw = torch.empty_like(self.out_nchw)
         self.need_input_grad = False
 
+        rec_ends = []       # len(self.bops) after each tape record, in backward order
         for rec in reversed(self.tape):
             kind = rec[0]
             if kind == "head":
@@ -1070,6 +1071,8 @@ class _Plan:
                 self._bop("bbdm_conv2d_nhwc_f32", dout, dout.ld, _TensorRef(pk.packed), None, None, 0, self.dx0,
                           self.dx0.ld, 0, None, 0, None, None, 0, 0, N, x.H, x.W, dout.C, x.C, 3)
                 self.bops_x0, self.bops = self.bops, main
+            rec_ends.append(len(self.bops))
+        self._segment_backward(rec_ends)
         self._ws_f.t = torch.empty(ws_floats[0], **f32)
         self._ws_d.t = torch.empty(colsum_c[0], dtype=torch.float64, device=dev)
         self._ws_d2.t = torch.empty(ws_doubles[0], dtype=torch.float64, device=dev)
@@ -1083,29 +1086,127 @@ class _Plan:
                                        lib.bbdm_linear_bwd_workspace_floats(min(N, self.emb_rows), ted, ted), 1), **f32)
         self._bbound: List[tuple] = []
 
-    def run_backward(self, dout: torch.Tensor, need_dx: bool):
-        """Gradient of everything w.r.t. ``dout`` (NCHW).  Returns (flat parameter gradient, d input NHWC view or None)."""
-        with _lib.device_guard(self.device):
-            return self._run_backward(dout, need_dx)
+    # Backward segments.  The gradient plan is cut into a few runs of whole layers (head side first) so that the autograd
+    # graph can be a CHAIN of nodes, one per segment (bbdm_amd/autograd.py): the engine hands the parameter gradients of a
+    # finished segment to their AccumulateGrad nodes -- and with them to DDP's reducer hooks (runners/BaseRunner.py:76) --
+    # before it runs the next segment, so the bucketed RCCL all-reduce of the late layers overlaps the backward kernels of
+    # the early ones instead of starting after the whole UNet's backward has been enqueued.
+    N_SEGMENTS = 4
 
-    def _run_backward(self, dout: torch.Tensor, need_dx: bool):
-        m, N = self.m, self.N
+    @staticmethod
+    def _record_params(rec):
+        kind = rec[0]
+        mods = []
+        if kind == "head":
+            mods = [rec[1][0], rec[1][2]]
+        elif kind == "res":
+            rb = rec[1]
+            mods = [rb.in_layers[0], rb.in_layers[2], rb.out_layers[0], rb.out_layers[3]]
+            if isinstance(rb.skip_connection, nn.Conv2d):
+                mods.append(rb.skip_connection)
+        elif kind == "attn":
+            ab = rec[1]
+            mods = [ab.norm, ab.qkv, ab.proj_out]
+        elif kind == "down":
+            mods = [rec[1].op] if rec[1].use_conv else []
+        elif kind == "up":
+            mods = [rec[1].conv] if rec[1].use_conv else []
+        elif kind == "stem":
+            mods = [rec[1]]
+        return [p for mod in mods for p in mod.parameters()]
+
+    def _segment_backward(self, rec_ends):
+        """Cut the backward op list at layer boundaries into <= N_SEGMENTS runs of roughly equal parameter count.
+        ``self.bsegs[k]`` = (first op, last op + 1, parameters whose gradients are complete when the run ends); k = 0 is
+        the head side (runs first).  The embedding path (time_embed + every ResBlock's emb_layers: their gradients need the
+        d FiLM rows of ALL blocks) belongs to the last segment."""
+        recs = list(reversed(self.tape))
+        per_rec = [self._record_params(r) for r in recs]
+        seen = set()
+        for ps in per_rec:
+            for q in ps:
+                seen.add(id(q))
+        rest = [q for q in self.param_list if id(q) not in seen]         # embedding path
+        total = sum(q.numel() for ps in per_rec for q in ps) + sum(q.numel() for q in rest)
+        want = max(1, min(self.N_SEGMENTS, len(recs)))
+        segs, start, acc, cur = [], 0, 0, []
+        for i, ps in enumerate(per_rec):
+            cur += ps
+            acc += sum(q.numel() for q in ps)
+            last = i == len(recs) - 1
+            if last or (len(segs) < want - 1 and acc >= total * (len(segs) + 1) / want):
+                segs.append([start, rec_ends[i], cur + (rest if last else [])])
+                start, cur = rec_ends[i], []
+        self.bsegs = segs
+
+    def _pick_flat_grad(self):
+        """The flat gradient buffer of this backward pass.  Two persistent buffers instead of a fresh 0.95 GB allocation per
+        call: autograd may have adopted last pass's views as ``param.grad`` (first backward after ``zero_grad``), and
+        accumulating this pass's gradients into them must not alias, so the buffer no ``.grad`` points into is taken."""
+        if not hasattr(self, "_flat_bufs"):
+            self._flat_bufs = []
+        busy = set()
+        for q in self.param_list:
+            gq = q.grad
+            if gq is not None:
+                ptr = gq.data_ptr()
+                for j, fb in enumerate(self._flat_bufs):
+                    if fb.data_ptr() <= ptr < fb.data_ptr() + 4 * fb.numel():
+                        busy.add(j)
+        for j, fb in enumerate(self._flat_bufs):
+            if j not in busy:
+                return fb.zero_()
+        if len(self._flat_bufs) < 2:
+            self._flat_bufs.append(torch.zeros(self.grad_total, dtype=torch.float32, device=self.device))
+            return self._flat_bufs[-1]
+        return torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)      # both adopted: rare
+
+    def grad_view(self, q):
+        off = self.grad_off[id(q)]
+        return self._flat_grad[off:off + q.numel()].view_as(q)
+
+    def backward_begin(self, dout: torch.Tensor):
+        with _lib.device_guard(self.device):
+            self._flat_grad = self._pick_flat_grad()
+            self.dout_nchw.copy_(dout)
+            stream = _lib.current_stream(self.device)
+            for pk in self.dconvs:
+                pk.refresh(stream)
+
+    def backward_segment(self, k: int, need_dx: bool = False):
+        """Enqueue segment ``k`` of the gradient plan (0 = head side).  The last segment also runs the embedding path and,
+        on request, the input gradient; returns the NHWC input-gradient view or None."""
+        with _lib.device_guard(self.device):
+            return self._backward_segment(k, need_dx)
+
+    def _backward_segment(self, k, need_dx):
+        lo, hi, _ = self.bsegs[k]
+        last = k == len(self.bsegs) - 1
         stream = _lib.current_stream(self.device)
-        f32 = dict(dtype=torch.float32, device=self.device)
-        self._flat_grad = torch.zeros(self.grad_total, **f32)      # fresh per call: autograd may keep views of it
-        self.dout_nchw.copy_(dout)
-        for pk in self.dconvs:
-            pk.refresh(stream)
         lib = self.lib
-        bound = [(getattr(lib, name), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
-                 for name, args in (self.bops + (self.bops_x0 if need_dx else []))]
+        ops = self.bops[lo:hi] + (self.bops_x0 if (last and need_dx) else [])
         check = _lib.check
-        for fn, args in bound:
-            rc = fn(*args, stream)
+        for name, args in ops:
+            fn = getattr(lib, name)
+            rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
             if rc != 0:
-                check(rc, fn.__name__)
+                check(rc, name)
+        if not last:
+            return None
+        return self._backward_embedding(stream, need_dx)
+
+    def run_backward(self, dout: torch.Tensor, need_dx: bool):
+        """Whole gradient plan in one go.  Returns (flat parameter gradient, d input NHWC view or None)."""
+        self.backward_begin(dout)
+        dx_in = None
+        for k in range(len(self.bsegs)):
+            dx_in = self.backward_segment(k, need_dx)
+        return self._flat_grad, dx_in
+
+    def _backward_embedding(self, stream, need_dx: bool):
+        m, N = self.m, self.N
         flat = self._flat_grad
-        gslice = lambda p: flat[self.grad_off[id(p)]: self.grad_off[id(p)] + p.numel()].view_as(p)
+        gslice = self.grad_view
         for w, t in self._padded_wgrads:
             gslice(w).copy_(t[:, : w.shape[1]])
         # ---- embedding path: film projections -> time_embed.2 -> time_embed.0 ------------------------------------
@@ -1147,7 +1248,7 @@ class _Plan:
         if need_dx:
             v = self.dx0
             dx_in = v.buf.tensor[: v.N * v.H * v.W * v.ld].view(v.N, v.H, v.W, v.ld)
-        return flat, dx_in
+        return dx_in
 
     # ---- execution ------------------------------------------------------------------------------------------------
     def _bind(self):

@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--accumulate", type=int, default=4, help="c4: accumulate_grad_batches (Template-LBBDM-f4.yaml:9)")
+    ap.add_argument("--sync-every-micro-step", action="store_true", help="c4: all-reduce on every micro-step (reference)")
+    ap.add_argument("--torch-adam", action="store_true", help="c4: torch.optim.Adam instead of the fused Adam+EMA pass")
     ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
@@ -241,19 +244,38 @@ def main():
     training = args.workload == "c4"
 
     if training:
-        # the reference's training step (runners/BaseRunner.py:398-417, BBDMRunner.py:164-176): net(x, x_cond) ->
-        # loss.backward() -> Adam step; DDP (BaseRunner.py:76) all-reduces the UNet gradients over RCCL/xGMI.
+        # the reference's training micro-step (runners/BaseRunner.py:398-423, BBDMRunner.py:164-176): net(x, x_cond) ->
+        # loss.backward() -> every accumulate_grad_batches-th micro-step optimizer.step() + zero_grad(); EMA update every
+        # update_ema_interval * accumulate_grad_batches micro-steps (Template-LBBDM-f4.yaml:9,43-47: 4, 8).  DDP
+        # (BaseRunner.py:76) all-reduces the UNet gradients over RCCL/xGMI -- here only on the accumulation boundary
+        # (dist_utils.accumulation_sync; --sync-every-micro-step restores the reference's behaviour for an A/B).
+        from bbdm_amd.optim import EMA, FusedAdam
         model.train()
         net = model
         if dist is not None:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], output_device=local_rank)
-        opt = torch.optim.Adam(model.get_parameters(), lr=1e-4, betas=(0.9, 0.999))
+        accumulate, ema_every = args.accumulate, 8
+        if args.torch_adam:
+            opt = torch.optim.Adam(model.get_parameters(), lr=1e-4, betas=(0.9, 0.999))
+            ema = None
+        else:
+            opt = FusedAdam(model.get_parameters(), lr=1e-4, betas=(0.9, 0.999))
+            ema = EMA(0.995)
+            ema.register(model)
 
         def step(i, img):
-            opt.zero_grad(set_to_none=True)
-            loss, _ = net(x_t, y)
-            loss.backward()
-            opt.step()
+            gstep = i + 1                                     # the runner's 1-based global_step
+            ctx_mgr = (dist_utils.accumulation_sync(net, gstep, accumulate) if not args.sync_every_micro_step
+                       else dist_utils.accumulation_sync(net, gstep, 1))
+            with ctx_mgr:
+                loss, _ = net(x_t, y)
+                loss.backward()
+            if gstep % accumulate == 0:
+                if ema is not None and gstep % (ema_every * accumulate) == 0:
+                    opt.step(ema=ema, ema_with_decay=False)   # before start_ema_step (30000): shadow = weights
+                else:
+                    opt.step()
+                opt.zero_grad(set_to_none=True)
             return loss.detach().reshape(1)
     else:
         def step(i, img):
@@ -381,7 +403,7 @@ def main():
         line = {
             "metric": "denoise-UNet sampling steps/sec (one step = p_sample of the whole local batch: UNet forward + "
                       "Brownian-Bridge update) at 256x256 pixel-space BBDM" if args.workload == "c2" else
-                      ("training steps/sec (c4: forward + backward + Adam)" if training else
+                      ("training micro-steps/sec (c4: forward + backward; fused Adam + EMA every accumulate_grad_batches-th)" if training else
                        f"denoise-UNet sampling steps/sec ({args.workload})"),
             "value": steps_per_s_job, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -229,6 +229,29 @@ int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const f
                            int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
                            int resample, void* stream);
 
+/* ---- optimizer + EMA in one pass (training) ------------------------------------------------ */
+/* Replaces torch.optim.Adam.step() (runners/utils.py:48-51; called at runners/BaseRunner.py:413-415) and
+ * EMA.update() (runners/base/EMA.py:21-29; called at BaseRunner.py:173-178,422-423) for all parameters with ONE launch.
+ * `table` is DEVICE memory: one entry per <= bbdm_opt_chunk_elems() consecutive elements of one parameter tensor; the
+ * pointers address that chunk inside the parameter, its .grad, its Adam moments and its EMA shadow (grad / shadow may be
+ * NULL: that chunk skips the Adam / the EMA part).  do_adam: apply the Adam update with `step` = the 1-based count of
+ * optimizer steps (bias corrections 1 - beta^step); ema_mode: 0 = no EMA, 1 = shadow = (1 - decay) * p + decay * shadow
+ * (the UPDATED p when do_adam), 2 = shadow = p (EMA.update(with_decay=False), BaseRunner.py:174).  Arithmetic: the
+ * single-tensor formulas of torch.optim.Adam (lerp / mul+addcmul / sqrt / div / addcdiv), fp32, no FMA contraction. */
+typedef struct BbdmOptChunk {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float* shadow;
+    int n;
+    int pad_;
+} BbdmOptChunk;
+int bbdm_opt_chunk_elems(void);
+int bbdm_adam_ema_step_f32(const BbdmOptChunk* table, int nchunks, int do_adam, double lr, double beta1, double beta2,
+                           double eps, double weight_decay, long long step, int ema_mode, double ema_decay,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,10 @@ def _nchw(x):
 
 
 CONV_BWD = [(2, 16, 16, 32, 64, 3), (1, 24, 40, 64, 128, 3), (3, 8, 8, 128, 96, 3), (4, 4, 4, 256, 64, 3),
-            (2, 16, 16, 64, 192, 1), (1, 13, 9, 8, 3, 3), (8, 32, 32, 128, 128, 3), (2, 8, 8, 4, 32, 3)]
+            (2, 16, 16, 64, 192, 1), (1, 13, 9, 8, 3, 3), (8, 32, 32, 128, 128, 3), (2, 8, 8, 4, 32, 3),
+            # the layer shapes of the 237 M-parameter UNet at a 64x64 latent, batch 2 (split-K tiles, 4-16 Cout tiles)
+            (2, 16, 16, 1024, 1024, 3), (2, 16, 16, 2048, 1024, 3), (2, 32, 32, 1536, 512, 3), (2, 64, 64, 640, 128, 3),
+            (2, 16, 16, 2048, 1024, 1), (2, 64, 64, 128, 128, 3), (2, 32, 32, 512, 512, 3)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks", CONV_BWD)
@@ -55,7 +58,8 @@ def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
     assert rel_err(db.cpu(), b.grad) < TOL and rel_err(db2.cpu(), b.grad) < TOL
 
 
-GN_BWD = [(2, 16, 16, 128), (1, 8, 8, 640), (2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32), (2, 32, 32, 256)]
+GN_BWD = [(2, 16, 16, 128), (1, 8, 8, 640), (2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32), (2, 32, 32, 256),
+          (2, 16, 16, 2048), (2, 32, 32, 1536), (2, 64, 64, 640), (2, 16, 16, 1024)]      # full-size UNet layers
 
 
 @pytest.mark.parametrize("N,H,W,C", GN_BWD)
@@ -117,7 +121,7 @@ def test_resample_only_backward(dev):
         assert rel_err(_nchw(dx.cpu()), x.grad) < 1e-6
 
 
-ATTN_BWD = [(2, 16, 4, 64), (1, 256, 2, 64), (2, 100, 3, 32), (3, 16, 2, 16), (1, 300, 1, 64)]
+ATTN_BWD = [(2, 16, 4, 64), (1, 256, 2, 64), (2, 100, 3, 32), (3, 16, 2, 16), (1, 300, 1, 64), (2, 256, 16, 64)]
 
 
 @pytest.mark.parametrize("N,T,heads,ch", ATTN_BWD)
@@ -146,7 +150,7 @@ def test_attention_backward(dev, N, T, heads, ch, new_order):
 
 
 @pytest.mark.parametrize("N,In,Out,act", [(4, 128, 512, False), (16, 512, 1000, True), (33, 96, 70, True),
-                                           (64, 512, 2048, True)])
+                                           (64, 512, 2048, True), (2, 512, 25088, True)])
 def test_linear_backward(dev, N, In, Out, act):
     import kernel_ops as ops
     g = torch.Generator().manual_seed(N + In)
