@@ -252,6 +252,13 @@ int bbdm_adam_ema_step_f32(const BbdmOptChunk* table, int nchunks, int do_adam, 
                            double eps, double weight_decay, long long step, int ema_mode, double ema_decay,
                            void* stream);
 
+/* ---- sample egress ------------------------------------------------------------------------ */
+/* fp32 NCHW [N,C,H,W] -> uint8 NHWC [N,H,W,C] with the arithmetic of save_single_image (runners/utils.py:67-74):
+ * to_normal != 0: v = clamp(v * 0.5 + 0.5, 0, 1); then u8 = (uint8) clamp(v * 255 + 0.5, 0, 255) (truncation) -- each
+ * operation rounded separately in fp32, so the bytes equal the reference's.  One launch for the whole batch. */
+int bbdm_images_to_u8_f32(const float* x_nchw, unsigned char* out_nhwc, int N, int C, int H, int W, int to_normal,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,9 @@ def adam_parity(dev, wd, beta1):
     a, b = make_net(1, dev), make_net(1, dev)
     oa = FusedAdam(a.parameters(), lr=1e-3, betas=(beta1, 0.999), weight_decay=wd)
     ob = torch.optim.Adam(b.parameters(), lr=1e-3, betas=(beta1, 0.999), weight_decay=wd)
+    # weight decay: ATen forms g + wd * p with one rounding on the CPU (what the kernel does: fmaf) and with two in its HIP
+    # foreach kernels; where g and wd * p cancel that last-ulp difference is amplified by 1 / (|g'| + eps)
+    tol = 1e-6 if wd == 0.0 else 3e-6
     g = torch.Generator().manual_seed(5)
     for it in range(6):
         for pa, pb in zip(a.parameters(), b.parameters()):
@@ -62,7 +65,7 @@ def adam_parity(dev, wd, beta1):
         oa.step()
         ob.step()
         for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
-            assert rel(pa, pb) < 1e-6, (it, k)
+            assert rel(pa, pb) < tol, (it, k, rel(pa, pb))
     sa, sb = oa.state_dict(), ob.state_dict()
     assert sa["state"].keys() == sb["state"].keys()
     for i in sa["state"]:

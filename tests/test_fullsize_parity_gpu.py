@@ -125,26 +125,38 @@ def test_attention_T4096(dev, new_order):
     assert e < 1e-5
 
 
-def _oracle_loss_grads(sd, up, bb, x0, y, t, nz, dtype):
-    sd_o = {"denoise_fn." + k: v.to(dtype).clone().requires_grad_() for k, v in sd.items()}
+def _oracle_grads(sd, up, bb, x0, y, t, nz, sign=None):
+    """Autograd on the oracle.  ``sign`` = None: the model's own loss (BrownianBridgeModel.py:98-126).  ``sign`` given
+    (l1 only): d|target - pred| / d pred is taken with THAT sign pattern, i.e. loss = sum(sign * (target - pred)) / count --
+    the L1 loss with the non-differentiable sign() frozen (see the test's docstring)."""
+    sd_o = {"denoise_fn." + k: v.clone().requires_grad_() for k, v in sd.items()}
     ora = O.OracleBBDM(sd_o, O.UNetSpec(**up), **bb)
-    lo, _ = ora.p_losses(x0.to(dtype), y.to(dtype), None, t, nz.to(dtype))
+    x_t, target = O.q_sample(ora.bufs, x0, y, t, nz, ora.objective)
+    pred = ora.denoise(x_t, t, None)
+    if sign is None:
+        lo = O.bb_loss(target, pred, ora.loss_type)
+    else:
+        lo = (sign * (target - pred)).sum() / pred.numel()
     lo.backward()
-    return float(lo.detach()), {k[len("denoise_fn."):]: v.grad for k, v in sd_o.items()}
+    return float(lo.detach()), pred.detach(), target, {k[len("denoise_fn."):]: v.grad for k, v in sd_o.items()}
 
 
-def test_c4_full_size_loss_and_all_gradients(dev):
+@pytest.mark.parametrize("loss_type", ["l2", "l1"])
+def test_c4_full_size_loss_and_all_gradients(dev, loss_type):
     """BASELINE.json configs[3] per-GPU work at the real model size: LBBDM-f4 UNet (in 3, nocond), latent 3x64x64, batch 2 --
-    loss and every one of the 248 parameter gradients against autograd on the oracle (BrownianBridgeModel.py:98-126).
+    loss and every one of the 248 parameter gradients against autograd on the oracle (BrownianBridgeModel.py:98-126), with
+    the Winograd plan (default), F(4x4) and the direct kernels.
 
-    At this size a handful of gradients (GroupNorm gains of wide layers, FiLM projections: sums of thousands of
-    cancelling terms) are conditioned worse than 1e-3 in fp32 -- the oracle's OWN fp32 gradients differ from an fp64
-    evaluation of the same graph by more than that.  So the oracle is evaluated twice (fp32 = the reference's arithmetic,
-    fp64 = the exact value) and a parameter passes when the HIP gradient is within 1e-3 of the fp32 oracle, OR is as close
-    to the fp64 value as the fp32 oracle itself is (factor 4).  Errors are scaled by max(|g|_max, 1e-3 * largest |g| in
-    the model), as in tests/test_training_gpu.py."""
+    'l2' is compared as is.  For 'l1' (the templates' loss) d loss / d pred = -sign(target - pred) / count is discontinuous:
+    of the 24 576 output elements a few have |target - pred| below the fp32 forward difference between the two
+    implementations (~1e-5), their sign flips, and ONE flipped element already moves every gradient of the network by
+    ~1e-3 of its magnitude (round-2 diagnosis: gradients were 2e-3..2e-2 off in every layer, cosine 0.99999, while the fp32
+    oracle is within 3e-6 of an fp64 evaluation and every backward kernel passes at these shapes).  That is a property of
+    the loss, not of the backward pass, so the oracle is differentiated with the HIP forward's sign pattern (the number of
+    flipped elements is printed); the loss VALUE is compared unmodified."""
     up = dict(UNET_PIXEL, image_size=64, in_channels=3, condition_key="nocond")
-    m, sd = _model(up, BB, 4040, dev)
+    bb = dict(BB, loss_type=loss_type)
+    m, sd = _model(up, bb, 4040, dev)
     m.train()
     g = torch.Generator().manual_seed(77)
     N = 2
@@ -152,42 +164,39 @@ def test_c4_full_size_loss_and_all_gradients(dev):
     y = torch.randn(N, 3, 64, 64, generator=g)
     t = torch.tensor([812, 37])
     nz = torch.randn(N, 3, 64, 64, generator=g)
-    l32, g32 = _oracle_loss_grads(sd, up, BB, x0, y, t, nz, torch.float32)
-    l64, g64 = _oracle_loss_grads(sd, up, BB, x0, y, t, nz, torch.float64)
-    assert len(g32) == 248
-    gmax = max(float(v.abs().max()) for v in g64.values())
-    scale = {k: max(float(v.abs().max()), 1e-3 * gmax) for k, v in g64.items()}
-    e_ora = {k: float((g32[k].double() - g64[k]).abs().max()) / scale[k] for k in g64}
-    worst_ora = sorted(((e, k) for k, e in e_ora.items()), reverse=True)[:3]
-    print(f"C4 full-size: oracle fp32 vs fp64 loss {l32:.7f} / {l64:.7f}; worst fp32-oracle gradient errors vs fp64: " +
-          "; ".join(f"{k} {e:.2e}" for e, k in worst_ora))
-    failures = []
+    l_ref, pred_ref, target, g_plain = _oracle_grads(sd, up, bb, x0, y, t, nz)
+    worst_all = 0.0
     for wino in (6, 4, 0):
         m.denoise_fn.winograd = wino
         m.denoise_fn._plans = {}
         m.zero_grad(set_to_none=True)
-        loss, _ = m.p_losses(x0.to(dev), y.to(dev), None, t.to(dev), nz.to(dev))
+        loss, log = m.p_losses(x0.to(dev), y.to(dev), None, t.to(dev), nz.to(dev))
         loss.backward()
         torch.cuda.synchronize()
         lv = float(loss.detach())
-        assert abs(lv - l32) < 1e-5 * max(1.0, abs(l32))
+        assert abs(lv - l_ref) < 1e-5 * max(1.0, abs(l_ref))
+        g_ref, flips = g_plain, 0
+        if loss_type == "l1":
+            # the HIP forward's prediction, recovered from the logged x0_recon = x_t - pred ('grad' objective)
+            with torch.no_grad():
+                x_t, _ = m.q_sample(x0.to(dev), y.to(dev), t.to(dev), nz.to(dev))
+                pred_gpu = (x_t - log["x0_recon"]).cpu()
+            sign = torch.sign(target - pred_gpu)
+            flips = int((sign != torch.sign(target - pred_ref)).sum())
+            _, _, _, g_ref = _oracle_grads(sd, up, bb, x0, y, t, nz, sign=sign)
+        gmax = max(float(v.abs().max()) for v in g_ref.values())
         rows = []
         for k, p in m.denoise_fn.named_parameters():
             assert p.grad is not None, k
-            gg = p.grad.cpu()
-            e32 = float((gg - g32[k]).abs().max()) / scale[k]
-            e64 = float((gg.double() - g64[k]).abs().max()) / scale[k]
-            ok = e32 < 1e-3 or e64 <= 4.0 * e_ora[k] + 1e-6
-            rows.append((e32, e64, e_ora[k], k, ok))
+            ref = g_ref[k]
+            rows.append((float((p.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax), k))
         rows.sort(reverse=True)
-        n_tol = sum(r[0] < 1e-3 for r in rows)
-        print(f"C4 full-size gradients (237 M, batch {N}), winograd={wino}: loss {lv:.6f}; {n_tol}/248 within 1e-3 of the "
-              "fp32 oracle; worst (vs fp32 oracle | vs fp64 | fp32 oracle vs fp64): " +
-              "; ".join(f"{k} {a:.2e}|{b:.2e}|{c:.2e}" for a, b, c, k, _ in rows[:4]))
-        failures += [(wino, k, a, b, c) for a, b, c, k, ok in rows if not ok]
+        worst_all = max(worst_all, rows[0][0])
+        print(f"C4 full-size gradients (237 M, batch {N}, {loss_type}), winograd={wino}: loss {lv:.6f} (oracle {l_ref:.6f}); "
+              f"sign flips {flips}/{target.numel()}; worst of 248: " + "; ".join(f"{k} {e:.2e}" for e, k in rows[:3]))
+        assert rows[0][0] < 1e-3, rows[0]
     m.denoise_fn._plans = {}
     torch.cuda.empty_cache()
-    assert not failures, failures[:5]
 
 
 def test_c5_real_f16_template_step(dev):
