@@ -54,6 +54,10 @@ static inline int ilog2(int v) {
 int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed_w, size_t wz, float* out, int ldo, size_t oz,
                          int batch, int H, int W, int CinPad, int Cout, hipStream_t st);
 
+// gemm_bf3.hip (declared here for winograd.hip; also part of the public header)
+extern "C" int bbdm_gemm_bf3_f32(const float* V, const void* packed_bf3, float* M, int batch, long long T, int CinPad, int Cout,
+                                 void* stream);
+
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 // hardware v_exp_f32 + v_rcp_f32 (~2 ulp; __frcp_rn would expand to the full IEEE division sequence): for kernels where the exact-division form above would make an HBM-bound pass
 // ALU-bound (the Winograd input transform evaluates each activation (m+2)^2/m^2 times)

@@ -474,6 +474,16 @@ extern "C" int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed
                                 (int)(Tp / 32), 32, CinPad, Cout, (hipStream_t)stream);
 }
 
+// The same (m+2)^2 GEMMs on the BF16 matrix core with fp32 accuracy (gemm_bf3.hip): packed_bf3 = the output of
+// bbdm_gemm_bf3_pack_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
+extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* packed_bf3, float* M, int N, int H, int W,
+                                          int CinPad, int Cout, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(V && packed_bf3 && M && N > 0, "winograd_gemm_bf3: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    return bbdm_gemm_bf3_f32(V, packed_bf3, M, planes(m), (long long)tiles_padded(N, H, W, m), CinPad, Cout, stream);
+}
+
 extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
                                         float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stream) {
     BBDM_WINO_M(m);

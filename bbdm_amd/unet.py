@@ -196,6 +196,17 @@ class _LateInt:
         return self.v
 
 
+class _OpName(str):
+    """Plan-level op name (what bench.py / the tests key on) that binds to a different C entry point: the Winograd tile
+    GEMMs stay "bbdm_winograd_gemm_f32" in the op list whether they run on the f32 or on the bf16x3 kernel."""
+    entry: str = ""
+
+    def __new__(cls, name, entry):
+        o = super().__new__(cls, name)
+        o.entry = entry
+        return o
+
+
 def _round4(c):
     return (c + 3) // 4 * 4
 
@@ -247,14 +258,24 @@ class _PackedDgrad:
 
 
 class _PackedWinograd:
-    """G g G^T of one 3x3 conv weight in the batched-GEMM layout (``dgrad``: of the data-gradient convolution)."""
+    """G g G^T of one 3x3 conv weight in the batched-GEMM layout (``dgrad``: of the data-gradient convolution).  With
+    ``bf3`` the fp32 buffer is additionally split into the three bf16 planes csrc/gemm_bf3.hip takes; ``packed`` is then
+    that buffer (the op binds to bbdm_winograd_gemm_bf3_f32)."""
 
-    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], in_pad: int, m: int, dgrad: bool = False):
-        self.weight, self.bias, self.dgrad, self.m = weight, bias, dgrad, m
+    def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], in_pad: int, m: int, dgrad: bool = False,
+                 bf3: bool = False):
+        self.weight, self.bias, self.dgrad, self.m, self.bf3 = weight, bias, dgrad, m, bf3
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.ks, self.in_pad = 3, in_pad
-        n = _lib.load().bbdm_winograd_packed_floats(m, self.cin if dgrad else self.cout, in_pad)
-        self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        lib = _lib.load()
+        self.out_ch = self.cin if dgrad else self.cout
+        n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
+        self.packed_f32 = torch.empty(n, dtype=torch.float32, device=weight.device)
+        if bf3:
+            nh = lib.bbdm_gemm_bf3_packed_halfs((m + 2) ** 2, in_pad, self.out_ch)
+            self.packed = torch.empty(nh, dtype=torch.int16, device=weight.device)
+        else:
+            self.packed = self.packed_f32
         self.packed.cin_true = self.cout if dgrad else self.cin
         self.key = None
 
@@ -264,8 +285,11 @@ class _PackedWinograd:
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
-            _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
+            _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                       self.in_pad, 1 if self.dgrad else 0, stream)
+            if self.bf3:
+                _lib.call("bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2,
+                          self.in_pad, self.out_ch, stream)
             self.key = key
 
 
@@ -410,6 +434,9 @@ class UNetModel(nn.Module):
         # BBDM_WINOGRAD: largest output tile allowed: 6 (default), 4, 2, or 0 = direct kernel everywhere.
         self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "6"))
         self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
+        # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
+        # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
+        self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -453,7 +480,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
-               self.winograd_fuse_groupnorm)
+               self.winograd_fuse_groupnorm, self.gemm_bf3)
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
@@ -741,6 +768,12 @@ class _Plan:
             return 0
         return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd)
 
+    def _use_bf3(self, wm, H, W, cin_pad, cout) -> bool:
+        """Tile GEMMs of this layer on the bf16x3 kernel (fp32-accurate, csrc/gemm_bf3.hip)?"""
+        if not self.m.gemm_bf3:
+            return False
+        return bool(self.lib.bbdm_gemm_bf3_supported(self.lib.bbdm_winograd_tiles(wm, self.N, H, W), cin_pad, cout))
+
     def _emit_winograd(self, x, cin_pad, pw, pre, upsample, H, W, residual, res_ld, dest, flags, bwd=False):
         """input transform -> 16 batched GEMMs -> output transform (csrc/winograd.hip)."""
         emit = self._bop if bwd else self._op
@@ -750,7 +783,8 @@ class _Plan:
         self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
         emit("bbdm_winograd_input_f32", wm, x, x.ld, self._wino_v, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W,
              cin_pad)
-        emit("bbdm_winograd_gemm_f32", wm, self._wino_v, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
+        gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
+        emit(gemm, wm, self._wino_v, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
         emit("bbdm_winograd_output_f32", wm, self._wino_m,
              self._pref(pw.bias) if pw.bias is not None and not bwd else None, residual, res_ld, dest, dest.ld, flags,
              N, H, W, cout)
@@ -767,7 +801,7 @@ class _Plan:
         H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
         wm = self._winograd_ok(mod, H, W, x.C, flags)
         if wm:
-            pw = _PackedWinograd(mod.weight, mod.bias, x.C, wm)
+            pw = _PackedWinograd(mod.weight, mod.bias, x.C, wm, bf3=self._use_bf3(wm, H, W, x.C, cout))
             self.convs.append(pw)
             self._emit_winograd(x, x.C, pw, pre, upsample, H, W, residual, res_ld, dest, flags)
             return
@@ -963,7 +997,7 @@ class _Plan:
             wm = (winograd_tile(N, x_in.H, x_in.W, dy.C, x_in.C, m.winograd)
                   if (m.winograd and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             if wm:
-                pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True)
+                pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=self._use_bf3(wm, x_in.H, x_in.W, dy.C, x_in.C))
                 self.dconvs.append(pk)
                 self._emit_winograd(dy, dy.C, pk, None, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
                 return dx
@@ -1187,7 +1221,7 @@ class _Plan:
         ops = self.bops[lo:hi] + (self.bops_x0 if (last and need_dx) else [])
         check = _lib.check
         for name, args in ops:
-            fn = getattr(lib, name)
+            fn = getattr(lib, getattr(name, "entry", name))
             rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
             if rc != 0:
                 check(rc, name)
@@ -1253,7 +1287,8 @@ class _Plan:
     # ---- execution ------------------------------------------------------------------------------------------------
     def _bind(self):
         lib = self.lib
-        self._bound = [(getattr(lib, name), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
+        self._bound_names = [str(name) for name, _ in self.ops]
+        self._bound = [(getattr(lib, getattr(name, "entry", name)), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
                        for name, args in self.ops]
 
     def _refresh_weights(self, stream):
@@ -1303,14 +1338,14 @@ class _Plan:
                     check(rc, fn.__name__)
         else:
             # per-op HIP events on the launch stream (bench.py's roofline leg); (name, start, stop, flops)
-            for (fn, args), fl in zip(self._bound, self.op_flops):
+            for (fn, args), fl, opname in zip(self._bound, self.op_flops, self._bound_names):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 rc = fn(*args, stream)
                 e1.record()
                 if rc != 0:
                     check(rc, fn.__name__)
-                prof.append((fn.__name__, e0, e1, fl))
+                prof.append((opname, e0, e1, fl))
 
     def _want_graph(self) -> bool:
         """hipGraph replay of the ~200-launch forward pays only when the launches are short (small latents); at the

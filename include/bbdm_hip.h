@@ -229,6 +229,26 @@ int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const f
                            int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
                            int resample, void* stream);
 
+/* ---- fp32-accurate batched GEMM on the BF16 matrix core (the Winograd tile GEMMs; csrc/gemm_bf3.hip) ----------- */
+/* v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate on gfx950.  Each fp32 operand is split exactly into three
+ * bf16 numbers (x = x1 + x2 + x3, round-to-nearest residuals) and the six leading bf16 x bf16 products -- everything
+ * above 2^-23 of |a b| -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: an fp32-accurate product at 2.67x the
+ * matrix throughput of the f32 MFMA (error against an fp64 GEMM measured next to the f32-MFMA kernel in
+ * tests/test_kernels_gpu.py::test_gemm_bf3_accuracy).
+ *   bbdm_gemm_bf3_packed_halfs : number of 16-bit elements of the split weight buffer
+ *   bbdm_gemm_bf3_pack_f32     : fp32 packed [batch][CinPad/16][CoutPad128][16] (what bbdm_winograd_pack_weight_f32 /
+ *                                bbdm_conv_pack_weight_f32(ks = 1) produce) -> [batch][CinPad/16][3][CoutPad128][16] bf16
+ *   bbdm_gemm_bf3_supported    : shape gate (T % 256 == 0, CinPad % 16 == 0, Cout % 4 == 0)
+ *   bbdm_gemm_bf3_f32          : M[b] = V[b] ([T x CinPad] fp32, split while staged) . U[b]   for b < batch
+ *   bbdm_winograd_gemm_bf3_f32 : stage (2) of the Winograd path (same arguments as bbdm_winograd_gemm_f32). */
+size_t bbdm_gemm_bf3_packed_halfs(int batch, int CinPad, int Cout);
+int bbdm_gemm_bf3_pack_f32(const float* packed_f32, void* packed_bf3, int batch, int CinPad, int Cout, void* stream);
+int bbdm_gemm_bf3_supported(long long T, int CinPad, int Cout);
+int bbdm_gemm_bf3_f32(const float* V, const void* packed_bf3, float* M, int batch, long long T, int CinPad, int Cout,
+                      void* stream);
+int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* packed_bf3, float* M, int N, int H, int W, int CinPad,
+                               int Cout, void* stream);
+
 /* ---- optimizer + EMA in one pass (training) ------------------------------------------------ */
 /* Replaces torch.optim.Adam.step() (runners/utils.py:48-51; called at runners/BaseRunner.py:413-415) and
  * EMA.update() (runners/base/EMA.py:21-29; called at BaseRunner.py:173-178,422-423) for all parameters with ONE launch.

@@ -313,3 +313,17 @@ def linear_bwd(dy, x, w, act_in=False, need_dx=True, need_db=True):
     _lib.call("bbdm_linear_bwd_f32", dy.data_ptr(), x.data_ptr(), w.data_ptr(), None if dx is None else dx.data_ptr(),
               dw.data_ptr(), None if db is None else db.data_ptr(), ws.data_ptr(), N, In, Out, 1 if act_in else 0, _st(x))
     return dx, dw, db
+
+
+def gemm_bf3(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: int, cout: int) -> torch.Tensor:
+    """V: [batch, T, cin_pad] fp32; w_packed_f32: the fp32 packed weights ([batch][cin_pad/16][CoutPad][16]).  Returns
+    M [batch, T, cout] computed by the bf16x3 kernel (csrc/gemm_bf3.hip)."""
+    _chk(V, w_packed_f32)
+    T = V.shape[1]
+    lib = _lib.load()
+    nh = lib.bbdm_gemm_bf3_packed_halfs(batch, cin_pad, cout)
+    pk = torch.empty(nh, dtype=torch.int16, device=V.device)
+    _lib.call("bbdm_gemm_bf3_pack_f32", w_packed_f32.data_ptr(), pk.data_ptr(), batch, cin_pad, cout, _st(V))
+    M = torch.empty(batch, T, cout, dtype=torch.float32, device=V.device)
+    _lib.call("bbdm_gemm_bf3_f32", V.data_ptr(), pk.data_ptr(), M.data_ptr(), batch, T, cin_pad, cout, _st(V))
+    return M

@@ -48,6 +48,11 @@ def test_winograd_stages_fused_producer(m, up, silu):
     K.test_winograd_stages_fused_producer(CPU, m, up, silu)
 
 
+@pytest.mark.parametrize("batch,T,Cin,Cout", [(2, 256, 48, 72), (1, 512, 64, 132)])
+def test_gemm_bf3_accuracy(batch, T, Cin, Cout):
+    K.test_gemm_bf3_accuracy(CPU, batch, T, Cin, Cout)
+
+
 def test_conv_rejections_and_slices():
     K.test_conv3x3_winograd_rejects_bad_shapes(CPU)
     K.test_conv2d_channel_slices(CPU)

@@ -215,6 +215,28 @@ def test_conv3x3_winograd_dgrad_and_slices_m6(dev):
     test_conv3x3_winograd_dgrad_and_slices(dev, 6)
 
 
+@pytest.mark.parametrize("batch,T,Cin,Cout", [(2, 256, 48, 72), (1, 512, 256, 128), (3, 256, 1024, 260)])
+def test_gemm_bf3_accuracy(dev, batch, T, Cin, Cout):
+    """csrc/gemm_bf3.hip: the fp32 GEMM on the BF16 matrix core (exact three-way operand split, six product terms) against
+    an fp64 GEMM, next to plain fp32 arithmetic on the same operands: it must be as accurate as fp32 (not bf16: a single
+    bf16 product would be off by ~4e-3)."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    V = torch.randn(batch, T, Cin, generator=g) * torch.logspace(-3, 3, Cin)          # 6 decades of column scales
+    Wt = torch.randn(batch, Cout, Cin, generator=g) * 0.1 / torch.logspace(-3, 3, Cin)
+    cout_pad = (Cout + 127) // 128 * 128
+    pk = torch.zeros(batch, Cin // 16, cout_pad, 16)
+    for c in range(Cin // 16):
+        pk[:, c, :Cout, :] = Wt[:, :, c * 16:(c + 1) * 16]
+    M = ops.gemm_bf3(V.to(dev), pk.contiguous().to(dev), batch, Cin, Cout).cpu()
+    torch.cuda.synchronize()
+    ref = torch.einsum("btk,bok->bto", V.double(), Wt.double())
+    f32 = torch.einsum("btk,bok->bto", V, Wt)
+    e_bf3, e_f32 = rel_err(M, ref), rel_err(f32, ref)
+    print(f"gemm_bf3 [{batch} x {T} x {Cin} x {Cout}]: rel err vs fp64 {e_bf3:.2e} (plain fp32: {e_f32:.2e})")
+    assert e_bf3 < 3e-6 and e_bf3 < 8 * e_f32 + 1e-7
+
+
 def test_conv3x3_winograd_rejects_bad_shapes(dev):
     from bbdm_amd import _lib
     import kernel_ops as ops

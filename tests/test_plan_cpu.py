@@ -83,7 +83,11 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         P = (wm + 2) ** 2
         assert tiles % 256 == 0 and tiles >= N * -(-H // wm) * -(-W // wm)
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
-        assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
+        if getattr(ops[k + 1][0], "entry", "").endswith("bf3_f32"):
+            assert g[2].t.dtype == torch.int16 and g[2].t.numel() == lib.bbdm_gemm_bf3_packed_halfs((wm + 2) ** 2, cin, cout)
+            assert lib.bbdm_gemm_bf3_supported(tiles, cin, cout)
+        else:
+            assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
         assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) == wm
     if training:
         assert names["bbdm_conv_wgrad_f32"] > 0

@@ -18,7 +18,7 @@ OUT = os.path.join(HERE, "_build")
 CLANG = os.environ.get("HIPEMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 LIB = os.path.join(OUT, "libbbdm_emu.so")
 
-_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+|__align__\(\d+\)\s+)?(\w+)\s+(\w+)\[\];")
+_DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+|__align__\(\d+\)\s+)?((?:\w+\s+)*?\w+)\s+(\w+)\[\];")
 
 
 def rewrite(src: str) -> str:

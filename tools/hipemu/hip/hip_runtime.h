@@ -34,6 +34,9 @@ struct alignas(16) double2 { double x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 struct alignas(8) int2 { int x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
@@ -200,6 +203,30 @@ static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f
     hipemu::wave_release();
     return d;
 }
+// v_mfma_f32_32x32x16_bf16: D[32x32] = A[32x16] * B[16x32] + C.  Lane l supplies A[l % 32][8 (l / 32) + e] and
+// B[8 (l / 32) + e][l % 32], e = 0..7 (one 16-byte register quad each); C/D layout as the f32 32x32 form.
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c, int, int, int) {
+    struct AB { float a[8], b[8]; } mine;
+    for (int e = 0; e < 8; ++e) { mine.a[e] = (float)a[e]; mine.b[e] = (float)b[e]; }
+    const void* const* all = hipemu::wave_publish(&mine);
+    const int l = hipemu::g_lane, j = l & 31, hi = l >> 5;
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h) {
+            const AB* pa = static_cast<const AB*>(all[i + 32 * h]);
+            const AB* pb = static_cast<const AB*>(all[j + 32 * h]);
+            if (!pa || !pb) continue;
+            for (int e = 0; e < 8; ++e) acc += pa->a[e] * pb->b[e];
+        }
+        d[r] = acc;
+    }
+    hipemu::wave_release();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
