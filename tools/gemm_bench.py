@@ -29,7 +29,8 @@ SHAPES = [  # N, H, W, Cin, Cout
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--m", type=int, default=4)
+    ap.add_argument("--m", type=int, default=6)
+    ap.add_argument("--bf3", type=int, default=1, help="1 = bf16x3 kernel (csrc/gemm_bf3.hip), 0 = f32 MFMA kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -41,7 +42,14 @@ def main():
         V = torch.randn(P * tiles * Cin, device=dev)
         M = torch.empty(P * tiles * Cout, device=dev)
         pw = ops.pack_winograd_weight(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02, m=m)
-        call = lambda: _lib.call("bbdm_winograd_gemm_f32", m, V.data_ptr(), pw.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, st)
+        if args.bf3:
+            pk = torch.empty(lib.bbdm_gemm_bf3_packed_halfs(P, Cin, Cout), dtype=torch.int16, device=dev)
+            _lib.call("bbdm_gemm_bf3_pack_f32", pw.data_ptr(), pk.data_ptr(), P, Cin, Cout, st)
+            call = lambda: _lib.call("bbdm_winograd_gemm_bf3_f32", m, V.data_ptr(), pk.data_ptr(), M.data_ptr(), N, H, W, Cin,
+                                     Cout, st)
+        else:
+            call = lambda: _lib.call("bbdm_winograd_gemm_f32", m, V.data_ptr(), pw.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout,
+                                     st)
         call()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
