@@ -434,6 +434,86 @@ conv_igemm_f32(const ConvArgs a_in) {
     }
 }
 
+// ---- 3x3 convolution with a handful of output channels (the UNet head: 128 -> 3, openaimodel.py:687-691) -----------------
+// The MFMA kernel pads Cout to a 128-wide tile: at Cout = 3 97 % of the matrix work is wasted (2.3 ms at 256x256, batch 16,
+// 3 TFLOP/s).  Here one thread owns one output pixel and all CO (<= 8) output channels; the 18 x 18 halo patch of a 16 x 16
+// pixel tile is staged in LDS per 16-channel chunk (fused GroupNorm -> SiLU coefficients applied while staging, as in the
+// MFMA kernel), the [9][16][CO] weight slab is read as LDS broadcasts.  FMA on the vector ALU: 2 * 9 * Cin * CO FLOP per
+// pixel is small next to the 4 * Cin bytes the pixel reads, so the kernel is HBM / LDS bound, not ALU bound.
+template <int CO, bool PRE>
+__global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
+    constexpr int TS = 16, PS = TS + 2, NPP = PS * PS;             // tile side, patch side, patch pixels
+    __shared__ __attribute__((aligned(16))) float patch[NPP * KP];   // [patch pixel][16 + 4 pad]
+    __shared__ __attribute__((aligned(16))) float wsm[9 * KC * CO];  // [tap][k][co]
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int tilesX = (a.W + TS - 1) / TS;
+    const int tile_y = blockIdx.x / tilesX, tile_x = blockIdx.x - tile_y * tilesX;
+    const int n = blockIdx.y;
+    const int h0 = tile_y * TS - 1, w0 = tile_x * TS - 1;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    const size_t wChunk = (size_t)a.CoutPad * KC;                    // packed weights: [tap][chunk][CoutPad][16]
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const int cbase = chunk * KC;
+        for (int f = tid; f < NPP * 4; f += 256) {
+            const int pp = f >> 2, c4 = f & 3;
+            const int py = pp / PS, px = pp - py * PS;
+            const int h = h0 + py, w = w0 + px, c = cbase + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin) {
+                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + c);
+                if (PRE) {
+                    const float4 sc = *reinterpret_cast<const float4*>(a.pre_sc + (size_t)n * a.pre_ld + c);
+                    const float4 bi = *reinterpret_cast<const float4*>(a.pre_bi + (size_t)n * a.pre_ld + c);
+                    v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+                    if (a.pre_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                }
+            }
+            *reinterpret_cast<float4*>(patch + pp * KP + c4 * 4) = v;
+        }
+        for (int f = tid; f < 9 * KC * CO; f += 256) {
+            const int co = f % CO, k = (f / CO) % KC, tap = f / (CO * KC);
+            wsm[f] = co < a.Cout ? a.w[((size_t)tap * a.nchunks + chunk) * wChunk + (size_t)co * KC + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* P = patch + ((ty + tap / 3) * PS + tx + tap % 3) * KP;
+            const float* Wt = wsm + tap * KC * CO;
+#pragma unroll
+            for (int k4 = 0; k4 < KC; k4 += 4) {
+                const float4 xv = *reinterpret_cast<const float4*>(P + k4);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) acc[c] = fmaf(xs[e], Wt[(k4 + e) * CO + c], acc[c]);
+            }
+        }
+        __syncthreads();
+    }
+    const int h = tile_y * TS + ty, w = tile_x * TS + tx;
+    if (h < a.H && w < a.W) {
+        const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            if (c >= a.Cout) continue;
+            const float v = acc[c] + (a.bias ? a.bias[c] : 0.f);
+            if (a.out_nchw & 1) a.out[((size_t)(n * a.Cout + c) * a.H + h) * a.W + w] = v;
+            else a.out[pix * a.ldo + c] = v;
+        }
+    }
+}
+
+template <int CO>
+void launch_narrow(const ConvArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16)), (unsigned)a.N);
+    if (a.pre_sc) hipLaunchKernelGGL((conv3x3_narrow_kernel<CO, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_narrow_kernel<CO, false>), grid, dim3(256), 0, st, a);
+}
+
 // out = sum_s ws[s] + bias (+ residual): fixed summation order -> deterministic
 __global__ void conv_splitk_reduce_kernel(const ConvArgs a) {
     const size_t M = (size_t)a.N * a.H * a.W;
@@ -657,6 +737,11 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     a.batch = 1; a.xz = a.wz = a.oz = 0; a.dbg = nullptr;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
+    if (ks == 3 && Cout <= 8 && !residual && M >= 4096) {      // a few output channels: one thread per pixel (see above)
+        if (Cout <= 4) launch_narrow<4>(a, st); else launch_narrow<8>(a, st);
+        BBDM_CHECK_LAUNCH("conv2d(narrow)");
+        return BBDM_OK;
+    }
     const ConvPlan plan = conv_plan(M, Cout, a.nchunks);
     a.splits = plan.splits;
     int rc;

@@ -627,7 +627,10 @@ class _Plan:
             h = self._emit_block(blk, cb, dest)
         # head: GN -> SiLU -> conv3x3 -> NCHW  (openaimodel.py:687-691,759)
         head_stats = self._gn_count
-        a, pre = self._gn_input(h, m.out[0], None, silu=1, name="A")
+        # the head's few output channels take the one-thread-per-pixel kernel (csrc/conv_igemm.hip: conv3x3_narrow_kernel),
+        # an HBM-bound pass with idle ALUs: GroupNorm -> SiLU is folded into its patch staging
+        narrow_head = m.out_channels <= 8 and N * H * W >= 4096
+        a, pre = self._gn_input(h, m.out[0], None, silu=1, name="A", fuse_direct=narrow_head)
         pc = self._conv(m.out[2], a.C)
         self._op("bbdm_conv2d_nhwc_f32", a, a.ld, _TensorRef(pc.packed), self._pref(pc.bias), None, 0,
                  _TensorRef(self.out_nchw), 0, 1, None, 0, *pre, N, a.H, a.W, a.C, pc.cout, 3)
@@ -734,7 +737,7 @@ class _Plan:
 
     NO_PRE = (None, None, 0, 0)
 
-    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None):
+    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None, fuse_direct: bool = False):
         """Input of a conv that follows GroupNorm [-> FiLM] [-> SiLU] at the same resolution.
 
         Inference plans do not materialise the normalised tensor: they emit the statistics + a tiny per-(image, channel)
@@ -743,8 +746,8 @@ class _Plan:
         into the direct conv kernel only on request (``fuse_groupnorm``: it costs more MFMA stalls than the pass it
         removes) but always into the HBM-bound Winograd input transform of ``consumer``, where it is
         free."""
-        fuse = self.m.fuse_groupnorm or (consumer is not None and self.m.winograd_fuse_groupnorm
-                                         and self._winograd_ok(consumer, x.H, x.W, x.C))
+        fuse = fuse_direct or self.m.fuse_groupnorm or (consumer is not None and self.m.winograd_fuse_groupnorm
+                                                        and self._winograd_ok(consumer, x.H, x.W, x.C))
         if self.training or not fuse:
             return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
         N = self.N

@@ -36,6 +36,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
 
 # BASELINE.json configs (UNetParams per configs/Template-*.yaml)
@@ -360,11 +361,27 @@ def main():
     extra = sum(_direct_flops(oa) - fl for (nm, oa), fl in zip(plan0.ops, plan0.op_flops)
                 if nm == "bbdm_winograd_gemm_f32")              # per forward pass: direct count - executed count
     total_flops_per_step = executed_flops_per_step + (extra if not training else 0.0)
-    conv_launches = conv[0]
-    conv_ms = conv[1]
-    flops_per_launch = conv[2] / max(1, conv_launches)
+    # The dominant kernel.  With the default plan the Winograd tile GEMMs run on gemm_bf3_kernel (csrc/gemm_bf3.hip): fp32
+    # arithmetic emulated EXACTLY-to-fp32-rounding on the BF16 matrix core (each operand split into 3 bf16, 6 product terms,
+    # fp32 accumulate).  Its roofline is the dense bf16 MFMA peak; one fp32-equivalent FLOP costs 6 bf16 FLOP, so the bound
+    # for the algorithmic (fp32) FLOPs is PEAK_BF16 / 6.  With BBDM_GEMM_BF3=0 (or where the shape gate rejects a layer)
+    # the GEMMs run on conv_igemm_f32 (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s) together with the direct convolutions.
+    bf3_ops = sum(getattr(nm, "entry", "").endswith("bf3_f32") for nm, _ in plan0.ops)
+    use_bf3 = bf3_ops > 0
+    if use_bf3:
+        dom, dom_name = wino, "gemm_bf3_kernel (v_mfma_f32_32x32x16_bf16 x 6 terms = one fp32-accurate product)"
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+    else:
+        dom, dom_name, peak = conv, "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
+    conv_launches = dom[0]
+    conv_ms = dom[1]
+    flops_per_launch = dom[2] / max(1, conv_launches)
     avg_launch_ms = conv_ms / max(1, conv_launches)
     achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
+    # whole step against the matrix peaks: time-at-peak of every MFMA kernel's work / step time
+    f32_flops = (executed_flops_per_step - (wino[2] / max(1, args.steps) if use_bf3 else 0.0))
+    t_at_peak = f32_flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
+        ((wino[2] / max(1, args.steps)) / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12) if use_bf3 else 0.0)
     # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
     # rocprofv3 PMC passes of this same command (profiles/*_pmc_<workload>_traffic.json), per launch, or null.
     traffic = None
@@ -373,7 +390,7 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
-            hits = [v for k, v in pm["kernels"].items() if k.startswith("conv_igemm_f32")]
+            hits = [v for k, v in pm["kernels"].items() if k.startswith("gemm_bf3_kernel" if use_bf3 else "conv_igemm_f32")]
             if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
                 nl = sum(v["launches"] for v in hits)
                 traffic = {"bytes_per_launch": sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in hits) / nl,
@@ -386,10 +403,10 @@ def main():
     for nm, oa in plan0.ops:
         if nm == "bbdm_winograd_gemm_f32":
             wm, gN, gH, gW, gci, gco = oa[0], *oa[4:9]
-            P, T = (wm + 2) ** 2, gN * (gH // wm) * (gW // wm)
-            alg_bytes += 4.0 * (P * T * (gci + gco) + P * gci * gco)
+            P, T = (wm + 2) ** 2, gN * -(-gH // wm) * -(-gW // wm)
+            alg_bytes += 4.0 * (P * T * (gci + gco)) + (6.0 if use_bf3 else 4.0) * P * gci * gco
             alg_n += 1
-        elif nm == "bbdm_conv2d_nhwc_f32":
+        elif nm == "bbdm_conv2d_nhwc_f32" and not use_bf3:
             gN, gH, gW, gci, gco, gks = oa[15:21]
             alg_bytes += 4.0 * (gN * gH * gW * (gci + gco) + gks * gks * gci * gco)
             alg_n += 1
@@ -407,7 +424,8 @@ def main():
                        f"denoise-UNet sampling steps/sec ({args.workload})"),
             "value": steps_per_s_job, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
+            "dtype": ("f32 (tile GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA terms, fp32 accumulate -- fp32-accurate; "
+                      "all other kernels native fp32)") if use_bf3 else "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
             "config": {"workload": desc, "batch_per_gpu": batch, "image_size": size, "unet_params_M": nparams / 1e6,
                        "schedule_steps": nsteps_table, "parallelism": f"dp{world} (independent image-pair shards)"},
             "devices": devices,
@@ -417,17 +435,24 @@ def main():
             "imgs_per_sec_whole_job": steps_per_s_job * batch / nsteps_table,
             "tflops_algorithmic": total_flops_per_step / (ms_per_step * 1e-3) / 1e12,
             "tflops_executed": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "frac_step": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         "frac_step_note": "whole step: FLOPs executed on the MFMA by every kernel / step time / peak",
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_note": ("fp32-equivalent bound = dense bf16 MFMA peak 2500 / 6 (six bf16 MFMA terms per fp32 "
+                                       "product); executed bf16 rate = 6 x achieved") if use_bf3 else
+                                      "fp32-input MFMA peak (MI355X_MICROARCH.md)",
+                         "executed_bf16_tflops": 6.0 * achieved if use_bf3 else None,
+                         "frac_step": t_at_peak / (ms_per_step * 1e-3),
+                         "frac_step_note": "whole step: time the MFMA work of every kernel would take at its matrix peak "
+                                           "(bf16x6 for the tile GEMMs, f32 MFMA for the rest) / step time",
                          "traffic": traffic, "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
-                         "conv_share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,
-                         "flops_counted": "executed on the MFMA (Winograd layers: (m+2)^2 tile GEMMs = 4/9 (m=2) or 1/4 (m=4) of the direct count)",
+                         "share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,
+                         "flops_counted": "fp32-equivalent FLOPs executed: a Winograd layer's (m+2)^2 tile GEMMs = 4/9 (m=2), "
+                                          "1/4 (m=4) or 16/81 (m=6) of its direct-convolution count",
                          "winograd_gemm_launches_per_step": wino[0] / max(1, args.steps),
                          "winograd_gemm_tflops": (wino[2] / (wino[1] * 1e-3) / 1e12) if wino[1] > 0 else None,
-                         "direct_conv_tflops": (direct[2] / (direct[1] * 1e-3) / 1e12) if direct[1] > 0 else None},
+                         "direct_conv_tflops": (direct[2] / (direct[1] * 1e-3) / 1e12) if direct[1] > 0 else None,
+                         "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
         }
         if not args.no_cpu and world == 1:

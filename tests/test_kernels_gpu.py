@@ -48,6 +48,8 @@ CONV_CASES = [
     (32, 4, 4, 1024, 1024, 3, True),     # split-K: 32 output tiles, 64 chunks
     (4, 16, 16, 2048, 512, 1, True),     # split-K on a 1x1
     (2, 8, 8, 640, 96, 3, False),        # split-K with ragged Cout
+    (1, 64, 64, 32, 3, 3, False),        # the UNet head: few output channels -> one-thread-per-pixel kernel
+    (2, 48, 50, 20, 8, 3, False),        # same, ragged tiles, Cin not a multiple of 16, Cout = 8
 ]
 
 
@@ -466,7 +468,8 @@ def test_layout_roundtrip(dev):
 
 
 @pytest.mark.parametrize("N,H,W,C,Cout,ks,film,silu", [(2, 16, 16, 128, 64, 3, True, True), (3, 8, 8, 96, 128, 3, False, True),
-                                                        (1, 32, 32, 256, 128, 1, False, False), (20, 4, 4, 640, 256, 3, True, True)])
+                                                        (1, 32, 32, 256, 128, 1, False, False), (20, 4, 4, 640, 256, 3, True, True),
+                                                        (1, 64, 64, 64, 3, 3, False, True)])       # narrow head + fused GN
 def test_conv_with_fused_groupnorm_producer(dev, N, H, W, C, Cout, ks, film, silu):
     """GroupNorm -> [FiLM] -> [SiLU] -> conv with the normalisation applied while the patch is staged."""
     import kernel_ops as ops
