@@ -20,9 +20,12 @@ constexpr int KT = 32;        // keys per tile
 constexpr int QB = 128;       // queries per block
 
 template <int CH>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, int ldq, float* __restrict__ out,
-                                                       int ldo, float* __restrict__ lse, int T, int heads, int new_order,
-                                                       float scale) {
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
+                                                       const float* __restrict__ ksrc, const float* __restrict__ vsrc, int ldkv,
+                                                       int hskv, float* __restrict__ out, int ldo, float* __restrict__ lse,
+                                                       int Tq, int T, int heads, float qscale, float scale) {
+    // q: [N][Tq][ldq], head h at channel h * hsq;  k, v: [N][T][ldkv], head h at channel h * hskv (T = number of keys).
+    // qscale / scale multiply q / k while they are loaded (legacy: ch^-1/4 each; CrossAttention: ch^-1/2 and 1).
     constexpr int KPITCH = CH + 4;                 // K tile pitch: b128 reads by 32 keys conflict-free
     constexpr int VPITCH = CH < 32 ? 32 : CH;      // V tile pitch (lanes sweep channels)
     constexpr int CT = (CH + 31) / 32;             // 32-row channel tiles of O^T
@@ -36,23 +39,22 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
-    const int qblocks = (T + QB - 1) / QB;
+    const int qblocks = (Tq + QB - 1) / QB;
     const int qb = blockIdx.x % qblocks;
     const int nh = blockIdx.x / qblocks;
     const int h = nh % heads, n = nh / heads;
-    const int qoff = new_order ? h * CH : h * 3 * CH;
-    const int koff = new_order ? heads * CH + h * CH : h * 3 * CH + CH;
-    const int voff = new_order ? 2 * heads * CH + h * CH : h * 3 * CH + 2 * CH;
-    const float* base = qkv + (size_t)n * T * ldq;
+    const float* qbase = qsrc + (size_t)n * Tq * ldq + h * hsq;
+    const float* kbase = ksrc + (size_t)n * T * ldkv + h * hskv;
+    const float* vbase = vsrc + (size_t)n * T * ldkv + h * hskv;
 
     // ---- Q^T fragment: lane holds q[c] for c = kg*8 + hi*4 + j -------------------------------------------------
     const int q = qb * QB + wave * 32 + lq;
     float4 qf[KG];
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) {
-        if (q < T) {
-            float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * ldq + qoff + kg * 8 + hi * 4);
-            qf[kg] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+        if (q < Tq) {
+            float4 v = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + kg * 8 + hi * 4);
+            qf[kg] = make_float4(v.x * qscale, v.y * qscale, v.z * qscale, v.w * qscale);
         } else {
             qf[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -72,10 +74,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
             const int f = tid + s * 256;
             const int key = tile * KT + f / (CH / 4), c = (f % (CH / 4)) * 4;
             if (f < KV4 && key < T) {
-                const float* row = base + (size_t)key * ldq;
-                float4 kv = *reinterpret_cast<const float4*>(row + koff + c);
+                float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)key * ldkv + c);
                 kreg[s] = make_float4(kv.x * scale, kv.y * scale, kv.z * scale, kv.w * scale);
-                vreg[s] = *reinterpret_cast<const float4*>(row + voff + c);
+                vreg[s] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ldkv + c);
             } else {
                 kreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
                 vreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     float* obuf = smem;                                    // 128 * (CH+1) floats <= the K/V buffers for CH >= 16
     static_assert(QB * OPITCH <= 2 * KT * KPITCH + 2 * KT * VPITCH, "epilogue staging does not fit");
     const float inv = 1.0f / l_run;
-    if (lse && hi == 0 && q < T) lse[((size_t)n * heads + h) * T + q] = m_run + logf(l_run);   // for the backward pass
+    if (lse && hi == 0 && q < Tq) lse[((size_t)n * heads + h) * Tq + q] = m_run + logf(l_run);   // for the backward pass
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -181,11 +182,28 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     for (int i = tid; i < QB * CH; i += 256) {
         const int ql = i / CH, c = i - ql * CH;
         const int qq = qb * QB + ql;
-        if (qq < T) out[((size_t)n * T + qq) * ldo + h * CH + c] = obuf[ql * OPITCH + c];
+        if (qq < Tq) out[((size_t)n * Tq + qq) * ldo + h * CH + c] = obuf[ql * OPITCH + c];
     }
 }
 
 }  // namespace
+
+static int launch_attention(const float* q, int ldq, int hsq, const float* k, const float* v, int ldkv, int hskv, float* out,
+                            int ldo, float* lse, int N, int Tq, int Tk, int heads, int ch, float qscale, float kscale,
+                            hipStream_t st) {
+    const int qblocks = (Tq + QB - 1) / QB;
+    const dim3 grid((unsigned)((long long)N * heads * qblocks));
+    if (ch == 64)
+        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk,
+                           heads, qscale, kscale);
+    else if (ch == 32)
+        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk,
+                           heads, qscale, kscale);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk,
+                           heads, qscale, kscale);
+    return 0;
+}
 
 extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads,
                                   int ch, int new_order, void* stream) {
@@ -195,18 +213,30 @@ extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo
     BBDM_REQUIRE(ldq % 4 == 0 && ldq >= 3 * heads * ch && ldo >= heads * ch && ((uintptr_t)qkv & 15) == 0,
                  "attention: bad pitch / alignment");
     const float scale = 1.0f / sqrtf(sqrtf((float)ch));
-    const int qblocks = (T + QB - 1) / QB;
-    const dim3 grid((unsigned)((long long)N * heads * qblocks));
-    hipStream_t st = (hipStream_t)stream;
-    if (ch == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, lse, T, heads, new_order,
-                           scale);
-    else if (ch == 32)
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, lse, T, heads, new_order,
-                           scale);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, qkv, ldq, out, ldo, lse, T, heads, new_order,
-                           scale);
+    const int C = heads * ch;
+    if (new_order)      // QKVAttention: q | k | v thirds, head h at h * ch inside each
+        launch_attention(qkv, ldq, ch, qkv + C, qkv + 2 * C, ldq, ch, out, ldo, lse, N, T, T, heads, ch, scale, scale,
+                         (hipStream_t)stream);
+    else                // QKVAttentionLegacy: per head (q, k, v) triples
+        launch_attention(qkv, ldq, 3 * ch, qkv + ch, qkv + 2 * ch, ldq, 3 * ch, out, ldo, lse, N, T, T, heads, ch, scale,
+                         scale, (hipStream_t)stream);
     BBDM_CHECK_LAUNCH("attention");
+    return BBDM_OK;
+}
+
+// CrossAttention.forward (model/BrownianBridge/base/modules/attention.py:170-194): q [N][Tq][heads*ch] from the image
+// tokens, k / v [N][Tk][heads*ch] from the context tokens (Tk != Tq in general; k = v source = x for self-attention),
+// softmax_j(q_i . k_j * ch^-1/2) v_j, heads laid out 'b n (h d)'.
+extern "C" int bbdm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
+                                        int N, int Tq, int Tk, int heads, int ch, void* stream) {
+    BBDM_REQUIRE(q && k && v && out, "cross_attention: null pointer");
+    BBDM_REQUIRE(N > 0 && Tq > 0 && Tk > 0 && heads > 0, "cross_attention: bad shape");
+    BBDM_REQUIRE(ch == 16 || ch == 32 || ch == 64, "cross_attention: head channels %d unsupported (16, 32, 64)", ch);
+    BBDM_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldq >= heads * ch && ldkv >= heads * ch && ldo >= heads * ch &&
+                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0,
+                 "cross_attention: bad pitch / alignment");
+    launch_attention(q, ldq, ch, k, v, ldkv, ch, out, ldo, nullptr, N, Tq, Tk, heads, ch, 1.0f / sqrtf((float)ch), 1.0f,
+                     (hipStream_t)stream);
+    BBDM_CHECK_LAUNCH("cross_attention");
     return BBDM_OK;
 }

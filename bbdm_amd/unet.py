@@ -126,6 +126,80 @@ class AttentionBlock(nn.Module):
     forward = _no_forward
 
 
+class CrossAttention(nn.Module):
+    """model/BrownianBridge/base/modules/attention.py:153-194 (parameter holder)."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = query_dim if context_dim is None else context_dim
+        self.scale, self.heads, self.dim_head = dim_head ** -0.5, heads, dim_head
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+
+    forward = _no_forward
+
+
+class GEGLU(nn.Module):
+    """attention.py:38-46."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    forward = _no_forward
+
+
+class FeedForward(nn.Module):
+    """attention.py:48-64."""
+
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        inner_dim = int(dim * mult)
+        dim_out = dim if dim_out is None else dim_out
+        project_in = nn.Sequential(nn.Linear(dim, inner_dim), nn.GELU()) if not glu else GEGLU(dim, inner_dim)
+        self.net = nn.Sequential(project_in, nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+
+    forward = _no_forward
+
+
+class BasicTransformerBlock(nn.Module):
+    """attention.py:196-219 (construction order = the reference's: attn1, ff, attn2, norm1..3)."""
+
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True):
+        super().__init__()
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                                    dropout=dropout)
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+
+    forward = _no_forward
+
+
+class SpatialTransformer(nn.Module):
+    """attention.py:222-263: GroupNorm(eps 1e-6) -> 1x1 conv -> depth x BasicTransformerBlock over the pixel tokens (self-
+    attention, cross-attention to the context image's pixels, GEGLU feed-forward) -> zero-initialised 1x1 conv + input."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None):
+        super().__init__()
+        self.in_channels, self.n_heads, self.d_head = in_channels, n_heads, d_head
+        inner_dim = n_heads * d_head
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim)
+             for _ in range(depth)])
+        self.proj_out = _zero_(nn.Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0))
+
+    forward = _no_forward
+
+
 # --------------------------------------------------------------------------------------------------------------
 # small helpers for the executor
 # --------------------------------------------------------------------------------------------------------------
@@ -347,8 +421,6 @@ class UNetModel(nn.Module):
             unsupported.append(f"dims={dims}")
         if num_classes is not None:
             unsupported.append("num_classes")
-        if use_spatial_transformer:
-            unsupported.append("use_spatial_transformer (SURVEY.md §8f 'next')")
         if n_embed is not None:
             unsupported.append("n_embed")
         if dropout:
@@ -384,9 +456,21 @@ class UNetModel(nn.Module):
             return ResBlock(ch, ted, dropout, out_channels=out_ch, use_scale_shift_norm=use_scale_shift_norm,
                             up=up, down=down)
 
+        self.use_spatial_transformer = use_spatial_transformer
+        self.context_dim = context_dim
+
         def attn(ch, heads):
-            return AttentionBlock(ch, num_heads=heads, num_head_channels=num_head_channels,
-                                  use_new_attention_order=use_new_attention_order)
+            if not use_spatial_transformer:
+                return AttentionBlock(ch, num_heads=heads, num_head_channels=num_head_channels,
+                                      use_new_attention_order=use_new_attention_order)
+            # openaimodel.py:546-565: heads = ch // num_head_channels when that is given (else num_heads); with legacy=True
+            # the SpatialTransformer's head width is ch // heads
+            nh = num_heads if num_head_channels == -1 else ch // num_head_channels
+            d_head = ch // nh
+            if d_head not in (16, 32, 64):
+                raise NotImplementedError(f"bbdm_amd.UNetModel: SpatialTransformer head width {d_head} (channels {ch} / "
+                                          f"{nh} heads) is not implemented; the attention kernel takes 16, 32 or 64")
+            return SpatialTransformer(ch, nh, d_head, depth=transformer_depth, context_dim=context_dim)
 
         # construction order == openaimodel.py:518-691 (keeps RNG consumption, hence seeded init, identical)
         self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, mc, 3, padding=1))])
@@ -532,6 +616,7 @@ class _Plan:
         self.lib = _lib.load()
         self._n_coeffs, self._coeff_need = 0, 1
         self._coeff_bufs = [(_LateTensor(), _LateTensor()), (_LateTensor(), _LateTensor())]
+        self._ctx_tokens = None
         self._conv_ws_need = 0
         self._conv_ws = _LateTensor()             # split-K scratch shared by every conv of the plan
         self._conv_ws_floats = _LateInt()
@@ -866,6 +951,71 @@ class _Plan:
             self.tape.append(("attn", ab, x, a, qkv, at, lse, out, s0))
         return out
 
+    def _context_tokens(self) -> Optional[_View]:
+        """The cross-attention context as NHWC tokens [N, Hc*Wc, context channels padded to 4]: 'b c h w -> b (h w) c'
+        (attention.py:175-176) of the tensor the UNet was called with; None = self-attention (condition_key 'nocond')."""
+        if self.ctx_in is None:
+            return None
+        if self._ctx_tokens is None:
+            N, Cc, Hc, Wc = self.ctx_in.shape
+            v = self._new(N, Hc, Wc, _round4(Cc))
+            self._op("bbdm_nchw_to_nhwc_f32", _TensorRef(self.ctx_in), Cc, None, 0, v, v.ld, v.C, N, Hc, Wc)
+            self._ctx_tokens = v
+        return self._ctx_tokens
+
+    def _emit_transformer(self, st: "SpatialTransformer", x: _View, dest: Optional[_View]) -> _View:
+        """SpatialTransformer.forward (attention.py:249-263).  NHWC activations ARE the token matrix [N*H*W, C]; every
+        Linear is a 1x1 convolution on the matrix core, LayerNorm / GEGLU are streaming kernels (csrc/transformer.hip), the
+        softmax(QK^T)V of both attentions is the streaming-softmax kernel with its own key/value source."""
+        if self.training:
+            raise NotImplementedError("bbdm_amd: training through SpatialTransformer blocks is not implemented yet "
+                                      "(use_spatial_transformer is supported on the sampling path)")
+        N, H, W = self.N, x.H, x.W
+        heads, d = st.n_heads, st.d_head
+        inner = heads * d
+        ctx = self._context_tokens()
+        a, pre = self._gn_input(x, st.norm, None, silu=0, name="A")
+        hb = self._tmp("ST_H", N, H, W, inner)
+        self._emit_conv(a, st.proj_in, None, hb, pre=pre)
+
+        def layernorm(ln_mod, src: _View, name: str) -> _View:
+            out = self._tmp(name, N, H, W, src.C)
+            self._op("bbdm_layernorm_f32", src, src.ld, self._pref(ln_mod.weight), self._pref(ln_mod.bias), out, out.ld,
+                     N * H * W, src.C, float(ln_mod.eps))
+            return out
+
+        def attention(att: "CrossAttention", xin: _View, kv_src: _View):
+            qkv = self._tmp("ST_QKV", N, H, W, inner)
+            self._emit_conv(xin, att.to_q, None, qkv)
+            kvb = self._tmp("ST_KV", kv_src.N, kv_src.H, kv_src.W, 2 * inner)
+            kview = _View(kvb.buf, 0, kvb.ld, kv_src.N, kv_src.H, kv_src.W, inner)
+            vview = _View(kvb.buf, inner, kvb.ld, kv_src.N, kv_src.H, kv_src.W, inner)
+            self._emit_conv(kv_src, att.to_k, None, kview)
+            self._emit_conv(kv_src, att.to_v, None, vview)
+            at = self._tmp("ST_AT", N, H, W, inner)
+            self._op("bbdm_cross_attention_f32", qkv, qkv.ld, kview, vview, kvb.ld, at, at.ld, N, H * W,
+                     kv_src.H * kv_src.W, heads, d)
+            self._emit_conv(at, att.to_out[0], hb, hb)              # + x, in place (the residual aliases the output)
+
+        for blk in st.transformer_blocks:
+            ln1 = layernorm(blk.norm1, hb, "ST_LN")
+            attention(blk.attn1, ln1, ln1)                            # self-attention
+            ln2 = layernorm(blk.norm2, hb, "ST_LN")
+            attention(blk.attn2, ln2, ctx if ctx is not None else ln2)
+            ln3 = layernorm(blk.norm3, hb, "ST_LN")
+            ff = blk.ff
+            if not isinstance(ff.net[0], GEGLU):
+                raise NotImplementedError("bbdm_amd: FeedForward without GEGLU (gated_ff=False) is not implemented")
+            inner_ff = ff.net[2].in_features
+            pr = self._tmp("ST_FF", N, H, W, 2 * inner_ff)
+            self._emit_conv(ln3, ff.net[0].proj, None, pr)
+            gl = self._tmp("ST_GL", N, H, W, inner_ff)
+            self._op("bbdm_geglu_f32", pr, pr.ld, gl, gl.ld, N * H * W, inner_ff)
+            self._emit_conv(gl, ff.net[2], hb, hb)
+        out = dest if dest is not None else self._new(N, H, W, x.C)
+        self._emit_conv(hb, st.proj_out, x, out)
+        return out
+
     def _emit_block(self, blk, h: _View, dest: Optional[_View]) -> _View:
         layers = list(blk)
         for k, layer in enumerate(layers):
@@ -880,6 +1030,8 @@ class _Plan:
                 h = self._emit_res(layer, h, d)
             elif isinstance(layer, AttentionBlock):
                 h = self._emit_attn(layer, h, d)
+            elif isinstance(layer, SpatialTransformer):
+                h = self._emit_transformer(layer, h, d)
             elif isinstance(layer, Downsample):
                 h = self._emit_down(layer, h, d)
             elif isinstance(layer, Upsample):

@@ -229,6 +229,20 @@ int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const f
                            int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
                            int resample, void* stream);
 
+/* ---- SpatialTransformer / cross-attention conditioning (attention.py = model/BrownianBridge/base/
+ *      modules/attention.py) -------------------------------------------------------------------------------------------- */
+/* CrossAttention.forward (attention.py:170-194): out[n, i, h*ch + d] = sum_j softmax_j(q_i . k_j * ch^-1/2) v_j per head.
+ * q: [N][Tq][ldq], k / v: [N][Tk][ldkv] token-major ('b n (h d)': head h at channel h*ch), out: [N][Tq][ldo].
+ * ch in {16, 32, 64}.  Streaming softmax on the f32 matrix core, same kernel as bbdm_attention_f32. */
+int bbdm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, int N,
+                             int Tq, int Tk, int heads, int ch, void* stream);
+/* nn.LayerNorm(C) over the channel axis of `rows` tokens (attention.py:204-206): y = (x - mean) / sqrt(var + eps) * gamma
+ * + beta, biased variance, fp32. */
+int bbdm_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, long long rows,
+                       int C, float eps, void* stream);
+/* GEGLU (attention.py:38-46): y[r][c] = a[r][c] * gelu(a[r][inner + c]), exact (erf) GELU; a = proj(x) with 2*inner columns. */
+int bbdm_geglu_f32(const float* a, int lda, float* y, int ldy, long long rows, int inner, void* stream);
+
 /* ---- fp32-accurate batched GEMM on the BF16 matrix core (the Winograd tile GEMMs; csrc/gemm_bf3.hip) ----------- */
 /* v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate on gfx950.  Each fp32 operand is split exactly into three
  * bf16 numbers (x = x1 + x2 + x3, round-to-nearest residuals) and the six leading bf16 x bf16 products -- everything

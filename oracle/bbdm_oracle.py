@@ -219,6 +219,41 @@ def attention_block(sd: StateDict, p: str, x: Tensor, n_heads: int, new_order: b
     return (xf + a).reshape(b, c, hh, ww)
 
 
+def _cross_attention(sd: StateDict, p: str, x: Tensor, context: Optional[Tensor], heads: int) -> Tensor:
+    """CrossAttention.forward, model/BrownianBridge/base/modules/attention.py:170-194.  x: [b, n, c] tokens;
+    context: [b, c', h, w] image or None (= self-attention)."""
+    q = F.linear(x, sd[p + "to_q.weight"])
+    ctx = x if context is None else context.flatten(2).transpose(1, 2)            # 'b c h w -> b (h w) c'
+    k = F.linear(ctx, sd[p + "to_k.weight"])
+    v = F.linear(ctx, sd[p + "to_v.weight"])
+    b, n, inner = q.shape
+    d = inner // heads
+    split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(b * heads, t.shape[1], d)
+    q, k, v = split(q), split(k), split(v)
+    sim = torch.einsum("bid,bjd->bij", q, k) * (d ** -0.5)
+    out = torch.einsum("bij,bjd->bid", sim.softmax(dim=-1), v)
+    out = out.reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, inner)
+    return F.linear(out, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+
+
+def spatial_transformer(sd: StateDict, p: str, x: Tensor, context: Optional[Tensor], heads: int, depth: int) -> Tensor:
+    """SpatialTransformer.forward + BasicTransformerBlock._forward + FeedForward/GEGLU (attention.py:38-64,196-263)."""
+    b, c, hh, ww = x.shape
+    h = F.group_norm(x, 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    h = F.conv2d(h, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    t = h.flatten(2).transpose(1, 2)                                               # 'b c h w -> b (h w) c'
+    for i in range(depth):
+        q = f"{p}transformer_blocks.{i}."
+        ln = lambda name, z: F.layer_norm(z, z.shape[-1:], sd[q + name + ".weight"], sd[q + name + ".bias"], 1e-5)
+        t = _cross_attention(sd, q + "attn1.", ln("norm1", t), None, heads) + t
+        t = _cross_attention(sd, q + "attn2.", ln("norm2", t), context, heads) + t
+        g = F.linear(ln("norm3", t), sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"])
+        a, gate = g.chunk(2, dim=-1)
+        t = F.linear(a * F.gelu(gate), sd[q + "ff.net.2.weight"], sd[q + "ff.net.2.bias"]) + t
+    h = t.transpose(1, 2).reshape(b, -1, hh, ww)
+    return F.conv2d(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"]) + x
+
+
 class UNetSpec:
     """The UNetParams keys that shape the graph (openaimodel.py:446-473)."""
 
@@ -228,7 +263,9 @@ class UNetSpec:
                  num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
                  use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
                  context_dim=None, n_embed=None, legacy=True, condition_key="concat"):
-        assert dims == 2 and num_classes is None and not use_spatial_transformer and n_embed is None
+        assert dims == 2 and num_classes is None and n_embed is None
+        self.use_spatial_transformer = use_spatial_transformer
+        self.transformer_depth = transformer_depth
         self.image_size = image_size
         self.in_channels = in_channels
         self.model_channels = model_channels
@@ -253,6 +290,9 @@ class UNetSpec:
         """
         mc = self.model_channels
         heads_of = lambda ch, default: (default if self.num_head_channels == -1 else ch // self.num_head_channels)
+        # with use_spatial_transformer every AttentionBlock site holds a SpatialTransformer (openaimodel.py:556-565,610-618,
+        # 658-666) whose head count is ch // num_head_channels when that is set, else num_heads
+        kind_attn = "st" if self.use_spatial_transformer else "attn"
         inp: List[List[tuple]] = [[("conv",)]]
         ch, ds = mc, 1
         for level, mult in enumerate(self.channel_mult):
@@ -260,7 +300,7 @@ class UNetSpec:
                 blk = [("res", False, False)]
                 ch = mult * mc
                 if ds in self.attention_resolutions:
-                    blk.append(("attn", heads_of(ch, self.num_heads)))
+                    blk.append((kind_attn, heads_of(ch, self.num_heads)))
                 inp.append(blk)
             if level != len(self.channel_mult) - 1:
                 if self.resblock_updown:
@@ -268,7 +308,7 @@ class UNetSpec:
                 else:
                     inp.append([("down_conv",) if self.conv_resample else ("down_pool",)])
                 ds *= 2
-        mid = [("res", False, False), ("attn", heads_of(ch, self.num_heads)), ("res", False, False)]
+        mid = [("res", False, False), (kind_attn, heads_of(ch, self.num_heads)), ("res", False, False)]
         out: List[List[tuple]] = []
         for level, mult in list(enumerate(self.channel_mult))[::-1]:
             for i in range(self.num_res_blocks + 1):
@@ -277,7 +317,8 @@ class UNetSpec:
                 if ds in self.attention_resolutions:
                     # openaimodel.py:662 passes num_heads_upsample, but AttentionBlock prefers
                     # num_head_channels when it is not -1 (openaimodel.py:298-304)
-                    blk.append(("attn", heads_of(ch, self.num_heads_upsample)))
+                    blk.append((kind_attn, heads_of(ch, self.num_heads if self.use_spatial_transformer
+                                                    else self.num_heads_upsample)))
                 if level and i == self.num_res_blocks:
                     blk.append(("res", True, False) if self.resblock_updown else ("up", self.conv_resample))
                     ds //= 2
@@ -285,7 +326,7 @@ class UNetSpec:
         return inp, mid, out
 
 
-def _run_block(sd, spec: UNetSpec, prefix: str, blk, h, emb):
+def _run_block(sd, spec: UNetSpec, prefix: str, blk, h, emb, context=None):
     for j, layer in enumerate(blk):
         p = f"{prefix}{j}."
         kind = layer[0]
@@ -295,6 +336,8 @@ def _run_block(sd, spec: UNetSpec, prefix: str, blk, h, emb):
             h = resblock(sd, p, h, emb, up=layer[1], down=layer[2], scale_shift=spec.use_scale_shift_norm)
         elif kind == "attn":
             h = attention_block(sd, p, h, layer[1], spec.use_new_attention_order)
+        elif kind == "st":
+            h = spatial_transformer(sd, p, h, context, layer[1], spec.transformer_depth)
         elif kind == "down_conv":
             h = _conv(sd, p + "op", h, padding=1, stride=2)
         elif kind == "down_pool":
@@ -322,12 +365,12 @@ def unet_forward(sd: StateDict, spec: UNetSpec, x: Tensor, timesteps: Tensor,
     h = x
     hs = []
     for i, blk in enumerate(inp):
-        h = _run_block(sd, spec, f"input_blocks.{i}.", blk, h, emb)
+        h = _run_block(sd, spec, f"input_blocks.{i}.", blk, h, emb, context)
         hs.append(h)
-    h = _run_block(sd, spec, "middle_block.", mid, h, emb)
+    h = _run_block(sd, spec, "middle_block.", mid, h, emb, context)
     for i, blk in enumerate(out):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = _run_block(sd, spec, f"output_blocks.{i}.", blk, h, emb)
+        h = _run_block(sd, spec, f"output_blocks.{i}.", blk, h, emb, context)
     h = F.silu(_gn(sd, "out.0", h))
     return _conv(sd, "out.2", h, padding=1)
 

@@ -53,6 +53,12 @@ CASES = {
                         condition_key="first_stage", use_scale_shift_norm=False, resblock_updown=False),
                    dict(objective="ysubx", loss_type="l1", mt_type="linear", skip_sample=True, sample_step=10,
                         eta=0.5, max_var=0.7), 2),
+    # SpatialTransformer at every attention site (self-attention + cross-attention to the 8x8 condition image's 64 pixel
+    # tokens: 64 and 16 queries against 64 keys) + GEGLU feed-forward; openaimodel.py:556-565, attention.py:153-263
+    "tiny_xattn": (dict(image_size=8, in_channels=6, out_channels=3, model_channels=32, channel_mult=(1, 2),
+                        attention_resolutions=(1, 2), num_head_channels=16, use_spatial_transformer=True,
+                        transformer_depth=1, context_dim=3, condition_key="SpatialRescaler"),
+                   dict(objective="grad", loss_type="l1", mt_type="linear", skip_sample=True, sample_step=10), 2),
 }
 
 
@@ -67,11 +73,23 @@ def randomize(model, seed):
 
 def main():
     sys.path.insert(0, REF)
+    if "omegaconf" not in sys.modules:            # openaimodel.py:480 imports it only to unwrap a ListConfig context_dim
+        try:
+            import omegaconf  # noqa: F401
+        except ImportError:
+            import types
+            oc, lc = types.ModuleType("omegaconf"), types.ModuleType("omegaconf.listconfig")
+            lc.ListConfig = type("ListConfig", (list,), {})
+            oc.listconfig = lc
+            sys.modules["omegaconf"], sys.modules["omegaconf.listconfig"] = oc, lc
     import model.BrownianBridge.BrownianBridgeModel as M
     from model.BrownianBridge.BrownianBridgeModel import BrownianBridgeModel
 
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])                     # python oracle/make_golden.py [case ...]: regenerate only these
     for ci, (name, (unet_over, bb_over, batch)) in enumerate(CASES.items()):
+        if only and name not in only:
+            continue
         cfg = base_cfg()
         cfg["BB"]["params"].update(bb_over)
         cfg["BB"]["params"]["UNetParams"].update(unet_over)
@@ -128,6 +146,8 @@ def main():
         print(f"{name}: {nparam/1e6:.2f} M state floats, steps={n_steps}, loss={float(loss):.6f} -> {path} "
               f"({os.path.getsize(path)/1e6:.1f} MB)")
 
+    if only:
+        return
     # schedule known-answer values for both schedules at T=1000
     kat = {}
     for mt in ("linear", "sin"):

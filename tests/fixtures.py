@@ -8,6 +8,8 @@ import bbdm_oracle as O                            # oracle/
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx")
+# + SpatialTransformer / cross-attention conditioning: sampling path only (no backward yet)
+INFER_CASES = CASES + ("tiny_xattn",)
 
 
 def load_case(name):

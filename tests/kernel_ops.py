@@ -327,3 +327,31 @@ def gemm_bf3(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: i
     M = torch.empty(batch, T, cout, dtype=torch.float32, device=V.device)
     _lib.call("bbdm_gemm_bf3_f32", V.data_ptr(), pk.data_ptr(), M.data_ptr(), batch, T, cin_pad, cout, _st(V))
     return M
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """x: [rows, C] -> nn.LayerNorm(C) per row."""
+    _chk(x, gamma, beta)
+    y = torch.empty_like(x)
+    _lib.call("bbdm_layernorm_f32", x.data_ptr(), x.shape[1], gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), x.shape[1],
+              x.shape[0], x.shape[1], float(eps), _st(x))
+    return y
+
+
+def geglu(a: torch.Tensor) -> torch.Tensor:
+    """a: [rows, 2 * inner] -> a[:, :inner] * gelu(a[:, inner:])."""
+    _chk(a)
+    inner = a.shape[1] // 2
+    y = torch.empty(a.shape[0], inner, dtype=torch.float32, device=a.device)
+    _lib.call("bbdm_geglu_f32", a.data_ptr(), a.shape[1], y.data_ptr(), inner, a.shape[0], inner, _st(a))
+    return y
+
+
+def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+    """q: [N, Tq, heads*ch], k / v: [N, Tk, heads*ch] (separate contiguous tensors of equal pitch)."""
+    _chk(q, k, v)
+    N, Tq, C = q.shape
+    out = torch.empty_like(q)
+    _lib.call("bbdm_cross_attention_f32", q.data_ptr(), C, k.data_ptr(), v.data_ptr(), C, out.data_ptr(), C, N, Tq,
+              k.shape[1], heads, C // heads, _st(q))
+    return out

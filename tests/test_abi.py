@@ -54,8 +54,8 @@ def test_product_path_has_no_cpu_fallback():
 def test_state_dict_layout_matches_reference_fixture():
     """Same keys / shapes as the reference state_dict recorded in the golden fixture (SURVEY.md §5 checkpoint row)."""
     import bbdm_amd
-    from fixtures import CASES, load_case
-    for name in CASES:
+    from fixtures import INFER_CASES, load_case
+    for name in INFER_CASES:
         rec = load_case(name)
         up = rec["unet_params"]
         m = bbdm_amd.BrownianBridgeModel(_ns({"BB": {"params": dict(rec["bb_params"], UNetParams=up)}}))

@@ -75,6 +75,16 @@ def test_attention(N, T, heads, ch, new_order):
     K.test_attention(CPU, N, T, heads, ch, new_order)
 
 
+@pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(2, 64, 64, 2, 16), (1, 16, 64, 4, 16), (2, 100, 37, 3, 32)])
+def test_cross_attention(N, Tq, Tk, heads, ch):
+    K.test_cross_attention(CPU, N, Tq, Tk, heads, ch)
+
+
+@pytest.mark.parametrize("rows,C", [(7, 64), (130, 32), (3, 260)])
+def test_layernorm_and_geglu(rows, C):
+    K.test_layernorm_and_geglu(CPU, rows, C)
+
+
 def test_attention_forces_rescale():
     K.test_attention_forces_rescale(CPU)
 

@@ -24,7 +24,7 @@ def _build(rec, train=False):
     return m.train() if train else m.eval()
 
 
-@pytest.mark.parametrize("name", ["tiny_concat", "tiny_ysubx"])
+@pytest.mark.parametrize("name", ["tiny_concat", "tiny_ysubx", "tiny_xattn"])
 def test_unet_forward_and_p_sample_match_reference_golden(name):
     rec = load_case(name)
     m = _build(rec)

@@ -372,6 +372,37 @@ def test_attention(dev, N, T, heads, ch, new_order):
     assert rel_err(out.cpu().permute(0, 2, 1), ref) < TOL
 
 
+@pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(2, 64, 64, 2, 16), (1, 16, 64, 4, 16), (2, 100, 37, 3, 32), (1, 256, 1024, 2, 64)])
+def test_cross_attention(dev, N, Tq, Tk, heads, ch):
+    """CrossAttention.forward (attention.py:170-194) with its own key / value source (Tk != Tq)."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(Tq + Tk)
+    C = heads * ch
+    q, k, v = (torch.randn(N, T, C, generator=g) for T in (Tq, Tk, Tk))
+    sp = lambda t: t.reshape(N, t.shape[1], heads, ch).permute(0, 2, 1, 3).double()
+    sim = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * ch ** -0.5
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(N, Tq, C)
+    out = ops.cross_attention(q.to(dev), k.to(dev), v.to(dev), heads)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("rows,C", [(7, 64), (130, 32), (64, 1024), (3, 260)])
+def test_layernorm_and_geglu(dev, rows, C):
+    """nn.LayerNorm over the token's channels and GEGLU (attention.py:38-46,204-206)."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g) * 3 + 0.7
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    y = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5)
+    a = torch.randn(rows, 2 * C, generator=g) * 2
+    z = ops.geglu(a.to(dev))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu(), F.layer_norm(x.double(), (C,), gamma.double(), beta.double(), 1e-5)) < TOL
+    xa, gate = a.double().chunk(2, dim=-1)
+    assert rel_err(z.cpu(), xa * F.gelu(gate)) < TOL
+
+
 def test_attention_forces_rescale(dev):
     """A key whose score dwarfs all earlier ones appears late: the online-softmax rescale branch must be exact."""
     import kernel_ops as ops

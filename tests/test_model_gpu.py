@@ -7,7 +7,7 @@ import argparse
 import pytest
 import torch
 
-from fixtures import CASES, load_case, oracle_model, rel_err
+from fixtures import INFER_CASES as CASES, load_case, oracle_model, rel_err
 
 pytestmark = pytest.mark.gpu
 STEP_TOL = 1e-4

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import bbdm_oracle as O
-from fixtures import CASES, GOLDEN, load_case, oracle_model, rel_err
+from fixtures import INFER_CASES as CASES, GOLDEN, load_case, oracle_model, rel_err
 
 TOL = 2e-5      # oracle and reference run the same ATen ops on CPU; only op grouping differs
 
