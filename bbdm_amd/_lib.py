@@ -61,6 +61,11 @@ SIGNATURES = {
                                           _P, _P, c_int, c_int, _P]),
     "bbdm_bb_predict_x0_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "bbdm_bb_loss_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+    "bbdm_gemm_packed_b_floats": (c_size_t, [c_int, c_int]),
+    "bbdm_gemm_pack_b_f32": (c_int, [_P, c_int, c_size_t, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_gemm_batched_f32": (c_int, [_P, c_int, c_size_t, _P, _P, c_int, c_size_t, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_softmax_rows_f32": (c_int, [_P, c_int, ctypes.c_longlong, c_int, c_float, _P]),
+    "bbdm_vq_nearest_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_cross_attention_f32": (c_int, [_P, c_int, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_layernorm_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, ctypes.c_longlong, c_int, c_float, _P]),
     "bbdm_geglu_f32": (c_int, [_P, c_int, _P, c_int, ctypes.c_longlong, c_int, _P]),

@@ -648,6 +648,26 @@ extern "C" int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int
     return BBDM_OK;
 }
 
+// Batched activation-by-activation GEMM (VQGAN AttnBlock, model/VQGAN/model.py:166-185: w_ = bmm(q, k), h_ = bmm(v, w_)): the
+// B operand of batch element b is a ROW-MAJOR activation matrix Bm_b [R x K] (transposed == 0: out = A Bm^T, e.g. q k^T) or
+// [K x R] (transposed != 0: out = A Bm, e.g. softmax(w) v), packed into the kernel's weight layout by this kernel.
+__global__ void pack_activation_kernel(const float* __restrict__ src, size_t sz, int lds_, float* __restrict__ p, size_t pz, int R,
+                                       int K, int RPad, int nchunks, int transposed) {
+    const size_t per = (size_t)nchunks * RPad * KC;
+    const float* s = src + (size_t)blockIdx.y * sz;
+    float* d = p + (size_t)blockIdx.y * pz;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < per; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = i % KC;
+        size_t t = i / KC;
+        const int r = t % RPad;
+        const int chunk = t / RPad;
+        const int kk = chunk * KC + k;
+        float v = 0.0f;
+        if (r < R && kk < K) v = transposed ? s[(size_t)kk * lds_ + r] : s[(size_t)r * lds_ + kk];
+        d[i] = v;
+    }
+}
+
 // Tile / split-K choice.  The 256x128 tile (8 waves, 2 blocks per CU) is the efficient one; it needs >= 512 blocks to
 // fill the chip, so problems with fewer output tiles get the Cin reduction split over 2..32 extra workgroups each
 // (partials summed in a fixed order by conv_splitk_reduce_kernel).
@@ -759,5 +779,36 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
     }
     if (rc < 0) return rc;
     BBDM_CHECK_LAUNCH("conv2d");
+    return BBDM_OK;
+}
+
+// ---- batched GEMM with activation operands (see pack_activation_kernel) ------------------------------------------------
+extern "C" size_t bbdm_gemm_packed_b_floats(int R, int K) { return (size_t)cdiv(K, KC) * (cdiv(R, 128) * 128) * KC; }
+
+extern "C" int bbdm_gemm_pack_b_f32(const float* b, int ldb, size_t b_stride, float* packed, int batch, int R, int K,
+                                    int transposed, void* stream) {
+    BBDM_REQUIRE(b && packed && batch > 0 && R > 0 && K > 0 && ldb >= (transposed ? R : K), "gemm_pack_b: bad args");
+    const size_t per = bbdm_gemm_packed_b_floats(R, K);
+    unsigned blocks = (unsigned)((per + 255) / 256 > 2048 ? 2048 : (per + 255) / 256);
+    hipLaunchKernelGGL(pack_activation_kernel, dim3(blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream, b, b_stride, ldb,
+                       packed, per, R, K, cdiv(R, 128) * 128, cdiv(K, KC), transposed);
+    BBDM_CHECK_LAUNCH("gemm_pack_b");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_gemm_batched_f32(const float* a, int lda, size_t a_stride, const float* packed_b, float* out, int ldo,
+                                     size_t out_stride, int batch, int rows, int K, int R, void* stream) {
+    // out_b [rows x R] = A_b [rows x K] . B_b   (B_b as packed by bbdm_gemm_pack_b_f32); K % 4 == 0
+    BBDM_REQUIRE(a && packed_b && out && batch > 0 && rows > 0 && K > 0 && R > 0, "gemm_batched: bad args");
+    BBDM_REQUIRE(K % 4 == 0 && lda % 4 == 0 && lda >= K && ldo >= R && a_stride % 4 == 0 && ((uintptr_t)a & 15) == 0,
+                 "gemm_batched: K=%d lda=%d ldo=%d must be multiples of 4 / aligned", K, lda, ldo);
+    BBDM_REQUIRE((size_t)rows * (size_t)lda < (1ull << 32), "gemm_batched: one A matrix exceeds 2^32 elements");
+    // rows are laid out as an image of width 32 when possible (whole 8x32 spatial tiles), else as one column
+    int H = rows, W = 1;
+    if (rows % 32 == 0) { H = rows / 32; W = 32; }
+    int rc = bbdm_conv1x1_batched(a, lda, a_stride, packed_b, bbdm_gemm_packed_b_floats(R, K), out, ldo, out_stride, batch, H, W, K,
+                                  R, (hipStream_t)stream);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("gemm_batched");
     return BBDM_OK;
 }

@@ -135,7 +135,7 @@ __device__ __forceinline__ float4 gn_xform(const ApplyArgs& a, float4 v, float4 
 __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
     const int n = blockIdx.y;
     const int C4 = a.C >> 2;
-    const bool halve = a.resample == 1 || a.resample == 3;
+    const bool halve = a.resample == 1 || a.resample == 3 || a.resample == 4;
     const int Hu = halve ? a.H >> 1 : a.H;
     const int Wu = halve ? a.W >> 1 : a.W;
     const long long units = (long long)Hu * Wu * C4;
@@ -181,9 +181,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
         if (a.resample == 0) {
             const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)pu * a.ldx + c);
             *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = gn_xform(a, v, sc, bi);
-        } else if (a.resample == 3) {
-            const int ho = pu / Wu, wo = pu - ho * Wu;
-            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)(2 * ho) * a.W + 2 * wo) * a.ldx + c);
+        } else if (a.resample == 3 || a.resample == 4) {     // keep the even (3) / odd (4) positions of both axes
+            const int ho = pu / Wu, wo = pu - ho * Wu, o = a.resample == 4 ? 1 : 0;
+            const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)(2 * ho + o) * a.W + 2 * wo + o) * a.ldx + c);
             *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = gn_xform(a, v, sc, bi);
         } else if (a.resample == 1) {
             const int ho = pu / Wu, wo = pu - ho * Wu;
@@ -296,8 +296,8 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     const int norm = gamma != nullptr;
     BBDM_REQUIRE(!norm || (stats && beta), "gn_apply: gamma given without stats/beta");
     BBDM_REQUIRE(norm || !film, "gn_apply: film without norm");
-    BBDM_REQUIRE(resample >= 0 && resample <= 3, "gn_apply: resample=%d", resample);
-    BBDM_REQUIRE((resample != 1 && resample != 3) || (H % 2 == 0 && W % 2 == 0), "gn_apply: down-sampling needs even H, W");
+    BBDM_REQUIRE(resample >= 0 && resample <= 4, "gn_apply: resample=%d", resample);
+    BBDM_REQUIRE((resample != 1 && resample < 3) || (H % 2 == 0 && W % 2 == 0), "gn_apply: down-sampling needs even H, W");
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldx >= C && ldy >= C,
                  "gn_apply: bad shape / pitch");
     BBDM_REQUIRE(!norm || (G > 0 && C % G == 0), "gn_apply: C %% G != 0");
@@ -307,7 +307,7 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.y = y;
     a.ldx = ldx; a.ldy = ldy; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample; a.norm = norm;
-    const long long units = (long long)((resample == 1 || resample == 3) ? (H / 2) * (W / 2) : H * W) * (C / 4);
+    const long long units = (long long)((resample == 1 || resample >= 3) ? (H / 2) * (W / 2) : H * W) * (C / 4);
     long long blocks = (units + 255) / 256;
     const long long cap = cdiv(8192, N) > 1 ? cdiv(8192, N) : 1;
     if (blocks > cap) blocks = cap;

@@ -236,7 +236,7 @@ class VQModel(nn.Module):
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
         # GAN / perceptual-loss weights of a VQGAN training checkpoint are not part of the frozen first stage
         sd = {k: v for k, v in sd.items() if not k.startswith("loss.")}
-        self.load_state_dict(sd, strict=False)
+        self.load_state_dict(sd, strict=True)        # a half-loaded first stage would sample garbage silently
         print(f"Restored from {path}")
 
     def encode(self, x):

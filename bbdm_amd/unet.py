@@ -602,9 +602,9 @@ class _Plan:
 
     SAVED_ROLES = ("A", "H1", "A2", "XR", "QKV", "AT")     # activations the backward pass re-reads
 
-    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int, training: bool = False):
-        self.m, self.N, self.H, self.W, self.device, self.cx = m, N, H, W, device, cx
-        self.training = training
+    def _init_state(self, m, N: int, device, training: bool):
+        """Emitter state shared by every plan built on these kernels (the UNet's, and bbdm_amd/first_stage_hip.py's)."""
+        self.m, self.N, self.device, self.training = m, N, device, training
         self.tape: List[tuple] = []         # training: one record per layer, replayed in reverse by _emit_backward
         self.bops: List[tuple] = []         # training: backward op list
         self.ops: List[tuple] = []          # (fn_name, args with unresolved refs)
@@ -622,6 +622,28 @@ class _Plan:
         self._conv_ws_floats = _LateInt()
         self._wino_v, self._wino_m = _LateTensor(), _LateTensor()      # Winograd V / M planes shared by every layer
         self._wino_v_need = self._wino_m_need = 0
+        self.film, self.film_total, self.resblocks, self._film_key = None, 0, [], None
+
+    def _allocate(self):
+        f32 = dict(dtype=torch.float32, device=self.device)
+        for pair in self._coeff_bufs:
+            for lt in pair:
+                lt.t = torch.empty(self._coeff_need, **f32)
+        self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
+        self._conv_ws_floats.v = self._conv_ws_need
+        self._wino_v.t = torch.empty(max(1, self._wino_v_need), **f32)
+        self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
+        for b in self.bufs:
+            b.tensor = torch.empty(max(1, b.numel), **f32)
+        self.stats = torch.zeros(max(1, self._gn_count) * self.N * self.GROUPS * 2, dtype=torch.float64, device=self.device)
+        self._param_key = None
+        self._bound: List[tuple] = []
+        self._graph, self._graph_key = None, None
+        self.op_flops = [self._algorithmic_flops(name, args) for name, args in self.ops]
+
+    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int, training: bool = False):
+        self._init_state(m, N, device, training)
+        self.H, self.W, self.cx = H, W, cx
         mc = m.model_channels
         ted = 4 * mc
         f32 = dict(dtype=torch.float32, device=device)
@@ -723,21 +745,7 @@ class _Plan:
             self.tape.append(("head", m.out, h, a, head_stats))
             self._emit_backward(x0)
 
-        # ---- allocate -----------------------------------------------------------------------------------------------
-        for pair in self._coeff_bufs:
-            for lt in pair:
-                lt.t = torch.empty(self._coeff_need, **f32)
-        self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
-        self._conv_ws_floats.v = self._conv_ws_need
-        self._wino_v.t = torch.empty(max(1, self._wino_v_need), **f32)
-        self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
-        for b in self.bufs:
-            b.tensor = torch.empty(max(1, b.numel), **f32)
-        self.stats = torch.zeros(max(1, self._gn_count) * N * self.GROUPS * 2, dtype=torch.float64, device=device)
-        self._param_key = None
-        self._bound: List[tuple] = []
-        self._graph, self._graph_key = None, None
-        self.op_flops = [self._algorithmic_flops(name, args) for name, args in self.ops]
+        self._allocate()
 
     @staticmethod
     def _algorithmic_flops(name, args):

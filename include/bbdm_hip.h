@@ -146,8 +146,9 @@ int bbdm_groupnorm_coeffs_f32(const double* stats, const float* gamma, const flo
  *   GroupNorm32 -> [FiLM: openaimodel.py:270-273] -> SiLU -> [avg-pool 2x2 :159 | nearest x2 :118].
  * stats: as produced above (may be NULL with gamma == NULL: pure resample of x, the x_upd path :263).
  * film: [N][film_ld] with scale at [n][c] and shift at [n][C + c] (the emb_layers output :267-272), or NULL.
- * silu: 0/1.  resample: 0 none, 1 avg-pool 2x2 (H, W even), 2 nearest x2, 3 keep every second pixel (turns a stride-1
- * conv output into the stride-2 conv of Downsample(use_conv=True), openaimodel.py:153-156).  H, W are INPUT dims. */
+ * silu: 0/1.  resample: 0 none, 1 avg-pool 2x2 (H, W even), 2 nearest x2, 3 keep the even positions (turns a stride-1
+ * conv output into the stride-2, pad-1 conv of Downsample(use_conv=True), openaimodel.py:153-156), 4 keep the odd positions
+ * (the stride-2 conv on a (0,1,0,1)-padded input of the VQGAN's Downsample, model/VQGAN/model.py:68-72).  H, W are INPUT dims. */
 int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
                              const float* film, int film_ld, float* y, int ldy, int N, int H, int W, int C, int G,
                              float eps, int silu, int resample, void* stream);
@@ -228,6 +229,25 @@ int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const f
                            float* dx, int lddx, int accumulate, float* dgamma, float* dbeta, float* dfilm,
                            int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
                            int resample, void* stream);
+
+/* ---- VQGAN first stage: the ops model/VQGAN/model.py + quantize.py need beyond the UNet's --------- */
+/* Batched GEMM with ACTIVATION operands (AttnBlock's bmm(q, k) and bmm(v, w_), model.py:166-185, one head over all channels):
+ * bbdm_gemm_pack_b_f32 packs, per batch element, a row-major matrix [R x K] (transposed = 0; out = A B^T) or [K x R]
+ * (transposed != 0; out = A B) into the matrix-core kernel's operand layout (bbdm_gemm_packed_b_floats floats each);
+ * bbdm_gemm_batched_f32 then computes out_b [rows x R] = A_b [rows x K] . B_b on v_mfma_f32_32x32x2_f32. */
+size_t bbdm_gemm_packed_b_floats(int R, int K);
+int bbdm_gemm_pack_b_f32(const float* b, int ldb, size_t b_stride, float* packed, int batch, int R, int K, int transposed,
+                         void* stream);
+int bbdm_gemm_batched_f32(const float* a, int lda, size_t a_stride, const float* packed_b, float* out, int ldo,
+                          size_t out_stride, int batch, int rows, int K, int R, void* stream);
+/* In-place softmax(scale * s) over each row of s [rows][T] (pitch ld): w_ = softmax(w_ * c^-0.5, dim=2), model.py:175-176. */
+int bbdm_softmax_rows_f32(float* s, int ld, long long rows, int T, float scale, void* stream);
+/* VectorQuantizer2.forward (quantize.py:271-286): per latent pixel z [e_dim] the index of the nearest codebook row under
+ * d = sum(z^2) + sum(e^2) - 2 z.e (fp32, the reference's term order; first minimum wins) and/or that row itself.
+ * z: [pixels][ldz] (NHWC latent), codebook: [n_e][e_dim] (embedding.weight), indices: int64 [pixels] or NULL,
+ * zq: [pixels][ldq] or NULL.  e_dim <= 8. */
+int bbdm_vq_nearest_f32(const float* z, int ldz, const float* codebook, long long* indices, float* zq, int ldq,
+                        long long pixels, int n_e, int e_dim, void* stream);
 
 /* ---- SpatialTransformer / cross-attention conditioning (attention.py = model/BrownianBridge/base/
  *      modules/attention.py) -------------------------------------------------------------------------------------------- */

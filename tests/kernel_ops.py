@@ -355,3 +355,14 @@ def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: in
     _lib.call("bbdm_cross_attention_f32", q.data_ptr(), C, k.data_ptr(), v.data_ptr(), C, out.data_ptr(), C, N, Tq,
               k.shape[1], heads, C // heads, _st(q))
     return out
+
+
+def vq_nearest(z: torch.Tensor, codebook: torch.Tensor):
+    """z: [pixels, e_dim], codebook: [n_e, e_dim] -> (int64 indices [pixels], nearest rows [pixels, e_dim])."""
+    _chk(z, codebook)
+    P, D = z.shape
+    idx = torch.empty(P, dtype=torch.int64, device=z.device)
+    zq = torch.empty(P, D, dtype=torch.float32, device=z.device)
+    _lib.call("bbdm_vq_nearest_f32", z.data_ptr(), D, codebook.data_ptr(), idx.data_ptr(), zq.data_ptr(), D, P,
+              codebook.shape[0], D, _st(z))
+    return idx, zq
