@@ -73,6 +73,7 @@ SIGNATURES = {
     "bbdm_gemm_bf3_pack_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "bbdm_gemm_bf3_supported": (c_int, [ctypes.c_longlong, c_int, c_int]),
     "bbdm_gemm_bf3_f32": (c_int, [_P, _P, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
+    "bbdm_conv1x1_bf3_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_winograd_gemm_bf3_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_images_to_u8_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_opt_chunk_elems": (c_int, []),

@@ -22,6 +22,7 @@
 //    slots of the 256-B bank window.
 //  * Lane l supplies row (l & 31) and the 8 consecutive k of half (l >> 5) for A and for B alike (the sum over k does not
 //    depend on which k a lane carries as long as A and B agree); C/D layout = the f32 32x32 layout (cdna_hip_programming.md).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -39,6 +40,9 @@ struct Bf3Args {
     float* M;                // [batch][T][Cout] fp32
     size_t vz, uz, mz;       // per-batch strides (elements of the respective type)
     int T, Cin, Cout, CoutPad, nchunks, tilesN;
+    int lda, ldo, ldr;       // row pitches of V, M and the residual (floats)
+    const float* bias;       // [Cout] or null
+    const float* res;        // [T][ldr] or null; may alias M
 };
 
 __device__ __forceinline__ float bf16_round(float x) {       // x rounded to bf16 (RNE), returned as fp32
@@ -79,6 +83,10 @@ __device__ __forceinline__ int xcd_block(int nblk, int x, int off) {
     return start + ((x - ((c - off) & 7)) >> 3);
 }
 
+// DEPTH = how many K-chunks ahead the fp32 A tile is requested from HBM (register ring); the split weights (L2-resident) stay
+// one chunk ahead.  RES: add a residual row in the epilogue (compile-time: a run-time branch per store would serialise the
+// stores behind vmcnt(0), see conv_igemm.hip).
+template <int DEPTH, bool RES>
 __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -99,7 +107,7 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int f = tid + s * NTHR, row = f >> 2, q = f & 3;
-        asrc[s] = V + (size_t)(row0 + row) * a.Cin + q * 4;
+        asrc[s] = V + (size_t)(row0 + row) * a.lda + q * 4;
         adst[s] = swz(row, q * 8);
     }
     // W: per plane 128 rows x 32 B = 512 units of 8 B: thread owns unit tid of each of the 3 planes
@@ -124,20 +132,22 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 areg[2];
+    float4 areg[DEPTH][2];
     uint2 wreg[3];
-    auto load = [&](int chunk) {
+    auto load_a = [&](float4 (&dst)[2], int chunk) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) areg[s] = *reinterpret_cast<const float4*>(asrc[s] + chunk * KC);
+        for (int s = 0; s < 2; ++s) dst[s] = *reinterpret_cast<const float4*>(asrc[s] + chunk * KC);
+    };
+    auto load_w = [&](int chunk) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             wreg[p] = *reinterpret_cast<const uint2*>(wsrc + (size_t)(chunk * 3 + p) * wplane);
     };
-    auto store = [&](unsigned char* st) {
+    auto store = [&](const float4 (&src)[2], unsigned char* st) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint2 p1, p2, p3;
-            split4(areg[s], p1, p2, p3);
+            split4(src[s], p1, p2, p3);
             *reinterpret_cast<uint2*>(st + adst[s]) = p1;
             *reinterpret_cast<uint2*>(st + A_PLANE + adst[s]) = p2;
             *reinterpret_cast<uint2*>(st + 2 * A_PLANE + adst[s]) = p3;
@@ -145,49 +155,89 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(st + 3 * A_PLANE + p * W_PLANE + wdst) = wreg[p];
     };
-
-    load(0);
-    store(smem);
-    __syncthreads();
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const bool more = chunk + 1 < a.nchunks;
-        if (more) load(chunk + 1);
-        const unsigned char* st = smem + (chunk & 1) * STAGE;
-        bf16x8 af[2][3], bf[2][3];
+    auto mfma_chunk = [&](const unsigned char* st) {
+        bf16x8 bf[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                af[t][p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE + aoff[t]);
-                bf[t][p] = *reinterpret_cast<const bf16x8*>(st + p * W_PLANE + boff[t]);
-            }
+            for (int p = 0; p < 3; ++p) bf[t][p] = *reinterpret_cast<const bf16x8*>(st + p * W_PLANE + boff[t]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE + aoff[i]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // smallest terms first: they meet an accumulator that has not yet grown by this chunk's leading term
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], acc[i][j], 0, 0, 0);
             }
-        if (more) store(smem + ((chunk + 1) & 1) * STAGE);
+        }
+    };
+    const int n = a.nchunks;
+    // chunk c is computed from LDS stage c & 1; while it is, the A tile of chunk c + DEPTH is in flight, the tile of chunk
+    // c + 1 (requested DEPTH - 1 phases ago) is split and stored into the other stage
+    auto phase = [&](int c, float4 (&cur)[2], float4 (&nxt)[2]) {
+        if (c + 1 < n) load_w(c + 1);
+        if (c + DEPTH < n) load_a(nxt, c + DEPTH);
+        mfma_chunk(smem + (c & 1) * STAGE);
+        if (c + 1 < n) store(cur, smem + ((c + 1) & 1) * STAGE);
         __syncthreads();
+    };
+    load_a(areg[0], 0);
+    load_w(0);
+    store(areg[0], smem);
+    __syncthreads();
+    if constexpr (DEPTH == 1) {
+        for (int c = 0; c < n; ++c) phase(c, areg[0], areg[0]);      // cur == nxt: loaded before, stored after the MFMAs
+    } else {
+        if (1 < n) load_a(areg[0], 1);
+        for (int c = 0; c < n; c += 2) {
+            phase(c, areg[0], areg[1]);
+            if (c + 1 < n) phase(c + 1, areg[1], areg[0]);
+        }
     }
 
-    // ---- epilogue: 32 lanes x 4 B = one 128-B line per store instruction -----------------------------------------------------
+    // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            float* dst = M + (size_t)row * a.Cout;
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float rv[8][2];
+            if (RES) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                if (co < a.Cout) dst[co] = acc[i][j][r];
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = r0 + rr;
+                    const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                        rv[rr][j] = co < a.Cout ? a.res[(size_t)row * a.ldr + co] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + rr;
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* dst = M + (size_t)row * a.ldo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                    float v = acc[i][j][r] + bv[j];
+                    if (RES) v += rv[rr][j];
+                    if (co < a.Cout) dst[co] = v;
+                }
             }
         }
 }
@@ -236,6 +286,43 @@ extern "C" int bbdm_gemm_bf3_supported(long long T, int CinPad, int Cout) {
            (size_t)T * (size_t)CinPad < (1ull << 32);
 }
 
+static int bf3_depth() {
+    static const int d = []() { const char* e = getenv("BBDM_BF3_DEPTH"); return (e && e[0] == '1') ? 1 : 2; }();
+    return d;
+}
+
+template <int DEPTH, bool RES>
+static int bf3_launch(const Bf3Args& a, long long blocks, int batch, hipStream_t st) {
+    static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[bbdm_device_slot()];
+    const size_t lds = 2 * STAGE;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<DEPTH, RES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            bbdm_set_error("gemm_bf3: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf3_kernel<DEPTH, RES>), dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, st, a);
+    return BBDM_OK;
+}
+
+static int bf3_run(Bf3Args& a, int batch, hipStream_t st) {
+    a.CoutPad = cdiv(a.Cout, 128) * 128;
+    a.nchunks = a.Cin / KC;
+    a.tilesN = a.CoutPad / BN;
+    a.uz = (size_t)a.nchunks * 3 * a.CoutPad * KC;
+    const long long blocks = ((long long)a.T / BM) * a.tilesN;
+    BBDM_REQUIRE(blocks < (1ll << 31), "gemm_bf3: too many tiles");
+    int rc;
+    if (bf3_depth() == 1) rc = a.res ? bf3_launch<1, true>(a, blocks, batch, st) : bf3_launch<1, false>(a, blocks, batch, st);
+    else rc = a.res ? bf3_launch<2, true>(a, blocks, batch, st) : bf3_launch<2, false>(a, blocks, batch, st);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("gemm_bf3");
+    return BBDM_OK;
+}
+
 extern "C" int bbdm_gemm_bf3_f32(const float* V, const void* packed_bf3, float* M, int batch, long long T, int CinPad, int Cout,
                                  void* stream) {
     BBDM_REQUIRE(V && packed_bf3 && M && batch > 0, "gemm_bf3: null pointer / bad batch");
@@ -244,23 +331,28 @@ extern "C" int bbdm_gemm_bf3_f32(const float* V, const void* packed_bf3, float* 
     BBDM_REQUIRE((((uintptr_t)V | (uintptr_t)M | (uintptr_t)packed_bf3) & 15) == 0, "gemm_bf3: 16-byte alignment");
     Bf3Args a;
     a.V = V; a.U = (const unsigned short*)packed_bf3; a.M = M;
-    a.T = (int)T; a.Cin = CinPad; a.Cout = Cout; a.CoutPad = cdiv(Cout, 128) * 128;
-    a.nchunks = CinPad / KC; a.tilesN = a.CoutPad / BN;
-    a.vz = (size_t)T * CinPad; a.uz = (size_t)a.nchunks * 3 * a.CoutPad * KC; a.mz = (size_t)T * Cout;
-    const long long blocks = (T / BM) * a.tilesN;
-    BBDM_REQUIRE(blocks < (1ll << 31), "gemm_bf3: too many tiles");
-    static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
-    bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = 2 * STAGE;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            bbdm_set_error("gemm_bf3: hipFuncSetAttribute(%zu B LDS) failed", lds);
-            return BBDM_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_bf3_kernel, dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, (hipStream_t)stream, a);
-    BBDM_CHECK_LAUNCH("gemm_bf3");
-    return BBDM_OK;
+    a.T = (int)T; a.Cin = CinPad; a.Cout = Cout;
+    a.lda = CinPad; a.ldo = Cout; a.ldr = 0; a.bias = nullptr; a.res = nullptr;
+    a.vz = (size_t)T * CinPad; a.mz = (size_t)T * Cout;
+    return bf3_run(a, batch, (hipStream_t)stream);
+}
+
+// 1x1 convolution / Linear on NHWC activations = one GEMM [pixels x CinPad] . [CinPad x Cout] + bias (+ residual), with the
+// operand pitches of channel slices (the UNet's skip 1x1 convs, qkv / proj_out, the SpatialTransformer's Linears).
+// packed_bf3: bbdm_gemm_bf3_pack_f32(batch = 1) of the buffer bbdm_conv_pack_weight_f32(ks = 1) filled.
+extern "C" int bbdm_conv1x1_bf3_f32(const float* x, int ldx, const void* packed_bf3, const float* bias, const float* residual,
+                                    int ldr, float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream) {
+    BBDM_REQUIRE(x && packed_bf3 && out, "conv1x1_bf3: null pointer");
+    BBDM_REQUIRE(bbdm_gemm_bf3_supported(pixels, CinPad, Cout), "conv1x1_bf3: pixels=%lld CinPad=%d Cout=%d unsupported", pixels,
+                 CinPad, Cout);
+    BBDM_REQUIRE(ldx % 4 == 0 && ldx >= CinPad && ldo >= Cout && (!residual || ldr >= Cout) &&
+                     (((uintptr_t)x | (uintptr_t)packed_bf3) & 15) == 0,
+                 "conv1x1_bf3: bad pitch / alignment");
+    BBDM_REQUIRE((size_t)pixels * (size_t)ldx < (1ull << 32), "conv1x1_bf3: input exceeds 2^32 elements");
+    Bf3Args a;
+    a.V = x; a.U = (const unsigned short*)packed_bf3; a.M = out;
+    a.T = (int)pixels; a.Cin = CinPad; a.Cout = Cout;
+    a.lda = ldx; a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    a.vz = 0; a.mz = 0;
+    return bf3_run(a, 1, (hipStream_t)stream);
 }

@@ -310,6 +310,30 @@ class _PackedConv:
             self.key = key
 
 
+class _PackedConvBf3(_PackedConv):
+    """A 1x1 conv / Linear weight split into the three bf16 planes of csrc/gemm_bf3.hip (``packed``); the fp32 packing is
+    kept as the intermediate."""
+
+    def __init__(self, weight, bias, cin_pad):
+        super().__init__(weight, bias, cin_pad)
+        self.packed_f32 = self.packed
+        nh = _lib.load().bbdm_gemm_bf3_packed_halfs(1, cin_pad, self.cout)
+        self.packed = torch.empty(nh, dtype=torch.int16, device=weight.device)
+        self.packed.cin_true = self.cin
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
+                      self.cin_pad, 1, stream)
+            _lib.call("bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), 1, self.cin_pad, self.cout,
+                      stream)
+            self.key = key
+
+
 class _PackedDgrad:
     """Packed transposed + flipped copy of a conv weight: the forward kernel run with it computes the data gradient."""
 
@@ -750,6 +774,10 @@ class _Plan:
     @staticmethod
     def _algorithmic_flops(name, args):
         """2*MACs of the contraction an op performs (conv / linear / attention matmuls only)."""
+        if name == "bbdm_conv1x1_bf3_f32":
+            pixels, cin_pad, cout = args[8:11]
+            cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
+            return 2.0 * pixels * cout * cin
         if name == "bbdm_conv2d_nhwc_f32":
             N, H, W, cin_pad, cout, ks = args[15:21]
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
@@ -902,6 +930,18 @@ class _Plan:
             self._emit_winograd(x, x.C, pw, pre, upsample, H, W, residual, res_ld, dest, flags)
             return
         assert not upsample
+        ks = mod.weight.shape[2] if mod.weight.dim() == 4 else 1
+        pixels = self.N * x.H * x.W
+        if (ks == 1 and self.m.gemm_bf3 and not pre and flags == 0 and not self.training
+                and self.lib.bbdm_gemm_bf3_supported(pixels, x.C, cout)
+                and (pixels // 256) * -(-cout // 128) >= 256):
+            # wide 1x1 convolutions / Linears (skip connections, qkv / proj_out, transformer projections): the fp32-accurate
+            # bf16x3 GEMM with bias + residual in its epilogue (csrc/gemm_bf3.hip); small problems keep the split-K f32 kernel
+            pb = _PackedConvBf3(mod.weight, mod.bias, x.C)
+            self.convs.append(pb)
+            self._op("bbdm_conv1x1_bf3_f32", x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
+                     residual, res_ld, dest, dest.ld, pixels, x.C, cout)
+            return
         pc = self._conv(mod, x.C)
         self._conv_ws_need = max(self._conv_ws_need,
                                  self.lib.bbdm_conv_splitk_workspace_floats(self.N, x.H, x.W, x.C, pc.cout, pc.ks))

@@ -328,7 +328,9 @@ def main():
             for k in sorted(agg):
                 name, ms, fl = agg[k]
                 oargs = plan.ops[k][1]
-                if name == "bbdm_conv2d_nhwc_f32":
+                if name == "bbdm_conv1x1_bf3_f32":
+                    shp = "pixels{} {}->{} k1 (bf16x3)".format(*oargs[8:11])
+                elif name == "bbdm_conv2d_nhwc_f32":
                     shp = "N{} {}x{} {}->{} k{}".format(*oargs[15:21])
                 elif name == "bbdm_winograd_gemm_f32":
                     shp = "N{} {}x{} {}->{} F({m}x{m},3x3) {p} GEMMs".format(*oargs[4:9], m=oargs[0], p=(oargs[0] + 2) ** 2)
@@ -379,9 +381,10 @@ def main():
     avg_launch_ms = conv_ms / max(1, conv_launches)
     achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
     # whole step against the matrix peaks: time-at-peak of every MFMA kernel's work / step time
-    f32_flops = (executed_flops_per_step - (wino[2] / max(1, args.steps) if use_bf3 else 0.0))
-    t_at_peak = f32_flops / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
-        ((wino[2] / max(1, args.steps)) / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12) if use_bf3 else 0.0)
+    c1x1 = by.get("bbdm_conv1x1_bf3_f32", [0, 0.0, 0.0])            # wide 1x1 convs / Linears on the same bf16x3 kernel
+    bf3_flops = ((wino[2] if use_bf3 else 0.0) + c1x1[2]) / max(1, args.steps)
+    t_at_peak = (executed_flops_per_step - bf3_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
+        bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12)
     # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
     # rocprofv3 PMC passes of this same command (profiles/*_pmc_<workload>_traffic.json), per launch, or null.
     traffic = None
@@ -452,6 +455,7 @@ def main():
                          "winograd_gemm_launches_per_step": wino[0] / max(1, args.steps),
                          "winograd_gemm_tflops": (wino[2] / (wino[1] * 1e-3) / 1e12) if wino[1] > 0 else None,
                          "direct_conv_tflops": (direct[2] / (direct[1] * 1e-3) / 1e12) if direct[1] > 0 else None,
+                         "conv1x1_bf3_tflops": (c1x1[2] / (c1x1[1] * 1e-3) / 1e12) if c1x1[1] > 0 else None,
                          "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
         }

@@ -280,6 +280,11 @@ int bbdm_gemm_bf3_pack_f32(const float* packed_f32, void* packed_bf3, int batch,
 int bbdm_gemm_bf3_supported(long long T, int CinPad, int Cout);
 int bbdm_gemm_bf3_f32(const float* V, const void* packed_bf3, float* M, int batch, long long T, int CinPad, int Cout,
                       void* stream);
+/* 1x1 convolution / nn.Linear on NHWC activations on the same kernel: out = x . W^T + bias (+ residual), operand pitches
+ * ldx / ldo / ldr address channel slices; packed_bf3 = bbdm_gemm_bf3_pack_f32(batch 1) of bbdm_conv_pack_weight_f32(ks 1).
+ * pixels % 256 == 0, CinPad % 16 == 0 (bbdm_gemm_bf3_supported).  residual may alias out. */
+int bbdm_conv1x1_bf3_f32(const float* x, int ldx, const void* packed_bf3, const float* bias, const float* residual, int ldr,
+                         float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream);
 int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* packed_bf3, float* M, int N, int H, int W, int CinPad,
                                int Cout, void* stream);
 

@@ -53,6 +53,11 @@ def test_gemm_bf3_accuracy(batch, T, Cin, Cout):
     K.test_gemm_bf3_accuracy(CPU, batch, T, Cin, Cout)
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True)])
+def test_conv1x1_bf3(pixels, Cin, Cout, res):
+    K.test_conv1x1_bf3(CPU, pixels, Cin, Cout, res)
+
+
 def test_conv_rejections_and_slices():
     K.test_conv3x3_winograd_rejects_bad_shapes(CPU)
     K.test_conv2d_channel_slices(CPU)

@@ -239,6 +239,23 @@ def test_gemm_bf3_accuracy(dev, batch, T, Cin, Cout):
     assert e_bf3 < 3e-6 and e_bf3 < 8 * e_f32 + 1e-7
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (1024, 1536, 512, True)])
+def test_conv1x1_bf3(dev, pixels, Cin, Cout, res):
+    """1x1 convolution / Linear on the bf16x3 kernel: bias, in-place residual, input taken from a channel slice of a wider
+    buffer, output written into a slice."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(pixels + Cin)
+    wide = torch.randn(pixels, Cin + 16, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(pixels, Cout, generator=g) if res else None
+    ref = wide[:, 16:].double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    buf = r.clone().to(dev) if res else None
+    out = ops.conv1x1_bf3(wide.to(dev), w.to(dev), b.to(dev), residual=buf, out=buf, cin=Cin, x_off=16)
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu(), ref) < 3e-6
+
+
 def test_conv3x3_winograd_rejects_bad_shapes(dev):
     from bbdm_amd import _lib
     import kernel_ops as ops
