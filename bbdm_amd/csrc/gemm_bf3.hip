@@ -22,7 +22,6 @@
 //    slots of the 256-B bank window.
 //  * Lane l supplies row (l & 31) and the 8 consecutive k of half (l >> 5) for A and for B alike (the sum over k does not
 //    depend on which k a lane carries as long as A and B agree); C/D layout = the f32 32x32 layout (cdna_hip_programming.md).
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -83,10 +82,12 @@ __device__ __forceinline__ int xcd_block(int nblk, int x, int off) {
     return start + ((x - ((c - off) & 7)) >> 3);
 }
 
-// DEPTH = how many K-chunks ahead the fp32 A tile is requested from HBM (register ring); the split weights (L2-resident) stay
-// one chunk ahead.  RES: add a residual row in the epilogue (compile-time: a run-time branch per store would serialise the
-// stores behind vmcnt(0), see conv_igemm.hip).
-template <int DEPTH, bool RES>
+// The fp32 A tile of chunk c + 1 is requested from HBM before the MFMAs of chunk c and split + stored after them; a second
+// register set that requests it two chunks ahead was measured 8 % SLOWER (15 spilled VGPRs at the 128-register budget of
+// two workgroups per CU; round-2 A/B: C2 step 166.0 vs 153.8 ms) and removed.
+// RES: add a residual row in the epilogue (compile-time: a run-time branch per store would serialise the stores behind
+// vmcnt(0), see conv_igemm.hip).
+template <bool RES>
 __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -132,22 +133,20 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 areg[DEPTH][2];
+    float4 areg[2];
     uint2 wreg[3];
-    auto load_a = [&](float4 (&dst)[2], int chunk) {
+    auto load = [&](int chunk) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) dst[s] = *reinterpret_cast<const float4*>(asrc[s] + chunk * KC);
-    };
-    auto load_w = [&](int chunk) {
+        for (int s = 0; s < 2; ++s) areg[s] = *reinterpret_cast<const float4*>(asrc[s] + chunk * KC);
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             wreg[p] = *reinterpret_cast<const uint2*>(wsrc + (size_t)(chunk * 3 + p) * wplane);
     };
-    auto store = [&](const float4 (&src)[2], unsigned char* st) {
+    auto store = [&](unsigned char* st) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint2 p1, p2, p3;
-            split4(src[s], p1, p2, p3);
+            split4(areg[s], p1, p2, p3);
             *reinterpret_cast<uint2*>(st + adst[s]) = p1;
             *reinterpret_cast<uint2*>(st + A_PLANE + adst[s]) = p2;
             *reinterpret_cast<uint2*>(st + 2 * A_PLANE + adst[s]) = p3;
@@ -155,51 +154,36 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) *reinterpret_cast<uint2*>(st + 3 * A_PLANE + p * W_PLANE + wdst) = wreg[p];
     };
-    auto mfma_chunk = [&](const unsigned char* st) {
-        bf16x8 bf[2][3];
+
+    load(0);
+    store(smem);
+    __syncthreads();
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const bool more = chunk + 1 < a.nchunks;
+        if (more) load(chunk + 1);
+        const unsigned char* st = smem + (chunk & 1) * STAGE;
+        bf16x8 af[2][3], bf[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[t][p] = *reinterpret_cast<const bf16x8*>(st + p * W_PLANE + boff[t]);
+            for (int p = 0; p < 3; ++p) {
+                af[t][p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE + aoff[t]);
+                bf[t][p] = *reinterpret_cast<const bf16x8*>(st + p * W_PLANE + boff[t]);
+            }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x8 af[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE + aoff[i]);
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 // smallest terms first: they meet an accumulator that has not yet grown by this chunk's leading term
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
-        }
-    };
-    const int n = a.nchunks;
-    // chunk c is computed from LDS stage c & 1; while it is, the A tile of chunk c + DEPTH is in flight, the tile of chunk
-    // c + 1 (requested DEPTH - 1 phases ago) is split and stored into the other stage
-    auto phase = [&](int c, float4 (&cur)[2], float4 (&nxt)[2]) {
-        if (c + 1 < n) load_w(c + 1);
-        if (c + DEPTH < n) load_a(nxt, c + DEPTH);
-        mfma_chunk(smem + (c & 1) * STAGE);
-        if (c + 1 < n) store(cur, smem + ((c + 1) & 1) * STAGE);
+        if (more) store(smem + ((chunk + 1) & 1) * STAGE);
         __syncthreads();
-    };
-    load_a(areg[0], 0);
-    load_w(0);
-    store(areg[0], smem);
-    __syncthreads();
-    if constexpr (DEPTH == 1) {
-        for (int c = 0; c < n; ++c) phase(c, areg[0], areg[0]);      // cur == nxt: loaded before, stored after the MFMAs
-    } else {
-        if (1 < n) load_a(areg[0], 1);
-        for (int c = 0; c < n; c += 2) {
-            phase(c, areg[0], areg[1]);
-            if (c + 1 < n) phase(c + 1, areg[1], areg[0]);
-        }
     }
 
     // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
@@ -286,25 +270,20 @@ extern "C" int bbdm_gemm_bf3_supported(long long T, int CinPad, int Cout) {
            (size_t)T * (size_t)CinPad < (1ull << 32);
 }
 
-static int bf3_depth() {
-    static const int d = []() { const char* e = getenv("BBDM_BF3_DEPTH"); return (e && e[0] == '1') ? 1 : 2; }();
-    return d;
-}
-
-template <int DEPTH, bool RES>
+template <bool RES>
 static int bf3_launch(const Bf3Args& a, long long blocks, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
     const size_t lds = 2 * STAGE;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<DEPTH, RES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_kernel<RES>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf3_kernel<DEPTH, RES>), dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf3_kernel<RES>), dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, st, a);
     return BBDM_OK;
 }
 
@@ -315,9 +294,7 @@ static int bf3_run(Bf3Args& a, int batch, hipStream_t st) {
     a.uz = (size_t)a.nchunks * 3 * a.CoutPad * KC;
     const long long blocks = ((long long)a.T / BM) * a.tilesN;
     BBDM_REQUIRE(blocks < (1ll << 31), "gemm_bf3: too many tiles");
-    int rc;
-    if (bf3_depth() == 1) rc = a.res ? bf3_launch<1, true>(a, blocks, batch, st) : bf3_launch<1, false>(a, blocks, batch, st);
-    else rc = a.res ? bf3_launch<2, true>(a, blocks, batch, st) : bf3_launch<2, false>(a, blocks, batch, st);
+    const int rc = a.res ? bf3_launch<true>(a, blocks, batch, st) : bf3_launch<false>(a, blocks, batch, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3");
     return BBDM_OK;

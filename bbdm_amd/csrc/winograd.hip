@@ -245,25 +245,36 @@ __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __res
         float2 t[AL][AL];
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
+            // One column of the window at a time, its 8 loads issued back to back: out-of-image taps read a clamped (valid)
+            // address and are zeroed by a 0/1 factor afterwards.  With a bounds-check branch per tap the waitcnt pass falls
+            // back to vmcnt(0) between the loads -- ONE load in flight per thread, which is what held this HBM-bound kernel at
+            // 2.9 TB/s.  (Batching the whole 8x8 window instead costs 128 more VGPRs: the m = 4 experiment of that kind lost.)
             const int w = MO * tw - 1 + j;
+            const int wc = min(max(w, 0), W - 1);
+            const int wsrc = UP ? wc >> 1 : wc;
+            const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
             float2 d[AL], col[AL];
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
+                const int hc = min(max(MO * th - 1 + i, 0), H - 1);
+                const int hs = UP ? hc >> 1 : hc;
+                d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+            }
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
                 const int h = MO * th - 1 + i;
-                float2 v = make_float2(0.f, 0.f);
-                if (h >= 0 && h < H && w >= 0 && w < W) {
-                    const int hs = UP ? h >> 1 : h, wsrc = UP ? w >> 1 : w;
-                    v = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
-                    if (PRE) {
-                        v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
-                        if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
-                    }
+                const float mask = (h >= 0 && h < H) ? wmask : 0.f;
+                float2 v = d[i];
+                if (PRE) {
+                    v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
+                    if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
                 }
-                d[i] = v;
+                d[i] = make_float2(mask * v.x, mask * v.y);
             }
             bt_transform<MO>(d, col);
 #pragma unroll
             for (int i = 0; i < AL; ++i) t[i][j] = col[i];
+            __builtin_amdgcn_sched_barrier(0);          // keep the columns sequential: 8 loads in flight, not 64
         }
         float* o = V + (size_t)tile * C + c;
 #pragma unroll
@@ -276,6 +287,7 @@ __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __res
     }
 }
 
+template <bool RES>
 __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldr, int res_per_image,
@@ -307,17 +319,27 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
             float2 o[MO];
             at_transform<MO>(s[a], o);
             const int oh = MO * th + a;
+            const int ohc = min(oh, H - 1);
+            // the residuals of one output row are fetched together (clamped addresses for the masked edge pixels), then the
+            // row is stored: with a load inside each pixel's bounds branch every store waited for the previous pixel's
+            // round trip (gfx9 counts loads and stores in the one in-order vmcnt)
+            float2 rv[MO];
+            if (RES) {
+#pragma unroll
+                for (int b = 0; b < MO; ++b) {
+                    const int owc = min(MO * tw + b, W - 1);
+                    const float* rp = res_per_image ? res + (size_t)n * ldr + c
+                                                    : res + ((size_t)(n * H + ohc) * W + owc) * ldr + c;
+                    rv[b] = *reinterpret_cast<const float2*>(rp);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < MO; ++b) {
                 const int ow = MO * tw + b;
                 if (oh < H && ow < W) {
-                    const size_t pix = (size_t)(n * H + oh) * W + ow;
                     float2 val = o[b] + b2;
-                    if (res) {
-                        const float* rp = res_per_image ? res + (size_t)n * ldr + c : res + pix * ldr + c;
-                        val = val + *reinterpret_cast<const float2*>(rp);
-                    }
-                    *reinterpret_cast<float2*>(y + pix * ldy + c) = val;
+                    if (RES) val = val + rv[b];
+                    *reinterpret_cast<float2*>(y + ((size_t)(n * H + oh) * W + ow) * ldy + c) = val;
                 }
             }
         }
@@ -499,8 +521,11 @@ extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias
     long long blocks = (units + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0;
-    if (m == 6)
-        hipLaunchKernelGGL(winograd_output6_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
+    if (m == 6 && residual)
+        hipLaunchKernelGGL(winograd_output6_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
+                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+    else if (m == 6)
+        hipLaunchKernelGGL(winograd_output6_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
                            Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
     else if (m == 2)
         hipLaunchKernelGGL(winograd_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
