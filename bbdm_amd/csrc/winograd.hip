@@ -139,27 +139,34 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
         const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
         float4 t[AL][AL];                 // t[i][j] = (B^T d)[i][j]
 #pragma unroll
-        for (int j = 0; j < AL; ++j) {    // column j of the tile, transformed down the rows as soon as it is loaded
-            const int w = MO * tw - 1 + j;
+        for (int j = 0; j < AL; ++j) {    // column j of the tile: its loads issued together (clamped addresses + 0/1 mask, see
+            const int w = MO * tw - 1 + j;    // winograd_input6_kernel), then transformed down the rows
+            const int wc = min(max(w, 0), W - 1);
+            const int wsrc = UP ? wc >> 1 : wc;
+            const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
             float4 d[AL], col[AL];
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
+                const int hc = min(max(MO * th - 1 + i, 0), H - 1);
+                const int hs = UP ? hc >> 1 : hc;
+                d[i] = *reinterpret_cast<const float4*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+            }
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
                 const int h = MO * th - 1 + i;
-                float4 v = f4zero();
-                if (h >= 0 && h < H && w >= 0 && w < W) {
-                    const int hs = UP ? h >> 1 : h, wsrc = UP ? w >> 1 : w;
-                    v = *reinterpret_cast<const float4*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
-                    if (PRE) {
-                        v.x = v.x * s4.x + b4.x; v.y = v.y * s4.y + b4.y;
-                        v.z = v.z * s4.z + b4.z; v.w = v.w * s4.w + b4.w;
-                        if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
-                    }
+                const float mask = (h >= 0 && h < H) ? wmask : 0.f;
+                float4 v = d[i];
+                if (PRE) {
+                    v.x = v.x * s4.x + b4.x; v.y = v.y * s4.y + b4.y;
+                    v.z = v.z * s4.z + b4.z; v.w = v.w * s4.w + b4.w;
+                    if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
                 }
-                d[i] = v;
+                d[i] = mask * v;
             }
             bt_transform<MO>(d, col);
 #pragma unroll
             for (int i = 0; i < AL; ++i) t[i][j] = col[i];
+            __builtin_amdgcn_sched_barrier(0);          // keep the columns sequential: AL loads in flight, not AL^2
         }
         float* o = V + (size_t)tile * C + c;
 #pragma unroll
@@ -205,16 +212,17 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
         for (int a = 0; a < MO; ++a) {
             float4 o[MO];
             at_transform<MO>(s[a], o);
+            const size_t pix0 = (size_t)(n * H + MO * th + a) * W + MO * tw;
+            float4 rv[MO];            // the residuals of one output row fetched together, then the row stored
 #pragma unroll
-            for (int b = 0; b < MO; ++b) {
-                const size_t pix = (size_t)(n * H + MO * th + a) * W + MO * tw + b;
-                float4 val = o[b] + b4;
-                if (res) {
-                    const float* rp = res_per_image ? res + (size_t)n * ldr + c : res + pix * ldr + c;
-                    val = val + *reinterpret_cast<const float4*>(rp);
-                }
-                *reinterpret_cast<float4*>(y + pix * ldy + c) = val;
+            for (int b = 0; b < MO; ++b) rv[b] = f4zero();
+            if (res) {
+#pragma unroll
+                for (int b = 0; b < MO; ++b)
+                    rv[b] = *reinterpret_cast<const float4*>(res_per_image ? res + (size_t)n * ldr + c : res + (pix0 + b) * ldr + c);
             }
+#pragma unroll
+            for (int b = 0; b < MO; ++b) *reinterpret_cast<float4*>(y + (pix0 + b) * ldy + c) = (o[b] + b4) + rv[b];
         }
     }
 }
