@@ -44,30 +44,35 @@ struct Bf3Args {
     const float* res;        // [T][ldr] or null; may alias M
 };
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float bf16_round(float x) {       // x rounded to bf16 (RNE), returned as fp32
     return (float)(__bf16)x;
 }
-__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {     // the bf16 bit patterns of two bf16-valued floats
-    return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xFFFF0000u);
+// two fp32 -> two bf16 (RNE) packed in one dword: ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+__device__ __forceinline__ float lo_as_f32(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float hi_as_f32(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
 __device__ __forceinline__ int swz(int row, int byte_in_row) {          // byte offset inside a plane
     return row * ROWB + (byte_in_row ^ (((row >> 3) & 1) << 4));
 }
 
+// a pair of fp32 -> the pair's three packed bf16 planes (11 VALU ops per pair)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = cvt_pk(x0, x1);
+    const float r0 = x0 - lo_as_f32(p1), r1 = x1 - hi_as_f32(p1);          // exact
+    p2 = cvt_pk(r0, r1);
+    p3 = cvt_pk(r0 - lo_as_f32(p2), r1 - hi_as_f32(p2));
+}
+
 // a 4-element fp32 group -> 3 x (4 bf16 = 8 B)
 __device__ __forceinline__ void split4(float4 v, uint2& p1, uint2& p2, uint2& p3) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    float a[4], b[4], c[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        a[e] = bf16_round(x[e]);
-        const float r1 = x[e] - a[e];
-        b[e] = bf16_round(r1);
-        c[e] = bf16_round(r1 - b[e]);
-    }
-    p1 = make_uint2(pack_hi16(a[0], a[1]), pack_hi16(a[2], a[3]));
-    p2 = make_uint2(pack_hi16(b[0], b[1]), pack_hi16(b[2], b[3]));
-    p3 = make_uint2(pack_hi16(c[0], c[1]), pack_hi16(c[2], c[3]));
+    split2(v.x, v.y, p1.x, p2.x, p3.x);
+    split2(v.z, v.w, p1.y, p2.y, p3.y);
 }
 
 __device__ __forceinline__ int xcd_block(int nblk, int x, int off) {
