@@ -22,7 +22,6 @@
 //    slots of the 256-B bank window.
 //  * Lane l supplies row (l & 31) and the 8 consecutive k of half (l >> 5) for A and for B alike (the sum over k does not
 //    depend on which k a lane carries as long as A and B agree); C/D layout = the f32 32x32 layout (cdna_hip_programming.md).
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -90,7 +89,9 @@ __device__ __forceinline__ int xcd_block(int nblk, int x, int off) {
 
 // The fp32 A tile of chunk c + 1 is requested from HBM before the MFMAs of chunk c and split + stored after them; a second
 // register set that requests it two chunks ahead was measured 8 % SLOWER (15 spilled VGPRs at the 128-register budget of
-// two workgroups per CU; round-2 A/B: C2 step 166.0 vs 153.8 ms) and removed.
+// two workgroups per CU; round-2 A/B: C2 step 166.0 vs 153.8 ms) and removed; so was a K = 32-per-phase variant with ONE
+// workgroup per CU, 227 VGPRs and a 2-deep A ring (tile GEMMs 137.6 vs 154.5 "TFLOP/s", C2 step 149.0 vs 137.0 ms): two
+// co-resident workgroups covering each other's barriers matter more than the extra latency tolerance.
 // RES: add a residual row in the epilogue (compile-time: a run-time branch per store would serialise the stores behind
 // vmcnt(0), see conv_igemm.hip).
 template <bool RES>
@@ -176,190 +177,21 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
                 af[t][p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE + aoff[t]);
                 bf[t][p] = *reinterpret_cast<const bf16x8*>(st + p * W_PLANE + boff[t]);
             }
+        // term-major, tile-minor: consecutive MFMAs go to DIFFERENT accumulators (a dependent MFMA would wait for its
+        // predecessor's result); smallest terms first: they meet an accumulator not yet grown by this chunk's leading term
+        constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                // smallest terms first: they meet an accumulator that has not yet grown by this chunk's leading term
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t]], bf[j][TB[t]], acc[i][j], 0, 0, 0);
         if (more) store(smem + ((chunk + 1) & 1) * STAGE);
         __syncthreads();
     }
 
     // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8) {
-            float rv[8][2];
-            if (RES) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = r0 + rr;
-                    const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                        rv[rr][j] = co < a.Cout ? a.res[(size_t)row * a.ldr + co] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = r0 + rr;
-                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* dst = M + (size_t)row * a.ldo;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                    float v = acc[i][j][r] + bv[j];
-                    if (RES) v += rv[rr][j];
-                    if (co < a.Cout) dst[co] = v;
-                }
-            }
-        }
-}
-
-// ---- K = 32 per phase, ONE workgroup per CU (256-VGPR budget), A tile requested two phases ahead --------------------------
-// The 16-per-phase kernel above keeps two workgroups per CU, which caps it at 128 VGPRs: no room for a second A register set,
-// so an A tile has ONE phase (~1.3 us of MFMA work per SIMD) to arrive from HBM and the wait shows (43 % of the bf16x6 peak).
-// Here a phase is 32 channels (48 MFMAs per wave, 144 KB of LDS for the two stages), one workgroup owns the CU, and the
-// register budget pays for a 2-deep A ring: an A tile has two phases (~2.6 us) to arrive.
-constexpr int KC2 = 32, ROWB2 = 64;
-constexpr int A_PLANE2 = BM * ROWB2, W_PLANE2 = BN * ROWB2;
-constexpr int STAGE2 = 3 * A_PLANE2 + 3 * W_PLANE2;      // 73728 B
-
-__device__ __forceinline__ int swz2(int row, int byte_in_row) {         // 64-B rows: 16-B slot q lives at q ^ ((row >> 2) & 3)
-    return row * ROWB2 + (byte_in_row ^ (((row >> 2) & 3) << 4));
-}
-
-template <bool RES>
-__global__ void __launch_bounds__(NTHR, 2) gemm_bf3_k32_kernel(const Bf3Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const float* V = a.V + (size_t)blockIdx.z * a.vz;
-    const unsigned short* U = a.U + (size_t)blockIdx.z * a.uz;
-    float* M = a.M + (size_t)blockIdx.z * a.mz;
-    int bid = xcd_block((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
-    const int n_tile = bid % a.tilesN, m_tile = bid / a.tilesN;
-    const int row0 = m_tile * BM, cout0 = n_tile * BN;
-
-    // A: 256 rows x 32 fp32 = 2048 float4: thread owns f = tid + s * 512 -> (row = f >> 3, 4-k group q = f & 7)
-    const float* asrc[4];
-    int adst[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int f = tid + s * NTHR, row = f >> 3, q = f & 7;
-        asrc[s] = V + (size_t)(row0 + row) * a.lda + q * 4;
-        adst[s] = swz2(row, q * 8);
-    }
-    // W: per plane 128 rows x 64 B = 1024 units of 8 B: thread owns units tid and tid + 512 of each plane; unit u ->
-    // (row = u >> 3, q = u & 7): 16-channel chunk q >> 2 of the phase, 4-k group q & 3 inside it
-    const unsigned short* wsrc[2];
-    int wdst[2];
-    const size_t wplane = (size_t)a.CoutPad * KC;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int u = tid + j * NTHR, row = u >> 3, q = u & 7;
-        wsrc[j] = U + (size_t)(q >> 2) * 3 * wplane + ((size_t)cout0 + row) * KC + (q & 3) * 4;
-        wdst[j] = swz2(row, q * 8);
-    }
-    int aoff[2][2], boff[2][2];                      // [k-step][tile]
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            aoff[ks][t] = swz2(wm * 64 + t * 32 + (lane & 31), ks * 32 + (lane >> 5) * 16);
-            boff[ks][t] = 3 * A_PLANE2 + swz2(wn * 64 + t * 32 + (lane & 31), ks * 32 + (lane >> 5) * 16);
-        }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 areg[2][4];
-    uint2 wreg[3][2];
-    const int n = a.nchunks >> 1;                    // phases of 32 channels
-    auto load_a = [&](float4 (&dst)[4], int ph) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dst[s] = *reinterpret_cast<const float4*>(asrc[s] + ph * KC2);
-    };
-    auto load_w = [&](int ph) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                wreg[p][j] = *reinterpret_cast<const uint2*>(wsrc[j] + ((size_t)(2 * ph) * 3 + p) * wplane);
-    };
-    auto store = [&](const float4 (&src)[4], unsigned char* st) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint2 p1, p2, p3;
-            split4(src[s], p1, p2, p3);
-            *reinterpret_cast<uint2*>(st + adst[s]) = p1;
-            *reinterpret_cast<uint2*>(st + A_PLANE2 + adst[s]) = p2;
-            *reinterpret_cast<uint2*>(st + 2 * A_PLANE2 + adst[s]) = p3;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) *reinterpret_cast<uint2*>(st + 3 * A_PLANE2 + p * W_PLANE2 + wdst[j]) = wreg[p][j];
-    };
-    auto phase = [&](int c, float4 (&cur)[4], float4 (&nxt)[4]) {
-        if (c + 1 < n) load_w(c + 1);
-        if (c + 2 < n) load_a(nxt, c + 2);
-        const unsigned char* st = smem + (c & 1) * STAGE2;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2][3], bf[2][3];
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    af[t][p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE2 + aoff[ks][t]);
-                    bf[t][p] = *reinterpret_cast<const bf16x8*>(st + p * W_PLANE2 + boff[ks][t]);
-                }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (c + 1 < n) store(cur, smem + ((c + 1) & 1) * STAGE2);
-        __syncthreads();
-    };
-    load_a(areg[0], 0);
-    load_w(0);
-    store(areg[0], smem);
-    __syncthreads();
-    if (1 < n) load_a(areg[0], 1);
-    for (int c = 0; c < n; c += 2) {
-        phase(c, areg[0], areg[1]);
-        if (c + 1 < n) phase(c + 1, areg[1], areg[0]);
-    }
-
     float bv[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -460,23 +292,6 @@ static int bf3_launch(const Bf3Args& a, long long blocks, int batch, hipStream_t
     return BBDM_OK;
 }
 
-template <bool RES>
-static int bf3_launch_k32(const Bf3Args& a, long long blocks, int batch, hipStream_t st) {
-    static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
-    bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = 2 * STAGE2;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_k32_kernel<RES>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            bbdm_set_error("gemm_bf3(k32): hipFuncSetAttribute(%zu B LDS) failed", lds);
-            return BBDM_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_bf3_k32_kernel<RES>), dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, st, a);
-    return BBDM_OK;
-}
-
 static int bf3_run(Bf3Args& a, int batch, hipStream_t st) {
     a.CoutPad = cdiv(a.Cout, 128) * 128;
     a.nchunks = a.Cin / KC;
@@ -484,10 +299,7 @@ static int bf3_run(Bf3Args& a, int batch, hipStream_t st) {
     a.uz = (size_t)a.nchunks * 3 * a.CoutPad * KC;
     const long long blocks = ((long long)a.T / BM) * a.tilesN;
     BBDM_REQUIRE(blocks < (1ll << 31), "gemm_bf3: too many tiles");
-    static const bool k32 = []() { const char* e = getenv("BBDM_BF3_K32"); return e && e[0] == '1'; }();
-    int rc;
-    if (k32 && a.nchunks % 2 == 0) rc = a.res ? bf3_launch_k32<true>(a, blocks, batch, st) : bf3_launch_k32<false>(a, blocks, batch, st);
-    else rc = a.res ? bf3_launch<true>(a, blocks, batch, st) : bf3_launch<false>(a, blocks, batch, st);
+    const int rc = a.res ? bf3_launch<true>(a, blocks, batch, st) : bf3_launch<false>(a, blocks, batch, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3");
     return BBDM_OK;
