@@ -26,6 +26,11 @@ SIGNATURES = {
     "bbdm_conv_splitk_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbdm_conv2d_nhwc_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P, _P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_conv_stats_fusable": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "bbdm_conv2d_nhwc_stats_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, _P, c_size_t, _P, _P, c_int, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    "bbdm_winograd_output_stats_f32": (c_int, [c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               _P, c_int, c_int, _P, c_int, c_int, _P]),
     "bbdm_groupnorm_coeffs_f32": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "bbdm_winograd_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_winograd_pack_weight_f32": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -54,6 +54,10 @@ struct ConvArgs {
     int batch;
     long long* dbg;
     size_t xz, wz, oz;
+    // GroupNorm statistics of the output accumulated by this launch (VAR bit 3; see winograd.hip: StatArgs): fp64 [N][32][2]
+    // accumulators of up to two consumers, their group width and the channel offset of `out` in their tensor
+    double* st_s[2];
+    int st_cpg[2], st_coff[2];
 };
 
 // ---- epilogue: + bias (+ residual) -> global ----------------------------------------------------------------------
@@ -65,9 +69,10 @@ struct ConvArgs {
 // 8 rows, wait once, then store.
 // Row loop outside, column tiles inside: the pixel index of a row is computed once and consumed at once (with the column
 // tile outermost all MT*16 row addresses stayed live and accumulators were spilled to scratch).
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool STATS = false>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tile_x,
-                                                   int tile_y, int img0, int cout0, int wm, int wn, int lane) {
+                                                   int tile_y, int img0, int cout0, int wm, int wn, int lane,
+                                                   double* psum = nullptr, double* psq = nullptr) {
     constexpr int MT = BM / WM / 32, NTL = BN / WN / 32;
     constexpr int RG = 8;                        // rows per residual batch
     const int TW = 1 << a.TWl, TH = 1 << a.THl;
@@ -124,12 +129,53 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16 (&a
                     else if (MODE == 3) {
                         if (a.res) v += (a.out_nchw & 2) ? a.res[(size_t)n * a.ldr + co[nt]] : a.res[pix * a.ldr + co[nt]];
                         a.out[((size_t)(n * a.Cout + co[nt]) * a.H + h) * a.W + w] = v;
-                    } else
+                    } else {
                         a.out[pix * a.ldo + co[nt]] = v;
+                        if (STATS) { psum[nt] += (double)v; psq[nt] += (double)v * v; }
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the row groups sequential: no batching of address math
         }
+    }
+}
+
+// Epilogue + GroupNorm statistics of the stored values (modes 0-2, one image per workgroup: the host checks that): per-lane
+// fp64 partials -> LDS (the pipeline's buffers are idle by now) -> one fp64 atomic per touched (image, group).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tile_x,
+                                                    int tile_y, int img0, int cout0, int wm, int wn, int lane, float* smem) {
+    constexpr int NTL = BN / WN / 32;
+    double psum[NTL], psq[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) psum[nt] = psq[nt] = 0.0;
+    if (!a.res)
+        conv_epilogue_rows<BM, BN, WM, WN, 0, true>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, psum, psq);
+    else if (a.out_nchw & 2)
+        conv_epilogue_rows<BM, BN, WM, WN, 2, true>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, psum, psq);
+    else
+        conv_epilogue_rows<BM, BN, WM, WN, 1, true>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, psum, psq);
+    double* ls = reinterpret_cast<double*>(smem);            // [2 consumers][32 groups][2]
+    const int tid = threadIdx.x;
+    if (tid < 128) ls[tid] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt) {
+        const int co = cout0 + wn * (BN / WN) + nt * 32 + (lane & 31);
+        if (co >= a.Cout) continue;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!a.st_s[k]) continue;
+            const int g = (a.st_coff[k] + co) / a.st_cpg[k];
+            atomicAdd(ls + (k * 32 + g) * 2, psum[nt]);
+            atomicAdd(ls + (k * 32 + g) * 2 + 1, psq[nt]);
+        }
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const int k = tid >> 6;
+        const double v = ls[tid];
+        if (a.st_s[k] && v != 0.0) atomicAdd(a.st_s[k] + (size_t)img0 * 64 + (tid & 63), v);
     }
 }
 
@@ -188,7 +234,7 @@ __device__ __forceinline__ int xcd_swizzled_block() {
 template <int BM, int BN, int WM, int WN, int PSLOTS, int OCC, int VAR>
 __global__ void __launch_bounds__(WM * WN * 64, OCC * WM * WN / 4)
 conv_igemm_f32(const ConvArgs a_in) {
-    constexpr bool PRE = (VAR & 1) != 0, SPLIT = (VAR & 2) != 0, GEMM = (VAR & 4) != 0;
+    constexpr bool PRE = (VAR & 1) != 0, SPLIT = (VAR & 2) != 0, GEMM = (VAR & 4) != 0, STATS = (VAR & 8) != 0;
     ConvArgs a = a_in;
     a.x += (size_t)blockIdx.z * a.xz;
     a.w += (size_t)blockIdx.z * a.wz;
@@ -423,7 +469,10 @@ conv_igemm_f32(const ConvArgs a_in) {
     }
 
     if (a.dbg) tdbg2 = wall_clock64();
-    conv_epilogue<BM, BN, WM, WN, SPLIT>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
+    if constexpr (STATS)
+        conv_epilogue_stats<BM, BN, WM, WN>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, smem);
+    else
+        conv_epilogue<BM, BN, WM, WN, SPLIT>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
     if (a.dbg && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -606,6 +655,10 @@ int launch_conv(ConvArgs& a, hipStream_t stream) {
         tile_gemm = var == 0 && a.taps == 1;
     if (tile_gemm) {
         if constexpr (BM == 256 && PSLOTS == 2) lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 4>(a, lds, blocks, stream);
+    } else if (a.st_s[0] || a.st_s[1]) {
+        if (a.splits > 1 || IM != 1 || (a.out_nchw & 1)) return 2;          // not fusable: the caller asked for the impossible
+        lrc = a.pre_sc ? launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 9>(a, lds, blocks, stream)
+                       : launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 8>(a, lds, blocks, stream);
     } else {
         switch (var) {
             case 0: lrc = launch_variant<BM, BN, WM, WN, PSLOTS, OCC, 0>(a, lds, blocks, stream); break;
@@ -719,6 +772,7 @@ int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed
     a.ws = nullptr; a.ws_cap = 0; a.ldw = (Cout + 3) & ~3;
     a.pre_sc = nullptr; a.pre_bi = nullptr; a.pre_ld = 0; a.pre_silu = 0;
     a.batch = batch; a.xz = xz; a.wz = wz; a.oz = oz;
+    a.st_s[0] = a.st_s[1] = nullptr; a.st_cpg[0] = a.st_cpg[1] = 1; a.st_coff[0] = a.st_coff[1] = 0;
     a.dbg = g_conv_trace;
     a.splits = 1;
     int rc = launch_conv<256, 128, 4, 2, 2, 2>(a, st);
@@ -729,10 +783,25 @@ int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed
     return rc;
 }
 
-extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
-                                    const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
-                                    size_t ws_floats, const float* pre_scale, const float* pre_bias, int pre_ld,
-                                    int pre_silu, int N, int H, int W, int CinPad, int Cout, int ks, void* stream) {
+// Can bbdm_conv2d_nhwc_stats_f32 accumulate GroupNorm statistics for this shape?  (no split-K, one image per workgroup tile,
+// not the narrow / NCHW head)
+extern "C" int bbdm_conv_stats_fusable(int N, int H, int W, int CinPad, int Cout, int ks) {
+    if (Cout % 4 || Cout <= 8) return 0;
+    const long long M = (long long)N * H * W;
+    const ConvPlan p = conv_plan(M, Cout, cdiv(CinPad, KC));
+    if (p.splits > 1) return 0;
+    const int BMv = p.big ? 256 : 128;
+    const int TWc = ceil_pow2(W) < 32 ? ceil_pow2(W) : 32;
+    int THc = BMv / TWc;
+    if (THc > ceil_pow2(H)) THc = ceil_pow2(H);
+    return TWc * THc == BMv ? 1 : 0;
+}
+
+extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, const float* bias,
+                                          const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
+                                          size_t ws_floats, const float* pre_scale, const float* pre_bias, int pre_ld,
+                                          int pre_silu, int N, int H, int W, int CinPad, int Cout, int ks, double* stats0,
+                                          int cpg0, int coff0, double* stats1, int cpg1, int coff1, void* stream) {
     BBDM_REQUIRE(x && packed_w && out, "conv2d: null pointer");
     BBDM_REQUIRE(ks == 1 || ks == 3, "conv2d: ks=%d unsupported (1 or 3)", ks);
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && CinPad > 0, "conv2d: bad shape");
@@ -755,6 +824,13 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
                  "conv2d: pre_ld / alignment of the fused-producer coefficients");
     a.pre_sc = pre_scale; a.pre_bi = pre_bias; a.pre_ld = pre_ld; a.pre_silu = pre_silu;
     a.batch = 1; a.xz = a.wz = a.oz = 0; a.dbg = nullptr;
+    BBDM_REQUIRE((!stats0 && !stats1) || bbdm_conv_stats_fusable(N, H, W, CinPad, Cout, ks),
+                 "conv2d: GroupNorm statistics cannot be accumulated for this shape (bbdm_conv_stats_fusable)");
+    BBDM_REQUIRE((!stats0 || (cpg0 > 0 && coff0 >= 0 && (coff0 + Cout - 1) / cpg0 < 32)) &&
+                     (!stats1 || (cpg1 > 0 && coff1 >= 0 && (coff1 + Cout - 1) / cpg1 < 32)),
+                 "conv2d: statistics targets need (coff + Cout) / cpg <= 32");
+    a.st_s[0] = stats0; a.st_cpg[0] = cpg0 > 0 ? cpg0 : 1; a.st_coff[0] = coff0;
+    a.st_s[1] = stats1; a.st_cpg[1] = cpg1 > 0 ? cpg1 : 1; a.st_coff[1] = coff1;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     if (ks == 3 && Cout <= 8 && !residual && M >= 4096) {      // a few output channels: one thread per pixel (see above)
@@ -773,13 +849,22 @@ extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed
         if (rc == 1) { a.splits = plan.splits; rc = launch_conv<128, 128, 4, 2, 3, 2>(a, st); }
         if (rc == 1) { a.splits = plan.splits; rc = launch_conv<128, 128, 2, 2, 6, 2>(a, st); }
     }
-    if (rc == 1) {
-        bbdm_set_error("conv2d: no tile configuration fits N=%d H=%d W=%d", N, H, W);
+    if (rc == 1 || rc == 2) {
+        bbdm_set_error(rc == 1 ? "conv2d: no tile configuration fits N=%d H=%d W=%d"
+                               : "conv2d: statistics requested for a launch that cannot accumulate them (N=%d H=%d W=%d)", N, H, W);
         return BBDM_E_BADARG;
     }
     if (rc < 0) return rc;
     BBDM_CHECK_LAUNCH("conv2d");
     return BBDM_OK;
+}
+
+extern "C" int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const float* bias,
+                                    const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
+                                    size_t ws_floats, const float* pre_scale, const float* pre_bias, int pre_ld,
+                                    int pre_silu, int N, int H, int W, int CinPad, int Cout, int ks, void* stream) {
+    return bbdm_conv2d_nhwc_stats_f32(x, ldx, packed_w, bias, residual, ldr, out, ldo, out_nchw, ws, ws_floats, pre_scale, pre_bias,
+                                      pre_ld, pre_silu, N, H, W, CinPad, Cout, ks, nullptr, 0, 0, nullptr, 0, 0, stream);
 }
 
 // ---- batched GEMM with activation operands (see pack_activation_kernel) ------------------------------------------------

@@ -180,17 +180,68 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 }
 
 // ---- (3) output transform: one thread = one (tile, output-channel quad) ---------------------------------------------
+// GroupNorm statistics of the tensor being written, accumulated by its PRODUCER (openaimodel.py:205,229,306,688: every 3x3
+// conv output of the UNet is normalised next): per (image, group) sum / sum of squares in fp64, up to two consumers with
+// their own group width and channel offset (a block output is normalised by the next block as [C] and, through the concat,
+// by an output block as a slice of [C + C']).  This removes the separate statistics pass -- a full re-read of every
+// activation (25.8 GB and 5.3 ms per 256x256 / batch-16 step).  A workgroup owns a contiguous run of `iters` x 256
+// (tile, channel-group) units, i.e. a few consecutive tiles of at most ST_IMGS images: its partial sums meet in LDS
+// (ds_add_f64) and reach HBM as one fp64 atomic per touched (image, group) -- a few hundred atomics per address per launch.
+struct StatArgs {
+    double* s[2];        // [N][32][2] fp64 accumulators (zeroed by the caller), or null
+    int cpg[2];          // channels per group of that consumer (a multiple of the kernel's channel vector)
+    int coff[2];         // channel offset of this tensor inside the consumer's tensor
+};
+constexpr int ST_IMGS = 4;
+constexpr int ST_DOUBLES = 2 * ST_IMGS * 32 * 2;
+
+__device__ __forceinline__ void stat_add(double* lsum, const StatArgs& st, int n_local, int n, int c, double sum, double sq) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!st.s[k]) continue;
+        const int g = (st.coff[k] + c) / st.cpg[k];
+        if (n_local < ST_IMGS) {
+            double* d = lsum + ((size_t)(k * ST_IMGS + n_local) * 32 + g) * 2;
+            atomicAdd(d, sum);
+            atomicAdd(d + 1, sq);
+        } else {                           // a run spanning more than ST_IMGS images (tiny images): straight to HBM
+            double* d = st.s[k] + ((size_t)n * 32 + g) * 2;
+            atomicAdd(d, sum);
+            atomicAdd(d + 1, sq);
+        }
+    }
+}
+__device__ __forceinline__ void stat_flush(const double* lsum, const StatArgs& st, int n0, int N) {
+    for (int i = threadIdx.x; i < ST_DOUBLES; i += 256) {
+        const int k = i / (ST_IMGS * 64), rem = i - k * (ST_IMGS * 64);
+        const int n = n0 + rem / 64;
+        const double v = lsum[i];
+        if (st.s[k] && n < N && v != 0.0) atomicAdd(st.s[k] + (size_t)n * 64 + (rem & 63), v);
+    }
+}
+
 // y[MO*th + a][MO*tw + b] = (A^T m A)[a][b] + bias (+ residual)
 template <int MO>
 __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int ldr, int res_per_image,
-                                                              float* __restrict__ y, int ldy, int N, int H, int W, int Cout) {
+                                                              float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
+                                                              int iters, const StatArgs st) {
     constexpr int AL = MO + 2;
+    __shared__ double lsum[ST_DOUBLES];
     const int C4 = Cout >> 2;
     const int TH = H / MO, TW = W / MO;
     const long long total = (long long)N * TH * TW * C4;
-    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
+    const long long base = (long long)blockIdx.x * iters * 256;
+    const int n0 = (int)((base / C4) / ((long long)TH * TW));
+    const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
+    if (stats) {
+        for (int i = threadIdx.x; i < ST_DOUBLES; i += 256) lsum[i] = 0.0;
+        __syncthreads();
+    }
+    for (int it = 0; it < iters; ++it) {
+        const long long u = base + (long long)it * 256 + threadIdx.x;
+        if (u >= total) break;
         const int c = (int)(u % C4) * 4;
         const long long tile = u / C4;
         const int tw = (int)(tile % TW);
@@ -208,6 +259,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
             for (int a = 0; a < MO; ++a) s[a][j] = sj[a];
         }
         const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + c) : f4zero();
+        double psum = 0.0, psq = 0.0;
 #pragma unroll
         for (int a = 0; a < MO; ++a) {
             float4 o[MO];
@@ -222,8 +274,20 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
                     rv[b] = *reinterpret_cast<const float4*>(res_per_image ? res + (size_t)n * ldr + c : res + (pix0 + b) * ldr + c);
             }
 #pragma unroll
-            for (int b = 0; b < MO; ++b) *reinterpret_cast<float4*>(y + (pix0 + b) * ldy + c) = (o[b] + b4) + rv[b];
+            for (int b = 0; b < MO; ++b) {
+                const float4 val = (o[b] + b4) + rv[b];
+                *reinterpret_cast<float4*>(y + (pix0 + b) * ldy + c) = val;
+                if (stats) {
+                    psum += ((double)val.x + (double)val.y) + ((double)val.z + (double)val.w);
+                    psq += ((double)val.x * val.x + (double)val.y * val.y) + ((double)val.z * val.z + (double)val.w * val.w);
+                }
+            }
         }
+        if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);
+    }
+    if (stats) {
+        __syncthreads();
+        stat_flush(lsum, st, n0, N);
     }
 }
 
@@ -299,12 +363,23 @@ template <bool RES>
 __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldr, int res_per_image,
-                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout) {
+                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
+                                                               int iters, const StatArgs st) {
     constexpr int MO = 6, AL = 8;
+    __shared__ double lsum[ST_DOUBLES];
     const int C2 = Cout >> 1;
     const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
     const long long total = (long long)N * TH * TW * C2;
-    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < total; u += (long long)gridDim.x * 256) {
+    const long long base = (long long)blockIdx.x * iters * 256;
+    const int n0 = (int)((base / C2) / ((long long)TH * TW));
+    const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
+    if (stats) {
+        for (int i = threadIdx.x; i < ST_DOUBLES; i += 256) lsum[i] = 0.0;
+        __syncthreads();
+    }
+    for (int it = 0; it < iters; ++it) {
+        const long long u = base + (long long)it * 256 + threadIdx.x;
+        if (u >= total) break;
         const int c = (int)(u % C2) * 2;
         const long long tile = u / C2;
         const int tw = (int)(tile % TW);
@@ -322,6 +397,7 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
             for (int a = 0; a < MO; ++a) s[a][j] = sj[a];
         }
         const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
+        double psum = 0.0, psq = 0.0;
 #pragma unroll
         for (int a = 0; a < MO; ++a) {
             float2 o[MO];
@@ -348,9 +424,18 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
                     float2 val = o[b] + b2;
                     if (RES) val = val + rv[b];
                     *reinterpret_cast<float2*>(y + ((size_t)(n * H + oh) * W + ow) * ldy + c) = val;
+                    if (stats) {
+                        psum += (double)val.x + (double)val.y;
+                        psq += (double)val.x * val.x + (double)val.y * val.y;
+                    }
                 }
             }
         }
+        if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);
+    }
+    if (stats) {
+        __syncthreads();
+        stat_flush(lsum, st, n0, N);
     }
 }
 
@@ -514,8 +599,12 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
     return bbdm_gemm_bf3_f32(V, packed_bf3, M, planes(m), (long long)tiles_padded(N, H, W, m), CinPad, Cout, stream);
 }
 
-extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
-                                        float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stream) {
+// stats0 / stats1 (each may be NULL): fp64 [N][32][2] GroupNorm accumulators (sum, sum of squares per image and group) of up
+// to two consumers of `out`; cpg = channels per group of that consumer (a multiple of 4), coff = channel offset of `out` in
+// the consumer's tensor.  The caller zeroes them; the kernel ADDS (several producers may fill one consumer's statistics).
+extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
+                                              float* out, int ldo, int flags, int N, int H, int W, int Cout, double* stats0,
+                                              int cpg0, int coff0, double* stats1, int cpg1, int coff1, void* stream) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
@@ -524,25 +613,42 @@ extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias
     BBDM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= Cout && ((uintptr_t)residual & 15) == 0), "winograd_output: ldr=%d", ldr);
     BBDM_REQUIRE(!bias || ((uintptr_t)bias & 15) == 0, "winograd_output: bias alignment");
     BBDM_REQUIRE((((uintptr_t)M | (uintptr_t)out) & 15) == 0, "winograd_output: 16-byte alignment");
+    BBDM_REQUIRE((!stats0 || (cpg0 > 0 && cpg0 % 4 == 0 && coff0 >= 0 && (coff0 + Cout - 1) / cpg0 < 32)) &&
+                     (!stats1 || (cpg1 > 0 && cpg1 % 4 == 0 && coff1 >= 0 && (coff1 + Cout - 1) / cpg1 < 32)),
+                 "winograd_output: statistics targets need cpg %% 4 == 0 and (coff + Cout) / cpg <= 32");
+    StatArgs st;
+    st.s[0] = stats0; st.cpg[0] = cpg0 > 0 ? cpg0 : 1; st.coff[0] = coff0;
+    st.s[1] = stats1; st.cpg[1] = cpg1 > 0 ? cpg1 : 1; st.coff[1] = coff1;
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const long long units = (long long)T * (Cout / (m == 6 ? 2 : 4));
-    long long blocks = (units + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
+    // contiguous runs of iters x 256 units per workgroup: >= ~1500 workgroups to fill the chip, <= 32 iterations
+    long long iters = units / (256ll * 1536);
+    iters = iters < 1 ? 1 : (iters > 32 ? 32 : iters);
+    const long long blocks = (units + 256 * iters - 1) / (256 * iters);
+    BBDM_REQUIRE(blocks < (1ll << 31), "winograd_output: too many workgroups");
     const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0;
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t s_ = (hipStream_t)stream;
     if (m == 6 && residual)
-        hipLaunchKernelGGL(winograd_output6_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
-                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+        hipLaunchKernelGGL(winograd_output6_kernel<true>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st);
     else if (m == 6)
-        hipLaunchKernelGGL(winograd_output6_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
-                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+        hipLaunchKernelGGL(winograd_output6_kernel<false>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st);
     else if (m == 2)
-        hipLaunchKernelGGL(winograd_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
-                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+        hipLaunchKernelGGL(winograd_output_kernel<2>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N,
+                           H, W, Cout, (int)iters, st);
     else
-        hipLaunchKernelGGL(winograd_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, M,
-                           Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout);
+        hipLaunchKernelGGL(winograd_output_kernel<4>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N,
+                           H, W, Cout, (int)iters, st);
     BBDM_CHECK_LAUNCH("winograd_output");
     return BBDM_OK;
+}
+
+extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
+                                        float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stream) {
+    return bbdm_winograd_output_stats_f32(m, M, bias, residual, ldr, out, ldo, flags, N, H, W, Cout, nullptr, 0, 0, nullptr, 0,
+                                          0, stream);
 }
 
 extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packed_wino, const float* bias,

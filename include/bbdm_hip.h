@@ -75,6 +75,19 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
                          const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
                          int N, int H, int W, int CinPad, int Cout, int ks, void* stream);
 
+/* The same convolution with the GroupNorm statistics of its OUTPUT accumulated in the epilogue (every conv output of the
+ * UNet is normalised next: openaimodel.py:205,229,306,688) instead of by a separate bbdm_groupnorm_stats_f32 pass that
+ * re-reads the tensor.  stats0 / stats1 (either may be NULL): fp64 [N][32][2] accumulators (sum, sum of squares per image
+ * and 32-group index) of up to two consumers of `out` -- the next block's GroupNorm and, through the copy-free concat, an
+ * output block's; cpg = channels per group of that consumer, coff = channel offset of `out` inside the consumer's tensor.
+ * The caller zeroes them; the kernel adds.  Only where bbdm_conv_stats_fusable() says so (no split-K, one image per tile). */
+int bbdm_conv_stats_fusable(int N, int H, int W, int CinPad, int Cout, int ks);
+int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, const float* bias,
+                               const float* residual, int ldr, float* out, int ldo, int flags, float* ws, size_t ws_floats,
+                               const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
+                               int N, int H, int W, int CinPad, int Cout, int ks, double* stats0, int cpg0, int coff0,
+                               double* stats1, int cpg1, int coff1, void* stream);
+
 /* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2 or 4 [6: experimental] (same call sites, wide layers) */
 /* Y = A^T[(G g G^T) (.) (B^T d B)]A: (m+2)^2 multiplies per m^2 outputs instead of 9 m^2 -- 2.25x (m = 2) or 4x (m = 4)
  * fewer MFMA FLOP; the choice cuDNN / MIOpen make for the reference's wide 3x3 layers (openaimodel.py:207,233,524;
@@ -109,6 +122,10 @@ int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const floa
                             int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
 int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed_wino, float* M, int N, int H, int W, int CinPad,
                            int Cout, void* stream);
+/* stage (3) with the output's GroupNorm statistics accumulated (see bbdm_conv2d_nhwc_stats_f32; cpg % 4 == 0) */
+int bbdm_winograd_output_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
+                                   int ldo, int flags, int N, int H, int W, int Cout, double* stats0, int cpg0, int coff0,
+                                   double* stats1, int cpg1, int coff1, void* stream);
 int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
                              int ldo, int flags, int N, int H, int W, int Cout, void* stream);
 
