@@ -46,6 +46,7 @@ class _Flags:
         self.winograd_fuse_groupnorm = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
         self.gemm_bf3 = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
         self.fuse_groupnorm = False
+        self.fuse_stats = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
         self.hip_graph = False
         self.op_profile = None
 

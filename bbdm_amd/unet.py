@@ -545,6 +545,9 @@ class UNetModel(nn.Module):
         # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
         # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
         self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
+        # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
+        # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
+        self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -588,7 +591,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3)
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats)
         plan = self._plans.get(key)
         if plan is None:
             plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
@@ -647,6 +650,10 @@ class _Plan:
         self._wino_v, self._wino_m = _LateTensor(), _LateTensor()      # Winograd V / M planes shared by every layer
         self._wino_v_need = self._wino_m_need = 0
         self.film, self.film_total, self.resblocks, self._film_key = None, 0, [], None
+        # (id(buffer), channel offset) -> record of the conv op that LAST wrote that channel slice: where a GroupNorm
+        # consumer can ask the producer to accumulate its statistics (bbdm_*_stats_f32) instead of re-reading the tensor
+        self._writers: Dict[tuple, dict] = {}
+        self.fused_stats = 0
 
     def _allocate(self):
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -811,6 +818,7 @@ class _Plan:
             self._scratch[name] = b
             self.bufs.append(b)
         b.numel = max(b.numel, N * H * W * C)
+        self._writers = {k: v for k, v in self._writers.items() if k[0] != id(b)}     # a new tensor lives there now
         return _View(b, 0, C, N, H, W, C)
 
     class _StatsRef:
@@ -830,7 +838,9 @@ class _Plan:
         return _ParamRef(p)
 
     def _op(self, name, *args):
-        self.ops.append((name, args))
+        rec = (name, list(args))          # a list: a later consumer may patch statistics targets into its producer
+        self.ops.append(rec)
+        return rec
 
     def _conv(self, mod, cin_pad) -> _PackedConv:
         pc = _PackedConv(mod.weight, mod.bias, cin_pad)
@@ -847,7 +857,7 @@ class _Plan:
         if gn is not None:
             ref = _Plan._StatsRef(self, self._gn_count)
             self._gn_count += 1
-            self._op("bbdm_groupnorm_stats_f32", x, x.ld, ref, N, x.H * x.W, x.C, self.GROUPS)
+            self._emit_stats(x, ref)
             film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
             self._op("bbdm_groupnorm_apply_f32", x, x.ld, ref, self._pref(gn.weight), self._pref(gn.bias),
                      film, self.film_total, y, y.ld, N, x.H, x.W, x.C, self.GROUPS, float(gn.eps), silu, resample)
@@ -857,6 +867,39 @@ class _Plan:
         return y
 
     NO_PRE = (None, None, 0, 0)
+
+    def _note_writer(self, dest: _View, rec, first_stat_arg: Optional[int]):
+        """``rec`` (an op record) now holds the final value of ``dest``; ``first_stat_arg`` = index of its (stats0, cpg0,
+        coff0, stats1, cpg1, coff1) arguments, or None when that kernel cannot accumulate statistics."""
+        for k in [k for k in self._writers if k[0] == id(dest.buf) and k[1] < dest.off + dest.C and
+                  dest.off < k[1] + self._writers[k]["C"]]:
+            del self._writers[k]                                   # overlapped older writers are history
+        self._writers[(id(dest.buf), dest.off)] = dict(rec=rec, C=dest.C, arg=first_stat_arg, used=0,
+                                                       shape=(dest.N, dest.H, dest.W))
+
+    def _emit_stats(self, x: _View, ref):
+        """GroupNorm statistics of ``x`` into slot ``ref``: patched into the producer(s) of ``x`` when they are conv kernels
+        that can accumulate them (csrc/winograd.hip: StatArgs), else the stand-alone streaming pass."""
+        cpg = x.C // self.GROUPS
+        parts, pos = [], x.off
+        if self.m.fuse_stats and x.C % self.GROUPS == 0 and cpg % 4 == 0:
+            while pos < x.off + x.C:
+                w = self._writers.get((id(x.buf), pos))
+                if (w is None or w["arg"] is None or w["used"] >= 2 or pos + w["C"] > x.off + x.C
+                        or w["shape"] != (x.N, x.H, x.W)):
+                    parts = []
+                    break
+                parts.append((w, pos - x.off))
+                pos += w["C"]
+        if not parts:
+            self._op("bbdm_groupnorm_stats_f32", x, x.ld, ref, self.N, x.H * x.W, x.C, self.GROUPS)
+            return
+        for w, coff in parts:
+            a = w["rec"][1]
+            i = w["arg"] + 3 * w["used"]
+            a[i], a[i + 1], a[i + 2] = ref, cpg, coff
+            w["used"] += 1
+        self.fused_stats += 1
 
     def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None, fuse_direct: bool = False):
         """Input of a conv that follows GroupNorm [-> FiLM] [-> SiLU] at the same resolution.
@@ -874,7 +917,7 @@ class _Plan:
         N = self.N
         ref = _Plan._StatsRef(self, self._gn_count)
         self._gn_count += 1
-        self._op("bbdm_groupnorm_stats_f32", x, x.ld, ref, N, x.H * x.W, x.C, self.GROUPS)
+        self._emit_stats(x, ref)
         k = self._n_coeffs
         self._n_coeffs += 1
         self._coeff_need = max(self._coeff_need, N * x.C)
@@ -909,9 +952,13 @@ class _Plan:
              cin_pad)
         gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
         emit(gemm, wm, self._wino_v, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
-        emit("bbdm_winograd_output_f32", wm, self._wino_m,
-             self._pref(pw.bias) if pw.bias is not None and not bwd else None, residual, res_ld, dest, dest.ld, flags,
-             N, H, W, cout)
+        if bwd:
+            emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout)
+        else:
+            rec = emit(_OpName("bbdm_winograd_output_f32", "bbdm_winograd_output_stats_f32"), wm, self._wino_m,
+                       self._pref(pw.bias) if pw.bias is not None else None, residual, res_ld, dest, dest.ld, flags,
+                       N, H, W, cout, None, 0, 0, None, 0, 0)
+            self._note_writer(dest, rec, 12)
 
     def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0,
                    pre=None, upsample: bool = False):
@@ -939,15 +986,18 @@ class _Plan:
             # bf16x3 GEMM with bias + residual in its epilogue (csrc/gemm_bf3.hip); small problems keep the split-K f32 kernel
             pb = _PackedConvBf3(mod.weight, mod.bias, x.C)
             self.convs.append(pb)
-            self._op("bbdm_conv1x1_bf3_f32", x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
-                     residual, res_ld, dest, dest.ld, pixels, x.C, cout)
+            rec = self._op("bbdm_conv1x1_bf3_f32", x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
+                           residual, res_ld, dest, dest.ld, pixels, x.C, cout)
+            self._note_writer(dest, rec, None)
             return
         pc = self._conv(mod, x.C)
         self._conv_ws_need = max(self._conv_ws_need,
                                  self.lib.bbdm_conv_splitk_workspace_floats(self.N, x.H, x.W, x.C, pc.cout, pc.ks))
-        self._op("bbdm_conv2d_nhwc_f32", x, x.ld, _TensorRef(pc.packed), self._pref(pc.bias), residual, res_ld,
-                 dest, dest.ld, flags, self._conv_ws, self._conv_ws_floats, *(pre or self.NO_PRE), self.N, x.H, x.W, x.C,
-                 pc.cout, pc.ks)
+        fusable = bool(self.lib.bbdm_conv_stats_fusable(self.N, x.H, x.W, x.C, pc.cout, pc.ks))
+        rec = self._op(_OpName("bbdm_conv2d_nhwc_f32", "bbdm_conv2d_nhwc_stats_f32"), x, x.ld, _TensorRef(pc.packed),
+                       self._pref(pc.bias), residual, res_ld, dest, dest.ld, flags, self._conv_ws, self._conv_ws_floats,
+                       *(pre or self.NO_PRE), self.N, x.H, x.W, x.C, pc.cout, pc.ks, None, 0, 0, None, 0, 0)
+        self._note_writer(dest, rec, 21 if fusable else None)
 
     def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
         """ResBlock._forward (openaimodel.py:258-278)."""
@@ -1135,7 +1185,9 @@ class _Plan:
             return self.plan._flat_grad.data_ptr() + 4 * self.off
 
     def _bop(self, name, *args):
-        self.bops.append((name, args))
+        rec = (name, list(args))
+        self.bops.append(rec)
+        return rec
 
     def _emit_backward(self, x0: _View):
         """Walk the tape in reverse and emit the gradient ops.

@@ -58,6 +58,15 @@ def test_conv1x1_bf3(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3(CPU, pixels, Cin, Cout, res)
 
 
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 14, 20, 32, 64), (4, 3, 8, 12, 16, 128), (6, 9, 6, 6, 16, 32)])
+def test_winograd_output_accumulates_groupnorm_statistics(m, N, H, W, Cin, Cout):
+    K.test_winograd_output_accumulates_groupnorm_statistics(CPU, m, N, H, W, Cin, Cout)
+
+
+def test_conv2d_accumulates_groupnorm_statistics():
+    K.test_conv2d_accumulates_groupnorm_statistics(CPU)
+
+
 def test_conv_rejections_and_slices():
     K.test_conv3x3_winograd_rejects_bad_shapes(CPU)
     K.test_conv2d_channel_slices(CPU)

@@ -55,3 +55,37 @@ def test_loss_and_all_parameter_gradients():
         ref = g_ref[k]
         scale = max(float(ref.abs().max()), 1e-3 * gmax)
         assert float((p.grad - ref).abs().max()) / scale < T.GRAD_TOL, k
+
+
+def test_groupnorm_statistics_fused_into_the_producers():
+    """A UNet wide enough (128 channels -> 4 per group) for the conv epilogues to accumulate the GroupNorm statistics of
+    their outputs (block outputs feeding the next block AND, through the concat, an output block): same result as with the
+    stand-alone statistics pass, and both match the oracle."""
+    import argparse
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    up = dict(image_size=16, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 1), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 31)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.eval()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(16, 4, 16, 16, generator=g)          # 16 images: enough 4x4 tiles for the Winograd path at 16x16
+    t = torch.arange(16) * 3 + 5
+    outs = {}
+    for fuse in (True, False):
+        m.fuse_stats = fuse
+        with torch.no_grad():
+            outs[fuse] = m(x, timesteps=t, context=None).clone()
+        plan = m._plan_for(x, False)
+        n_alone = sum(str(n) == "bbdm_groupnorm_stats_f32" for n, _ in plan.ops)
+        assert (plan.fused_stats > 0) == fuse and (n_alone == 0 or not fuse or plan.fused_stats > 0)
+        if fuse:
+            assert plan.fused_stats >= 3, (plan.fused_stats, n_alone)
+    ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
+    assert rel_err(outs[True], outs[False]) < 1e-6
+    assert rel_err(outs[True], ref) < M.STEP_TOL

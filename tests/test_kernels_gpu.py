@@ -256,6 +256,86 @@ def test_conv1x1_bf3(dev, pixels, Cin, Cout, res):
     assert rel_err(out.cpu(), ref) < 3e-6
 
 
+def _group_sums(y_nhwc, cpg, coff, ctot_groups=32):
+    """fp64 [N][32][2] (sum, sum of squares) of the channels of y placed at offset coff in a tensor with groups of cpg."""
+    N, H, W, C = y_nhwc.shape
+    out = torch.zeros(N, ctot_groups, 2, dtype=torch.float64)
+    yd = y_nhwc.double()
+    for c in range(C):
+        g = (coff + c) // cpg
+        out[:, g, 0] += yd[..., c].sum(dim=(1, 2))
+        out[:, g, 1] += (yd[..., c] ** 2).sum(dim=(1, 2))
+    return out
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 14, 20, 32, 64), (4, 3, 8, 12, 16, 128), (2, 5, 4, 4, 16, 32), (6, 9, 6, 6, 16, 32)])
+def test_winograd_output_accumulates_groupnorm_statistics(dev, m, N, H, W, Cin, Cout):
+    """bbdm_winograd_output_stats_f32: the output transform also accumulates the (image, group) sums two GroupNorm consumers
+    need -- the next block's norm over [Cout] and an output block's norm over a concat [Cout' + Cout] -- so that no separate
+    statistics pass re-reads the tensor.  The last case spans more images per workgroup than the LDS table holds."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m * 100 + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, H, W, Cout, generator=g)
+    xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
+    pw = ops.pack_winograd_weight(w.to(dev), in_pad=Cin, m=m)
+    st = None if dev.type != "cuda" else torch.cuda.current_stream().cuda_stream
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    P = (m + 2) ** 2
+    V = torch.zeros(P * tiles * Cin, device=dev)
+    M = torch.zeros(P * tiles * Cout, device=dev)
+    out = r.clone().to(dev)                                       # in-place residual
+    cpg0, cpg1, coff1 = Cout // 32 * 4 if Cout >= 128 else 4, 8, 64          # consumer 1: a [64 + Cout]-channel concat
+    s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    _lib.call("bbdm_winograd_input_f32", m, xg.data_ptr(), Cin, V.data_ptr(), None, None, 0, 0, 0, N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_f32", m, V.data_ptr(), pw.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, st)
+    _lib.call("bbdm_winograd_output_stats_f32", m, M.data_ptr(), b.to(dev).data_ptr(), out.data_ptr(), Cout, out.data_ptr(),
+              Cout, 0, N, H, W, Cout, s0.data_ptr(), cpg0, 0, s1.data_ptr(), cpg1, coff1, st)
+    torch.cuda.synchronize()
+    y = out.cpu()
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + r.double()
+    assert rel_err(y, ref.float()) < WINO_TOL[m]
+    for got, cpg, coff in ((s0, cpg0, 0), (s1, cpg1, coff1)):
+        want = _group_sums(y, cpg, coff)
+        assert float((got.cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
+
+
+def test_conv2d_accumulates_groupnorm_statistics(dev):
+    """bbdm_conv2d_nhwc_stats_f32 (direct kernel epilogue) on a shape bbdm_conv_stats_fusable() accepts, and its refusal
+    where a workgroup tile spans several images."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    N, H, W, Cin, Cout = 3, 16, 16, 32, 64
+    assert lib.bbdm_conv_stats_fusable(N, H, W, Cin, Cout, 3) == 1 and lib.bbdm_conv_stats_fusable(8, 4, 4, Cin, Cout, 3) == 0
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
+    pk = ops.pack_conv_weight(w.to(dev), cin_pad=Cin)
+    out = torch.empty(N, H, W, Cout, device=dev)
+    s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    st = None if dev.type != "cuda" else torch.cuda.current_stream().cuda_stream
+    _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), b.to(dev).data_ptr(), None, 0, out.data_ptr(),
+              Cout, 0, None, 0, None, None, 0, 0, N, H, W, Cin, Cout, 3, s0.data_ptr(), 2, 0, s1.data_ptr(), 4, 32, st)
+    torch.cuda.synchronize()
+    y = out.cpu()
+    assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < TOL
+    for got, cpg, coff in ((s0, 2, 0), (s1, 4, 32)):
+        want = _group_sums(y, cpg, coff)
+        assert float((got.cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
+    with pytest.raises(_lib.BBDMHipError, match="statistics"):
+        _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), None, None, 0, out.data_ptr(), Cout, 0, None,
+                  0, None, None, 0, 0, 8, 4, 4, Cin, Cout, 3, s0.data_ptr(), 2, 0, None, 0, 0, st)
+
+
 def test_conv3x3_winograd_rejects_bad_shapes(dev):
     from bbdm_amd import _lib
     import kernel_ops as ops
