@@ -621,9 +621,10 @@ extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float
     st.s[1] = stats1; st.cpg[1] = cpg1 > 0 ? cpg1 : 1; st.coff[1] = coff1;
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const long long units = (long long)T * (Cout / (m == 6 ? 2 : 4));
-    // contiguous runs of iters x 256 units per workgroup: >= ~1500 workgroups to fill the chip, <= 32 iterations
-    long long iters = units / (256ll * 1536);
-    iters = iters < 1 ? 1 : (iters > 32 ? 32 : iters);
+    // contiguous runs of iters x 256 units per workgroup: >= ~6000 workgroups (the chip holds ~1000 at a time: a 1536-workgroup
+    // launch measured 13 % slower for its ragged last wave), <= 16 iterations
+    long long iters = units / (256ll * 6144);
+    iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
     const long long blocks = (units + 256 * iters - 1) / (256 * iters);
     BBDM_REQUIRE(blocks < (1ll << 31), "winograd_output: too many workgroups");
     const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0;
