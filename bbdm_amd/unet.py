@@ -979,7 +979,7 @@ class _Plan:
         assert not upsample
         ks = mod.weight.shape[2] if mod.weight.dim() == 4 else 1
         pixels = self.N * x.H * x.W
-        if (ks == 1 and self.m.gemm_bf3 and not pre and flags == 0 and not self.training
+        if (ks == 1 and self.m.gemm_bf3 and (pre is None or pre[0] is None) and flags == 0 and not self.training
                 and self.lib.bbdm_gemm_bf3_supported(pixels, x.C, cout)
                 and (pixels // 256) * -(-cout // 128) >= 256):
             # wide 1x1 convolutions / Linears (skip connections, qkv / proj_out, transformer projections): the fp32-accurate
