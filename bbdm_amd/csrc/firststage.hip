@@ -8,7 +8,7 @@
 //
 // model/VQGAN/quantize.py:271-286 (VectorQuantizer2.forward): nearest codebook entry,
 //     d = sum(z^2, 1) + sum(e^2, 1) - 2 z e^T;  argmin_j d
-// e_dim is 3..8, so one thread evaluates a pixel against the whole codebook held in LDS.
+// e_dim is 3..8: one thread evaluates a pixel against the codebook streamed through LDS.
 #include "common.h"
 
 namespace {
@@ -36,46 +36,56 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ s
     for (int j = lane; j < T; j += 64) r[j] *= inv;
 }
 
-// codebook [n_e][D] in LDS (n_e * D floats); thread = one latent pixel.  The arithmetic follows the reference expression
-// term by term in fp32: zz = sum_k z_k^2, ee_j = sum_k e_jk^2 (both sequential), dot = fma chain over k starting from the
-// first product (what an fp32 GEMM micro-kernel computes for K <= 8), d = (zz + ee_j) - 2 * dot; first minimum wins.
+// thread = one latent pixel; the codebook streams through LDS in chunks of VQ_CHUNK rows (the f8 / f16 codebooks, 16384 x 4..8
+// floats, do not fit it whole).  The arithmetic follows the reference expression term by term in fp32: zz = sum_k z_k^2,
+// ee_j = sum_k e_jk^2 (both sequential), dot = fma chain over k starting from the first product (what an fp32 GEMM
+// micro-kernel computes for K <= 8), d = (zz + ee_j) - 2 * dot; the first minimum wins (chunks are visited in index order).
+constexpr int VQ_CHUNK = 1024;
+
 template <int D>
 __global__ void __launch_bounds__(256) vq_argmin_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ cb,
                                                         long long* __restrict__ idx, float* __restrict__ zq, int ldq,
                                                         long long pixels, int n_e) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* e = smem;                   // [n_e][D]
-    float* ee = smem + (size_t)n_e * D;    // [n_e]
-    for (int i = threadIdx.x; i < n_e * D; i += 256) e[i] = cb[i];
-    __syncthreads();
-    for (int j = threadIdx.x; j < n_e; j += 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < D; ++k) s += e[j * D + k] * e[j * D + k];
-        ee[j] = s;
-    }
-    __syncthreads();
-    for (long long p = blockIdx.x * 256ll + threadIdx.x; p < pixels; p += (long long)gridDim.x * 256) {
+    __shared__ float e[VQ_CHUNK * D];
+    __shared__ float ee[VQ_CHUNK];
+    for (long long base = blockIdx.x * 256ll; base < pixels; base += (long long)gridDim.x * 256) {   // uniform per block
+        const long long p = base + threadIdx.x;
+        const bool valid = p < pixels;
         float zv[D];
         float zz = 0.f;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            zv[k] = z[(size_t)p * ldz + k];
+            zv[k] = valid ? z[(size_t)p * ldz + k] : 0.f;
             zz += zv[k] * zv[k];
         }
         float best = INFINITY;
         int bj = 0;
-        for (int j = 0; j < n_e; ++j) {
-            float dot = zv[0] * e[j * D];
+        for (int c0 = 0; c0 < n_e; c0 += VQ_CHUNK) {
+            const int cn = min(VQ_CHUNK, n_e - c0);
+            __syncthreads();                               // the previous chunk is no longer being read
+            for (int i = threadIdx.x; i < cn * D; i += 256) e[i] = cb[(size_t)c0 * D + i];
+            __syncthreads();
+            for (int j = threadIdx.x; j < cn; j += 256) {
+                float s2 = 0.f;
 #pragma unroll
-            for (int k = 1; k < D; ++k) dot = fmaf(zv[k], e[j * D + k], dot);
-            const float d = (zz + ee[j]) - 2.f * dot;
-            if (d < best) { best = d; bj = j; }
+                for (int k = 0; k < D; ++k) s2 += e[j * D + k] * e[j * D + k];
+                ee[j] = s2;
+            }
+            __syncthreads();
+            for (int j = 0; j < cn; ++j) {
+                float dot = zv[0] * e[j * D];
+#pragma unroll
+                for (int k = 1; k < D; ++k) dot = fmaf(zv[k], e[j * D + k], dot);
+                const float d = (zz + ee[j]) - 2.f * dot;
+                if (d < best) { best = d; bj = c0 + j; }
+            }
         }
-        if (idx) idx[p] = bj;
-        if (zq) {
+        if (valid) {
+            if (idx) idx[p] = bj;
+            if (zq) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) zq[(size_t)p * ldq + k] = e[bj * D + k];
+                for (int k = 0; k < D; ++k) zq[(size_t)p * ldq + k] = cb[(size_t)bj * D + k];
+            }
         }
     }
 }
@@ -95,27 +105,14 @@ extern "C" int bbdm_vq_nearest_f32(const float* z, int ldz, const float* codeboo
                                    long long pixels, int n_e, int e_dim, void* stream) {
     BBDM_REQUIRE(z && codebook && (indices || zq) && pixels > 0 && n_e > 0, "vq_nearest: bad args");
     BBDM_REQUIRE(e_dim >= 1 && e_dim <= 8 && ldz >= e_dim && (!zq || ldq >= e_dim), "vq_nearest: e_dim=%d (1..8)", e_dim);
-    const size_t lds = ((size_t)n_e * e_dim + n_e) * sizeof(float);
-    BBDM_REQUIRE(lds <= 160 * 1024, "vq_nearest: codebook of %d x %d floats does not fit the LDS", n_e, e_dim);
     long long blocks = (pixels + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
-    static size_t lds_set_dev[BBDM_MAX_DEVICES][9] = {};
 #define BBDM_VQ(D)                                                                                                          \
-    case D: {                                                                                                               \
-        size_t& set = lds_set_dev[bbdm_device_slot()][D];                                                                   \
-        if (lds > 64 * 1024 && lds > set) {                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(vq_argmin_kernel<D>),                                     \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                  \
-                bbdm_set_error("vq_nearest: hipFuncSetAttribute(%zu B LDS) failed", lds);                                   \
-                return BBDM_E_LAUNCH;                                                                                       \
-            }                                                                                                               \
-            set = lds;                                                                                                      \
-        }                                                                                                                   \
-        hipLaunchKernelGGL(vq_argmin_kernel<D>, dim3((unsigned)blocks), dim3(256), lds, st, z, ldz, codebook, indices, zq,   \
-                           ldq, pixels, n_e);                                                                               \
-        break;                                                                                                              \
-    }
+    case D:                                                                                                                 \
+        hipLaunchKernelGGL(vq_argmin_kernel<D>, dim3((unsigned)blocks), dim3(256), 0, st, z, ldz, codebook, indices, zq, ldq, \
+                           pixels, n_e);                                                                                    \
+        break;
     switch (e_dim) {
         BBDM_VQ(1) BBDM_VQ(2) BBDM_VQ(3) BBDM_VQ(4) BBDM_VQ(5) BBDM_VQ(6) BBDM_VQ(7) BBDM_VQ(8)
     }

@@ -530,6 +530,7 @@ class UNetModel(nn.Module):
         self.out = nn.Sequential(GroupNorm32(32, ch), nn.SiLU(), _zero_(nn.Conv2d(mc, out_channels, 3, padding=1)))
 
         self._plans: Dict[tuple, "_Plan"] = {}
+        self.max_cached_plans = 4
         self._freqs: Optional[torch.Tensor] = None
         self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
         self.hip_graph: Optional[bool] = None       # None = automatic (small latents), True / False = force
@@ -592,10 +593,14 @@ class UNetModel(nn.Module):
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats)
-        plan = self._plans.get(key)
+        plan = self._plans.pop(key, None)
         if plan is None:
+            # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
+            # few shapes a run alternates between (train batch, validation batch, the runner's 4-image sample), drop the rest
+            while len(self._plans) >= self.max_cached_plans:
+                self._plans.pop(next(iter(self._plans)))
             plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
-            self._plans[key] = plan
+        self._plans[key] = plan                       # most recently used last
         return plan
 
     def _apply(self, fn, *a, **k):

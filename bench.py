@@ -61,6 +61,42 @@ WORKLOADS["c4"] = ("LBBDM-f4 training step (forward + backward + Adam), latent 3
                    dict(_UNET_PIXEL, image_size=64, in_channels=3, condition_key="nocond"), 3, 64, 32, True, 200)
 BB = dict(mt_type="linear", objective="grad", loss_type="l1", sample_type="linear", num_timesteps=1000, eta=1.0,
           max_var=1.0)
+# first stages of the latent workloads (configs/Template-LBBDM-f4.yaml:55-72, Template-LBBDM-f16.yaml:54-75)
+FIRST_STAGE = {
+    "c3": dict(embed_dim=3, n_embed=8192, ddconfig=dict(double_z=False, z_channels=3, resolution=256, in_channels=3, out_ch=3,
+                                                         ch=128, ch_mult=(1, 2, 4), num_res_blocks=2, attn_resolutions=[],
+                                                         dropout=0.0)),
+    "c5": dict(embed_dim=8, n_embed=16384, ddconfig=dict(double_z=False, z_channels=8, resolution=256, in_channels=3, out_ch=3,
+                                                          ch=128, ch_mult=(1, 1, 2, 2, 4), num_res_blocks=2,
+                                                          attn_resolutions=[16], dropout=0.0)),
+}
+
+
+def first_stage_pipeline(workload, batch, dev, ms_per_step, nsteps_table):
+    """Whole LBBDM pipeline per batch (LatentBrownianBridgeModel.sample, LatentBrownianBridgeModel.py:103-132): encode the
+    condition image, `nsteps_table` UNet steps (timed above), quantize + decode -- the first stage on the HIP kernels
+    (bbdm_amd/first_stage_hip.py), random-init weights of the template's VQGAN geometry."""
+    from bbdm_amd.first_stage_hip import VQModel
+    torch.manual_seed(7)
+    vq = VQModel(**FIRST_STAGE[workload]).eval().to(dev)
+    x = torch.randn(batch, 3, 256, 256, device=dev).clamp(-1, 1)
+    z = vq.encode_latent(x)
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps
+    enc, dec = timed(lambda: vq.encode_latent(x)), timed(lambda: vq.decode_latent(z))
+    total_ms = enc + nsteps_table * ms_per_step + dec
+    return {"encode_ms": enc, "decode_ms": dec, "unet_ms": nsteps_table * ms_per_step, "latent": list(z.shape[1:]),
+            "imgs_per_sec_per_gpu": batch / (total_ms * 1e-3),
+            "note": "encode(x_cond) + schedule_steps x the timed UNet step + quantize/decode, batch of 256x256 images"}
 
 
 def _ns(c):
@@ -199,6 +235,7 @@ def main():
     ap.add_argument("--accumulate", type=int, default=4, help="c4: accumulate_grad_batches (Template-LBBDM-f4.yaml:9)")
     ap.add_argument("--sync-every-micro-step", action="store_true", help="c4: all-reduce on every micro-step (reference)")
     ap.add_argument("--torch-adam", action="store_true", help="c4: torch.optim.Adam instead of the fused Adam+EMA pass")
+    ap.add_argument("--no-pipeline", action="store_true", help="c3 / c5: skip the first-stage (VQGAN encode / decode) timing")
     ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
@@ -459,6 +496,8 @@ def main():
                          "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
         }
+        if args.workload in FIRST_STAGE and not args.no_pipeline:
+            line["pipeline"] = first_stage_pipeline(args.workload, batch, dev, ms_per_step, nsteps_table)
         if not args.no_cpu and world == 1:
             # parity sample: one more p_sample of the SAME batch with known step noise (untimed), image 0 of which the
             # CPU path recomputes in its warm-up step

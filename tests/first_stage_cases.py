@@ -54,7 +54,7 @@ def vq_indices_bit_exact(dev):
     """bbdm_vq_nearest_f32 against the reference expression (quantize.py:280-285) on hard inputs: many near-ties."""
     import kernel_ops as ops
     g = torch.Generator().manual_seed(11)
-    for e_dim, n_e in ((3, 8192), (4, 256), (8, 1024)):
+    for e_dim, n_e in ((3, 8192), (4, 256), (8, 16384)):
         cb = torch.randn(n_e, e_dim, generator=g) * 0.5
         z = torch.randn(5000, e_dim, generator=g) * 0.6
         z[:1000] = cb[torch.randint(0, n_e, (1000,), generator=g)] + 1e-4 * torch.randn(1000, e_dim, generator=g)

@@ -66,7 +66,7 @@ def test_groupnorm_statistics_fused_into_the_producers():
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     up = dict(image_size=16, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=(),
-              channel_mult=(1, 1), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
     m = bbdm_amd.unet.UNetModel(**up)
     sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 31)

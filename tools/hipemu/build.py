@@ -35,7 +35,7 @@ def build(force=False) -> str:
         glob.glob(os.path.join(HERE, "hip", "*.h")) + [os.path.join(ROOT, "include", "bbdm_hip.h"), __file__]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps):
         return LIB
-    flags = ["-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas",
+    flags = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas",
              "-Wno-unknown-attributes", "-Wno-pass-failed", "-I", HERE, "-I", CSRC]
     objs, procs = [], []
     for s in srcs:
