@@ -57,10 +57,9 @@ __device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
 }
 __device__ __forceinline__ float lo_as_f32(unsigned p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float hi_as_f32(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
-// byte offset inside a plane.  The LDS serves 128 B per clock (32 banks): a ds_read_b128 is conflict-free when every 8
-// consecutive lanes (8 consecutive rows, same 16-B half) hit 8 distinct 16-B slots of a 128-B window -- rows r and r + 4 share
-// a window, so bit 2 of the row flips the half; bit 3 is folded in as well so that 16 consecutive rows are distinct in a
-// 256-B window too.  (Round 2 first shipped `(row >> 3) & 1` alone: 2-way conflicts on every fragment read.)
+// byte offset inside a plane: 32-B rows, the 16-B half flips with bits 2 and 3 of the row, so that the 8 (and 16) consecutive
+// rows a ds_read_b128 group touches land on distinct 16-B slots of a 128-B (256-B) window.  Measured: indistinguishable from the
+// `(row >> 3) & 1` swizzle this kernel first shipped with (tools/bf3_probe.py, +-1 %) -- fragment reads are not what bounds it.
 __device__ __forceinline__ int swz(int row, int byte_in_row) {
     return row * ROWB + (byte_in_row ^ ((((row >> 2) ^ (row >> 3)) & 1) << 4));
 }
