@@ -45,6 +45,12 @@ SIGNATURES = {
     "bbdm_conv_pack_weight_dgrad_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_conv_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbdm_conv_wgrad_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_winograd_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "bbdm_conv3x3_winograd_wgrad_f32": (c_int, [c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_winograd_dy_transform_f32": (c_int, [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_gemm_tn_splits": (c_int, [c_int, c_int64, c_int, c_int]),
+    "bbdm_gemm_tn_batched_f32": (c_int, [_P, c_int, c_size_t, _P, c_int, c_size_t, _P, c_int, c_int64, c_int, c_int, _P]),
+    "bbdm_winograd_wgrad_finish_f32": (c_int, [c_int, _P, c_int, _P, c_int, c_int, _P]),
     "bbdm_colsum_f32": (c_int, [_P, c_int, _P, _P, ctypes.c_longlong, c_int, _P]),
     "bbdm_colsum_batched_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, ctypes.c_longlong, c_int, _P]),
     "bbdm_groupnorm_stats_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),

@@ -18,99 +18,11 @@
 // out-of-image outputs are not written.  Measured on MI355X (round 2, profiles/r02_wino_bench.txt): 1.1-1.25x faster
 // than m = 4 per layer where the image is >= 64 pixels a side (little edge waste) and there are >= ~1000 tiles; slower
 // on 16x16 / 32x32 latents, where m = 4 stays (bbdm_amd/unet.py: winograd_tile).
-#include "common.h"
+#include "winograd_math.h"
 
 namespace {
 
 constexpr int KC = 16;
-
-__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
-__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
-
-// ---- the 1-D transforms (host + device: bbdm_debug_winograd_transform_1d runs the same code on the CPU for the tests) ---
-// t = B^T d.  m = 2: points {0, 1, -1, inf}; m = 4: points {0, 1, -1, 2, -2, inf} (Lavin & Gray, arXiv:1509.09308).
-template <int MO, typename T>
-__host__ __device__ __forceinline__ void bt_transform(const T (&d)[MO + 2], T (&t)[MO + 2]) {
-    if constexpr (MO == 2) {
-        t[0] = d[0] - d[2];
-        t[1] = d[1] + d[2];
-        t[2] = d[2] - d[1];
-        t[3] = d[1] - d[3];
-    } else if constexpr (MO == 4) {
-        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-        t[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
-        t[2] = 4.f * (d[1] - d[2]) + (d[4] - d[3]);
-        t[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
-        t[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
-        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-    } else {        // m = 6: points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (the 8x8 transform of NNPACK / wincnn)
-        const T e0 = (d[2] + d[6]) - 4.25f * d[4], o0 = (d[1] + d[5]) - 4.25f * d[3];
-        const T e1 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], o1 = (0.5f * d[1] + 2.f * d[5]) - 2.5f * d[3];
-        const T e2 = (d[6] + 4.f * d[2]) - 5.f * d[4], o2 = (2.f * d[1] + 0.5f * d[5]) - 2.5f * d[3];
-        t[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
-        t[1] = e0 + o0;
-        t[2] = e0 - o0;
-        t[3] = e1 + o1;
-        t[4] = e1 - o1;
-        t[5] = e2 + o2;
-        t[6] = e2 - o2;
-        t[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
-    }
-}
-// s = A^T m
-template <int MO, typename T>
-__host__ __device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&s)[MO]) {
-    if constexpr (MO == 2) {
-        s[0] = m[0] + m[1] + m[2];
-        s[1] = m[1] - m[2] - m[3];
-    } else if constexpr (MO == 4) {
-        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
-        s[0] = m[0] + p12 + p34;
-        s[1] = m12 + 2.f * m34;
-        s[2] = p12 + 4.f * p34;
-        s[3] = m12 + 8.f * m34 + m[5];
-    } else {
-        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4], p56 = m[5] + m[6],
-                m56 = m[5] - m[6];
-        s[0] = m[0] + p12 + p34 + p56;
-        s[1] = m12 + 2.f * m34 + 0.5f * m56;
-        s[2] = p12 + 4.f * p34 + 0.25f * p56;
-        s[3] = m12 + 8.f * m34 + 0.125f * m56;
-        s[4] = p12 + 16.f * p34 + 0.0625f * p56;
-        s[5] = m12 + 32.f * m34 + 0.03125f * m56 + m[7];
-    }
-}
-// u = G g
-template <int MO>
-__host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
-    if constexpr (MO == 2) {
-        u[0] = g[0];
-        u[1] = 0.5f * (g[0] + g[1] + g[2]);
-        u[2] = 0.5f * (g[0] - g[1] + g[2]);
-        u[3] = g[2];
-    } else if constexpr (MO == 4) {
-        u[0] = 0.25f * g[0];
-        u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
-        u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
-        u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
-        u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
-        u[5] = g[2];
-    } else {
-        u[0] = g[0];
-        u[1] = (-2.f / 9.f) * (g[0] + g[1] + g[2]);
-        u[2] = (-2.f / 9.f) * (g[0] - g[1] + g[2]);
-        u[3] = (1.f / 90.f) * g[0] + (1.f / 45.f) * g[1] + (2.f / 45.f) * g[2];
-        u[4] = (1.f / 90.f) * g[0] - (1.f / 45.f) * g[1] + (2.f / 45.f) * g[2];
-        u[5] = (32.f / 45.f) * g[0] + (16.f / 45.f) * g[1] + (8.f / 45.f) * g[2];
-        u[6] = (32.f / 45.f) * g[0] - (16.f / 45.f) * g[1] + (8.f / 45.f) * g[2];
-        u[7] = g[2];
-    }
-}
 
 // ---- (1) input transform: one thread = one (tile, channel quad) ------------------------------------------------------
 // PRE: the tensor being convolved is act(x * sc[n][c] + bi[n][c]) (GroupNorm [+FiLM] [+SiLU] folded into per-image,
@@ -174,7 +86,8 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
             float4 row[AL];
             bt_transform<MO>(t[i], row);  // (B^T d B)[i][.] = B^T applied along the row
 #pragma unroll
-            for (int j = 0; j < AL; ++j) *reinterpret_cast<float4*>(o + (size_t)(i * AL + j) * plane) = row[j];
+            for (int j = 0; j < AL; ++j) { *reinterpret_cast<float4*>(o) = row[j]; o += plane; }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -354,7 +267,9 @@ __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __res
             float2 row[AL];
             bt_transform<MO>(t[i], row);
 #pragma unroll
-            for (int j = 0; j < AL; ++j) *reinterpret_cast<float2*>(o + (size_t)(i * AL + j) * plane) = row[j];
+            for (int j = 0; j < AL; ++j) { *reinterpret_cast<float2*>(o) = row[j]; o += plane; }
+            __builtin_amdgcn_sched_barrier(0);      // rows sequential, ONE walking pointer: the 64 plane addresses computed up front
+                                                    // cost 2 VGPRs each (non-fused variant: 472 VGPRs = 1 wave per SIMD; now 226)
         }
     }
 }
@@ -479,19 +394,11 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
     }
 }
 
-inline size_t tiles_raw(int N, int H, int W, int m) { return (size_t)N * cdiv(H, m) * cdiv(W, m); }
-inline size_t tiles_padded(int N, int H, int W, int m) {
-    return (tiles_raw(N, H, W, m) + 255) / 256 * 256;      // whole 8x32 GEMM tiles
-}
-inline int planes(int m) { return (m + 2) * (m + 2); }
+inline size_t tiles_raw(int N, int H, int W, int m) { return wino_tiles_raw(N, H, W, m); }
+inline size_t tiles_padded(int N, int H, int W, int m) { return wino_tiles_padded(N, H, W, m); }
+inline int planes(int m) { return wino_planes(m); }
 
 }  // namespace
-
-#define BBDM_WINO_M(m) \
-    BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6, "winograd: output tile m=%d unsupported (2, 4 or 6)", (m))
-#define BBDM_WINO_HW(m, H, W)                                                                                          \
-    BBDM_REQUIRE((H) > 0 && (W) > 0 && ((m) == 6 || ((H) % (m) == 0 && (W) % (m) == 0)),                                \
-                 "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)
 
 extern "C" size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad) {
     return (size_t)planes(m) * cdiv(CinPad, KC) * (cdiv(Cout, 128) * 128) * KC;
@@ -668,10 +575,10 @@ extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const f
 
 // Test hook (exported, not part of the public header): the 1-D transforms above evaluated on the HOST, so that the CPU
 // test-suite can check the hand-factored formulas against the transform matrices (tests/test_winograd_math_cpu.py).
-// which: 0 = B^T (m+2 -> m+2), 1 = A^T (m+2 -> m), 2 = G (3 -> m+2).
+// which: 0 = B^T (m+2 -> m+2), 1 = A^T (m+2 -> m), 2 = G (3 -> m+2), 3 = A (m -> m+2), 4 = G^T (m+2 -> 3).
 extern "C" int bbdm_debug_winograd_transform_1d(int m, int which, const float* in, float* out) {
     BBDM_WINO_M(m);
-    BBDM_REQUIRE(in && out && which >= 0 && which <= 2, "winograd_transform_1d: bad args");
+    BBDM_REQUIRE(in && out && which >= 0 && which <= 4, "winograd_transform_1d: bad args");
 #define BBDM_WINO_1D(MO)                                                             \
     do {                                                                             \
         if (which == 0) {                                                            \
@@ -684,11 +591,21 @@ extern "C" int bbdm_debug_winograd_transform_1d(int m, int which, const float* i
             for (int i = 0; i < MO + 2; ++i) v[i] = in[i];                           \
             at_transform<MO>(v, r);                                                  \
             for (int i = 0; i < MO; ++i) out[i] = r[i];                              \
-        } else {                                                                     \
+        } else if (which == 2) {                                                     \
             float g[3], u[MO + 2];                                                   \
             for (int i = 0; i < 3; ++i) g[i] = in[i];                                \
             g_transform<MO>(g, u);                                                   \
             for (int i = 0; i < MO + 2; ++i) out[i] = u[i];                          \
+        } else if (which == 3) {                                                     \
+            float v[MO], r[MO + 2];                                                  \
+            for (int i = 0; i < MO; ++i) v[i] = in[i];                               \
+            a_transform<MO>(v, r);                                                   \
+            for (int i = 0; i < MO + 2; ++i) out[i] = r[i];                          \
+        } else {                                                                     \
+            float u[MO + 2], g[3];                                                   \
+            for (int i = 0; i < MO + 2; ++i) u[i] = in[i];                           \
+            gt_transform<MO>(u, g);                                                  \
+            for (int i = 0; i < 3; ++i) out[i] = g[i];                               \
         }                                                                            \
     } while (0)
     if (m == 2) BBDM_WINO_1D(2); else if (m == 4) BBDM_WINO_1D(4); else BBDM_WINO_1D(6);

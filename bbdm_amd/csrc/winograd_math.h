@@ -1,0 +1,161 @@
+// winograd_math.h -- the 1-D Winograd transforms shared by winograd.hip (forward / data gradient) and winograd_wgrad.hip
+// (weight gradient).  Host + device: bbdm_debug_winograd_transform_1d runs the same code on the CPU for the tests
+// (tests/test_winograd_math_cpu.py checks every hand-factored formula against its transform matrix).
+#pragma once
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float2 operator+(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 operator-(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 operator*(float s, float2 a) { return make_float2(s * a.x, s * a.y); }
+
+// ---- the 1-D transforms (host + device: bbdm_debug_winograd_transform_1d runs the same code on the CPU for the tests) ---
+// t = B^T d.  m = 2: points {0, 1, -1, inf}; m = 4: points {0, 1, -1, 2, -2, inf} (Lavin & Gray, arXiv:1509.09308).
+template <int MO, typename T>
+__host__ __device__ __forceinline__ void bt_transform(const T (&d)[MO + 2], T (&t)[MO + 2]) {
+    if constexpr (MO == 2) {
+        t[0] = d[0] - d[2];
+        t[1] = d[1] + d[2];
+        t[2] = d[2] - d[1];
+        t[3] = d[1] - d[3];
+    } else if constexpr (MO == 4) {
+        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        t[1] = (d[3] + d[4]) - 4.f * (d[1] + d[2]);
+        t[2] = 4.f * (d[1] - d[2]) + (d[4] - d[3]);
+        t[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
+        t[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
+        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    } else {        // m = 6: points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (the 8x8 transform of NNPACK / wincnn)
+        const T e0 = (d[2] + d[6]) - 4.25f * d[4], o0 = (d[1] + d[5]) - 4.25f * d[3];
+        const T e1 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], o1 = (0.5f * d[1] + 2.f * d[5]) - 2.5f * d[3];
+        const T e2 = (d[6] + 4.f * d[2]) - 5.f * d[4], o2 = (2.f * d[1] + 0.5f * d[5]) - 2.5f * d[3];
+        t[0] = (d[0] - d[6]) + 5.25f * (d[4] - d[2]);
+        t[1] = e0 + o0;
+        t[2] = e0 - o0;
+        t[3] = e1 + o1;
+        t[4] = e1 - o1;
+        t[5] = e2 + o2;
+        t[6] = e2 - o2;
+        t[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+    }
+}
+// s = A^T m
+template <int MO, typename T>
+__host__ __device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&s)[MO]) {
+    if constexpr (MO == 2) {
+        s[0] = m[0] + m[1] + m[2];
+        s[1] = m[1] - m[2] - m[3];
+    } else if constexpr (MO == 4) {
+        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4];
+        s[0] = m[0] + p12 + p34;
+        s[1] = m12 + 2.f * m34;
+        s[2] = p12 + 4.f * p34;
+        s[3] = m12 + 8.f * m34 + m[5];
+    } else {
+        const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4], p56 = m[5] + m[6],
+                m56 = m[5] - m[6];
+        s[0] = m[0] + p12 + p34 + p56;
+        s[1] = m12 + 2.f * m34 + 0.5f * m56;
+        s[2] = p12 + 4.f * p34 + 0.25f * p56;
+        s[3] = m12 + 8.f * m34 + 0.125f * m56;
+        s[4] = p12 + 16.f * p34 + 0.0625f * p56;
+        s[5] = m12 + 32.f * m34 + 0.03125f * m56 + m[7];
+    }
+}
+// u = G g
+template <int MO>
+__host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
+    if constexpr (MO == 2) {
+        u[0] = g[0];
+        u[1] = 0.5f * (g[0] + g[1] + g[2]);
+        u[2] = 0.5f * (g[0] - g[1] + g[2]);
+        u[3] = g[2];
+    } else if constexpr (MO == 4) {
+        u[0] = 0.25f * g[0];
+        u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
+        u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
+        u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+        u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+        u[5] = g[2];
+    } else {
+        u[0] = g[0];
+        u[1] = (-2.f / 9.f) * (g[0] + g[1] + g[2]);
+        u[2] = (-2.f / 9.f) * (g[0] - g[1] + g[2]);
+        u[3] = (1.f / 90.f) * g[0] + (1.f / 45.f) * g[1] + (2.f / 45.f) * g[2];
+        u[4] = (1.f / 90.f) * g[0] - (1.f / 45.f) * g[1] + (2.f / 45.f) * g[2];
+        u[5] = (32.f / 45.f) * g[0] + (16.f / 45.f) * g[1] + (8.f / 45.f) * g[2];
+        u[6] = (32.f / 45.f) * g[0] - (16.f / 45.f) * g[1] + (8.f / 45.f) * g[2];
+        u[7] = g[2];
+    }
+}
+
+// t = A s (the transpose of at_transform: m -> m+2; the dY side of the weight gradient, dM = A dY A^T)
+template <int MO, typename T>
+__host__ __device__ __forceinline__ void a_transform(const T (&s)[MO], T (&t)[MO + 2]) {
+    if constexpr (MO == 2) {
+        t[0] = s[0];
+        t[1] = s[0] + s[1];
+        t[2] = s[0] - s[1];
+        t[3] = -1.f * s[1];
+    } else if constexpr (MO == 4) {
+        const T e = s[0] + s[2], o = s[1] + s[3], e2 = s[0] + 4.f * s[2], o2 = 2.f * s[1] + 8.f * s[3];
+        t[0] = s[0];
+        t[1] = e + o;
+        t[2] = e - o;
+        t[3] = e2 + o2;
+        t[4] = e2 - o2;
+        t[5] = s[3];
+    } else {
+        const T e1 = (s[0] + s[2]) + s[4], o1 = (s[1] + s[3]) + s[5];
+        const T e2 = (s[0] + 4.f * s[2]) + 16.f * s[4], o2 = (2.f * s[1] + 8.f * s[3]) + 32.f * s[5];
+        const T e3 = (s[0] + 0.25f * s[2]) + 0.0625f * s[4], o3 = (0.5f * s[1] + 0.125f * s[3]) + 0.03125f * s[5];
+        t[0] = s[0];
+        t[1] = e1 + o1;
+        t[2] = e1 - o1;
+        t[3] = e2 + o2;
+        t[4] = e2 - o2;
+        t[5] = e3 + o3;
+        t[6] = e3 - o3;
+        t[7] = s[5];
+    }
+}
+// g = G^T u (the transpose of g_transform: m+2 -> 3; the last step of the weight gradient, dg = G^T dU G)
+template <int MO>
+__host__ __device__ __forceinline__ void gt_transform(const float (&u)[MO + 2], float (&g)[3]) {
+    if constexpr (MO == 2) {
+        const float p = 0.5f * (u[1] + u[2]);
+        g[0] = u[0] + p;
+        g[1] = 0.5f * (u[1] - u[2]);
+        g[2] = p + u[3];
+    } else if constexpr (MO == 4) {
+        const float p12 = u[1] + u[2], m12 = u[1] - u[2], p34 = u[3] + u[4], m34 = u[3] - u[4];
+        g[0] = 0.25f * u[0] - (1.f / 6.f) * p12 + (1.f / 24.f) * p34;
+        g[1] = (1.f / 12.f) * m34 - (1.f / 6.f) * m12;
+        g[2] = (1.f / 6.f) * (p34 - p12) + u[5];
+    } else {
+        const float p12 = u[1] + u[2], m12 = u[1] - u[2], p34 = u[3] + u[4], m34 = u[3] - u[4], p56 = u[5] + u[6],
+                    m56 = u[5] - u[6];
+        g[0] = u[0] - (2.f / 9.f) * p12 + (1.f / 90.f) * p34 + (32.f / 45.f) * p56;
+        g[1] = (1.f / 45.f) * m34 + (16.f / 45.f) * m56 - (2.f / 9.f) * m12;
+        g[2] = (2.f / 45.f) * p34 + (8.f / 45.f) * p56 - (2.f / 9.f) * p12 + u[7];
+    }
+}
+
+inline size_t wino_tiles_raw(int N, int H, int W, int m) { return (size_t)N * cdiv(H, m) * cdiv(W, m); }
+inline size_t wino_tiles_padded(int N, int H, int W, int m) {
+    return (wino_tiles_raw(N, H, W, m) + 255) / 256 * 256;      // whole 8x32 GEMM tiles
+}
+inline int wino_planes(int m) { return (m + 2) * (m + 2); }
+
+}  // namespace
+
+#define BBDM_WINO_M(m) \
+    BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6, "winograd: output tile m=%d unsupported (2, 4 or 6)", (m))
+#define BBDM_WINO_HW(m, H, W)                                                                                          \
+    BBDM_REQUIRE((H) > 0 && (W) > 0 && ((m) == 6 || ((H) % (m) == 0 && (W) % (m) == 0)),                                \
+                 "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)

@@ -413,6 +413,20 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6) -
     return 0
 
 
+def winograd_wgrad_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6) -> int:
+    """Tile m of the Winograd-domain WEIGHT gradient (csrc/winograd_wgrad.hip) for this 3x3 layer, or 0 = the direct
+    kernel (conv_wgrad.hip).  The (m+2)^2 TN GEMMs contract over the tiles, so what matters is a long K (tiles) and
+    operands wide enough for 128-wide MFMA tiles; ragged m = 6 tiles only pay while the edge waste stays small."""
+    if cin % 4 or cout % 4 or cin < 64 or cout < 64:
+        return 0
+    t6h, t6w = -(-H // 6), -(-W // 6)
+    if max_m >= 6 and N * t6h * t6w >= 900 and (6 * t6h) * (6 * t6w) <= 1.10 * H * W:
+        return 6
+    if max_m >= 4 and H % 4 == 0 and W % 4 == 0 and N * (H // 4) * (W // 4) >= 256:
+        return 4
+    return 0
+
+
 # --------------------------------------------------------------------------------------------------------------
 # the model
 # --------------------------------------------------------------------------------------------------------------
@@ -549,6 +563,9 @@ class UNetModel(nn.Module):
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
+        # Training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
+        # BBDM_WINOGRAD_WGRAD=0: the direct kernel (conv_wgrad.hip) everywhere.
+        self.winograd_wgrad: int = int(os.environ.get("BBDM_WINOGRAD_WGRAD", "6"))
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -592,7 +609,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats)
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats, self.winograd_wgrad)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -801,6 +818,16 @@ class _Plan:
         if name == "bbdm_attention_f32":
             N, T, heads, ch = args[5:9]
             return 2.0 * 2.0 * N * heads * T * T * ch
+        # training (gradient plan)
+        if name == "bbdm_conv_wgrad_f32":
+            N, H, W, cin, cout, ks = args[7:13]
+            return 2.0 * N * H * W * cout * cin * ks * ks
+        if name == "bbdm_conv3x3_winograd_wgrad_f32":   # the (m+2)^2 TN GEMMs actually executed
+            wm, (N, H, W, cin, cout) = args[0], args[8:13]
+            return 2.0 * (wm + 2) ** 2 * N * -(-H // wm) * -(-W // wm) * cin * cout
+        if name == "bbdm_attention_bwd_f32":            # S recomputed + dP, dV, dQ, dK: five T x T x ch products
+            N, T, heads, ch = args[10:14]
+            return 5.0 * 2.0 * N * heads * T * T * ch
         return 0.0
 
     def activation_bytes(self):
@@ -1249,8 +1276,16 @@ class _Plan:
                 t = torch.empty(cout, x_in.C, ks, ks, dtype=torch.float32, device=dev)
                 self._padded_wgrads.append((w, t))
                 dw_dst = _TensorRef(t)
-            self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst,
-                      gref(mod.bias) if mod.bias is not None else None, self._ws_f, N, x_in.H, x_in.W, x_in.C, cout, ks)
+            wgm = (winograd_wgrad_tile(N, x_in.H, x_in.W, x_in.C, cout, m.winograd_wgrad)
+                   if (m.winograd_wgrad and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
+            dbias = gref(mod.bias) if mod.bias is not None else None
+            if wgm:
+                ws_floats[0] = max(ws_floats[0], lib.bbdm_winograd_wgrad_workspace_floats(wgm, N, x_in.H, x_in.W, x_in.C, cout))
+                self._bop("bbdm_conv3x3_winograd_wgrad_f32", wgm, x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N,
+                          x_in.H, x_in.W, x_in.C, cout)
+            else:
+                self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N, x_in.H, x_in.W,
+                          x_in.C, cout, ks)
             if not need_dx:
                 return None
             dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
@@ -1480,9 +1515,17 @@ class _Plan:
         lib = self.lib
         ops = self.bops[lo:hi] + (self.bops_x0 if (last and need_dx) else [])
         check = _lib.check
+        prof = self.m.op_profile
         for name, args in ops:
             fn = getattr(lib, getattr(name, "entry", name))
-            rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
+            if prof is None:
+                rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
+            else:                                   # per-op HIP events (bench.py's roofline leg), as in _launch_forward
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
+                e1.record()
+                prof.append((str(name) + ":bwd", e0, e1, self._algorithmic_flops(str(name), args)))
             if rc != 0:
                 check(rc, name)
         if not last:

@@ -336,7 +336,8 @@ def main():
 
     # barrier + synchronize on both sides, MAX over ranks (bbdm_amd/dist_utils.py)
     elapsed = dist_utils.timed_region(timed, dist, dev)
-    if plan_graph:
+    if plan_graph or training:
+        # (training: the timed region is the plain product path as well; forward AND gradient-plan launches are timed here)
         model.denoise_fn.op_profile = prof
         timed()
         torch.cuda.synchronize(dev)
@@ -388,8 +389,11 @@ def main():
                 f.write(f"| {k} | {name.replace('bbdm_', '')} | {shp} | {ms:.3f} | {tf:.1f} |\n")
     # conv_igemm_f32 is launched by the direct convolutions and by the 16-GEMM stage of the Winograd layers; the
     # roofline counts the FLOPs the kernel EXECUTES (for a Winograd layer 4/9 of the direct-convolution FLOPs).
-    direct = by.get("bbdm_conv2d_nhwc_f32", [0, 0.0, 0.0])
-    wino = by.get("bbdm_winograd_gemm_f32", [0, 0.0, 0.0])
+    def both(name):                 # forward launches + the same entry point launched by the gradient plan (":bwd")
+        f, b = by.get(name, [0, 0.0, 0.0]), by.get(name + ":bwd", [0, 0.0, 0.0])
+        return [f[0] + b[0], f[1] + b[1], f[2] + b[2]]
+    direct = both("bbdm_conv2d_nhwc_f32")
+    wino = both("bbdm_winograd_gemm_f32")
     conv = [direct[0] + wino[0], direct[1] + wino[1], direct[2] + wino[2]]
     executed_flops_per_step = sum(v[2] for v in by.values()) / max(1, args.steps)
     # SURVEY.md §8d's algorithmic figure is the direct-convolution count: a Winograd GEMM stands for 2.25x its FLOPs
@@ -418,7 +422,7 @@ def main():
     avg_launch_ms = conv_ms / max(1, conv_launches)
     achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
     # whole step against the matrix peaks: time-at-peak of every MFMA kernel's work / step time
-    c1x1 = by.get("bbdm_conv1x1_bf3_f32", [0, 0.0, 0.0])            # wide 1x1 convs / Linears on the same bf16x3 kernel
+    c1x1 = both("bbdm_conv1x1_bf3_f32")                             # wide 1x1 convs / Linears on the same bf16x3 kernel
     bf3_flops = ((wino[2] if use_bf3 else 0.0) + c1x1[2]) / max(1, args.steps)
     t_at_peak = (executed_flops_per_step - bf3_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
         bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12)

@@ -143,6 +143,23 @@ int bbdm_conv_pack_weight_dgrad_f32(const float* w_oihw, float* packed, int Cout
 size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks);
 int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* ws,
                         int N, int H, int W, int Cin, int Cout, int ks, void* stream);
+/* The same weight gradient for ks = 3, stride 1 in the Winograd domain (csrc/winograd_wgrad.hip): dU_xi = V_xi^T dM_xi over
+ * the tiles with V = B^T d B (bbdm_winograd_input_f32) and dM = A dY A^T, then dW = G^T dU G -- (m+2)^2 / (9 m^2) of the
+ * direct FLOPs.  m = 2, 4 (H, W multiples of m) or 6 (any H, W); Cin % 4 == 0, Cout % 4 == 0.  Deterministic (K splits are
+ * added in a fixed order).  ws: bbdm_winograd_wgrad_workspace_floats() floats, 16-byte aligned.
+ *   bbdm_conv3x3_winograd_wgrad_f32 chains the stages below (+ bbdm_colsum_f32 for dbias != NULL):
+ *   bbdm_winograd_dy_transform_f32 : dy NHWC (pitch ld) -> dM[(m+2)^2][bbdm_winograd_tiles()][Cout]
+ *   bbdm_gemm_tn_batched_f32       : C[z][b][M][N] = sum_{k in K-range z} A[b][k][M] B[b][k][N] (fp32 MFMA; z <
+ *                                    bbdm_gemm_tn_splits(batch, K, M, N) partial sums for the consumer to add in order)
+ *   bbdm_winograd_wgrad_finish_f32 : dU[splits][(m+2)^2][Cin][Cout] -> dW OIHW. */
+size_t bbdm_winograd_wgrad_workspace_floats(int m, int N, int H, int W, int Cin, int Cout);
+int bbdm_conv3x3_winograd_wgrad_f32(int m, const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias,
+                                    float* ws, int N, int H, int W, int Cin, int Cout, void* stream);
+int bbdm_winograd_dy_transform_f32(int m, const float* dy, int ld, float* dM, int N, int H, int W, int Cout, void* stream);
+int bbdm_gemm_tn_splits(int batch, long long K, int M, int N);
+int bbdm_gemm_tn_batched_f32(const float* A, int lda, size_t a_stride, const float* B, int ldb, size_t b_stride, float* C,
+                             int batch, long long K, int M, int N, void* stream);
+int bbdm_winograd_wgrad_finish_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, void* stream);
 /* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: fp64[C] scratch. */
 int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream);
 /* Per-image column sums out[n*ldo + c] = sum_{m < M} dy[(n*M + m)*ld + c] (gradient of a per-image broadcast add).

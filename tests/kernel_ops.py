@@ -266,6 +266,34 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, cin: int, cout: int, ks: int, 
     return (dw, db) if with_bias else dw
 
 
+def conv3x3_winograd_wgrad(x: torch.Tensor, dy: torch.Tensor, cout: int, m: int, with_bias: bool = False):
+    """x: [N,H,W,Cin], dy: [N,H,W,>=cout] -> dW [cout, Cin, 3, 3] (+ db) through the Winograd-domain weight gradient."""
+    _chk(x, dy)
+    N, H, W, cin = x.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.bbdm_winograd_wgrad_workspace_floats(m, N, H, W, cin, cout), dtype=torch.float32, device=x.device)
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if with_bias else None
+    _lib.call("bbdm_conv3x3_winograd_wgrad_f32", m, x.data_ptr(), cin, dy.data_ptr(), dy.shape[-1], dw.data_ptr(),
+              None if db is None else db.data_ptr(), ws.data_ptr(), N, H, W, cin, cout, _st(x))
+    return (dw, db) if with_bias else dw
+
+
+def gemm_tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a: [batch, K, M], b: [batch, K, N] -> sum over the K splits of C[z][batch][M][N] = a^T b (fp32 MFMA)."""
+    _chk(a, b)
+    batch, K, M = a.shape
+    N = b.shape[2]
+    lib = _lib.load()
+    splits = lib.bbdm_gemm_tn_splits(batch, K, M, N)
+    c = torch.empty(splits, batch, M, N, dtype=torch.float32, device=a.device)
+    _lib.call("bbdm_gemm_tn_batched_f32", a.data_ptr(), M, K * M, b.data_ptr(), N, K * N, c.data_ptr(), batch, K, M, N, _st(a))
+    out = c[0].clone()
+    for z in range(1, splits):
+        out += c[z]
+    return out
+
+
 def colsum(dy: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     _chk(dy)
     ld = dy.shape[-1]

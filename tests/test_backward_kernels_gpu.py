@@ -58,6 +58,47 @@ def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
     assert rel_err(db.cpu(), b.grad) < TOL and rel_err(db2.cpu(), b.grad) < TOL
 
 
+# (m, N, H, W, Cin, Cout): the Winograd-domain weight gradient (csrc/winograd_wgrad.hip) incl. ragged m = 6 tiles, K splits,
+# both GEMM tile heights (Cin % 256 == 0 or not) and the LBBDM-f4 training layer shapes at batch 2
+WINO_WGRAD = [(2, 2, 8, 8, 16, 24), (4, 1, 8, 12, 32, 64), (6, 2, 12, 12, 64, 128), (6, 1, 7, 10, 16, 8), (6, 3, 16, 20, 48, 72),
+              (4, 2, 16, 16, 256, 132), (6, 2, 64, 64, 128, 128), (6, 2, 64, 64, 640, 128), (4, 2, 32, 32, 512, 512),
+              (4, 2, 32, 32, 1536, 512), (4, 2, 16, 16, 1024, 1024), (4, 2, 16, 16, 2048, 1024), (6, 8, 64, 64, 256, 128)]
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", WINO_WGRAD)
+def test_winograd_wgrad(dev, m, N, H, W, Cin, Cout):
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(m + N + H + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, b, padding=1).backward(dy.double())              # fp64 reference gradient
+    pitch = Cout + 8                                                         # dy as a channel slice of a wider buffer
+    dyg = torch.randn(N, H, W, pitch, generator=g)
+    dyg[..., :Cout] = _nhwc(dy)
+    dw, db = ops.conv3x3_winograd_wgrad(_nhwc(x).to(dev), dyg.to(dev), Cout, m, with_bias=True)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    e = rel_err(dw.cpu(), w.grad.float())
+    print(f"winograd wgrad m={m} N{N} {H}x{W} {Cin}->{Cout}: rel err {e:.2e}")
+    # against the fp64 gradient; fp32 Winograd rounding grows with the tile (tests/test_winograd_math_cpu.py) and with the
+    # number of pixels summed: measured 3e-7 (m = 2) ... 2.8e-5 (m = 6, 8 x 64 x 64 pixels) -- gradient bar: 1e-3
+    assert e < 1e-4
+    assert rel_err(db.cpu(), b.grad.float()) < TOL
+
+
+@pytest.mark.parametrize("batch,K,M,N", [(3, 40, 64, 36), (2, 1000, 256, 128), (36, 512, 132, 260), (1, 5000, 128, 128)])
+def test_gemm_tn_batched(dev, batch, K, M, N):
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(batch + K + M + N)
+    a = torch.randn(batch, K, M, generator=g)
+    b = torch.randn(batch, K, N, generator=g)
+    want = torch.einsum("bkm,bkn->bmn", a.double(), b.double()).float()
+    got = ops.gemm_tn_batched(a.to(dev), b.to(dev))
+    assert rel_err(got.cpu(), want) < 1e-5
+
+
 GN_BWD = [(2, 16, 16, 128), (1, 8, 8, 640), (2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32), (2, 32, 32, 256),
           (2, 16, 16, 2048), (2, 32, 32, 1536), (2, 64, 64, 640), (2, 16, 16, 1024)]      # full-size UNet layers
 

@@ -126,6 +126,16 @@ def test_conv_backward(N, H, W, Cin, Cout, ks):
     BK.test_conv_backward(CPU, N, H, W, Cin, Cout, ks)
 
 
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [c for c in BK.WINO_WGRAD if c[1] * c[2] * c[3] * c[4] * c[5] <= 6e6])
+def test_winograd_wgrad(m, N, H, W, Cin, Cout):
+    BK.test_winograd_wgrad(CPU, m, N, H, W, Cin, Cout)
+
+
+@pytest.mark.parametrize("batch,K,M,N", [(3, 40, 64, 36), (2, 1000, 256, 128), (4, 512, 132, 260)])
+def test_gemm_tn_batched(batch, K, M, N):
+    BK.test_gemm_tn_batched(CPU, batch, K, M, N)
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 4, 4, 1536), (2, 8, 8, 96), (3, 16, 16, 32)])
 @pytest.mark.parametrize("mode", ["plain", "film_silu", "silu_pool", "silu_up", "silu_add_acc"])
 def test_groupnorm_backward(N, H, W, C, mode):

@@ -89,3 +89,34 @@ def test_groupnorm_statistics_fused_into_the_producers():
     ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
     assert rel_err(outs[True], outs[False]) < 1e-6
     assert rel_err(outs[True], ref) < M.STEP_TOL
+
+
+def test_weight_gradients_in_the_winograd_domain():
+    """Training plan of a UNet with enough tiles (16 images of 16x16 = 256 4x4 tiles, 64 channels) for the 3x3 layers' weight
+    gradients to take the Winograd-domain path (csrc/winograd_wgrad.hip): every parameter gradient against the oracle's
+    autograd."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 41)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.train()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(16, 4, 16, 16, generator=g)
+    t = torch.arange(16) * 5 + 2
+    dout = torch.randn(16, 4, 16, 16, generator=g)
+    (m(x, timesteps=t, context=None) * dout).sum().backward()
+    plan = m._plan_for(x, True)
+    assert sum(str(n) == "bbdm_conv3x3_winograd_wgrad_f32" for n, _ in plan.bops) >= 4
+    sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    (O.unet_forward(sdg, O.UNetSpec(**up), x, t, None) * dout).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for v in sdg.values())
+    for k, p in m.named_parameters():
+        ref = sdg[k].grad
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
+        assert float((p.grad - ref).abs().max()) / scale < T.GRAD_TOL, k
