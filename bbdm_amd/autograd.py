@@ -58,6 +58,9 @@ class _UNetSeg(torch.autograd.Function):
                 dx = nchw[:, :ctx.cx].contiguous()
             if need_ctx:
                 dctx = nchw[:, ctx.cx:ctx.cx + ctx.cctx].contiguous()
+                via_attention = plan.context_token_grad()         # SpatialTransformer: + the cross-attention keys / values
+                if via_attention is not None:
+                    dctx = dctx + via_attention
         dtoken = None if link == 0 else torch.zeros(1, dtype=torch.float32, device=plan.device)
         return (None, None, None, dx, None, dctx, dtoken, *grads)
 

@@ -228,14 +228,14 @@ extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo
 // tokens, k / v [N][Tk][heads*ch] from the context tokens (Tk != Tq in general; k = v source = x for self-attention),
 // softmax_j(q_i . k_j * ch^-1/2) v_j, heads laid out 'b n (h d)'.
 extern "C" int bbdm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo,
-                                        int N, int Tq, int Tk, int heads, int ch, void* stream) {
+                                        float* lse, int N, int Tq, int Tk, int heads, int ch, void* stream) {
     BBDM_REQUIRE(q && k && v && out, "cross_attention: null pointer");
     BBDM_REQUIRE(N > 0 && Tq > 0 && Tk > 0 && heads > 0, "cross_attention: bad shape");
     BBDM_REQUIRE(ch == 16 || ch == 32 || ch == 64, "cross_attention: head channels %d unsupported (16, 32, 64)", ch);
     BBDM_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldq >= heads * ch && ldkv >= heads * ch && ldo >= heads * ch &&
                      (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0,
                  "cross_attention: bad pitch / alignment");
-    launch_attention(q, ldq, ch, k, v, ldkv, ch, out, ldo, nullptr, N, Tq, Tk, heads, ch, 1.0f / sqrtf((float)ch), 1.0f,
+    launch_attention(q, ldq, ch, k, v, ldkv, ch, out, ldo, lse, N, Tq, Tk, heads, ch, 1.0f / sqrtf((float)ch), 1.0f,
                      (hipStream_t)stream);
     BBDM_CHECK_LAUNCH("cross_attention");
     return BBDM_OK;

@@ -7,6 +7,9 @@
 //   qs = q s, ks = k s (s = ch^-1/4),  S = qs.ks,  P = exp(S - lse),  O = P V
 //   D[t]  = sum_c dO[t,c] O[t,c]                                   (prep kernel)
 //   dS    = P o (dO.V^T - D),  dq = s sum_s dS ks,  dk = s sum_t dS qs,  dv = sum_t P dO
+// The kernels take q / k / v / dq / dk / dv as separate pointers with their own pitches and per-head channel strides, Tq
+// queries against Tk keys and separate q / k scales: the packed-qkv self-attention of the AttentionBlock (s = ch^-1/4 on both)
+// and CrossAttention (attention.py:170-194: q scaled by ch^-1/2, keys / values from the context tokens, Tk != Tq) share them.
 // Two kernels in the same transposed-operand style as the forward (a query / a key is a LANE, so lse and D are
 // per-lane scalars and the recomputed P / dS registers are used in place as the next MFMA's B operand):
 //   attn_bwd_dq  : workgroup = 128 queries, streams key tiles   -> dq
@@ -17,10 +20,6 @@ namespace {
 
 constexpr int TT = 32;         // streamed tile (keys in dq, queries in dkv)
 constexpr int BB = 128;        // rows owned by a block
-
-__device__ __forceinline__ int part_off(int new_order, int heads, int CH, int h, int part) {
-    return new_order ? part * heads * CH + h * CH : h * 3 * CH + part * CH;
-}
 
 // D[n][h][t] = sum_c dO[n,t,h*CH+c] * O[n,t,h*CH+c]
 __global__ void attn_bwd_prep_kernel(const float* __restrict__ out, int ldo, const float* __restrict__ dout, int lddo,
@@ -62,11 +61,13 @@ __device__ __forceinline__ void store_rows(float* stage, const f32x16 (&acc)[CT]
 }
 
 template <int CH>
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ qkv, int ldq,
-                                                          const float* __restrict__ dout, int lddo,
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
+                                                          const float* __restrict__ ksrc, const float* __restrict__ vsrc,
+                                                          int ldkv, int hskv, const float* __restrict__ dout, int lddo,
                                                           const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                          float* __restrict__ dqkv, int lddq, int T, int heads,
-                                                          int new_order, float scale) {
+                                                          float* __restrict__ dqdst, int lddq, int Tq, int T, int heads,
+                                                          float qscale, float scale) {
+    // T = number of keys; q / dq rows [N][Tq], head h at channel h * hsq; k, v rows [N][T], head h at channel h * hskv
     constexpr int KP = CH + 4;
     constexpr int CT = (CH + 31) / 32;
     constexpr int KG = CH / 8;
@@ -80,27 +81,27 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     float* vbuf = smem + 2 * TILE;      // [2][TT][KP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, lq = lane & 31;
-    const int qblocks = (T + BB - 1) / BB;
+    const int qblocks = (Tq + BB - 1) / BB;
     const int qb = blockIdx.x % qblocks, nh = blockIdx.x / qblocks, h = nh % heads, n = nh / heads;
-    const int qoff = part_off(new_order, heads, CH, h, 0), koff = part_off(new_order, heads, CH, h, 1),
-              voff = part_off(new_order, heads, CH, h, 2);
-    const float* base = qkv + (size_t)n * T * ldq;
-    const float* dob = dout + (size_t)n * T * lddo + h * CH;
+    const float* qbase = qsrc + (size_t)n * Tq * ldq + h * hsq;
+    const float* kbase = ksrc + (size_t)n * T * ldkv + h * hskv;
+    const float* vbase = vsrc + (size_t)n * T * ldkv + h * hskv;
+    const float* dob = dout + (size_t)n * Tq * lddo + h * CH;
     const int q = qb * BB + wave * 32 + lq;
-    const bool qok = q < T;
+    const bool qok = q < Tq;
 
     float4 qf[KG], dof[KG];
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) {
         qf[kg] = dof[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (qok) {
-            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)q * ldq + qoff + kg * 8 + hi * 4);
-            qf[kg] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+            const float4 v = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + kg * 8 + hi * 4);
+            qf[kg] = make_float4(v.x * qscale, v.y * qscale, v.z * qscale, v.w * qscale);
             dof[kg] = *reinterpret_cast<const float4*>(dob + (size_t)q * lddo + kg * 8 + hi * 4);
         }
     }
-    const float Lq = qok ? lse[((size_t)n * heads + h) * T + q] : 0.f;
-    const float Dq = qok ? Dv[((size_t)n * heads + h) * T + q] : 0.f;
+    const float Lq = qok ? lse[((size_t)n * heads + h) * Tq + q] : 0.f;
+    const float Dq = qok ? Dv[((size_t)n * heads + h) * Tq + q] : 0.f;
 
     f32x16 dq[CT];
 #pragma unroll
@@ -116,10 +117,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
             const int key = tile * TT + f / (CH / 4), c = (f % (CH / 4)) * 4;
             kreg[s] = vreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (f < KV4 && key < T) {
-                const float* row = base + (size_t)key * ldq;
-                const float4 kv = *reinterpret_cast<const float4*>(row + koff + c);
+                const float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)key * ldkv + c);
                 kreg[s] = make_float4(kv.x * scale, kv.y * scale, kv.z * scale, kv.w * scale);
-                vreg[s] = *reinterpret_cast<const float4*>(row + voff + c);
+                vreg[s] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ldkv + c);
             }
         }
     };
@@ -181,15 +181,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
         if (tile + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
-    store_rows<CH, CT>(smem, dq, scale, dqkv + (size_t)n * T * lddq + qoff, lddq, qb * BB, T, wave, lq, hi, tid);
+    store_rows<CH, CT>(smem, dq, qscale, dqdst + (size_t)n * Tq * lddq + h * hsq, lddq, qb * BB, Tq, wave, lq, hi, tid);
 }
 
 template <int CH>
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ qkv, int ldq,
-                                                           const float* __restrict__ dout, int lddo,
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
+                                                           const float* __restrict__ ksrc, const float* __restrict__ vsrc,
+                                                           int ldkv, int hskv, const float* __restrict__ dout, int lddo,
                                                            const float* __restrict__ lse, const float* __restrict__ Dv,
-                                                           float* __restrict__ dqkv, int lddq, int T, int heads,
-                                                           int new_order, float scale) {
+                                                           float* __restrict__ dkdst, float* __restrict__ dvdst, int lddkv,
+                                                           int Tq, int T, int heads, float qscale, float scale) {
     constexpr int KP = CH + 4;
     constexpr int CT = (CH + 31) / 32;
     constexpr int KG = CH / 8;
@@ -206,12 +207,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, lq = lane & 31;
     const int kblocks = (T + BB - 1) / BB;
     const int kb_ = blockIdx.x % kblocks, nh = blockIdx.x / kblocks, h = nh % heads, n = nh / heads;
-    const int qoff = part_off(new_order, heads, CH, h, 0), koff = part_off(new_order, heads, CH, h, 1),
-              voff = part_off(new_order, heads, CH, h, 2);
-    const float* base = qkv + (size_t)n * T * ldq;
-    const float* dob = dout + (size_t)n * T * lddo + h * CH;
-    const float* lrow = lse + ((size_t)n * heads + h) * T;
-    const float* drow = Dv + ((size_t)n * heads + h) * T;
+    const float* qbase = qsrc + (size_t)n * Tq * ldq + h * hsq;
+    const float* kbase = ksrc + (size_t)n * T * ldkv + h * hskv;
+    const float* vbase = vsrc + (size_t)n * T * ldkv + h * hskv;
+    const float* dob = dout + (size_t)n * Tq * lddo + h * CH;
+    const float* lrow = lse + ((size_t)n * heads + h) * Tq;
+    const float* drow = Dv + ((size_t)n * heads + h) * Tq;
     const int key = kb_ * BB + wave * 32 + lq;
     const bool kok = key < T;
 
@@ -220,10 +221,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     for (int kg = 0; kg < KG; ++kg) {
         kf[kg] = vf[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (kok) {
-            const float* row = base + (size_t)key * ldq;
-            const float4 a = *reinterpret_cast<const float4*>(row + koff + kg * 8 + hi * 4);
+            const float4 a = *reinterpret_cast<const float4*>(kbase + (size_t)key * ldkv + kg * 8 + hi * 4);
             kf[kg] = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
-            vf[kg] = *reinterpret_cast<const float4*>(row + voff + kg * 8 + hi * 4);
+            vf[kg] = *reinterpret_cast<const float4*>(vbase + (size_t)key * ldkv + kg * 8 + hi * 4);
         }
     }
     f32x16 dk[CT], dv[CT];
@@ -240,16 +240,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
             const int f = tid + s * 256;
             const int qq = tile * TT + f / (CH / 4), c = (f % (CH / 4)) * 4;
             qreg[s] = dreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < KV4 && qq < T) {
-                const float4 a = *reinterpret_cast<const float4*>(base + (size_t)qq * ldq + qoff + c);
-                qreg[s] = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+            if (f < KV4 && qq < Tq) {
+                const float4 a = *reinterpret_cast<const float4*>(qbase + (size_t)qq * ldq + c);
+                qreg[s] = make_float4(a.x * qscale, a.y * qscale, a.z * qscale, a.w * qscale);
                 dreg[s] = *reinterpret_cast<const float4*>(dob + (size_t)qq * lddo + c);
             }
         }
         if (tid < TT) {
             const int qq = tile * TT + tid;
-            lreg = qq < T ? lrow[qq] : 0.f;
-            ddreg = qq < T ? drow[qq] : 0.f;
+            lreg = qq < Tq ? lrow[qq] : 0.f;
+            ddreg = qq < Tq ? drow[qq] : 0.f;
         }
     };
     auto store_tile = [&](int buf) {
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     };
     for (int i = tid; i < SMEM; i += 256) smem[i] = 0.f;
     __syncthreads();
-    const int ntiles = (T + TT - 1) / TT;
+    const int ntiles = (Tq + TT - 1) / TT;
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) {
             const int ql = (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int qq = q0 + (r & 3) + 8 * (r >> 2);
-            const float pr = (qq < T && kok) ? __expf(s[r] - lbuf[buf * TT + ql]) : 0.f;
+            const float pr = (qq < Tq && kok) ? __expf(s[r] - lbuf[buf * TT + ql]) : 0.f;
             p[r] = pr;
             s[r] = pr * (dp[r] - lbuf[2 * TT + buf * TT + ql]);        // dS
         }
@@ -320,20 +320,35 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         if (tile + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
-    float* dbase = dqkv + (size_t)n * T * lddq;
-    store_rows<CH, CT>(smem, dk, scale, dbase + koff, lddq, kb_ * BB, T, wave, lq, hi, tid);
-    store_rows<CH, CT>(smem, dv, 1.0f, dbase + voff, lddq, kb_ * BB, T, wave, lq, hi, tid);
+    const size_t doff = (size_t)n * T * lddkv + h * hskv;
+    store_rows<CH, CT>(smem, dk, scale, dkdst + doff, lddkv, kb_ * BB, T, wave, lq, hi, tid);
+    store_rows<CH, CT>(smem, dv, 1.0f, dvdst + doff, lddkv, kb_ * BB, T, wave, lq, hi, tid);
 }
 
 template <int CH>
-void launch_bwd(const float* qkv, int ldq, const float* dout, int lddo, const float* lse, const float* D, float* dqkv,
-                int lddq, int N, int T, int heads, int new_order, float scale, hipStream_t st) {
-    const int blocks = (T + BB - 1) / BB;
-    const dim3 grid((unsigned)((long long)N * heads * blocks));
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<CH>, grid, dim3(256), 0, st, qkv, ldq, dout, lddo, lse, D, dqkv, lddq, T, heads,
-                       new_order, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<CH>, grid, dim3(256), 0, st, qkv, ldq, dout, lddo, lse, D, dqkv, lddq, T, heads,
-                       new_order, scale);
+void launch_bwd(const float* q, int ldq, int hsq, const float* k, const float* v, int ldkv, int hskv, const float* dout, int lddo,
+                const float* lse, const float* D, float* dq, int lddq, float* dk, float* dv, int lddkv, int N, int Tq, int Tk,
+                int heads, float qscale, float kscale, hipStream_t st) {
+    const dim3 gq((unsigned)((long long)N * heads * ((Tq + BB - 1) / BB))), gk((unsigned)((long long)N * heads * ((Tk + BB - 1) / BB)));
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<CH>, gq, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, dout, lddo, lse, D, dq, lddq,
+                       Tq, Tk, heads, qscale, kscale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<CH>, gk, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, dout, lddo, lse, D, dk, dv,
+                       lddkv, Tq, Tk, heads, qscale, kscale);
+}
+
+int attention_bwd_common(const float* q, int ldq, int hsq, const float* k, const float* v, int ldkv, int hskv, const float* out,
+                         int ldo, const float* dout, int lddo, const float* lse, float* dwork, float* dq, int lddq, float* dk,
+                         float* dv, int lddkv, int N, int Tq, int Tk, int heads, int ch, float qscale, float kscale,
+                         hipStream_t st) {
+    const long long total = (long long)N * heads * Tq;
+    int pb = (int)((total + 255) / 256);
+    if (pb > 4096) pb = 4096;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, out, ldo, dout, lddo, dwork, N, Tq, heads, ch);
+#define BBDM_ATTN_BWD(CH) \
+    launch_bwd<CH>(q, ldq, hsq, k, v, ldkv, hskv, dout, lddo, lse, dwork, dq, lddq, dk, dv, lddkv, N, Tq, Tk, heads, qscale, kscale, st)
+    if (ch == 64) BBDM_ATTN_BWD(64); else if (ch == 32) BBDM_ATTN_BWD(32); else BBDM_ATTN_BWD(16);
+#undef BBDM_ATTN_BWD
+    return 0;
 }
 
 }  // namespace
@@ -347,15 +362,33 @@ extern "C" int bbdm_attention_bwd_f32(const float* qkv, int ldq, const float* ou
                      ldo >= heads * ch && lddo >= heads * ch,
                  "attention_bwd: bad pitch");
     BBDM_REQUIRE((((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout) & 15) == 0, "attention_bwd: 16-byte alignment");
-    hipStream_t st = (hipStream_t)stream;
     const float scale = 1.0f / sqrtf(sqrtf((float)ch));
-    const long long total = (long long)N * heads * T;
-    int pb = (int)((total + 255) / 256);
-    if (pb > 4096) pb = 4096;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3(pb), dim3(256), 0, st, out, ldo, dout, lddo, dwork, N, T, heads, ch);
-    if (ch == 64) launch_bwd<64>(qkv, ldq, dout, lddo, lse, dwork, dqkv, lddq, N, T, heads, new_order, scale, st);
-    else if (ch == 32) launch_bwd<32>(qkv, ldq, dout, lddo, lse, dwork, dqkv, lddq, N, T, heads, new_order, scale, st);
-    else launch_bwd<16>(qkv, ldq, dout, lddo, lse, dwork, dqkv, lddq, N, T, heads, new_order, scale, st);
+    const int C = heads * ch;
+    // QKVAttention (new order): q | k | v thirds, head h at h * ch inside each; QKVAttentionLegacy: per-head (q, k, v) triples
+    const int hs = new_order ? ch : 3 * ch, ko = new_order ? C : ch, vo = new_order ? 2 * C : 2 * ch;
+    attention_bwd_common(qkv, ldq, hs, qkv + ko, qkv + vo, ldq, hs, out, ldo, dout, lddo, lse, dwork, dqkv, lddq, dqkv + ko,
+                         dqkv + vo, lddq, N, T, T, heads, ch, scale, scale, (hipStream_t)stream);
     BBDM_CHECK_LAUNCH("attention_bwd");
+    return BBDM_OK;
+}
+
+// Backward of bbdm_cross_attention_f32 (CrossAttention.forward, attention.py:170-194): dq [N][Tq][heads*ch] (pitch lddq),
+// dk / dv [N][Tk][heads*ch] (pitch lddkv), all overwritten.  lse: the forward's [N][heads][Tq] log-sum-exp; dwork: N*heads*Tq
+// floats of scratch.
+extern "C" int bbdm_cross_attention_bwd_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out,
+                                            int ldo, const float* dout, int lddo, const float* lse, float* dwork, float* dq,
+                                            int lddq, float* dk, float* dv, int lddkv, int N, int Tq, int Tk, int heads, int ch,
+                                            void* stream) {
+    BBDM_REQUIRE(q && k && v && out && dout && lse && dwork && dq && dk && dv, "cross_attention_bwd: null pointer");
+    BBDM_REQUIRE(N > 0 && Tq > 0 && Tk > 0 && heads > 0 && (ch == 16 || ch == 32 || ch == 64),
+                 "cross_attention_bwd: bad shape (ch=%d)", ch);
+    const int C = heads * ch;
+    BBDM_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && lddo % 4 == 0 && ldo % 4 == 0 && ldq >= C && ldkv >= C && ldo >= C && lddo >= C &&
+                     lddq >= C && lddkv >= C, "cross_attention_bwd: bad pitch");
+    BBDM_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout) & 15) == 0,
+                 "cross_attention_bwd: 16-byte alignment");
+    attention_bwd_common(q, ldq, ch, k, v, ldkv, ch, out, ldo, dout, lddo, lse, dwork, dq, lddq, dk, dv, lddkv, N, Tq, Tk, heads,
+                         ch, 1.0f / sqrtf((float)ch), 1.0f, (hipStream_t)stream);
+    BBDM_CHECK_LAUNCH("cross_attention_bwd");
     return BBDM_OK;
 }

@@ -190,6 +190,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// 1x1 layers on the TN GEMM (winograd_wgrad.hip: gemm_tn_f32): dW[co][ci] = sum_z dU[z][ci][co] -- the K splits added in a
+// fixed order and the tile transposed through LDS (32 x 32, reads and writes both in 128-B segments).
+__global__ void __launch_bounds__(256) tn_finish_kernel(const float* __restrict__ dU, int splits, float* __restrict__ dw, int Cin,
+                                                        int Cout) {
+    __shared__ float tile[32][33];
+    const int tilesCo = (Cout + 31) / 32;
+    const int co0 = (int)(blockIdx.x % tilesCo) * 32, ci0 = (int)(blockIdx.x / tilesCo) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t per = (size_t)Cin * Cout;
+    for (int r = ty; r < 32; r += 8) {
+        float s = 0.f;
+        if (ci0 + r < Cin && co0 + tx < Cout) {
+            const float* p = dU + (size_t)(ci0 + r) * Cout + co0 + tx;
+            for (int z = 0; z < splits; ++z) s += p[z * per];
+        }
+        tile[r][tx] = s;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (co0 + r < Cout && ci0 + tx < Cin) dw[(size_t)(co0 + r) * Cin + ci0 + tx] = tile[tx][r];
+}
+
 // db[c] = sum over rows of dy[M][ld]; fp64 per-thread accumulation + fp64 atomics (order-independent to fp32 rounding)
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc,
                                                      long long M, int C, int rows_per_block) {
@@ -207,6 +229,44 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
             for (long long r = r0 + rl; r < r1; r += RL) s += (double)dy[(size_t)r * ld + c];
             atomicAdd(&acc[c], s);
         }
+    }
+}
+
+// vectorised variant (C % 4 == 0, 16-byte aligned rows): a workgroup owns 256 columns (64 lanes x float4) of a row range, its
+// four waves take every fourth row with four loads in flight each; fp64 per-lane accumulators, one LDS reduction over the
+// waves, then fp64 atomics.  (The scalar kernel above keeps ONE 4-byte load in flight per thread: 0.23 ms for a 268 MB dY.)
+__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc, long long M,
+                                                      int C, int rows_per_block) {
+    __shared__ double red[4][64][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + lane * 4;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < C) {
+        const float* p = dy + c;
+        long long r = r0 + wave;
+        for (; r + 12 < r1; r += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)r * ld);
+            const float4 b = *reinterpret_cast<const float4*>(p + (size_t)(r + 4) * ld);
+            const float4 d = *reinterpret_cast<const float4*>(p + (size_t)(r + 8) * ld);
+            const float4 e = *reinterpret_cast<const float4*>(p + (size_t)(r + 12) * ld);
+            s0 += ((double)a.x + (double)b.x) + ((double)d.x + (double)e.x);
+            s1 += ((double)a.y + (double)b.y) + ((double)d.y + (double)e.y);
+            s2 += ((double)a.z + (double)b.z) + ((double)d.z + (double)e.z);
+            s3 += ((double)a.w + (double)b.w) + ((double)d.w + (double)e.w);
+        }
+        for (; r < r1; r += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)r * ld);
+            s0 += (double)a.x; s1 += (double)a.y; s2 += (double)a.z; s3 += (double)a.w;
+        }
+    }
+    red[wave][lane][0] = s0; red[wave][lane][1] = s1; red[wave][lane][2] = s2; red[wave][lane][3] = s3;
+    __syncthreads();
+    if (wave == 0 && c < C) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            atomicAdd(&acc[c + j], (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]));
     }
 }
 
@@ -279,9 +339,18 @@ static WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout) {
     return g;
 }
 
+// 1x1 layers wide enough for 128-wide MFMA tiles take the TN GEMM of winograd_wgrad.hip (K = pixels): 100-117 TFLOP/s where
+// conv_wgrad_f32<1, 4> (one 32x32 accumulator per wave, 21 FLOP per LDS byte) reaches ~70
+static bool wgrad_tn_path(int Cin, int Cout, int ks) { return ks == 1 && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 64 && Cout >= 64; }
+
 extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
     const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout);
-    return (size_t)g.splits * ks * ks * g.CinP * g.CoutP + (size_t)g.splits * g.CoutP;
+    size_t need = (size_t)g.splits * ks * ks * g.CinP * g.CoutP + (size_t)g.splits * g.CoutP;
+    if (wgrad_tn_path(Cin, Cout, ks)) {
+        const size_t tn = (size_t)bbdm_gemm_tn_splits(1, (long long)N * H * W, Cin, Cout) * Cin * Cout + 2 * (size_t)Cout + 2;
+        if (tn > need) need = tn;
+    }
+    return need;
 }
 
 template <int TAPS, int WI>
@@ -312,6 +381,21 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     BBDM_REQUIRE(ldy >= Cout && (Cout % 4 != 0 || (ldy % 4 == 0 && ((uintptr_t)dy & 15) == 0)),
                  "conv_wgrad: dy pitch/alignment (ldy=%d)", ldy);
     BBDM_REQUIRE(Cin % 4 == 0, "conv_wgrad: Cin=%d must be a multiple of 4 (pad the input tensor)", Cin);
+    hipStream_t st = (hipStream_t)stream;
+    if (wgrad_tn_path(Cin, Cout, ks) && ((uintptr_t)dy & 15) == 0 && ldy % 4 == 0 && ((uintptr_t)ws & 15) == 0) {
+        const long long K = (long long)N * H * W;
+        const int splits = bbdm_gemm_tn_splits(1, K, Cin, Cout);
+        int rc = bbdm_gemm_tn_batched_f32(x, ldx, 0, dy, ldy, 0, ws, 1, K, Cin, Cout, stream);
+        if (rc != BBDM_OK) return rc;
+        hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 32))), dim3(256), 0, st, ws, splits,
+                           dw_oihw, Cin, Cout);
+        BBDM_CHECK_LAUNCH("conv_wgrad(tn)");
+        if (dbias) {
+            size_t off = ((size_t)splits * Cin * Cout + 1) & ~(size_t)1;        // 8-byte alignment of the fp64 scratch
+            rc = bbdm_colsum_f32(dy, ldy, reinterpret_cast<double*>(ws + off), dbias, K, Cout, stream);
+        }
+        return rc;
+    }
     const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout);
     WgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.ldx = ldx; a.ldy = ldy;
@@ -323,7 +407,6 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     a.tiles_per_split = g.tiles_per_split;
     const int splits = g.splits;
     a.wsb = dbias ? ws + (size_t)splits * ks * ks * a.CinP * a.CoutP : nullptr;
-    hipStream_t st = (hipStream_t)stream;
     const dim3 grid(a.CinP / g.cti, a.CoutP / CT, splits);
     int rc;
     if (ks == 3) rc = g.cti == 128 ? launch_wgrad<9, 4>(a, grid, st) : launch_wgrad<9, 2>(a, grid, st);
@@ -346,7 +429,17 @@ extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out,
     if (blocks > 1024) blocks = 1024;
     const int rpb = (int)((M + blocks - 1) / blocks);
     blocks = (M + rpb - 1) / rpb;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ld, acc, M, C, rpb);
+    if (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)dy & 15) == 0) {
+        const int cchunks = cdiv(C, 256);
+        long long rb = 2048 / cchunks;                                // ~8 workgroups per CU in total
+        if (rb > (M + 63) / 64) rb = (M + 63) / 64;                   // >= 64 rows (16 per wave) per workgroup
+        if (rb < 1) rb = 1;
+        const int rows = (int)((M + rb - 1) / rb);
+        rb = (M + rows - 1) / rows;
+        hipLaunchKernelGGL(colsum4_kernel, dim3((unsigned)rb, cchunks), dim3(256), 0, st, dy, ld, acc, M, C, rows);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ld, acc, M, C, rpb);
+    }
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, acc, out, C);
     BBDM_CHECK_LAUNCH("colsum");
     return BBDM_OK;

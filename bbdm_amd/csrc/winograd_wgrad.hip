@@ -13,7 +13,7 @@
 //   (2) winograd_dy_kernel   : dY NHWC -> dM[(m+2)^2][tiles][Cout]                                          HBM-bound
 //   (3) gemm_tn_f32          : dU[split][xi] = V_xi^T dM_xi over a K range of tiles, fp32 MFMA              MFMA-bound
 //   (4) wgrad_finish_kernel  : sum the K splits in a fixed order (deterministic), G^T . G, write OIHW
-// The bias gradient (column sums of dY) is bbdm_colsum_f32 (conv_wgrad.hip).
+// The bias gradient = column sums of the ONE plane dM_(1,1) (row 1 of A is all ones: that plane holds the tile sums of dY).
 // fp32 throughout; rounding error of the gradient relative to fp64 (tests/test_winograd_math_cpu.py): direct 5e-7,
 // m = 2: 6e-7, m = 4: 3e-6, m = 6: 5e-6.
 #include "winograd_math.h"
@@ -376,9 +376,12 @@ extern "C" int bbdm_conv3x3_winograd_wgrad_f32(int m, const float* x, int ldx, c
                                       stream);
     if (rc == BBDM_OK) rc = bbdm_winograd_wgrad_finish_f32(m, dU, splits, dw_oihw, Cin, Cout, stream);
     if (rc == BBDM_OK && dbias) {
+        // Row 1 of A is all ones (the transform point x = 1), so dM at xi = (1, 1) is the SUM of the tile's dY: the bias
+        // gradient is the column sum of that one plane over the tiles -- m^2 x fewer rows than a pass over dY itself.
         size_t off = (size_t)(dU - ws) + (size_t)splits * P * Cin * Cout;
         off = (off + 1) & ~(size_t)1;                                       // 8-byte alignment of the fp64 scratch
-        rc = bbdm_colsum_f32(dy, ldy, reinterpret_cast<double*>(ws + off), dbias, (long long)N * H * W, Cout, stream);
+        rc = bbdm_colsum_f32(dM + (size_t)(m + 3) * Tp * Cout, Cout, reinterpret_cast<double*>(ws + off), dbias, (long long)T,
+                             Cout, stream);
     }
     return rc;
 }

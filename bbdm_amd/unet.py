@@ -1097,53 +1097,65 @@ class _Plan:
         """SpatialTransformer.forward (attention.py:249-263).  NHWC activations ARE the token matrix [N*H*W, C]; every
         Linear is a 1x1 convolution on the matrix core, LayerNorm / GEGLU are streaming kernels (csrc/transformer.hip), the
         softmax(QK^T)V of both attentions is the streaming-softmax kernel with its own key/value source."""
-        if self.training:
-            raise NotImplementedError("bbdm_amd: training through SpatialTransformer blocks is not implemented yet "
-                                      "(use_spatial_transformer is supported on the sampling path)")
         N, H, W = self.N, x.H, x.W
         heads, d = st.n_heads, st.d_head
         inner = heads * d
+        train = self.training
         ctx = self._context_tokens()
+        # training plans keep every intermediate the gradient plan re-reads in a buffer of its own (and the residual
+        # stream out of place: LayerNorm's backward needs each block input); inference reuses one scratch buffer per role
+        tmp = (lambda name, n, h, w, c: self._new(n, h, w, c)) if train else self._tmp
+        s0 = self._gn_count
         a, pre = self._gn_input(x, st.norm, None, silu=0, name="A")
-        hb = self._tmp("ST_H", N, H, W, inner)
+        hb = tmp("ST_H", N, H, W, inner)
         self._emit_conv(a, st.proj_in, None, hb, pre=pre)
 
         def layernorm(ln_mod, src: _View, name: str) -> _View:
-            out = self._tmp(name, N, H, W, src.C)
+            out = tmp(name, N, H, W, src.C)
             self._op("bbdm_layernorm_f32", src, src.ld, self._pref(ln_mod.weight), self._pref(ln_mod.bias), out, out.ld,
                      N * H * W, src.C, float(ln_mod.eps))
             return out
 
-        def attention(att: "CrossAttention", xin: _View, kv_src: _View):
-            qkv = self._tmp("ST_QKV", N, H, W, inner)
-            self._emit_conv(xin, att.to_q, None, qkv)
-            kvb = self._tmp("ST_KV", kv_src.N, kv_src.H, kv_src.W, 2 * inner)
+        def attention(att: "CrossAttention", xin: _View, kv_src: _View, res: _View):
+            q = tmp("ST_QKV", N, H, W, inner)
+            self._emit_conv(xin, att.to_q, None, q)
+            kvb = tmp("ST_KV", kv_src.N, kv_src.H, kv_src.W, 2 * inner)
             kview = _View(kvb.buf, 0, kvb.ld, kv_src.N, kv_src.H, kv_src.W, inner)
             vview = _View(kvb.buf, inner, kvb.ld, kv_src.N, kv_src.H, kv_src.W, inner)
             self._emit_conv(kv_src, att.to_k, None, kview)
             self._emit_conv(kv_src, att.to_v, None, vview)
-            at = self._tmp("ST_AT", N, H, W, inner)
-            self._op("bbdm_cross_attention_f32", qkv, qkv.ld, kview, vview, kvb.ld, at, at.ld, N, H * W,
+            at = tmp("ST_AT", N, H, W, inner)
+            lse = _TensorRef(torch.empty(N * heads * H * W, dtype=torch.float32, device=self.device)) if train else None
+            self._op("bbdm_cross_attention_f32", q, q.ld, kview, vview, kvb.ld, at, at.ld, lse, N, H * W,
                      kv_src.H * kv_src.W, heads, d)
-            self._emit_conv(at, att.to_out[0], hb, hb)              # + x, in place (the residual aliases the output)
+            out = self._new(N, H, W, inner) if train else res      # inference: + x in place (the residual aliases the output)
+            self._emit_conv(at, att.to_out[0], res, out)
+            return out, (att, xin, kv_src, q, kview, vview, at, lse)
 
+        blocks = []
         for blk in st.transformer_blocks:
-            ln1 = layernorm(blk.norm1, hb, "ST_LN")
-            attention(blk.attn1, ln1, ln1)                            # self-attention
-            ln2 = layernorm(blk.norm2, hb, "ST_LN")
-            attention(blk.attn2, ln2, ctx if ctx is not None else ln2)
-            ln3 = layernorm(blk.norm3, hb, "ST_LN")
+            h_in = hb
+            ln1 = layernorm(blk.norm1, h_in, "ST_LN")
+            h1, rec1 = attention(blk.attn1, ln1, ln1, h_in)                      # self-attention
+            ln2 = layernorm(blk.norm2, h1, "ST_LN")
+            h2, rec2 = attention(blk.attn2, ln2, ctx if ctx is not None else ln2, h1)
+            ln3 = layernorm(blk.norm3, h2, "ST_LN")
             ff = blk.ff
             if not isinstance(ff.net[0], GEGLU):
                 raise NotImplementedError("bbdm_amd: FeedForward without GEGLU (gated_ff=False) is not implemented")
             inner_ff = ff.net[2].in_features
-            pr = self._tmp("ST_FF", N, H, W, 2 * inner_ff)
+            pr = tmp("ST_FF", N, H, W, 2 * inner_ff)
             self._emit_conv(ln3, ff.net[0].proj, None, pr)
-            gl = self._tmp("ST_GL", N, H, W, inner_ff)
+            gl = tmp("ST_GL", N, H, W, inner_ff)
             self._op("bbdm_geglu_f32", pr, pr.ld, gl, gl.ld, N * H * W, inner_ff)
-            self._emit_conv(gl, ff.net[2], hb, hb)
+            h3 = self._new(N, H, W, inner) if train else h2
+            self._emit_conv(gl, ff.net[2], h2, h3)
+            blocks.append((blk, h_in, rec1, h1, rec2, h2, ln3, pr, gl))
+            hb = h3
         out = dest if dest is not None else self._new(N, H, W, x.C)
         self._emit_conv(hb, st.proj_out, x, out)
+        if train:
+            self.tape.append(("st", st, x, a, s0, blocks, hb, out, ctx))
         return out
 
     def _emit_block(self, blk, h: _View, dest: Optional[_View]) -> _View:
@@ -1322,6 +1334,7 @@ class _Plan:
         self._ws_d2 = _LateTensor()
         self.dout_nchw = torch.empty_like(self.out_nchw)
         self.need_input_grad = False
+        self.dctx_tokens: Optional[_View] = None    # d context through the cross-attention keys / values (SpatialTransformer)
 
         rec_ends = []       # len(self.bops) after each tape record, in backward order
         for rec in reversed(self.tape):
@@ -1367,6 +1380,75 @@ class _Plan:
                 da = conv_bwd(ab.qkv, a, dqkv, True, "DA")
                 dx = gview(x)
                 gn_bwd(ab.norm, x, s0, None, da, dout, 0, 0, dx, first_write(x))
+            elif kind == "st":
+                # SpatialTransformer (attention.py:249-263) in reverse; BasicTransformerBlock._forward (attention.py:215-218):
+                # x = attn1(norm1(x)) + x;  x = attn2(norm2(x), context) + x;  x = ff(norm3(x)) + x
+                _, st, x, a, s0, blocks, h_last, out, ctx = rec
+                heads, dh_ch = st.n_heads, st.d_head
+                inner = heads * dh_ch
+                H, W = x.H, x.W
+                rows = N * H * W
+                dout = gview(out)
+                ring = ["ST_DHA", "ST_DHB", "ST_DHC"]                      # gradient of the residual stream: three live at most
+                turn = [0]
+
+                def next_dh():
+                    turn[0] = (turn[0] + 1) % 3
+                    return self._tmp(ring[turn[0]], N, H, W, inner)
+
+                def accumulate(src: _View, dst: _View, acc: int):
+                    self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, src, src.ld, dst, dst.ld,
+                              acc, None, None, None, 0, None, src.N, src.H, src.W, src.C, 1, 0.0, 0, 0)
+
+                def ln_bwd(ln_mod, xin: _View, dy: _View, dadd: _View) -> _View:
+                    ws_doubles[0] = max(ws_doubles[0], 2 * xin.C)
+                    dxv = next_dh()
+                    self._bop("bbdm_layernorm_bwd_f32", xin, xin.ld, self._pref(ln_mod.weight), dy, dy.ld, dadd, dadd.ld, dxv,
+                              dxv.ld, gref(ln_mod.weight), gref(ln_mod.bias), self._ws_d2, rows, xin.C, float(ln_mod.eps))
+                    return dxv
+
+                def attn_bwd(arec, dres: _View) -> _View:
+                    """dres = gradient of (to_out(attention) + residual); returns the gradient of the LayerNorm output."""
+                    att, xin, kv_src, q, kview, vview, at, lse = arec
+                    Tk = kv_src.H * kv_src.W
+                    dat = conv_bwd(att.to_out[0], at, dres, True, "ST_DAT")
+                    dq = self._tmp("ST_DQ", N, H, W, inner)
+                    dkv = self._tmp("ST_DKV", kv_src.N, kv_src.H, kv_src.W, 2 * inner)
+                    dk = _View(dkv.buf, 0, dkv.ld, kv_src.N, kv_src.H, kv_src.W, inner)
+                    dv = _View(dkv.buf, inner, dkv.ld, kv_src.N, kv_src.H, kv_src.W, inner)
+                    dwork = _TensorRef(torch.empty(N * heads * H * W, **f32))
+                    self._bop("bbdm_cross_attention_bwd_f32", q, q.ld, kview, vview, kview.ld, at, at.ld, dat, dat.ld, lse, dwork,
+                              dq, dq.ld, dk, dv, dkv.ld, N, H * W, Tk, heads, dh_ch)
+                    dln = conv_bwd(att.to_q, xin, dq, True, "ST_DLN")
+                    dsk = conv_bwd(att.to_k, kv_src, dk, True, "ST_DSK")
+                    dsv = conv_bwd(att.to_v, kv_src, dv, True, "ST_DSV")
+                    if kv_src is ctx:                       # context tokens: their gradient leaves through the UNet's d input
+                        if self.dctx_tokens is None:
+                            self.dctx_tokens = self._new(ctx.N, ctx.H, ctx.W, ctx.C)
+                            accumulate(dsk, self.dctx_tokens, 0)
+                        else:
+                            accumulate(dsk, self.dctx_tokens, 1)
+                        accumulate(dsv, self.dctx_tokens, 1)
+                    else:                                   # self-attention: keys and values come from the same LayerNorm output
+                        accumulate(dsk, dln, 1)
+                        accumulate(dsv, dln, 1)
+                    return dln
+
+                dh = conv_bwd(st.proj_out, h_last, dout, True, ring[0])
+                for blk, h_in, rec1, h1, rec2, h2, ln3, pr, gl in reversed(blocks):
+                    ff = blk.ff
+                    dgl = conv_bwd(ff.net[2], gl, dh, True, "ST_DGL")
+                    dpr = self._tmp("ST_DPR", N, H, W, pr.C)
+                    self._bop("bbdm_geglu_bwd_f32", pr, pr.ld, dgl, dgl.ld, dpr, dpr.ld, rows, gl.C)
+                    dln3 = conv_bwd(ff.net[0].proj, ln3, dpr, True, "ST_DLN")
+                    dh2 = ln_bwd(blk.norm3, h2, dln3, dh)
+                    dln2 = attn_bwd(rec2, dh2)
+                    dh1 = ln_bwd(blk.norm2, h1, dln2, dh2)
+                    dln1 = attn_bwd(rec1, dh1)
+                    dh = ln_bwd(blk.norm1, h_in, dln1, dh1)
+                da = conv_bwd(st.proj_in, a, dh, True, "DA")
+                dx = gview(x)
+                gn_bwd(st.norm, x, s0, None, da, dout, 0, 0, dx, first_write(x))
             elif kind == "down":
                 _, ds, x, out = rec
                 dout = gview(out)
@@ -1436,6 +1518,8 @@ class _Plan:
         elif kind == "attn":
             ab = rec[1]
             mods = [ab.norm, ab.qkv, ab.proj_out]
+        elif kind == "st":
+            mods = [rec[1]]
         elif kind == "down":
             mods = [rec[1].op] if rec[1].use_conv else []
         elif kind == "up":
@@ -1532,6 +1616,16 @@ class _Plan:
             return None
         return self._backward_embedding(stream, need_dx)
 
+    def context_token_grad(self) -> Optional[torch.Tensor]:
+        """Gradient reaching the context through the cross-attention keys / values, [N, Cc, Hc, Wc] (None without
+        SpatialTransformer blocks); valid after the last backward segment.  The context's other gradient -- it is also
+        concatenated to the UNet input (openaimodel.py:741-742) -- is part of the input gradient."""
+        v = self.dctx_tokens
+        if v is None:
+            return None
+        t = v.buf.tensor[v.off: v.off + v.N * v.H * v.W * v.ld].view(v.N, v.H, v.W, v.ld)
+        return t[..., :self.ctx_in.shape[1]].permute(0, 3, 1, 2)
+
     def run_backward(self, dout: torch.Tensor, need_dx: bool):
         """Whole gradient plan in one go.  Returns (flat parameter gradient, d input NHWC view or None)."""
         self.backward_begin(dout)
@@ -1545,7 +1639,7 @@ class _Plan:
         flat = self._flat_grad
         gslice = self.grad_view
         for w, t in self._padded_wgrads:
-            gslice(w).copy_(t[:, : w.shape[1]])
+            gslice(w).copy_(t[:, : w.shape[1]].reshape(w.shape))      # (Linear weights are 2-D: ks = 1)
         # ---- embedding path: film projections -> time_embed.2 -> time_embed.0 ------------------------------------
         mc, ted = m.model_channels, 4 * m.model_channels
         call = _lib.call

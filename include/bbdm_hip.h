@@ -287,15 +287,29 @@ int bbdm_vq_nearest_f32(const float* z, int ldz, const float* codebook, long lon
  *      modules/attention.py) -------------------------------------------------------------------------------------------- */
 /* CrossAttention.forward (attention.py:170-194): out[n, i, h*ch + d] = sum_j softmax_j(q_i . k_j * ch^-1/2) v_j per head.
  * q: [N][Tq][ldq], k / v: [N][Tk][ldkv] token-major ('b n (h d)': head h at channel h*ch), out: [N][Tq][ldo].
- * ch in {16, 32, 64}.  Streaming softmax on the f32 matrix core, same kernel as bbdm_attention_f32. */
-int bbdm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, int N,
-                             int Tq, int Tk, int heads, int ch, void* stream);
+ * ch in {16, 32, 64}.  Streaming softmax on the f32 matrix core, same kernel as bbdm_attention_f32.
+ * lse (may be NULL): [N][heads][Tq] log-sum-exp of the scaled scores, kept for the backward pass.
+ * bbdm_cross_attention_bwd_f32 (autograd of the above; the reference re-runs the block under CheckpointFunction,
+ * attention.py:212-213): dq [N][Tq] (pitch lddq), dk / dv [N][Tk] (pitch lddkv), overwritten; dwork: N*heads*Tq floats. */
+int bbdm_cross_attention_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, float* out, int ldo, float* lse,
+                             int N, int Tq, int Tk, int heads, int ch, void* stream);
+int bbdm_cross_attention_bwd_f32(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* out, int ldo,
+                                 const float* dout, int lddo, const float* lse, float* dwork, float* dq, int lddq, float* dk,
+                                 float* dv, int lddkv, int N, int Tq, int Tk, int heads, int ch, void* stream);
 /* nn.LayerNorm(C) over the channel axis of `rows` tokens (attention.py:204-206): y = (x - mean) / sqrt(var + eps) * gamma
  * + beta, biased variance, fp32. */
 int bbdm_layernorm_f32(const float* x, int ldx, const float* gamma, const float* beta, float* y, int ldy, long long rows,
                        int C, float eps, void* stream);
 /* GEGLU (attention.py:38-46): y[r][c] = a[r][c] * gelu(a[r][inner + c]), exact (erf) GELU; a = proj(x) with 2*inner columns. */
 int bbdm_geglu_f32(const float* a, int lda, float* y, int ldy, long long rows, int inner, void* stream);
+/* Their gradients (training through SpatialTransformer blocks).  layernorm_bwd: dx = d/dx of the LayerNorm (+ dadd when given:
+ * the residual branch of BasicTransformerBlock, attention.py:215-218), dgamma / dbeta overwritten; ws: 2*C doubles.
+ * geglu_bwd: da[rows][2*inner] from the forward input a and dy[rows][inner]. */
+int bbdm_layernorm_bwd_f32(const float* x, int ldx, const float* gamma, const float* dy, int lddy, const float* dadd, int ldadd,
+                           float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long rows, int C, float eps,
+                           void* stream);
+int bbdm_geglu_bwd_f32(const float* a, int lda, const float* dy, int lddy, float* da, int ldda, long long rows, int inner,
+                       void* stream);
 
 /* ---- fp32-accurate batched GEMM on the BF16 matrix core (the Winograd tile GEMMs; csrc/gemm_bf3.hip) ----------- */
 /* v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate on gfx950.  Each fp32 operand is split exactly into three

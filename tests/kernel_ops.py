@@ -375,14 +375,52 @@ def geglu(a: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int) -> torch.Tensor:
+def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, return_lse: bool = False):
     """q: [N, Tq, heads*ch], k / v: [N, Tk, heads*ch] (separate contiguous tensors of equal pitch)."""
     _chk(q, k, v)
     N, Tq, C = q.shape
     out = torch.empty_like(q)
-    _lib.call("bbdm_cross_attention_f32", q.data_ptr(), C, k.data_ptr(), v.data_ptr(), C, out.data_ptr(), C, N, Tq,
-              k.shape[1], heads, C // heads, _st(q))
-    return out
+    lse = torch.empty(N, heads, Tq, dtype=torch.float32, device=q.device) if return_lse else None
+    _lib.call("bbdm_cross_attention_f32", q.data_ptr(), C, k.data_ptr(), v.data_ptr(), C, out.data_ptr(), C,
+              None if lse is None else lse.data_ptr(), N, Tq, k.shape[1], heads, C // heads, _st(q))
+    return (out, lse) if return_lse else out
+
+
+def cross_attention_bwd(q, k, v, out, lse, dout, heads: int):
+    """-> (dq, dk, dv) of cross_attention."""
+    _chk(q, k, v, out, lse, dout)
+    N, Tq, C = q.shape
+    Tk = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dwork = torch.empty(N * heads * Tq, dtype=torch.float32, device=q.device)
+    _lib.call("bbdm_cross_attention_bwd_f32", q.data_ptr(), C, k.data_ptr(), v.data_ptr(), C, out.data_ptr(), C, dout.data_ptr(),
+              C, lse.data_ptr(), dwork.data_ptr(), dq.data_ptr(), C, dk.data_ptr(), dv.data_ptr(), C, N, Tq, Tk, heads,
+              C // heads, _st(q))
+    return dq, dk, dv
+
+
+def layernorm_bwd(x, gamma, dy, eps: float = 1e-5, dadd=None):
+    """x, dy: [rows, C] -> (dx [+ dadd], dgamma, dbeta)."""
+    _chk(x, gamma, dy, dadd)
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    _lib.call("bbdm_layernorm_bwd_f32", x.data_ptr(), C, gamma.data_ptr(), dy.data_ptr(), C,
+              None if dadd is None else dadd.data_ptr(), C, dx.data_ptr(), C, dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, C,
+              eps, _st(x))
+    return dx, dg, db
+
+
+def geglu_bwd(a, dy):
+    """a: [rows, 2 * inner], dy: [rows, inner] -> da [rows, 2 * inner]."""
+    _chk(a, dy)
+    inner = a.shape[1] // 2
+    da = torch.empty_like(a)
+    _lib.call("bbdm_geglu_bwd_f32", a.data_ptr(), a.shape[1], dy.data_ptr(), inner, da.data_ptr(), a.shape[1], a.shape[0], inner,
+              _st(a))
+    return da
 
 
 def vq_nearest(z: torch.Tensor, codebook: torch.Tensor):

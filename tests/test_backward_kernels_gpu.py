@@ -203,3 +203,51 @@ def test_linear_backward(dev, N, In, Out, act):
     dx, dw, db = ops.linear_bwd(dy.to(dev), x.detach().to(dev), w.detach().to(dev), act_in=act)
     torch.cuda.synchronize()
     assert rel_err(dx.cpu(), x.grad) < TOL and rel_err(dw.cpu(), w.grad) < TOL and rel_err(db.cpu(), b.grad) < TOL
+
+
+# ---- SpatialTransformer pieces (attention.py:153-219): cross-attention, LayerNorm, GEGLU -------------------------------------
+@pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(2, 64, 64, 2, 32), (1, 200, 77, 4, 64), (2, 130, 260, 1, 16), (1, 1024, 256, 8, 64)])
+def test_cross_attention_backward(dev, N, Tq, Tk, heads, ch):
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(N + Tq + Tk + heads)
+    C = heads * ch
+    q = torch.randn(N, Tq, C, generator=g).requires_grad_()
+    k = torch.randn(N, Tk, C, generator=g).requires_grad_()
+    v = torch.randn(N, Tk, C, generator=g).requires_grad_()
+    dout = torch.randn(N, Tq, C, generator=g)
+    split = lambda t: t.view(N, -1, heads, ch).permute(0, 2, 1, 3)            # 'b n (h d) -> b h n d'
+    sim = torch.einsum("bhid,bhjd->bhij", split(q), split(k)) * ch ** -0.5   # attention.py:178-190
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), split(v)).permute(0, 2, 1, 3).reshape(N, Tq, C)
+    ref.backward(dout)
+    out, lse = ops.cross_attention(q.detach().to(dev), k.detach().to(dev), v.detach().to(dev), heads, return_lse=True)
+    dq, dk, dv = ops.cross_attention_bwd(q.detach().to(dev), k.detach().to(dev), v.detach().to(dev), out, lse, dout.to(dev), heads)
+    assert rel_err(out.cpu(), ref.detach()) < TOL
+    assert rel_err(dq.cpu(), q.grad) < TOL and rel_err(dk.cpu(), k.grad) < TOL and rel_err(dv.cpu(), v.grad) < TOL
+
+
+@pytest.mark.parametrize("rows,C,with_add", [(37, 64, False), (512, 320, True), (4096, 1024, True)])
+def test_layernorm_backward(dev, rows, C, with_add):
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 1.7 + 0.4).requires_grad_()
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).requires_grad_()
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_()
+    dy = torch.randn(rows, C, generator=g)
+    dadd = torch.randn(rows, C, generator=g) if with_add else None
+    F.layer_norm(x, (C,), gamma, beta, 1e-5).backward(dy)
+    dx, dg, db = ops.layernorm_bwd(x.detach().to(dev), gamma.detach().to(dev), dy.to(dev), 1e-5,
+                                   None if dadd is None else dadd.to(dev))
+    want = x.grad + (dadd if dadd is not None else 0.0)
+    assert rel_err(dx.cpu(), want) < TOL
+    assert rel_err(dg.cpu(), gamma.grad) < TOL and rel_err(db.cpu(), beta.grad) < TOL
+
+
+@pytest.mark.parametrize("rows,inner", [(33, 32), (1024, 1280)])
+def test_geglu_backward(dev, rows, inner):
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(rows + inner)
+    a = (torch.randn(rows, 2 * inner, generator=g) * 1.5).requires_grad_()
+    dy = torch.randn(rows, inner, generator=g)
+    (a[:, :inner] * F.gelu(a[:, inner:])).backward(dy)
+    da = ops.geglu_bwd(a.detach().to(dev), dy.to(dev))
+    assert rel_err(da.cpu(), a.grad) < TOL

@@ -155,3 +155,17 @@ def test_attention_backward(N, T, heads, ch, new_order):
 @pytest.mark.parametrize("N,In,Out,act", [(4, 128, 512, False), (33, 96, 70, True)])
 def test_linear_backward(N, In, Out, act):
     BK.test_linear_backward(CPU, N, In, Out, act)
+
+
+@pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(2, 64, 64, 2, 32), (1, 200, 77, 4, 64), (2, 130, 260, 1, 16)])
+def test_cross_attention_backward(N, Tq, Tk, heads, ch):
+    BK.test_cross_attention_backward(CPU, N, Tq, Tk, heads, ch)
+
+
+@pytest.mark.parametrize("rows,C,with_add", [(37, 64, False), (512, 320, True)])
+def test_layernorm_backward(rows, C, with_add):
+    BK.test_layernorm_backward(CPU, rows, C, with_add)
+
+
+def test_geglu_backward():
+    BK.test_geglu_backward(CPU, 33, 32)

@@ -43,11 +43,13 @@ def test_unet_forward_and_p_sample_match_reference_golden(name):
         torch.randn_like = orig
 
 
-def test_loss_and_all_parameter_gradients():
-    rec = load_case("tiny_nocond")
+@pytest.mark.parametrize("name", ["tiny_nocond", "tiny_xattn"])
+def test_loss_and_all_parameter_gradients(name):
+    rec = load_case(name)
     loss_ref, g_ref = T._oracle_grads(rec)
     m = _build(rec, train=True)
-    loss, log = m.p_losses(rec["x0"], rec["y"], None, rec["t"], rec["noise"])
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"]
+    loss, log = m.p_losses(rec["x0"], rec["y"], ctx, rec["t"], rec["noise"])
     loss.backward()
     assert abs(float(loss.detach()) - loss_ref) < 1e-5 * max(1.0, abs(loss_ref))
     gmax = max(float(v.abs().max()) for v in g_ref.values())
@@ -55,6 +57,10 @@ def test_loss_and_all_parameter_gradients():
         ref = g_ref[k]
         scale = max(float(ref.abs().max()), 1e-3 * gmax)
         assert float((p.grad - ref).abs().max()) / scale < T.GRAD_TOL, k
+
+
+def test_context_gradient_through_cross_attention():
+    T.test_context_gradient_through_cross_attention(CPU)
 
 
 def test_groupnorm_statistics_fused_into_the_producers():

@@ -11,7 +11,7 @@ from fixtures import load_case, oracle_model, rel_err
 
 pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-3          # per-parameter: max|g - g_ref| / max|g_ref|
-CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx")
+CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx", "tiny_xattn")       # tiny_xattn: SpatialTransformer blocks
 
 
 def _ns(c):
@@ -93,6 +93,24 @@ def test_gradient_accumulation_and_input_grad(dev):
     loss2.backward()
     for k, p in m.named_parameters():
         assert rel_err(p.grad, 2 * g1[k]) < 1e-5, k
+
+
+def test_context_gradient_through_cross_attention(dev):
+    """use_spatial_transformer: the context reaches the UNet twice -- concatenated to the input (openaimodel.py:741-742) and as
+    the cross-attention keys / values of every SpatialTransformer (attention.py:174-176); d loss / d context sums both."""
+    rec = load_case("tiny_xattn")
+    m = build(rec, dev).train()
+    x0, y, t, nz = (rec[k].to(dev) for k in ("x0", "y", "t", "noise"))
+    ctx = y.clone().requires_grad_()
+    loss, _ = m.p_losses(x0, y, ctx, t, nz)
+    loss.backward()
+    ora = oracle_model(rec)
+    c_ref = rec["y"].clone().requires_grad_()
+    x_t, target = O.q_sample(ora.bufs, rec["x0"], rec["y"], rec["t"], rec["noise"], ora.objective)
+    l_ref = O.bb_loss(target, ora.denoise(x_t, rec["t"], c_ref), ora.loss_type)
+    l_ref.backward()
+    assert abs(float(loss.detach()) - float(l_ref.detach())) < 1e-5 * max(1.0, abs(float(l_ref.detach())))
+    assert rel_err(ctx.grad.cpu(), c_ref.grad) < GRAD_TOL
 
 
 def test_adam_steps_follow_the_oracle(dev):
