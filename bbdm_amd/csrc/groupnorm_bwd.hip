@@ -22,6 +22,7 @@ struct BwdArgs {
     const float* da;
     const float* dadd;
     const double* sg;
+    const float4* coef;          // [N][G] {rstd, mean, S1/cnt, S2/cnt} in fp32, written by the finalize kernel
     double* pq;
     float* dx;
     int ldx, ldda, ldadd, lddx, film_ld;
@@ -117,7 +118,27 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
             const int c = c4 * 4;
             const Norm4 nm = load_norm(a, n, c, cpg, cnt);
             double P[4] = {0, 0, 0, 0}, Q[4] = {0, 0, 0, 0};
-            for (int p = p0 + prow; p < p1; p += PP) {
+            int p = p0 + prow;
+            if (a.resample == 0) {
+                // common case (no resampling): four pixels per trip, their eight loads issued before any arithmetic -- the
+                // one-pixel loop below keeps a single load pair in flight per thread (latency-bound at 2.4 TB/s)
+                for (; p + 3 * PP < p1; p += 4 * PP) {
+                    float4 xv[4], dz[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xv[u] = *reinterpret_cast<const float4*>(xb + (size_t)(p + u * PP) * a.ldx + c);
+                        dz[u] = *reinterpret_cast<const float4*>(dab + (size_t)(p + u * PP) * a.ldda + c);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float xh[4], dv[4];
+                        quad_dv(a, n, c, nm, xv[u], dz[u], xh, dv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { P[e] += (double)dv[e] * xh[e]; Q[e] += (double)dv[e]; }
+                    }
+                }
+            }
+            for (; p < p1; p += PP) {
                 const int h = p / a.W, w = p - h * a.W;
                 const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * a.ldx + c);
                 const float4 dz = gather_grad(dab, a.ldda, a.resample, h, w, a.H, a.W, c);
@@ -141,7 +162,9 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
 __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __restrict__ pq, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ film,
                                                               int film_ld, double* __restrict__ sg, double* __restrict__ dgb,
-                                                              float* __restrict__ dfilm, int dfilm_ld, int C, int G) {
+                                                              float* __restrict__ dfilm, int dfilm_ld, int C, int G,
+                                                              const double* __restrict__ stats, float4* __restrict__ coef,
+                                                              double cnt, float eps) {
     // grid = N; dgb: fp64 [C][2] accumulators (zeroed by the launcher) for dgamma / dbeta over n
     __shared__ double s12[64 * 2];
     const int n = blockIdx.x, tid = threadIdx.x, cpg = C / G;
@@ -162,6 +185,16 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __re
     }
     __syncthreads();
     if (tid < 2 * G) sg[(size_t)n * G * 2 + tid] = s12[tid];
+    // what the apply pass needs per (image, group), once, in fp32 -- it used to redo these fp64 divisions / square roots for
+    // every channel quad of every pixel, which made an HBM-bound pass ALU-bound (2.5 TB/s)
+    if (tid < G) {
+        const double sm = stats[((size_t)n * G + tid) * 2], ss = stats[((size_t)n * G + tid) * 2 + 1];
+        const double mean = sm / cnt;
+        double var = ss / cnt - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        coef[(size_t)n * G + tid] = make_float4((float)(1.0 / sqrt(var + (double)eps)), (float)mean, (float)(s12[2 * tid] / cnt),
+                                                (float)(s12[2 * tid + 1] / cnt));
+    }
 }
 
 __global__ void gn_bwd_params_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -179,7 +212,6 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a) {
     const int C4 = a.C >> 2, HW = a.H * a.W;
     const long long units = (long long)HW * C4;
     const int cpg = a.G > 0 ? a.C / a.G : a.C;
-    const double cnt = (double)HW * cpg;
     const int Ho = (a.resample == 1 || a.resample == 3) ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
     const int Wo = (a.resample == 1 || a.resample == 3) ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
     const float* xb = a.x ? a.x + (size_t)n * HW * a.ldx : nullptr;
@@ -191,19 +223,28 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a) {
         const int h = p / a.W, w = p - h * a.W;
         float out[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.gamma) {
-            const Norm4 nm = load_norm(a, n, c, cpg, cnt);
+            Norm4 nm;
+            float s1[4], s2[4];
+            if ((cpg & 3) == 0) {                       // the quad lies in one group
+                const float4 cf = a.coef[(size_t)n * a.G + c / cpg];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { nm.rs[e] = cf.x; nm.mu[e] = cf.y; s1[e] = cf.z; s2[e] = cf.w; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 cf = a.coef[(size_t)n * a.G + (c + e) / cpg];
+                    nm.rs[e] = cf.x; nm.mu[e] = cf.y; s1[e] = cf.z; s2[e] = cf.w;
+                }
+            }
             const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * a.ldx + c);
             const float4 dz = gather_grad(dab, a.ldda, a.resample, h, w, a.H, a.W, c);
             float xh[4], dv[4];
             quad_dv(a, n, c, nm, xv, dz, xh, dv);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int g = (c + e) / cpg;
-                const float s1 = (float)(a.sg[((size_t)n * a.G + g) * 2] / cnt);
-                const float s2 = (float)(a.sg[((size_t)n * a.G + g) * 2 + 1] / cnt);
                 float gs = a.gamma[c + e];
                 if (a.film) gs *= 1.f + a.film[(size_t)n * a.film_ld + c + e];
-                out[e] = nm.rs[e] * (gs * dv[e] - s1 - xh[e] * s2);
+                out[e] = nm.rs[e] * (gs * dv[e] - s1[e] - xh[e] * s2[e]);
             }
         }
         if (addb) {
@@ -221,9 +262,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a) {
 
 }  // namespace
 
-// Workspace (fp64 elements): pq [N][C][2] + sg [N][G][2] + dgb [C][2]
+// Workspace (fp64 elements): pq [N][C][2] + sg [N][G][2] + dgb [C][2] + coef [N][G] float4 (= 2 doubles each)
 extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
-    return (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2;
+    return (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2 + (size_t)N * G * 2;
 }
 
 extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
@@ -246,14 +287,15 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.da = da; a.dadd = dadd; a.dx = dx;
     a.ldx = ldx; a.ldda = ldda; a.ldadd = ldadd; a.lddx = lddx; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample;
-    a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr;
+    a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr;
     const int HW = H * W;
     if (norm) {
         double* pq = ws;
         double* sg = ws + (size_t)N * C * 2;
         double* dgb = sg + (size_t)N * G * 2;
-        (void)hipMemsetAsync(ws, 0, sizeof(double) * bbdm_groupnorm_bwd_workspace_doubles(N, C, G), st);
-        a.pq = pq; a.sg = sg;
+        float4* coef = reinterpret_cast<float4*>(dgb + (size_t)C * 2);
+        (void)hipMemsetAsync(ws, 0, sizeof(double) * ((size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2), st);
+        a.pq = pq; a.sg = sg; a.coef = coef;
         const int C4 = C / 4;
         const int PP = C4 <= 256 ? 256 / C4 : 1;
         int splits = cdiv(1024, N);
@@ -266,7 +308,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
         else if (C4 <= 512) hipLaunchKernelGGL(gn_bwd_reduce_kernel<2>, grid, dim3(256), lds, st, a, ppb);
         else hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, grid, dim3(256), lds, st, a, ppb);
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, pq, gamma, beta, film, film_ld, sg, dgb, dfilm,
-                           dfilm_ld, C, G);
+                           dfilm_ld, C, G, stats, coef, (double)HW * (C / G), eps);
         hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dgb, dgamma, dbeta, C);
     }
     const long long units = (long long)HW * (C / 4);
