@@ -334,6 +334,31 @@ class _PackedConvBf3(_PackedConv):
             self.key = key
 
 
+class _PackedDgradBf3:
+    """The transposed weight of a 1x1 conv / Linear in the three-bf16-plane layout of csrc/gemm_bf3.hip: the data gradient
+    dX = dY W as one more fp32-accurate GEMM on the BF16 matrix core (``packed``; the fp32 dgrad packing is the intermediate)."""
+
+    def __init__(self, weight: nn.Parameter, cout_in: int):
+        self.weight = weight
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.cout_in = cout_in
+        lib = _lib.load()
+        self.packed_f32 = torch.empty(lib.bbdm_conv_packed_dgrad_floats(self.cout, self.cin, cout_in, 1), dtype=torch.float32,
+                                      device=weight.device)
+        self.packed = torch.empty(lib.bbdm_gemm_bf3_packed_halfs(1, cout_in, self.cin), dtype=torch.int16, device=weight.device)
+        self.key = None
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
+                      self.cout_in, 1, stream)
+            _lib.call("bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), 1, self.cout_in, self.cin,
+                      stream)
+            self.key = key
+
+
 class _PackedDgrad:
     """Packed transposed + flipped copy of a conv weight: the forward kernel run with it computes the data gradient."""
 
@@ -560,6 +585,7 @@ class UNetModel(nn.Module):
         # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
         # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
         self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
+        self.bf3_min_tiles: int = 256       # 1x1 layers with fewer 256x128 output tiles keep the split-K f32 kernel (one wave of tiles)
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
@@ -609,7 +635,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats, self.winograd_wgrad)
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1011,9 +1037,9 @@ class _Plan:
         assert not upsample
         ks = mod.weight.shape[2] if mod.weight.dim() == 4 else 1
         pixels = self.N * x.H * x.W
-        if (ks == 1 and self.m.gemm_bf3 and (pre is None or pre[0] is None) and flags == 0 and not self.training
+        if (ks == 1 and self.m.gemm_bf3 and (pre is None or pre[0] is None) and flags == 0
                 and self.lib.bbdm_gemm_bf3_supported(pixels, x.C, cout)
-                and (pixels // 256) * -(-cout // 128) >= 256):
+                and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles):
             # wide 1x1 convolutions / Linears (skip connections, qkv / proj_out, transformer projections): the fp32-accurate
             # bf16x3 GEMM with bias + residual in its epilogue (csrc/gemm_bf3.hip); small problems keep the split-K f32 kernel
             pb = _PackedConvBf3(mod.weight, mod.bias, x.C)
@@ -1307,6 +1333,13 @@ class _Plan:
                 pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=self._use_bf3(wm, x_in.H, x_in.W, dy.C, x_in.C))
                 self.dconvs.append(pk)
                 self._emit_winograd(dy, dy.C, pk, None, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
+                return dx
+            pixels = x_in.N * x_in.H * x_in.W
+            if (ks == 1 and m.gemm_bf3 and x_in.C == cin and lib.bbdm_gemm_bf3_supported(pixels, dy.C, x_in.C)
+                    and (pixels // 256) * -(-x_in.C // 128) >= m.bf3_min_tiles):
+                pk = _PackedDgradBf3(w, dy.C)           # wide 1x1 layers: dX = dY W on the bf16x3 GEMM, like their forward
+                self.dconvs.append(pk)
+                self._bop("bbdm_conv1x1_bf3_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, pixels, dy.C, x_in.C)
                 return dx
             pk = _PackedDgrad(w, dy.C)
             self.dconvs.append(pk)

@@ -99,8 +99,8 @@ def test_groupnorm_statistics_fused_into_the_producers():
 
 def test_weight_gradients_in_the_winograd_domain():
     """Training plan of a UNet with enough tiles (16 images of 16x16 = 256 4x4 tiles, 64 channels) for the 3x3 layers' weight
-    gradients to take the Winograd-domain path (csrc/winograd_wgrad.hip): every parameter gradient against the oracle's
-    autograd."""
+    gradients to take the Winograd-domain path (csrc/winograd_wgrad.hip), with the 1x1 skip convolutions (forward and data
+    gradient) on the bf16x3 GEMM as at full size: every parameter gradient against the oracle's autograd."""
     import bbdm_amd
     import bbdm_oracle as O
     from fixture_weights import synth_weights
@@ -111,6 +111,7 @@ def test_weight_gradients_in_the_winograd_domain():
     sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 41)
     m.load_state_dict(sd, strict=True)
     m.hip_graph = False
+    m.bf3_min_tiles = 1        # also drive the 1x1 skip convolutions (forward and data gradient) through the bf16x3 GEMM
     m.train()
     g = torch.Generator().manual_seed(3)
     x = torch.randn(16, 4, 16, 16, generator=g)
@@ -119,6 +120,8 @@ def test_weight_gradients_in_the_winograd_domain():
     (m(x, timesteps=t, context=None) * dout).sum().backward()
     plan = m._plan_for(x, True)
     assert sum(str(n) == "bbdm_conv3x3_winograd_wgrad_f32" for n, _ in plan.bops) >= 4
+    assert sum(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.bops) >= 1 and \
+        sum(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.ops) >= 1
     sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
     (O.unet_forward(sdg, O.UNetSpec(**up), x, t, None) * dout).sum().backward()
     gmax = max(float(v.grad.abs().max()) for v in sdg.values())
