@@ -47,6 +47,8 @@ class _Flags:
         self.gemm_bf3 = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
         self.fuse_groupnorm = False
         self.fuse_stats = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
+        self.bf3_min_tiles = 256
+        self.winograd_wgrad = 0             # (inference plans only)
         self.hip_graph = False
         self.op_profile = None
 
