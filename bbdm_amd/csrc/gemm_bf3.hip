@@ -23,6 +23,7 @@
 //  * Lane l supplies row (l & 31) and the 8 consecutive k of half (l >> 5) for A and for B alike (the sum over k does not
 //    depend on which k a lane carries as long as A and B agree); C/D layout = the f32 32x32 layout (cdna_hip_programming.md).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,6 +40,7 @@ struct Bf3Args {
     float* M;                // [batch][T][Cout] fp32
     size_t vz, uz, mz;       // per-batch strides (elements of the respective type)
     int T, Cin, Cout, CoutPad, nchunks, tilesN;
+    int tiles, batch, by_batch;   // by_batch: each XCD owns whole batch entries (1-D launch), see the kernel
     int lda, ldo, ldr;       // row pitches of V, M and the residual (floats)
     const float* bias;       // [Cout] or null
     const float* res;        // [T][ldr] or null; may alias M
@@ -102,12 +104,26 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;                                    // 4 (M) x 2 (N) waves of 64 x 64
-    const float* V = a.V + (size_t)blockIdx.z * a.vz;
-    const unsigned short* U = a.U + (size_t)blockIdx.z * a.uz;
-    float* M = a.M + (size_t)blockIdx.z * a.mz;
-
-    // XCD-aware tile order: the Cout tiles of one row tile (same V rows) land on one XCD / one L2 (see conv_igemm.hip)
-    int bid = xcd_block((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
+    // Workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).
+    int bid, bz;
+    if (a.by_batch) {
+        // batched launches (the (m+2)^2 Winograd GEMMs): XCD c owns the batch entries c, c + 8, ... and runs ALL their tiles, so an
+        // entry's V rows and U slice are fetched over the fabric by one L2 only (with the row tiles of every entry spread over
+        // the 8 XCDs each L2 fetched the whole of U and the Cout tiles' shared V rows arrived 2.4x: 3.8 GB per launch against
+        // 2.3 GB algorithmic)
+        const int L = (int)blockIdx.x, j = L >> 3;
+        bz = (L & 7) + 8 * (j / a.tiles);
+        if (bz >= a.batch) return;
+        bid = j % a.tiles;
+    } else {
+        // one GEMM (1x1 layers) or a batch that is no multiple of 8: a contiguous range of the (n_tile fastest) tile order per
+        // XCD, so that the Cout tiles of one row tile share its V rows through one L2 (see conv_igemm.hip)
+        bz = (int)blockIdx.z;
+        bid = xcd_block((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
+    }
+    const float* V = a.V + (size_t)bz * a.vz;
+    const unsigned short* U = a.U + (size_t)bz * a.uz;
+    float* M = a.M + (size_t)bz * a.mz;
     const int n_tile = bid % a.tilesN, m_tile = bid / a.tilesN;
     const int row0 = m_tile * BM, cout0 = n_tile * BN;
 
@@ -291,7 +307,10 @@ static int bf3_launch(const Bf3Args& a, long long blocks, int batch, hipStream_t
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf3_kernel<RES>), dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, st, a);
+    if (a.by_batch)
+        hipLaunchKernelGGL((gemm_bf3_kernel<RES>), dim3((unsigned)(8 * blocks * ((batch + 7) / 8))), dim3(NTHR), lds, st, a);
+    else
+        hipLaunchKernelGGL((gemm_bf3_kernel<RES>), dim3((unsigned)blocks, 1, batch), dim3(NTHR), lds, st, a);
     return BBDM_OK;
 }
 
@@ -301,7 +320,11 @@ static int bf3_run(Bf3Args& a, int batch, hipStream_t st) {
     a.tilesN = a.CoutPad / BN;
     a.uz = (size_t)a.nchunks * 3 * a.CoutPad * KC;
     const long long blocks = ((long long)a.T / BM) * a.tilesN;
-    BBDM_REQUIRE(blocks < (1ll << 31), "gemm_bf3: too many tiles");
+    BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3: too many tiles");
+    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
+    a.tiles = (int)blocks;
+    a.batch = batch;
+    a.by_batch = (by_batch_env && batch >= 8 && (batch % 8 == 0 || by_batch_env == 2)) ? 1 : 0;
     const int rc = a.res ? bf3_launch<true>(a, blocks, batch, st) : bf3_launch<false>(a, blocks, batch, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3");
