@@ -697,6 +697,7 @@ class _Plan:
         self._conv_ws_floats = _LateInt()
         self._wino_v, self._wino_m = _LateTensor(), _LateTensor()      # Winograd V / M planes shared by every layer
         self._wino_v_need = self._wino_m_need = 0
+        self._saved_V: Dict[int, tuple] = {}         # training: id(conv weight) -> (V kept by the forward, tile m)
         self.film, self.film_total, self.resblocks, self._film_key = None, 0, [], None
         # (id(buffer), channel offset) -> record of the conv op that LAST wrote that channel slice: where a GroupNorm
         # consumer can ask the producer to accumulate its statistics (bbdm_*_stats_f32) instead of re-reading the tensor
@@ -851,6 +852,9 @@ class _Plan:
         if name == "bbdm_conv3x3_winograd_wgrad_f32":   # the (m+2)^2 TN GEMMs actually executed
             wm, (N, H, W, cin, cout) = args[0], args[8:13]
             return 2.0 * (wm + 2) ** 2 * N * -(-H // wm) * -(-W // wm) * cin * cout
+        if name == "bbdm_gemm_tn_batched_f32":          # (the Winograd-domain weight gradient on a V kept by the forward)
+            batch, K, M, Nn = args[7:11]
+            return 2.0 * batch * K * M * Nn
         if name == "bbdm_attention_bwd_f32":            # S recomputed + dP, dV, dQ, dK: five T x T x ch products
             N, T, heads, ch = args[10:14]
             return 5.0 * 2.0 * N * heads * T * T * ch
@@ -1006,10 +1010,19 @@ class _Plan:
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad)
         self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
-        emit("bbdm_winograd_input_f32", wm, x, x.ld, self._wino_v, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W,
-             cin_pad)
+        vbuf = self._wino_v
+        if (self.training and not bwd and not upsample and (pre is None or pre[0] is None) and cin_pad == pw.cin
+                and self.m.winograd_wgrad and winograd_wgrad_tile(N, H, W, cin_pad, cout, self.m.winograd_wgrad) == wm):
+            # training: this layer's weight gradient contracts the SAME transformed input (csrc/winograd_wgrad.hip) -- keep V
+            # in a buffer of its own instead of re-running the input transform in the backward pass (memory: (m+2)^2/m^2 x
+            # the activation, ~8 GB over the LBBDM-f4 UNet at batch 32, of the 288 GB)
+            b = _Buf((wm + 2) ** 2 * tiles * cin_pad)
+            self.bufs.append(b)
+            vbuf = _View(b, 0, cin_pad, 1, 1, 1, cin_pad)
+            self._saved_V[id(pw.weight)] = (vbuf, wm)
+        emit("bbdm_winograd_input_f32", wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
         gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
-        emit(gemm, wm, self._wino_v, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
+        emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
         if bwd:
             emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout)
         else:
@@ -1317,7 +1330,23 @@ class _Plan:
             wgm = (winograd_wgrad_tile(N, x_in.H, x_in.W, x_in.C, cout, m.winograd_wgrad)
                    if (m.winograd_wgrad and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             dbias = gref(mod.bias) if mod.bias is not None else None
-            if wgm:
+            saved = self._saved_V.get(id(w)) if wgm else None
+            if saved is not None and saved[1] == wgm:
+                # the forward kept this layer's V: dY transform -> TN GEMM -> finish (the stages bbdm_conv3x3_winograd_wgrad_f32 chains)
+                P, Tp = (wgm + 2) ** 2, lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
+                T = N * -(-x_in.H // wgm) * -(-x_in.W // wgm)
+                splits = lib.bbdm_gemm_tn_splits(P, T, x_in.C, cout)
+                o_du = P * Tp * cout
+                o_acc = (o_du + splits * P * x_in.C * cout + 1) & ~1
+                ws_floats[0] = max(ws_floats[0], o_acc + 2 * cout + 2)
+                dM, dU = _TensorRef(self._ws_f, 0), _TensorRef(self._ws_f, 4 * o_du)
+                self._bop("bbdm_winograd_dy_transform_f32", wgm, dy, dy.ld, dM, N, x_in.H, x_in.W, cout)
+                self._bop("bbdm_gemm_tn_batched_f32", saved[0], x_in.C, Tp * x_in.C, dM, cout, Tp * cout, dU, P, T, x_in.C, cout)
+                self._bop("bbdm_winograd_wgrad_finish_f32", wgm, dU, splits, dw_dst, x_in.C, cout)
+                if dbias is not None:       # column sums of the plane dM_(1,1) = the tile sums of dY (csrc/winograd_wgrad.hip)
+                    self._bop("bbdm_colsum_f32", _TensorRef(self._ws_f, 4 * (wgm + 3) * Tp * cout), cout,
+                              _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
+            elif wgm:
                 ws_floats[0] = max(ws_floats[0], lib.bbdm_winograd_wgrad_workspace_floats(wgm, N, x_in.H, x_in.W, x_in.C, cout))
                 self._bop("bbdm_conv3x3_winograd_wgrad_f32", wgm, x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N,
                           x_in.H, x_in.W, x_in.C, cout)
