@@ -698,6 +698,7 @@ class _Plan:
         self._wino_v, self._wino_m = _LateTensor(), _LateTensor()      # Winograd V / M planes shared by every layer
         self._wino_v_need = self._wino_m_need = 0
         self._saved_V: Dict[int, tuple] = {}         # training: id(conv weight) -> (V kept by the forward, tile m)
+        self._fused_train = set()                    # training: id(conv weight) of layers whose GN->SiLU input was never materialised
         self.film, self.film_total, self.resblocks, self._film_key = None, 0, [], None
         # (id(buffer), channel offset) -> record of the conv op that LAST wrote that channel slice: where a GroupNorm
         # consumer can ask the producer to accumulate its statistics (bbdm_*_stats_f32) instead of re-reading the tensor
@@ -974,7 +975,14 @@ class _Plan:
         free."""
         fuse = fuse_direct or self.m.fuse_groupnorm or (consumer is not None and self.m.winograd_fuse_groupnorm
                                                         and self._winograd_ok(consumer, x.H, x.W, x.C))
-        if self.training or not fuse:
+        if self.training:
+            # Training plans materialise the activated tensor for the weight gradient -- unless that gradient will contract the V
+            # this layer's forward keeps (Winograd layer, same tile both ways: _emit_winograd / conv_bwd): then nothing
+            # re-reads the activation and GN -> FiLM -> SiLU folds into the input transform exactly as in sampling.
+            if not (self.m.winograd_fuse_groupnorm and self._train_keeps_V(consumer, x)):
+                return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
+            self._fused_train.add(id(consumer.weight))
+        elif not fuse:
             return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
         N = self.N
         ref = _Plan._StatsRef(self, self._gn_count)
@@ -989,6 +997,15 @@ class _Plan:
         self._op("bbdm_groupnorm_coeffs_f32", ref, self._pref(gn.weight), self._pref(gn.bias), film, self.film_total, sc, bi,
                  x.C, N, x.H * x.W, x.C, self.GROUPS, float(gn.eps))
         return x, (sc, bi, x.C, silu)
+
+    def _train_keeps_V(self, consumer, x: _View) -> bool:
+        """Will the training forward of conv ``consumer`` on ``x`` keep its transformed input for the weight gradient?"""
+        if consumer is None or not self.m.winograd_wgrad:
+            return False
+        w = consumer.weight
+        wm = self._winograd_ok(consumer, x.H, x.W, x.C)
+        return bool(wm) and w.shape[1] == x.C and \
+            winograd_wgrad_tile(self.N, x.H, x.W, x.C, w.shape[0], self.m.winograd_wgrad) == wm
 
     def _winograd_ok(self, mod, H, W, cin_pad, flags=0) -> int:
         """Winograd output tile for this conv (0 = direct kernel)."""
@@ -1011,7 +1028,7 @@ class _Plan:
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad)
         self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
         vbuf = self._wino_v
-        if (self.training and not bwd and not upsample and (pre is None or pre[0] is None) and cin_pad == pw.cin
+        if (self.training and not bwd and not upsample and cin_pad == pw.cin
                 and self.m.winograd_wgrad and winograd_wgrad_tile(N, H, W, cin_pad, cout, self.m.winograd_wgrad) == wm):
             # training: this layer's weight gradient contracts the SAME transformed input (csrc/winograd_wgrad.hip) -- keep V
             # in a buffer of its own instead of re-running the input transform in the backward pass (memory: (m+2)^2/m^2 x
@@ -1346,6 +1363,8 @@ class _Plan:
                 if dbias is not None:       # column sums of the plane dM_(1,1) = the tile sums of dY (csrc/winograd_wgrad.hip)
                     self._bop("bbdm_colsum_f32", _TensorRef(self._ws_f, 4 * (wgm + 3) * Tp * cout), cout,
                               _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
+            elif id(w) in self._fused_train:
+                raise RuntimeError("bbdm_amd: internal error: the activation of a fused-producer training layer was not kept")
             elif wgm:
                 ws_floats[0] = max(ws_floats[0], lib.bbdm_winograd_wgrad_workspace_floats(wgm, N, x_in.H, x_in.W, x_in.C, cout))
                 self._bop("bbdm_conv3x3_winograd_wgrad_f32", wgm, x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N,

@@ -126,6 +126,7 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     # (layers whose forward ran the same Winograd tile keep their V: the gradient plan then holds the stages, not the chained entry)
     assert sum(str(n) in ("bbdm_conv3x3_winograd_wgrad_f32", "bbdm_winograd_wgrad_finish_f32") for n, _ in plan.bops) >= 4
     assert sum(str(n) == "bbdm_gemm_tn_batched_f32" for n, _ in plan.bops) >= 1
+    assert len(plan._fused_train) >= 2          # ... and those layers' GN -> SiLU input was folded into the transform, not materialised
     assert sum(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.bops) >= 1 and \
         sum(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.ops) >= 1
     sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
