@@ -110,9 +110,22 @@ def test_flop_accounting_direct_equivalent_matches_the_direct_plan():
         assert executed < want and abs(equiv - want) < 1e-6 * want
 
 
-def test_fused_producers_only_in_inference_plans():
+def test_fused_producers_in_training_plans_only_where_the_forward_keeps_V():
+    """Inference plans fold GN -> FiLM -> SiLU into the Winograd input transforms.  A training plan does so only for the layers
+    whose weight gradient contracts the transformed input the forward keeps (same Winograd tile both ways); every other layer
+    materialises the activation for its weight gradient."""
     _, inf = _plan("c1", 16)
-    _, trn = _plan("c1", 16, training=True)
+    m, trn = _plan("c1", 16, training=True)
     fused = lambda p: sum(n == "bbdm_winograd_input_f32" and a[4] is not None for n, a in p.ops)
-    assert fused(inf) > 0 and fused(trn) == 0        # training keeps the normalised tensor for the weight gradient
-    assert sum(n == "bbdm_groupnorm_coeffs_f32" for n, _ in trn.ops) == 0
+    assert fused(inf) > 0
+    assert fused(trn) == len(trn._fused_train) == sum(n == "bbdm_groupnorm_coeffs_f32" for n, _ in trn.ops)
+    assert trn._fused_train <= set(trn._saved_V)                      # fused => its V is kept
+    n_staged = sum(n == "bbdm_gemm_tn_batched_f32" for n, _ in trn.bops)
+    assert n_staged == len(trn._saved_V)                              # ... and the gradient plan uses it
+    # with direct weight gradients nothing may be fused: the activation is what conv_wgrad_f32 reads
+    desc, up, ch, size, n, *_ = bench.WORKLOADS["c1"]
+    m0 = unet.UNetModel(**up)
+    m0.winograd, m0.winograd_wgrad = 4, 0
+    trn0 = m0._plan_for(torch.zeros(16, up["in_channels"], size, size), True)
+    assert fused(trn0) == 0 and not trn0._fused_train and not trn0._saved_V
+    assert sum(n == "bbdm_groupnorm_coeffs_f32" for n, _ in trn0.ops) == 0
