@@ -12,14 +12,20 @@
 // B operand wants, for its two k, lanes <32 -> k0 and lanes >=32 -> k1.  Choosing (k0,k1) = (key_lo(r), key_lo(r)+4)
 // for step r makes register r of P^T exactly the B operand of step r -- no LDS round trip, no shuffles; row
 // max / sum are 15 VALU ops + one cross-half exchange.  The running max / sum / rescale are per-lane scalars.
-#include "common.h"
+#include "bf3_split.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int KT = 32;        // keys per tile
 constexpr int QB = 128;       // queries per block
 
-template <int CH>
+// BQ: S^T = K Q^T on the BF16 matrix core with fp32 accuracy (bf3_split.h: both operands split exactly into three bf16 planes,
+// six product terms, fp32 accumulate): 6 x CH/16 MFMAs of 32 cycles per key tile instead of CH/2 of 64 -- 2.7x less matrix-core
+// time for half of the attention FLOPs.  K is split while it is staged (planes [3][key][CH] bf16 in LDS, +16 B row pad: the 8 rows
+// of a ds_read_b128 group fall on distinct 16-B slots), Q once per workgroup; the bf16 MFMA's C/D layout is the f32 one, so the
+// softmax and the P V product below (f32 MFMA: its B operand is the P registers in place) are untouched.
+template <int CH, bool BQ>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
                                                        const float* __restrict__ ksrc, const float* __restrict__ vsrc, int ldkv,
                                                        int hskv, float* __restrict__ out, int ldo, float* __restrict__ lse,
@@ -33,9 +39,14 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     constexpr int KV4 = KT * CH / 4;               // float4 per K (or V) tile
     constexpr int SLOTS = (KV4 + 255) / 256;
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * KT * KPITCH + 2 * KT * VPITCH];
+    constexpr int KS = CH / 16;                    // BQ: MFMA K-steps of 16 channels
+    constexpr int KROWB = CH * 2 + 16;             // BQ: bytes per key row of one bf16 plane
+    constexpr int KPLANE = KT * KROWB;             // BQ: bytes per plane
+    constexpr int KSTAGE = BQ ? 3 * KPLANE / 4 : KT * KPITCH;      // floats per K stage
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * KSTAGE + 2 * KT * VPITCH];
     float* kbuf = smem;
-    float* vbuf = smem + 2 * KT * KPITCH;
+    float* vbuf = smem + 2 * KSTAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
@@ -49,14 +60,34 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 
     // ---- Q^T fragment: lane holds q[c] for c = kg*8 + hi*4 + j -------------------------------------------------
     const int q = qb * QB + wave * 32 + lq;
-    float4 qf[KG];
+    float4 qf[BQ ? 1 : KG];
+    bf16x8 qb3[BQ ? KS : 1][3];                    // BQ: lane holds q[c], c = ks*16 + hi*8 + 0..7, as three bf16 planes
+    if (BQ) {
 #pragma unroll
-    for (int kg = 0; kg < KG; ++kg) {
-        if (q < Tq) {
-            float4 v = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + kg * 8 + hi * 4);
-            qf[kg] = make_float4(v.x * qscale, v.y * qscale, v.z * qscale, v.w * qscale);
-        } else {
-            qf[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ks = 0; ks < KS; ++ks) {
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (q < Tq) {
+                v0 = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + ks * 16 + hi * 8);
+                v1 = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + ks * 16 + hi * 8 + 4);
+            }
+            v0 = make_float4(v0.x * qscale, v0.y * qscale, v0.z * qscale, v0.w * qscale);
+            v1 = make_float4(v1.x * qscale, v1.y * qscale, v1.z * qscale, v1.w * qscale);
+            uint2 a1, a2, a3, b1, b2, b3;
+            split4(v0, a1, a2, a3);
+            split4(v1, b1, b2, b3);
+            qb3[ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+            qb3[ks][1] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+            qb3[ks][2] = __builtin_bit_cast(bf16x8, make_uint4(a3.x, a3.y, b3.x, b3.y));
+        }
+    } else {
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            if (q < Tq) {
+                float4 v = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + kg * 8 + hi * 4);
+                qf[kg] = make_float4(v.x * qscale, v.y * qscale, v.z * qscale, v.w * qscale);
+            } else {
+                qf[kg] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
 
@@ -89,7 +120,16 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
             const int f = tid + s * 256;
             if (f < KV4) {
                 const int key = f / (CH / 4), c = (f % (CH / 4)) * 4;
-                *reinterpret_cast<float4*>(kbuf + buf * KT * KPITCH + key * KPITCH + c) = kreg[s];
+                if (BQ) {
+                    uint2 p1, p2, p3;
+                    split4(kreg[s], p1, p2, p3);
+                    unsigned char* kd = reinterpret_cast<unsigned char*>(kbuf + buf * KSTAGE) + key * KROWB + c * 2;
+                    *reinterpret_cast<uint2*>(kd) = p1;
+                    *reinterpret_cast<uint2*>(kd + KPLANE) = p2;
+                    *reinterpret_cast<uint2*>(kd + 2 * KPLANE) = p3;
+                } else {
+                    *reinterpret_cast<float4*>(kbuf + buf * KSTAGE + key * KPITCH + c) = kreg[s];
+                }
                 *reinterpret_cast<float4*>(vbuf + buf * KT * VPITCH + key * VPITCH + c) = vreg[s];
             }
         }
@@ -113,14 +153,34 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const float* kb = kbuf + buf * KT * KPITCH + lq * KPITCH + hi * 4;
+        if (BQ) {
+            f32x16 s1;                      // two accumulators: consecutive MFMAs do not wait for each other
 #pragma unroll
-        for (int kg = 0; kg < KG; ++kg) {
-            const float4 kf = *reinterpret_cast<const float4*>(kb + kg * 8);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kg].x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kg].y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kg].z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kg].w, s, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) s1[r] = 0.f;
+            const unsigned char* kb = reinterpret_cast<const unsigned char*>(kbuf + buf * KSTAGE) + lq * KROWB + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 kf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(kb + p * KPLANE + ks * 32);
+#pragma unroll
+                for (int t = 0; t < 6; t += 2) {
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t]], qb3[ks][BF3_TB[t]], s, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t + 1]], qb3[ks][BF3_TB[t + 1]], s1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += s1[r];
+        } else {
+            const float* kb = kbuf + buf * KSTAGE + lq * KPITCH + hi * 4;
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                const float4 kf = *reinterpret_cast<const float4*>(kb + kg * 8);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[kg].x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[kg].y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[kg].z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[kg].w, s, 0, 0, 0);
+            }
         }
 
         // ---- online softmax over the 32 keys of this tile (16 here, 16 in lane^32) --------------------------------
@@ -168,7 +228,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     // ---- epilogue: O^T / l -> LDS [query][c] -> coalesced rows ----------------------------------------------------
     constexpr int OPITCH = CH + 1;
     float* obuf = smem;                                    // 128 * (CH+1) floats <= the K/V buffers for CH >= 16
-    static_assert(QB * OPITCH <= 2 * KT * KPITCH + 2 * KT * VPITCH, "epilogue staging does not fit");
+    static_assert(QB * OPITCH <= 2 * KSTAGE + 2 * KT * VPITCH, "epilogue staging does not fit");
     const float inv = 1.0f / l_run;
     if (lse && hi == 0 && q < Tq) lse[((size_t)n * heads + h) * Tq + q] = m_run + logf(l_run);   // for the backward pass
 #pragma unroll
@@ -193,15 +253,15 @@ static int launch_attention(const float* q, int ldq, int hsq, const float* k, co
                             hipStream_t st) {
     const int qblocks = (Tq + QB - 1) / QB;
     const dim3 grid((unsigned)((long long)N * heads * qblocks));
-    if (ch == 64)
-        hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk,
-                           heads, qscale, kscale);
-    else if (ch == 32)
-        hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk,
-                           heads, qscale, kscale);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk,
-                           heads, qscale, kscale);
+    // Q K^T on the bf16x3 path (BBDM_ATTN_BF3=0: f32 MFMA, for the A/B)
+    static const int bq = [] { const char* e = getenv("BBDM_ATTN_BF3"); return e ? atoi(e) : 1; }();
+#define BBDM_ATTN_FWD(CH, BQ)                                                                                              \
+    hipLaunchKernelGGL((attn_fwd_kernel<CH, BQ>), grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk, \
+                       heads, qscale, kscale)
+    if (ch == 64) { if (bq) BBDM_ATTN_FWD(64, true); else BBDM_ATTN_FWD(64, false); }
+    else if (ch == 32) { if (bq) BBDM_ATTN_FWD(32, true); else BBDM_ATTN_FWD(32, false); }
+    else { if (bq) BBDM_ATTN_FWD(16, true); else BBDM_ATTN_FWD(16, false); }
+#undef BBDM_ATTN_FWD
     return 0;
 }
 

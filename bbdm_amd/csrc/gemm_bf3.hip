@@ -22,7 +22,7 @@
 //    slots of the 256-B bank window.
 //  * Lane l supplies row (l & 31) and the 8 consecutive k of half (l >> 5) for A and for B alike (the sum over k does not
 //    depend on which k a lane carries as long as A and B agree); C/D layout = the f32 32x32 layout (cdna_hip_programming.md).
-#include "common.h"
+#include "bf3_split.h"
 #include <stdlib.h>
 
 namespace {
@@ -31,8 +31,6 @@ constexpr int BM = 256, BN = 128, KC = 16, NTHR = 512;
 constexpr int ROWB = 32;                       // bytes per LDS row (16 bf16)
 constexpr int A_PLANE = BM * ROWB, W_PLANE = BN * ROWB;
 constexpr int STAGE = 3 * A_PLANE + 3 * W_PLANE;      // 36864 B
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct Bf3Args {
     const float* V;          // [batch][T][Cin] fp32
@@ -46,38 +44,11 @@ struct Bf3Args {
     const float* res;        // [T][ldr] or null; may alias M
 };
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float bf16_round(float x) {       // x rounded to bf16 (RNE), returned as fp32
-    return (float)(__bf16)x;
-}
-// two fp32 -> two bf16 (RNE) packed in one dword: ONE v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned cvt_pk(float lo, float hi) {
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float lo_as_f32(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float hi_as_f32(unsigned p) { return __uint_as_float(p & 0xFFFF0000u); }
 // byte offset inside a plane: 32-B rows, the 16-B half flips with bits 2 and 3 of the row, so that the 8 (and 16) consecutive
 // rows a ds_read_b128 group touches land on distinct 16-B slots of a 128-B (256-B) window.  Measured: indistinguishable from the
 // `(row >> 3) & 1` swizzle this kernel first shipped with (tools/bf3_probe.py, +-1 %) -- fragment reads are not what bounds it.
 __device__ __forceinline__ int swz(int row, int byte_in_row) {
     return row * ROWB + (byte_in_row ^ ((((row >> 2) ^ (row >> 3)) & 1) << 4));
-}
-
-// a pair of fp32 -> the pair's three packed bf16 planes (11 VALU ops per pair)
-__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    p1 = cvt_pk(x0, x1);
-    const float r0 = x0 - lo_as_f32(p1), r1 = x1 - hi_as_f32(p1);          // exact
-    p2 = cvt_pk(r0, r1);
-    p3 = cvt_pk(r0 - lo_as_f32(p2), r1 - hi_as_f32(p2));
-}
-
-// a 4-element fp32 group -> 3 x (4 bf16 = 8 B)
-__device__ __forceinline__ void split4(float4 v, uint2& p1, uint2& p2, uint2& p3) {
-    split2(v.x, v.y, p1.x, p2.x, p3.x);
-    split2(v.z, v.w, p1.y, p2.y, p3.y);
 }
 
 __device__ __forceinline__ int xcd_block(int nblk, int x, int off) {
@@ -198,14 +169,13 @@ __global__ void __launch_bounds__(NTHR, 4) gemm_bf3_kernel(const Bf3Args a) {
             }
         // term-major, tile-minor: consecutive MFMAs go to DIFFERENT accumulators (a dependent MFMA would wait for its
         // predecessor's result); smallest terms first: they meet an accumulator not yet grown by this chunk's leading term
-        constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t]], bf[j][TB[t]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][BF3_TA[t]], bf[j][BF3_TB[t]], acc[i][j], 0, 0, 0);
         if (more) store(smem + ((chunk + 1) & 1) * STAGE);
         __syncthreads();
     }
