@@ -56,6 +56,20 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert lib_tiles(6, 16, 64, 64) == 2048 and lib_tiles(4, 16, 64, 64) == 4096 and lib_tiles(2, 3, 8, 12) == 256
 
 
+def test_winograd_wgrad_tile_choice_follows_the_measured_crossovers():
+    """profiles/r02_wgrad_bench.txt (MI355X, batch 32; direct / m = 4 / m = 6 in ms)."""
+    wt = unet.winograd_wgrad_tile
+    assert wt(32, 64, 64, 512, 512) == 6               # 4.82 / 2.17 / 1.69
+    assert wt(32, 64, 64, 128, 128) == 6               # 0.51 / 0.46 / 0.38
+    assert wt(32, 64, 64, 640, 128) == 6               # 1.69 / 0.89 / 0.77
+    assert wt(32, 32, 32, 1536, 512) == 4              # 4.78 / 1.60 / 1.46: m = 6 only ties here (27 % edge waste) ...
+    assert wt(32, 16, 16, 2048, 1024) == 4             # 2.67 / 1.31 / 1.40: ... and loses on 16x16
+    assert wt(2, 64, 64, 128, 128) == 4                # 512 4x4 tiles but only 242 8x8 tiles
+    assert wt(2, 16, 16, 1024, 1024) == 0              # too few tiles for the TN GEMMs' K: direct kernel
+    assert wt(32, 64, 64, 8, 128) == 0 and wt(32, 64, 64, 128, 3) == 0      # stem / head
+    assert wt(32, 64, 64, 512, 512, 4) == 4 and wt(32, 64, 64, 512, 512, 0) == 0     # the cap (BBDM_WINOGRAD_WGRAD)
+
+
 @pytest.mark.parametrize("workload,batch,training,cap", [("c1", 4, False, 4), ("c1", 16, False, 4), ("c1", 16, True, 4),
                                                          ("c5", 32, False, 4), ("c1", 16, False, 6), ("c2", 2, False, 6),
                                                          ("c3", 32, True, 6)])
