@@ -31,8 +31,9 @@ def variant(no_lds_read=False, no_stage=False, no_barrier=False, no_mfma=False):
                             "        if (chunk == 0)\n#pragma unroll\n        for (int t = 0; t < 2; ++t)\n#pragma unroll\n            for (int p = 0; p < 3; ++p) {")
         loop = loop.replace("    for (int chunk = 0; chunk < a.nchunks; ++chunk) {", "    bf16x8 af[2][3], bf[2][3];\n    for (int chunk = 0; chunk < a.nchunks; ++chunk) {")
     if no_mfma:
-        loop = loop.replace("acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[t]], bf[j][TB[t]], acc[i][j], 0, 0, 0);",
-                            "acc[i][j][t] += (float)af[i][TA[t]][0] * (float)bf[j][TB[t]][0];")
+        loop = loop.replace("acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][BF3_TA[t]], bf[j][BF3_TB[t]], acc[i][j], 0, 0, 0);",
+                            "acc[i][j][t] += (float)af[i][BF3_TA[t]][0] * (float)bf[j][BF3_TB[t]][0];")
+    assert loop != LOOP_OLD or not (no_lds_read or no_stage or no_barrier or no_mfma), "a patch did not apply: csrc/gemm_bf3.hip changed"
     return src.replace(LOOP_OLD, loop)
 
 
