@@ -32,9 +32,8 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "oracle")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 32 cycles per 32x32x16)
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD * 1024 SIMD * 2.4 GHz
@@ -107,7 +106,10 @@ def _ns(c):
 
 
 def synth_state(model_unet, seed=777):
-    from fixture_weights import synth_weights          # deterministic N(0, 0.02)-style weights (oracle/)
+    tests_dir = os.path.join(ROOT, "tests")                    # deterministic N(0, 0.02)-style weights: tests/fixture_weights.py
+    if tests_dir not in sys.path:                              # (a weight generator shared with the fixtures, not the oracle)
+        sys.path.insert(0, tests_dir)
+    from fixture_weights import synth_weights
     shapes = [(k, tuple(v.shape)) for k, v in model_unet.state_dict().items()]
     return synth_weights(shapes, seed, w_std=0.02)
 
@@ -141,6 +143,9 @@ class _CpuPath:
     """p_sample of the reference (kind 'reference') or of oracle/bbdm_oracle.py (kind 'port') on the host cores."""
 
     def __init__(self, up, skip, sstep, sd):
+        odir = os.path.join(ROOT, "oracle")                     # the cpu_baseline leg is the only user of oracle/ in this file
+        if odir not in sys.path:
+            sys.path.insert(0, odir)
         import bbdm_oracle as O
         self.ref = _reference_model(up, skip, sstep, sd)
         self.kind = "reference" if self.ref is not None else "port"

@@ -21,8 +21,8 @@ import yaml
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, HERE)
-from fixture_weights import synth_weights  # noqa: E402
+sys.path[:0] = [HERE, os.path.join(os.path.dirname(HERE), "tests")]
+from fixture_weights import synth_weights  # noqa: E402  (tests/fixture_weights.py)
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 
@@ -63,7 +63,7 @@ CASES = {
 
 
 def randomize(model, seed):
-    """Fill the UNet with oracle/fixture_weights.synth_weights (regenerable from the seed, so the
+    """Fill the UNet with tests/fixture_weights.synth_weights (regenerable from the seed, so the
     fixtures need not carry the weights)."""
     shapes = [(k, tuple(v.shape)) for k, v in model.denoise_fn.state_dict().items()]
     sd = synth_weights(shapes, seed)

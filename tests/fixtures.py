@@ -3,7 +3,7 @@ import os
 
 import torch
 
-from fixture_weights import synth_weights          # oracle/
+from fixture_weights import synth_weights          # tests/fixture_weights.py
 import bbdm_oracle as O                            # oracle/
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
