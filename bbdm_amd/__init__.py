@@ -5,5 +5,6 @@ hand-written HIP kernels behind a C-ABI (include/bbdm_hip.h), exposed through dr
 """
 from .model import BrownianBridgeModel, LatentBrownianBridgeModel, bridge_schedule  # noqa: F401
 from .unet import UNetModel  # noqa: F401
+from .cond_stage import SpatialRescaler  # noqa: F401
 
-__all__ = ["BrownianBridgeModel", "LatentBrownianBridgeModel", "UNetModel", "bridge_schedule"]
+__all__ = ["BrownianBridgeModel", "LatentBrownianBridgeModel", "UNetModel", "SpatialRescaler", "bridge_schedule"]

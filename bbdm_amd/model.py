@@ -267,19 +267,6 @@ def disabled_train(self, mode=True):
     return self
 
 
-def _reference_class(module: str, name: str, why: str):
-    """Resolve a first-stage / conditioning class from the BBDM checkout on ``sys.path``.
-
-    VQGAN encode/decode stay on PyTorch-ROCm (BASELINE.json north_star): used as a
-    drop-in inside the reference tree the reference's own classes are instantiated; bbdm_amd ships none."""
-    import importlib
-    try:
-        return getattr(importlib.import_module(module), name)
-    except Exception as e:                             # pragma: no cover
-        raise ImportError(f"{why} needs {module}.{name} from the BBDM checkout on sys.path (out of bbdm_amd's "
-                          "hot-path scope; it stays on PyTorch-ROCm)") from e
-
-
 class LatentBrownianBridgeModel(BrownianBridgeModel):
     """LatentBrownianBridgeModel.py:19-147: the same bridge run in the latent space of a frozen VQGAN.
 
@@ -307,9 +294,8 @@ class LatentBrownianBridgeModel(BrownianBridgeModel):
         elif key == 'first_stage':
             self.cond_stage_model = self.vqgan
         elif key == 'SpatialRescaler':
-            rescaler = _reference_class("model.BrownianBridge.base.modules.encoders.modules", "SpatialRescaler",
-                                        "condition_key='SpatialRescaler'")
-            self.cond_stage_model = rescaler(**vars(model_config.CondStageParams))
+            from .cond_stage import SpatialRescaler          # same constructor / state_dict as the reference's class
+            self.cond_stage_model = SpatialRescaler(**vars(model_config.CondStageParams))
         else:
             raise NotImplementedError
 
