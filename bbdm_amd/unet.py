@@ -486,8 +486,6 @@ class UNetModel(nn.Module):
             unsupported.append("num_classes")
         if n_embed is not None:
             unsupported.append("n_embed")
-        if dropout:
-            unsupported.append(f"dropout={dropout}")
         if unsupported:
             raise NotImplementedError("bbdm_amd.UNetModel does not implement: " + ", ".join(unsupported))
 
@@ -605,6 +603,11 @@ class UNetModel(nn.Module):
         """openaimodel.py:721-759.  x: [N, C, H, W] fp32 on the GPU; returns [N, out_channels, H, W] fp32."""
         assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
+        if self.dropout and self.training:
+            # nn.Dropout is the identity in eval(): a checkpoint trained with dropout samples exactly; the masks of train()
+            # mode are not implemented (the four reference templates set dropout 0.0)
+            raise NotImplementedError(f"bbdm_amd.UNetModel: dropout={self.dropout} in train() mode is not implemented "
+                                      "(sampling / eval() with such a config is supported)")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .autograd import unet_apply          # training path (autograd.Function over the same kernels)
             return unet_apply(self, x, timesteps, context)

@@ -143,3 +143,20 @@ def test_fused_producers_in_training_plans_only_where_the_forward_keeps_V():
     trn0 = m0._plan_for(torch.zeros(16, up["in_channels"], size, size), True)
     assert fused(trn0) == 0 and not trn0._fused_train and not trn0._saved_V
     assert sum(n == "bbdm_groupnorm_coeffs_f32" for n, _ in trn0.ops) == 0
+
+
+def test_unsupported_options_fail_loudly_and_only_where_they_matter():
+    """`num_classes`, `dims != 2`, `n_embed` raise at construction; `dropout > 0` only in train() mode (nn.Dropout is the identity
+    in eval(): a checkpoint trained with dropout must sample)."""
+    base = dict(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+                channel_mult=(1,), num_head_channels=32, condition_key="nocond")
+    for bad in (dict(num_classes=10), dict(dims=3), dict(n_embed=16)):
+        with pytest.raises(NotImplementedError):
+            unet.UNetModel(**base, **bad)
+    m = unet.UNetModel(**base, dropout=0.1)
+    m.eval()
+    plan = m._plan_for(torch.zeros(2, 4, 8, 8), False)          # an inference plan builds: dropout is the identity there
+    assert len(plan.ops) > 0
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 4, 8, 8), timesteps=torch.zeros(2, dtype=torch.int64))
