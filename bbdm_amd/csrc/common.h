@@ -58,7 +58,15 @@ int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed
 extern "C" int bbdm_gemm_bf3_f32(const float* V, const void* packed_bf3, float* M, int batch, long long T, int CinPad, int Cout,
                                  void* stream);
 
+// gemm_bf3p.hip (declared here for winograd.hip; also part of the public header)
+extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                  float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
+
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 // hardware v_exp_f32 + v_rcp_f32 (~2 ulp; __frcp_rn would expand to the full IEEE division sequence): for kernels where the exact-division form above would make an HBM-bound pass
 // ALU-bound (the Winograd input transform evaluates each activation (m+2)^2/m^2 times)
+// gemm_bf3p.hip (declared here for winograd.hip; also part of the public header)
+extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                  float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
+
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }

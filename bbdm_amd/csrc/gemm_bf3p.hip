@@ -1,0 +1,326 @@
+// gemm_bf3p.hip -- the fp32-accurate bf16x3 GEMM of gemm_bf3.hip with BOTH operands pre-split by their producers.
+//
+// gemm_bf3.hip takes fp32 rows and splits them into their three bf16 planes while it stages them: global -> registers -> 11 VALU
+// ops per pair -> three ds_writes, on the same waves that issue the MFMAs.  Its ablation (profiles/r02_bf3_ablation.txt: MFMAs
+// alone 2.38 ms, staging alone 1.68 ms, together 3.38 ms) says that work overlaps the matrix pipe only half.  Here the A operand
+// arrives ALREADY split -- the Winograd input transform (winograd.hip: winograd_input_split_kernel) or bbdm_gemm_bf3p_split_rows_f32
+// write the three planes -- and already in the order the matrix core wants it, so the GEMM's main loop is LDS-DMA copies,
+// fragment reads and MFMAs: no VALU arithmetic, no ds_write, no staging registers.  Arithmetic is gemm_bf3.hip's to the bit (the
+// same exact three-way split, the same six terms in the same order, fp32 accumulation in the MFMA).
+//
+// Operand layout ("fragment units"): a unit is 32 rows x 16 k of ONE bf16 plane = 1 KB, stored in the order the lanes of
+// v_mfma_f32_32x32x16_bf16 consume it: lane l supplies row (l & 31) and the 8 consecutive k of half (l >> 5), so element (r, k)
+// sits at byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 and a wave reads its fragment with ONE ds_read_b128 at lane * 16 -- linear,
+// bank-conflict free by construction, and exactly the image one global_load_lds_dwordx4 (wave-uniform LDS base + lane * 16)
+// deposits when every lane fetches global unit + lane * 16: one perfectly coalesced 1 KB request per unit, no swizzle anywhere.
+//   A (V planes): [batch][T / 32 row groups][nchunks][3 planes][1 KB]      6 B per element (fp32: 4 B)
+//   B (U planes): [batch][CoutPad / 32 col groups][nchunks][3 planes][1 KB]
+// The chunks of one row group are contiguous: a workgroup streams its 8 row groups as 8 sequential 3 KB-per-chunk streams.
+//
+// Kernel: workgroup = WM x WN waves of 64 x 64 outputs (2 x 2 MFMA tiles, 64 accumulator VGPRs); 256 x 128 with 8 waves, two
+// workgroups per CU (128 VGPRs, 72 KB LDS) is the default.  K is walked 16 at a time (one MFMA K-step): per chunk and wave 12
+// fragment reads, 24 MFMAs and its share of the next chunk's (24 + 12) unit copies into the other LDS stage, then ONE wait +
+// barrier.  The copies are issued after the fragment reads and land under the MFMAs.
+#include "bf3_split.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int KC = 16;
+constexpr int UNIT = 1024;                     // bytes of one fragment unit
+
+struct Bf3pArgs {
+    const unsigned char* A;  // [batch][T / 32][nchunks][3][UNIT]
+    const unsigned char* B;  // [batch][CoutPad / 32][nchunks][3][UNIT]
+    float* M;                // [batch][T][ldo] fp32
+    size_t az, bz, mz;       // per-batch strides: bytes, bytes, floats
+    int T, Cout, nchunks, tilesN;
+    int tiles, batch, by_batch;
+    int ldo, ldr;
+    const float* bias;       // [Cout] or null
+    const float* res;        // [T][ldr] or null; may alias M
+};
+
+__device__ __forceinline__ int xcd_block_p(int nblk, int x, int off) {
+    if (nblk < 64) return x;
+    const int c = (off + x) & 7;
+    int start = 0;
+    for (int cc = 0; cc < 8; ++cc) {
+        if (cc == c) break;
+        const int first = (cc - off) & 7;
+        start += (nblk - first + 7) >> 3;
+    }
+    return start + ((x - ((c - off) & 7)) >> 3);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one LDS-DMA: every lane fetches 16 B at gsrc (per-lane address), the wave's 1 KB lands at lds_wave_base + lane * 16
+__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// WM x WN waves, each 64 x 64.  RES: add a residual row in the epilogue (compile-time, see gemm_bf3.hip).
+template <int WM, int WN, bool RES>
+__global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_kernel(const Bf3pArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
+    constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
+    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
+    constexpr int KMAX = (NU + NW - 1) / NW;                                  // copies per wave and chunk (the last may be partial)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bid, bz;
+    if (a.by_batch) {        // XCD c owns the batch entries c, c + 8, ...: an entry's operands cross the fabric into ONE L2
+        const int L = (int)blockIdx.x, j = L >> 3;
+        bz = (L & 7) + 8 * (j / a.tiles);
+        if (bz >= a.batch) return;
+        bid = j % a.tiles;
+    } else {
+        bz = (int)blockIdx.z;
+        bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
+    }
+    const int n_tile = bid % a.tilesN, m_tile = bid / a.tilesN;
+    const int row0 = m_tile * BM, cout0 = n_tile * BN;
+    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;                       // bytes of one row / col group (all chunks)
+    const unsigned char* A = a.A + (size_t)bz * a.az + (size_t)m_tile * (WM * 2) * gstride;
+    const unsigned char* B = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride;
+    float* M = a.M + (size_t)bz * a.mz;
+
+    // ---- this wave's share of a stage: units wave, wave + NW, ... of [A: (row group i, plane p) | B: (col group j, plane p)] ----
+    const unsigned char* src[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int u = wave + k * NW;
+        const int ub = u - NA;
+        src[k] = (u < NA ? A + (size_t)(u / 3) * gstride + (u % 3) * UNIT
+                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT) + lane * 16;
+    }
+    auto issue = [&](int chunk, unsigned char* st) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int u = wave + k * NW;
+            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), st + u * UNIT);
+        }
+    };
+
+    // ---- fragment addresses: unit (2 wm + t, p) of A, unit (2 wn + t, p) of B, one 16-B slot per lane ----------------------
+    const int aoff = (wm * 2) * 3 * UNIT + lane * 16;
+    const int boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // bias before the main loop: its load is long complete when the epilogue uses it (hipcc does not see the counted waits of the
+    // loop and would otherwise re-wait vmcnt(0) in front of every store)
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+    issue(0, smem);
+    wait_vmcnt<0>();
+    __syncthreads();
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const unsigned char* st = smem + (chunk & 1) * STAGE;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[t][p] = *reinterpret_cast<const bf16x8*>(st + aoff + (t * 3 + p) * UNIT);
+                bf[t][p] = *reinterpret_cast<const bf16x8*>(st + boff + (t * 3 + p) * UNIT);
+            }
+        __builtin_amdgcn_sched_barrier(0);          // the copies below are issued AFTER the reads (no LDS read while a copy is in flight)
+        if (chunk + 1 < a.nchunks) issue(chunk + 1, smem + ((chunk + 1) & 1) * STAGE);
+        // term-major, tile-minor: consecutive MFMAs go to different accumulators; smallest terms first (gemm_bf3.hip)
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][BF3_TA[t]], bf[j][BF3_TB[t]], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the register-only MFMAs below the barrier)
+        wait_vmcnt<0>();                            // this wave's copies of the next stage have landed ...
+        __syncthreads();                            // ... and so have everybody else's; everybody is done reading this stage
+    }
+
+    // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float rv[8][2];
+            if (RES) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = r0 + rr;
+                    const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                        rv[rr][j] = co < a.Cout ? a.res[(size_t)row * a.ldr + co] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + rr;
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* dst = M + (size_t)row * a.ldo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                    float v = acc[i][j][r] + bv[j];
+                    if (RES) v += rv[rr][j];
+                    if (co < a.Cout) dst[co] = v;
+                }
+            }
+        }
+}
+
+// byte offset of element (row r, k) inside a fragment unit
+__device__ __forceinline__ int unit_off(int r, int k) { return (k >> 3) * 512 + r * 16 + (k & 7) * 2; }
+
+// fp32 packed [batch][nchunks][CoutPad][16] (bbdm_conv_pack_weight_f32 ks = 1 / bbdm_winograd_pack_weight_f32) ->
+// B planes [batch][CoutPad / 32][nchunks][3][UNIT]; one thread = one (cout, k pair)
+__global__ void bf3p_pack_b_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t batch_chunks,
+                                   int nchunks, int CoutPad) {
+    const size_t pairs = batch_chunks * CoutPad * (KC / 2);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+        const int kp = (int)(i % (KC / 2));
+        size_t t = i / (KC / 2);
+        const int co = (int)(t % CoutPad);
+        const size_t bc = t / CoutPad;
+        const size_t b = bc / nchunks;
+        const int chunk = (int)(bc % nchunks);
+        const float2 v = *reinterpret_cast<const float2*>(src + (bc * CoutPad + co) * KC + kp * 2);
+        unsigned p1, p2, p3;
+        split2(v.x, v.y, p1, p2, p3);
+        unsigned char* d = dst + (((b * (CoutPad / 32) + co / 32) * nchunks + chunk) * 3) * (size_t)UNIT + unit_off(co & 31, kp * 2);
+        *reinterpret_cast<unsigned*>(d) = p1;
+        *reinterpret_cast<unsigned*>(d + UNIT) = p2;
+        *reinterpret_cast<unsigned*>(d + 2 * UNIT) = p3;
+    }
+}
+
+// fp32 rows [batch][T][ld] -> A planes [batch][T / 32][nchunks][3][UNIT].  Workgroup = 32 rows x 8 channel pairs (one unit per
+// plane): a wave writes 8 rows x 16 B twice = two full 128-B lines per store instruction.
+__global__ void __launch_bounds__(256) bf3p_split_rows_kernel(const float* __restrict__ x, int ld, size_t xz,
+                                                               unsigned char* __restrict__ dst, size_t dz, int T, int nchunks) {
+    const int chunk = (int)blockIdx.x % nchunks, g = (int)blockIdx.x / nchunks, b = (int)blockIdx.y;
+    const int r = threadIdx.x >> 3, kp = threadIdx.x & 7;
+    const int row = g * 32 + r;
+    float2 v = make_float2(0.f, 0.f);
+    if (row < T) v = *reinterpret_cast<const float2*>(x + (size_t)b * xz + (size_t)row * ld + chunk * KC + kp * 2);
+    unsigned p1, p2, p3;
+    split2(v.x, v.y, p1, p2, p3);
+    unsigned char* d = dst + (size_t)b * dz + (((size_t)g * nchunks + chunk) * 3) * UNIT + unit_off(r, kp * 2);
+    *reinterpret_cast<unsigned*>(d) = p1;
+    *reinterpret_cast<unsigned*>(d + UNIT) = p2;
+    *reinterpret_cast<unsigned*>(d + 2 * UNIT) = p3;
+}
+
+}  // namespace
+
+extern "C" size_t bbdm_gemm_bf3p_a_bytes(int batch, long long T, int CinPad) {
+    return (size_t)batch * (size_t)((T + 255) / 256 * 256) * (size_t)CinPad * 6;
+}
+extern "C" size_t bbdm_gemm_bf3p_b_bytes(int batch, int CinPad, int Cout) {
+    return (size_t)batch * (size_t)(cdiv(Cout, 128) * 128) * (size_t)CinPad * 6;
+}
+
+// Can this shape take the pre-split kernel?  (whole 256-row tiles, whole 16-channel chunks)
+extern "C" int bbdm_gemm_bf3p_supported(long long T, int CinPad, int Cout) {
+    return T > 0 && T % 256 == 0 && CinPad > 0 && CinPad % KC == 0 && Cout > 0 && Cout % 4 == 0 && T < (1ll << 31);
+}
+
+extern "C" int bbdm_gemm_bf3p_pack_b_f32(const float* packed_f32, void* b_planes, int batch, int CinPad, int Cout, void* stream) {
+    BBDM_REQUIRE(packed_f32 && b_planes && batch > 0 && CinPad > 0 && CinPad % KC == 0 && Cout > 0, "gemm_bf3p_pack_b: bad args");
+    const int CoutPad = cdiv(Cout, 128) * 128, nchunks = CinPad / KC;
+    const size_t pairs = (size_t)batch * nchunks * CoutPad * (KC / 2);
+    size_t blocks = (pairs + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bf3p_pack_b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, packed_f32,
+                       (unsigned char*)b_planes, (size_t)batch * nchunks, nchunks, CoutPad);
+    BBDM_CHECK_LAUNCH("gemm_bf3p_pack_b");
+    return BBDM_OK;
+}
+
+// fp32 rows -> the A planes (rows T .. the next multiple of 256 are written as zeros).  The Winograd path does not need it (its
+// input transform writes the planes); it serves GEMMs whose A operand is an ordinary fp32 matrix, and the tests.
+extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_planes, int batch, long long T, int CinPad,
+                                             void* stream) {
+    BBDM_REQUIRE(x && a_planes && batch > 0 && T > 0 && CinPad > 0 && CinPad % KC == 0 && ldx >= CinPad && ldx % 2 == 0,
+                 "gemm_bf3p_split_rows: bad args");
+    BBDM_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)a_planes & 15) == 0, "gemm_bf3p_split_rows: alignment");
+    const long long Tp = (T + 255) / 256 * 256;
+    const int nchunks = CinPad / KC;
+    BBDM_REQUIRE((Tp / 32) * nchunks < (1ll << 31) && batch < 65536, "gemm_bf3p_split_rows: too large");
+    hipLaunchKernelGGL(bf3p_split_rows_kernel, dim3((unsigned)((Tp / 32) * nchunks), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, (size_t)T * ldx, (unsigned char*)a_planes, (size_t)Tp * CinPad * 6, (int)T,
+                       nchunks);
+    BBDM_CHECK_LAUNCH("gemm_bf3p_split_rows");
+    return BBDM_OK;
+}
+
+template <int WM, int WN, bool RES>
+static int bf3p_launch(const Bf3pArgs& a, long long blocks, int batch, hipStream_t st) {
+    static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[bbdm_device_slot()];
+    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_kernel<WM, WN, RES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    if (a.by_batch)
+        hipLaunchKernelGGL((gemm_bf3p_kernel<WM, WN, RES>), dim3((unsigned)(8 * blocks * ((batch + 7) / 8))), dim3(WM * WN * 64),
+                           lds, st, a);
+    else
+        hipLaunchKernelGGL((gemm_bf3p_kernel<WM, WN, RES>), dim3((unsigned)blocks, 1, batch), dim3(WM * WN * 64), lds, st, a);
+    return BBDM_OK;
+}
+
+// M[b][T][ldo] = A_b . B_b (+ bias) (+ residual): A, B in the plane layout of the header
+extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                  float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream) {
+    BBDM_REQUIRE(a_planes && b_planes && M && batch > 0, "gemm_bf3p: null pointer / bad batch");
+    BBDM_REQUIRE(bbdm_gemm_bf3p_supported(T, CinPad, Cout), "gemm_bf3p: T=%lld CinPad=%d Cout=%d unsupported (T %% 256, CinPad %% 16)",
+                 T, CinPad, Cout);
+    BBDM_REQUIRE((((uintptr_t)a_planes | (uintptr_t)b_planes) & 15) == 0 && ((uintptr_t)M & 3) == 0 && ldo >= Cout &&
+                     (!residual || ldr >= Cout),
+                 "gemm_bf3p: alignment / pitch");
+    Bf3pArgs a;
+    a.A = (const unsigned char*)a_planes; a.B = (const unsigned char*)b_planes; a.M = M;
+    a.T = (int)T; a.Cout = Cout; a.nchunks = CinPad / KC;
+    const int CoutPad = cdiv(Cout, 128) * 128;
+    a.tilesN = CoutPad / 128;
+    a.az = (size_t)T * CinPad * 6; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo;
+    a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    const long long blocks = (T / 256) * a.tilesN;
+    BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3p: too many tiles");
+    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
+    a.tiles = (int)blocks;
+    a.batch = batch;
+    a.by_batch = (by_batch_env && batch >= 8 && (batch % 8 == 0 || by_batch_env == 2)) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = residual ? bf3p_launch<4, 2, true>(a, blocks, batch, st) : bf3p_launch<4, 2, false>(a, blocks, batch, st);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("gemm_bf3p");
+    return BBDM_OK;
+}

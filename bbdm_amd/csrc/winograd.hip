@@ -19,6 +19,7 @@
 // than m = 4 per layer where the image is >= 64 pixels a side (little edge waste) and there are >= ~1000 tiles; slower
 // on 16x16 / 32x32 latents, where m = 4 stays (bbdm_amd/unet.py: winograd_tile).
 #include "winograd_math.h"
+#include "bf3_split.h"
 
 namespace {
 
@@ -274,6 +275,95 @@ __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __res
     }
 }
 
+// ---- (1') input transform that writes the three bf16 planes gemm_bf3p.hip consumes -----------------------------------------
+// Same arithmetic as the kernels above (B^T d B in fp32, GroupNorm -> FiLM -> SiLU / nearest x2 folded in), followed by the
+// exact three-way bf16 split of every transformed value (bf3_split.h): the GEMM's main loop then copies and multiplies, nothing
+// else.  Output = the A-plane layout of gemm_bf3p.hip, [xi][tile / 32][chunk][3][1 KB fragment unit].
+// One thread = one (tile, channel PAIR) for every m; a workgroup = 32 consecutive tiles (one row group) x 8 pairs (one 16-channel
+// chunk), thread = tile_local * 8 + pair: a wave reads 8 tiles x 64 B per load and writes, per plane and transform point, rows
+// 8 w .. 8 w + 7 of the unit's two k-halves = two full 128-B lines per store instruction.  Workgroups are dealt so that the
+// chunks of one row group run on ONE XCD (block id % 8): the two 64-B halves of an input line meet in that L2.
+// Rows between the real tile count and the padded one (whole 256-row GEMM tiles) are written as zeros.
+template <int MO, bool PRE, bool UP>
+__global__ void __launch_bounds__(256) winograd_input_split_kernel(const float* __restrict__ x, int ldx,
+                                                                   unsigned char* __restrict__ Vp, const float* __restrict__ sc,
+                                                                   const float* __restrict__ bi, int pre_ld, int pre_silu, int N,
+                                                                   int H, int W, int nchunks, long long T, int RG, size_t plane) {
+    constexpr int AL = MO + 2;
+    const int L = (int)blockIdx.x, j = L >> 3;
+    const int chunk = j % nchunks, g = (j / nchunks) * 8 + (L & 7);
+    if (g >= RG) return;
+    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const int rl = threadIdx.x >> 3, cp = threadIdx.x & 7;
+    const long long tile = (long long)g * 32 + rl;
+    const int c = chunk * KC + cp * 2;
+    // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
+    unsigned char* o = Vp + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
+    if (tile >= T) {
+        for (int xi = 0; xi < AL * AL; ++xi) {
+            *reinterpret_cast<unsigned*>(o) = 0u;
+            *reinterpret_cast<unsigned*>(o + 1024) = 0u;
+            *reinterpret_cast<unsigned*>(o + 2048) = 0u;
+            o += plane;
+        }
+        return;
+    }
+    const int tw = (int)(tile % TW);
+    const long long r = tile / TW;
+    const int th = (int)(r % TH), n = (int)(r / TH);
+    float2 s2 = make_float2(1.f, 1.f), b2 = make_float2(0.f, 0.f);
+    if (PRE) {
+        s2 = *reinterpret_cast<const float2*>(sc + (size_t)n * pre_ld + c);
+        b2 = *reinterpret_cast<const float2*>(bi + (size_t)n * pre_ld + c);
+    }
+    const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
+    float2 t[AL][AL];
+#pragma unroll
+    for (int jj = 0; jj < AL; ++jj) {       // one column of the window at a time, its loads issued together (see winograd_input6_kernel)
+        const int w = MO * tw - 1 + jj;
+        const int wc = min(max(w, 0), W - 1);
+        const int wsrc = UP ? wc >> 1 : wc;
+        const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
+        float2 d[AL], col[AL];
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int hc = min(max(MO * th - 1 + i, 0), H - 1);
+            const int hs = UP ? hc >> 1 : hc;
+            d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+        }
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            const int h = MO * th - 1 + i;
+            const float mask = (h >= 0 && h < H) ? wmask : 0.f;
+            float2 v = d[i];
+            if (PRE) {
+                v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
+                if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
+            }
+            d[i] = make_float2(mask * v.x, mask * v.y);
+        }
+        bt_transform<MO>(d, col);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) t[i][jj] = col[i];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        float2 row[AL];
+        bt_transform<MO>(t[i], row);
+#pragma unroll
+        for (int jj = 0; jj < AL; ++jj) {
+            unsigned p1, p2, p3;
+            split2(row[jj].x, row[jj].y, p1, p2, p3);
+            *reinterpret_cast<unsigned*>(o) = p1;
+            *reinterpret_cast<unsigned*>(o + 1024) = p2;
+            *reinterpret_cast<unsigned*>(o + 2048) = p3;
+            o += plane;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <bool RES>
 __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                                const float* __restrict__ bias,
@@ -504,6 +594,52 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
     BBDM_REQUIRE(V && packed_bf3 && M && N > 0, "winograd_gemm_bf3: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     return bbdm_gemm_bf3_f32(V, packed_bf3, M, planes(m), (long long)tiles_padded(N, H, W, m), CinPad, Cout, stream);
+}
+
+// The input transform that writes the three bf16 planes of gemm_bf3p.hip (same arguments as bbdm_winograd_input_f32; Vp holds
+// bbdm_gemm_bf3p_a_bytes((m+2)^2, tiles, CinPad) bytes; CinPad a multiple of 16), and the tile GEMMs on them: b_planes =
+// bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
+extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale,
+                                            const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
+                                            int CinPad, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    BBDM_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "winograd_input_bf3p: upsample needs even H, W");
+    BBDM_REQUIRE(CinPad > 0 && CinPad % KC == 0 && ldx % 2 == 0 && ldx >= CinPad, "winograd_input_bf3p: CinPad=%d ldx=%d", CinPad, ldx);
+    BBDM_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)Vp & 15) == 0, "winograd_input_bf3p: alignment");
+    BBDM_REQUIRE((pre_scale == nullptr) == (pre_bias == nullptr), "winograd_input_bf3p: pre_scale / pre_bias must come together");
+    BBDM_REQUIRE(!pre_scale || (pre_ld % 2 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 7) == 0),
+                 "winograd_input_bf3p: pre_ld / alignment of the fused-producer coefficients");
+    const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
+    const int nchunks = CinPad / KC, RG = (int)(Tp / 32);
+    const size_t plane = Tp * (size_t)CinPad * 6;                  // bytes of one transform point
+    const long long blocks = 8ll * ((RG + 7) / 8) * nchunks;
+    BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t st = (hipStream_t)stream;
+#define BBDM_WINO_INS(MO, PRE, UP)                                                                                          \
+    hipLaunchKernelGGL((winograd_input_split_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, (unsigned char*)Vp, pre_scale, pre_bias, \
+                       pre_ld, pre_silu, N, H, W, nchunks, (long long)T, RG, plane)
+#define BBDM_WINO_INS_M(MO)                                                                       \
+    do {                                                                                          \
+        if (pre_scale) { if (upsample) BBDM_WINO_INS(MO, true, true); else BBDM_WINO_INS(MO, true, false); }   \
+        else           { if (upsample) BBDM_WINO_INS(MO, false, true); else BBDM_WINO_INS(MO, false, false); } \
+    } while (0)
+    if (m == 2) BBDM_WINO_INS_M(2); else if (m == 4) BBDM_WINO_INS_M(4); else BBDM_WINO_INS_M(6);
+#undef BBDM_WINO_INS_M
+#undef BBDM_WINO_INS
+    BBDM_CHECK_LAUNCH("winograd_input_bf3p");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
+                                           int CinPad, int Cout, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(Vp && b_planes && M && N > 0, "winograd_gemm_bf3p: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    return bbdm_gemm_bf3p_f32(Vp, b_planes, nullptr, nullptr, 0, M, Cout, planes(m), (long long)tiles_padded(N, H, W, m), CinPad,
+                              Cout, stream);
 }
 
 // stats0 / stats1 (each may be NULL): fp64 [N][32][2] GroupNorm accumulators (sum, sum of squares per image and group) of up

@@ -383,7 +383,8 @@ class _PackedDgrad:
 class _PackedWinograd:
     """G g G^T of one 3x3 conv weight in the batched-GEMM layout (``dgrad``: of the data-gradient convolution).  With
     ``bf3`` the fp32 buffer is additionally split into the three bf16 planes csrc/gemm_bf3.hip takes; ``packed`` is then
-    that buffer (the op binds to bbdm_winograd_gemm_bf3_f32)."""
+    that buffer (the op binds to bbdm_winograd_gemm_bf3_f32).  ``bf3 == "p"``: the planes in the fragment-unit layout of
+    csrc/gemm_bf3p.hip, whose A operand the input transform writes pre-split (bbdm_winograd_input_bf3p_f32 / _gemm_bf3p_f32)."""
 
     def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], in_pad: int, m: int, dgrad: bool = False,
                  bf3: bool = False):
@@ -394,7 +395,10 @@ class _PackedWinograd:
         self.out_ch = self.cin if dgrad else self.cout
         n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
         self.packed_f32 = torch.empty(n, dtype=torch.float32, device=weight.device)
-        if bf3:
+        if bf3 == "p":
+            self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes((m + 2) ** 2, in_pad, self.out_ch), dtype=torch.uint8,
+                                      device=weight.device)
+        elif bf3:
             nh = lib.bbdm_gemm_bf3_packed_halfs((m + 2) ** 2, in_pad, self.out_ch)
             self.packed = torch.empty(nh, dtype=torch.int16, device=weight.device)
         else:
@@ -411,8 +415,8 @@ class _PackedWinograd:
             _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                       self.in_pad, 1 if self.dgrad else 0, stream)
             if self.bf3:
-                _lib.call("bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2,
-                          self.in_pad, self.out_ch, stream)
+                _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 == "p" else "bbdm_gemm_bf3_pack_f32",
+                          self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2, self.in_pad, self.out_ch, stream)
             self.key = key
 
 
@@ -583,6 +587,9 @@ class UNetModel(nn.Module):
         # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
         # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
         self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
+        # ... with the A operand split into its three bf16 planes by the Winograd input transform (csrc/gemm_bf3p.hip: the GEMM's main
+        # loop is LDS-DMA copies + MFMAs); layers whose fp32 V the training backward re-reads keep the kernel above.  0: never.
+        self.gemm_bf3p: bool = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
         self.bf3_min_tiles: int = 256       # 1x1 layers with fewer 256x128 output tiles keep the split-K f32 kernel (one wave of tiles)
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
@@ -638,7 +645,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles)
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1017,22 +1024,32 @@ class _Plan:
             return 0
         return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd)
 
-    def _use_bf3(self, wm, H, W, cin_pad, cout) -> bool:
-        """Tile GEMMs of this layer on the bf16x3 kernel (fp32-accurate, csrc/gemm_bf3.hip)?"""
+    def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
+        """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
+        split while staged), "p" = csrc/gemm_bf3p.hip (V written pre-split by the input transform; not when the training
+        backward re-reads the fp32 V: ``keeps_V``)."""
         if not self.m.gemm_bf3:
             return False
-        return bool(self.lib.bbdm_gemm_bf3_supported(self.lib.bbdm_winograd_tiles(wm, self.N, H, W), cin_pad, cout))
+        tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
+        if self.m.gemm_bf3p and not keeps_V and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout):
+            return "p"
+        return bool(self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout))
+
+    def _keeps_V(self, wm, H, W, cin_pad, cin, cout, upsample, bwd) -> bool:
+        """Training forward: does this Winograd layer keep its fp32 V for the Winograd-domain weight gradient?"""
+        return bool(self.training and not bwd and not upsample and cin_pad == cin and self.m.winograd_wgrad
+                    and winograd_wgrad_tile(self.N, H, W, cin_pad, cout, self.m.winograd_wgrad) == wm)
 
     def _emit_winograd(self, x, cin_pad, pw, pre, upsample, H, W, residual, res_ld, dest, flags, bwd=False):
         """input transform -> 16 batched GEMMs -> output transform (csrc/winograd.hip)."""
         emit = self._bop if bwd else self._op
         N, cout, wm = self.N, dest.C, pw.m
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
-        self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad)
+        split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
+        self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
         self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
         vbuf = self._wino_v
-        if (self.training and not bwd and not upsample and cin_pad == pw.cin
-                and self.m.winograd_wgrad and winograd_wgrad_tile(N, H, W, cin_pad, cout, self.m.winograd_wgrad) == wm):
+        if (not split and self._keeps_V(wm, H, W, cin_pad, pw.cin, cout, upsample, bwd)):
             # training: this layer's weight gradient contracts the SAME transformed input (csrc/winograd_wgrad.hip) -- keep V
             # in a buffer of its own instead of re-running the input transform in the backward pass (memory: (m+2)^2/m^2 x
             # the activation, ~8 GB over the LBBDM-f4 UNet at batch 32, of the 288 GB)
@@ -1040,8 +1057,10 @@ class _Plan:
             self.bufs.append(b)
             vbuf = _View(b, 0, cin_pad, 1, 1, 1, cin_pad)
             self._saved_V[id(pw.weight)] = (vbuf, wm)
-        emit("bbdm_winograd_input_f32", wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
-        gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
+        emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
+             wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
+        gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
+                       "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
         emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
         if bwd:
             emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout)
@@ -1063,7 +1082,8 @@ class _Plan:
         H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
         wm = self._winograd_ok(mod, H, W, x.C, flags)
         if wm:
-            pw = _PackedWinograd(mod.weight, mod.bias, x.C, wm, bf3=self._use_bf3(wm, H, W, x.C, cout))
+            pw = _PackedWinograd(mod.weight, mod.bias, x.C, wm, bf3=self._use_bf3(
+                wm, H, W, x.C, cout, keeps_V=self._keeps_V(wm, H, W, x.C, mod.weight.shape[1], cout, upsample, False)))
             self.convs.append(pw)
             self._emit_winograd(x, x.C, pw, pre, upsample, H, W, residual, res_ld, dest, flags)
             return

@@ -336,6 +336,32 @@ int bbdm_conv1x1_bf3_f32(const float* x, int ldx, const void* packed_bf3, const 
 int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* packed_bf3, float* M, int N, int H, int W, int CinPad,
                                int Cout, void* stream);
 
+/* ---- the same fp32-accurate GEMM with BOTH operands pre-split by their producers (csrc/gemm_bf3p.hip) ----------- */
+/* Replaces the contraction of nn.Conv2d 3x3 on the wide layers (openaimodel.py:207,233,524) like bbdm_gemm_bf3_f32, arithmetic
+ * identical to it bit for bit; the difference is WHERE the exact three-way bf16 split happens: the producer of the A operand
+ * (the Winograd input transform, or bbdm_gemm_bf3p_split_rows_f32 for an ordinary fp32 matrix) writes the three planes, in the
+ * order the matrix core consumes them, so the GEMM's main loop is LDS-DMA copies + MFMAs with no VALU arithmetic.
+ * Plane layout: 1 KB "fragment units" of 32 rows x 16 k of one plane, element (r, k) at byte (k>>3)*512 + r*16 + (k&7)*2;
+ *   A planes: [batch][T/32][CinPad/16][3][1 KB],  B planes: [batch][CoutPad128/32][CinPad/16][3][1 KB]  (6 B per element).
+ *   bbdm_gemm_bf3p_a_bytes / _b_bytes : buffer sizes (T rounded up to 256 rows, Cout to 128 columns)
+ *   bbdm_gemm_bf3p_supported          : shape gate (T % 256 == 0, CinPad % 16 == 0, Cout % 4 == 0)
+ *   bbdm_gemm_bf3p_pack_b_f32         : fp32 packed [batch][CinPad/16][CoutPad128][16] -> B planes
+ *   bbdm_gemm_bf3p_split_rows_f32     : fp32 rows [batch][T][ldx] -> A planes (rows up to the next multiple of 256 zeroed)
+ *   bbdm_gemm_bf3p_f32                : M[b][T][ldo] = A_b . B_b (+ bias) (+ residual; may alias M)   for b < batch
+ *   bbdm_winograd_input_bf3p_f32      : stage (1) of the Winograd path writing A planes (arguments of bbdm_winograd_input_f32)
+ *   bbdm_winograd_gemm_bf3p_f32       : stage (2) on them (arguments of bbdm_winograd_gemm_f32) */
+size_t bbdm_gemm_bf3p_a_bytes(int batch, long long T, int CinPad);
+size_t bbdm_gemm_bf3p_b_bytes(int batch, int CinPad, int Cout);
+int bbdm_gemm_bf3p_supported(long long T, int CinPad, int Cout);
+int bbdm_gemm_bf3p_pack_b_f32(const float* packed_f32, void* b_planes, int batch, int CinPad, int Cout, void* stream);
+int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_planes, int batch, long long T, int CinPad, void* stream);
+int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr, float* M,
+                       int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
+int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
+                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
+int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
+                                int Cout, void* stream);
+
 /* ---- optimizer + EMA in one pass (training) ------------------------------------------------ */
 /* Replaces torch.optim.Adam.step() (runners/utils.py:48-51; called at runners/BaseRunner.py:413-415) and
  * EMA.update() (runners/base/EMA.py:21-29; called at BaseRunner.py:173-178,422-423) for all parameters with ONE launch.

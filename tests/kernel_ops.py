@@ -357,6 +357,27 @@ def gemm_bf3(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: i
     return M
 
 
+def gemm_bf3p(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: int, cout: int,
+              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The GEMM of :func:`gemm_bf3` on the pre-split kernel (csrc/gemm_bf3p.hip): V [batch, T, cin_pad] fp32 is split into
+    its three bf16 planes by bbdm_gemm_bf3p_split_rows_f32, the weights by bbdm_gemm_bf3p_pack_b_f32.  T need not be a
+    multiple of 256 (the planes are zero-padded; the result is cut back)."""
+    _chk(V, w_packed_f32, bias, residual)
+    T = V.shape[1]
+    Tp = (T + 255) // 256 * 256
+    lib = _lib.load()
+    ap = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(batch, T, cin_pad), dtype=torch.uint8, device=V.device)
+    bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(batch, cin_pad, cout), dtype=torch.uint8, device=V.device)
+    _lib.call("bbdm_gemm_bf3p_split_rows_f32", V.data_ptr(), V.shape[2], ap.data_ptr(), batch, T, cin_pad, _st(V))
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", w_packed_f32.data_ptr(), bp.data_ptr(), batch, cin_pad, cout, _st(V))
+    M = torch.empty(batch, Tp, cout, dtype=torch.float32, device=V.device)
+    if residual is not None:
+        M[:, :T] = residual
+    _lib.call("bbdm_gemm_bf3p_f32", ap.data_ptr(), bp.data_ptr(), None if bias is None else bias.data_ptr(),
+              None if residual is None else M.data_ptr(), cout, M.data_ptr(), cout, batch, Tp, cin_pad, cout, _st(V))
+    return M[:, :T]
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """x: [rows, C] -> nn.LayerNorm(C) per row."""
     _chk(x, gamma, beta)

@@ -53,6 +53,17 @@ def test_gemm_bf3_accuracy(batch, T, Cin, Cout):
     K.test_gemm_bf3_accuracy(CPU, batch, T, Cin, Cout)
 
 
+@pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(2, 256, 48, 72, 0), (1, 300, 32, 132, 2), (8, 256, 32, 40, 1)])
+def test_gemm_bf3p_matches_bf3_bitwise(batch, T, Cin, Cout, extra):
+    K.test_gemm_bf3p_matches_bf3_bitwise(CPU, batch, T, Cin, Cout, extra)
+
+
+@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 1, 1, 2, 12, 12, 32, 40), (4, 0, 1, 1, 8, 8, 16, 8),
+                                                      (2, 1, 0, 1, 8, 8, 16, 24)])
+def test_winograd_bf3p_stages(m, up, silu, N, H, W, Cin, Cout):
+    K.test_winograd_bf3p_stages(CPU, m, up, silu, N, H, W, Cin, Cout)
+
+
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True)])
 def test_conv1x1_bf3(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3(CPU, pixels, Cin, Cout, res)

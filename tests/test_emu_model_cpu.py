@@ -97,6 +97,39 @@ def test_groupnorm_statistics_fused_into_the_producers():
     assert rel_err(outs[True], ref) < M.STEP_TOL
 
 
+def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
+    """Inference plan with the Winograd layers on csrc/gemm_bf3p.hip (input transform writes the three bf16 planes, LDS-DMA GEMM):
+    bit-equal to the same plan on csrc/gemm_bf3.hip (fp32 V split while staged), and within the step tolerance of the oracle."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
+                        lambda N, H, W, cin, cout, max_m=6: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+    up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 43)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(16, 4, 16, 16, generator=g)
+    t = torch.arange(16) * 7 + 1
+    outs = {}
+    for p in (True, False):
+        m.gemm_bf3p = p
+        with torch.no_grad():
+            outs[p] = m(x, timesteps=t, context=None).clone()
+        plan = m._plan_for(x, False)
+        entries = [getattr(n, "entry", str(n)) for n, _ in plan.ops]
+        assert ("bbdm_winograd_gemm_bf3p_f32" in entries) == p and ("bbdm_winograd_input_bf3p_f32" in entries) == p
+        assert ("bbdm_winograd_gemm_bf3_f32" in entries) == (not p)
+    assert torch.equal(outs[True], outs[False])
+    ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
+    assert rel_err(outs[True], ref) < M.STEP_TOL
+
+
 def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     """Training plan of a UNet with enough tiles (16 images of 16x16 = 256 4x4 tiles, 64 channels) for the 3x3 layers' weight
     gradients to take the Winograd-domain path (csrc/winograd_wgrad.hip), with the 1x1 skip convolutions (forward and data

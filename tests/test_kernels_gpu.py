@@ -239,6 +239,93 @@ def test_gemm_bf3_accuracy(dev, batch, T, Cin, Cout):
     assert e_bf3 < 3e-6 and e_bf3 < 8 * e_f32 + 1e-7
 
 
+@pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(2, 256, 48, 72, 0), (1, 512, 256, 128, 1), (3, 256, 1024, 260, 2),
+                                                    (8, 300, 64, 132, 0), (16, 768, 32, 256, 0)])
+def test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, extra):
+    """csrc/gemm_bf3p.hip (operands pre-split by their producers, LDS-DMA staging) must reproduce csrc/gemm_bf3.hip BIT FOR BIT --
+    same exact split, same six terms in the same order -- and hence its fp32-class accuracy against an fp64 GEMM.  extra: 1 = bias,
+    2 = bias + residual (in place).  batch 8 / 16 take the each-XCD-owns-whole-entries launch; T = 300 the zero-padded rows."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(Cin + Cout + T)
+    V = torch.randn(batch, T, Cin, generator=g) * torch.logspace(-3, 3, Cin)
+    Wt = torch.randn(batch, Cout, Cin, generator=g) * 0.1 / torch.logspace(-3, 3, Cin)
+    cout_pad = (Cout + 127) // 128 * 128
+    pk = torch.zeros(batch, Cin // 16, cout_pad, 16)
+    for c in range(Cin // 16):
+        pk[:, c, :Cout, :] = Wt[:, :, c * 16:(c + 1) * 16]
+    pk = pk.contiguous().to(dev)
+    bias = torch.randn(Cout, generator=g) if extra else None
+    res = torch.randn(batch, T, Cout, generator=g) if extra == 2 else None
+    M = ops.gemm_bf3p(V.to(dev), pk, batch, Cin, Cout, None if bias is None else bias.to(dev),
+                      None if res is None else res.to(dev)).cpu()
+    torch.cuda.synchronize()
+    ref = torch.einsum("btk,bok->bto", V.double(), Wt.double())
+    if bias is not None:
+        ref = ref + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    e = rel_err(M, ref)
+    print(f"gemm_bf3p [{batch} x {T} x {Cin} x {Cout}]: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6
+    if T % 256 == 0 and not extra:
+        M0 = ops.gemm_bf3(V.to(dev), pk, batch, Cin, Cout).cpu()
+        torch.cuda.synchronize()
+        assert torch.equal(M, M0), (M - M0).abs().max()
+
+
+@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 3, 16, 24, 64, 96), (6, 1, 1, 2, 20, 12, 32, 136),
+                                                      (4, 0, 1, 3, 16, 24, 64, 96), (4, 1, 0, 1, 8, 8, 16, 8),
+                                                      (2, 1, 1, 3, 16, 24, 64, 96), (6, 0, 0, 5, 7, 9, 48, 260)])
+def test_winograd_bf3p_stages(dev, m, up, silu, N, H, W, Cin, Cout):
+    """The Winograd path with the input transform writing the three bf16 planes (bbdm_winograd_input_bf3p_f32) and the tile GEMMs
+    on the pre-split kernel: against the fp64 convolution, and BIT-EQUAL to the bbdm_winograd_input_f32 + bbdm_winograd_gemm_bf3_f32
+    pipeline (the split commutes with where it is done)."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(31 + 2 * up + silu + m)
+    hs, ws_ = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(N, Cin, hs, ws_, generator=g)
+    sc = torch.randn(N, Cin, generator=g)
+    bi = torch.randn(N, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    a = x.double() * sc.double()[:, :, None, None] + bi.double()[:, :, None, None]
+    if silu:
+        a = F.silu(a)
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    ref = F.conv2d(a, w.double(), b.double(), padding=1).float()
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    xg, scg, big, bg = _nhwc(x).to(dev), sc.to(dev), bi.to(dev), b.to(dev)
+    pw = ops.pack_winograd_weight(w.to(dev), m=m)
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    P = (m + 2) ** 2
+    Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
+    Bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(P, Cin, Cout), dtype=torch.uint8, device=dev)
+    M = torch.empty(P * tiles * Cout, device=dev)
+    out = torch.empty(N, H, W, Cout, device=dev)
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", pw.data_ptr(), Bp.data_ptr(), P, Cin, Cout, st)
+    _lib.call("bbdm_winograd_input_bf3p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), scg.data_ptr(), big.data_ptr(), Cin, silu, up,
+              N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, st)
+    _lib.call("bbdm_winograd_output_f32", m, M.data_ptr(), bg.data_ptr(), None, 0, out.data_ptr(), Cout, 0, N, H, W, Cout, st)
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out.cpu()), ref) < WINO_TOL[m]
+    # the fp32-V pipeline on gemm_bf3.hip
+    V = torch.empty(P * tiles * Cin, device=dev)
+    M0 = torch.empty(P * tiles * Cout, device=dev)
+    pk = torch.empty(lib.bbdm_gemm_bf3_packed_halfs(P, Cin, Cout), dtype=torch.int16, device=dev)
+    _lib.call("bbdm_gemm_bf3_pack_f32", pw.data_ptr(), pk.data_ptr(), P, Cin, Cout, st)
+    _lib.call("bbdm_winograd_input_f32", m, xg.data_ptr(), Cin, V.data_ptr(), scg.data_ptr(), big.data_ptr(), Cin, silu, up,
+              N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_bf3_f32", m, V.data_ptr(), pk.data_ptr(), M0.data_ptr(), N, H, W, Cin, Cout, st)
+    torch.cuda.synchronize()
+    T_raw = N * -(-H // m) * -(-W // m)
+    a_, b_ = M.view(P, tiles, Cout)[:, :T_raw].cpu(), M0.view(P, tiles, Cout)[:, :T_raw].cpu()
+    assert torch.equal(a_, b_), (a_ - b_).abs().max()
+
+
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (1024, 1536, 512, True)])
 def test_conv1x1_bf3(dev, pixels, Cin, Cout, res):
     """1x1 convolution / Linear on the bf16x3 kernel: bias, in-place residual, input taken from a channel slice of a wider

@@ -97,7 +97,15 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         P = (wm + 2) ** 2
         assert tiles % 256 == 0 and tiles >= N * -(-H // wm) * -(-W // wm)
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
-        if getattr(ops[k + 1][0], "entry", "").endswith("bf3_f32"):
+        entry = getattr(ops[k + 1][0], "entry", "")
+        if entry.endswith("bf3p_f32"):          # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
+            assert getattr(ops[k][0], "entry", "") == "bbdm_winograd_input_bf3p_f32"
+            assert 4 * plan._wino_v.t.numel() >= lib.bbdm_gemm_bf3p_a_bytes(P, tiles, cin) and cin % 16 == 0
+            assert g[2].t.dtype == torch.uint8 and g[2].t.numel() == lib.bbdm_gemm_bf3p_b_bytes(P, cin, cout)
+            assert lib.bbdm_gemm_bf3p_supported(tiles, cin, cout)
+            assert not (training and id(plan) and any(v is i[3] for v, _ in plan._saved_V.values()))   # never a kept V
+        elif entry.endswith("bf3_f32"):
+            assert getattr(ops[k][0], "entry", "bbdm_winograd_input_f32") == "bbdm_winograd_input_f32"
             assert g[2].t.dtype == torch.int16 and g[2].t.numel() == lib.bbdm_gemm_bf3_packed_halfs((wm + 2) ** 2, cin, cout)
             assert lib.bbdm_gemm_bf3_supported(tiles, cin, cout)
         else:

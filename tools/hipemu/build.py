@@ -24,6 +24,9 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 def rewrite(src: str) -> str:
     src = _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_smem());", src)
     src = re.sub(r'asm volatile\("s_barrier"[^;]*;', "__syncthreads();", src)
+    # counted waits for LDS-DMA copies: template form `"s_waitcnt vmcnt(%0)" ::"n"(N)` and literal form `"s_waitcnt vmcnt(3)"`
+    src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\((\w+)\)[^;]*;', r"hipemu::dma_wait(\1);", src)
+    src = re.sub(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)"[^;]*;', r"hipemu::dma_wait(\1);", src)
     src = re.sub(r'asm volatile\("s_waitcnt[^;]*;', ";", src)
     return src
 

@@ -62,6 +62,8 @@ void* dyn_smem();                     // base of the dynamic LDS allocation of t
 void block_sync();                    // __syncthreads
 const void* const* wave_publish(const void* mine);   // publish a pointer, wave-sync, return the 64 published pointers
 void wave_release();                  // second wave-sync: everybody has read, the published objects may die
+void dma_issue(const char* gsrc_lane, char* lds_wave_base, int size);   // LDS-DMA, deferred (see the bottom of this header)
+void dma_wait(int keep_in_flight);
 typedef void (*body_fn)(void*);
 void launch(dim3 grid, dim3 block, size_t shmem, body_fn fn, void* ctx);
 template <class F>
@@ -237,5 +239,11 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipem
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0
-#define __builtin_amdgcn_global_load_lds(...) (fprintf(stderr, "hipemu: LDS-DMA is not emulated\n"), abort())
+// LDS-DMA (global_load_lds_dwordx4 & co): every lane fetches `size` bytes at its own global address; the wave's 64 pieces land
+// at wave-uniform LDS base + lane * size.  Emulated as a DEFERRED copy: the destination is poisoned at issue and the bytes only
+// arrive when the issuing thread executes a counted wait (s_waitcnt vmcnt(N) -> hipemu::dma_wait(N): all but the newest N of its
+// copies complete) -- a fragment read that is not covered by a wait (+ barrier) sees NaNs, a copy issued over data another wave
+// still reads destroys it, and a thread that ends with copies outstanding aborts.
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+    hipemu::dma_issue((const char*)(g) + (off), (char*)(l) + (off), (size))
 #define __builtin_amdgcn_s_barrier() hipemu::block_sync()

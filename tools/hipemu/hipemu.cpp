@@ -59,8 +59,15 @@ void yield_to_scheduler(int state) {
     hipemu_switch(&f.sp, g_sched_sp);
 }
 
+struct PendingCopy { const char* src; char* dst; int size; };
+std::vector<std::vector<PendingCopy>> g_pending;       // LDS-DMA copies in flight, per thread of the block
+bool dma_outstanding(int t) { return t < (int)g_pending.size() && !g_pending[t].empty(); }
 void fiber_main() {
     g_fn(g_ctx);
+    if (dma_outstanding(g_cur)) {
+        fprintf(stderr, "hipemu: a thread finished with LDS-DMA copies it never waited for\n");
+        abort();
+    }
     g_wave_slots[g_cur >> 6][g_cur & 63] = nullptr;
     yield_to_scheduler(DONE);
     fprintf(stderr, "hipemu: resumed a finished fiber\n");
@@ -141,6 +148,7 @@ void run_block(int nthr) {
 void fiber_main_export() { fiber_main(); }
 
 void* dyn_smem() { return g_smem.data(); }
+
 void block_sync() { yield_to_scheduler(AT_BLOCK); }
 const void* const* wave_publish(const void* mine) {
     g_wave_slots[g_cur >> 6][g_cur & 63] = mine;
@@ -148,6 +156,33 @@ const void* const* wave_publish(const void* mine) {
     return g_wave_slots[g_cur >> 6];
 }
 void wave_release() { yield_to_scheduler(AT_WAVE); }
+
+// ---- LDS-DMA: deferred copies, per issuing thread (every lane of a wave issues the same sequence) -------------------------------
+void dma_issue(const char* gsrc_lane, char* lds_wave_base, int size) {
+    const void* const* all = wave_publish(lds_wave_base);
+    for (int i = 0; i < 64; ++i)
+        if (all[i] && all[i] != (const void*)lds_wave_base) {
+            fprintf(stderr, "hipemu: LDS-DMA destination base is not wave-uniform\n");
+            abort();
+        }
+    wave_release();
+    char* dst = lds_wave_base + (size_t)g_lane * size;
+    if (dst < g_smem.data() || dst + size > g_smem.data() + g_smem.size()) {
+        fprintf(stderr, "hipemu: LDS-DMA destination outside the dynamic LDS allocation\n");
+        abort();
+    }
+    memset(dst, 0xFF, size);                            // in flight: whoever reads it now gets NaNs
+    if ((int)g_pending.size() <= g_cur) g_pending.resize(g_cur + 1);
+    g_pending[g_cur].push_back(PendingCopy{gsrc_lane, dst, size});
+}
+void dma_wait(int keep) {
+    if ((int)g_pending.size() <= g_cur) return;
+    auto& q = g_pending[g_cur];
+    const int done = (int)q.size() - keep;
+    if (done <= 0) return;
+    for (int i = 0; i < done; ++i) memcpy(q[i].dst, q[i].src, q[i].size);
+    q.erase(q.begin(), q.begin() + done);
+}
 
 void launch(dim3 grid, dim3 block, size_t shmem, body_fn fn, void* ctx) {
     const int nthr = (int)(block.x * block.y * block.z);
