@@ -58,6 +58,12 @@ def test_gemm_bf3p_matches_bf3_bitwise(batch, T, Cin, Cout, extra):
     K.test_gemm_bf3p_matches_bf3_bitwise(CPU, batch, T, Cin, Cout, extra)
 
 
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("batch,T,Cin,Cout", [(1, 256, 16, 256), (1, 256, 32, 256), (8, 256, 80, 260), (2, 512, 64, 256)])
+def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):
+    K.test_gemm_bf3p_kernel_variants(CPU, kernel, batch, T, Cin, Cout)
+
+
 @pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 1, 1, 2, 12, 12, 32, 40), (4, 0, 1, 1, 8, 8, 16, 8),
                                                       (2, 1, 0, 1, 8, 8, 16, 24)])
 def test_winograd_bf3p_stages(m, up, silu, N, H, W, Cin, Cout):

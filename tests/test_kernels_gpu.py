@@ -239,6 +239,22 @@ def test_gemm_bf3_accuracy(dev, batch, T, Cin, Cout):
     assert e_bf3 < 3e-6 and e_bf3 < 8 * e_f32 + 1e-7
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3])
+@pytest.mark.parametrize("batch,T,Cin,Cout", [(2, 512, 16, 256), (1, 256, 32, 512), (8, 256, 80, 260), (3, 768, 1024, 256)])
+def test_gemm_bf3p_kernel_variants(dev, kernel, batch, T, Cin, Cout):
+    """Every kernel of csrc/gemm_bf3p.hip (bbdm_debug_set_bf3p_kernel: 0 = two stages / two workgroups per CU, 1 = 256 x 256 tile
+    with a 3-stage ring and counted waits, 2 = 4-stage ring, 3 = 256 x 256 two stages) is bit-equal to csrc/gemm_bf3.hip; Cin = 16 /
+    32 are the one- and two-chunk edge cases of the ring prologue, Cout = 260 falls back from the 256-column tiles."""
+    from bbdm_amd import _lib
+    lib = _lib.load()
+    old = lib.bbdm_debug_set_bf3p_kernel(kernel)
+    try:
+        test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, 0)
+        test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, 2)
+    finally:
+        lib.bbdm_debug_set_bf3p_kernel(old)
+
+
 @pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(2, 256, 48, 72, 0), (1, 512, 256, 128, 1), (3, 256, 1024, 260, 2),
                                                     (8, 300, 64, 132, 0), (16, 768, 32, 256, 0)])
 def test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, extra):

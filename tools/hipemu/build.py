@@ -24,6 +24,12 @@ _DYN = re.compile(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)
 def rewrite(src: str) -> str:
     src = _DYN.sub(lambda m: f"{m.group(1)}* {m.group(2)} = reinterpret_cast<{m.group(1)}*>(hipemu::dyn_smem());", src)
     src = re.sub(r'asm volatile\("s_barrier"[^;]*;', "__syncthreads();", src)
+    # hand-written fragment reads: `asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_address), "n"(offset));`
+    # with lds_address(p) = byte offset of p inside the emulated dynamic LDS allocation
+    src = re.sub(r'asm volatile\("ds_read_b128 %0, %1 offset:%2"\s*:\s*"=v"\((.+?)\)\s*:\s*"v"\((.+?)\),\s*"n"\((.+?)\)\);',
+                 r"\1 = *reinterpret_cast<const __typeof__(\1)*>((const char*)hipemu::dyn_smem() + (\2) + (\3));", src)
+    src = re.sub(r'return \(unsigned\)\(uintptr_t\)\(__attribute__\(\(address_space\(3\)\)\) void\*\)p;',
+                 "return (unsigned)((const char*)p - (const char*)hipemu::dyn_smem());", src)
     # counted waits for LDS-DMA copies: template form `"s_waitcnt vmcnt(%0)" ::"n"(N)` and literal form `"s_waitcnt vmcnt(3)"`
     src = re.sub(r'asm volatile\("s_waitcnt vmcnt\(%0\)"\s*::\s*"n"\((\w+)\)[^;]*;', r"hipemu::dma_wait(\1);", src)
     src = re.sub(r'asm volatile\("s_waitcnt vmcnt\((\d+)\)"[^;]*;', r"hipemu::dma_wait(\1);", src)
