@@ -58,9 +58,15 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// one LDS-DMA: every lane fetches 16 B at gsrc (per-lane address), the wave's 1 KB lands at lds_wave_base + lane * 16
-__device__ __forceinline__ void glds16(const unsigned char* gsrc, unsigned char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+// one LDS-DMA: every lane fetches 16 B at unit + lane16 (unit: wave-uniform, pinned to SGPRs so that the instruction takes its
+// scalar-base + 32-bit-lane-offset form instead of a 64-bit address VGPR pair per copy), the wave's 1 KB lands at
+// lds_wave_base + lane * 16
+__device__ __forceinline__ void glds16(const unsigned char* unit, unsigned lane16, unsigned char* lds_wave_base) {
+    const unsigned long long u = (unsigned long long)(uintptr_t)unit;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    const unsigned char* base = (const unsigned char*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane16),
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
@@ -75,6 +81,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_kernel(const Bf3pAr
     constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
     constexpr int KMAX = (NU + NW - 1) / NW;                                  // copies per wave and chunk (the last may be partial)
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lane16 = lane * 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int bid, bz;
@@ -103,13 +110,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_kernel(const Bf3pAr
         const int u = wave + k * NW;
         const int ub = u - NA;
         src[k] = (u < NA ? A + (size_t)(u / 3) * gstride + (u % 3) * UNIT
-                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT) + lane * 16;
+                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
     }
     auto issue = [&](int chunk, unsigned char* st) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int u = wave + k * NW;
-            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), st + u * UNIT);
+            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + u * UNIT);
         }
     };
 
@@ -212,6 +219,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_ring_kernel(const B
     constexpr int KMAX = (NU + NW - 1) / NW, KFULL = NU / NW;                 // copies per wave and chunk: KMAX for the first NU % NW waves
     static_assert(NS >= 3, "the ring needs a stage in flight besides the one being read and the one landing");
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lane16 = lane * 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     int bid, bz;
@@ -239,13 +247,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_ring_kernel(const B
         const int u = wave + k * NW;
         const int ub = u - NA;
         src[k] = (u < NA ? A + (size_t)(u / 3) * gstride + (u % 3) * UNIT
-                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT) + lane * 16;
+                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
     }
     const bool extra = KMAX != KFULL && wave < NU - KFULL * NW;               // this wave issues KMAX copies per chunk (wave-uniform)
     auto issue = [&](int chunk, unsigned char* st) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-            if (k < KFULL || extra) glds16(src[k] + (size_t)chunk * (3 * UNIT), st + (wave + k * NW) * UNIT);
+            if (k < KFULL || extra) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + (wave + k * NW) * UNIT);
     };
     // leave the copies of `chunks_in_flight` (0 .. NS - 2) chunks outstanding
     auto wait_keep = [&](int chunks_in_flight) {
@@ -272,7 +280,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_ring_kernel(const B
         const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
         bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the bias has arrived: from here on only copies count
+    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));     // a USE of the bias: hipcc waits for its load here, where it can see the wait (it does
+                                                    // not see the counted waits below and would re-wait vmcnt(0) before every store)
     const int n = a.nchunks;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -336,6 +345,179 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_ring_kernel(const B
                     float v = acc[i][j][r] + bv[j];
                     if (RES) v += rv[rr][j];
                     if (co < a.Cout) dst[co] = v;
+                }
+            }
+        }
+}
+
+// ---- software-pipelined variant: the fragments of chunk c + 1 are read WHILE the MFMAs of chunk c run ------------------------------
+// In the two kernels above every wave does its front-end work (fragment reads, copy issue) right after the barrier -- all waves at
+// once, the matrix pipe idle meanwhile (measured: ~12 % of the kernel with one 16-wave workgroup per CU).  Here a wave enters an
+// iteration with the fragments of its chunk already in registers and issues, between the six term groups of its 24 MFMAs, the
+// copies of chunk c + 2 and the reads of chunk c + 1 -- each fragment register is re-loaded right after the last term that uses
+// it (term order BF3_TA / BF3_TB = (1,1) (0,2) (2,0) (0,1) (1,0) (0,0): plane 2 of B dies first, then plane 2 of A, plane 1 of B,
+// ... -- bit-equal results), so no second register set is needed.  Two LDS stages: chunk c + 2 goes to
+// the stage chunk c was read from (one iteration ago).  One wait (copies landed, reads returned) + barrier per chunk, and after
+// it every wave continues with MFMAs at once.
+template <int WM, int WN, bool RES>
+__global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const Bf3pArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
+    constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
+    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
+    constexpr int KMAX = (NU + NW - 1) / NW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lane16 = lane * 16;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int bid, bz;
+    if (a.by_batch) {
+        const int L = (int)blockIdx.x, j = L >> 3;
+        bz = (L & 7) + 8 * (j / a.tiles);
+        if (bz >= a.batch) return;
+        bid = j % a.tiles;
+    } else {
+        bz = (int)blockIdx.z;
+        bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
+    }
+    const int tilesN = a.tilesN * 2 / WN;
+    const int n_tile = bid % tilesN, m_tile = bid / tilesN;
+    const int row0 = m_tile * BM, cout0 = n_tile * BN;
+    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
+    const int rg_last = a.T / 32 - 1;                                          // a ragged last row tile (T % BM != 0) re-reads the last
+    const unsigned char* A = a.A + (size_t)bz * a.az;                          // row group instead of running past the buffer; its
+    const unsigned char* B = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride;     // rows are not stored
+    float* M = a.M + (size_t)bz * a.mz;
+    const float* res = a.res + (size_t)bz * a.rz;
+
+    const unsigned char* src[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int u = wave + k * NW;
+        const int ub = u - NA;
+        src[k] = (u < NA ? A + (size_t)min(m_tile * (WM * 2) + u / 3, rg_last) * gstride + (u % 3) * UNIT
+                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
+    }
+    auto issue = [&](int chunk, unsigned char* st) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int u = wave + k * NW;
+            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + u * UNIT);
+        }
+    };
+    const unsigned lds0 = lds_address(smem);
+    const unsigned aoff = (wm * 2) * 3 * UNIT + lane * 16;
+    const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));     // a USE of the bias: hipcc waits for its load here (see gemm_bf3p_ring_kernel)
+    bf16x8 fa[3][2], fb[3][2];                                                 // [plane][tile]
+#define BF3P_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
+#define BF3P_READ_A(p, base) do { BF3P_READ(fa[p][0], base, p, 0); BF3P_READ(fa[p][1], base, p, 1); } while (0)
+#define BF3P_READ_B(p, base) do { BF3P_READ(fb[p][0], base, p, 0); BF3P_READ(fb[p][1], base, p, 1); } while (0)
+#define BF3P_ALL_LANDED()                                                                                                      \
+    do {                                                                                                                        \
+        wait_vmcnt<0>();                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),          \
+                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1])           \
+                     :: "memory");                                                                                              \
+    } while (0)
+#define BF3P_TERM(pa, pb)                                                                                                       \
+    do {                                                                                                                        \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][0], acc[0][0], 0, 0, 0);                          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][1], acc[0][1], 0, 0, 0);                          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][0], acc[1][0], 0, 0, 0);                          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][1], acc[1][1], 0, 0, 0);                          \
+    } while (0)
+    const int n = a.nchunks;
+    issue(0, smem);
+    if (n > 1) issue(1, smem + STAGE);
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    {
+        const unsigned sa = lds0 + aoff, sb = lds0 + boff;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { BF3P_READ_A(p, sa); BF3P_READ_B(p, sb); }
+    }
+    BF3P_ALL_LANDED();
+    asm volatile("s_barrier" ::: "memory");                                    // everybody holds chunk 0: stage 0 may be overwritten
+    for (int chunk = 0; chunk < n; ++chunk) {
+        const bool has_next = chunk + 1 < n;
+        const unsigned nxt = lds0 + ((chunk + 1) & 1) * STAGE;
+        const unsigned sa = nxt + aoff, sb = nxt + boff;
+        __builtin_amdgcn_sched_barrier(0);
+        BF3P_TERM(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (chunk + 2 < n) issue(chunk + 2, smem + (chunk & 1) * STAGE);       // under the first MFMAs; stage free since the last barrier
+        __builtin_amdgcn_sched_barrier(0);
+        BF3P_TERM(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3P_READ_B(2, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3P_TERM(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3P_READ_A(2, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3P_TERM(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3P_READ_B(1, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3P_TERM(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3P_READ_A(1, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3P_TERM(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+        BF3P_ALL_LANDED();                                                     // my copies of chunk + 2 have landed, my reads of chunk + 1 returned
+        asm volatile("s_barrier" ::: "memory");                                // ... everybody's
+    }
+#undef BF3P_TERM
+#undef BF3P_ALL_LANDED
+#undef BF3P_READ_B
+#undef BF3P_READ_A
+#undef BF3P_READ
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float rv[8][2];
+            if (RES) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = r0 + rr;
+                    const int row = min(row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.T - 1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                        rv[rr][j] = co < a.Cout ? res[(size_t)row * a.ldr + co] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + rr;
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* dst = M + (size_t)row * a.ldo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                    float v = acc[i][j][r] + bv[j];
+                    if (RES) v += rv[rr][j];
+                    if (co < a.Cout && row < a.T) dst[co] = v;
                 }
             }
         }
@@ -426,15 +608,17 @@ extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_pl
     return BBDM_OK;
 }
 
-// KIND 0: gemm_bf3p_kernel (two stages, one wait + barrier per chunk); KIND = NS >= 3: gemm_bf3p_ring_kernel with NS stages
+// KIND 0: gemm_bf3p_kernel (two stages, one wait + barrier per chunk); KIND 1: gemm_bf3p_pipe_kernel (fragments one chunk ahead);
+// KIND = NS >= 3: gemm_bf3p_ring_kernel with NS stages
 template <int WM, int WN, int KIND, bool RES>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    constexpr int NS = KIND == 0 ? 2 : KIND;
+    constexpr int NS = KIND < 3 ? 2 : KIND;
     const size_t lds = NS * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
     const void* fn = KIND == 0 ? reinterpret_cast<const void*>(gemm_bf3p_kernel<WM, WN, RES>)
-                               : reinterpret_cast<const void*>(gemm_bf3p_ring_kernel<WM, WN, (KIND == 0 ? 3 : KIND), RES>);
+                   : KIND == 1 ? reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>)
+                               : reinterpret_cast<const void*>(gemm_bf3p_ring_kernel<WM, WN, (KIND < 3 ? 3 : KIND), RES>);
     if (!attr_set) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
@@ -442,20 +626,23 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
         }
         attr_set = true;
     }
-    const long long blocks = ((long long)a.T / (WM * 64)) * (a.tilesN * 2 / WN);
+    const long long blocks = (((long long)a.T + WM * 64 - 1) / (WM * 64)) * (a.tilesN * 2 / WN);     // (a ragged last row tile: KIND 1 only)
     BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3p: too many tiles");
     a.tiles = (int)blocks;
     const dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
     if (KIND == 0)
         hipLaunchKernelGGL((gemm_bf3p_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
+    else if (KIND == 1)
+        hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
     else
-        hipLaunchKernelGGL((gemm_bf3p_ring_kernel<WM, WN, (KIND == 0 ? 3 : KIND), RES>), grid, dim3(WM * WN * 64), lds, st, a);
+        hipLaunchKernelGGL((gemm_bf3p_ring_kernel<WM, WN, (KIND < 3 ? 3 : KIND), RES>), grid, dim3(WM * WN * 64), lds, st, a);
     return BBDM_OK;
 }
 
 // Kernel choice (A/B runs; exported, not part of the public header): 0 = 256 x 128 tile, two stages, two workgroups per CU;
 // 1 = 256 x 256 tile, 16 waves, 3-stage ring (where Cout fills 256-column tiles); 2 = 256 x 128 tile, 8 waves, 4-stage ring;
-// 3 = 256 x 256 tile, 16 waves, two stages.
+// 3 = 256 x 256 tile, 16 waves, two stages; 4 = the software-pipelined kernel, 256 x 256 tile where Cout fills it, else 512 x 128;
+// 5 = software-pipelined 256 x 128 (8 waves, two workgroups per CU).
 static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 0; }();
 extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_variant; g_bf3p_variant = v; return old; }
 
@@ -485,6 +672,9 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
     if (g_bf3p_variant == 1 && wide) rc = BBDM_BF3P_GO(4, 4, 3);
     else if (g_bf3p_variant == 2) rc = BBDM_BF3P_GO(4, 2, 4);
     else if (g_bf3p_variant == 3 && wide) rc = BBDM_BF3P_GO(4, 4, 0);
+    else if (g_bf3p_variant == 4 && wide) rc = BBDM_BF3P_GO(4, 4, 1);
+    else if (g_bf3p_variant == 4) rc = BBDM_BF3P_GO(8, 2, 1);
+    else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2, 1);
     else rc = BBDM_BF3P_GO(4, 2, 0);
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;

@@ -1365,7 +1365,7 @@ class _Plan:
                 dw_dst = gref(w)
             else:                                   # padded stem input: gradient of the padding channels is dropped
                 t = torch.empty(cout, x_in.C, ks, ks, dtype=torch.float32, device=dev)
-                self._padded_wgrads.append((w, t))
+                self._padded_wgrads.append((w, t, len(self.bops)))     # (.., index of the op that fills t: its segment copies it out)
                 dw_dst = _TensorRef(t)
             wgm = (winograd_wgrad_tile(N, x_in.H, x_in.W, x_in.C, cout, m.winograd_wgrad)
                    if (m.winograd_wgrad and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
@@ -1656,27 +1656,32 @@ class _Plan:
                 start, cur = rec_ends[i], []
         self.bsegs = segs
 
+    @staticmethod
+    def _only_owner(t: torch.Tensor) -> bool:
+        """True when nothing but ``t`` itself references its storage: no ``param.grad`` adopted by autograd, no tensor returned by
+        ``torch.autograd.grad`` or kept by the caller across ``zero_grad(set_to_none=True)``, no DDP bucket view."""
+        use_count = getattr(torch._C, "_storage_Use_Count", None)
+        if use_count is None:
+            return False                                   # cannot tell: never recycle
+        return use_count(t.untyped_storage()._cdata) <= 2  # t + the temporary storage handle of this query
+
     def _pick_flat_grad(self):
-        """The flat gradient buffer of this backward pass.  Two persistent buffers instead of a fresh 0.95 GB allocation per
-        call: autograd may have adopted last pass's views as ``param.grad`` (first backward after ``zero_grad``), and
-        accumulating this pass's gradients into them must not alias, so the buffer no ``.grad`` points into is taken."""
+        """The flat gradient buffer of this backward pass.  Up to two persistent buffers instead of a fresh 0.95 GB allocation
+        per call -- but a buffer is recycled only when NOTHING else holds its storage: the gradients handed to autograd are views
+        of it (``param.grad`` after the first backward, the tensors ``torch.autograd.grad`` returns, anything the caller keeps for
+        logging or a gradient penalty), and zeroing it under them would silently rewrite those tensors."""
         if not hasattr(self, "_flat_bufs"):
             self._flat_bufs = []
-        busy = set()
-        for q in self.param_list:
-            gq = q.grad
-            if gq is not None:
-                ptr = gq.data_ptr()
-                for j, fb in enumerate(self._flat_bufs):
-                    if fb.data_ptr() <= ptr < fb.data_ptr() + 4 * fb.numel():
-                        busy.add(j)
-        for j, fb in enumerate(self._flat_bufs):
-            if j not in busy:
+        self._flat_grad = None                              # (drop this plan's own second handle before counting owners)
+        for fb in self._flat_bufs:
+            if self._only_owner(fb):
                 return fb.zero_()
+        fresh = torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)
         if len(self._flat_bufs) < 2:
-            self._flat_bufs.append(torch.zeros(self.grad_total, dtype=torch.float32, device=self.device))
-            return self._flat_bufs[-1]
-        return torch.zeros(self.grad_total, dtype=torch.float32, device=self.device)      # both adopted: rare
+            self._flat_bufs.append(fresh)
+        else:                                               # both still referenced: keep the newer pair candidate
+            self._flat_bufs[0], self._flat_bufs[1] = self._flat_bufs[1], fresh
+        return fresh
 
     def grad_view(self, q):
         off = self.grad_off[id(q)]
@@ -1716,6 +1721,12 @@ class _Plan:
                 prof.append((str(name) + ":bwd", e0, e1, self._algorithmic_flops(str(name), args)))
             if rc != 0:
                 check(rc, name)
+        # weight gradients computed against a channel-padded input (stem, cross-attention to_k / to_v on a 3-channel context) live
+        # in a padded scratch tensor: cut them into the flat gradient BEFORE this segment's views are handed to autograd (DDP's
+        # reducer hooks and gradient accumulation read them as soon as the segment's node returns)
+        for w, t, at in self._padded_wgrads:
+            if lo <= at < hi:
+                self.grad_view(w).copy_(t[:, : w.shape[1]].reshape(w.shape))      # (Linear weights are 2-D: ks = 1)
         if not last:
             return None
         return self._backward_embedding(stream, need_dx)
@@ -1742,8 +1753,6 @@ class _Plan:
         m, N = self.m, self.N
         flat = self._flat_grad
         gslice = self.grad_view
-        for w, t in self._padded_wgrads:
-            gslice(w).copy_(t[:, : w.shape[1]].reshape(w.shape))      # (Linear weights are 2-D: ks = 1)
         # ---- embedding path: film projections -> time_embed.2 -> time_embed.0 ------------------------------------
         mc, ted = m.model_channels, 4 * m.model_channels
         call = _lib.call

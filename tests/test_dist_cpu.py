@@ -68,7 +68,7 @@ def test_shard_range_properties():
 
 
 # ---- the real model under DDP, world size 2, on the CPU-emulated kernels ---------------------------------------------
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, case="tiny_nocond"):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
@@ -81,7 +81,7 @@ def _ddp_worker(rank, world, port, q):
     import test_training_gpu as T
     dist = du.init(backend="gloo")
     with emulated_backend():
-        rec = load_case("tiny_nocond")
+        rec = load_case(case)
         m = T.build(rec, torch.device("cpu")).train()
         m.denoise_fn.hip_graph = False
         assert len(next(iter([m.denoise_fn._plan_for(rec["x0"][:1], True)])).bsegs) > 1      # a chain, not one node
@@ -101,7 +101,8 @@ def _ddp_worker(rank, world, port, q):
         opt.step()
         q.put((rank, hooks, {k: v.tolist() for k, v in list(grads.items())[:3]},
                [float(p.detach().double().sum()) for p in m.get_parameters()],
-               {k: v.numpy().tolist() for k, v in grads.items() if k.endswith("out.2.bias") or k.endswith("time_embed.0.bias")}))
+               {k: v.numpy().tolist() for k, v in grads.items() if k.endswith("out.2.bias") or k.endswith("time_embed.0.bias")
+                or k.endswith("attn2.to_k.weight") or k.endswith("attn2.to_v.weight")}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -119,15 +120,16 @@ def _ddp_losses(ddp, x0, y, t, nz):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_ddp_training_step_on_the_emulated_kernels():
+@pytest.mark.parametrize("case,port", [("tiny_nocond", 29617), ("tiny_xattn", 29619)])
+def test_two_rank_ddp_training_step_on_the_emulated_kernels(case, port):
     """World size 2 over gloo: the chain-of-segments autograd graph drives DDP's reducer (buckets become ready segment by
     segment), accumulation_sync() skips the collective on the non-boundary micro-step, FusedAdam steps; both ranks end with
     identical parameters, and the reduced gradient equals autograd on the oracle over the COMBINED batch."""
     sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
-    world, port = 2, 29617
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, case)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=540) for _ in range(world)], key=lambda r: r[0])
@@ -140,7 +142,9 @@ def test_two_rank_ddp_training_step_on_the_emulated_kernels():
     # oracle: two accumulated micro-steps on the same data = 2 x the gradient of the mean loss over the combined batch
     from fixtures import load_case
     import test_training_gpu as T
-    rec = load_case("tiny_nocond")
+    rec = load_case(case)
+    if case == "tiny_xattn":            # the padded to_k / to_v weight gradients left their segment filled (not as zero views)
+        assert sum(k.endswith("attn2.to_k.weight") or k.endswith("attn2.to_v.weight") for k in g0) >= 2
     used = (rec["x0"].shape[0] // world) * world                   # each rank took x0.shape[0] // world samples
     for k in ("x0", "y", "t", "noise"):
         rec[k] = rec[k][:used]

@@ -63,6 +63,15 @@ def test_context_gradient_through_cross_attention():
     T.test_context_gradient_through_cross_attention(CPU)
 
 
+@pytest.mark.parametrize("name", ["tiny_concat", "tiny_xattn"])
+def test_gradient_accumulation_and_input_grad(name):
+    T.test_gradient_accumulation_and_input_grad(CPU, name)
+
+
+def test_gradients_handed_out_are_never_overwritten():
+    T.test_gradients_handed_out_are_never_overwritten(CPU)
+
+
 def test_groupnorm_statistics_fused_into_the_producers():
     """A UNet wide enough (128 channels -> 4 per group) for the conv epilogues to accumulate the GroupNorm statistics of
     their outputs (block outputs feeding the next block AND, through the concat, an output block): same result as with the

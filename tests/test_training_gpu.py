@@ -70,10 +70,14 @@ def test_loss_and_all_parameter_gradients(dev, name):
     assert errs[0][0] < GRAD_TOL, errs[0]
 
 
-def test_gradient_accumulation_and_input_grad(dev):
+@pytest.mark.parametrize("name", ["tiny_concat", "tiny_xattn"])
+def test_gradient_accumulation_and_input_grad(dev, name):
     """Two backward passes accumulate into .grad (accumulate_grad_batches, BaseRunner.py:412-417); d loss / d context
-    reaches a conditioning input that requires grad (trainable SpatialRescaler case)."""
-    rec = load_case("tiny_concat")
+    reaches a conditioning input that requires grad (trainable SpatialRescaler case).  tiny_xattn: the to_k / to_v weights of
+    the cross-attention act on a 3-channel context padded to 4 -- their gradients are cut out of a padded scratch tensor by the
+    backward SEGMENT that owns them (a copy deferred to the last segment handed autograd a still-zero view: the second pass then
+    accumulated 1x instead of 2x, and DDP reduced zeros)."""
+    rec = load_case(name)
     m = build(rec, dev).train()
     x0, y, t, nz = (rec[k].to(dev) for k in ("x0", "y", "t", "noise"))
     ctx = y.clone().requires_grad_()
@@ -93,6 +97,33 @@ def test_gradient_accumulation_and_input_grad(dev):
     loss2.backward()
     for k, p in m.named_parameters():
         assert rel_err(p.grad, 2 * g1[k]) < 1e-5, k
+
+
+def test_gradients_handed_out_are_never_overwritten(dev):
+    """The parameter gradients are views of a recycled flat buffer: tensors returned by torch.autograd.grad, or a .grad the caller
+    keeps across zero_grad(set_to_none=True), must survive the next backward pass (gradient penalties, logging, manual
+    accumulation)."""
+    rec = load_case("tiny_nocond")
+    m = build(rec, dev).train()
+    x0, y, t, nz = (rec[k].to(dev) for k in ("x0", "y", "t", "noise"))
+    params = [p for p in m.parameters() if p.requires_grad]
+    loss, _ = m.p_losses(x0, y, None, t, nz)
+    ga = torch.autograd.grad(loss, params)
+    snap = [g.clone() for g in ga]
+    loss, _ = m.p_losses(x0 * 0.5, y, None, t, nz)          # different data: different gradients
+    gb = torch.autograd.grad(loss, params)
+    assert all(torch.equal(a, s) for a, s in zip(ga, snap))
+    assert any(not torch.equal(a, b) for a, b in zip(ga, gb))
+    loss, _ = m.p_losses(x0, y, None, t, nz)
+    loss.backward()
+    kept = [p.grad for p in params]
+    snap = [g.clone() for g in kept]
+    m.zero_grad(set_to_none=True)
+    for scale in (0.5, 0.25, 2.0):                            # more passes than there are persistent buffers
+        loss, _ = m.p_losses(x0 * scale, y, None, t, nz)
+        loss.backward()
+        m.zero_grad(set_to_none=True)
+    assert all(torch.equal(a, s) for a, s in zip(kept, snap))
 
 
 def test_context_gradient_through_cross_attention(dev):
