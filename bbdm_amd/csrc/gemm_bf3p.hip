@@ -642,8 +642,8 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
 // Kernel choice (A/B runs; exported, not part of the public header): 0 = 256 x 128 tile, two stages, two workgroups per CU;
 // 1 = 256 x 256 tile, 16 waves, 3-stage ring (where Cout fills 256-column tiles); 2 = 256 x 128 tile, 8 waves, 4-stage ring;
 // 3 = 256 x 256 tile, 16 waves, two stages; 4 = the software-pipelined kernel, 256 x 256 tile where Cout fills it, else 512 x 128;
-// 5 = software-pipelined 256 x 128 (8 waves, two workgroups per CU).
-static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 0; }();
+// 5 = software-pipelined 256 x 128 (8 waves, two workgroups per CU); 6 (default) = 4 where Cout fills 256-column tiles, else 5.
+static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 6; }();
 extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_variant; g_bf3p_variant = v; return old; }
 
 // M[b][T][ldo] = A_b . B_b (+ bias) (+ residual[b][T][ldr]): A, B in the plane layout of the header
@@ -675,6 +675,7 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
     else if (g_bf3p_variant == 4 && wide) rc = BBDM_BF3P_GO(4, 4, 1);
     else if (g_bf3p_variant == 4) rc = BBDM_BF3P_GO(8, 2, 1);
     else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2, 1);
+    else if (g_bf3p_variant == 6) rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(4, 2, 1);     // the default (measured best per shape)
     else rc = BBDM_BF3P_GO(4, 2, 0);
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;

@@ -19,6 +19,7 @@
 // than m = 4 per layer where the image is >= 64 pixels a side (little edge waste) and there are >= ~1000 tiles; slower
 // on 16x16 / 32x32 latents, where m = 4 stays (bbdm_amd/unet.py: winograd_tile).
 #include "winograd_math.h"
+#include <stdlib.h>
 #include "bf3_split.h"
 
 namespace {
@@ -291,6 +292,8 @@ __global__ void __launch_bounds__(256) winograd_input_split_kernel(const float* 
                                                                    int H, int W, int nchunks, long long T, int RG, size_t plane) {
     constexpr int AL = MO + 2;
     const int L = (int)blockIdx.x, j = L >> 3;
+    // (giving each XCD a CONTIGUOUS run of row groups, so that the window rows shared with the tiles below are found in its L2,
+    // measured no gain: 21.8 vs 21.1 ms per C2 step -- gpurun_out/r03c; the halo re-reads are Infinity-Cache hits already)
     const int chunk = j % nchunks, g = (j / nchunks) * 8 + (L & 7);
     if (g >= RG) return;
     const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
@@ -361,6 +364,98 @@ __global__ void __launch_bounds__(256) winograd_input_split_kernel(const float* 
             o += plane;
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- (1'') the same transform in two phases through LDS: (m+2) waves per workgroup, 8x the threads in flight -------------------------
+// The one-thread-per-(tile, channel pair) kernel above keeps the whole (m+2)^2 window of its pair in registers: 174 VGPRs at m = 6,
+// two waves per SIMD -- and its ablation (tools/wino_variants.py: loads alone 0.145 ms, stores alone 0.159 ms, together 0.258 ms at
+// 64x64 x 1024 channels) shows the two memory streams and the arithmetic overlapping poorly with so few waves.  Here a workgroup owns
+// 64 units (8 consecutive tiles x the 8 channel pairs of one 16-channel chunk), lane = unit, and its m + 2 waves split the window:
+//   phase A: wave j loads column j of the window (m + 2 loads per lane, issued together), applies the fused GroupNorm -> FiLM ->
+//            SiLU, transforms it down the rows (B^T d) and leaves the m + 2 results in LDS [i][j][unit];
+//   phase B: wave i reads row i of the intermediate ([i][0..m+1][unit]: consecutive lanes, consecutive 8-byte words), transforms it
+//            (. B), splits each value into its three bf16 planes and stores them -- per plane and transform point the wave writes
+//            8 rows x 16 B of the fragment unit twice = two full 128-B lines, as above.
+// ~60 VGPRs and 32 KB of LDS per workgroup: 4 workgroups = 32 waves per CU.
+template <int MO, bool PRE, bool UP>
+__global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
+                                                                              unsigned char* __restrict__ Vp,
+                                                                              const float* __restrict__ sc, const float* __restrict__ bi,
+                                                                              int pre_ld, int pre_silu, int N, int H, int W, int nchunks,
+                                                                              long long T, int TG, size_t plane) {
+    constexpr int AL = MO + 2;
+    __shared__ float2 lds[AL * AL * 64];
+    const int L = (int)blockIdx.x, q = L >> 3;
+    // the chunks of one tile group run on ONE XCD (block id % 8): the two 64-B halves of an input line meet in that L2
+    const int chunk = q % nchunks, tg = (q / nchunks) * 8 + (L & 7);
+    if (tg >= TG) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const int tl = lane >> 3, cp = lane & 7;
+    const long long tile = (long long)tg * 8 + tl;
+    const int c = chunk * KC + cp * 2;
+    {   // ---- phase A: column `wave` of the window ------------------------------------------------------------------------------
+        const int jj = wave;
+        float2 d[AL], col[AL];
+        if (tile < T) {
+            const int tw = (int)(tile % TW);
+            const long long r = tile / TW;
+            const int th = (int)(r % TH), n = (int)(r / TH);
+            float2 s2 = make_float2(1.f, 1.f), b2 = make_float2(0.f, 0.f);
+            if (PRE) {
+                s2 = *reinterpret_cast<const float2*>(sc + (size_t)n * pre_ld + c);
+                b2 = *reinterpret_cast<const float2*>(bi + (size_t)n * pre_ld + c);
+            }
+            const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
+            const int w = MO * tw - 1 + jj;
+            const int wc = min(max(w, 0), W - 1);
+            const int wsrc = UP ? wc >> 1 : wc;
+            const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {            // clamped addresses, out-of-image taps zeroed afterwards: the loads issue together
+                const int hc = min(max(MO * th - 1 + i, 0), H - 1);
+                const int hs = UP ? hc >> 1 : hc;
+                d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+            }
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int h = MO * th - 1 + i;
+                const float mask = (h >= 0 && h < H) ? wmask : 0.f;
+                float2 v = d[i];
+                if (PRE) {
+                    v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
+                    if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
+                }
+                d[i] = make_float2(mask * v.x, mask * v.y);
+            }
+        } else {                                      // rows between the real and the padded tile count: zeros
+#pragma unroll
+            for (int i = 0; i < AL; ++i) d[i] = make_float2(0.f, 0.f);
+        }
+        bt_transform<MO>(d, col);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) lds[(i * AL + jj) * 64 + lane] = col[i];
+    }
+    __syncthreads();
+    {   // ---- phase B: row `wave` of the intermediate -> the 3 bf16 planes of transform points (wave, 0 .. m + 1) ------------------
+        const int i = wave;
+        float2 t[AL], row[AL];
+#pragma unroll
+        for (int jj = 0; jj < AL; ++jj) t[jj] = lds[(i * AL + jj) * 64 + lane];
+        bt_transform<MO>(t, row);
+        const int g = (int)(tile >> 5), rl = (int)(tile & 31);
+        // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
+        unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
+#pragma unroll
+        for (int jj = 0; jj < AL; ++jj) {
+            unsigned p1, p2, p3;
+            split2(row[jj].x, row[jj].y, p1, p2, p3);
+            *reinterpret_cast<unsigned*>(o) = p1;
+            *reinterpret_cast<unsigned*>(o + 1024) = p2;
+            *reinterpret_cast<unsigned*>(o + 2048) = p3;
+            o += plane;
+        }
     }
 }
 
@@ -612,12 +707,32 @@ extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void
     BBDM_REQUIRE(!pre_scale || (pre_ld % 2 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 7) == 0),
                  "winograd_input_bf3p: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
-    const int nchunks = CinPad / KC, RG = (int)(Tp / 32);
+    const int nchunks = CinPad / KC, RG = (int)(Tp / 32), TG = (int)(Tp / 8);
     const size_t plane = Tp * (size_t)CinPad * 6;                  // bytes of one transform point
+    hipStream_t st = (hipStream_t)stream;
+    // BBDM_WINO_INPUT_LDS=0: the one-thread-per-window kernel (A/B; see winograd_input_split2_kernel)
+    static const int two_phase = [] { const char* e = getenv("BBDM_WINO_INPUT_LDS"); return e ? atoi(e) : 1; }();
+    if (two_phase) {
+        const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
+        BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
+        const dim3 g((unsigned)blocks);
+#define BBDM_WINO_INS2(MO, PRE, UP)                                                                                          \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp,  \
+                       pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (long long)T, TG, plane)
+#define BBDM_WINO_INS2_M(MO)                                                                        \
+    do {                                                                                            \
+        if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true); else BBDM_WINO_INS2(MO, true, false); }   \
+        else           { if (upsample) BBDM_WINO_INS2(MO, false, true); else BBDM_WINO_INS2(MO, false, false); } \
+    } while (0)
+        if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else BBDM_WINO_INS2_M(6);
+#undef BBDM_WINO_INS2_M
+#undef BBDM_WINO_INS2
+        BBDM_CHECK_LAUNCH("winograd_input_bf3p");
+        return BBDM_OK;
+    }
     const long long blocks = 8ll * ((RG + 7) / 8) * nchunks;
     BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
     const dim3 g((unsigned)blocks), b(256);
-    hipStream_t st = (hipStream_t)stream;
 #define BBDM_WINO_INS(MO, PRE, UP)                                                                                          \
     hipLaunchKernelGGL((winograd_input_split_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, (unsigned char*)Vp, pre_scale, pre_bias, \
                        pre_ld, pre_silu, N, H, W, nchunks, (long long)T, RG, plane)

@@ -3,7 +3,7 @@
 
     python tools/rocprof_counters.py pass1_results.db [pass2_results.db ...] > profiles/rNN_pmc_<what>.md
 Prints one markdown table: kernel, launches, then the per-launch mean of every counter, plus derived columns when their inputs
-are present: MfmaUtil % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), the SQ wave-cycle split
+are present: MfmaUtil % = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs), the SQ wave-cycle split
 (WAIT_ANY / WAIT_INST_ANY / ACTIVE_INST_ANY over WAVE_CYCLES: parked at a waitcnt or barrier / issue-stalled / issuing), the LDS
 bank-conflict share of the LDS-array cycles, and the effective clock GRBM_GUI_ACTIVE / kernel time."""
 import re
@@ -14,7 +14,7 @@ import sys
 def main():
     data, order = {}, []
     dur = {}
-    for path in sys.argv[1:]:
+    for path in [a for a in sys.argv[1:] if not a.startswith('--')]:
         db = sqlite3.connect(path)
         for name, cname, value in db.execute("select kernel_name, counter_name, value from counters_collection"):
             short = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
@@ -25,6 +25,9 @@ def main():
             c[1] += float(value)
             if cname not in order:
                 order.append(cname)
+        if "--schema" in sys.argv:
+            for r in db.execute("select name from sqlite_master where type='table'"):
+                print("table", r[0], file=sys.stderr)
         try:
             tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")]
             syms = [r[0] for r in db.execute("select name from sqlite_master where type='table' and name like 'rocpd_info_kernel_symbol%'")]
@@ -47,11 +50,13 @@ def main():
         us = dur[k][1] / dur[k][0] / 1e3 if k in dur and dur[k][0] else float("nan")
         g = lambda c: d.get(c)
         row = [f"{d[c]:.4g}" if c in d else "" for c in order]
-        mf = 100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") * 1024) if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE") else None
+        # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs (32 cycles per
+        # v_mfma_f32_32x32x16_bf16: MI355X_MICROARCH.md)
+        mf = 100 * g("SQ_VALU_MFMA_BUSY_CYCLES") / 1024 / (g("GRBM_GUI_ACTIVE") / 8) if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("GRBM_GUI_ACTIVE") else None
         wc = g("SQ_WAVE_CYCLES")
         pct = lambda c: 100 * g(c) / wc if wc and g(c) is not None else None
         ldc = 100 * g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None else None
-        clk = g("GRBM_GUI_ACTIVE") / (us * 1e3) if g("GRBM_GUI_ACTIVE") and us == us and us > 0 else None
+        clk = g("GRBM_GUI_ACTIVE") / 8 / (us * 1e3) if g("GRBM_GUI_ACTIVE") and us == us and us > 0 else None
         dv = [mf, pct("SQ_WAIT_ANY"), pct("SQ_WAIT_INST_ANY"), pct("SQ_ACTIVE_INST_ANY"), ldc, clk]
         print(f"| {k} | {n} | {us:.1f} | " + " | ".join(row + [("" if v is None else f"{v:.3g}") for v in dv]) + " |")
 
