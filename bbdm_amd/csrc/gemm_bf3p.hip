@@ -17,10 +17,14 @@
 //   B (U planes): [batch][CoutPad / 32 col groups][nchunks][3 planes][1 KB]
 // The chunks of one row group are contiguous: a workgroup streams its 8 row groups as 8 sequential 3 KB-per-chunk streams.
 //
-// Kernel: workgroup = WM x WN waves of 64 x 64 outputs (2 x 2 MFMA tiles, 64 accumulator VGPRs); 256 x 128 with 8 waves, two
-// workgroups per CU (128 VGPRs, 72 KB LDS) is the default.  K is walked 16 at a time (one MFMA K-step): per chunk and wave 12
-// fragment reads, 24 MFMAs and its share of the next chunk's (24 + 12) unit copies into the other LDS stage, then ONE wait +
-// barrier.  The copies are issued after the fragment reads and land under the MFMAs.
+// Kernels: workgroup = WM x WN waves of 64 x 64 outputs (2 x 2 MFMA tiles, 64 accumulator VGPRs), K walked 16 at a time (one MFMA
+// K-step): per chunk and wave 12 fragment reads, 24 MFMAs and its share of the next chunks' unit copies into the other LDS stage.
+//   * gemm_bf3p_kernel: reads, copy issue, MFMAs, ONE wait + barrier per chunk -- the plain structure (kept as the A/B baseline);
+//   * gemm_bf3p_pipe_kernel (the default): the fragments of chunk c + 1 are read and the copies of chunk c + 2 issued BETWEEN the
+//     MFMAs of chunk c, so that after the barrier every wave continues with MFMAs at once; 256 x 256 tiles (16 waves, one
+//     workgroup per CU: a third less L2 -> LDS traffic per FLOP than 256 x 128) where Cout fills them.
+// Measured (MI355X, the 42 Winograd layers of the C2 step): 216 TFLOP/s fp32-equivalent = 1.30 PFLOP/s of bf16 MFMA = 0.52 of the
+// 416.7 (2500 / 6) peak, MfmaUtil 75 % at the 1.77 GHz the chip sustains under this load; gemm_bf3.hip: 181 = 0.43, MfmaUtil 54 %.
 #include "bf3_split.h"
 #include <stdlib.h>
 
@@ -202,154 +206,6 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_kernel(const Bf3pAr
         }
 }
 
-// ---- ring variant: NS-stage LDS ring, copies run NS - 1 chunks ahead and stay in flight across the barrier --------------------
-// Iteration c: issue the copies of chunk c + NS - 1 into the stage chunk c - 1 was read from (free since the last barrier), read
-// the fragments of chunk c, 24 MFMAs, then wait only until this wave's copies of chunk c + 1 have landed -- a COUNTED
-// s_waitcnt vmcnt(copies of the chunks still allowed in flight) -- and one raw s_barrier (everybody's copies of chunk c + 1 have
-// landed; everybody is done reading chunk c).  A copy has (NS - 2) whole iterations + the MFMAs of its own to land, instead of
-// the MFMAs of one iteration.  The fragment reads are inline asm: for a compiler-visible LDS load hipcc first drains every
-// LDS-DMA in flight (s_waitcnt vmcnt(0) before the first ds_read), which would serialise the ring; they read a stage that a
-// counted wait + barrier completed one iteration earlier (cdna_hip_programming.md: read a staged buffer one phase after the
-// wait that retires it).  Ordinary loads (bias) are kept out of the loop: the counts assume only copies are outstanding.
-template <int WM, int WN, int NS, bool RES>
-__global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_ring_kernel(const Bf3pArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][STAGE]
-    constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
-    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
-    constexpr int KMAX = (NU + NW - 1) / NW, KFULL = NU / NW;                 // copies per wave and chunk: KMAX for the first NU % NW waves
-    static_assert(NS >= 3, "the ring needs a stage in flight besides the one being read and the one landing");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned lane16 = lane * 16;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    int bid, bz;
-    if (a.by_batch) {
-        const int L = (int)blockIdx.x, j = L >> 3;
-        bz = (L & 7) + 8 * (j / a.tiles);
-        if (bz >= a.batch) return;
-        bid = j % a.tiles;
-    } else {
-        bz = (int)blockIdx.z;
-        bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
-    }
-    const int tilesN = a.tilesN * 2 / WN;                                     // a.tilesN counts 128-column tiles
-    const int n_tile = bid % tilesN, m_tile = bid / tilesN;
-    const int row0 = m_tile * BM, cout0 = n_tile * BN;
-    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
-    const unsigned char* A = a.A + (size_t)bz * a.az + (size_t)m_tile * (WM * 2) * gstride;
-    const unsigned char* B = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride;
-    float* M = a.M + (size_t)bz * a.mz;
-    const float* res = a.res + (size_t)bz * a.rz;
-
-    const unsigned char* src[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int u = wave + k * NW;
-        const int ub = u - NA;
-        src[k] = (u < NA ? A + (size_t)(u / 3) * gstride + (u % 3) * UNIT
-                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
-    }
-    const bool extra = KMAX != KFULL && wave < NU - KFULL * NW;               // this wave issues KMAX copies per chunk (wave-uniform)
-    auto issue = [&](int chunk, unsigned char* st) {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k < KFULL || extra) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + (wave + k * NW) * UNIT);
-    };
-    // leave the copies of `chunks_in_flight` (0 .. NS - 2) chunks outstanding
-    auto wait_keep = [&](int chunks_in_flight) {
-        if (chunks_in_flight <= 0) { wait_vmcnt<0>(); return; }
-        if (NS == 3 || chunks_in_flight == 1) { if (extra) wait_vmcnt<KMAX>(); else wait_vmcnt<KFULL>(); return; }
-        if (extra) wait_vmcnt<2 * KMAX>(); else wait_vmcnt<2 * KFULL>();
-    };
-    static_assert(NS <= 4, "wait_keep handles at most two chunks in flight");
-
-    const unsigned lds0 = lds_address(smem);
-    const unsigned aoff = (wm * 2) * 3 * UNIT + lane * 16;
-    const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));     // a USE of the bias: hipcc waits for its load here, where it can see the wait (it does
-                                                    // not see the counted waits below and would re-wait vmcnt(0) before every store)
-    const int n = a.nchunks;
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < n) issue(s, smem + s * STAGE);
-    wait_keep(min(n, NS - 1) - 1);
-    asm volatile("s_barrier" ::: "memory");
-    int stage = 0;                                                            // stage of chunk c; the copies of c + NS - 1 go to stage - 1
-    for (int chunk = 0; chunk < n; ++chunk) {
-        if (chunk + NS - 1 < n) issue(chunk + NS - 1, smem + (stage == 0 ? NS - 1 : stage - 1) * STAGE);
-        const unsigned sa = lds0 + stage * STAGE + aoff, sb = lds0 + stage * STAGE + boff;
-        bf16x8 af[2][3], bf[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[t][p]) : "v"(sa), "n"((t * 3 + p) * UNIT));
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[t][p]) : "v"(sb), "n"((t * 3 + p) * UNIT));
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]),
-                       "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][BF3_TA[t]], bf[j][BF3_TB[t]], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_keep(min(n - chunk - 2, NS - 2));                                // chunk + 1 has landed (mine) ...
-        asm volatile("s_barrier" ::: "memory");                               // ... (everybody's); everybody is done reading `stage`
-        stage = stage + 1 == NS ? 0 : stage + 1;
-    }
-
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8) {
-            float rv[8][2];
-            if (RES) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = r0 + rr;
-                    const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                        rv[rr][j] = co < a.Cout ? res[(size_t)row * a.ldr + co] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = r0 + rr;
-                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* dst = M + (size_t)row * a.ldo;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                    float v = acc[i][j][r] + bv[j];
-                    if (RES) v += rv[rr][j];
-                    if (co < a.Cout) dst[co] = v;
-                }
-            }
-        }
-}
-
 // ---- software-pipelined variant: the fragments of chunk c + 1 are read WHILE the MFMAs of chunk c run ------------------------------
 // In the two kernels above every wave does its front-end work (fragment reads, copy issue) right after the barrier -- all waves at
 // once, the matrix pipe idle meanwhile (measured: ~12 % of the kernel with one 16-wave workgroup per CU).  Here a wave enters an
@@ -421,7 +277,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
         const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
         bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
-    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));     // a USE of the bias: hipcc waits for its load here (see gemm_bf3p_ring_kernel)
+    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));     // a USE of the bias: hipcc waits for its load here, where it can see the wait (it does not see the
+                                                    // waits inside the asm statements below and would re-wait vmcnt(0) before every epilogue store)
     bf16x8 fa[3][2], fb[3][2];                                                 // [plane][tile]
 #define BF3P_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
 #define BF3P_READ_A(p, base) do { BF3P_READ(fa[p][0], base, p, 0); BF3P_READ(fa[p][1], base, p, 1); } while (0)
@@ -608,17 +465,14 @@ extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_pl
     return BBDM_OK;
 }
 
-// KIND 0: gemm_bf3p_kernel (two stages, one wait + barrier per chunk); KIND 1: gemm_bf3p_pipe_kernel (fragments one chunk ahead);
-// KIND = NS >= 3: gemm_bf3p_ring_kernel with NS stages
+// KIND 0: gemm_bf3p_kernel (two stages, front-end work after every barrier); KIND 1: gemm_bf3p_pipe_kernel (fragments one chunk ahead)
 template <int WM, int WN, int KIND, bool RES>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    constexpr int NS = KIND < 3 ? 2 : KIND;
-    const size_t lds = NS * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
     const void* fn = KIND == 0 ? reinterpret_cast<const void*>(gemm_bf3p_kernel<WM, WN, RES>)
-                   : KIND == 1 ? reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>)
-                               : reinterpret_cast<const void*>(gemm_bf3p_ring_kernel<WM, WN, (KIND < 3 ? 3 : KIND), RES>);
+                               : reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>);
     if (!attr_set) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
@@ -632,17 +486,18 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     const dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
     if (KIND == 0)
         hipLaunchKernelGGL((gemm_bf3p_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
-    else if (KIND == 1)
-        hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
     else
-        hipLaunchKernelGGL((gemm_bf3p_ring_kernel<WM, WN, (KIND < 3 ? 3 : KIND), RES>), grid, dim3(WM * WN * 64), lds, st, a);
+        hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
     return BBDM_OK;
 }
 
-// Kernel choice (A/B runs; exported, not part of the public header): 0 = 256 x 128 tile, two stages, two workgroups per CU;
-// 1 = 256 x 256 tile, 16 waves, 3-stage ring (where Cout fills 256-column tiles); 2 = 256 x 128 tile, 8 waves, 4-stage ring;
-// 3 = 256 x 256 tile, 16 waves, two stages; 4 = the software-pipelined kernel, 256 x 256 tile where Cout fills it, else 512 x 128;
-// 5 = software-pipelined 256 x 128 (8 waves, two workgroups per CU); 6 (default) = 4 where Cout fills 256-column tiles, else 5.
+// Kernel choice (A/B runs; exported, not part of the public header; env BBDM_BF3P_KERNEL).  Measured on the 42 Winograd layers of
+// the C2 step, launch-weighted fp32-equivalent TFLOP/s (profiles/r03_bf3p_variants.txt; gemm_bf3.hip on the same GEMMs: 181):
+//   0 = gemm_bf3p_kernel 256 x 128, two workgroups per CU            181      3 = gemm_bf3p_kernel 256 x 256, 16 waves      194-204
+//   4 = pipe kernel 256 x 256 (512 x 128 where Cout < 256)         213-214    5 = pipe kernel 256 x 128, two per CU         204-210
+//   6 (default) = pipe kernel 256 x 256 where Cout fills 256-column tiles, else 256 x 128                                  211-216
+// (a 3-stage LDS ring with counted vmcnt waits for the non-pipelined kernel measured 185-191 and was deleted: what it hides --
+// copy latency -- was not the bound; the front-end bubble after each barrier was.)
 static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 6; }();
 extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_variant; g_bf3p_variant = v; return old; }
 
@@ -669,14 +524,11 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
     const bool wide = CoutPad % 256 == 0;
     int rc;
 #define BBDM_BF3P_GO(WM, WN, KIND) (residual ? bf3p_launch<WM, WN, KIND, true>(a, batch, st) : bf3p_launch<WM, WN, KIND, false>(a, batch, st))
-    if (g_bf3p_variant == 1 && wide) rc = BBDM_BF3P_GO(4, 4, 3);
-    else if (g_bf3p_variant == 2) rc = BBDM_BF3P_GO(4, 2, 4);
-    else if (g_bf3p_variant == 3 && wide) rc = BBDM_BF3P_GO(4, 4, 0);
-    else if (g_bf3p_variant == 4 && wide) rc = BBDM_BF3P_GO(4, 4, 1);
-    else if (g_bf3p_variant == 4) rc = BBDM_BF3P_GO(8, 2, 1);
+    if (g_bf3p_variant == 0) rc = BBDM_BF3P_GO(4, 2, 0);
+    else if (g_bf3p_variant == 3) rc = wide ? BBDM_BF3P_GO(4, 4, 0) : BBDM_BF3P_GO(4, 2, 0);
+    else if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(8, 2, 1);
     else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2, 1);
-    else if (g_bf3p_variant == 6) rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(4, 2, 1);     // the default (measured best per shape)
-    else rc = BBDM_BF3P_GO(4, 2, 0);
+    else rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(4, 2, 1);
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p");

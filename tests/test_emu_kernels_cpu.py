@@ -58,7 +58,7 @@ def test_gemm_bf3p_matches_bf3_bitwise(batch, T, Cin, Cout, extra):
     K.test_gemm_bf3p_matches_bf3_bitwise(CPU, batch, T, Cin, Cout, extra)
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [0, 3, 4, 5])
 @pytest.mark.parametrize("batch,T,Cin,Cout", [(1, 256, 16, 256), (1, 256, 32, 256), (8, 256, 80, 260), (2, 512, 64, 256),
                                               (1, 768, 48, 128)])
 def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):

@@ -28,17 +28,13 @@ def main():
         if "--schema" in sys.argv:
             for r in db.execute("select name from sqlite_master where type='table'"):
                 print("table", r[0], file=sys.stderr)
-        try:
-            tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table' and name like 'rocpd_kernel_dispatch%'")]
-            syms = [r[0] for r in db.execute("select name from sqlite_master where type='table' and name like 'rocpd_info_kernel_symbol%'")]
-            if tabs and syms:
-                q = (f"select s.kernel_name, d.end - d.start from {tabs[0]} d join {syms[0]} s on d.kernel_id = s.id")
-                for name, ns in db.execute(q):
-                    short = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
-                    short = re.sub(r"\(.*$", "", short)
-                    t = dur.setdefault(short, [0, 0.0])
-                    t[0] += 1
-                    t[1] += float(ns)
+        try:                                             # kernel durations (the `kernels` view of the rocpd schema, ns)
+            for name, ns in db.execute("select name, duration from kernels"):
+                short = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+                short = re.sub(r"\(.*$", "", short)
+                t = dur.setdefault(short, [0, 0.0])
+                t[0] += 1
+                t[1] += float(ns)
         except sqlite3.Error:
             pass
     derived = ["MfmaUtil%", "parked%", "issue_stall%", "issuing%", "lds_conflict%", "clock_GHz"]
