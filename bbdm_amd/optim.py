@@ -120,6 +120,10 @@ class FusedAdam(torch.optim.Optimizer):
             for (device, step_no), rows in kinds.items():
                 table, n = self._tables.setdefault((gi, device, len(kinds) > 1 and step_no), _ChunkTable()).get(rows, device)
                 _launch(device, table, n, True, group, step_no, mode, ema.ema_decay if ema is not None else 0.0)
+                # the kernel rewrote the parameters behind autograd's back: bump their version counters, as an in-place torch op
+                # would -- the UNet keys its packed weight copies (and autograd its saved-tensor checks) on them.  Without this the
+                # next forward ran on the conv weights of BEFORE the step.
+                torch.autograd.graph.increment_version([r[0] for r in rows])
         return loss
 
 

@@ -229,6 +229,75 @@ def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
     return out, parity
 
 
+def parity_only(workload, sd, parity_inputs):
+    """The parity sample without the timing leg: image 0 of the benchmarked batch, one p_sample step on the CPU path."""
+    desc, up, ch, size, batch, skip, sstep = WORKLOADS[workload]
+    path = _CpuPath(up, skip, sstep, sd)
+    x_t, y, i_par, eps, g_a, g_b = parity_inputs
+    x_t, y, eps = x_t[:1].cpu(), y[:1].cpu(), eps[:1].cpu()
+    ctx = None if up["condition_key"] == "nocond" else y
+    a_ref, b_ref = path.p_sample(x_t, y, ctx, i_par, eps)
+
+    def rel(a, b):
+        a, b = a.double().cpu(), b.double()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    return {"rel_err_x_tminus": rel(g_a, a_ref[0]), "rel_err_x0_recon": rel(g_b, b_ref[0]), "bar": 1e-3,
+            "metric": "max|gpu - cpu| / max|cpu| on image 0 of the benchmarked batch, one p_sample step "
+                      f"(schedule index {i_par}), same weights / inputs / step noise",
+            "against": path.kind}
+
+
+def training_parity(model, sd, up, skip, sstep, x0, y, dev):
+    """c4: loss and named parameter gradients of ONE micro-step on the benchmarked batch (batch 32, the benchmarked training plan)
+    against autograd on the oracle (CPU, the whole batch).  l2 loss: d|t - p|/dp of the l1 loss is discontinuous, a single
+    flipped sign of the 393 216 loss terms moves every gradient by ~1e-3 of its size; the loss kernel is the
+    only thing that differs between the two."""
+    odir = os.path.join(ROOT, "oracle")
+    if odir not in sys.path:
+        sys.path.insert(0, odir)
+    import bbdm_oracle as O
+    batch = x0.shape[0]
+    g = torch.Generator().manual_seed(2468)
+    t = torch.randint(0, 1000, (batch,), generator=g)
+    noise = torch.randn(x0.shape, generator=g)
+    names = ["input_blocks.0.0.weight", "input_blocks.4.0.in_layers.2.weight", "middle_block.1.qkv.weight",
+             "middle_block.2.out_layers.3.weight", "output_blocks.5.0.skip_connection.weight", "time_embed.0.weight",
+             "out.2.weight", "out.2.bias"]
+    names = [n for n in names if n in sd]
+    keep = model.loss_type
+    model.loss_type = "l2"
+    try:
+        model.zero_grad(set_to_none=True)
+        loss, _ = model.p_losses(x0, y, None, t.to(dev), noise.to(dev))
+        loss.backward()
+        torch.cuda.synchronize(dev)
+        got = {n: dict(model.denoise_fn.named_parameters())[n].grad.detach().cpu().clone() for n in names}
+        loss_gpu = float(loss.detach())
+        model.zero_grad(set_to_none=True)
+    finally:
+        model.loss_type = keep
+    # (the timed micro-steps have stepped the optimizer: the oracle takes the model's CURRENT weights, not the initial ones)
+    cur = {k: v.detach().cpu().clone() for k, v in model.denoise_fn.state_dict().items()}
+    sdg = {"denoise_fn." + k: (v.requires_grad_() if k in names else v) for k, v in cur.items()}
+    ora = O.OracleBBDM(sdg, O.UNetSpec(**up), skip_sample=skip, sample_step=sstep, **dict(BB, loss_type="l2"))
+    t0 = time.perf_counter()
+    loss_ref, _ = ora.p_losses(x0.cpu(), y.cpu(), None, t, noise)
+    loss_ref.backward()
+    secs = time.perf_counter() - t0
+    gmax = max(float(sdg["denoise_fn." + n].grad.abs().max()) for n in names)
+    errs = {}
+    for n in names:
+        ref = sdg["denoise_fn." + n].grad
+        errs[n] = float((got[n] - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
+    lr = float(loss_ref.detach())
+    return {"rel_err_loss": abs(loss_gpu - lr) / max(abs(lr), 1e-30), "rel_err_grad_worst": max(errs.values()), "bar": 1e-3,
+            "grad_errors": errs, "loss_gpu": loss_gpu, "loss_cpu": lr,
+            "metric": f"one training micro-step on the benchmarked batch ({batch} x {tuple(x0.shape[1:])}, l2 loss, fixed t / noise): "
+                      "|loss_gpu - loss_cpu| / |loss_cpu| and, per named parameter, max|g_gpu - g_cpu| / max(|g_cpu|max, 1e-3 x the "
+                      "largest gradient magnitude)",
+            "against": "port (oracle autograd)", "cpu_seconds": secs}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +313,8 @@ def main():
     ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
+    ap.add_argument("--no-f32mfma", action="store_true", help="c2: skip the strict-f32-MFMA A/B steps after the timed region")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked batch against the oracle")
     args = ap.parse_args()
 
     if args.cpu_only:                      # build-container check of the cpu_baseline leg (no GPU needed)
@@ -350,6 +421,28 @@ def main():
     img = state["img"]
     if not bool(torch.isfinite(img).all()):
         raise RuntimeError("non-finite sample")
+    # the same step with the tile GEMMs / 1x1 layers on the f32 MFMA (BBDM_GEMM_BF3=0): a driver-timed number for a reader who
+    # does not accept the bf16x3 emulation as fp32 arithmetic (5 steps after 2 warm-ups, outside the timed region)
+    f32mfma_ms = None
+    if args.workload == "c2" and not training and world == 1 and not args.no_f32mfma and model.denoise_fn.gemm_bf3:
+        model.denoise_fn.gemm_bf3 = False
+        try:
+            for i in range(2):
+                state["img"] = step(i, state["img"])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5):
+                state["img"] = step(2 + i, state["img"])
+            e1.record()
+            torch.cuda.synchronize(dev)
+            f32mfma_ms = e0.elapsed_time(e1) / 5
+        finally:
+            model.denoise_fn.gemm_bf3 = True
+        plan_keys = list(model.denoise_fn._plans)
+        for k in plan_keys[1:]:                    # drop the A/B plan's buffers again
+            del model.denoise_fn._plans[k]
+        torch.cuda.empty_cache()
 
     # ---- per-kernel accounting from the HIP events recorded inside the timed region -------------------------
     by = {}
@@ -414,10 +507,16 @@ def main():
     # fp32 accumulate).  Its roofline is the dense bf16 MFMA peak; one fp32-equivalent FLOP costs 6 bf16 FLOP, so the bound
     # for the algorithmic (fp32) FLOPs is PEAK_BF16 / 6.  With BBDM_GEMM_BF3=0 (or where the shape gate rejects a layer)
     # the GEMMs run on conv_igemm_f32 (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s) together with the direct convolutions.
-    bf3_ops = sum(getattr(nm, "entry", "").endswith("bf3_f32") for nm, _ in plan0.ops)
-    use_bf3 = bf3_ops > 0
+    all_ops = list(plan0.ops) + (list(plan0.bops) if training else [])
+    entries = [getattr(nm, "entry", "") for nm, _ in all_ops if nm == "bbdm_winograd_gemm_f32"]
+    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") for e in entries), sum(e.endswith("bf3_f32") for e in entries)
+    use_bf3 = bf3p_ops + bf3_ops > 0
     if use_bf3:
-        dom, dom_name = wino, "gemm_bf3_kernel (v_mfma_f32_32x32x16_bf16 x 6 terms = one fp32-accurate product)"
+        # the tile GEMMs run on csrc/gemm_bf3p.hip (both operands pre-split by their producers, LDS-DMA + MFMA main loop) where the
+        # input transform writes the planes, else on csrc/gemm_bf3.hip (fp32 V split while staged): same arithmetic, bit for bit
+        kname = ("gemm_bf3p_pipe_kernel" if bf3p_ops >= bf3_ops else "gemm_bf3_kernel")
+        dom, dom_name = wino, (f"{kname} (v_mfma_f32_32x32x16_bf16 x 6 terms = one fp32-accurate product; {bf3p_ops} launches per "
+                               f"pass on gemm_bf3p, {bf3_ops} on gemm_bf3)")
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
     else:
         dom, dom_name, peak = conv, "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
@@ -434,26 +533,49 @@ def main():
     # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
     # rocprofv3 PMC passes of this same command (profiles/*_pmc_<workload>_traffic.json), per launch, or null.
     traffic = None
+    traffic_step = None
+    import glob
     try:
-        import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
-            hits = [v for k, v in pm["kernels"].items() if k.startswith("gemm_bf3_kernel" if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in pm["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
             if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
                 nl = sum(v["launches"] for v in hits)
                 traffic = {"bytes_per_launch": sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in hits) / nl,
                            "source": os.path.basename(cands[-1]),
                            "note": "L2<->fabric bytes (FETCH_SIZE x2 + WRITE_SIZE), Infinity-Cache hits included"}
+            tot = pm.get("totals")
+            if tot:                        # whole step: every kernel's fabric bytes minus the one-time weight packing
+                traffic_step = {"bytes_per_step": tot["bytes_per_step_excl_packing"], "source": os.path.basename(cands[-1]),
+                                "algorithmic_bytes_per_step": tot.get("algorithmic_bytes_per_step"),
+                                "note": "sum over all kernels of FETCH_SIZE x2 + WRITE_SIZE (L2<->fabric, Infinity-Cache hits "
+                                        "included), one-time weight packing excluded; algorithmic = SURVEY.md 8(d)"}
     except Exception:
         traffic = None
+    # MFMA utilisation of the dominant kernel from the committed PMC pass (tools/rocprof_counters.py --json)
+    mfma_util = None
+    try:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_mfma_util.json")))
+        if cands:
+            mu = json.load(open(cands[-1]))
+            hits = [v for k, v in mu["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            if hits:
+                best = max(hits, key=lambda v: v.get("launches", 0))
+                mfma_util = {"percent": best.get("MfmaUtil%"), "effective_clock_GHz": best.get("clock_GHz"),
+                             "source": os.path.basename(cands[-1]),
+                             "note": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): share of the kernel's cycles the "
+                                     "matrix pipes are busy, at the clock the chip sustains under this load"}
+    except Exception:
+        mfma_util = None
     # algorithmic HBM bytes of the dominant kernel per launch: operands read once + result written once
     alg_bytes, alg_n = 0.0, 0
     for nm, oa in plan0.ops:
         if nm == "bbdm_winograd_gemm_f32":
             wm, gN, gH, gW, gci, gco = oa[0], *oa[4:9]
             P, T = (wm + 2) ** 2, gN * -(-gH // wm) * -(-gW // wm)
-            alg_bytes += 4.0 * (P * T * (gci + gco)) + (6.0 if use_bf3 else 4.0) * P * gci * gco
+            a_bytes = 6.0 if getattr(nm, "entry", "").endswith("bf3p_f32") else 4.0     # V as three bf16 planes / fp32
+            alg_bytes += P * T * (a_bytes * gci + 4.0 * gco) + (6.0 if use_bf3 else 4.0) * P * gci * gco
             alg_n += 1
         elif nm == "bbdm_conv2d_nhwc_f32" and not use_bf3:
             gN, gH, gW, gci, gco, gks = oa[15:21]
@@ -493,7 +615,8 @@ def main():
                          "frac_step": t_at_peak / (ms_per_step * 1e-3),
                          "frac_step_note": "whole step: time the MFMA work of every kernel would take at its matrix peak "
                                            "(bf16x6 for the tile GEMMs, f32 MFMA for the rest) / step time",
-                         "traffic": traffic, "launches_per_step": conv_launches / max(1, args.steps),
+                         "traffic": traffic, "traffic_step": traffic_step, "mfma_util": mfma_util,
+                         "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
                          "share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,
                          "flops_counted": "fp32-equivalent FLOPs executed: a Winograd layer's (m+2)^2 tile GEMMs = 4/9 (m=2), "
@@ -504,32 +627,36 @@ def main():
                          "conv1x1_bf3_tflops": (c1x1[2] / (c1x1[1] * 1e-3) / 1e12) if c1x1[1] > 0 else None,
                          "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
+            "f32mfma_ms_per_step": f32mfma_ms,
         }
         if args.workload in FIRST_STAGE and not args.no_pipeline:
             line["pipeline"] = first_stage_pipeline(args.workload, batch, dev, ms_per_step, nsteps_table)
+        # parity sample (every workload, world 1, unless --no-parity): one more p_sample of the SAME batch with known step noise
+        # (untimed), image 0 of which the CPU path recomputes (in its warm-up step when the cpu_baseline leg runs too); c4: the
+        # loss and a handful of named gradients of the benchmarked batch against the oracle's autograd
+        par_in = None
+        if not training and not args.no_parity and world == 1:
+            i_par = 431 % (nsteps_table - 1)
+            eps = torch.randn(x_t.shape, generator=torch.Generator().manual_seed(4321)).to(dev)
+            orig_rl = torch.randn_like
+            torch.randn_like = lambda t, **k: eps
+            try:
+                g_a, g_b = model.p_sample(x_t, y, ctx, i_par, clip_denoised=False)
+            finally:
+                torch.randn_like = orig_rl
+            torch.cuda.synchronize(dev)
+            par_in = (x_t, y, i_par, eps, g_a[0].cpu(), g_b[0].cpu())
+        line["cpu_baseline"], line["parity"] = None, None
         if not args.no_cpu and world == 1:
-            # parity sample: one more p_sample of the SAME batch with known step noise (untimed), image 0 of which the
-            # CPU path recomputes in its warm-up step
-            par_in = None
-            if not training:
-                i_par = 431 % (nsteps_table - 1)
-                eps = torch.randn(x_t.shape, generator=torch.Generator().manual_seed(4321)).to(dev)
-                orig_rl = torch.randn_like
-                torch.randn_like = lambda t, **k: eps
-                try:
-                    g_a, g_b = model.p_sample(x_t, y, ctx, i_par, clip_denoised=False)
-                finally:
-                    torch.randn_like = orig_rl
-                torch.cuda.synchronize(dev)
-                par_in = (x_t, y, i_par, eps, g_a[0].cpu(), g_b[0].cpu())
             line["cpu_baseline"], line["parity"] = cpu_baseline(args.workload, sd, args.cpu_budget, par_in)
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-            if line["parity"] is not None and not (line["parity"]["rel_err_x_tminus"] < 1e-3
-                                                   and line["parity"]["rel_err_x0_recon"] < 1e-3):
-                raise RuntimeError(f"bench parity check failed: {line['parity']}")
-        else:
-            line["cpu_baseline"] = None
-            line["parity"] = None
+        elif par_in is not None:
+            line["parity"] = parity_only(args.workload, sd, par_in)
+        if training and not args.no_parity and world == 1:
+            line["parity"] = training_parity(model, sd, up, skip, sstep, x_t, y, dev)
+        par = line["parity"]
+        if par is not None and not all(v < par["bar"] for k, v in par.items() if k.startswith("rel_err")):
+            raise RuntimeError(f"bench parity check failed: {par}")
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

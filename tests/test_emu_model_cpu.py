@@ -72,6 +72,10 @@ def test_gradients_handed_out_are_never_overwritten():
     T.test_gradients_handed_out_are_never_overwritten(CPU)
 
 
+def test_fused_adam_steps_follow_the_oracle():
+    T.test_adam_steps_follow_the_oracle(CPU, True)
+
+
 def test_groupnorm_statistics_fused_into_the_producers():
     """A UNet wide enough (128 channels -> 4 per group) for the conv epilogues to accumulate the GroupNorm statistics of
     their outputs (block outputs feeding the next block AND, through the concat, an output block): same result as with the

@@ -144,11 +144,15 @@ def test_context_gradient_through_cross_attention(dev):
     assert rel_err(ctx.grad.cpu(), c_ref.grad) < GRAD_TOL
 
 
-def test_adam_steps_follow_the_oracle(dev):
-    """Five Adam steps on one batch: the loss curve tracks an identical run of the oracle on the CPU."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_adam_steps_follow_the_oracle(dev, fused):
+    """Five Adam steps on one batch: the loss curve tracks an identical run of the oracle on the CPU -- with torch.optim.Adam and
+    with bbdm_amd.optim.FusedAdam, whose kernel rewrites the parameters outside autograd: the forward of the next step must see
+    the new weights (packed conv copies are keyed on the parameter's version counter, which FusedAdam bumps)."""
+    from bbdm_amd.optim import FusedAdam
     rec = load_case("tiny_nocond")
     m = build(rec, dev).train()
-    opt = torch.optim.Adam(m.get_parameters(), lr=1e-4, betas=(0.9, 0.999))
+    opt = (FusedAdam if fused else torch.optim.Adam)(m.get_parameters(), lr=1e-4, betas=(0.9, 0.999))
     rec_o = dict(rec)
     rec_o["state_dict"] = {k: (v.clone().requires_grad_() if k.startswith("denoise_fn.") else v)
                            for k, v in rec["state_dict"].items()}

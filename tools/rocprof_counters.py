@@ -38,8 +38,11 @@ def main():
         except sqlite3.Error:
             pass
     derived = ["MfmaUtil%", "parked%", "issue_stall%", "issuing%", "lds_conflict%", "clock_GHz"]
-    print("| kernel | launches | us | " + " | ".join(order + derived) + " |")
-    print("|---|---|---|" + "---|" * (len(order) + len(derived)))
+    as_json = "--json" in sys.argv
+    jout = {}
+    if not as_json:
+        print("| kernel | launches | us | " + " | ".join(order + derived) + " |")
+        print("|---|---|---|" + "---|" * (len(order) + len(derived)))
     for k in sorted(data, key=lambda k: -sum(v[1] for v in data[k].values())):
         d = {c: v[1] / v[0] for c, v in data[k].items()}
         n = max(v[0] for v in data[k].values())
@@ -54,7 +57,14 @@ def main():
         ldc = 100 * g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None else None
         clk = g("GRBM_GUI_ACTIVE") / 8 / (us * 1e3) if g("GRBM_GUI_ACTIVE") and us == us and us > 0 else None
         dv = [mf, pct("SQ_WAIT_ANY"), pct("SQ_WAIT_INST_ANY"), pct("SQ_ACTIVE_INST_ANY"), ldc, clk]
-        print(f"| {k} | {n} | {us:.1f} | " + " | ".join(row + [("" if v is None else f"{v:.3g}") for v in dv]) + " |")
+        if as_json:
+            jout[k] = dict({"launches": n, "avg_us": None if us != us else us}, **d, **{nm: v for nm, v in zip(derived, dv)})
+        else:
+            print(f"| {k} | {n} | {us:.1f} | " + " | ".join(row + [("" if v is None else f"{v:.3g}") for v in dv]) + " |")
+    if as_json:
+        import json
+        json.dump({"units": "per-launch means; GRBM_GUI_ACTIVE summed over the 8 XCDs, SQ_* summed over the chip; MfmaUtil% = "
+                            "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)", "kernels": jout}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,9 @@
 """Per-kernel HBM-side traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one pass each, with
 --kernel-trace only -- the combination gpurun allows).
 
-    python tools/rocprof_pmc.py FETCH_results.db WRITE_results.db "<command that was profiled>" > profiles/rNN_pmc_<wl>_traffic.json
+    python tools/rocprof_pmc.py FETCH_results.db WRITE_results.db "<command that was profiled>" [steps [algorithmic_bytes_per_step]] \
+        > profiles/rNN_pmc_<wl>_traffic.json
+(steps = forward passes the command ran: adds `totals` with the whole-step fabric bytes, one-time weight packing excluded)
 
 Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE / WRITE_SIZE are
 reported in KiB; FETCH_SIZE under-counts by 2x on gfx950 (64 B requests are counted as 32 B), so
@@ -39,7 +41,15 @@ def main():
         wk = sw / nw if nw else 0.0
         kernels[k] = {"launches": n, "FETCH_SIZE_KiB_per_launch": fk, "WRITE_SIZE_KiB_per_launch": wk,
                       "fabric_bytes_per_launch_corrected": (2.0 * fk + wk) * 1024.0}
-    json.dump({"command": cmd,
+    steps = float(sys.argv[4]) if len(sys.argv) > 4 else None         # forward passes the profiled command ran (warm-up + timed)
+    totals = None
+    if steps:
+        allb = sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in kernels.values())
+        packb = sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for k, v in kernels.items() if "pack" in k or "weight_kernel" in k)
+        totals = {"steps_profiled": steps, "all_kernels_bytes": allb, "one_time_weight_packing_bytes": packb,
+                  "bytes_per_step_excl_packing": (allb - packb) / steps,
+                  "algorithmic_bytes_per_step": float(sys.argv[5]) if len(sys.argv) > 5 else None}
+    json.dump({"command": cmd, "totals": totals,
                "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 (gfx950 "
                         "half-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported. They count L2<->fabric "
                         "requests: Infinity-Cache (MALL) hits are INCLUDED, so this is an upper bound on HBM bytes",
