@@ -4,7 +4,9 @@
 //     w = softmax_over_s( (q*s)^T (k*s) ),  a = v w^T,   s = ch^-1/4
 // without ever materialising the [N*heads, T, T] score tensor (17 GB at 256^2 / batch 16).
 //
-// One workgroup = 4 waves = 128 consecutive queries of one (image, head); each wave owns 32 queries.
+// One workgroup = NW waves (8: 256 consecutive queries of one (image, head); 4 for short sequences); each wave owns 32 queries.
+// Workgroup ids are dealt so that every query block of one (image, head) runs on ONE XCD: its K / V (2 MB at T = 4096) cross the
+// fabric into that L2 once instead of once per XCD (measured before: 4.8 GB of fabric traffic per launch against 1.07 GB).
 // Everything is computed TRANSPOSED so that a query is a lane (column) in every MFMA result:
 //   S^T[key, query] = K[key, :] . Q^T[:, query]     A = K tile from LDS, B = Q^T held in 2*CH/4 VGPRs
 //   O^T[c,   query] += V^T[c, key] . P^T[key, query] A = V^T read from LDS, B = P^T = exp(S^T - m) IN PLACE:
@@ -18,18 +20,24 @@
 namespace {
 
 constexpr int KT = 32;        // keys per tile
-constexpr int QB = 128;       // queries per block
 
 // BQ: S^T = K Q^T on the BF16 matrix core with fp32 accuracy (bf3_split.h: both operands split exactly into three bf16 planes,
 // six product terms, fp32 accumulate): 6 x CH/16 MFMAs of 32 cycles per key tile instead of CH/2 of 64 -- 2.7x less matrix-core
 // time for half of the attention FLOPs.  K is split while it is staged (planes [3][key][CH] bf16 in LDS, +16 B row pad: the 8 rows
 // of a ds_read_b128 group fall on distinct 16-B slots), Q once per workgroup; the bf16 MFMA's C/D layout is the f32 one, so the
 // softmax and the P V product below (f32 MFMA: its B operand is the P registers in place) are untouched.
-template <int CH, bool BQ>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
+// BV: O^T += V^T P^T on the BF16 matrix core with fp32 accuracy as well: V is split into three bf16 planes while it is staged
+// (row-major [plane][16-channel subtile][key][16 ch]: 8-byte writes, like K) and reaches the MFMA's A operand -- rows = channels,
+// k = keys -- through ds_read_b64_tr_b16, the LDS transpose read: a 16-lane group reads a [4 keys][16 channels] block and lane i
+// receives the 4 keys of channel i.  P^T = exp(S^T - m) is the B operand IN PLACE as before: register r of lane (query, hi) holds
+// key (r & 3) + 8 (r >> 2) + 4 hi, so registers 8 ks .. 8 ks + 7 -- keys {0-3, 8-11} + 4 hi + 16 ks -- are the lane's 8 k-slots of
+// K-step ks once split and packed pairwise (lane-local: no shuffles), and the transpose reads fetch exactly those keys.
+// 6 x 2 x CH/32 MFMAs of 32 cycles per key tile instead of 16 x CH/32 of 64.
+template <int CH, bool BQ, bool BV, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
                                                        const float* __restrict__ ksrc, const float* __restrict__ vsrc, int ldkv,
                                                        int hskv, float* __restrict__ out, int ldo, float* __restrict__ lse,
-                                                       int Tq, int T, int heads, float qscale, float scale) {
+                                                       int Tq, int T, int heads, int nheads_total, float qscale, float scale) {
     // q: [N][Tq][ldq], head h at channel h * hsq;  k, v: [N][T][ldkv], head h at channel h * hskv (T = number of keys).
     // qscale / scale multiply q / k while they are loaded (legacy: ch^-1/4 each; CrossAttention: ch^-1/2 and 1).
     constexpr int KPITCH = CH + 4;                 // K tile pitch: b128 reads by 32 keys conflict-free
@@ -37,22 +45,34 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     constexpr int CT = (CH + 31) / 32;             // 32-row channel tiles of O^T
     constexpr int KG = CH / 8;                     // k-groups of 8 channels for QK^T
     constexpr int KV4 = KT * CH / 4;               // float4 per K (or V) tile
-    constexpr int SLOTS = (KV4 + 255) / 256;
+    constexpr int NTHR = NW * 64, QB = NW * 32;
+    constexpr int SLOTS = (KV4 + NTHR - 1) / NTHR;
+    static_assert(!BV || (BQ && CH % 32 == 0), "the bf16x3 P V path needs whole 32-channel tiles and the split K path");
 
     constexpr int KS = CH / 16;                    // BQ: MFMA K-steps of 16 channels
     constexpr int KROWB = CH * 2 + 16;             // BQ: bytes per key row of one bf16 plane
     constexpr int KPLANE = KT * KROWB;             // BQ: bytes per plane
     constexpr int KSTAGE = BQ ? 3 * KPLANE / 4 : KT * KPITCH;      // floats per K stage
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * KSTAGE + 2 * KT * VPITCH];
+    constexpr int VSUB = KT * 32 + 128;            // BV: bytes from the first [32 keys][16 ch] bf16 subtile of a 32-channel tile to the
+                                                   //     second (+128: the two subtiles a 32-lane half reads fall on different bank halves)
+    constexpr int VCT = 2 * KT * 32 + 128;         // BV: bytes per 32-channel tile (two subtiles)
+    constexpr int VPLANE = (CH / 32) * VCT;        // BV: bytes per plane
+    constexpr int VSTAGE = BV ? 3 * VPLANE / 4 : KT * VPITCH;      // floats per V stage
+    constexpr int OPITCH = CH + 1;                 // epilogue: O^T / l staged [query][CH + 1] through the same LDS
+    constexpr int SMEM = 2 * KSTAGE + 2 * VSTAGE > QB * OPITCH ? 2 * KSTAGE + 2 * VSTAGE : QB * OPITCH;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* kbuf = smem;
     float* vbuf = smem + 2 * KSTAGE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int qblocks = (Tq + QB - 1) / QB;
-    const int qb = blockIdx.x % qblocks;
-    const int nh = blockIdx.x / qblocks;
+    // XCD x (block id % 8) owns the (image, head) pairs x, x + 8, ...: all query blocks of a pair share its K / V through one L2
+    const int L = (int)blockIdx.x, slot = L >> 3;
+    const int qb = slot % qblocks;
+    const int nh = (L & 7) + 8 * (slot / qblocks);
+    if (nh >= nheads_total) return;
     const int h = nh % heads, n = nh / heads;
     const float* qbase = qsrc + (size_t)n * Tq * ldq + h * hsq;
     const float* kbase = ksrc + (size_t)n * T * ldkv + h * hskv;
@@ -102,7 +122,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     auto load_tile = [&](int tile) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int f = tid + s * 256;
+            const int f = tid + s * NTHR;
             const int key = tile * KT + f / (CH / 4), c = (f % (CH / 4)) * 4;
             if (f < KV4 && key < T) {
                 float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)key * ldkv + c);
@@ -117,7 +137,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int f = tid + s * 256;
+            const int f = tid + s * NTHR;
             if (f < KV4) {
                 const int key = f / (CH / 4), c = (f % (CH / 4)) * 4;
                 if (BQ) {
@@ -130,13 +150,23 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
                 } else {
                     *reinterpret_cast<float4*>(kbuf + buf * KSTAGE + key * KPITCH + c) = kreg[s];
                 }
-                *reinterpret_cast<float4*>(vbuf + buf * KT * VPITCH + key * VPITCH + c) = vreg[s];
+                if (BV) {
+                    uint2 p1, p2, p3;
+                    split4(vreg[s], p1, p2, p3);
+                    unsigned char* vd = reinterpret_cast<unsigned char*>(vbuf + buf * VSTAGE) + (c >> 5) * VCT + ((c >> 4) & 1) * VSUB + key * 32 +
+                                        (c & 15) * 2;
+                    *reinterpret_cast<uint2*>(vd) = p1;
+                    *reinterpret_cast<uint2*>(vd + VPLANE) = p2;
+                    *reinterpret_cast<uint2*>(vd + 2 * VPLANE) = p3;
+                } else {
+                    *reinterpret_cast<float4*>(vbuf + buf * VSTAGE + key * VPITCH + c) = vreg[s];
+                }
             }
         }
     };
 
     if (CH < 32) {   // rows of V^T beyond CH are read by the MFMA A operand: keep them finite
-        for (int i = tid; i < 2 * KT * VPITCH; i += 256) vbuf[i] = 0.f;
+        for (int i = tid; i < 2 * VSTAGE; i += NTHR) vbuf[i] = 0.f;
         __syncthreads();
     }
 
@@ -210,14 +240,49 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
 
         // ---- O^T += V^T P^T ------------------------------------------------------------------------------------
-        const float* vb = vbuf + buf * KT * VPITCH + lq;
+        if (BV) {
+            typedef short v4s __attribute__((ext_vector_type(4)));
+            // transpose-read address of this lane: 16-lane group g reads subtile 2 ct + g; lane i of the group supplies the 8-byte
+            // word (key row i >> 2, channel quad i & 3) and receives channel i, 4 consecutive keys
+            const unsigned char* vt = reinterpret_cast<const unsigned char*>(vbuf + buf * VSTAGE) + ((lane >> 4) & 1) * VSUB +
+                                      (4 * hi + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 pf[3];                                   // P^T planes of the lane's 8 k-slots: registers 8 ks .. 8 ks + 7
+                {
+                    unsigned w[3][4];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const float vf = vb[krow * VPITCH + ct * 32];
-                o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[ct], 0, 0, 0);
+                    for (int d = 0; d < 4; ++d) split2(s[8 * ks + 2 * d], s[8 * ks + 2 * d + 1], w[0][d], w[1][d], w[2][d]);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    bf16x8 vf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned char* a = vt + p * VPLANE + ct * VCT + ks * 16 * 32;
+                        const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a));
+                        const v4s hi8 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 8 * 32));
+                        typedef short v8s __attribute__((ext_vector_type(8)));
+                        const v8s both = {lo[0], lo[1], lo[2], lo[3], hi8[0], hi8[1], hi8[2], hi8[3]};
+                        vf[p] = __builtin_bit_cast(bf16x8, both);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+                        o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[BF3_TA[t]], pf[BF3_TB[t]], o[ct], 0, 0, 0);
+                }
+            }
+        } else {
+            const float* vb = vbuf + buf * VSTAGE + lq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = (r & 3) + 8 * (r >> 2) + 4 * hi;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float vf = vb[krow * VPITCH + ct * 32];
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[ct], 0, 0, 0);
+                }
             }
         }
 
@@ -226,9 +291,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     }
 
     // ---- epilogue: O^T / l -> LDS [query][c] -> coalesced rows ----------------------------------------------------
-    constexpr int OPITCH = CH + 1;
-    float* obuf = smem;                                    // 128 * (CH+1) floats <= the K/V buffers for CH >= 16
-    static_assert(QB * OPITCH <= 2 * KSTAGE + 2 * KT * VPITCH, "epilogue staging does not fit");
+    float* obuf = smem;
     const float inv = 1.0f / l_run;
     if (lse && hi == 0 && q < Tq) lse[((size_t)n * heads + h) * Tq + q] = m_run + logf(l_run);   // for the backward pass
 #pragma unroll
@@ -239,7 +302,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
             if (c < CH) obuf[(wave * 32 + lq) * OPITCH + c] = o[ct][r] * inv;
         }
     __syncthreads();
-    for (int i = tid; i < QB * CH; i += 256) {
+    for (int i = tid; i < QB * CH; i += NTHR) {
         const int ql = i / CH, c = i - ql * CH;
         const int qq = qb * QB + ql;
         if (qq < Tq) out[((size_t)n * Tq + qq) * ldo + h * CH + c] = obuf[ql * OPITCH + c];
@@ -251,16 +314,22 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 static int launch_attention(const float* q, int ldq, int hsq, const float* k, const float* v, int ldkv, int hskv, float* out,
                             int ldo, float* lse, int N, int Tq, int Tk, int heads, int ch, float qscale, float kscale,
                             hipStream_t st) {
-    const int qblocks = (Tq + QB - 1) / QB;
-    const dim3 grid((unsigned)((long long)N * heads * qblocks));
-    // Q K^T on the bf16x3 path (BBDM_ATTN_BF3=0: f32 MFMA, for the A/B)
+    // Q K^T and P V on the bf16x3 path (BBDM_ATTN_BF3=0: both on the f32 MFMA; 2: only Q K^T, the round-2 kernel -- for the A/B)
     static const int bq = [] { const char* e = getenv("BBDM_ATTN_BF3"); return e ? atoi(e) : 1; }();
-#define BBDM_ATTN_FWD(CH, BQ)                                                                                              \
-    hipLaunchKernelGGL((attn_fwd_kernel<CH, BQ>), grid, dim3(256), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, lse, Tq, Tk, \
-                       heads, qscale, kscale)
-    if (ch == 64) { if (bq) BBDM_ATTN_FWD(64, true); else BBDM_ATTN_FWD(64, false); }
-    else if (ch == 32) { if (bq) BBDM_ATTN_FWD(32, true); else BBDM_ATTN_FWD(32, false); }
-    else { if (bq) BBDM_ATTN_FWD(16, true); else BBDM_ATTN_FWD(16, false); }
+    // 4 waves (128 queries) per workgroup, three workgroups per CU; BBDM_ATTN_WAVES=8: 256 queries, K / V staged once per 256 (A/B)
+    static const int nw_env = [] { const char* e = getenv("BBDM_ATTN_WAVES"); return e ? atoi(e) : 4; }();
+    const int nw = (nw_env == 8 && Tq > 128) ? 8 : 4;
+    const int qblocks = (Tq + nw * 32 - 1) / (nw * 32);
+    const int nht = N * heads;
+    const dim3 grid((unsigned)(8ll * ((nht + 7) / 8) * qblocks));
+#define BBDM_ATTN_FWD(CH, BQ, BV, NW)                                                                                      \
+    hipLaunchKernelGGL((attn_fwd_kernel<CH, BQ, BV, NW>), grid, dim3(NW * 64), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, \
+                       lse, Tq, Tk, heads, nht, qscale, kscale)
+#define BBDM_ATTN_FWD_NW(CH, BQ, BV) do { if (nw == 8) BBDM_ATTN_FWD(CH, BQ, BV, 8); else BBDM_ATTN_FWD(CH, BQ, BV, 4); } while (0)
+    if (ch == 64) { if (bq == 1) BBDM_ATTN_FWD_NW(64, true, true); else if (bq) BBDM_ATTN_FWD_NW(64, true, false); else BBDM_ATTN_FWD_NW(64, false, false); }
+    else if (ch == 32) { if (bq == 1) BBDM_ATTN_FWD_NW(32, true, true); else if (bq) BBDM_ATTN_FWD_NW(32, true, false); else BBDM_ATTN_FWD_NW(32, false, false); }
+    else { if (bq) BBDM_ATTN_FWD_NW(16, true, false); else BBDM_ATTN_FWD_NW(16, false, false); }
+#undef BBDM_ATTN_FWD_NW
 #undef BBDM_ATTN_FWD
     return 0;
 }

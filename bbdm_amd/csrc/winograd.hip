@@ -186,7 +186,10 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
             if (res) {
 #pragma unroll
                 for (int b = 0; b < MO; ++b)
-                    rv[b] = *reinterpret_cast<const float4*>(res_per_image ? res + (size_t)n * ldr + c : res + (pix0 + b) * ldr + c);
+                    rv[b] = *reinterpret_cast<const float4*>(
+                        res_per_image == 1 ? res + (size_t)n * ldr + c
+                        : res_per_image == 2 ? res + ((size_t)(n * (H >> 1) + ((MO * th + a) >> 1)) * (W >> 1) + ((MO * tw + b) >> 1)) * ldr + c
+                                             : res + (pix0 + b) * ldr + c);
             }
 #pragma unroll
             for (int b = 0; b < MO; ++b) {
@@ -512,8 +515,9 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
 #pragma unroll
                 for (int b = 0; b < MO; ++b) {
                     const int owc = min(MO * tw + b, W - 1);
-                    const float* rp = res_per_image ? res + (size_t)n * ldr + c
-                                                    : res + ((size_t)(n * H + ohc) * W + owc) * ldr + c;
+                    const float* rp = res_per_image == 1 ? res + (size_t)n * ldr + c
+                                      : res_per_image == 2 ? res + ((size_t)(n * (H >> 1) + (ohc >> 1)) * (W >> 1) + (owc >> 1)) * ldr + c
+                                                           : res + ((size_t)(n * H + ohc) * W + owc) * ldr + c;
                     rv[b] = *reinterpret_cast<const float2*>(rp);
                 }
             }
@@ -767,7 +771,11 @@ extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float
     BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldo % 4 == 0 && ldo >= Cout, "winograd_output: Cout=%d ldo=%d", Cout, ldo);
-    BBDM_REQUIRE((flags & ~BBDM_CONV_RES_PER_IMAGE) == 0, "winograd_output: unsupported flags 0x%x", flags);
+    BBDM_REQUIRE((flags & ~(BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE)) == 0 &&
+                     (flags & (BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE)) != (BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE),
+                 "winograd_output: unsupported flags 0x%x", flags);
+    BBDM_REQUIRE(!(flags & BBDM_CONV_RES_UPSAMPLE) || (residual && H % 2 == 0 && W % 2 == 0),
+                 "winograd_output: BBDM_CONV_RES_UPSAMPLE needs a residual and even H, W");
     BBDM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= Cout && ((uintptr_t)residual & 15) == 0), "winograd_output: ldr=%d", ldr);
     BBDM_REQUIRE(!bias || ((uintptr_t)bias & 15) == 0, "winograd_output: bias alignment");
     BBDM_REQUIRE((((uintptr_t)M | (uintptr_t)out) & 15) == 0, "winograd_output: 16-byte alignment");
@@ -785,7 +793,7 @@ extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float
     iters = iters < 1 ? 1 : (iters > 16 ? 16 : iters);
     const long long blocks = (units + 256 * iters - 1) / (256 * iters);
     BBDM_REQUIRE(blocks < (1ll << 31), "winograd_output: too many workgroups");
-    const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : 0;
+    const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : (flags & BBDM_CONV_RES_UPSAMPLE) ? 2 : 0;     // residual addressing mode
     const dim3 g((unsigned)blocks), b(256);
     hipStream_t s_ = (hipStream_t)stream;
     if (m == 6 && residual)

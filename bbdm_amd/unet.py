@@ -974,7 +974,8 @@ class _Plan:
             w["used"] += 1
         self.fused_stats += 1
 
-    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None, fuse_direct: bool = False):
+    def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None, fuse_direct: bool = False,
+                  upsample: bool = False):
         """Input of a conv that follows GroupNorm [-> FiLM] [-> SiLU] at the same resolution.
 
         Inference plans do not materialise the normalised tensor: they emit the statistics + a tiny per-(image, channel)
@@ -983,8 +984,10 @@ class _Plan:
         into the direct conv kernel only on request (``fuse_groupnorm``: it costs more MFMA stalls than the pass it
         removes) but always into the HBM-bound Winograd input transform of ``consumer``, where it is
         free."""
+        up = 2 if upsample else 1         # (``upsample``: the consumer convolves the nearest x2 upsampling of the activated tensor)
         fuse = fuse_direct or self.m.fuse_groupnorm or (consumer is not None and self.m.winograd_fuse_groupnorm
-                                                        and self._winograd_ok(consumer, x.H, x.W, x.C))
+                                                        and self._winograd_ok(consumer, up * x.H, up * x.W, x.C))
+        assert not upsample or (fuse and not self.training)
         if self.training:
             # Training plans materialise the activated tensor for the weight gradient -- unless that gradient will contract the V
             # this layer's forward keeps (Winograd layer, same tile both ways: _emit_winograd / conv_bwd): then nothing
@@ -1020,7 +1023,7 @@ class _Plan:
     def _winograd_ok(self, mod, H, W, cin_pad, flags=0) -> int:
         """Winograd output tile for this conv (0 = direct kernel)."""
         w = mod.weight
-        if not self.m.winograd or w.dim() != 4 or w.shape[2] != 3 or (flags & ~2) != 0:
+        if not self.m.winograd or w.dim() != 4 or w.shape[2] != 3 or (flags & ~6) != 0:
             return 0
         return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd)
 
@@ -1072,7 +1075,8 @@ class _Plan:
 
     def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0,
                    pre=None, upsample: bool = False):
-        """``residual`` is an NHWC view, or (with flags & 2) a per-image [N][res_ld] tensor reference.
+        """``residual`` is an NHWC view, or (with flags & 2) a per-image [N][res_ld] tensor reference, or (flags & 4, Winograd path only)
+        an NHWC view at half the resolution that is added nearest-upsampled x2.
         ``upsample``: the convolved tensor is the nearest x2 upsampling of ``x`` (Winograd path only)."""
         cout = mod.weight.shape[0]
         assert dest.C == cout, (dest.C, cout)
@@ -1116,13 +1120,26 @@ class _Plan:
         film = rb.use_scale_shift_norm
         rs = 2 if rb.up else (1 if rb.down else 0)
         s1 = self._gn_count
+        # Up-sampling block, inference, both 3x3 convs on the Winograd path at the upsampled size: nothing is resampled explicitly.
+        # GN -> SiLU -> nearest x2 folds into the input transform of in_layers[2] (index shift, csrc/winograd.hip: UP), and the skip path
+        # x_upd(x) is the out conv's residual read at [h/2][w/2] (BBDM_CONV_RES_UPSAMPLE): the two gn_apply passes that wrote and
+        # re-read 4x-size tensors (1.65 ms per C2 step) disappear and the input transform reads a quarter of the bytes.
+        fold_up = (rs == 2 and not self.training and self.m.winograd_fuse_groupnorm and film
+                   and not isinstance(rb.skip_connection, nn.Conv2d)
+                   and self._winograd_ok(rb.in_layers[2], 2 * x.H, 2 * x.W, x.C)
+                   and self._winograd_ok(rb.out_layers[3], 2 * x.H, 2 * x.W, rb.out_channels))
         if rs == 0:
             a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A", consumer=rb.in_layers[2])
+        elif fold_up:
+            a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A", consumer=rb.in_layers[2], upsample=True)
         else:       # up / down blocks resample between the activation and the conv: explicit apply pass
             a, pre1 = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A"), None
-        xr = x if rs == 0 else self._gn_apply(x, None, None, 0, rs, name="XR")
-        h1 = self._tmp("H1", N, a.H, a.W, rb.out_channels)
-        if film:
+        xr = x if (rs == 0 or fold_up) else self._gn_apply(x, None, None, 0, rs, name="XR")
+        oh, ow = (2 * x.H, 2 * x.W) if fold_up else (a.H, a.W)
+        h1 = self._tmp("H1", N, oh, ow, rb.out_channels)
+        if fold_up:
+            self._emit_conv(a, rb.in_layers[2], None, h1, pre=pre1, upsample=True)
+        elif film:
             self._emit_conv(a, rb.in_layers[2], None, h1, pre=pre1)
         else:       # h = h + emb_out[..., None, None] (openaimodel.py:275): per-image row added in the conv epilogue
             self._emit_conv(a, rb.in_layers[2], _TensorRef(self.film, 4 * self.film_off[id(rb)]), h1,
@@ -1130,10 +1147,12 @@ class _Plan:
         s2 = self._gn_count
         a2, pre2 = self._gn_input(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, name="A2",
                                   consumer=rb.out_layers[3])
-        out = dest if dest is not None else self._new(N, a.H, a.W, rb.out_channels)
+        out = dest if dest is not None else self._new(N, oh, ow, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
             self._emit_conv(xr, rb.skip_connection, None, out)
             self._emit_conv(a2, rb.out_layers[3], out, out, pre=pre2)
+        elif fold_up:
+            self._emit_conv(a2, rb.out_layers[3], xr, out, pre=pre2, flags=4)        # residual = x at half resolution
         else:
             self._emit_conv(a2, rb.out_layers[3], xr, out, pre=pre2)
         if self.training:

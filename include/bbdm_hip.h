@@ -60,6 +60,8 @@ int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int 
  * None] of the use_scale_shift_norm=False ResBlock, openaimodel.py:275).  Implicit GEMM on v_mfma_f32_32x32x2_f32. */
 #define BBDM_CONV_OUT_NCHW 1
 #define BBDM_CONV_RES_PER_IMAGE 2
+#define BBDM_CONV_RES_UPSAMPLE 4   /* Winograd output transform only: residual is [N][H/2][W/2][ldr], added nearest-upsampled x2 (the
+                                      skip path x_upd(x) of an up-sampling ResBlock, openaimodel.py:259-264) */
 /* ws (may be NULL) / ws_floats: scratch for split-K.  When the output tiles alone cannot fill the 256 CUs (small
  * latents: LBBDM-f16 runs the 1024-channel layers on 4x4 images) the Cin reduction is spread over extra workgroups
  * whose partial sums are added in a fixed order by a second kernel (deterministic).  Size it with
@@ -116,7 +118,7 @@ int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packe
  *           [-> SiLU] producer as bbdm_conv2d_nhwc_f32.  upsample != 0: x is [N, H/2, W/2, ldx] and the convolved tensor
  *           is its nearest x2 upsampling (Upsample.forward, openaimodel.py:111-121) -- never materialised.
  *   gemm  : M[xi] = V[xi] . U[xi] for the (m+2)^2 transform points, one launch.
- *   output: M[(m+2)^2][tiles][Cout] -> out NHWC (+ bias, + residual; flags: BBDM_CONV_RES_PER_IMAGE). */
+ *   output: M[(m+2)^2][tiles][Cout] -> out NHWC (+ bias, + residual; flags: BBDM_CONV_RES_PER_IMAGE or BBDM_CONV_RES_UPSAMPLE). */
 size_t bbdm_winograd_tiles(int m, int N, int H, int W);
 int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale, const float* pre_bias,
                             int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);

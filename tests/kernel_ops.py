@@ -142,8 +142,9 @@ def pack_winograd_weight(w: torch.Tensor, in_pad: Optional[int] = None, dgrad: b
 
 def conv3x3_winograd(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
                      residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                     res_per_image: bool = False, m: int = 2) -> torch.Tensor:
-    """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [N, H, W, CinPad] -> [N, H, W, cout]."""
+                     res_per_image: bool = False, m: int = 2, res_upsample: bool = False) -> torch.Tensor:
+    """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [N, H, W, CinPad] -> [N, H, W, cout].
+    ``res_upsample``: the residual is [N, H/2, W/2, cout] and is added nearest-upsampled x2 (BBDM_CONV_RES_UPSAMPLE)."""
     _chk(x, packed_w, bias, residual, out)
     N, H, W, cin_pad = x.shape
     if out is None:
@@ -152,8 +153,8 @@ def conv3x3_winograd(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[tor
     ws = torch.empty(max(1, nws), dtype=torch.float32, device=x.device)
     _lib.call("bbdm_conv3x3_winograd_f32", m, x.data_ptr(), cin_pad, packed_w.data_ptr(),
               None if bias is None else bias.data_ptr(), None if residual is None else residual.data_ptr(),
-              0 if residual is None else residual.shape[-1], out.data_ptr(), out.shape[-1], 2 if res_per_image else 0,
-              ws.data_ptr(), N, H, W, cin_pad, cout, _st(x))
+              0 if residual is None else residual.shape[-1], out.data_ptr(), out.shape[-1],
+              2 if res_per_image else (4 if res_upsample else 0), ws.data_ptr(), N, H, W, cin_pad, cout, _st(x))
     return out
 
 

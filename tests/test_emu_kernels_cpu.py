@@ -58,6 +58,11 @@ def test_gemm_bf3p_matches_bf3_bitwise(batch, T, Cin, Cout, extra):
     K.test_gemm_bf3p_matches_bf3_bitwise(CPU, batch, T, Cin, Cout, extra)
 
 
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8)])
+def test_winograd_output_adds_upsampled_residual(m, N, H, W, Cin, Cout):
+    K.test_winograd_output_adds_upsampled_residual(CPU, m, N, H, W, Cin, Cout)
+
+
 @pytest.mark.parametrize("kernel", [0, 3, 4, 5])
 @pytest.mark.parametrize("batch,T,Cin,Cout", [(1, 256, 16, 256), (1, 256, 32, 256), (8, 256, 80, 260), (2, 512, 64, 256),
                                               (1, 768, 48, 128)])

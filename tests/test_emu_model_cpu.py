@@ -143,6 +143,40 @@ def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
     assert rel_err(outs[True], ref) < M.STEP_TOL
 
 
+def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):
+    """resblock_updown: an up-sampling ResBlock of an inference plan emits NO resampling pass -- GroupNorm -> SiLU -> nearest x2 is the
+    index shift of the first conv's Winograd input transform and x_upd(x) the out conv's residual read at [h/2][w/2]
+    (BBDM_CONV_RES_UPSAMPLE) -- and computes what the explicit passes compute (openaimodel.py:259-264), which is what the oracle does."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
+                        lambda N, H, W, cin, cout, max_m=6: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+    up = dict(image_size=8, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 47)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(16, 4, 8, 8, generator=g)
+    t = torch.arange(16) * 11 + 3
+    outs = {}
+    for fold in (True, False):
+        m.winograd_fuse_groupnorm = fold
+        with torch.no_grad():
+            outs[fold] = m(x, timesteps=t, context=None).clone()
+        plan = m._plan_for(x, False)
+        resamplers = [a for n, a in plan.ops if str(n) == "bbdm_groupnorm_apply_f32" and a[-1] == 2]
+        up_reads = [a for n, a in plan.ops if str(n) == "bbdm_winograd_output_f32" and a[7] == 4]
+        assert (len(resamplers) == 0 and len(up_reads) == 1) if fold else (len(resamplers) == 2 and not up_reads)
+    assert rel_err(outs[True], outs[False]) < 2e-5
+    ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
+    assert rel_err(outs[True], ref) < M.STEP_TOL
+
+
 def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     """Training plan of a UNet with enough tiles (16 images of 16x16 = 256 4x4 tiles, 64 channels) for the 3x3 layers' weight
     gradients to take the Winograd-domain path (csrc/winograd_wgrad.hip), with the 1x1 skip convolutions (forward and data

@@ -291,6 +291,23 @@ def test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, extra):
         assert torch.equal(M, M0), (M - M0).abs().max()
 
 
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72)])
+def test_winograd_output_adds_upsampled_residual(dev, m, N, H, W, Cin, Cout):
+    """BBDM_CONV_RES_UPSAMPLE: the output transform adds a residual given at half the resolution, nearest-upsampled x2 -- the
+    skip path x_upd(x) of an up-sampling ResBlock (openaimodel.py:259-264) without a resampling pass."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(m + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + F.interpolate(r.double(), scale_factor=2, mode="nearest")
+    pw = ops.pack_winograd_weight(w.to(dev), m=m)
+    out = ops.conv3x3_winograd(_nhwc(x).to(dev), pw, b.to(dev), Cout, residual=_nhwc(r).to(dev), m=m, res_upsample=True)
+    torch.cuda.synchronize()
+    assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL[m]
+
+
 @pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 3, 16, 24, 64, 96), (6, 1, 1, 2, 20, 12, 32, 136),
                                                       (4, 0, 1, 3, 16, 24, 64, 96), (4, 1, 0, 1, 8, 8, 16, 8),
                                                       (2, 1, 1, 3, 16, 24, 64, 96), (6, 0, 0, 5, 7, 9, 48, 260)])

@@ -228,6 +228,24 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(hipemu_bf16x8 a, hipem
     hipemu::wave_release();
     return d;
 }
+// ds_read_b64_tr_b16 (the LDS transpose read): every lane reads the 8-byte word (4 x 16 bit) at ITS address; inside each 16-lane
+// group lane i receives element (i & 3) of the words of lanes 4 j + (i >> 2), j = 0..3 -- i.e. when the group's words form a
+// row-major [4][16] matrix (lanes 0-3 row 0, lanes 4-7 row 1, ...), lane i gets column i (cdna_hip_programming.md, LDS section).
+typedef short hipemu_v4s __attribute__((ext_vector_type(4)));
+static inline hipemu_v4s hipemu_ds_read_tr16_b64(const void* p) {
+    struct W { short e[4]; } mine;
+    memcpy(&mine, p, 8);
+    const void* const* all = hipemu::wave_publish(&mine);
+    const int l = hipemu::g_lane, grp = l & ~15, i = l & 15;
+    hipemu_v4s r;
+    for (int j = 0; j < 4; ++j) {
+        const W* w = static_cast<const W*>(all[grp + 4 * j + (i >> 2)]);
+        r[j] = w ? w->e[i & 3] : (short)0x7fc0;
+    }
+    hipemu::wave_release();
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
