@@ -10,8 +10,9 @@
 // The tensors stay where torch put them (leaf nn.Parameters, .grad views of the backward plan's flat buffer or DDP bucket
 // views): the table holds raw pointers, so no flattening / re-pointing of parameters is needed.
 //
-// Arithmetic follows torch.optim.Adam's single-tensor path operation by operation (this file is built with
-// -ffp-contract=off, like bridge.hip):
+// Arithmetic follows the single-tensor path of torch.optim.Adam in torch >= 2.0 operation by operation (this file is built with
+// -ffp-contract=off, like bridge.hip) -- the torch the tests compare with.  The reference's torch 1.12 updates the first moment as
+// exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1): the same value up to one fp32 rounding per step, not bit for bit.
 //     g' = g + wd * p                                  (weight_decay != 0)
 //     m  = lerp(m, g', 1 - b1)                         (exp_avg.lerp_(grad, 1 - beta1); at::lerp's two-branch formula)
 //     v  = v * b2 + (1 - b2) * g' * g'                 (exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2))

@@ -9,6 +9,8 @@ bytes are identical), copied to pinned host memory with ONE asynchronous D2H cop
 threads (zlib releases the GIL) while the next batch is being sampled.
 
 * :func:`save_single_image` -- drop-in for ``runners.utils.save_single_image`` (same signature, identical file).
+* :func:`get_image_grid`    -- drop-in for ``runners.utils.get_image_grid`` (``runners/utils.py:77-84``): the grid image the
+  runner logs after every validation step (``BBDMRunner.py:205-222``), same bytes, without torchvision.
 * :func:`batch_to_uint8`    -- [N, C, H, W] fp32 on the GPU -> [N, H, W, C] uint8 host tensor (pinned).
 * :class:`ImageWriter`      -- ``submit(batch, directory, names, to_normal)`` returns at once; ``close()`` joins.
 No CPU fallback: the tensor must live on the GPU (the files themselves are written by PIL, as in the reference).
@@ -23,7 +25,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["batch_to_uint8", "save_single_image", "save_batch", "ImageWriter"]
+__all__ = ["batch_to_uint8", "save_single_image", "save_batch", "get_image_grid", "ImageWriter"]
 
 
 def _to_u8_device(batch: torch.Tensor, to_normal: bool) -> torch.Tensor:
@@ -78,6 +80,32 @@ def save_batch(batch, save_path, file_names: Sequence[str], to_normal=True):
     host = batch_to_uint8(batch, to_normal)
     for i, name in enumerate(file_names):
         _write_png(host[i], os.path.join(save_path, name))
+
+
+@torch.no_grad()
+def get_image_grid(batch, grid_size=4, to_normal=True):
+    """runners/utils.py:77-84, same signature and result: ``torchvision.utils.make_grid(batch, nrow=grid_size)`` (2-pixel zero
+    padding around every image, single-channel batches repeated to 3 channels, a single image returned as is) followed by the
+    [-1, 1] -> uint8 conversion, as a numpy array [H', W', C].  The conversion runs once over the batch on the GPU (the same fp32
+    arithmetic step by step); the grid is assembled from the bytes on the host -- a padding pixel, value 0 before the conversion,
+    becomes 0 * 0.5 + 0.5 -> 128 (``to_normal``) or 0."""
+    import numpy as np
+    if batch.dim() != 4:
+        raise ValueError(f"expected [N, C, H, W], got {tuple(batch.shape)}")
+    if batch.shape[1] == 1:
+        batch = batch.expand(-1, 3, -1, -1)
+    px = batch_to_uint8(batch, to_normal).numpy()                    # [N, H, W, C]
+    n, h, w, c = px.shape
+    if n == 1:
+        return px[0].copy()
+    pad = 2
+    xmaps = min(int(grid_size), n)
+    ymaps = -(-n // xmaps)
+    grid = np.full((ymaps * (h + pad) + pad, xmaps * (w + pad) + pad, c), 128 if to_normal else 0, dtype=np.uint8)
+    for k in range(n):
+        y, x = divmod(k, xmaps)
+        grid[y * (h + pad) + pad: y * (h + pad) + pad + h, x * (w + pad) + pad: x * (w + pad) + pad + w] = px[k]
+    return grid
 
 
 class ImageWriter:

@@ -236,7 +236,15 @@ class VQModel(nn.Module):
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
         # GAN / perceptual-loss weights of a VQGAN training checkpoint are not part of the frozen first stage
         sd = {k: v for k, v in sd.items() if not k.startswith("loss.")}
-        self.load_state_dict(sd, strict=True)        # a half-loaded first stage would sample garbage silently
+        # like the reference (vqgan.py:66-75: strict=False): extra keys of a training checkpoint (model_ema.*, a colorize buffer)
+        # are ignored with a note -- but a MISSING key would leave part of the first stage at its random initialisation and sample
+        # garbage silently, so that raises
+        missing, unexpected = self.load_state_dict(sd, strict=False)
+        if missing:
+            raise RuntimeError(f"{path}: first-stage weights missing from the checkpoint: {sorted(missing)[:8]} ...")
+        if unexpected:
+            print(f"{path}: ignored {len(unexpected)} checkpoint entries that are not part of the first stage "
+                  f"({sorted(unexpected)[:4]} ...)")
         print(f"Restored from {path}")
 
     def encode(self, x):

@@ -222,7 +222,11 @@ class BrownianBridgeModel(nn.Module):
             raise IndexError(f"timestep {max(step, nxt)} is out of range for the {self.num_timesteps}-entry schedule")
         x_t, y = _f32c(x_t), _f32c(y)
         t = torch.full((x_t.shape[0],), step, device=x_t.device, dtype=torch.long)
-        objective_recon = self.denoise_fn(x_t, timesteps=t, context=context)
+        fn = self.denoise_fn
+        if isinstance(fn, UNetModel):       # the prediction is consumed by the fused kernel below at once: no per-step copy of it
+            objective_recon = fn.infer(x_t, t, context, borrow=True)
+        else:
+            objective_recon = fn(x_t, timesteps=t, context=context)
         is_last = step == 0
         noise = None if is_last else torch.randn_like(x_t)
         x_next, x0_recon = torch.empty_like(x_t), torch.empty_like(x_t)
@@ -272,9 +276,12 @@ class LatentBrownianBridgeModel(BrownianBridgeModel):
 
     Only the wrapper API lives here (constructor, ``forward``, ``encode``/``decode``, ``sample``, the externally
     assigned ``ori_latent_mean/std`` and ``cond_latent_mean/std`` attributes -- BBDMRunner.py:41-44).  The first stage
-    is any module exposing ``encoder / quant_conv / quantize / decode``: by default ``bbdm_amd.first_stage.VQModel``
-    built from ``model_config.VQGAN.params`` (plain PyTorch-ROCm, loads the reference's VQGAN checkpoints), or whatever
-    is passed as ``vqgan=`` (e.g. the checkout's own ``model.VQGAN.vqgan.VQModel``).
+    is any module exposing ``encoder / quant_conv / quantize / decode``: by default ``bbdm_amd.first_stage_hip.VQModel``
+    built from ``model_config.VQGAN.params`` (encode / decode on the HIP kernels for GPU tensors; loads the reference's VQGAN
+    checkpoints), or whatever is passed as ``vqgan=`` (e.g. the checkout's own ``model.VQGAN.vqgan.VQModel``).  The first stage
+    is the ONE place with a PyTorch branch: a foreign ``vqgan`` without ``encode_latent`` / ``decode_latent``, or CPU tensors, go
+    through the module's own PyTorch ``encoder`` / ``quantize`` / ``decode`` (north_star leaves the VQGAN on PyTorch-ROCm); the UNet
+    and the bridge have none.
     """
 
     def __init__(self, model_config, vqgan: nn.Module = None):

@@ -99,8 +99,13 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
             kinds: Dict[tuple, list] = {}        # (device, step count) -> rows; normally ONE kind = one launch
-            for p in group["params"]:
+            no_grad_rows = []                    # parameters without a gradient: no Adam update (as torch) -- but EMA.update covers
+            for p in group["params"]:           # EVERY registered parameter (EMA.py:21-29), so the fused pass does too
                 if p.grad is None:
+                    shadow = ema._shadow_of(p) if ema is not None else None
+                    if shadow is not None:
+                        _check_param(p)
+                        no_grad_rows.append((p, None, None, None, shadow))
                     continue
                 _check_param(p)
                 g = p.grad
@@ -117,6 +122,12 @@ class FusedAdam(torch.optim.Optimizer):
                 shadow = ema._shadow_of(p) if ema is not None else None
                 kinds.setdefault((p.device, int(st["step"])), []).append((p, g, st["exp_avg"], st["exp_avg_sq"], shadow))
             mode = 0 if ema is None else (1 if ema_with_decay else 2)
+            by_dev: Dict[torch.device, list] = {}
+            for r in no_grad_rows:
+                by_dev.setdefault(r[0].device, []).append(r)
+            for device, rows in by_dev.items():
+                table, n = self._tables.setdefault((gi, device, "ema-only"), _ChunkTable()).get(rows, device)
+                _launch(device, table, n, False, None, 0, mode, ema.ema_decay)
             for (device, step_no), rows in kinds.items():
                 table, n = self._tables.setdefault((gi, device, len(kinds) > 1 and step_no), _ChunkTable()).get(rows, device)
                 _launch(device, table, n, True, group, step_no, mode, ema.ema_decay if ema is not None else 0.0)

@@ -636,11 +636,13 @@ class UNetModel(nn.Module):
         return x, ctx
 
     @torch.no_grad()
-    def infer(self, x, timesteps, context=None, out: Optional[torch.Tensor] = None):
+    def infer(self, x, timesteps, context=None, out: Optional[torch.Tensor] = None, borrow: bool = False):
+        """``borrow``: return the plan's own output buffer instead of a copy -- valid only until the next call with this input
+        shape; for callers that consume it at once (BrownianBridgeModel.p_sample feeds it to the fused bridge kernel)."""
         x, ctx = self._check_inputs(x, context)
         plan = self._plan_for(x, training=False)
         t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
-        return plan.run(x, t, ctx, out)
+        return plan.run(x, t, ctx, out, borrow)
 
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
@@ -1884,11 +1886,11 @@ class _Plan:
             return bool(pref)
         return not self.training and self.N * self.H * self.W <= 32 * 64 * 64
 
-    def run(self, x, t, ctx, out=None):
+    def run(self, x, t, ctx, out=None, borrow=False):
         with _lib.device_guard(self.device):        # NULL-stream launches follow the current device (see _lib.device_guard)
-            return self._run(x, t, ctx, out)
+            return self._run(x, t, ctx, out, borrow)
 
-    def _run(self, x, t, ctx, out=None):
+    def _run(self, x, t, ctx, out=None, borrow=False):
         m = self.m
         self.generation = getattr(self, "generation", 0) + 1
         stream = _lib.current_stream(self.device)
@@ -1912,6 +1914,6 @@ class _Plan:
         else:
             self._launch_forward(stream, prof)
         if out is None:
-            return self.out_nchw.clone()
+            return self.out_nchw if borrow else self.out_nchw.clone()
         out.copy_(self.out_nchw)
         return out

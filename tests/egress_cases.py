@@ -59,3 +59,47 @@ def files_byte_identical(dev, tmp_path):
     sha = lambda p: hashlib.sha256(open(p, "rb").read()).hexdigest()
     for n in names:
         assert sha(ref_dir / n) == sha(out_dir / n) == sha(out2 / n), n
+
+
+def make_grid_reference(tensor, nrow=8, padding=2, pad_value=0.0):
+    """torchvision.utils.make_grid (the call of runners/utils.py:79; torchvision is not installed here), restated from its source:
+    single-channel batches repeated to 3 channels, one image returned as is, otherwise images copied into a pad_value canvas."""
+    import math
+    if tensor.dim() == 4 and tensor.size(1) == 1:
+        tensor = torch.cat((tensor, tensor, tensor), 1)
+    if tensor.size(0) == 1:
+        return tensor.squeeze(0)
+    nmaps = tensor.size(0)
+    xmaps = min(nrow, nmaps)
+    ymaps = int(math.ceil(float(nmaps) / xmaps))
+    height, width = int(tensor.size(2) + padding), int(tensor.size(3) + padding)
+    grid = tensor.new_full((tensor.size(1), height * ymaps + padding, width * xmaps + padding), pad_value)
+    k = 0
+    for y in range(ymaps):
+        for x in range(xmaps):
+            if k >= nmaps:
+                break
+            grid.narrow(1, y * height + padding, height - padding).narrow(2, x * width + padding, width - padding).copy_(tensor[k])
+            k += 1
+    return grid
+
+
+def reference_get_image_grid(batch, grid_size=4, to_normal=True):
+    """runners/utils.py:77-84 with make_grid restated above."""
+    batch = batch.detach().clone()
+    image_grid = make_grid_reference(batch, nrow=grid_size)
+    if to_normal:
+        image_grid = image_grid.mul_(0.5).add_(0.5).clamp_(0, 1.)
+    return image_grid.mul_(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to('cpu', torch.uint8).numpy()
+
+
+def image_grid_identical(dev):
+    import numpy as np
+    from bbdm_amd import egress
+    for N, C, H, W, gs, tn in ((5, 3, 20, 28, 4, True), (8, 3, 16, 16, 4, True), (3, 1, 9, 11, 2, True), (1, 3, 8, 8, 4, True),
+                               (6, 3, 12, 10, 4, False), (2, 3, 8, 8, 5, True)):
+        x = make_batch(N, C, H, W, seed=N + H)
+        got = egress.get_image_grid(x.to(dev), grid_size=gs, to_normal=tn)
+        ref = reference_get_image_grid(x, grid_size=gs, to_normal=tn)
+        assert isinstance(got, np.ndarray) and got.dtype == np.uint8 and got.shape == ref.shape, (got.shape, ref.shape)
+        assert np.array_equal(got, ref), (N, C, H, W, gs, tn)

@@ -65,3 +65,37 @@ def vq_indices_bit_exact(dev):
         same = int((idx.cpu() == ref).sum())
         assert same == z.shape[0], (e_dim, n_e, z.shape[0] - same)
         assert torch.equal(zq.cpu(), cb[ref])
+
+
+def golden_vq_f4(dev, hip: bool, tol=1e-3):
+    """tests/golden/vq_f4_small.pt = encode / code indices / decode of the REAL reference VQModel (oracle/make_golden_vq.py) at the
+    VQ-f4 geometry (ch 128, ch_mult (1, 2, 4), 8192 x 3 codebook, single-head 512-channel AttnBlock at the 16x16 level), 64x64
+    images.  ``hip``: bbdm_amd.first_stage_hip.VQModel on the HIP kernels, else the in-package PyTorch first stage."""
+    import os
+    from fixture_weights import synth_weights
+    rec = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vq_f4_small.pt"))
+    if hip:
+        from bbdm_amd.first_stage_hip import VQModel
+    else:
+        from bbdm_amd.first_stage import VQModel
+    m = VQModel(ddconfig=dict(rec["ddconfig"]), n_embed=rec["n_embed"], embed_dim=rec["embed_dim"]).eval()
+    sd = synth_weights(rec["shapes"], rec["weight_seed"])
+    sd["quantize.embedding.weight"] = rec["codebook"]
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev)
+    x, z_ref = rec["x"].to(dev), rec["z"]
+    with torch.no_grad():
+        if hip:
+            z = m.encode_latent(x, quant_conv=True)
+            img, idx = m.decode_latent(z_ref.to(dev), return_indices=True)          # the golden latent: indices must be bit-equal
+            _, idx_tie = m.decode_latent(rec["z_tie"].to(dev), return_indices=True)
+        else:
+            z = m.quant_conv(m.encoder(x))
+            zq, _, (_, _, idx) = m.quantize(z_ref.to(dev))
+            img = m.decode(zq)
+            _, _, (_, _, idx_tie) = m.quantize(rec["z_tie"].to(dev))
+    e_z, e_img = rel_err(z.cpu(), z_ref), rel_err(img.cpu(), rec["img"])
+    print(f"VQ-f4 golden ({'HIP' if hip else 'PyTorch'} first stage): encode rel err {e_z:.2e}, decode rel err {e_img:.2e}")
+    assert e_z < tol and e_img < tol
+    assert torch.equal(idx.cpu().reshape(-1), rec["indices"])
+    assert torch.equal(idx_tie.cpu().reshape(-1), rec["indices_tie"])          # near ties: the reference's term order, bit for bit

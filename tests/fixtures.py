@@ -8,7 +8,8 @@ import bbdm_oracle as O                            # oracle/
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ("tiny_concat", "tiny_nocond", "tiny_ysubx")
-# + SpatialTransformer / cross-attention conditioning: sampling path only (no backward yet)
+# + SpatialTransformer / cross-attention conditioning: sampling, and -- by name -- the training tests
+# (gradients, accumulation, the two-rank DDP steps: its 3-channel context gives channel-padded to_k / to_v weight gradients)
 INFER_CASES = CASES + ("tiny_xattn",)
 
 

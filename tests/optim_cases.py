@@ -91,6 +91,8 @@ def ema_parity(dev):
         for pa, pb, pc in zip(a.parameters(), b.parameters(), c.parameters()):
             gr = torch.randn(pa.shape, generator=g).to(dev)
             pa.grad, pb.grad, pc.grad = gr.clone(), gr.clone(), gr.clone()
+        if it == 3:                                   # a parameter without a gradient: no Adam update, but EMA.update covers EVERY
+            a[2].bias.grad = b[2].bias.grad = c[2].bias.grad = None      # registered parameter (EMA.py:21-29) -- the fused pass too
         decay = it >= 2                               # with_decay=False before start_ema_step (BaseRunner.py:174)
         oa.step(); ea.update(a, with_decay=decay)     # the unmodified runner's order: step, then EMA.update
         ob.step(); eb.update(b, with_decay=decay)

@@ -21,3 +21,7 @@ def test_uint8_pixels_are_bit_exact(to_normal):
 
 def test_png_files_are_byte_identical(tmp_path):
     C.files_byte_identical(CPU, tmp_path)
+
+
+def test_image_grid_is_identical_to_the_reference():
+    C.image_grid_identical(CPU)

@@ -23,6 +23,11 @@ def test_png_files_are_byte_identical(dev, tmp_path):
     C.files_byte_identical(dev, tmp_path)
 
 
+def test_image_grid_is_identical_to_the_reference(dev):
+    """get_image_grid (runners/utils.py:77-84, used at BBDMRunner.py:205-222): same array as make_grid + the uint8 conversion."""
+    C.image_grid_identical(dev)
+
+
 def test_batch16_256x256_rate(dev):
     from bbdm_amd import egress
     x = torch.randn(16, 3, 256, 256, device=dev).clamp(-1, 1)

@@ -21,6 +21,11 @@ def test_vq_indices_bit_exact(dev):
     C.vq_indices_bit_exact(dev)
 
 
+def test_golden_of_the_real_reference_vqmodel(dev):
+    """Encode / indices / decode against outputs of the reference's own VQModel (tests/golden/vq_f4_small.pt)."""
+    C.golden_vq_f4(dev, hip=True)
+
+
 def test_encode_decode_match_the_pytorch_first_stage(dev):
     C.encode_decode_parity(dev, N=3)
 

@@ -92,8 +92,8 @@ def test_latent_wrapper_sample_and_train(normalize):
 
 
 def test_latent_with_builtin_first_stage():
-    """No ``vqgan=``: the first stage is built from ``model_config.VQGAN.params`` by bbdm_amd.first_stage.VQModel
-    (same schema as configs/Template-LBBDM-f4.yaml, shrunk)."""
+    """No ``vqgan=``: the first stage is built from ``model_config.VQGAN.params`` by bbdm_amd.first_stage_hip.VQModel -- encode / decode
+    on the HIP kernels (same schema as configs/Template-LBBDM-f4.yaml, shrunk)."""
     import bbdm_amd
     dev = torch.device("cuda:0")
     rec = load_case("tiny_nocond")
