@@ -45,6 +45,7 @@ class _Flags:
         self.winograd = int(os.environ.get("BBDM_WINOGRAD", "6"))
         self.winograd_fuse_groupnorm = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
         self.gemm_bf3 = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
+        self.gemm_bf3p = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
         self.fuse_groupnorm = False
         self.fuse_stats = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
         self.bf3_min_tiles = 256
@@ -246,7 +247,7 @@ class VQModel(FS.VQModel):
 
     def _plan(self, kind, x, quant_conv) -> _FSPlan:
         N, _, H, W = x.shape
-        key = (kind, N, H, W, x.device.index, bool(quant_conv), self._flags.winograd, self._flags.gemm_bf3)
+        key = (kind, N, H, W, x.device.index, bool(quant_conv), self._flags.winograd, self._flags.gemm_bf3, self._flags.gemm_bf3p)
         p = self._fs_plans.get(key)
         if p is None:
             if len(self._fs_plans) >= 4:           # a training loop alternates 2 encode shapes + 1 decode shape at most
