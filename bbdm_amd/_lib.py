@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -98,6 +98,13 @@ SIGNATURES = {
     "bbdm_gemm_bf3p_f32": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_winograd_input_bf3p_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_gemm_bf3p_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_winograd_input_bf3p_tr_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "bbdm_winograd_dy_transform_bf3p_f32": (c_int, [c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_gemm_bf3p_tn_at_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
+    "bbdm_gemm_bf3p_tn_bt_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
+    "bbdm_gemm_bf3p_tn_supported": (c_int, [ctypes.c_longlong, c_int, c_int]),
+    "bbdm_gemm_bf3p_tn_splits": (c_int, [c_int, ctypes.c_longlong, c_int, c_int]),
+    "bbdm_gemm_bf3p_tn_f32": (c_int, [_P, _P, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_images_to_u8_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_opt_chunk_elems": (c_int, []),
     "bbdm_adam_ema_step_f32": (c_int, [_P, c_int, c_int, c_double, c_double, c_double, c_double, c_double,

@@ -40,6 +40,7 @@ struct Bf3pArgs {
     size_t az, bz, mz, rz;   // per-batch strides: bytes, bytes, floats (M), floats (residual)
     int T, Cout, nchunks, tilesN;
     int tiles, batch, by_batch;
+    int ksplits, kps, P;     // split-K (pipe kernel): batch index = z * P + entry; split z walks chunks [z kps, (z+1) kps) of nchunks
     int ldo, ldr;
     const float* bias;       // [Cout] or null
     const float* res;        // [T][ldr] or null; may alias M
@@ -240,8 +241,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
     const int row0 = m_tile * BM, cout0 = n_tile * BN;
     const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
     const int rg_last = a.T / 32 - 1;                                          // a ragged last row tile (T % BM != 0) re-reads the last
-    const unsigned char* A = a.A + (size_t)bz * a.az;                          // row group instead of running past the buffer; its
-    const unsigned char* B = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride;     // rows are not stored
+    // split-K (the weight-gradient GEMMs: few output tiles, long contraction): entry = bz % P, split z = bz / P
+    const int zs = a.ksplits > 1 ? bz / a.P : 0, ent = a.ksplits > 1 ? bz - zs * a.P : bz;
+    const size_t koff = (size_t)zs * a.kps * (3 * UNIT);
+    const unsigned char* A = a.A + (size_t)ent * a.az + koff;                  // row group instead of running past the buffer; its
+    const unsigned char* B = a.B + (size_t)ent * a.bz + koff + (size_t)n_tile * (WN * 2) * gstride;     // rows are not stored
     float* M = a.M + (size_t)bz * a.mz;
     const float* res = a.res + (size_t)bz * a.rz;
 
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][0], acc[1][0], 0, 0, 0);                          \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][1], acc[1][1], 0, 0, 0);                          \
     } while (0)
-    const int n = a.nchunks;
+    const int n = a.ksplits > 1 ? min(a.kps, a.nchunks - zs * a.kps) : a.nchunks;
     issue(0, smem);
     if (n > 1) issue(1, smem + STAGE);
     wait_vmcnt<0>();
@@ -517,6 +521,7 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
     a.tilesN = CoutPad / 128;
     a.az = (size_t)T * CinPad * 6; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo; a.rz = (size_t)T * ldr;
     a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    a.ksplits = 1; a.kps = a.nchunks; a.P = batch;
     static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
     a.batch = batch;
     a.by_batch = (by_batch_env && batch >= 8 && (batch % 8 == 0 || by_batch_env == 2)) ? 1 : 0;
@@ -532,5 +537,68 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p");
+    return BBDM_OK;
+}
+
+// ---- C = A^T B with the contraction over the ROWS of both operands (the Winograd-domain weight gradient dU_xi = V_xi^T dM_xi, tiles
+// contracted; replaces gemm_tn_f32 of winograd_wgrad.hip where its operands come as planes) ------------------------------------------
+// at_planes: [batch][M / 32][K / 16][3][1 KB] -- units whose rows are the M index and whose k is the contraction index, i.e. the
+// TRANSPOSED operands as bbdm_winograd_input_bf3p_tr_f32 / bbdm_winograd_dy_transform_bf3p_f32 write them; bt_planes likewise
+// [batch][NPad128 / 32][K / 16][3][1 KB].  It is the kernel above verbatim (rows = M, columns = N, chunks = K / 16) plus split-K:
+// C[z][b][M][N], z < bbdm_gemm_bf3p_tn_splits, partial sums over disjoint K ranges (added in a fixed order by the consumer:
+// bbdm_winograd_wgrad_finish_f32 -- deterministic).  K % 16 == 0 (zero-padded), M % 32 == 0, N % 4 == 0.
+namespace {
+struct TnSplit { int splits, kps; };
+TnSplit tn_split(int batch, long long K, int M, int N) {
+    const int nchunks = (int)(K / KC);
+    const int NPad = cdiv(N, 128) * 128;
+    const long long base = (long long)batch * cdiv(M, 256) * (NPad % 256 == 0 ? NPad / 256 : NPad / 128);
+    long long splits = (512 + base - 1) / base;                  // two workgroups' worth of tiles per CU when K allows
+    const long long max_splits = nchunks / 16 > 1 ? nchunks / 16 : 1;     // >= 16 chunks per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    TnSplit t;
+    t.kps = (int)((nchunks + splits - 1) / splits);
+    t.splits = (nchunks + t.kps - 1) / t.kps;
+    return t;
+}
+}  // namespace
+
+extern "C" size_t bbdm_gemm_bf3p_tn_at_bytes(int batch, long long K, int M) {
+    return (size_t)batch * (size_t)((M + 31) / 32 * 32) * (size_t)((K + 255) / 256 * 256) * 6;
+}
+extern "C" size_t bbdm_gemm_bf3p_tn_bt_bytes(int batch, long long K, int N) {
+    return (size_t)batch * (size_t)(cdiv(N, 128) * 128) * (size_t)((K + 255) / 256 * 256) * 6;
+}
+extern "C" int bbdm_gemm_bf3p_tn_supported(long long K, int M, int N) {
+    return K > 0 && K % 256 == 0 && K < (1ll << 31) && M > 0 && M % 32 == 0 && N > 0 && N % 4 == 0;
+}
+extern "C" int bbdm_gemm_bf3p_tn_splits(int batch, long long K, int M, int N) {
+    if (batch <= 0 || !bbdm_gemm_bf3p_tn_supported(K, M, N)) return 0;
+    return tn_split(batch, K, M, N).splits;
+}
+
+extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N,
+                                     void* stream) {
+    BBDM_REQUIRE(at_planes && bt_planes && C && batch > 0, "gemm_bf3p_tn: null pointer / bad batch");
+    BBDM_REQUIRE(bbdm_gemm_bf3p_tn_supported(K, M, N), "gemm_bf3p_tn: K=%lld M=%d N=%d unsupported (K %% 256, M %% 32, N %% 4)", K, M, N);
+    BBDM_REQUIRE((((uintptr_t)at_planes | (uintptr_t)bt_planes) & 15) == 0 && ((uintptr_t)C & 3) == 0, "gemm_bf3p_tn: alignment");
+    const TnSplit sp = tn_split(batch, K, M, N);
+    Bf3pArgs a;
+    a.A = (const unsigned char*)at_planes; a.B = (const unsigned char*)bt_planes; a.M = C;
+    a.T = M; a.Cout = N; a.nchunks = (int)(K / KC);
+    const int NPad = cdiv(N, 128) * 128;
+    a.tilesN = NPad / 128;
+    a.az = (size_t)((M + 31) / 32 * 32) * K * 6; a.bz = (size_t)NPad * K * 6; a.mz = (size_t)M * N; a.rz = 0;
+    a.ldo = N; a.ldr = 0; a.bias = nullptr; a.res = nullptr;
+    a.ksplits = sp.splits; a.kps = sp.kps; a.P = batch;
+    const int nb = batch * sp.splits;
+    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
+    a.batch = nb;
+    a.by_batch = (by_batch_env && nb >= 8) ? 1 : 0;              // (the pipe kernel returns early for the padding entries of a batch % 8 != 0)
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = NPad % 256 == 0 ? bf3p_launch<4, 4, 1, false>(a, nb, st) : bf3p_launch<4, 2, 1, false>(a, nb, st);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("gemm_bf3p_tn");
     return BBDM_OK;
 }

@@ -370,6 +370,50 @@ __global__ void __launch_bounds__(256) winograd_input_split_kernel(const float* 
     }
 }
 
+// The lanes of a wave hold, for AL transform points xi = (i, 0 .. AL-1) and the three bf16 planes, one dword each = the channel pair
+// 2 cp, 2 cp + 1 of tile tl (lane = tl * 8 + cp: 8 consecutive tiles x 16 channels).  Write them TRANSPOSED: per (xi, plane) the
+// [8 tiles][16 channels] block becomes [16 channels][8 tiles] -- 16-byte runs of 8 consecutive tiles per channel, 256 B contiguous --
+// inside the fragment unit (rows = channels c % 32, k = tiles t % 16) of the layout [c / 32][t / 16][3][1 KB].  The 2-byte transpose is the
+// LDS transpose read: the block is staged row-major ([tile][16 ch] = 32-B rows) in the wave's own scratch and a 16-lane group reads
+// it back with ds_read_b64_tr_b16 -- lane i of the group receives channel i, 4 tiles per read.  Four groups = four (xi, plane)
+// blocks per pass; AL / 2 transform points per round so that the scratch stays inside the wave's 8 x 64 x 8 B region.
+template <int AL>
+__device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][3], unsigned char* scratch, int lane, unsigned char* dst_xi0,
+                                                 size_t plane_t, int chunk, int tile0, int tchunks) {
+    typedef short v4s __attribute__((ext_vector_type(4)));
+    constexpr int HALF = AL / 2, COMBOS = 3 * HALF, PITCH = 256 + 64;       // bytes between blocks (+64: stagger the bank rows)
+    static_assert(COMBOS * PITCH <= AL * 64 * 8, "transposition scratch exceeds the wave's LDS region");
+    const int grp = lane >> 4, i16 = lane & 15;
+    const int c = chunk * KC + i16;                                           // this lane's channel in the transposed store
+    // unit (c / 32, t / 16), k-half (t % 16) / 8, row c % 32
+    unsigned char* dst = dst_xi0 + (((size_t)(c >> 5) * tchunks + (tile0 >> 4)) * 3) * 1024 + ((tile0 >> 3) & 1) * 512 + (c & 31) * 16;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        // (the wave runs in lockstep: every lane has read its row of the intermediate / the previous round's blocks before this
+        // store instruction issues; the wave barrier only pins that order for the compiler -- and for the CPU emulation's fibers)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < HALF; ++q)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<unsigned*>(scratch + (q * 3 + p) * PITCH + lane * 4) = pl[round * HALF + q][p];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < (COMBOS + 3) / 4; ++it) {
+            const int combo = it * 4 + grp;
+            const int cc = combo < COMBOS ? combo : COMBOS - 1;       // (every lane reads: no divergence around the cross-lane read)
+            const unsigned char* a = scratch + cc * PITCH + (i16 >> 2) * 32 + (i16 & 3) * 8;
+            const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a));
+            const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 4 * 32));
+            typedef short v8s __attribute__((ext_vector_type(8)));
+            const v8s both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const int q = cc / 3, p = cc - 3 * q;
+            if (combo < COMBOS)
+                *reinterpret_cast<uint4*>(dst + (size_t)(round * HALF + q) * plane_t + p * 1024) = __builtin_bit_cast(uint4, both);
+        }
+    }
+}
+
 // ---- (1'') the same transform in two phases through LDS: (m+2) waves per workgroup, 8x the threads in flight -------------------------
 // The one-thread-per-(tile, channel pair) kernel above keeps the whole (m+2)^2 window of its pair in registers: 174 VGPRs at m = 6,
 // two waves per SIMD -- and its ablation (tools/wino_variants.py: loads alone 0.145 ms, stores alone 0.159 ms, together 0.258 ms at
@@ -381,12 +425,17 @@ __global__ void __launch_bounds__(256) winograd_input_split_kernel(const float* 
 //            (. B), splits each value into its three bf16 planes and stores them -- per plane and transform point the wave writes
 //            8 rows x 16 B of the fragment unit twice = two full 128-B lines, as above.
 // ~60 VGPRs and 32 KB of LDS per workgroup: 4 workgroups = 32 waves per CU.
-template <int MO, bool PRE, bool UP>
+// TR (training forward of a layer whose weight gradient is taken in the Winograd domain): the planes are ALSO written transposed,
+// Vt[xi][ci / 32][tile / 16][3][1 KB unit: rows = 32 channels, k = 16 tiles] -- the A operand of dU_xi = V_xi^T dM_xi as the SAME
+// gemm_bf3p kernel takes it (rows = ci, contraction over the tiles): see store_transposed().
+template <int MO, bool PRE, bool UP, bool TR>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
                                                                               unsigned char* __restrict__ Vp,
                                                                               const float* __restrict__ sc, const float* __restrict__ bi,
                                                                               int pre_ld, int pre_silu, int N, int H, int W, int nchunks,
-                                                                              long long T, int TG, size_t plane) {
+                                                                              long long T, int TG, size_t plane,
+                                                                              unsigned char* __restrict__ Vt, size_t plane_t,
+                                                                              int tchunks) {
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
     const int L = (int)blockIdx.x, q = L >> 3;
@@ -450,15 +499,79 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
         const int g = (int)(tile >> 5), rl = (int)(tile & 31);
         // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
         unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
+        unsigned pl[AL][3];
 #pragma unroll
         for (int jj = 0; jj < AL; ++jj) {
-            unsigned p1, p2, p3;
-            split2(row[jj].x, row[jj].y, p1, p2, p3);
-            *reinterpret_cast<unsigned*>(o) = p1;
-            *reinterpret_cast<unsigned*>(o + 1024) = p2;
-            *reinterpret_cast<unsigned*>(o + 2048) = p3;
+            split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
+            *reinterpret_cast<unsigned*>(o) = pl[jj][0];
+            *reinterpret_cast<unsigned*>(o + 1024) = pl[jj][1];
+            *reinterpret_cast<unsigned*>(o + 2048) = pl[jj][2];
             o += plane;
         }
+        if (TR)     // row i of the intermediate has been consumed: its LDS region (this wave's alone from here on) is the scratch
+            store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane,
+                                 Vt + (size_t)(i * AL) * plane_t, plane_t, chunk, (int)(tile - tl), tchunks);
+    }
+}
+
+// ---- dM = A dY A^T for the Winograd-domain weight gradient, written as TRANSPOSED bf16 planes ----------------------------------
+// dMt[xi][co / 32][tile / 16][3][1 KB unit: rows = 32 output channels, k = 16 tiles] = the B operand of dU_xi = V_xi^T dM_xi on the
+// gemm_bf3p kernel (contraction over the tiles), in two phases through LDS like the input transform above: wave j < m transforms
+// column j of the m x m window of dY (A d), wave i < m + 2 row i (. A^T), splits, and stores through store_transposed().  The one
+// fp32 plane the bias gradient needs -- xi = (1, 1): row 1 of A is all ones, so it holds the tile sums of dY -- goes to dm11[tile][C].
+template <int MO>
+__global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const float* __restrict__ dy, int ld,
+                                                                          unsigned char* __restrict__ dMt, float* __restrict__ dm11,
+                                                                          int N, int H, int W, int C, int nchunks, long long T, int TG,
+                                                                          size_t plane_t, int tchunks) {
+    constexpr int AL = MO + 2;
+    __shared__ float2 lds[AL * AL * 64];                 // [i][j < m][unit] intermediates; later each wave's transposition scratch
+    const int L = (int)blockIdx.x, q = L >> 3;
+    const int chunk = q % nchunks, tg = (q / nchunks) * 8 + (L & 7);
+    if (tg >= TG) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const int tl = lane >> 3, cp = lane & 7;
+    const long long tile = (long long)tg * 8 + tl;
+    const int c = chunk * KC + cp * 2;
+    if (wave < MO) {
+        const int jj = wave;
+        float2 d[MO], col[AL];
+        if (tile < T && c < C) {
+            const int tw = (int)(tile % TW);
+            const long long r = tile / TW;
+            const int th = (int)(r % TH), n = (int)(r / TH);
+            const int w = MO * tw + jj;
+            const int wc = min(w, W - 1);
+            const float wmask = w < W ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < MO; ++i) {
+                const int hc = min(MO * th + i, H - 1);
+                d[i] = *reinterpret_cast<const float2*>(dy + ((size_t)(n * H + hc) * W + wc) * ld + c);
+            }
+#pragma unroll
+            for (int i = 0; i < MO; ++i) d[i] = ((MO * th + i < H) ? wmask : 0.f) * d[i];
+        } else {                                          // padded tiles / channels: zeros (they enter the contraction over the tiles)
+#pragma unroll
+            for (int i = 0; i < MO; ++i) d[i] = make_float2(0.f, 0.f);
+        }
+        a_transform<MO>(d, col);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) lds[(i * AL + jj) * 64 + lane] = col[i];
+    }
+    __syncthreads();
+    {
+        const int i = wave;
+        float2 t[MO], row[AL];
+#pragma unroll
+        for (int jj = 0; jj < MO; ++jj) t[jj] = lds[(i * AL + jj) * 64 + lane];
+        a_transform<MO>(t, row);
+        if (i == 1 && tile < T && c < C) *reinterpret_cast<float2*>(dm11 + (size_t)tile * C + c) = row[1];
+        unsigned pl[AL][3];
+#pragma unroll
+        for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
+        store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane, dMt + (size_t)(i * AL) * plane_t,
+                             plane_t, chunk, (int)(tile - tl), tchunks);
     }
 }
 
@@ -698,9 +811,8 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 // The input transform that writes the three bf16 planes of gemm_bf3p.hip (same arguments as bbdm_winograd_input_f32; Vp holds
 // bbdm_gemm_bf3p_a_bytes((m+2)^2, tiles, CinPad) bytes; CinPad a multiple of 16), and the tile GEMMs on them: b_planes =
 // bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
-extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale,
-                                            const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
-                                            int CinPad, void* stream) {
+static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
+                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
@@ -713,20 +825,24 @@ extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const int nchunks = CinPad / KC, RG = (int)(Tp / 32), TG = (int)(Tp / 8);
     const size_t plane = Tp * (size_t)CinPad * 6;                  // bytes of one transform point
+    const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * 6;       // ... of the transposed copy (whole 32-channel row groups)
+    BBDM_REQUIRE(!Vt || (!upsample && ((uintptr_t)Vt & 15) == 0), "winograd_input_bf3p: the transposed copy needs upsample = 0, 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
     // BBDM_WINO_INPUT_LDS=0: the one-thread-per-window kernel (A/B; see winograd_input_split2_kernel)
     static const int two_phase = [] { const char* e = getenv("BBDM_WINO_INPUT_LDS"); return e ? atoi(e) : 1; }();
-    if (two_phase) {
+    if (two_phase || Vt) {
         const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
         BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
         const dim3 g((unsigned)blocks);
-#define BBDM_WINO_INS2(MO, PRE, UP)                                                                                          \
-    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp,  \
-                       pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (long long)T, TG, plane)
+#define BBDM_WINO_INS2(MO, PRE, UP, TR)                                                                                      \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
+                       pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (long long)T, TG, plane, (unsigned char*)Vt,   \
+                       plane_t, (int)(Tp / 16))
 #define BBDM_WINO_INS2_M(MO)                                                                        \
     do {                                                                                            \
-        if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true); else BBDM_WINO_INS2(MO, true, false); }   \
-        else           { if (upsample) BBDM_WINO_INS2(MO, false, true); else BBDM_WINO_INS2(MO, false, false); } \
+        if (Vt) { if (pre_scale) BBDM_WINO_INS2(MO, true, false, true); else BBDM_WINO_INS2(MO, false, false, true); }   \
+        else if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true, false); else BBDM_WINO_INS2(MO, true, false, false); }   \
+        else           { if (upsample) BBDM_WINO_INS2(MO, false, true, false); else BBDM_WINO_INS2(MO, false, false, false); } \
     } while (0)
         if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else BBDM_WINO_INS2_M(6);
 #undef BBDM_WINO_INS2_M
@@ -750,6 +866,22 @@ extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void
 #undef BBDM_WINO_INS
     BBDM_CHECK_LAUNCH("winograd_input_bf3p");
     return BBDM_OK;
+}
+
+extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale,
+                                            const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
+                                            int CinPad, void* stream) {
+    return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream);
+}
+
+// ... and, for the training forward, ALSO the transposed planes Vt (bbdm_gemm_bf3p_tn_at_bytes((m+2)^2, tiles, CinPad) bytes): the A
+// operand of the Winograd-domain weight gradient dU_xi = V_xi^T dM_xi on the same bf16x3 GEMM (bbdm_gemm_bf3p_tn_f32).
+// (same argument order as bbdm_winograd_input_bf3p_f32, Vt appended; upsample must be 0)
+extern "C" int bbdm_winograd_input_bf3p_tr_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale,
+                                               const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
+                                               int CinPad, void* Vt, void* stream) {
+    BBDM_REQUIRE(Vt && !upsample, "winograd_input_bf3p_tr: null pointer / upsample != 0");
+    return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream);
 }
 
 extern "C" int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
@@ -830,6 +962,33 @@ extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const f
     if (rc == BBDM_OK) rc = bbdm_winograd_gemm_f32(m, V, packed_wino, M, N, H, W, CinPad, Cout, stream);
     if (rc == BBDM_OK) rc = bbdm_winograd_output_f32(m, M, bias, residual, ldr, out, ldo, flags, N, H, W, Cout, stream);
     return rc;
+}
+
+// dY [N,H,W,Cout] (pitch ld) -> dMt = the transposed bf16 planes of A dY A^T (bbdm_gemm_bf3p_tn_bt_bytes((m+2)^2, tiles, Cout) bytes)
+// and dm11 [tiles][Cout] fp32 = its plane (1, 1), whose column sums are the bias gradient.  Cout a multiple of 4; the channels up to
+// the next multiple of 32 (whole fragment units) are written as zeros.
+extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W,
+                                                   int Cout, void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(dy && dMt && dm11 && N > 0, "winograd_dy_bf3p: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    BBDM_REQUIRE(Cout > 0 && Cout % 2 == 0 && ld % 2 == 0 && ld >= Cout && ((uintptr_t)dy & 7) == 0 && ((uintptr_t)dMt & 15) == 0 &&
+                     ((uintptr_t)dm11 & 7) == 0, "winograd_dy_bf3p: Cout=%d ld=%d / alignment", Cout, ld);
+    const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
+    const int CoutPad = cdiv(Cout, 128) * 128;                   // the B operand of the GEMM: whole 128-column tiles
+    const int nchunks = CoutPad / KC, TG = (int)(Tp / 8);
+    const size_t plane_t = (size_t)CoutPad * Tp * 6;
+    const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
+    BBDM_REQUIRE(blocks < (1ll << 31), "winograd_dy_bf3p: too many workgroups");
+    const dim3 g((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+#define BBDM_WINO_DYS(MO)                                                                                                    \
+    hipLaunchKernelGGL((winograd_dy_split_kernel<MO>), g, dim3((MO + 2) * 64), 0, st, dy, ld, (unsigned char*)dMt, dm11, N, H, W, \
+                       Cout, nchunks, (long long)T, TG, plane_t, (int)(Tp / 16))
+    if (m == 2) BBDM_WINO_DYS(2); else if (m == 4) BBDM_WINO_DYS(4); else BBDM_WINO_DYS(6);
+#undef BBDM_WINO_DYS
+    BBDM_CHECK_LAUNCH("winograd_dy_bf3p");
+    return BBDM_OK;
 }
 
 // Test hook (exported, not part of the public header): the 1-D transforms above evaluated on the HOST, so that the CPU

@@ -1031,13 +1031,14 @@ class _Plan:
 
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
-        split while staged), "p" = csrc/gemm_bf3p.hip (V written pre-split by the input transform; not when the training
-        backward re-reads the fp32 V: ``keeps_V``)."""
+        split while staged), "p" = csrc/gemm_bf3p.hip (V written pre-split by the input transform; with ``keeps_V`` -- the training
+        backward contracts this layer's V again -- only where the weight-gradient GEMM takes the transposed planes too)."""
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
-        if self.m.gemm_bf3p and not keeps_V and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout):
-            return "p"
+        if self.m.gemm_bf3p and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout) and \
+                (not keeps_V or self.lib.bbdm_gemm_bf3p_tn_supported(tiles, cin_pad, cout)):
+            return "p"          # (keeps_V: the weight gradient then contracts the TRANSPOSED planes the input transform also writes)
         return bool(self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout))
 
     def _keeps_V(self, wm, H, W, cin_pad, cin, cout, upsample, bwd) -> bool:
@@ -1054,7 +1055,8 @@ class _Plan:
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
         self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
         vbuf = self._wino_v
-        if (not split and self._keeps_V(wm, H, W, cin_pad, pw.cin, cout, upsample, bwd)):
+        keeps = self._keeps_V(wm, H, W, cin_pad, pw.cin, cout, upsample, bwd)
+        if keeps and not split:
             # training: this layer's weight gradient contracts the SAME transformed input (csrc/winograd_wgrad.hip) -- keep V
             # in a buffer of its own instead of re-running the input transform in the backward pass (memory: (m+2)^2/m^2 x
             # the activation, ~8 GB over the LBBDM-f4 UNet at batch 32, of the 288 GB)
@@ -1062,8 +1064,17 @@ class _Plan:
             self.bufs.append(b)
             vbuf = _View(b, 0, cin_pad, 1, 1, 1, cin_pad)
             self._saved_V[id(pw.weight)] = (vbuf, wm)
-        emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
-             wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
+        if keeps and split:
+            # ... as bf16 planes: the forward GEMM reads the shared scratch copy, the weight gradient the TRANSPOSED copy (rows =
+            # channels, contraction index = tiles) that the same input-transform launch writes -- 6 B per element kept
+            vt = _TensorRef(torch.empty(self.lib.bbdm_gemm_bf3p_tn_at_bytes((wm + 2) ** 2, tiles, cin_pad), dtype=torch.uint8,
+                                        device=self.device))
+            self._saved_V[id(pw.weight)] = (vt, wm, "tr")
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_tr_f32"), wm, x, x.ld, vbuf,
+                 *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt)
+        else:
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
+                 wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
         gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
                        "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
         emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
@@ -1392,7 +1403,24 @@ class _Plan:
                    if (m.winograd_wgrad and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             dbias = gref(mod.bias) if mod.bias is not None else None
             saved = self._saved_V.get(id(w)) if wgm else None
-            if saved is not None and saved[1] == wgm:
+            if saved is not None and saved[1] == wgm and len(saved) > 2:
+                # the forward kept the TRANSPOSED bf16 planes of V: dY transform (transposed planes of dM + the fp32 plane (1, 1)) ->
+                # the bf16x3 GEMM with the tiles as its K loop -> finish (csrc/gemm_bf3p.hip: bbdm_gemm_bf3p_tn_f32)
+                P, Tp = (wgm + 2) ** 2, lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
+                T = N * -(-x_in.H // wgm) * -(-x_in.W // wgm)
+                splits = lib.bbdm_gemm_bf3p_tn_splits(P, Tp, x_in.C, cout)
+                n_dmt = (lib.bbdm_gemm_bf3p_tn_bt_bytes(P, Tp, cout) + 3) // 4          # floats
+                o_dm11 = n_dmt
+                o_du = o_dm11 + Tp * cout
+                o_acc = (o_du + splits * P * x_in.C * cout + 1) & ~1
+                ws_floats[0] = max(ws_floats[0], o_acc + 2 * cout + 2)
+                dMt, dm11, dU = _TensorRef(self._ws_f, 0), _TensorRef(self._ws_f, 4 * o_dm11), _TensorRef(self._ws_f, 4 * o_du)
+                self._bop("bbdm_winograd_dy_transform_bf3p_f32", wgm, dy, dy.ld, dMt, dm11, N, x_in.H, x_in.W, cout)
+                self._bop("bbdm_gemm_bf3p_tn_f32", saved[0], dMt, dU, P, Tp, x_in.C, cout)
+                self._bop("bbdm_winograd_wgrad_finish_f32", wgm, dU, splits, dw_dst, x_in.C, cout)
+                if dbias is not None:       # column sums of dM's plane (1, 1) = the tile sums of dY
+                    self._bop("bbdm_colsum_f32", dm11, cout, _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
+            elif saved is not None and saved[1] == wgm:
                 # the forward kept this layer's V: dY transform -> TN GEMM -> finish (the stages bbdm_conv3x3_winograd_wgrad_f32 chains)
                 P, Tp = (wgm + 2) ** 2, lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
                 T = N * -(-x_in.H // wgm) * -(-x_in.W // wgm)

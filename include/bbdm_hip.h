@@ -364,6 +364,28 @@ int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const
 int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
                                 int Cout, void* stream);
 
+/* ---- Winograd-domain weight gradient on the same bf16x3 GEMM (training; csrc/gemm_bf3p.hip, csrc/winograd.hip) --------- */
+/* Replaces bbdm_gemm_tn_batched_f32 (f32 MFMA) in dW = G^T [ sum_tiles V_xi^T dM_xi ] G (autograd of nn.Conv2d 3x3 at
+ * openaimodel.py:207,233; BaseRunner.py:412) where both operands come as bf16 planes written TRANSPOSED by their producers -- rows =
+ * channels, contraction index = tiles -- so that the contraction over the tiles is the ordinary K loop of bbdm_gemm_bf3p_f32's kernel:
+ *   bbdm_winograd_input_bf3p_tr_f32     : the input transform of the TRAINING forward: the planes Vp for the forward GEMM and their
+ *                                         transposed copy Vt [xi][CinPad32 / 32][tiles / 16][3][1 KB] for the weight gradient
+ *   bbdm_winograd_dy_transform_bf3p_f32 : dY -> dMt [xi][CoutPad128 / 32][tiles / 16][3][1 KB] (A dY A^T, transposed planes) and
+ *                                         dm11 [tiles][Cout] fp32 = its plane (1, 1), whose column sums are the bias gradient
+ *   bbdm_gemm_bf3p_tn_at_bytes / _bt_bytes / _supported / _splits : buffer sizes, shape gate (K % 256, M % 32, N % 4), K splits
+ *   bbdm_gemm_bf3p_tn_f32               : C[z][b][M][N] = sum over the K range of split z of At_b^T-as-stored . Bt_b, z < splits
+ *                                         (the consumer adds the splits in order: bbdm_winograd_wgrad_finish_f32) */
+int bbdm_winograd_input_bf3p_tr_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
+                                    int pre_ld, int pre_silu, int upsample /* 0 */, int N, int H, int W, int CinPad, void* Vt,
+                                    void* stream);
+int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W, int Cout,
+                                        void* stream);
+size_t bbdm_gemm_bf3p_tn_at_bytes(int batch, long long K, int M);
+size_t bbdm_gemm_bf3p_tn_bt_bytes(int batch, long long K, int N);
+int bbdm_gemm_bf3p_tn_supported(long long K, int M, int N);
+int bbdm_gemm_bf3p_tn_splits(int batch, long long K, int M, int N);
+int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N, void* stream);
+
 /* ---- optimizer + EMA in one pass (training) ------------------------------------------------ */
 /* Replaces torch.optim.Adam.step() (runners/utils.py:48-51; called at runners/BaseRunner.py:413-415) and
  * EMA.update() (runners/base/EMA.py:21-29; called at BaseRunner.py:173-178,422-423) for all parameters with ONE launch.

@@ -280,6 +280,36 @@ def conv3x3_winograd_wgrad(x: torch.Tensor, dy: torch.Tensor, cout: int, m: int,
     return (dw, db) if with_bias else dw
 
 
+def conv3x3_winograd_wgrad_bf3p(x: torch.Tensor, dy: torch.Tensor, cout: int, m: int, with_bias: bool = False):
+    """The Winograd-domain weight gradient with both GEMM operands as transposed bf16 planes (csrc/gemm_bf3p.hip TN entry): x [N,H,W,Cin]
+    (Cin % 32 == 0), dy [N,H,W,ld >= cout] -> (dW OIHW, db or None).  Stages: bbdm_winograd_input_bf3p_tr_f32 (as the training forward
+    runs it), bbdm_winograd_dy_transform_bf3p_f32, bbdm_gemm_bf3p_tn_f32, bbdm_winograd_wgrad_finish_f32 (+ bbdm_colsum_f32 of dm11)."""
+    _chk(x, dy)
+    N, H, W, cin = x.shape
+    lib = _lib.load()
+    P, Tp = (m + 2) ** 2, lib.bbdm_winograd_tiles(m, N, H, W)
+    T = N * -(-H // m) * -(-W // m)
+    dev = x.device
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+    Vp, Vt = u8(lib.bbdm_gemm_bf3p_a_bytes(P, Tp, cin)), u8(lib.bbdm_gemm_bf3p_tn_at_bytes(P, Tp, cin))
+    dMt = u8(lib.bbdm_gemm_bf3p_tn_bt_bytes(P, Tp, cout))
+    dm11 = torch.zeros(Tp, cout, dtype=torch.float32, device=dev)
+    _lib.call("bbdm_winograd_input_bf3p_tr_f32", m, x.data_ptr(), cin, Vp.data_ptr(), None, None, 0, 0, 0, N, H, W, cin, Vt.data_ptr(), _st(x))
+    _lib.call("bbdm_winograd_dy_transform_bf3p_f32", m, dy.data_ptr(), dy.shape[-1], dMt.data_ptr(), dm11.data_ptr(), N, H, W, cout, _st(x))
+    assert lib.bbdm_gemm_bf3p_tn_supported(Tp, cin, cout)
+    splits = lib.bbdm_gemm_bf3p_tn_splits(P, Tp, cin, cout)
+    dU = torch.empty(splits * P * cin * cout, dtype=torch.float32, device=dev)
+    _lib.call("bbdm_gemm_bf3p_tn_f32", Vt.data_ptr(), dMt.data_ptr(), dU.data_ptr(), P, Tp, cin, cout, _st(x))
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
+    _lib.call("bbdm_winograd_wgrad_finish_f32", m, dU.data_ptr(), splits, dw.data_ptr(), cin, cout, _st(x))
+    db = None
+    if with_bias:
+        acc = torch.empty(cout, dtype=torch.float64, device=dev)
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
+        _lib.call("bbdm_colsum_f32", dm11.data_ptr(), cout, acc.data_ptr(), db.data_ptr(), T, cout, _st(x))
+    return dw, db
+
+
 def gemm_tn_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a: [batch, K, M], b: [batch, K, N] -> sum over the K splits of C[z][batch][M][N] = a^T b (fp32 MFMA)."""
     _chk(a, b)

@@ -88,6 +88,34 @@ def test_winograd_wgrad(dev, m, N, H, W, Cin, Cout):
     assert rel_err(db.cpu(), b.grad.float()) < TOL
 
 
+# the same gradient with both GEMM operands as transposed bf16 planes on the bf16x3 kernel (Cin % 32 == 0): ragged m = 6 tiles, padded
+# tile counts (zeros must enter the contraction), Cout below / not a multiple of the 128-column tile, split-K, the LBBDM-f4 layer shapes
+WINO_WGRAD_BF3P = [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 2, 12, 12, 64, 128), (6, 1, 7, 10, 32, 8), (6, 3, 16, 20, 96, 72),
+                   (4, 2, 16, 16, 256, 132), (6, 2, 64, 64, 128, 128), (6, 2, 64, 64, 640, 128), (4, 2, 32, 32, 512, 512),
+                   (4, 2, 32, 32, 1536, 512), (4, 2, 16, 16, 1024, 1024), (6, 8, 64, 64, 256, 128)]
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", WINO_WGRAD_BF3P)
+def test_winograd_wgrad_bf3p(dev, m, N, H, W, Cin, Cout):
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(m + N + H + Cin + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, b, padding=1).backward(dy.double())              # fp64 reference gradient
+    pitch = Cout + 8
+    dyg = torch.randn(N, H, W, pitch, generator=g)
+    dyg[..., :Cout] = _nhwc(dy)
+    dw, db = ops.conv3x3_winograd_wgrad_bf3p(_nhwc(x).to(dev), dyg.to(dev), Cout, m, with_bias=True)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    e = rel_err(dw.cpu(), w.grad.float())
+    print(f"winograd wgrad (bf16x3 TN GEMM) m={m} N{N} {H}x{W} {Cin}->{Cout}: rel err {e:.2e}")
+    assert e < 1e-4
+    assert rel_err(db.cpu(), b.grad.float()) < TOL
+
+
 @pytest.mark.parametrize("batch,K,M,N", [(3, 40, 64, 36), (2, 1000, 256, 128), (36, 512, 132, 260), (1, 5000, 128, 128)])
 def test_gemm_tn_batched(dev, batch, K, M, N):
     import kernel_ops as ops

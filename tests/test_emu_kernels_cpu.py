@@ -192,3 +192,8 @@ def test_layernorm_backward(rows, C, with_add):
 
 def test_geglu_backward():
     BK.test_geglu_backward(CPU, 33, 32)
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 1, 7, 10, 32, 8), (6, 2, 12, 12, 64, 132)])
+def test_winograd_wgrad_bf3p(m, N, H, W, Cin, Cout):
+    BK.test_winograd_wgrad_bf3p(CPU, m, N, H, W, Cin, Cout)

@@ -99,11 +99,17 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
         entry = getattr(ops[k + 1][0], "entry", "")
         if entry.endswith("bf3p_f32"):          # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
-            assert getattr(ops[k][0], "entry", "") == "bbdm_winograd_input_bf3p_f32"
+            in_entry = getattr(ops[k][0], "entry", "")
+            assert in_entry in ("bbdm_winograd_input_bf3p_f32", "bbdm_winograd_input_bf3p_tr_f32")
+            if in_entry.endswith("_tr_f32"):        # training forward of a layer whose weight gradient contracts the transposed planes
+                assert training and i[8] == 0 and i[13].t.numel() == lib.bbdm_gemm_bf3p_tn_at_bytes(P, tiles, cin)
+                assert lib.bbdm_gemm_bf3p_tn_supported(tiles, cin, cout)
             assert 4 * plan._wino_v.t.numel() >= lib.bbdm_gemm_bf3p_a_bytes(P, tiles, cin) and cin % 16 == 0
             assert g[2].t.dtype == torch.uint8 and g[2].t.numel() == lib.bbdm_gemm_bf3p_b_bytes(P, cin, cout)
             assert lib.bbdm_gemm_bf3p_supported(tiles, cin, cout)
-            assert not (training and id(plan) and any(v is i[3] for v, _ in plan._saved_V.values()))   # never a kept V
+            # a kept V is the transposed copy (an extra argument of the training forward's input transform), never the planes
+            # the forward GEMM reads (the shared scratch)
+            assert not any(v[0] is i[3] for v in plan._saved_V.values())
         elif entry.endswith("bf3_f32"):
             assert getattr(ops[k][0], "entry", "bbdm_winograd_input_f32") == "bbdm_winograd_input_f32"
             assert g[2].t.dtype == torch.int16 and g[2].t.numel() == lib.bbdm_gemm_bf3_packed_halfs((wm + 2) ** 2, cin, cout)
@@ -142,7 +148,7 @@ def test_fused_producers_in_training_plans_only_where_the_forward_keeps_V():
     assert fused(inf) > 0
     assert fused(trn) == len(trn._fused_train) == sum(n == "bbdm_groupnorm_coeffs_f32" for n, _ in trn.ops)
     assert trn._fused_train <= set(trn._saved_V)                      # fused => its V is kept
-    n_staged = sum(n == "bbdm_gemm_tn_batched_f32" for n, _ in trn.bops)
+    n_staged = sum(n in ("bbdm_gemm_tn_batched_f32", "bbdm_gemm_bf3p_tn_f32") for n, _ in trn.bops)
     assert n_staged == len(trn._saved_V)                              # ... and the gradient plan uses it
     # with direct weight gradients nothing may be fused: the activation is what conv_wgrad_f32 reads
     desc, up, ch, size, n, *_ = bench.WORKLOADS["c1"]

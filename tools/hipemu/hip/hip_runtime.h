@@ -246,6 +246,10 @@ static inline hipemu_v4s hipemu_ds_read_tr16_b64(const void* p) {
     return r;
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu_ds_read_tr16_b64((const void*)(p))
+// a wavefront executes in lockstep; the emulation's fibers do not: __builtin_amdgcn_wave_barrier() (a scheduling barrier on the GPU)
+// is where the kernels say "every lane of the wave has executed what precedes" -- here a real rendezvous of the wave's fibers
+static inline void hipemu_wave_barrier() { int dummy = 0; hipemu::wave_publish(&dummy); hipemu::wave_release(); }
+#define __builtin_amdgcn_wave_barrier() hipemu_wave_barrier()
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu_mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
