@@ -14,7 +14,8 @@ scaled to the spread of the encoder's latents so that the nearest-code search is
 
 Stored: the input images, the pre-quantisation latent, the codebook, the code indices, the quantised latent and the decoded
 images -- plus a NEAR-TIE case for the codebook search: latents on the midpoint between a code and its nearest other code
-(pushed 1e-6 of their distance towards the first) with the indices the reference returns.
+(pushed 1e-6 of their distance towards the first -- below the fp32 resolution of the distance expression, so WHICH of the two
+wins is rounding noise of the host's matmul) with the two candidates and the indices the reference returned here.
 """
 from __future__ import annotations
 
@@ -74,7 +75,7 @@ def main():
         _, _, (_, _, idx_tie) = ref.quantize(z_tie)
     rec = {"ddconfig": DDCONFIG, "n_embed": N_EMBED, "embed_dim": EMBED_DIM, "weight_seed": WEIGHT_SEED, "shapes": shapes,
            "x": x, "z": z, "codebook": cb, "indices": idx.reshape(-1).clone(), "zq": zq, "img": img,
-           "z_tie": z_tie, "indices_tie": idx_tie.reshape(-1).clone()}
+           "z_tie": z_tie, "indices_tie": idx_tie.reshape(-1).clone(), "tie_pairs": pairs.clone()}
     torch.save(rec, OUT)
     nparam = sum(int(np.prod(s)) for _, s in shapes)
     print(f"vq_f4_small: {nparam / 1e6:.1f} M parameters, latent {tuple(z.shape)}, {len(set(idx.reshape(-1).tolist()))} distinct codes of "
