@@ -505,39 +505,95 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
 static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 6; }();
 extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_variant; g_bf3p_variant = v; return old; }
 
-// M[b][T][ldo] = A_b . B_b (+ bias) (+ residual[b][T][ldr]): A, B in the plane layout of the header
-extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr,
-                                  float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream) {
+// ---- forward GEMMs: tile and split-K choice -------------------------------------------------------------------------------------
+// Large problems (every Winograd layer of the 256^2 step) take 256 x 256 tiles, one 16-wave workgroup per CU.  SMALL problems -- the
+// latent / 64^2-pixel configurations: a few hundred rows, K up to 2048 -- would leave most of the 256 CUs without a workgroup and
+// stream their weights (read exactly once) through a handful of 2-deep prefetch queues: they take 128 x 128 tiles (4 waves) and, when
+// even those do not give every CU a workgroup, split K: split z writes its partial sums to M[z][batch][T][ldo] and the consumer adds
+// the partials in order (bbdm_winograd_output_splitk_stats_f32) -- deterministic.
+namespace {
+int fwd_splits(int batch, long long rows, int CinPad, int Cout) {
+    static const int target = [] { const char* e = getenv("BBDM_BF3P_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+    const int nchunks = CinPad / KC;
+    const long long base = (long long)batch * cdiv((int)rows, 128) * cdiv(Cout, 128);       // workgroups with the smallest tile
+    if (target <= 0 || base * 2 > target) return 1;
+    long long splits = (target + base - 1) / base;
+    const long long max_splits = nchunks / 16 > 1 ? nchunks / 16 : 1;                  // >= 16 chunks (K = 256) per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 8) splits = 8;
+    if (splits < 1) splits = 1;
+    const int kps = (int)((nchunks + splits - 1) / splits);
+    return (nchunks + kps - 1) / kps;
+}
+
+// rows: the rows actually computed (<= T, a multiple of 32; the tiles beyond them are neither launched nor stored); T: the row count
+// the buffers are laid out for (per-batch strides).
+int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr, float* M, int ldo,
+                 int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream) {
     BBDM_REQUIRE(a_planes && b_planes && M && batch > 0, "gemm_bf3p: null pointer / bad batch");
     BBDM_REQUIRE(bbdm_gemm_bf3p_supported(T, CinPad, Cout), "gemm_bf3p: T=%lld CinPad=%d Cout=%d unsupported (T %% 256, CinPad %% 16)",
                  T, CinPad, Cout);
+    BBDM_REQUIRE(rows > 0 && rows <= T && rows % 32 == 0, "gemm_bf3p: rows=%lld of T=%lld", rows, T);
     BBDM_REQUIRE((((uintptr_t)a_planes | (uintptr_t)b_planes) & 15) == 0 && ((uintptr_t)M & 3) == 0 && ldo >= Cout &&
                      (!residual || ldr >= Cout),
                  "gemm_bf3p: alignment / pitch");
+    BBDM_REQUIRE(splits >= 1 && splits <= CinPad / KC && (splits == 1 || (!bias && !residual)),
+                 "gemm_bf3p: splits=%d (partial sums carry neither bias nor residual)", splits);
     Bf3pArgs a;
     a.A = (const unsigned char*)a_planes; a.B = (const unsigned char*)b_planes; a.M = M;
-    a.T = (int)T; a.Cout = Cout; a.nchunks = CinPad / KC;
+    a.T = (int)rows; a.Cout = Cout; a.nchunks = CinPad / KC;
     const int CoutPad = cdiv(Cout, 128) * 128;
     a.tilesN = CoutPad / 128;
     a.az = (size_t)T * CinPad * 6; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo; a.rz = (size_t)T * ldr;
     a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
-    a.ksplits = 1; a.kps = a.nchunks; a.P = batch;
+    a.kps = (a.nchunks + splits - 1) / splits;
+    a.ksplits = (a.nchunks + a.kps - 1) / a.kps;
+    BBDM_REQUIRE(a.ksplits == splits, "gemm_bf3p: %d splits of %d chunks leave an empty split", splits, a.nchunks);
+    a.P = batch;
+    const int nb = batch * splits;
     static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
-    a.batch = batch;
-    a.by_batch = (by_batch_env && batch >= 8 && (batch % 8 == 0 || by_batch_env == 2)) ? 1 : 0;
+    a.batch = nb;
+    a.by_batch = (by_batch_env && nb >= 8 && (nb % 8 == 0 || by_batch_env == 2 || splits > 1)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = CoutPad % 256 == 0;
+    // workgroups a tile shape gives; below ~one per CU the next smaller shape takes over (pipe kernel only: it masks ragged row tiles)
+    static const int small_wg = [] { const char* e = getenv("BBDM_BF3P_SMALL_WG"); return e ? atoi(e) : 200; }();
+    auto wgs = [&](int bm, int bn) { return (long long)nb * cdiv((int)rows, bm) * cdiv(CoutPad, bn); };
     int rc;
-#define BBDM_BF3P_GO(WM, WN, KIND) (residual ? bf3p_launch<WM, WN, KIND, true>(a, batch, st) : bf3p_launch<WM, WN, KIND, false>(a, batch, st))
-    if (g_bf3p_variant == 0) rc = BBDM_BF3P_GO(4, 2, 0);
-    else if (g_bf3p_variant == 3) rc = wide ? BBDM_BF3P_GO(4, 4, 0) : BBDM_BF3P_GO(4, 2, 0);
+#define BBDM_BF3P_GO(WM, WN, KIND) (residual ? bf3p_launch<WM, WN, KIND, true>(a, nb, st) : bf3p_launch<WM, WN, KIND, false>(a, nb, st))
+    const bool plain = rows == T && splits == 1;                 // (the A/B kernels have neither ragged rows nor split-K)
+    if (g_bf3p_variant == 0 && plain) rc = BBDM_BF3P_GO(4, 2, 0);
+    else if (g_bf3p_variant == 3 && plain) rc = wide ? BBDM_BF3P_GO(4, 4, 0) : BBDM_BF3P_GO(4, 2, 0);
     else if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(8, 2, 1);
     else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2, 1);
-    else rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(4, 2, 1);
+    else if (g_bf3p_variant == 7) rc = BBDM_BF3P_GO(2, 2, 1);
+    else if (wide && wgs(256, 256) >= small_wg) rc = BBDM_BF3P_GO(4, 4, 1);
+    else if (wgs(256, 128) >= small_wg) rc = BBDM_BF3P_GO(4, 2, 1);
+    else rc = BBDM_BF3P_GO(2, 2, 1);
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p");
     return BBDM_OK;
+}
+}  // namespace
+
+// M[b][T][ldo] = A_b . B_b (+ bias) (+ residual[b][T][ldr]): A, B in the plane layout of the header
+extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                  float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream) {
+    return bf3p_forward(a_planes, b_planes, bias, residual, ldr, M, ldo, batch, T, T, CinPad, Cout, 1, stream);
+}
+
+// Split-K forward GEMM for small problems: `rows` (<= T, a multiple of 32) rows are computed, split z < splits writes its partial sums
+// to M[z][batch][T][ldo] (no bias / residual: the consumer adds the partials in order).  splits = bbdm_gemm_bf3p_fwd_splits(...) is the
+// measured choice (1 for every problem that fills the chip without splitting); any 1 <= splits <= CinPad / 16 that leaves no split
+// empty is accepted.
+extern "C" int bbdm_gemm_bf3p_fwd_splits(int batch, long long rows, int CinPad, int Cout) {
+    if (batch <= 0 || rows <= 0 || CinPad <= 0 || CinPad % KC || Cout <= 0) return 0;
+    return fwd_splits(batch, rows, CinPad, Cout);
+}
+extern "C" int bbdm_gemm_bf3p_splitk_f32(const void* a_planes, const void* b_planes, float* M, int ldo, int batch, long long T,
+                                         long long rows, int CinPad, int Cout, int splits, void* stream) {
+    return bf3p_forward(a_planes, b_planes, nullptr, nullptr, 0, M, ldo, batch, T, rows, CinPad, Cout, splits, stream);
 }
 
 // ---- C = A^T B with the contraction over the ROWS of both operands (the Winograd-domain weight gradient dU_xi = V_xi^T dM_xi, tiles

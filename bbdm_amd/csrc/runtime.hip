@@ -11,5 +11,5 @@ void bbdm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int bbdm_version(void) { return 11; }
+extern "C" int bbdm_version(void) { return 12; }
 extern "C" const char* bbdm_last_error(void) { return g_err; }

@@ -137,7 +137,7 @@ __device__ __forceinline__ void stat_flush(const double* lsum, const StatArgs& s
 
 // y[MO*th + a][MO*tw + b] = (A^T m A)[a][b] + bias (+ residual)
 template <int MO>
-__global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ M, size_t plane, int ldm,
+__global__ void __launch_bounds__(256) winograd_output_kernel(const float* __restrict__ M, size_t plane, int ldm, int splits,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int ldr, int res_per_image,
                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
@@ -169,6 +169,10 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
             float4 v[AL], sj[MO];
 #pragma unroll
             for (int i = 0; i < AL; ++i) v[i] = *reinterpret_cast<const float4*>(m + (size_t)(i * AL + j) * plane);
+            for (int z = 1; z < splits; ++z)      // split-K tile GEMMs (small layers): partial sums M[z][xi][tiles][Cout], added in order
+#pragma unroll
+                for (int i = 0; i < AL; ++i)
+                    v[i] = v[i] + *reinterpret_cast<const float4*>(m + ((size_t)z * (AL * AL) + (i * AL + j)) * plane);
             at_transform<MO>(v, sj);
 #pragma unroll
             for (int a = 0; a < MO; ++a) s[a][j] = sj[a];
@@ -884,22 +888,36 @@ extern "C" int bbdm_winograd_input_bf3p_tr_f32(int m, const float* x, int ldx, v
     return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream);
 }
 
-extern "C" int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
-                                           int CinPad, int Cout, void* stream) {
+// splits > 1 (small layers, bbdm_winograd_gemm_bf3p_splits): the partial sums of split z go to M[z][(m+2)^2][tiles][Cout] and
+// bbdm_winograd_output_splitk_stats_f32 adds them.  Only the row tiles holding real tiles are computed (tiles_raw rounded up to 32
+// rows: an 8x8 latent at batch 32 fills 128 of its 256 padded rows).
+extern "C" int bbdm_winograd_gemm_bf3p_splits(int m, int N, int H, int W, int CinPad, int Cout) {
+    if ((m != 2 && m != 4) || N <= 0 || H <= 0 || W <= 0) return 1;      // (m = 6 is chosen for layers that fill the chip many times over)
+    const int s = bbdm_gemm_bf3p_fwd_splits(planes(m), (long long)((tiles_raw(N, H, W, m) + 31) / 32 * 32), CinPad, Cout);
+    return s > 1 ? s : 1;
+}
+extern "C" int bbdm_winograd_gemm_bf3p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
+                                                  int CinPad, int Cout, int splits, void* stream) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(Vp && b_planes && M && N > 0, "winograd_gemm_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
-    return bbdm_gemm_bf3p_f32(Vp, b_planes, nullptr, nullptr, 0, M, Cout, planes(m), (long long)tiles_padded(N, H, W, m), CinPad,
-                              Cout, stream);
+    return bbdm_gemm_bf3p_splitk_f32(Vp, b_planes, M, Cout, planes(m), (long long)tiles_padded(N, H, W, m),
+                                     (long long)((tiles_raw(N, H, W, m) + 31) / 32 * 32), CinPad, Cout, splits, stream);
+}
+extern "C" int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
+                                           int CinPad, int Cout, void* stream) {
+    return bbdm_winograd_gemm_bf3p_splitk_f32(m, Vp, b_planes, M, N, H, W, CinPad, Cout, 1, stream);
 }
 
 // stats0 / stats1 (each may be NULL): fp64 [N][32][2] GroupNorm accumulators (sum, sum of squares per image and group) of up
 // to two consumers of `out`; cpg = channels per group of that consumer (a multiple of 4), coff = channel offset of `out` in
 // the consumer's tensor.  The caller zeroes them; the kernel ADDS (several producers may fill one consumer's statistics).
-extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
-                                              float* out, int ldo, int flags, int N, int H, int W, int Cout, double* stats0,
-                                              int cpg0, int coff0, double* stats1, int cpg1, int coff1, void* stream) {
+extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
+                                                     float* out, int ldo, int flags, int N, int H, int W, int Cout, double* stats0,
+                                                     int cpg0, int coff0, double* stats1, int cpg1, int coff1, int splits,
+                                                     void* stream) {
     BBDM_WINO_M(m);
+    BBDM_REQUIRE(splits >= 1 && (splits == 1 || m != 6), "winograd_output: splits=%d (m = 6 layers are never split)", splits);
     BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldo % 4 == 0 && ldo >= Cout, "winograd_output: Cout=%d ldo=%d", Cout, ldo);
@@ -935,13 +953,20 @@ extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float
         hipLaunchKernelGGL(winograd_output6_kernel<false>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out,
                            ldo, N, H, W, Cout, (int)iters, st);
     else if (m == 2)
-        hipLaunchKernelGGL(winograd_output_kernel<2>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N,
-                           H, W, Cout, (int)iters, st);
+        hipLaunchKernelGGL(winograd_output_kernel<2>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, splits, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st);
     else
-        hipLaunchKernelGGL(winograd_output_kernel<4>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out, ldo, N,
-                           H, W, Cout, (int)iters, st);
+        hipLaunchKernelGGL(winograd_output_kernel<4>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, splits, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st);
     BBDM_CHECK_LAUNCH("winograd_output");
     return BBDM_OK;
+}
+
+extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
+                                              float* out, int ldo, int flags, int N, int H, int W, int Cout, double* stats0,
+                                              int cpg0, int coff0, double* stats1, int cpg1, int coff1, void* stream) {
+    return bbdm_winograd_output_splitk_stats_f32(m, M, bias, residual, ldr, out, ldo, flags, N, H, W, Cout, stats0, cpg0, coff0,
+                                                 stats1, cpg1, coff1, 1, stream);
 }
 
 extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr,

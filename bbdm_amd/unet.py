@@ -420,7 +420,7 @@ class _PackedWinograd:
             self.key = key
 
 
-def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6) -> int:
+def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True) -> int:
     """Output tile m of the Winograd F(m x m, 3x3) path for this layer, or 0 = direct implicit GEMM.
 
     Measured on MI355X (tools/wino_bench.py -> profiles/r02_wino_bench.txt): the 2.25x (m = 2) / 4x
@@ -438,6 +438,13 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6) -
     if max_m >= 4 and H % 4 == 0 and W % 4 == 0 and cin >= 128 and hw >= 64 and N * (H // 4) * (W // 4) >= 256:
         return 4
     if max_m >= 2 and H % 2 == 0 and W % 2 == 0 and cin >= 256 and hw >= 100 and N * (H // 2) * (W // 2) >= 1024:
+        return 2
+    # SMALL layers (16x16 ... 4x4 maps of the latent models, the inner levels of the 64^2-pixel model): measured in round 3 on the
+    # bf16x3 pipe GEMM (tools/small_conv_bench.py -> profiles/r03_small_conv_bench.txt): F(2x2,3x3) beats the direct f32-MFMA kernel
+    # 1.3-2.8x from 128 tiles up (split-K + 128-row tiles fill the chip: csrc/gemm_bf3p.hip), and F(4x4) whose 256-row GEMM tiles
+    # would be mostly padding.  Needs whole 16-channel chunks (the pre-split operand layout).
+    if small and max_m >= 2 and H % 2 == 0 and W % 2 == 0 and cin % 16 == 0 and cin >= 128 and hw >= 64 \
+            and 128 <= N * (H // 2) * (W // 2) <= 8192:      # (narrow layers with more tiles: 1.0x, N32 64x64 128->128)
         return 2
     return 0
 
@@ -584,6 +591,8 @@ class UNetModel(nn.Module):
         # BBDM_WINOGRAD: largest output tile allowed: 6 (default), 4, 2, or 0 = direct kernel everywhere.
         self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "6"))
         self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
+        # BBDM_WINOGRAD_SMALL=0: the small 3x3 layers (< 256 F(4x4) tiles) keep the direct f32-MFMA kernel (round-2 plan)
+        self.winograd_small: bool = os.environ.get("BBDM_WINOGRAD_SMALL", "1") != "0"
         # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
         # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
         self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
@@ -647,7 +656,8 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles)
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
+               self.winograd_small)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1027,7 +1037,8 @@ class _Plan:
         w = mod.weight
         if not self.m.winograd or w.dim() != 4 or w.shape[2] != 3 or (flags & ~6) != 0:
             return 0
-        return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd)
+        return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd,
+                             small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small))
 
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
@@ -1053,7 +1064,9 @@ class _Plan:
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
-        self._wino_m_need = max(self._wino_m_need, (wm + 2) ** 2 * tiles * cout)
+        # small layers: split-K tile GEMMs, the partial sums M[z] are added by the output transform (csrc/gemm_bf3p.hip: fwd_splits)
+        ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if split else 1
+        self._wino_m_need = max(self._wino_m_need, ksplit * (wm + 2) ** 2 * tiles * cout)
         vbuf = self._wino_v
         keeps = self._keeps_V(wm, H, W, cin_pad, pw.cin, cout, upsample, bwd)
         if keeps and not split:
@@ -1075,15 +1088,24 @@ class _Plan:
         else:
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
                  wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
-        gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
-                       "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
-        emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
-        if bwd:
-            emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout)
+        if ksplit > 1:
+            emit(_OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_splitk_f32"), wm, vbuf, _TensorRef(pw.packed),
+                 self._wino_m, N, H, W, cin_pad, cout, ksplit)
         else:
-            rec = emit(_OpName("bbdm_winograd_output_f32", "bbdm_winograd_output_stats_f32"), wm, self._wino_m,
+            gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
+                           "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
+            emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
+        ks_tail = (ksplit,) if ksplit > 1 else ()
+        if bwd and ksplit == 1:
+            emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout)
+        elif bwd:
+            emit(_OpName("bbdm_winograd_output_f32", "bbdm_winograd_output_splitk_stats_f32"), wm, self._wino_m, None, residual,
+                 res_ld, dest, dest.ld, flags, N, H, W, cout, None, 0, 0, None, 0, 0, ksplit)
+        else:
+            rec = emit(_OpName("bbdm_winograd_output_f32", "bbdm_winograd_output_splitk_stats_f32" if ksplit > 1 else
+                               "bbdm_winograd_output_stats_f32"), wm, self._wino_m,
                        self._pref(pw.bias) if pw.bias is not None else None, residual, res_ld, dest, dest.ld, flags,
-                       N, H, W, cout, None, 0, 0, None, 0, 0)
+                       N, H, W, cout, None, 0, 0, None, 0, 0, *ks_tail)
             self._note_writer(dest, rec, 12)
 
     def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0,
@@ -1447,7 +1469,8 @@ class _Plan:
             if not need_dx:
                 return None
             dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
-            wm = (winograd_tile(N, x_in.H, x_in.W, dy.C, x_in.C, m.winograd)
+            wm = (winograd_tile(N, x_in.H, x_in.W, dy.C, x_in.C, m.winograd,
+                                small=bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small))
                   if (m.winograd and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             if wm:
                 pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=self._use_bf3(wm, x_in.H, x_in.W, dy.C, x_in.C))

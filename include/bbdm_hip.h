@@ -364,6 +364,29 @@ int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const
 int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
                                 int Cout, void* stream);
 
+/* ---- the SMALL 3x3 layers on the same GEMM (latent configurations: Template-LBBDM-f16.yaml:107-130 runs every conv of
+ * openaimodel.py:207,233 on 16x16 / 8x8 / 4x4 maps; the 64^2-pixel model its inner levels) -------------------------------------------
+ * A few hundred rows and K up to 2048: 256-row tiles would give a fraction of the 256 CUs a workgroup and stream the weights -- read
+ * exactly once -- through a handful of prefetch queues.  The forward GEMM therefore (1) computes only the row tiles that hold real
+ * rows (`rows` <= T, a multiple of 32), (2) drops to 128 x 128 tiles when larger ones leave CUs idle (inside bbdm_gemm_bf3p_f32 too),
+ * and (3) splits K: split z < splits writes its partial sums to M[z][batch][T][ldo] (no bias / residual) and the consumer adds the
+ * partials in order z = 0, 1, ... -- deterministic, no atomics.
+ *   bbdm_gemm_bf3p_fwd_splits            : the measured split count for a problem (1 = the problem fills the chip unsplit)
+ *   bbdm_gemm_bf3p_splitk_f32            : the GEMM (any 1 <= splits <= CinPad / 16 that leaves no split empty)
+ *   bbdm_winograd_gemm_bf3p_splits       : split count of a Winograd layer's tile GEMMs (m = 2, 4; always 1 for m = 6)
+ *   bbdm_winograd_gemm_bf3p_splitk_f32   : stage (2) writing M[splits][(m+2)^2][tiles][Cout]
+ *   bbdm_winograd_output_splitk_stats_f32: stage (3) adding the partials while it loads them (arguments of
+ *                                          bbdm_winograd_output_stats_f32, `splits` appended) */
+int bbdm_gemm_bf3p_fwd_splits(int batch, long long rows, int CinPad, int Cout);
+int bbdm_gemm_bf3p_splitk_f32(const void* a_planes, const void* b_planes, float* M, int ldo, int batch, long long T, long long rows,
+                              int CinPad, int Cout, int splits, void* stream);
+int bbdm_winograd_gemm_bf3p_splits(int m, int N, int H, int W, int CinPad, int Cout);
+int bbdm_winograd_gemm_bf3p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
+                                       int Cout, int splits, void* stream);
+int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
+                                          int ldo, int flags, int N, int H, int W, int Cout, double* stats0, int cpg0, int coff0,
+                                          double* stats1, int cpg1, int coff1, int splits, void* stream);
+
 /* ---- Winograd-domain weight gradient on the same bf16x3 GEMM (training; csrc/gemm_bf3p.hip, csrc/winograd.hip) --------- */
 /* Replaces bbdm_gemm_tn_batched_f32 (f32 MFMA) in dW = G^T [ sum_tiles V_xi^T dM_xi ] G (autograd of nn.Conv2d 3x3 at
  * openaimodel.py:207,233; BaseRunner.py:412) where both operands come as bf16 planes written TRANSPOSED by their producers -- rows =

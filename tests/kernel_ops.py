@@ -409,6 +409,24 @@ def gemm_bf3p(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: 
     return M[:, :T]
 
 
+def gemm_bf3p_splitk(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: int, cout: int, rows: int,
+                     splits: int, fill: float = 0.0) -> torch.Tensor:
+    """bbdm_gemm_bf3p_splitk_f32: only ``rows`` (a multiple of 32) of the T rows are computed, split z writes its partial sums to
+    M[z] -> [splits, batch, Tp, cout] (rows >= ``rows`` keep ``fill``)."""
+    _chk(V, w_packed_f32)
+    T = V.shape[1]
+    Tp = (T + 255) // 256 * 256
+    lib = _lib.load()
+    ap = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(batch, T, cin_pad), dtype=torch.uint8, device=V.device)
+    bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(batch, cin_pad, cout), dtype=torch.uint8, device=V.device)
+    _lib.call("bbdm_gemm_bf3p_split_rows_f32", V.data_ptr(), V.shape[2], ap.data_ptr(), batch, T, cin_pad, _st(V))
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", w_packed_f32.data_ptr(), bp.data_ptr(), batch, cin_pad, cout, _st(V))
+    M = torch.full((splits, batch, Tp, cout), fill, dtype=torch.float32, device=V.device)
+    _lib.call("bbdm_gemm_bf3p_splitk_f32", ap.data_ptr(), bp.data_ptr(), M.data_ptr(), cout, batch, Tp, rows, cin_pad, cout, splits,
+              _st(V))
+    return M
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """x: [rows, C] -> nn.LayerNorm(C) per row."""
     _chk(x, gamma, beta)

@@ -63,11 +63,21 @@ def test_winograd_output_adds_upsampled_residual(m, N, H, W, Cin, Cout):
     K.test_winograd_output_adds_upsampled_residual(CPU, m, N, H, W, Cin, Cout)
 
 
-@pytest.mark.parametrize("kernel", [0, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [0, 3, 4, 5, 7])
 @pytest.mark.parametrize("batch,T,Cin,Cout", [(1, 256, 16, 256), (1, 256, 32, 256), (8, 256, 80, 260), (2, 512, 64, 256),
                                               (1, 768, 48, 128)])
 def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):
     K.test_gemm_bf3p_kernel_variants(CPU, kernel, batch, T, Cin, Cout)
+
+
+@pytest.mark.parametrize("batch,T,rows,Cin,Cout,splits", [(2, 256, 96, 64, 72, 2), (1, 256, 256, 48, 132, 3), (8, 256, 32, 32, 40, 1)])
+def test_gemm_bf3p_splitk(batch, T, rows, Cin, Cout, splits):
+    K.test_gemm_bf3p_splitk(CPU, batch, T, rows, Cin, Cout, splits)
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,splits", [(2, 2, 4, 4, 32, 40, 2), (4, 1, 8, 8, 48, 32, 3)])
+def test_winograd_splitk_stages(m, N, H, W, Cin, Cout, splits):
+    K.test_winograd_splitk_stages(CPU, m, N, H, W, Cin, Cout, splits)
 
 
 @pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 1, 1, 2, 12, 12, 32, 40), (4, 0, 1, 1, 8, 8, 16, 8),

@@ -239,12 +239,13 @@ def test_gemm_bf3_accuracy(dev, batch, T, Cin, Cout):
     assert e_bf3 < 3e-6 and e_bf3 < 8 * e_f32 + 1e-7
 
 
-@pytest.mark.parametrize("kernel", [0, 3, 4, 5])
+@pytest.mark.parametrize("kernel", [0, 3, 4, 5, 7])
 @pytest.mark.parametrize("batch,T,Cin,Cout", [(2, 512, 16, 256), (1, 256, 32, 512), (8, 256, 80, 260), (3, 768, 1024, 256),
                                               (2, 768, 48, 128), (8, 1280, 128, 72)])
 def test_gemm_bf3p_kernel_variants(dev, kernel, batch, T, Cin, Cout):
     """Every kernel of csrc/gemm_bf3p.hip (bbdm_debug_set_bf3p_kernel: 0 / 3 = the plain two-stage kernel with 256 x 128 / 256 x 256
-    tiles, 4 / 5 = the software-pipelined kernel with 256 x 256 or 512 x 128 / 256 x 128 tiles; the default mixes 4 and 5) is
+    tiles, 4 / 5 = the software-pipelined kernel with 256 x 256 or 512 x 128 / 256 x 128 tiles, 7 = its 128 x 128 tiles for small
+    problems; the default picks among the pipelined shapes by the number of workgroups they give) is
     bit-equal to csrc/gemm_bf3.hip; Cin = 16 / 32 are the one- and two-chunk edge cases of the prologues, Cout = 260 falls back
     from the 256-column tiles, T = 768 / 1280 leave the 512-row tiles a ragged last row tile."""
     from bbdm_amd import _lib
@@ -289,6 +290,85 @@ def test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, extra):
         M0 = ops.gemm_bf3(V.to(dev), pk, batch, Cin, Cout).cpu()
         torch.cuda.synchronize()
         assert torch.equal(M, M0), (M - M0).abs().max()
+
+
+@pytest.mark.parametrize("batch,T,rows,Cin,Cout,splits", [(16, 256, 128, 1024, 1024, 4), (2, 256, 256, 256, 72, 2),
+                                                          (3, 512, 288, 48, 260, 3), (16, 256, 32, 512, 128, 1),
+                                                          (36, 256, 64, 2048, 512, 8)])
+def test_gemm_bf3p_splitk(dev, batch, T, rows, Cin, Cout, splits):
+    """The forward GEMM of the SMALL layers (csrc/gemm_bf3p.hip: bf3p_forward): only the row tiles holding real rows are computed,
+    K is split and split z writes its partial sums to M[z]; the partials added in order are the fp32-accurate product (vs fp64), the
+    rows beyond ``rows`` are never written, and one split is bit-equal to the unsplit kernel."""
+    import kernel_ops as ops
+    from bbdm_amd import _lib
+    g = torch.Generator().manual_seed(Cin + Cout + rows)
+    V = torch.randn(batch, T, Cin, generator=g) * torch.logspace(-2, 2, Cin)
+    Wt = torch.randn(batch, Cout, Cin, generator=g) * 0.1 / torch.logspace(-2, 2, Cin)
+    cout_pad = (Cout + 127) // 128 * 128
+    pk = torch.zeros(batch, Cin // 16, cout_pad, 16)
+    for c in range(Cin // 16):
+        pk[:, c, :Cout, :] = Wt[:, :, c * 16:(c + 1) * 16]
+    pk = pk.contiguous().to(dev)
+    Mz = ops.gemm_bf3p_splitk(V.to(dev), pk, batch, Cin, Cout, rows, splits, fill=-7.0).cpu()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert bool((Mz[:, :, rows:] == -7.0).all())                      # rows beyond `rows`: untouched
+    M = Mz[0, :, :rows].clone()
+    for z in range(1, splits):
+        M += Mz[z, :, :rows]
+    ref = torch.einsum("btk,bok->bto", V[:, :rows].double(), Wt.double())
+    e = rel_err(M, ref)
+    print(f"gemm_bf3p split-K [{batch} x {rows}/{T} x {Cin} x {Cout}] / {splits}: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6
+    if splits == 1:
+        M0 = ops.gemm_bf3p(V.to(dev), pk, batch, Cin, Cout).cpu()
+        assert torch.equal(M, M0[:, :rows])
+    lib = _lib.load()
+    s = lib.bbdm_gemm_bf3p_fwd_splits(batch, rows, Cin, Cout)
+    assert 1 <= s <= max(1, Cin // 256) and lib.bbdm_gemm_bf3p_fwd_splits(64, 32768, 1024, 1024) == 1
+
+
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,splits", [(2, 32, 4, 4, 1024, 128, 0), (2, 4, 8, 8, 512, 72, 2), (4, 3, 8, 16, 256, 136, 4),
+                                                     (2, 2, 6, 10, 64, 40, 1)])
+def test_winograd_splitk_stages(dev, m, N, H, W, Cin, Cout, splits):
+    """A small 3x3 layer end to end: bf16-plane input transform -> split-K tile GEMMs -> output transform adding the partials, with
+    bias, residual and the fused GroupNorm statistics, against the fp64 convolution.  splits = 0: the library's own choice."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5 * m + H + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(N, Cout, H, W, generator=g)
+    ref = (F.conv2d(x.double(), w.double(), b.double(), padding=1) + r.double()).float()
+    ks = splits or lib.bbdm_winograd_gemm_bf3p_splits(m, N, H, W, Cin, Cout)
+    if not splits:
+        assert ks > 1, "the library splits this shape (32 images of 4x4: 16 workgroups of 128 x 128, K = 1024)"
+    P, tiles = (m + 2) ** 2, lib.bbdm_winograd_tiles(m, N, H, W)
+    st = ops._st(x.to(dev))
+    xg, rg, bg = _nhwc(x).to(dev), _nhwc(r).to(dev), b.to(dev)
+    pw = ops.pack_winograd_weight(w.to(dev), m=m)
+    Bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(P, Cin, Cout), dtype=torch.uint8, device=dev)
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", pw.data_ptr(), Bp.data_ptr(), P, Cin, Cout, st)
+    Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
+    M = torch.full((ks * P * tiles * Cout,), float("nan"), device=dev)
+    out = torch.empty(N, H, W, Cout, device=dev)
+    cpg = Cout // 8 if Cout % 32 == 0 else 0
+    stats = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    _lib.call("bbdm_winograd_input_bf3p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), None, None, 0, 0, 0, N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_bf3p_splitk_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, ks, st)
+    _lib.call("bbdm_winograd_output_splitk_stats_f32", m, M.data_ptr(), bg.data_ptr(), rg.data_ptr(), Cout, out.data_ptr(), Cout, 0,
+              N, H, W, Cout, stats.data_ptr() if cpg else None, cpg, 0, None, 0, 0, ks, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    o = _nchw(out.cpu())
+    e = rel_err(o, ref)
+    print(f"winograd split-K m={m} N{N} {H}x{W} {Cin}->{Cout} / {ks}: rel err {e:.2e}")
+    assert e < WINO_TOL[m]
+    if cpg:
+        s_ref = o.double().reshape(N, 8, -1).sum(-1)
+        assert float((stats.cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72)])

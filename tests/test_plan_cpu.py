@@ -29,10 +29,16 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert wt(16, 256, 256, 128, 128, 4) == 4          # 1.27x
     assert wt(16, 128, 128, 128, 512, 4) == 4          # 1.46x
     assert wt(4, 32, 32, 512, 512) == 4                # 256 tiles: 1.50x
-    # ... loses below that (padded GEMM tiles, launch-bound), where F(2x2) does not pay either
-    assert wt(4, 16, 16, 1024, 1024) == 0              # 0.55x / 0.98x
-    assert wt(32, 4, 4, 1024, 1024) == 0
-    assert wt(32, 8, 8, 512, 512) == 0
+    # ... loses below that on the f32-MFMA tile GEMM (padded GEMM tiles, launch-bound), where F(2x2) did not pay either (round 2) ...
+    assert wt(4, 16, 16, 1024, 1024, small=False) == 0              # 0.55x / 0.98x
+    assert wt(32, 4, 4, 1024, 1024, small=False) == 0
+    assert wt(32, 8, 8, 512, 512, small=False) == 0
+    # ... and takes F(2x2) on the bf16x3 pipe GEMM with 128-row tiles + split-K (profiles/r03_small_conv_bench.txt: direct vs F2)
+    assert wt(4, 16, 16, 1024, 1024) == 2              # 0.183 vs 0.115 ms
+    assert wt(32, 4, 4, 1024, 1024) == 2               # 0.151 vs 0.115 ms (128 tiles: the floor of the rule)
+    assert wt(32, 8, 8, 512, 512) == 2                 # 0.111 vs 0.072 ms
+    assert wt(32, 8, 8, 2048, 1024) == 2               # 0.701 vs 0.250 ms
+    assert wt(32, 2, 2, 1024, 1024) == 0 and wt(32, 8, 8, 520, 512) == 0       # 32 tiles / K not whole 16-channel chunks
     # the stem / head / narrow outputs stay on the direct kernel
     assert wt(16, 256, 256, 8, 128) == 0 and wt(16, 256, 256, 128, 3) == 0 and wt(16, 64, 64, 64, 64) == 0
     # H, W not multiples of 4 -> F(2x2) if the layer is wide and large enough, else direct
@@ -49,7 +55,7 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert wt(8, 32, 32, 512, 512) == 4
     # the cap (UNetModel.winograd / BBDM_WINOGRAD)
     assert wt(16, 64, 64, 1024, 1024, 2) == 2 and wt(16, 64, 64, 1024, 1024, 0) == 0
-    assert wt(16, 8, 8, 1024, 1024, 6) == 0
+    assert wt(16, 8, 8, 1024, 1024, 6, small=False) == 0
     tiny = unet.UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
                           attention_resolutions=(), channel_mult=(1,), num_head_channels=32, condition_key="nocond")
     assert tiny.winograd == int(__import__("os").environ.get("BBDM_WINOGRAD", "6"))      # the default cap
@@ -98,7 +104,7 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert tiles % 256 == 0 and tiles >= N * -(-H // wm) * -(-W // wm)
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
         entry = getattr(ops[k + 1][0], "entry", "")
-        if entry.endswith("bf3p_f32"):          # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
+        if "bf3p" in entry:                     # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
             in_entry = getattr(ops[k][0], "entry", "")
             assert in_entry in ("bbdm_winograd_input_bf3p_f32", "bbdm_winograd_input_bf3p_tr_f32")
             if in_entry.endswith("_tr_f32"):        # training forward of a layer whose weight gradient contracts the transposed planes
@@ -116,7 +122,12 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             assert lib.bbdm_gemm_bf3_supported(tiles, cin, cout)
         else:
             assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
-        assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) == wm
+        assert unet.winograd_tile(N, H, W, cin, cout, m.winograd, small=bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)) == wm
+        if entry.endswith("splitk_f32"):        # small layer: split-K partials, added by the output transform of the same count
+            ks = g[-1]
+            assert ks == lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin, cout) > 1
+            assert getattr(ops[k + 2][0], "entry", "") == "bbdm_winograd_output_splitk_stats_f32" and ops[k + 2][1][-1] == ks
+            assert plan._wino_m.t.numel() >= ks * (wm + 2) ** 2 * tiles * cout
     if training:
         assert names["bbdm_conv_wgrad_f32"] > 0
         fwd_wino = sum(n == "bbdm_winograd_gemm_f32" for n, _ in plan.ops)
