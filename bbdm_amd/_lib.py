@@ -38,6 +38,7 @@ SIGNATURES = {
     "bbdm_conv3x3_winograd_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, _P,
                                            c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_tiles": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "bbdm_upsample_phase_weights_f32": (c_int, [_P, _P, c_int, c_int, _P]),
     "bbdm_winograd_input_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_gemm_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_output_f32": (c_int, [c_int, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

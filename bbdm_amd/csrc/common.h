@@ -38,6 +38,22 @@ static inline int bbdm_device_slot() {
     return d;
 }
 
+// Zero `bytes` (a multiple of 8, 8-byte aligned) on `st` with a KERNEL instead of hipMemsetAsync: the gradient plan is replayed as a
+// hipGraph, and a captured memset node does not reproduce the eager memset on this ROCm (the GroupNorm-backward accumulators kept
+// the previous replay's sums; found by bench.py's c4 parity check) -- kernel nodes do.
+namespace {
+__global__ void bbdm_zero8_kernel(unsigned long long* __restrict__ p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0ull;
+}
+}  // namespace
+static inline void bbdm_zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 8;
+    if (!n) return;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(bbdm_zero8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned long long*)p, n);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int ceil_pow2(int v) {
     int p = 1;

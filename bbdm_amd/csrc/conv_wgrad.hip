@@ -424,7 +424,7 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
 extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream) {
     BBDM_REQUIRE(dy && acc && out && M > 0 && C > 0 && ld >= C, "colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(acc, 0, sizeof(double) * C, st);
+    bbdm_zero_async(acc, sizeof(double) * C, st);
     long long blocks = (M + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     const int rpb = (int)((M + blocks - 1) / blocks);
@@ -449,7 +449,7 @@ extern "C" int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, flo
                                        void* stream) {
     BBDM_REQUIRE(dy && acc && out && N > 0 && M > 0 && C > 0 && ld >= C && ldo >= C, "colsum_batched: bad args");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(acc, 0, sizeof(double) * N * C, st);
+    bbdm_zero_async(acc, sizeof(double) * N * C, st);
     long long blocks = (M + 255) / 256;
     const long long cap = cdiv(1024, N) > 1 ? cdiv(1024, N) : 1;
     if (blocks > cap) blocks = cap;

@@ -567,9 +567,19 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     else if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(8, 2, 1);
     else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2, 1);
     else if (g_bf3p_variant == 7) rc = BBDM_BF3P_GO(2, 2, 1);
-    else if (wide && wgs(256, 256) >= small_wg) rc = BBDM_BF3P_GO(4, 4, 1);
-    else if (wgs(256, 128) >= small_wg) rc = BBDM_BF3P_GO(4, 2, 1);
-    else rc = BBDM_BF3P_GO(2, 2, 1);
+    else if (wgs(256, 128) < small_wg) rc = BBDM_BF3P_GO(2, 2, 1);
+    else {
+        // 256 x 256 (one workgroup per CU) vs 256 x 128 (two per CU): the CU that gets the most workgroups sets the time.  Mid-size
+        // problems (the 16x16 / 32x32 levels of the latent models: 288 ... 1152 tiles of 256 x 256 on 256 CUs) lose up to half a
+        // round to that quantisation; the smaller tile rounds in half steps at 0.94 of the large tile's rate (measured,
+        // profiles/r03_bf3p_tile_choice.txt).  by_batch launches quantise per XCD (32 CUs, whole batch entries).
+        auto rounds = [&](int bm, int bn) {
+            const long long per_entry = (long long)cdiv((int)rows, bm) * cdiv(CoutPad, bn);
+            return a.by_batch ? (double)((per_entry * ((nb + 7) / 8) + 31) / 32) : (double)((per_entry * nb + 255) / 256);
+        };
+        const double t44 = wide ? rounds(256, 256) : 1e30, t42 = rounds(256, 128) * 0.5 / 0.94;
+        rc = t44 <= t42 ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(4, 2, 1);
+    }
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p");

@@ -294,7 +294,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
         double* sg = ws + (size_t)N * C * 2;
         double* dgb = sg + (size_t)N * G * 2;
         float4* coef = reinterpret_cast<float4*>(dgb + (size_t)C * 2);
-        (void)hipMemsetAsync(ws, 0, sizeof(double) * ((size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2), st);
+        bbdm_zero_async(ws, sizeof(double) * ((size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2), st);
         a.pq = pq; a.sg = sg; a.coef = coef;
         const int C4 = C / 4;
         const int PP = C4 <= 256 ? 256 / C4 : 1;

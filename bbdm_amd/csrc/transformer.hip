@@ -214,7 +214,7 @@ extern "C" int bbdm_layernorm_bwd_f32(const float* x, int ldx, const float* gamm
     BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)dadd) & 15) == 0,
                  "layernorm_bwd: 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
+    bbdm_zero_async(ws, sizeof(double) * 2 * C, st);
     long long blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 2 * C, st, x, ldx, gamma, dy, lddy,

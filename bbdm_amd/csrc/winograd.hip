@@ -141,10 +141,10 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ res, int ldr, int res_per_image,
                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
-                                                              int iters, const StatArgs st) {
-    constexpr int AL = MO + 2;
+                                                              int iters, const StatArgs st, int ph) {
+    constexpr int AL = MO + 2;          // ph: see winograd_output6_kernel
     __shared__ double lsum[ST_DOUBLES];
-    const int C4 = Cout >> 2;
+    const int C4 = (ph ? 4 * Cout : Cout) >> 2;
     const int TH = H / MO, TW = W / MO;
     const long long total = (long long)N * TH * TW * C4;
     const long long base = (long long)blockIdx.x * iters * 256;
@@ -157,12 +157,13 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
     for (int it = 0; it < iters; ++it) {
         const long long u = base + (long long)it * 256 + threadIdx.x;
         if (u >= total) break;
-        const int c = (int)(u % C4) * 4;
+        const int cm = (int)(u % C4) * 4;
+        const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;
         const long long tile = u / C4;
         const int tw = (int)(tile % TW);
         const long long r = tile / TW;
         const int th = (int)(r % TH), n = (int)(r / TH);
-        const float* m = M + (size_t)tile * ldm + c;
+        const float* m = M + (size_t)tile * ldm + cm;
         float4 s[MO][AL];                 // s = A^T m, built one column of m at a time
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
@@ -198,7 +199,9 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
 #pragma unroll
             for (int b = 0; b < MO; ++b) {
                 const float4 val = (o[b] + b4) + rv[b];
-                *reinterpret_cast<float4*>(y + (pix0 + b) * ldy + c) = val;
+                const size_t pix = ph ? (size_t)(n * 2 * H + 2 * (MO * th + a) + (pq >> 1)) * (2 * W) + 2 * (MO * tw + b) + (pq & 1)
+                                      : pix0 + b;
+                *reinterpret_cast<float4*>(y + pix * ldy + c) = val;
                 if (stats) {
                     psum += ((double)val.x + (double)val.y) + ((double)val.z + (double)val.w);
                     psq += ((double)val.x * val.x + (double)val.y * val.y) + ((double)val.z * val.z + (double)val.w * val.w);
@@ -584,10 +587,12 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
                                                                const float* __restrict__ bias,
                                                                const float* __restrict__ res, int ldr, int res_per_image,
                                                                float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
-                                                               int iters, const StatArgs st) {
+                                                               int iters, const StatArgs st, int ph) {
+    // ph (BBDM_CONV_OUT_PHASES): M carries 4 Cout channels, channel (2 pa + pb) Cout + co of the tile grid position (oh, ow) is the
+    // output pixel (2 oh + pa, 2 ow + pb), channel co, of a [N, 2H, 2W] image (the four phase filters of conv3x3(nearest x2(x)))
     constexpr int MO = 6, AL = 8;
     __shared__ double lsum[ST_DOUBLES];
-    const int C2 = Cout >> 1;
+    const int C2 = (ph ? 4 * Cout : Cout) >> 1;
     const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
     const long long total = (long long)N * TH * TW * C2;
     const long long base = (long long)blockIdx.x * iters * 256;
@@ -600,12 +605,13 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
     for (int it = 0; it < iters; ++it) {
         const long long u = base + (long long)it * 256 + threadIdx.x;
         if (u >= total) break;
-        const int c = (int)(u % C2) * 2;
+        const int cm = (int)(u % C2) * 2;
+        const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;
         const long long tile = u / C2;
         const int tw = (int)(tile % TW);
         const long long r = tile / TW;
         const int th = (int)(r % TH), n = (int)(r / TH);
-        const float* m = M + (size_t)tile * ldm + c;
+        const float* m = M + (size_t)tile * ldm + cm;
         float2 s[MO][AL];
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
@@ -644,7 +650,9 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
                 if (oh < H && ow < W) {
                     float2 val = o[b] + b2;
                     if (RES) val = val + rv[b];
-                    *reinterpret_cast<float2*>(y + ((size_t)(n * H + oh) * W + ow) * ldy + c) = val;
+                    const size_t pix = ph ? (size_t)(n * 2 * H + 2 * oh + (pq >> 1)) * (2 * W) + 2 * ow + (pq & 1)
+                                          : (size_t)(n * H + oh) * W + ow;
+                    *reinterpret_cast<float2*>(y + pix * ldy + c) = val;
                     if (stats) {
                         psum += (double)val.x + (double)val.y;
                         psq += (double)val.x * val.x + (double)val.y * val.y;
@@ -700,11 +708,49 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
     }
 }
 
+// conv3x3(nearest x2 (x)) as four 3x3 "phase" filters on x: output pixel (2i + a, 2j + b) reads the upsampled rows 2i + a - 1 .. 2i + a
+// + 1 = x rows {i - 1, i, i} (a = 0) or {i, i, i + 1} (a = 1), so along each axis the taps collapse to [w0, w1 + w2, 0] (phase 0) or
+// [0, w0 + w1, w2] (phase 1) at offsets (-1, 0, +1); zero padding of the upsampled image = zero padding of x.  w4 [4 Cout][Cin][3][3],
+// filter (2a + b) Cout + co.  One thread = one (phase, co, ci).
+__global__ void upsample_phase_weight_kernel(const float* __restrict__ w, float* __restrict__ w4, int Cout, int Cin) {
+    const size_t n = (size_t)4 * Cout * Cin;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        const size_t t = i / Cin;
+        const int co = (int)(t % Cout), pq = (int)(t / Cout), pa = pq >> 1, pb = pq & 1;
+        const float* g = w + ((size_t)co * Cin + ci) * 9;
+        float rows[3][3];                 // taps collapsed along y: rows[dy][kx]
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            rows[0][kx] = pa ? 0.f : g[kx];
+            rows[1][kx] = pa ? g[kx] + g[3 + kx] : g[3 + kx] + g[6 + kx];
+            rows[2][kx] = pa ? g[6 + kx] : 0.f;
+        }
+        float* d = w4 + i * 9;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            d[dy * 3 + 0] = pb ? 0.f : rows[dy][0];
+            d[dy * 3 + 1] = pb ? rows[dy][0] + rows[dy][1] : rows[dy][1] + rows[dy][2];
+            d[dy * 3 + 2] = pb ? rows[dy][2] : 0.f;
+        }
+    }
+}
+
 inline size_t tiles_raw(int N, int H, int W, int m) { return wino_tiles_raw(N, H, W, m); }
 inline size_t tiles_padded(int N, int H, int W, int m) { return wino_tiles_padded(N, H, W, m); }
 inline int planes(int m) { return wino_planes(m); }
 
 }  // namespace
+
+extern "C" int bbdm_upsample_phase_weights_f32(const float* w_oihw, float* w4, int Cout, int Cin, void* stream) {
+    BBDM_REQUIRE(w_oihw && w4 && Cout > 0 && Cin > 0, "upsample_phase_weights: bad args");
+    const size_t n = (size_t)4 * Cout * Cin;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(upsample_phase_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, w4, Cout, Cin);
+    BBDM_CHECK_LAUNCH("upsample_phase_weights");
+    return BBDM_OK;
+}
 
 extern "C" size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad) {
     return (size_t)planes(m) * cdiv(CinPad, KC) * (cdiv(Cout, 128) * 128) * KC;
@@ -921,9 +967,12 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldo % 4 == 0 && ldo >= Cout, "winograd_output: Cout=%d ldo=%d", Cout, ldo);
-    BBDM_REQUIRE((flags & ~(BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE)) == 0 &&
+    BBDM_REQUIRE((flags & ~(BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE | BBDM_CONV_OUT_PHASES)) == 0 &&
                      (flags & (BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE)) != (BBDM_CONV_RES_PER_IMAGE | BBDM_CONV_RES_UPSAMPLE),
                  "winograd_output: unsupported flags 0x%x", flags);
+    const int ph = (flags & BBDM_CONV_OUT_PHASES) ? 1 : 0;
+    BBDM_REQUIRE(!ph || (!residual && splits == 1), "winograd_output: BBDM_CONV_OUT_PHASES takes neither a residual nor split-K partials");
+    const int Cm = ph ? 4 * Cout : Cout;                     // channels of M
     BBDM_REQUIRE(!(flags & BBDM_CONV_RES_UPSAMPLE) || (residual && H % 2 == 0 && W % 2 == 0),
                  "winograd_output: BBDM_CONV_RES_UPSAMPLE needs a residual and even H, W");
     BBDM_REQUIRE(!residual || (ldr % 4 == 0 && ldr >= Cout && ((uintptr_t)residual & 15) == 0), "winograd_output: ldr=%d", ldr);
@@ -936,7 +985,7 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     st.s[0] = stats0; st.cpg[0] = cpg0 > 0 ? cpg0 : 1; st.coff[0] = coff0;
     st.s[1] = stats1; st.cpg[1] = cpg1 > 0 ? cpg1 : 1; st.coff[1] = coff1;
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
-    const long long units = (long long)T * (Cout / (m == 6 ? 2 : 4));
+    const long long units = (long long)T * (Cm / (m == 6 ? 2 : 4));
     // contiguous runs of iters x 256 units per workgroup: >= ~6000 workgroups (the chip holds ~1000 at a time: a 1536-workgroup
     // launch measured 13 % slower for its ragged last wave), <= 16 iterations
     long long iters = units / (256ll * 6144);
@@ -947,17 +996,17 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     const dim3 g((unsigned)blocks), b(256);
     hipStream_t s_ = (hipStream_t)stream;
     if (m == 6 && residual)
-        hipLaunchKernelGGL(winograd_output6_kernel<true>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out,
-                           ldo, N, H, W, Cout, (int)iters, st);
+        hipLaunchKernelGGL(winograd_output6_kernel<true>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st, ph);
     else if (m == 6)
-        hipLaunchKernelGGL(winograd_output6_kernel<false>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, bias, residual, ldr, rpi, out,
-                           ldo, N, H, W, Cout, (int)iters, st);
+        hipLaunchKernelGGL(winograd_output6_kernel<false>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st, ph);
     else if (m == 2)
-        hipLaunchKernelGGL(winograd_output_kernel<2>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, splits, bias, residual, ldr, rpi, out,
-                           ldo, N, H, W, Cout, (int)iters, st);
+        hipLaunchKernelGGL(winograd_output_kernel<2>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, splits, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st, ph);
     else
-        hipLaunchKernelGGL(winograd_output_kernel<4>, g, b, 0, s_, M, Tp * (size_t)Cout, Cout, splits, bias, residual, ldr, rpi, out,
-                           ldo, N, H, W, Cout, (int)iters, st);
+        hipLaunchKernelGGL(winograd_output_kernel<4>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, splits, bias, residual, ldr, rpi, out,
+                           ldo, N, H, W, Cout, (int)iters, st, ph);
     BBDM_CHECK_LAUNCH("winograd_output");
     return BBDM_OK;
 }

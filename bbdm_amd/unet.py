@@ -387,12 +387,17 @@ class _PackedWinograd:
     csrc/gemm_bf3p.hip, whose A operand the input transform writes pre-split (bbdm_winograd_input_bf3p_f32 / _gemm_bf3p_f32)."""
 
     def __init__(self, weight: nn.Parameter, bias: Optional[nn.Parameter], in_pad: int, m: int, dgrad: bool = False,
-                 bf3: bool = False):
+                 bf3: bool = False, phases: bool = False):
         self.weight, self.bias, self.dgrad, self.m, self.bf3 = weight, bias, dgrad, m, bf3
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.ks, self.in_pad = 3, in_pad
         lib = _lib.load()
-        self.out_ch = self.cin if dgrad else self.cout
+        # ``phases``: the layer is conv3x3(nearest x2 (x)); packed are its four phase filters, a conv Cin -> 4 Cout on x itself
+        # (bbdm_upsample_phase_weights_f32, BBDM_CONV_OUT_PHASES)
+        assert not (phases and dgrad)
+        self.phases = phases
+        self.w4 = torch.empty(4 * self.cout, self.cin, 3, 3, dtype=torch.float32, device=weight.device) if phases else None
+        self.out_ch = self.cin if dgrad else (4 * self.cout if phases else self.cout)
         n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
         self.packed_f32 = torch.empty(n, dtype=torch.float32, device=weight.device)
         if bf3 == "p":
@@ -412,8 +417,13 @@ class _PackedWinograd:
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
-            _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
-                      self.in_pad, 1 if self.dgrad else 0, stream)
+            if self.phases:
+                _lib.call("bbdm_upsample_phase_weights_f32", w.data_ptr(), self.w4.data_ptr(), self.cout, self.cin, stream)
+                _lib.call("bbdm_winograd_pack_weight_f32", self.m, self.w4.data_ptr(), self.packed_f32.data_ptr(), 4 * self.cout,
+                          self.cin, self.in_pad, 0, stream)
+            else:
+                _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
+                          self.in_pad, 1 if self.dgrad else 0, stream)
             if self.bf3:
                 _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 == "p" else "bbdm_gemm_bf3_pack_f32",
                           self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2, self.in_pad, self.out_ch, stream)
@@ -582,6 +592,10 @@ class UNetModel(nn.Module):
         self._freqs: Optional[torch.Tensor] = None
         self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
         self.hip_graph: Optional[bool] = None       # None = automatic (small latents), True / False = force
+        # BBDM_TRAIN_GRAPH=1: training plans replay their forward and each backward segment as hipGraphs.  Off by default: measured on the
+        # LBBDM-f4 micro-step (C4) 74.7 vs 75.2 ms eager -- the GPU is not waiting for the host; what separates the 67 ms of plan
+        # kernels from the step is dispatch latency between ~1300 dependent launches, which a graph replay pays as well.
+        self.train_graph: bool = os.environ.get("BBDM_TRAIN_GRAPH", "0") == "1"
         # Fold GroupNorm/FiLM/SiLU into the consuming conv's LDS staging (inference).  Measured on MI355X it trades a
         # 2.5 % streaming pass for ~5 % more time in the MFMA-bound conv at 256^2 (VALU + coefficient loads on the
         # staging path), so it is off by default; kept for the small-latent regime and as a tested kernel feature.
@@ -593,6 +607,9 @@ class UNetModel(nn.Module):
         self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
         # BBDM_WINOGRAD_SMALL=0: the small 3x3 layers (< 256 F(4x4) tiles) keep the direct f32-MFMA kernel (round-2 plan)
         self.winograd_small: bool = os.environ.get("BBDM_WINOGRAD_SMALL", "1") != "0"
+        # BBDM_UPSAMPLE_PHASES=0: conv3x3(nearest x2 (x)) layers of inference plans transform the UPSAMPLED tensor (round-2 plan)
+        # instead of running their four phase filters on x (input transform and GEMM A operand 4x smaller)
+        self.upsample_phases: bool = os.environ.get("BBDM_UPSAMPLE_PHASES", "1") != "0"
         # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
         # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
         self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
@@ -657,7 +674,7 @@ class UNetModel(nn.Module):
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small)
+               self.winograd_small, self.upsample_phases)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1058,14 +1075,19 @@ class _Plan:
                     and winograd_wgrad_tile(self.N, H, W, cin_pad, cout, self.m.winograd_wgrad) == wm)
 
     def _emit_winograd(self, x, cin_pad, pw, pre, upsample, H, W, residual, res_ld, dest, flags, bwd=False):
-        """input transform -> 16 batched GEMMs -> output transform (csrc/winograd.hip)."""
+        """input transform -> 16 batched GEMMs -> output transform (csrc/winograd.hip).  ``pw.phases``: H, W are x's; the GEMMs produce the
+        4 Cout phase channels and the output transform scatters them over the [2H, 2W] result (BBDM_CONV_OUT_PHASES)."""
         emit = self._bop if bwd else self._op
-        N, cout, wm = self.N, dest.C, pw.m
+        N, cout_y, wm = self.N, dest.C, pw.m
+        cout = 4 * cout_y if pw.phases else cout_y          # channels of M
+        if pw.phases:
+            assert not bwd and not upsample and residual is None and (dest.H, dest.W) == (2 * H, 2 * W)
+            flags |= 8
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
         # small layers: split-K tile GEMMs, the partial sums M[z] are added by the output transform (csrc/gemm_bf3p.hip: fwd_splits)
-        ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if split else 1
+        ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if (split and not pw.phases) else 1
         self._wino_m_need = max(self._wino_m_need, ksplit * (wm + 2) ** 2 * tiles * cout)
         vbuf = self._wino_v
         keeps = self._keeps_V(wm, H, W, cin_pad, pw.cin, cout, upsample, bwd)
@@ -1097,15 +1119,15 @@ class _Plan:
             emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
         ks_tail = (ksplit,) if ksplit > 1 else ()
         if bwd and ksplit == 1:
-            emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout)
+            emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout_y)
         elif bwd:
             emit(_OpName("bbdm_winograd_output_f32", "bbdm_winograd_output_splitk_stats_f32"), wm, self._wino_m, None, residual,
-                 res_ld, dest, dest.ld, flags, N, H, W, cout, None, 0, 0, None, 0, 0, ksplit)
+                 res_ld, dest, dest.ld, flags, N, H, W, cout_y, None, 0, 0, None, 0, 0, ksplit)
         else:
             rec = emit(_OpName("bbdm_winograd_output_f32", "bbdm_winograd_output_splitk_stats_f32" if ksplit > 1 else
                                "bbdm_winograd_output_stats_f32"), wm, self._wino_m,
                        self._pref(pw.bias) if pw.bias is not None else None, residual, res_ld, dest, dest.ld, flags,
-                       N, H, W, cout, None, 0, 0, None, 0, 0, *ks_tail)
+                       N, H, W, cout_y, None, 0, 0, None, 0, 0, *ks_tail)
             self._note_writer(dest, rec, 12)
 
     def _emit_conv(self, x: _View, mod, residual, dest: _View, res_ld: Optional[int] = None, flags: int = 0,
@@ -1120,6 +1142,16 @@ class _Plan:
             res_ld = residual.ld if residual is not None else 0
         H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
         wm = self._winograd_ok(mod, H, W, x.C, flags)
+        if wm and upsample and self.m.upsample_phases and residual is None and flags == 0 and mod.weight.shape[1] == x.C:
+            # conv3x3(nearest x2 (x)) = four phase filters on x (Cin -> 4 Cout): same GEMM work, the input transform and the GEMM's
+            # A operand shrink 4x -- taken where x's own tile grid earns the same Winograd tile as the upsampled one
+            wl = winograd_tile(self.N, x.H, x.W, x.C, 4 * cout, self.m.winograd,
+                               small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small))
+            if wl >= wm:
+                pw = _PackedWinograd(mod.weight, mod.bias, x.C, wl, bf3=self._use_bf3(wl, x.H, x.W, x.C, 4 * cout), phases=True)
+                self.convs.append(pw)
+                self._emit_winograd(x, x.C, pw, pre, False, x.H, x.W, None, 0, dest, 0)
+                return
         if wm:
             pw = _PackedWinograd(mod.weight, mod.bias, x.C, wm, bf3=self._use_bf3(
                 wm, H, W, x.C, cout, keeps_V=self._keeps_V(wm, H, W, x.C, mod.weight.shape[1], cout, upsample, False)))
@@ -1781,6 +1813,31 @@ class _Plan:
         ops = self.bops[lo:hi] + (self.bops_x0 if (last and need_dx) else [])
         check = _lib.check
         prof = self.m.op_profile
+        if prof is None and self._want_graph():
+            # hipGraph replay of this segment's launches; one graph per (segment, flat gradient buffer, parameter storage): the
+            # gradient plan alternates between <= 2 flat buffers (_pick_flat_grad).  The first call with a key runs eagerly
+            # (kernel attributes, caches), the second captures.
+            gkey = (k, bool(last and need_dx), self._flat_grad.data_ptr(), self._param_key)
+            if not hasattr(self, "_bgraphs"):
+                self._bgraphs, self._bwarm = {}, set()
+            g = self._bgraphs.get(gkey)
+            if g is None and gkey in self._bwarm:
+                if len(self._bgraphs) >= 4 * len(self.bsegs):          # parameter storage keeps moving: do not pile up graphs
+                    self._bgraphs.clear()
+                torch.cuda.current_stream(self.device).synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    cs = _lib.current_stream(self.device)
+                    for name, args in ops:
+                        rc = getattr(lib, getattr(name, "entry", name))(*(a.resolve() if hasattr(a, "resolve") else a for a in args), cs)
+                        if rc != 0:
+                            check(rc, name)
+                self._bgraphs[gkey] = g
+            if g is not None:
+                g.replay()
+                ops = ()
+            else:
+                self._bwarm.add(gkey)
         for name, args in ops:
             fn = getattr(lib, getattr(name, "entry", name))
             if prof is None:
@@ -1931,11 +1988,15 @@ class _Plan:
 
     def _want_graph(self) -> bool:
         """hipGraph replay of the ~200-launch forward pays only when the launches are short (small latents); at the
-        256^2 pixel config one launch is milliseconds.  ``UNetModel.hip_graph`` = True / False overrides."""
+        256^2 pixel config one launch is milliseconds.  ``UNetModel.hip_graph`` = True / False overrides.  Training plans replay
+        their forward and each backward segment the same way on request (``UNetModel.train_graph`` / BBDM_TRAIN_GRAPH=1; measured
+        gain on C4: 0.6 %)."""
         pref = self.m.hip_graph
         if pref is not None:
             return bool(pref)
-        return not self.training and self.N * self.H * self.W <= 32 * 64 * 64
+        if self.device.type != "cuda" or (self.training and not self.m.train_graph):
+            return False
+        return self.N * self.H * self.W <= 32 * 64 * 64
 
     def run(self, x, t, ctx, out=None, borrow=False):
         with _lib.device_guard(self.device):        # NULL-stream launches follow the current device (see _lib.device_guard)

@@ -62,6 +62,11 @@ int bbdm_conv_pack_weight_f32(const float* w_oihw, float* packed, int Cout, int 
 #define BBDM_CONV_RES_PER_IMAGE 2
 #define BBDM_CONV_RES_UPSAMPLE 4   /* Winograd output transform only: residual is [N][H/2][W/2][ldr], added nearest-upsampled x2 (the
                                       skip path x_upd(x) of an up-sampling ResBlock, openaimodel.py:259-264) */
+#define BBDM_CONV_OUT_PHASES 8     /* Winograd output transform only: the layer is conv3x3(nearest x2 (x)) (Upsample.forward,
+                                      openaimodel.py:111-121) run as FOUR phase filters on the low-resolution x: H, W are x's; M carries
+                                      4 Cout channels, channel (2a + b) Cout + co at (i, j) is output pixel (2i + a, 2j + b), channel co, of
+                                      the [N][2H][2W][ldo] result -- the input transform and the GEMM's A operand are 4x smaller than on
+                                      the upsampled tensor, the GEMM's work is the same.  The phase filters: bbdm_upsample_phase_weights_f32 */
 /* ws (may be NULL) / ws_floats: scratch for split-K.  When the output tiles alone cannot fill the 256 CUs (small
  * latents: LBBDM-f16 runs the 1024-channel layers on 4x4 images) the Cin reduction is spread over extra workgroups
  * whose partial sums are added in a fixed order by a second kernel (deterministic).  Size it with
@@ -120,6 +125,10 @@ int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packe
  *   gemm  : M[xi] = V[xi] . U[xi] for the (m+2)^2 transform points, one launch.
  *   output: M[(m+2)^2][tiles][Cout] -> out NHWC (+ bias, + residual; flags: BBDM_CONV_RES_PER_IMAGE or BBDM_CONV_RES_UPSAMPLE). */
 size_t bbdm_winograd_tiles(int m, int N, int H, int W);
+/* The four phase filters of conv3x3(nearest x2 (x)) (Upsample.forward / the up-sampling ResBlock, openaimodel.py:111-121,259-264) as one
+ * 3x3 convolution Cin -> 4 Cout on the low-resolution x (see BBDM_CONV_OUT_PHASES): w4 [4 Cout][Cin][3][3] from w [Cout][Cin][3][3].
+ * Per axis the taps collapse to [w0, w1 + w2, 0] (phase 0) / [0, w0 + w1, w2] (phase 1): one fp32 addition per collapsed tap. */
+int bbdm_upsample_phase_weights_f32(const float* w_oihw, float* w4, int Cout, int Cin, void* stream);
 int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale, const float* pre_bias,
                             int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
 int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed_wino, float* M, int N, int H, int W, int CinPad,

@@ -70,6 +70,11 @@ def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):
     K.test_gemm_bf3p_kernel_variants(CPU, kernel, batch, T, Cin, Cout)
 
 
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,pre", [(6, 1, 7, 11, 16, 40, 1), (4, 1, 8, 8, 16, 32, 0), (2, 2, 4, 6, 16, 8, 1)])
+def test_upsample_conv_as_phase_filters(m, N, H, W, Cin, Cout, pre):
+    K.test_upsample_conv_as_phase_filters(CPU, m, N, H, W, Cin, Cout, pre)
+
+
 @pytest.mark.parametrize("batch,T,rows,Cin,Cout,splits", [(2, 256, 96, 64, 72, 2), (1, 256, 256, 48, 132, 3), (8, 256, 32, 32, 40, 1)])
 def test_gemm_bf3p_splitk(batch, T, rows, Cin, Cout, splits):
     K.test_gemm_bf3p_splitk(CPU, batch, T, rows, Cin, Cout, splits)

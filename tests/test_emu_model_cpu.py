@@ -117,7 +117,7 @@ def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -151,7 +151,7 @@ def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=8, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -172,7 +172,17 @@ def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):
         resamplers = [a for n, a in plan.ops if str(n) == "bbdm_groupnorm_apply_f32" and a[-1] == 2]
         up_reads = [a for n, a in plan.ops if str(n) == "bbdm_winograd_output_f32" and a[7] == 4]
         assert (len(resamplers) == 0 and len(up_reads) == 1) if fold else (len(resamplers) == 2 and not up_reads)
+        # ... and the first conv of the folded block runs as the four phase filters of conv3x3(nearest x2 (.)) on the LOW-resolution tensor
+        phase_convs = [a for n, a in plan.ops if str(n) == "bbdm_winograd_output_f32" and a[7] == 8]
+        assert len(phase_convs) == (1 if fold else 0)
     assert rel_err(outs[True], outs[False]) < 2e-5
+    m.winograd_fuse_groupnorm, m.upsample_phases = True, False         # the round-2 form: input transform of the upsampled tensor
+    with torch.no_grad():
+        out_up = m(x, timesteps=t, context=None).clone()
+    plan = m._plan_for(x, False)
+    assert not any(str(n) == "bbdm_winograd_output_f32" and a[7] == 8 for n, a in plan.ops)
+    assert any(str(n) == "bbdm_winograd_input_f32" and a[8] == 1 for n, a in plan.ops)
+    assert rel_err(outs[True], out_up) < 2e-5
     ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
     assert rel_err(outs[True], ref) < M.STEP_TOL
 
@@ -187,7 +197,7 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     # the forward's tile rule wants >= 128 channels (4x the emulation time): let the 64-channel layers take F(4x4) too, so that
     # the training forward keeps their V and the gradient plan runs the staged form (dY transform -> TN GEMM -> finish) on it
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")

@@ -371,6 +371,63 @@ def test_winograd_splitk_stages(dev, m, N, H, W, Cin, Cout, splits):
         assert float((stats.cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
 
 
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,pre", [(6, 2, 12, 20, 32, 40, 1), (4, 1, 8, 16, 16, 24, 0), (2, 3, 4, 6, 16, 8, 1),
+                                                  (6, 1, 7, 11, 48, 136, 0), (6, 2, 32, 32, 64, 128, 1)])
+def test_upsample_conv_as_phase_filters(dev, m, N, H, W, Cin, Cout, pre):
+    """conv3x3(nearest x2 (act(x))) (Upsample.forward, openaimodel.py:111-121; the up-sampling ResBlock's first conv, :259-264) run as
+    its four phase filters on the LOW-resolution x: bbdm_upsample_phase_weights_f32 -> Winograd with 4 Cout GEMM columns -> output
+    transform scattering channel (2a + b) Cout + co of (i, j) to pixel (2i + a, 2j + b) (BBDM_CONV_OUT_PHASES), with the fused
+    GroupNorm-coefficient producer and the consumer's GroupNorm statistics; against the fp64 convolution of the upsampled tensor."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11 * m + H + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    sc = torch.randn(N, Cin, generator=g)
+    bi = torch.randn(N, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    a = x.double()
+    if pre:
+        a = a * sc.double()[:, :, None, None] + bi.double()[:, :, None, None]
+        a = a * torch.sigmoid(a)
+    ref = F.conv2d(F.interpolate(a, scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1).float()
+    st = ops._st(x.to(dev))
+    wg = w.to(dev).contiguous()
+    w4 = torch.empty(4 * Cout, Cin, 3, 3, device=dev)
+    _lib.call("bbdm_upsample_phase_weights_f32", wg.data_ptr(), w4.data_ptr(), Cout, Cin, st)
+    # the phase filters themselves: each is the 3x3 filter with its taps collapsed onto the 2 x-pixels they read
+    w4c = w4.cpu().view(2, 2, Cout, Cin, 3, 3)
+    assert torch.equal(w4c[0, 0, :, :, 0, 0], w[:, :, 0, 0]) and torch.equal(w4c[1, 1, :, :, 2, 2], w[:, :, 2, 2])
+    assert torch.equal(w4c[0, 1, :, :, 1, 1], (w[:, :, 1, 0] + w[:, :, 2, 0]) + (w[:, :, 1, 1] + w[:, :, 2, 1]))
+    assert float(w4c[0, :, :, :, 2].abs().max()) == 0.0 and float(w4c[:, 1, :, :, :, 0].abs().max()) == 0.0
+    P, tiles = (m + 2) ** 2, lib.bbdm_winograd_tiles(m, N, H, W)
+    pw = ops.pack_winograd_weight(w4, m=m)
+    Bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(P, Cin, 4 * Cout), dtype=torch.uint8, device=dev)
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", pw.data_ptr(), Bp.data_ptr(), P, Cin, 4 * Cout, st)
+    Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
+    M = torch.empty(P * tiles * 4 * Cout, device=dev)
+    out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device=dev)
+    xg, scg, big, bg = _nhwc(x).to(dev), sc.to(dev), bi.to(dev), b.to(dev)
+    cpg = Cout // 8 if Cout % 32 == 0 else 0
+    stats = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    _lib.call("bbdm_winograd_input_bf3p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), scg.data_ptr() if pre else None,
+              big.data_ptr() if pre else None, Cin, pre, 0, N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cin, 4 * Cout, st)
+    _lib.call("bbdm_winograd_output_stats_f32", m, M.data_ptr(), bg.data_ptr(), None, 0, out.data_ptr(), Cout, 8, N, H, W, Cout,
+              stats.data_ptr() if cpg else None, cpg, 0, None, 0, 0, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    o = _nchw(out.cpu())
+    assert not bool(torch.isnan(o).any())                       # every pixel of the 2H x 2W result written
+    e = rel_err(o, ref)
+    print(f"upsample conv as phase filters m={m} N{N} {H}x{W}->{2 * H}x{2 * W} {Cin}->{Cout}: rel err {e:.2e}")
+    assert e < WINO_TOL[m]
+    if cpg:
+        s_ref = o.double().reshape(N, 8, -1).sum(-1)
+        assert float((stats.cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
+
+
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72)])
 def test_winograd_output_adds_upsampled_residual(dev, m, N, H, W, Cin, Cout):
     """BBDM_CONV_RES_UPSAMPLE: the output transform adds a residual given at half the resolution, nearest-upsampled x2 -- the

@@ -94,11 +94,16 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         N, H, W, cin = i[9:13]
         assert wm in (2, 4, 6) and g[0] == wm and o[0] == wm
         assert (wm == 6 or (H % wm == 0 and W % wm == 0)) and cin % 4 == 0
-        assert tuple(g[4:8]) == (N, H, W, cin) and tuple(o[8:11]) == (N, H, W) and o[11] == g[8]
+        phases = bool(o[7] & 8)          # conv3x3(nearest x2 (x)) as four phase filters on x: the GEMMs produce 4 Cout channels
+        assert tuple(g[4:8]) == (N, H, W, cin) and tuple(o[8:11]) == (N, H, W) and (4 if phases else 1) * o[11] == g[8]
         cout = g[8]
         up = i[8]
         src = i[1]                                            # the view being convolved
         assert (src.H, src.W) == ((H // 2, W // 2) if up else (H, W)) and src.C == cin
+        if phases:
+            dst = o[5]
+            assert not up and not training and (dst.H, dst.W, dst.C) == (2 * H, 2 * W, cout // 4) and o[3] is None
+            assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) >= unet.winograd_tile(N, 2 * H, 2 * W, cin, cout // 4, m.winograd)
         tiles = lib.bbdm_winograd_tiles(wm, N, H, W)
         P = (wm + 2) ** 2
         assert tiles % 256 == 0 and tiles >= N * -(-H // wm) * -(-W // wm)

@@ -39,6 +39,22 @@ SHAPES = [  # N, H, W, Cin, Cout, launches per C2 step (profiles/r02_c2_per_laun
 ]
 
 
+C3_SHAPES = [  # m, N, H, W, Cin, Cout, launches per C3 step (LBBDM-f4 latent 64x64, batch 32: gpurun_out/r03q/c3_per_launch.md)
+    (4, 32, 16, 16, 1024, 1024, 10),
+    (4, 32, 32, 32, 1024, 1024, 2),
+    (4, 32, 32, 32, 512, 512, 6),
+    (6, 32, 64, 64, 512, 512, 2),
+    (4, 32, 16, 16, 2048, 1024, 2),
+    (4, 32, 32, 32, 1536, 512, 1),
+    (6, 32, 64, 64, 128, 128, 7),
+    (4, 32, 32, 32, 1024, 512, 1),
+    (4, 32, 16, 16, 1536, 1024, 1),
+    (4, 32, 32, 32, 640, 512, 1),
+    (6, 32, 64, 64, 640, 128, 1),
+    (6, 32, 64, 64, 256, 128, 2),
+]
+
+
 def _time(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -57,16 +73,18 @@ def main():
     ap.add_argument("--m", type=int, default=6)
     ap.add_argument("--kernels", default="0,1,2,3")
     ap.add_argument("--shapes", default=None, help="indices into SHAPES, comma separated")
+    ap.add_argument("--set", default="c2", choices=("c2", "c3"), help="layer shapes of the C2 step (all m = --m) or of the C3 step")
     args = ap.parse_args()
     kernels = [int(k) for k in args.kernels.split(",")]
     dev = torch.device("cuda:0")
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
-    m, P = args.m, (args.m + 2) ** 2
     tot = {"in_old": 0.0, "in_new": 0.0, "g_old": 0.0, **{f"g{k}": 0.0 for k in kernels}}
     tot_fl = 0.0
-    shapes = SHAPES if args.shapes is None else [SHAPES[int(i)] for i in args.shapes.split(",")]
-    for N, H, W, Cin, Cout, cnt in shapes:
+    allshapes = [(args.m,) + s for s in SHAPES] if args.set == "c2" else C3_SHAPES
+    shapes = allshapes if args.shapes is None else [allshapes[int(i)] for i in args.shapes.split(",")]
+    for m, N, H, W, Cin, Cout, cnt in shapes:
+        P = (m + 2) ** 2
         tiles = lib.bbdm_winograd_tiles(m, N, H, W)
         x = torch.randn(N, H, W, Cin, device=dev)
         sc = torch.rand(N, Cin, device=dev) + 0.5
