@@ -74,7 +74,7 @@ constexpr int LB_OCH = 256;      // outputs per chunk
 
 __global__ void __launch_bounds__(256) linear_bwd_x_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                    float* __restrict__ part, int N, int In, int Out) {
-    __shared__ float dys[64 * LB_OCH];           // [n][o in chunk]
+    __shared__ __attribute__((aligned(16))) float dys[64 * LB_OCH];           // [n][o in chunk]
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int o0 = blockIdx.y * LB_OCH;
     const int on = min(LB_OCH, Out - o0);
@@ -87,7 +87,20 @@ __global__ void __launch_bounds__(256) linear_bwd_x_partial_kernel(const float* 
     float acc[64];
 #pragma unroll
     for (int n = 0; n < 64; ++n) acc[n] = 0.f;
-    for (int o = 0; o < on; ++o) {
+    // four outputs per step: one broadcast ds_read_b128 of dy per row feeds four FMAs (one LDS read per FMA made this kernel
+    // LDS-issue-bound: 490 us for the 51 MB FiLM projection of the LBBDM-f4 UNet); same accumulation order as the scalar loop
+    int o = 0;
+    for (; o + 4 <= on; o += 4) {
+        const float w0 = w[(size_t)(o0 + o) * In + i], w1 = w[(size_t)(o0 + o + 1) * In + i];
+        const float w2 = w[(size_t)(o0 + o + 2) * In + i], w3 = w[(size_t)(o0 + o + 3) * In + i];
+#pragma unroll
+        for (int n = 0; n < 64; ++n)
+            if (n < N) {
+                const float4 d = *reinterpret_cast<const float4*>(&dys[n * LB_OCH + o]);
+                acc[n] = fmaf(d.w, w3, fmaf(d.z, w2, fmaf(d.y, w1, fmaf(d.x, w0, acc[n]))));
+            }
+    }
+    for (; o < on; ++o) {
         const float wv = w[(size_t)(o0 + o) * In + i];
 #pragma unroll
         for (int n = 0; n < 64; ++n)

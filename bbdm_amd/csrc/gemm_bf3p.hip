@@ -614,19 +614,37 @@ extern "C" int bbdm_gemm_bf3p_splitk_f32(const void* a_planes, const void* b_pla
 // C[z][b][M][N], z < bbdm_gemm_bf3p_tn_splits, partial sums over disjoint K ranges (added in a fixed order by the consumer:
 // bbdm_winograd_wgrad_finish_f32 -- deterministic).  K % 16 == 0 (zero-padded), M % 32 == 0, N % 4 == 0.
 namespace {
-struct TnSplit { int splits, kps; };
-TnSplit tn_split(int batch, long long K, int M, int N) {
+struct TnSplit { int splits, kps, wn; };
+// split count for one tile width (256- or 128-column tiles, 256 rows): two workgroups' worth of tiles per CU when K allows
+TnSplit tn_split_for(int batch, long long K, int M, int N, int bn) {
     const int nchunks = (int)(K / KC);
     const int NPad = cdiv(N, 128) * 128;
-    const long long base = (long long)batch * cdiv(M, 256) * (NPad % 256 == 0 ? NPad / 256 : NPad / 128);
-    long long splits = (512 + base - 1) / base;                  // two workgroups' worth of tiles per CU when K allows
+    const long long base = (long long)batch * cdiv(M, 256) * cdiv(NPad, bn);
+    long long splits = (512 + base - 1) / base;
     const long long max_splits = nchunks / 16 > 1 ? nchunks / 16 : 1;     // >= 16 chunks per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     TnSplit t;
     t.kps = (int)((nchunks + splits - 1) / splits);
     t.splits = (nchunks + t.kps - 1) / t.kps;
+    t.wn = bn / 64;
     return t;
+}
+// ... and the tile width: the CU (of the XCD: by_batch launches deal whole batch entries to XCDs) with the most workgroups sets the
+// time = its workgroup count x chunks per workgroup x the tile's cost (256 x 128: half, at 0.94 of the large tile's rate) -- the
+// forward GEMM's rule (bf3p_forward), here with the split count in the model.  Deterministic in (batch, K, M, N): the consumer asks
+// bbdm_gemm_bf3p_tn_splits for the same answer.
+TnSplit tn_split(int batch, long long K, int M, int N) {
+    const int NPad = cdiv(N, 128) * 128;
+    const TnSplit narrow = tn_split_for(batch, K, M, N, 128);
+    if (NPad % 256) return narrow;
+    const TnSplit wide = tn_split_for(batch, K, M, N, 256);
+    auto cost = [&](const TnSplit& t, int bn) {
+        const long long per_entry = (long long)cdiv(M, 256) * cdiv(NPad, bn), nb = (long long)batch * t.splits;
+        const double rounds = nb >= 8 ? (double)((per_entry * ((nb + 7) / 8) + 31) / 32) : (double)((per_entry * nb + 255) / 256);
+        return rounds * (t.kps + 4) * (bn == 256 ? 1.0 : 0.5 / 0.94);           // (+ 4 chunks: prologue / epilogue of a workgroup)
+    };
+    return cost(wide, 256) <= cost(narrow, 128) ? wide : narrow;
 }
 }  // namespace
 
@@ -663,7 +681,7 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
     a.batch = nb;
     a.by_batch = (by_batch_env && nb >= 8) ? 1 : 0;              // (the pipe kernel returns early for the padding entries of a batch % 8 != 0)
     hipStream_t st = (hipStream_t)stream;
-    const int rc = NPad % 256 == 0 ? bf3p_launch<4, 4, 1, false>(a, nb, st) : bf3p_launch<4, 2, 1, false>(a, nb, st);
+    const int rc = sp.wn == 4 ? bf3p_launch<4, 4, 1, false>(a, nb, st) : bf3p_launch<4, 2, 1, false>(a, nb, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p_tn");
     return BBDM_OK;

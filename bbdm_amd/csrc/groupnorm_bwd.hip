@@ -31,8 +31,11 @@ struct BwdArgs {
     int silu, resample, accumulate;
 };
 
+// silu'(v) = s (1 + v (1 - s)), s = sigmoid(v), on the hardware v_exp_f32 + v_rcp_f32 (~2 ulp each; gradient bar 1e-3): both streaming
+// passes evaluate it per element, and the IEEE expf + division sequence (~25 VALU instructions) made them ALU-bound -- the same trade
+// as silu_fast in the Winograd input transform (common.h)
 __device__ __forceinline__ float dsilu(float v) {
-    const float s = 1.0f / (1.0f + expf(-v));
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
     return s * (1.0f + v * (1.0f - s));
 }
 

@@ -45,6 +45,8 @@ class _Flags:
         self.winograd = int(os.environ.get("BBDM_WINOGRAD", "6"))
         self.winograd_fuse_groupnorm = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
         self.winograd_small = os.environ.get("BBDM_WINOGRAD_SMALL", "1") != "0"
+        self.upsample_phases = os.environ.get("BBDM_UPSAMPLE_PHASES", "1") != "0"
+        self.train_graph = False
         self.gemm_bf3 = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
         self.gemm_bf3p = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
         self.fuse_groupnorm = False

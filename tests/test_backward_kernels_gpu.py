@@ -29,7 +29,9 @@ CONV_BWD = [(2, 16, 16, 32, 64, 3), (1, 24, 40, 64, 128, 3), (3, 8, 8, 128, 96, 
             (2, 16, 16, 64, 192, 1), (1, 13, 9, 8, 3, 3), (8, 32, 32, 128, 128, 3), (2, 8, 8, 4, 32, 3),
             # the layer shapes of the 237 M-parameter UNet at a 64x64 latent, batch 2 (split-K tiles, 4-16 Cout tiles)
             (2, 16, 16, 1024, 1024, 3), (2, 16, 16, 2048, 1024, 3), (2, 32, 32, 1536, 512, 3), (2, 64, 64, 640, 128, 3),
-            (2, 16, 16, 2048, 1024, 1), (2, 64, 64, 128, 128, 3), (2, 32, 32, 512, 512, 3)]
+            (2, 16, 16, 2048, 1024, 1), (2, 64, 64, 128, 128, 3), (2, 32, 32, 512, 512, 3),
+            # more 1x1 weight gradients (TN GEMM over the pixels): ragged channel tiles, K splits, a short K
+            (4, 16, 16, 160, 132, 1), (32, 16, 16, 1024, 512, 1), (3, 8, 8, 96, 72, 1)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks", CONV_BWD)

@@ -159,7 +159,7 @@ def test_conv_with_fused_groupnorm_producer(N, H, W, C, Cout, ks, film, silu):
 
 # ---- backward kernels -------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks", [(2, 16, 16, 32, 64, 3), (3, 8, 8, 128, 96, 3), (2, 16, 16, 64, 192, 1),
-                                               (1, 13, 9, 8, 3, 3), (2, 8, 8, 4, 32, 3)])
+                                               (1, 13, 9, 8, 3, 3), (2, 8, 8, 4, 32, 3), (1, 16, 16, 96, 68, 1)])
 def test_conv_backward(N, H, W, Cin, Cout, ks):
     BK.test_conv_backward(CPU, N, H, W, Cin, Cout, ks)
 

@@ -228,3 +228,11 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
         ref = sdg[k].grad
         scale = max(float(ref.abs().max()), 1e-3 * gmax)
         assert float((p.grad - ref).abs().max()) / scale < T.GRAD_TOL, k
+
+
+def test_first_stage_plans_on_the_emulator():
+    """The VQGAN first stage's encode / decode plans (bbdm_amd/first_stage_hip.py: the UNet plan's emitters driven by its own flag set)
+    on the CPU-emulated kernels against the PyTorch first stage -- the build-container check that the first stage's flag set knows
+    every switch the shared emitters read (a missing one surfaced only on the GPU box in round 3)."""
+    import first_stage_cases as C
+    C.encode_decode_parity(CPU, N=1, resolution=16, attn_resolutions=[8])

@@ -310,14 +310,18 @@ def test_upsample_conv_folded_into_the_winograd_input_transform(dev):
     with torch.no_grad():
         ref = ora.denoise(x, t, None)
     m = m.to(dev).eval()
-    for wino in (4, 0):
-        m.denoise_fn.winograd = wino
+    for wino, phases in ((4, True), (4, False), (0, True)):
+        m.denoise_fn.winograd, m.denoise_fn.upsample_phases = wino, phases
         with torch.no_grad():
             out = m.denoise_fn(x.to(dev), timesteps=t.to(dev), context=None)
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         plan = m.denoise_fn._plan_for(x.to(dev), False)
+        # round 3: the conv runs as its four phase filters on the LOW-resolution tensor (output transform scatters the phases,
+        # flag 8); upsample_phases = False: the round-2 form, index shift inside the input transform of the upsampled size
         folded = sum(n == "bbdm_winograd_input_f32" and a[8] == 1 for n, a in plan.ops)
-        assert folded == (1 if wino else 0)
+        as_phases = sum(n == "bbdm_winograd_output_f32" and a[7] == 8 for n, a in plan.ops)
+        assert (folded, as_phases) == ((0, 1) if (wino and phases) else (1, 0) if wino else (0, 0))
         e = rel_err(out.cpu(), ref)
-        print(f"winograd={wino}: {folded} upsample conv folded; UNet forward rel err {e:.2e}")
+        print(f"winograd={wino} phases={phases}: {folded} folded / {as_phases} as phase filters; UNet forward rel err {e:.2e}")
         assert e < 1e-4
