@@ -20,6 +20,7 @@
 namespace {
 
 constexpr int KT = 32;        // keys per tile
+constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
 
 // BQ: S^T = K Q^T on the BF16 matrix core with fp32 accuracy (bf3_split.h: both operands split exactly into three bf16 planes,
 // six product terms, fp32 accumulate): 6 x CH/16 MFMAs of 32 cycles per key tile instead of CH/2 of 64 -- 2.7x less matrix-core
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
     const int qblocks = (Tq + QB - 1) / QB;
+    qscale *= LOG2E;                               // softmax in base 2: exp(x) = 2^(x log2 e)
     // XCD x (block id % 8) owns the (image, head) pairs x, x + 8, ...: all query blocks of a pair share its K / V through one L2
     const int L = (int)blockIdx.x, slot = L >> 3;
     const int qb = slot % qblocks;
@@ -214,21 +216,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
         }
 
         // ---- online softmax over the 32 keys of this tile (16 here, 16 in lane^32) --------------------------------
-        const int key0 = tile * KT + 4 * hi;
+        // (scores carry the factor log2 e -- folded into the q scale above -- so that the exponentials are bare v_exp_f32; keys
+        // beyond T exist only in the last tile: the 32 compare / select pairs stay out of every other iteration)
+        if (tile * KT + KT > T) {
+            const int key0 = tile * KT + 4 * hi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) >= T) s[r] = -INFINITY;
+        }
         float mt = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = key0 + (r & 3) + 8 * (r >> 2);
-            if (key >= T) s[r] = -INFINITY;
-            mt = fmaxf(mt, s[r]);
-        }
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __expf(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
             psum += s[r];
         }
         psum += __shfl_xor(psum, 32);
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
     // ---- epilogue: O^T / l -> LDS [query][c] -> coalesced rows ----------------------------------------------------
     float* obuf = smem;
     const float inv = 1.0f / l_run;
-    if (lse && hi == 0 && q < Tq) lse[((size_t)n * heads + h) * Tq + q] = m_run + logf(l_run);   // for the backward pass
+    if (lse && hi == 0 && q < Tq) lse[((size_t)n * heads + h) * Tq + q] = m_run * LN2 + logf(l_run);   // for the backward pass (natural log)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll

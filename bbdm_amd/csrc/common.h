@@ -54,6 +54,25 @@ static inline void bbdm_zero_async(void* p, size_t bytes, hipStream_t st) {
     hipLaunchKernelGGL(bbdm_zero8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned long long*)p, n);
 }
 
+// Data that is written once and read once by the NEXT launch (the Winograd planes V and M: 0.5 - 7 GB per layer, many times the 256 MB
+// Infinity Cache) moves with the `nt` policy: it does not displace the lines that are re-read (the halo columns of x, the weights).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_nt(unsigned* p, unsigned v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_nt(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ float2 load_nt(const float2* p) {
+    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    return make_float2(v.x, v.y);
+}
+#ifndef BBDM_NT_VSTORE
+#define BBDM_NT_VSTORE 0
+#endif
+#ifndef BBDM_NT_MLOAD
+#define BBDM_NT_MLOAD 0
+#endif
+#ifndef BBDM_NT_MSTORE
+#define BBDM_NT_MSTORE 0
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int ceil_pow2(int v) {
     int p = 1;

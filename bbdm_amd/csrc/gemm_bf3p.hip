@@ -378,7 +378,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
                     const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
                     float v = acc[i][j][r] + bv[j];
                     if (RES) v += rv[rr][j];
+#if BBDM_NT_MSTORE
+                    if (co < a.Cout && row < a.T) store_nt(dst + co, v);
+#else
                     if (co < a.Cout && row < a.T) dst[co] = v;
+#endif
                 }
             }
         }

@@ -126,8 +126,8 @@ __device__ __forceinline__ void stat_add(double* lsum, const StatArgs& st, int n
         }
     }
 }
-__device__ __forceinline__ void stat_flush(const double* lsum, const StatArgs& st, int n0, int N) {
-    for (int i = threadIdx.x; i < ST_DOUBLES; i += 256) {
+__device__ __forceinline__ void stat_flush(const double* lsum, const StatArgs& st, int n0, int N, int nthreads = 256) {
+    for (int i = threadIdx.x; i < ST_DOUBLES; i += nthreads) {
         const int k = i / (ST_IMGS * 64), rem = i - k * (ST_IMGS * 64);
         const int n = n0 + rem / 64;
         const double v = lsum[i];
@@ -510,9 +510,15 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
 #pragma unroll
         for (int jj = 0; jj < AL; ++jj) {
             split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
+#if BBDM_NT_VSTORE
+            store_nt(reinterpret_cast<unsigned*>(o), pl[jj][0]);
+            store_nt(reinterpret_cast<unsigned*>(o + 1024), pl[jj][1]);
+            store_nt(reinterpret_cast<unsigned*>(o + 2048), pl[jj][2]);
+#else
             *reinterpret_cast<unsigned*>(o) = pl[jj][0];
             *reinterpret_cast<unsigned*>(o + 1024) = pl[jj][1];
             *reinterpret_cast<unsigned*>(o + 2048) = pl[jj][2];
+#endif
             o += plane;
         }
         if (TR)     // row i of the intermediate has been consumed: its LDS region (this wave's alone from here on) is the scratch
@@ -617,7 +623,11 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
         for (int j = 0; j < AL; ++j) {
             float2 v[AL], sj[MO];
 #pragma unroll
+#if BBDM_NT_MLOAD
+            for (int i = 0; i < AL; ++i) v[i] = load_nt(reinterpret_cast<const float2*>(m + (size_t)(i * AL + j) * plane));
+#else
             for (int i = 0; i < AL; ++i) v[i] = *reinterpret_cast<const float2*>(m + (size_t)(i * AL + j) * plane);
+#endif
             at_transform<MO>(v, sj);
 #pragma unroll
             for (int a = 0; a < MO; ++a) s[a][j] = sj[a];
@@ -665,6 +675,95 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
     if (stats) {
         __syncthreads();
         stat_flush(lsum, st, n0, N);
+    }
+}
+
+// ---- the m = 6 output transform in two phases through LDS (the counterpart of winograd_input_split2_kernel) ---------------------------
+// winograd_output6_kernel keeps the 8 x 8 window of its channel pair in registers and the compiler has all 64 loads (and the residual
+// rows) in flight at once: 245 VGPRs, TWO waves per SIMD, and its ablation (tools/wino_variants.py) shows the load stream, the store
+// stream and the arithmetic overlapping poorly (loads alone 0.165 ms, stores alone 0.159 ms, together 0.248 ms at 64x64 x 1024).
+// Here a workgroup owns ONE tile x 128 consecutive channels of M (lane = channel pair: every access of a wave is 512 contiguous
+// bytes) and its 8 waves split the window:
+//   phase A: wave j loads column j of the window (xi = (0..7, j): 8 loads per lane, issued together; M is read once: `nt`), transforms
+//            it down the rows (A^T m: 8 -> 6) and leaves the 6 results in LDS [a][j][lane];
+//   phase B: wave a < 6 reads row a of the intermediate, transforms it (. A: 8 -> 6), adds bias / residual, stores the 6 pixels of
+//            output row a and adds its GroupNorm partial sums to the workgroup's LDS table (flushed as in the kernel above).
+// ~50 VGPRs, 24 KB of LDS: four workgroups = 32 waves per CU.  Needs Cm % 128 == 0 (and Cout % 128 == 0 with the phase filters, so
+// that a channel block lies inside one phase); other shapes keep winograd_output6_kernel.
+template <bool RES>
+__global__ void __launch_bounds__(512) winograd_output6_lds_kernel(const float* __restrict__ M, size_t plane, int ldm,
+                                                                   const float* __restrict__ bias,
+                                                                   const float* __restrict__ res, int ldr, int res_per_image,
+                                                                   float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
+                                                                   int cblocks, const StatArgs st, int ph) {
+    constexpr int MO = 6, AL = 8;
+    __shared__ float2 lds[MO * AL * 64];
+    __shared__ double lsum[ST_DOUBLES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = (int)(blockIdx.x % (unsigned)cblocks);
+    const long long tile = blockIdx.x / (unsigned)cblocks;
+    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const int tw = (int)(tile % TW);
+    const long long r = tile / TW;
+    const int th = (int)(r % TH), n = (int)(r / TH);
+    const int cm = cb * 128 + 2 * lane;                       // channel of M
+    const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;    // phase filter, output channel
+    const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
+    if (stats)
+        for (int i = threadIdx.x; i < ST_DOUBLES; i += 512) lsum[i] = 0.0;
+    {   // ---- phase A: column `wave` of the window ------------------------------------------------------------------------------
+        const int j = wave;
+        const float* m = M + (size_t)tile * ldm + cm + (size_t)j * plane;
+        float2 v[AL], sj[MO];
+#pragma unroll
+        for (int i = 0; i < AL; ++i) v[i] = load_nt(reinterpret_cast<const float2*>(m + (size_t)(i * AL) * plane));
+        at_transform<MO>(v, sj);
+#pragma unroll
+        for (int a = 0; a < MO; ++a) lds[(a * AL + j) * 64 + lane] = sj[a];
+    }
+    __syncthreads();
+    if (wave < MO) {   // ---- phase B: output row `wave` -----------------------------------------------------------------------------
+        const int a = wave;
+        float2 t[AL], o[MO];
+#pragma unroll
+        for (int j = 0; j < AL; ++j) t[j] = lds[(a * AL + j) * 64 + lane];
+        const int oh = MO * th + a;
+        if (oh < H) {
+            float2 rv[MO];
+            if (RES) {     // the residuals of the row are fetched together (clamped addresses for the masked edge pixels)
+#pragma unroll
+                for (int b = 0; b < MO; ++b) {
+                    const int owc = min(MO * tw + b, W - 1);
+                    const float* rp = res_per_image == 1 ? res + (size_t)n * ldr + c
+                                      : res_per_image == 2 ? res + ((size_t)(n * (H >> 1) + (oh >> 1)) * (W >> 1) + (owc >> 1)) * ldr + c
+                                                           : res + ((size_t)(n * H + oh) * W + owc) * ldr + c;
+                    rv[b] = *reinterpret_cast<const float2*>(rp);
+                }
+            }
+            at_transform<MO>(t, o);
+            const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
+            double psum = 0.0, psq = 0.0;
+#pragma unroll
+            for (int b = 0; b < MO; ++b) {
+                const int ow = MO * tw + b;
+                if (ow < W) {
+                    float2 val = o[b] + b2;
+                    if (RES) val = val + rv[b];
+                    const size_t pix = ph ? (size_t)(n * 2 * H + 2 * oh + (pq >> 1)) * (2 * W) + 2 * ow + (pq & 1)
+                                          : (size_t)(n * H + oh) * W + ow;
+                    *reinterpret_cast<float2*>(y + pix * ldy + c) = val;
+                    if (stats) {
+                        psum += (double)val.x + (double)val.y;
+                        psq += (double)val.x * val.x + (double)val.y * val.y;
+                    }
+                }
+            }
+            if (stats) stat_add(lsum, st, 0, n, c, psum, psq);
+        }
+    }
+    if (stats) {
+        __syncthreads();
+        stat_flush(lsum, st, n, N, 512);
     }
 }
 
@@ -995,6 +1094,19 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : (flags & BBDM_CONV_RES_UPSAMPLE) ? 2 : 0;     // residual addressing mode
     const dim3 g((unsigned)blocks), b(256);
     hipStream_t s_ = (hipStream_t)stream;
+    // BBDM_WINO_OUTPUT_LDS=0: the one-thread-per-window kernel for every m = 6 shape (A/B; see winograd_output6_lds_kernel)
+    static const int two_phase = [] { const char* e = getenv("BBDM_WINO_OUTPUT_LDS"); return e ? atoi(e) : 1; }();
+    if (m == 6 && two_phase && Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
+        const dim3 g2((unsigned)(T * (size_t)(Cm / 128)));
+        if (residual)
+            hipLaunchKernelGGL(winograd_output6_lds_kernel<true>, g2, dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi,
+                               out, ldo, N, H, W, Cout, Cm / 128, st, ph);
+        else
+            hipLaunchKernelGGL(winograd_output6_lds_kernel<false>, g2, dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi,
+                               out, ldo, N, H, W, Cout, Cm / 128, st, ph);
+        BBDM_CHECK_LAUNCH("winograd_output");
+        return BBDM_OK;
+    }
     if (m == 6 && residual)
         hipLaunchKernelGGL(winograd_output6_kernel<true>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out,
                            ldo, N, H, W, Cout, (int)iters, st, ph);

@@ -58,7 +58,7 @@ def test_gemm_bf3p_matches_bf3_bitwise(batch, T, Cin, Cout, extra):
     K.test_gemm_bf3p_matches_bf3_bitwise(CPU, batch, T, Cin, Cout, extra)
 
 
-@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8)])
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 128)])
 def test_winograd_output_adds_upsampled_residual(m, N, H, W, Cin, Cout):
     K.test_winograd_output_adds_upsampled_residual(CPU, m, N, H, W, Cin, Cout)
 
@@ -70,7 +70,8 @@ def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):
     K.test_gemm_bf3p_kernel_variants(CPU, kernel, batch, T, Cin, Cout)
 
 
-@pytest.mark.parametrize("m,N,H,W,Cin,Cout,pre", [(6, 1, 7, 11, 16, 40, 1), (4, 1, 8, 8, 16, 32, 0), (2, 2, 4, 6, 16, 8, 1)])
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout,pre", [(6, 1, 7, 11, 16, 40, 1), (4, 1, 8, 8, 16, 32, 0), (2, 2, 4, 6, 16, 8, 1),
+                                                  (6, 1, 7, 11, 16, 128, 1)])
 def test_upsample_conv_as_phase_filters(m, N, H, W, Cin, Cout, pre):
     K.test_upsample_conv_as_phase_filters(CPU, m, N, H, W, Cin, Cout, pre)
 
@@ -96,7 +97,8 @@ def test_conv1x1_bf3(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3(CPU, pixels, Cin, Cout, res)
 
 
-@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 14, 20, 32, 64), (4, 3, 8, 12, 16, 128), (6, 9, 6, 6, 16, 32)])
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 14, 20, 32, 64), (4, 3, 8, 12, 16, 128), (6, 9, 6, 6, 16, 32), (6, 2, 14, 20, 16, 128),
+                                              (6, 3, 7, 9, 16, 256)])
 def test_winograd_output_accumulates_groupnorm_statistics(m, N, H, W, Cin, Cout):
     K.test_winograd_output_accumulates_groupnorm_statistics(CPU, m, N, H, W, Cin, Cout)
 

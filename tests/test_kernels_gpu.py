@@ -428,7 +428,8 @@ def test_upsample_conv_as_phase_filters(dev, m, N, H, W, Cin, Cout, pre):
         assert float((stats.cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
 
 
-@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72)])
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72),
+                                              (6, 2, 14, 10, 16, 128)])
 def test_winograd_output_adds_upsampled_residual(dev, m, N, H, W, Cin, Cout):
     """BBDM_CONV_RES_UPSAMPLE: the output transform adds a residual given at half the resolution, nearest-upsampled x2 -- the
     skip path x_upd(x) of an up-sampling ResBlock (openaimodel.py:259-264) without a resampling pass."""
@@ -529,7 +530,8 @@ def _group_sums(y_nhwc, cpg, coff, ctot_groups=32):
     return out
 
 
-@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 14, 20, 32, 64), (4, 3, 8, 12, 16, 128), (2, 5, 4, 4, 16, 32), (6, 9, 6, 6, 16, 32)])
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 14, 20, 32, 64), (4, 3, 8, 12, 16, 128), (2, 5, 4, 4, 16, 32), (6, 9, 6, 6, 16, 32),
+                                              (6, 2, 14, 20, 16, 128), (6, 3, 7, 9, 16, 256), (6, 2, 64, 64, 64, 512)])
 def test_winograd_output_accumulates_groupnorm_statistics(dev, m, N, H, W, Cin, Cout):
     """bbdm_winograd_output_stats_f32: the output transform also accumulates the (image, group) sums two GroupNorm consumers
     need -- the next block's norm over [Cout] and an output block's norm over a concat [Cout' + Cout] -- so that no separate
@@ -550,7 +552,8 @@ def test_winograd_output_accumulates_groupnorm_statistics(dev, m, N, H, W, Cin, 
     V = torch.zeros(P * tiles * Cin, device=dev)
     M = torch.zeros(P * tiles * Cout, device=dev)
     out = r.clone().to(dev)                                       # in-place residual
-    cpg0, cpg1, coff1 = Cout // 32 * 4 if Cout >= 128 else 4, 8, 64          # consumer 1: a [64 + Cout]-channel concat
+    cpg0, coff1 = Cout // 32 * 4 if Cout >= 128 else 4, 64                   # consumer 1: a [64 + Cout]-channel concat
+    cpg1 = max(8, (-(-(coff1 + Cout) // 32) + 3) // 4 * 4)
     s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
     s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
     _lib.call("bbdm_winograd_input_f32", m, xg.data_ptr(), Cin, V.data_ptr(), None, None, 0, 0, 0, N, H, W, Cin, st)

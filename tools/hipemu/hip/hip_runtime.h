@@ -255,6 +255,7 @@ static inline void hipemu_wave_barrier() { int dummy = 0; hipemu::wave_publish(&
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 #define __builtin_amdgcn_rcpf(v) (1.0f / (v))
+#define __builtin_amdgcn_exp2f(v) exp2f(v)
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)

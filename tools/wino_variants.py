@@ -18,32 +18,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bbdm_amd", "csrc")
 SRC = open(os.path.join(CSRC, "winograd.hip")).read()
 
-IN_STORE = """            *reinterpret_cast<unsigned*>(o) = p1;
-            *reinterpret_cast<unsigned*>(o + 1024) = p2;
-            *reinterpret_cast<unsigned*>(o + 2048) = p3;
-            o += plane;
-        }
-        __builtin_amdgcn_sched_barrier(0);"""
-IN_LOAD = "            d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);\n        }\n#pragma unroll\n        for (int i = 0; i < AL; ++i) {\n            const int h = MO * th - 1 + i;\n            const float mask = (h >= 0 && h < H) ? wmask : 0.f;\n            float2 v = d[i];\n            if (PRE) {\n                v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;\n                if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }\n            }\n            d[i] = make_float2(mask * v.x, mask * v.y);\n        }\n        bt_transform<MO>(d, col);\n#pragma unroll\n        for (int i = 0; i < AL; ++i) t[i][jj] = col[i];"
+# anchors in winograd_input_split2_kernel (the two-phase kernel, the default) and its launcher
+IN_STORE = """            *reinterpret_cast<unsigned*>(o) = pl[jj][0];
+            *reinterpret_cast<unsigned*>(o + 1024) = pl[jj][1];
+            *reinterpret_cast<unsigned*>(o + 2048) = pl[jj][2];"""
+IN_LOAD = "                d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);"
+IN_MAP = "    const int chunk = q % nchunks, tg = (q / nchunks) * 8 + (L & 7);"
+IN_BLOCKS = "        const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;"
+IN_PLANE = "    const size_t plane = Tp * (size_t)CinPad * 6;"
+PAD_BYTES = 4352            # 17 x 256 B
 
 
-def in_variant(kind):
-    s = SRC
-    assert IN_STORE in s and IN_LOAD in s, "csrc/winograd.hip changed: update the patch anchors"
+def in_variant(kind, s=None):
+    s = SRC if s is None else s
+    for a in (IN_STORE, IN_LOAD, IN_MAP, IN_BLOCKS, IN_PLANE) if s is SRC else ():
+        assert a in s, "csrc/winograd.hip changed: update the patch anchors: " + a
     if kind == "no_store":          # keep the arithmetic alive: store only for a value that never occurs
-        s = s.replace(IN_STORE, IN_STORE.replace("            *reinterpret_cast<unsigned*>(o) = p1;",
-                                                 "            if (p1 == 0x7fc12345u && p2 == 0x7fc54321u) *reinterpret_cast<unsigned*>(o) = p1;")
-                      .replace("            *reinterpret_cast<unsigned*>(o + 1024) = p2;\n", "")
-                      .replace("            *reinterpret_cast<unsigned*>(o + 2048) = p3;\n", "            if (p3 == 0x7fc99999u) *reinterpret_cast<unsigned*>(o + 2048) = p3;\n"))
+        s = s.replace(IN_STORE, "            if (pl[jj][0] == 0x7fc12345u && pl[jj][1] == 0x7fc54321u && pl[jj][2] == 0x7fc99999u) *reinterpret_cast<unsigned*>(o) = pl[jj][0];")
     elif kind == "no_load":
-        s = s.replace(IN_LOAD, IN_LOAD.replace("d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);",
-                                               "d[i] = make_float2((float)(hs + wsrc) * 1e-3f, (float)(c + n) * 1e-3f);"))
+        s = s.replace(IN_LOAD, "                d[i] = make_float2((float)(hs + wsrc) * 1e-3f, (float)(c + n) * 1e-3f);")
     elif kind == "nt_store":
-        s = s.replace(IN_STORE, IN_STORE.replace("*reinterpret_cast<unsigned*>(o) = p1;", "__builtin_nontemporal_store(p1, reinterpret_cast<unsigned*>(o));")
-                      .replace("*reinterpret_cast<unsigned*>(o + 1024) = p2;", "__builtin_nontemporal_store(p2, reinterpret_cast<unsigned*>(o + 1024));")
-                      .replace("*reinterpret_cast<unsigned*>(o + 2048) = p3;", "__builtin_nontemporal_store(p3, reinterpret_cast<unsigned*>(o + 2048));"))
+        s = s.replace(IN_STORE, "\n".join("            __builtin_nontemporal_store(pl[jj][%d], reinterpret_cast<unsigned*>(o + %d));" % (p, 1024 * p) for p in range(3)))
+    elif kind == "remap":           # the four 8-tile groups of a 32-row fragment unit run back to back on ONE XCD
+        s = s.replace(IN_MAP, "    const int chunk = (q >> 2) % nchunks, tg = (((q >> 2) / nchunks) * 8 + (L & 7)) * 4 + (q & 3);")
+        s = s.replace(IN_BLOCKS, "        const long long blocks = 8ll * ((TG + 31) / 32) * 4 * nchunks;")
+    elif kind == "remapc":          # ... chunk-major inside the XCD: a unit's four pieces are written further apart, the input line halves closer
+        s = s.replace(IN_MAP, "    const int chunk = q % nchunks, tg = (((q / nchunks) >> 2) * 8 + (L & 7)) * 4 + ((q / nchunks) & 3);")
+        s = s.replace(IN_BLOCKS, "        const long long blocks = 8ll * ((TG + 31) / 32) * 4 * nchunks;")
+    elif kind == "pad":             # plane pitch off the power-of-two multiples
+        s = s.replace(IN_PLANE, IN_PLANE.replace(";", " + %d;" % PAD_BYTES))
+    elif "+" in kind:               # combinations: apply the parts in turn
+        for part in kind.split("+"):
+            s = in_variant(part, s)
     elif kind.startswith("lb"):     # min waves per SIMD -> VGPR cap 512 / n
-        s = s.replace("__global__ void __launch_bounds__(256) winograd_input_split_kernel", f"__global__ void __launch_bounds__(256, {kind[2:]}) winograd_input_split_kernel")
+        s = s.replace("__global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel", f"__global__ void __launch_bounds__((MO + 2) * 64, {kind[2:]}) winograd_input_split2_kernel")
     elif kind != "full":
         raise ValueError(kind)
     assert kind == "full" or s != SRC
@@ -51,19 +59,52 @@ def in_variant(kind):
 
 
 OUT_LOAD = "            for (int i = 0; i < AL; ++i) v[i] = *reinterpret_cast<const float2*>(m + (size_t)(i * AL + j) * plane);"
-OUT_STORE = "                    *reinterpret_cast<float2*>(y + ((size_t)(n * H + oh) * W + ow) * ldy + c) = val;"
+OUT_STORE = "                    *reinterpret_cast<float2*>(y + pix * ldy + c) = val;"
 
 
 def out_variant(kind):
     s = SRC
     assert OUT_LOAD in s and OUT_STORE in s, "csrc/winograd.hip changed: update the patch anchors"
     if kind == "no_store":
-        s = s.replace(OUT_STORE, "                    if (val.x == 1.2345e33f) *reinterpret_cast<float2*>(y + ((size_t)(n * H + oh) * W + ow) * ldy + c) = val;")
+        s = s.replace(OUT_STORE, "                    if (val.x == 1.2345e33f) *reinterpret_cast<float2*>(y + pix * ldy + c) = val;")
     elif kind == "no_load":
         s = s.replace(OUT_LOAD, "            for (int i = 0; i < AL; ++i) v[i] = make_float2((float)(i + j + c) * 1e-3f, (float)(tw + th) * 1e-3f);")
     elif kind == "nt_load":
         s = s.replace(OUT_LOAD, "            for (int i = 0; i < AL; ++i) { const float* q = m + (size_t)(i * AL + j) * plane; "
                                 "v[i] = make_float2(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)); }")
+    elif kind == "no_stats":
+        assert s.count("    const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;") >= 2
+        s = s.replace("    const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;", "    const bool stats = false;")
+    elif kind == "st_noflush":      # statistics: per-thread sums + LDS atomics, no global atomics
+        assert s.count("        stat_flush(lsum, st, n0, N);") >= 2
+        s = s.replace("        stat_flush(lsum, st, n0, N);", "        if (lsum[threadIdx.x] == 1.2345e300) stat_flush(lsum, st, n0, N);")
+    elif kind == "st_noadd":        # statistics: per-thread sums only
+        s = s.replace("        if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);", "        if (stats && psum == 1.2345e300 && psq == 1.0) stat_add(lsum, st, n - n0, n, c, psum, psq);")
+    elif kind == "st_f32row":       # statistics: the 6 pixels of an output row summed in fp32, rows in fp64
+        a = """                    if (stats) {
+                        psum += (double)val.x + (double)val.y;
+                        psq += (double)val.x * val.x + (double)val.y * val.y;
+                    }
+                }
+            }
+        }
+        if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);"""
+        assert a in s
+        s = s.replace(a, """                    if (stats) {
+                        rsum += val.x + val.y;
+                        rsq = fmaf(val.x, val.x, fmaf(val.y, val.y, rsq));
+                    }
+                }
+            }
+            psum += (double)rsum; psq += (double)rsq;
+        }
+        if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);""")
+        b = "            float2 rv[MO];\n            if (RES) {"
+        assert b in s
+        s = s.replace(b, "            float rsum = 0.f, rsq = 0.f;\n" + b)
+    elif kind == "pad":
+        assert s.count("Tp * (size_t)Cm, Cm, bias") == 2
+        s = s.replace("Tp * (size_t)Cm, Cm, bias", "Tp * (size_t)Cm + %d, Cm, bias" % (PAD_BYTES // 4))
     elif kind.startswith("lb"):
         s = s.replace("__global__ void __launch_bounds__(256) winograd_output6_kernel", f"__global__ void __launch_bounds__(256, {kind[2:]}) winograd_output6_kernel")
     elif kind != "full":
@@ -104,15 +145,22 @@ def main():
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     P_, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
-    shapes = [(16, 64, 64, 1024), (16, 256, 256, 128), (16, 128, 128, 512)]
+    shapes = [(16, 64, 64, 1024), (16, 256, 256, 128), (16, 128, 128, 512), (16, 128, 128, 1024)]
     m, P = 6, 64
-    for side, kinds, variant in (("input (writes 3 bf16 planes)", ("full", "no_store", "no_load", "nt_store", "lb3"), in_variant),
-                                 ("output (+ residual, + GroupNorm statistics)", ("full", "no_store", "no_load", "nt_load", "lb3", "lb4"), out_variant)):
+    sides = (("input (writes 3 bf16 planes)", ("full", "nt_store", "nt_store+pad", "nt_store+remap", "nt_store+pad+remap", "pad+remap"), in_variant),
+             ("output (+ residual, + GroupNorm statistics)", ("full", "no_store", "no_load", "nt_load", "no_stats", "st_noflush", "st_noadd", "st_f32row", "pad"), out_variant))
+    only = args.only.split(",") if args.only else None
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(("in_" if side.startswith("input") else "out_") + kind, variant(kind)) for side, kinds, variant in sides for kind in kinds
+            if not only or kind in only]
+    with ThreadPoolExecutor(len(jobs)) as ex:            # hipcc runs side by side (~15 s each)
+        libs = dict(zip((j[0] for j in jobs), ex.map(lambda j: build(*j), jobs)))
+    for side, kinds, variant in sides:
         print(side)
         for kind in kinds:
-            if args.only and kind not in args.only.split(","):
+            if only and kind not in only:
                 continue
-            lib = build(("in_" if side.startswith("input") else "out_") + kind, variant(kind))
+            lib = libs[("in_" if side.startswith("input") else "out_") + kind]
             lib.bbdm_winograd_tiles.restype = ctypes.c_size_t
             lib.bbdm_winograd_input_bf3p_f32.argtypes = [I, P_, I, P_, P_, P_, I, I, I, I, I, I, I, P_]
             lib.bbdm_winograd_output_stats_f32.argtypes = [I, P_, P_, P_, I, P_, I, I, I, I, I, I, P_, I, I, P_, I, I, P_]
@@ -122,12 +170,12 @@ def main():
                 x = torch.randn(N, H, W, C, device=dev)
                 if side.startswith("input"):
                     sc, bi = torch.rand(N, C, device=dev) + 0.5, torch.randn(N, C, device=dev) * 0.1
-                    Vp = torch.empty(P * tiles * C * 6, dtype=torch.uint8, device=dev)
+                    Vp = torch.empty(P * (tiles * C * 6 + PAD_BYTES), dtype=torch.uint8, device=dev)
                     fn = lambda: lib.bbdm_winograd_input_bf3p_f32(m, x.data_ptr(), C, Vp.data_ptr(), sc.data_ptr(), bi.data_ptr(), C, 1, 0,
                                                                   N, H, W, C, st)
                     gb = (x.numel() * 4 + P * tiles * C * 6) / 1e9
                 else:
-                    M = torch.randn(P * tiles * C, device=dev)
+                    M = torch.randn(P * (tiles * C + PAD_BYTES // 4), device=dev)
                     b = torch.randn(C, device=dev)
                     y = torch.empty_like(x)
                     stats = torch.zeros(N * 64, dtype=torch.float64, device=dev)
