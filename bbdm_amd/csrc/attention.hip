@@ -223,6 +223,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (key0 + (r & 3) + 8 * (r >> 2) >= T) s[r] = -INFINITY;
+            BBDM_KEEP_IN_BRANCH(s);                  // (if-converted, the 32 selects would run in every iteration again)
         }
         float mt = -INFINITY;
 #pragma unroll
@@ -238,11 +239,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
         }
         psum += __shfl_xor(psum, 32);
         l_run = l_run * alpha + psum;
+        const float m_run_prev = m_run;
         m_run = m_new;
+        if (__ballot(m_new != m_run_prev) != 0ull) {   // the running maximum rarely moves after the first tiles: no rescale then (alpha == 1)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+                BBDM_KEEP_IN_BRANCH(o[ct]);
+            }
+        }
 
         // ---- O^T += V^T P^T ------------------------------------------------------------------------------------
         if (BV) {

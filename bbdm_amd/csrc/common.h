@@ -63,6 +63,11 @@ __device__ __forceinline__ float2 load_nt(const float2* p) {
     const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
     return make_float2(v.x, v.y);
 }
+// An empty asm that "modifies" v inside a rarely taken wave-uniform branch: without it the compiler if-converts the branch and runs its
+// selects / multiplies in every iteration (tools/hipemu defines it away).
+#ifndef BBDM_KEEP_IN_BRANCH
+#define BBDM_KEEP_IN_BRANCH(v) asm volatile("" : "+v"(v))
+#endif
 #ifndef BBDM_NT_VSTORE
 #define BBDM_NT_VSTORE 0
 #endif

@@ -40,6 +40,7 @@ struct Bf3pArgs {
     size_t az, bz, mz, rz;   // per-batch strides: bytes, bytes, floats (M), floats (residual)
     int T, Cout, nchunks, tilesN;
     int tiles, batch, by_batch;
+    int persist;             // pipe kernel, by_batch: workgroups walk the tiles blockIdx.x + k gridDim.x
     int ksplits, kps, P;     // split-K (pipe kernel): batch index = z * P + entry; split z walks chunks [z kps, (z+1) kps) of nchunks
     int ldo, ldr;
     const float* bias;       // [Cout] or null
@@ -216,6 +217,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_kernel(const Bf3pAr
 // ... -- bit-equal results), so no second register set is needed.  Two LDS stages: chunk c + 2 goes to
 // the stage chunk c was read from (one iteration ago).  One wait (copies landed, reads returned) + barrier per chunk, and after
 // it every wave continues with MFMAs at once.
+// Persistent tiles (a.persist: by_batch launches with more tiles than the chip holds workgroups): a workgroup walks the tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... -- gridDim.x is a multiple of 8, so a tile stays on the XCD the one-tile-per-workgroup
+// launch would have given it -- and issues the first two chunk copies of its NEXT tile before it stores the current tile's
+// accumulators: the workgroup turnover (drain the stores, free 96 KB of LDS, launch, first copy latency: ~7 us of a ~145 us
+// K = 1024 tile, from the K = 1024 / K = 2048 timings) shrinks to the store issue.
 template <int WM, int WN, bool RES>
 __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const Bf3pArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
@@ -226,37 +232,46 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
     const unsigned lane16 = lane * 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    int bid, bz;
-    if (a.by_batch) {
-        const int L = (int)blockIdx.x, j = L >> 3;
-        bz = (L & 7) + 8 * (j / a.tiles);
-        if (bz >= a.batch) return;
-        bid = j % a.tiles;
-    } else {
-        bz = (int)blockIdx.z;
-        bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
-    }
     const int tilesN = a.tilesN * 2 / WN;
-    const int n_tile = bid % tilesN, m_tile = bid / tilesN;
-    const int row0 = m_tile * BM, cout0 = n_tile * BN;
     const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
     const int rg_last = a.T / 32 - 1;                                          // a ragged last row tile (T % BM != 0) re-reads the last
-    // split-K (the weight-gradient GEMMs: few output tiles, long contraction): entry = bz % P, split z = bz / P
-    const int zs = a.ksplits > 1 ? bz / a.P : 0, ent = a.ksplits > 1 ? bz - zs * a.P : bz;
-    const size_t koff = (size_t)zs * a.kps * (3 * UNIT);
-    const unsigned char* A = a.A + (size_t)ent * a.az + koff;                  // row group instead of running past the buffer; its
-    const unsigned char* B = a.B + (size_t)ent * a.bz + koff + (size_t)n_tile * (WN * 2) * gstride;     // rows are not stored
-    float* M = a.M + (size_t)bz * a.mz;
-    const float* res = a.res + (size_t)bz * a.rz;
-
+                                                                               // row group instead of running past the buffer; its
+                                                                               // rows are not stored
+    // ---- the tile a (virtual) block index names; false beyond the last batch entry ----------------------------------------------
+    int row0 = 0, cout0 = 0, n = 0;
+    float* M = nullptr;
+    const float* res = nullptr;
     const unsigned char* src[KMAX];
+    auto setup = [&](int L) -> bool {
+        int bid, bz;
+        if (a.by_batch) {
+            const int j = L >> 3;
+            bz = (L & 7) + 8 * (j / a.tiles);
+            if (bz >= a.batch) return false;
+            bid = j % a.tiles;
+        } else {
+            bz = (int)blockIdx.z;
+            bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
+        }
+        const int n_tile = bid % tilesN, m_tile = bid / tilesN;
+        row0 = m_tile * BM; cout0 = n_tile * BN;
+        // split-K (the weight-gradient GEMMs: few output tiles, long contraction): entry = bz % P, split z = bz / P
+        const int zs = a.ksplits > 1 ? bz / a.P : 0, ent = a.ksplits > 1 ? bz - zs * a.P : bz;
+        const size_t koff = (size_t)zs * a.kps * (3 * UNIT);
+        const unsigned char* A = a.A + (size_t)ent * a.az + koff;
+        const unsigned char* B = a.B + (size_t)ent * a.bz + koff + (size_t)n_tile * (WN * 2) * gstride;
+        M = a.M + (size_t)bz * a.mz;
+        res = a.res + (size_t)bz * a.rz;
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int u = wave + k * NW;
-        const int ub = u - NA;
-        src[k] = (u < NA ? A + (size_t)min(m_tile * (WM * 2) + u / 3, rg_last) * gstride + (u % 3) * UNIT
-                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
-    }
+        for (int k = 0; k < KMAX; ++k) {
+            const int u = wave + k * NW;
+            const int ub = u - NA;
+            src[k] = (u < NA ? A + (size_t)min(m_tile * (WM * 2) + u / 3, rg_last) * gstride + (u % 3) * UNIT
+                             : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
+        }
+        n = a.ksplits > 1 ? min(a.kps, a.nchunks - zs * a.kps) : a.nchunks;
+        return true;
+    };
     auto issue = [&](int chunk, unsigned char* st) {
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
@@ -264,25 +279,24 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
             if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + u * UNIT);
         }
     };
+    auto load_bias = [&](float (&bv)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+            bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+        }
+    };
     const unsigned lds0 = lds_address(smem);
     const unsigned aoff = (wm * 2) * 3 * UNIT + lane * 16;
     const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int L = (int)blockIdx.x;
+    if (!setup(L)) return;
     float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));     // a USE of the bias: hipcc waits for its load here, where it can see the wait (it does not see the
-                                                    // waits inside the asm statements below and would re-wait vmcnt(0) before every epilogue store)
+    load_bias(bv);
+    issue(0, smem);
+    if (n > 1) issue(1, smem + STAGE);
+
     bf16x8 fa[3][2], fb[3][2];                                                 // [plane][tile]
 #define BF3P_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
 #define BF3P_READ_A(p, base) do { BF3P_READ(fa[p][0], base, p, 0); BF3P_READ(fa[p][1], base, p, 1); } while (0)
@@ -302,90 +316,111 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][0], acc[1][0], 0, 0, 0);                          \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][1], acc[1][1], 0, 0, 0);                          \
     } while (0)
-    const int n = a.ksplits > 1 ? min(a.kps, a.nchunks - zs * a.kps) : a.nchunks;
-    issue(0, smem);
-    if (n > 1) issue(1, smem + STAGE);
-    wait_vmcnt<0>();
-    asm volatile("s_barrier" ::: "memory");
-    {
-        const unsigned sa = lds0 + aoff, sb = lds0 + boff;
+    for (;;) {
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { BF3P_READ_A(p, sa); BF3P_READ_B(p, sb); }
-    }
-    BF3P_ALL_LANDED();
-    asm volatile("s_barrier" ::: "memory");                                    // everybody holds chunk 0: stage 0 may be overwritten
-    for (int chunk = 0; chunk < n; ++chunk) {
-        const bool has_next = chunk + 1 < n;
-        const unsigned nxt = lds0 + ((chunk + 1) & 1) * STAGE;
-        const unsigned sa = nxt + aoff, sb = nxt + boff;
-        __builtin_amdgcn_sched_barrier(0);
-        BF3P_TERM(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (chunk + 2 < n) issue(chunk + 2, smem + (chunk & 1) * STAGE);       // under the first MFMAs; stage free since the last barrier
-        __builtin_amdgcn_sched_barrier(0);
-        BF3P_TERM(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3P_READ_B(2, sb);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3P_TERM(2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3P_READ_A(2, sa);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3P_TERM(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3P_READ_B(1, sb);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3P_TERM(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3P_READ_A(1, sa);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3P_TERM(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
-        BF3P_ALL_LANDED();                                                     // my copies of chunk + 2 have landed, my reads of chunk + 1 returned
-        asm volatile("s_barrier" ::: "memory");                                // ... everybody's
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        wait_vmcnt<0>();
+        asm volatile("" :: "v"(bv[0]), "v"(bv[1]));  // a USE of the bias: hipcc waits for its load here, where it can see the wait (it does not see the
+                                                     // waits inside the asm statements below and would re-wait vmcnt(0) before every epilogue store)
+        asm volatile("s_barrier" ::: "memory");
+        {
+            const unsigned sa = lds0 + aoff, sb = lds0 + boff;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) { BF3P_READ_A(p, sa); BF3P_READ_B(p, sb); }
+        }
+        BF3P_ALL_LANDED();
+        asm volatile("s_barrier" ::: "memory");                                // everybody holds chunk 0: stage 0 may be overwritten
+        for (int chunk = 0; chunk < n; ++chunk) {
+            const bool has_next = chunk + 1 < n;
+            const unsigned nxt = lds0 + ((chunk + 1) & 1) * STAGE;
+            const unsigned sa = nxt + aoff, sb = nxt + boff;
+            __builtin_amdgcn_sched_barrier(0);
+            BF3P_TERM(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk + 2 < n) issue(chunk + 2, smem + (chunk & 1) * STAGE);   // under the first MFMAs; stage free since the last barrier
+            __builtin_amdgcn_sched_barrier(0);
+            BF3P_TERM(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3P_READ_B(2, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3P_TERM(2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3P_READ_A(2, sa);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3P_TERM(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3P_READ_B(1, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3P_TERM(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3P_READ_A(1, sa);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3P_TERM(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+            BF3P_ALL_LANDED();                                                 // my copies of chunk + 2 have landed, my reads of chunk + 1 returned
+            asm volatile("s_barrier" ::: "memory");                            // ... everybody's
+        }
+        // ---- the next tile's first copies go out before this tile's stores (both LDS stages are free: the last barrier is behind) --
+        const int crow0 = row0, ccout0 = cout0;
+        float* const cM = M;
+        const float* const cres = res;
+        const float cb0 = bv[0], cb1 = bv[1];
+        L += (int)gridDim.x;
+        const bool more = a.persist && setup(L);
+        if (more) {
+            issue(0, smem);
+            if (n > 1) issue(1, smem + STAGE);
+            load_bias(bv);
+        }
+        // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float rv[8][2];
+                if (RES) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = r0 + rr;
+                        const int row = min(crow0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.T - 1);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int co = ccout0 + wn * 64 + j * 32 + (lane & 31);
+                            rv[rr][j] = co < a.Cout ? cres[(size_t)row * a.ldr + co] : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = r0 + rr;
+                    const int row = crow0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float* dst = cM + (size_t)row * a.ldo;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = ccout0 + wn * 64 + j * 32 + (lane & 31);
+                        float v = acc[i][j][r] + (j ? cb1 : cb0);
+                        if (RES) v += rv[rr][j];
+#if BBDM_NT_MSTORE
+                        if (co < a.Cout && row < a.T) store_nt(dst + co, v);
+#else
+                        if (co < a.Cout && row < a.T) dst[co] = v;
+#endif
+                    }
+                }
+            }
+        if (!more) break;
     }
 #undef BF3P_TERM
 #undef BF3P_ALL_LANDED
 #undef BF3P_READ_B
 #undef BF3P_READ_A
 #undef BF3P_READ
-
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8) {
-            float rv[8][2];
-            if (RES) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = r0 + rr;
-                    const int row = min(row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.T - 1);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                        rv[rr][j] = co < a.Cout ? res[(size_t)row * a.ldr + co] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = r0 + rr;
-                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* dst = M + (size_t)row * a.ldo;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                    float v = acc[i][j][r] + bv[j];
-                    if (RES) v += rv[rr][j];
-#if BBDM_NT_MSTORE
-                    if (co < a.Cout && row < a.T) store_nt(dst + co, v);
-#else
-                    if (co < a.Cout && row < a.T) dst[co] = v;
-#endif
-                }
-            }
-        }
 }
 
 // byte offset of element (row r, k) inside a fragment unit
@@ -491,7 +526,28 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     const long long blocks = (((long long)a.T + WM * 64 - 1) / (WM * 64)) * (a.tilesN * 2 / WN);     // (a ragged last row tile: KIND 1 only)
     BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3p: too many tiles");
     a.tiles = (int)blocks;
-    const dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
+    dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
+    a.persist = 0;
+    if (KIND == 1 && a.by_batch) {
+        // persistent tiles (see gemm_bf3p_pipe_kernel): as many workgroups as the chip holds at once (LDS- and wave-limited per CU), a
+        // multiple of 8 so that tile L keeps its XCD L % 8.  BBDM_BF3P_PERSIST=0: one tile per workgroup (A/B)
+        static const int persist_env = [] { const char* e = getenv("BBDM_BF3P_PERSIST"); return e ? atoi(e) : 1; }();
+        static int cus_dev[BBDM_MAX_DEVICES] = {};
+        int& cus = cus_dev[bbdm_device_slot()];
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        const int by_lds = (int)((160 * 1024) / lds), by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
+        const int per_cu = by_lds < by_waves ? by_lds : by_waves;
+        const unsigned resident = (unsigned)(cus * (per_cu > 0 ? per_cu : 1)) / 8 * 8;
+        if (persist_env && resident >= 8 && grid.x > resident) {
+            a.persist = 1;
+            grid = dim3(resident);
+        }
+    }
     if (KIND == 0)
         hipLaunchKernelGGL((gemm_bf3p_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
     else

@@ -690,80 +690,89 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
 //            output row a and adds its GroupNorm partial sums to the workgroup's LDS table (flushed as in the kernel above).
 // ~50 VGPRs, 24 KB of LDS: four workgroups = 32 waves per CU.  Needs Cm % 128 == 0 (and Cout % 128 == 0 with the phase filters, so
 // that a channel block lies inside one phase); other shapes keep winograd_output6_kernel.
-template <bool RES>
+template <bool RES, int TPW>
 __global__ void __launch_bounds__(512) winograd_output6_lds_kernel(const float* __restrict__ M, size_t plane, int ldm,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ res, int ldr, int res_per_image,
                                                                    float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
-                                                                   int cblocks, const StatArgs st, int ph) {
-    constexpr int MO = 6, AL = 8;
-    __shared__ float2 lds[MO * AL * 64];
+                                                                   int cblocks, long long T, const StatArgs st, int ph) {
+    // TPW tiles (consecutive, same channel block) per workgroup, the intermediate double-buffered: the waves that finish phase B of a
+    // tile early -- and the two that have no output row -- already load the next tile's columns
+    constexpr int MO = 6, AL = 8, NBUF = TPW > 1 ? 2 : 1;
+    __shared__ float2 lds[NBUF * MO * AL * 64];
     __shared__ double lsum[ST_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cb = (int)(blockIdx.x % (unsigned)cblocks);
-    const long long tile = blockIdx.x / (unsigned)cblocks;
+    const long long tile0 = (long long)(blockIdx.x / (unsigned)cblocks) * TPW;
     const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
-    const int tw = (int)(tile % TW);
-    const long long r = tile / TW;
-    const int th = (int)(r % TH), n = (int)(r / TH);
+    const int n0 = (int)(tile0 / ((long long)TH * TW));
     const int cm = cb * 128 + 2 * lane;                       // channel of M
     const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;    // phase filter, output channel
     const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
     if (stats)
         for (int i = threadIdx.x; i < ST_DOUBLES; i += 512) lsum[i] = 0.0;
-    {   // ---- phase A: column `wave` of the window ------------------------------------------------------------------------------
-        const int j = wave;
-        const float* m = M + (size_t)tile * ldm + cm + (size_t)j * plane;
-        float2 v[AL], sj[MO];
+    const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
 #pragma unroll
-        for (int i = 0; i < AL; ++i) v[i] = load_nt(reinterpret_cast<const float2*>(m + (size_t)(i * AL) * plane));
-        at_transform<MO>(v, sj);
+    for (int k = 0; k < TPW; ++k) {
+        const long long tile = tile0 + k;
+        if (tile >= T) break;
+        float2* buf = lds + (k & (NBUF - 1)) * (MO * AL * 64);
+        {   // ---- phase A: column `wave` of the window --------------------------------------------------------------------------
+            const int j = wave;
+            const float* m = M + (size_t)tile * ldm + cm + (size_t)j * plane;
+            float2 v[AL], sj[MO];
 #pragma unroll
-        for (int a = 0; a < MO; ++a) lds[(a * AL + j) * 64 + lane] = sj[a];
-    }
-    __syncthreads();
-    if (wave < MO) {   // ---- phase B: output row `wave` -----------------------------------------------------------------------------
-        const int a = wave;
-        float2 t[AL], o[MO];
+            for (int i = 0; i < AL; ++i) v[i] = load_nt(reinterpret_cast<const float2*>(m + (size_t)(i * AL) * plane));
+            at_transform<MO>(v, sj);
 #pragma unroll
-        for (int j = 0; j < AL; ++j) t[j] = lds[(a * AL + j) * 64 + lane];
-        const int oh = MO * th + a;
-        if (oh < H) {
-            float2 rv[MO];
-            if (RES) {     // the residuals of the row are fetched together (clamped addresses for the masked edge pixels)
+            for (int a = 0; a < MO; ++a) buf[(a * AL + j) * 64 + lane] = sj[a];
+        }
+        __syncthreads();
+        if (wave < MO) {   // ---- phase B: output row `wave` -------------------------------------------------------------------------
+            const int a = wave;
+            const int tw = (int)(tile % TW);
+            const long long r = tile / TW;
+            const int th = (int)(r % TH), n = (int)(r / TH);
+            float2 t[AL], o[MO];
 #pragma unroll
-                for (int b = 0; b < MO; ++b) {
-                    const int owc = min(MO * tw + b, W - 1);
-                    const float* rp = res_per_image == 1 ? res + (size_t)n * ldr + c
-                                      : res_per_image == 2 ? res + ((size_t)(n * (H >> 1) + (oh >> 1)) * (W >> 1) + (owc >> 1)) * ldr + c
-                                                           : res + ((size_t)(n * H + oh) * W + owc) * ldr + c;
-                    rv[b] = *reinterpret_cast<const float2*>(rp);
-                }
-            }
-            at_transform<MO>(t, o);
-            const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
-            double psum = 0.0, psq = 0.0;
+            for (int j = 0; j < AL; ++j) t[j] = buf[(a * AL + j) * 64 + lane];
+            const int oh = MO * th + a;
+            if (oh < H) {
+                float2 rv[MO];
+                if (RES) {     // the residuals of the row are fetched together (clamped addresses for the masked edge pixels)
 #pragma unroll
-            for (int b = 0; b < MO; ++b) {
-                const int ow = MO * tw + b;
-                if (ow < W) {
-                    float2 val = o[b] + b2;
-                    if (RES) val = val + rv[b];
-                    const size_t pix = ph ? (size_t)(n * 2 * H + 2 * oh + (pq >> 1)) * (2 * W) + 2 * ow + (pq & 1)
-                                          : (size_t)(n * H + oh) * W + ow;
-                    *reinterpret_cast<float2*>(y + pix * ldy + c) = val;
-                    if (stats) {
-                        psum += (double)val.x + (double)val.y;
-                        psq += (double)val.x * val.x + (double)val.y * val.y;
+                    for (int b = 0; b < MO; ++b) {
+                        const int owc = min(MO * tw + b, W - 1);
+                        const float* rp = res_per_image == 1 ? res + (size_t)n * ldr + c
+                                          : res_per_image == 2 ? res + ((size_t)(n * (H >> 1) + (oh >> 1)) * (W >> 1) + (owc >> 1)) * ldr + c
+                                                               : res + ((size_t)(n * H + oh) * W + owc) * ldr + c;
+                        rv[b] = *reinterpret_cast<const float2*>(rp);
                     }
                 }
+                at_transform<MO>(t, o);
+                double psum = 0.0, psq = 0.0;
+#pragma unroll
+                for (int b = 0; b < MO; ++b) {
+                    const int ow = MO * tw + b;
+                    if (ow < W) {
+                        float2 val = o[b] + b2;
+                        if (RES) val = val + rv[b];
+                        const size_t pix = ph ? (size_t)(n * 2 * H + 2 * oh + (pq >> 1)) * (2 * W) + 2 * ow + (pq & 1)
+                                              : (size_t)(n * H + oh) * W + ow;
+                        *reinterpret_cast<float2*>(y + pix * ldy + c) = val;
+                        if (stats) {
+                            psum += (double)val.x + (double)val.y;
+                            psq += (double)val.x * val.x + (double)val.y * val.y;
+                        }
+                    }
+                }
+                if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);
             }
-            if (stats) stat_add(lsum, st, 0, n, c, psum, psq);
         }
     }
     if (stats) {
         __syncthreads();
-        stat_flush(lsum, st, n, N, 512);
+        stat_flush(lsum, st, n0, N, 512);
     }
 }
 
@@ -1097,13 +1106,15 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     // BBDM_WINO_OUTPUT_LDS=0: the one-thread-per-window kernel for every m = 6 shape (A/B; see winograd_output6_lds_kernel)
     static const int two_phase = [] { const char* e = getenv("BBDM_WINO_OUTPUT_LDS"); return e ? atoi(e) : 1; }();
     if (m == 6 && two_phase && Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
-        const dim3 g2((unsigned)(T * (size_t)(Cm / 128)));
-        if (residual)
-            hipLaunchKernelGGL(winograd_output6_lds_kernel<true>, g2, dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi,
-                               out, ldo, N, H, W, Cout, Cm / 128, st, ph);
-        else
-            hipLaunchKernelGGL(winograd_output6_lds_kernel<false>, g2, dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi,
-                               out, ldo, N, H, W, Cout, Cm / 128, st, ph);
+        static const int tpw = [] { const char* e = getenv("BBDM_WINO_OUTPUT_TPW"); return e ? atoi(e) : 2; }();
+#define BBDM_WINO_OUT6(RES_, TPW_)                                                                                                \
+    hipLaunchKernelGGL((winograd_output6_lds_kernel<RES_, TPW_>), dim3((unsigned)(((T + TPW_ - 1) / TPW_) * (size_t)(Cm / 128))), \
+                       dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, Cm / 128,        \
+                       (long long)T, st, ph)
+        if (tpw == 1) { if (residual) BBDM_WINO_OUT6(true, 1); else BBDM_WINO_OUT6(false, 1); }
+        else if (tpw == 4) { if (residual) BBDM_WINO_OUT6(true, 4); else BBDM_WINO_OUT6(false, 4); }
+        else { if (residual) BBDM_WINO_OUT6(true, 2); else BBDM_WINO_OUT6(false, 2); }
+#undef BBDM_WINO_OUT6
         BBDM_CHECK_LAUNCH("winograd_output");
         return BBDM_OK;
     }

@@ -49,6 +49,9 @@ enum { hipSuccess = 0 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
+struct hipDeviceProp_t { int multiProcessorCount; };
+// 8 "CUs": small enough that the test-sized by_batch GEMM launches walk several tiles per workgroup (gemm_bf3p.hip: persist)
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 8; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
@@ -256,6 +259,7 @@ static inline void hipemu_wave_barrier() { int dummy = 0; hipemu::wave_publish(&
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
 #define __builtin_amdgcn_rcpf(v) (1.0f / (v))
 #define __builtin_amdgcn_exp2f(v) exp2f(v)
+#define BBDM_KEEP_IN_BRANCH(v) ((void)0)
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
