@@ -539,6 +539,8 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
             hipDeviceProp_t prop;
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
+            // BBDM_BF3P_CUS=n: walk the tiles with the workgroups of n CUs only (probe: is the tile GEMM CU-bound or power-bound?)
+            if (const char* e = getenv("BBDM_BF3P_CUS")) { const int v = atoi(e); if (v >= 8 && v < cus) cus = v; }
         }
         const int by_lds = (int)((160 * 1024) / lds), by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
         const int per_cu = by_lds < by_waves ? by_lds : by_waves;

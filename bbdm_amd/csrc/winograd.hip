@@ -678,27 +678,28 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
     }
 }
 
-// ---- the m = 6 output transform in two phases through LDS (the counterpart of winograd_input_split2_kernel) ---------------------------
+// ---- the output transform in two phases through LDS (the counterpart of winograd_input_split2_kernel) ---------------------------------
 // winograd_output6_kernel keeps the 8 x 8 window of its channel pair in registers and the compiler has all 64 loads (and the residual
 // rows) in flight at once: 245 VGPRs, TWO waves per SIMD, and its ablation (tools/wino_variants.py) shows the load stream, the store
 // stream and the arithmetic overlapping poorly (loads alone 0.165 ms, stores alone 0.159 ms, together 0.248 ms at 64x64 x 1024).
 // Here a workgroup owns ONE tile x 128 consecutive channels of M (lane = channel pair: every access of a wave is 512 contiguous
-// bytes) and its 8 waves split the window:
+// bytes) and its m + 2 waves (8 at m = 6) split the window:
 //   phase A: wave j loads column j of the window (xi = (0..7, j): 8 loads per lane, issued together; M is read once: `nt`), transforms
 //            it down the rows (A^T m: 8 -> 6) and leaves the 6 results in LDS [a][j][lane];
 //   phase B: wave a < 6 reads row a of the intermediate, transforms it (. A: 8 -> 6), adds bias / residual, stores the 6 pixels of
 //            output row a and adds its GroupNorm partial sums to the workgroup's LDS table (flushed as in the kernel above).
 // ~50 VGPRs, 24 KB of LDS: four workgroups = 32 waves per CU.  Needs Cm % 128 == 0 (and Cout % 128 == 0 with the phase filters, so
-// that a channel block lies inside one phase); other shapes keep winograd_output6_kernel.
-template <bool RES, int TPW>
-__global__ void __launch_bounds__(512) winograd_output6_lds_kernel(const float* __restrict__ M, size_t plane, int ldm,
+// that a channel block lies inside one phase); other shapes keep the one-thread-per-window kernels.  m = 4 / m = 2 (the latent
+// configurations) run the same code with 6 / 4 waves; `splits` partial sums of a split-K tile GEMM are added in order while loading.
+template <int MO, bool RES, int TPW>
+__global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(const float* __restrict__ M, size_t plane, int ldm, int splits,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ res, int ldr, int res_per_image,
                                                                    float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
                                                                    int cblocks, long long T, const StatArgs st, int ph) {
     // TPW tiles (consecutive, same channel block) per workgroup, the intermediate double-buffered: the waves that finish phase B of a
     // tile early -- and the two that have no output row -- already load the next tile's columns
-    constexpr int MO = 6, AL = 8, NBUF = TPW > 1 ? 2 : 1;
+    constexpr int AL = MO + 2, NT = AL * 64, NBUF = TPW > 1 ? 2 : 1;
     __shared__ float2 lds[NBUF * MO * AL * 64];
     __shared__ double lsum[ST_DOUBLES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -710,7 +711,7 @@ __global__ void __launch_bounds__(512) winograd_output6_lds_kernel(const float* 
     const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;    // phase filter, output channel
     const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
     if (stats)
-        for (int i = threadIdx.x; i < ST_DOUBLES; i += 512) lsum[i] = 0.0;
+        for (int i = threadIdx.x; i < ST_DOUBLES; i += NT) lsum[i] = 0.0;
     const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
@@ -723,6 +724,10 @@ __global__ void __launch_bounds__(512) winograd_output6_lds_kernel(const float* 
             float2 v[AL], sj[MO];
 #pragma unroll
             for (int i = 0; i < AL; ++i) v[i] = load_nt(reinterpret_cast<const float2*>(m + (size_t)(i * AL) * plane));
+            for (int z = 1; z < splits; ++z)      // split-K tile GEMMs (small layers): partial sums M[z][xi][tiles][Cout], added in order
+#pragma unroll
+                for (int i = 0; i < AL; ++i)
+                    v[i] = v[i] + load_nt(reinterpret_cast<const float2*>(m + ((size_t)z * (AL * AL) + i * AL) * plane));
             at_transform<MO>(v, sj);
 #pragma unroll
             for (int a = 0; a < MO; ++a) buf[(a * AL + j) * 64 + lane] = sj[a];
@@ -772,7 +777,7 @@ __global__ void __launch_bounds__(512) winograd_output6_lds_kernel(const float* 
     }
     if (stats) {
         __syncthreads();
-        stat_flush(lsum, st, n0, N, 512);
+        stat_flush(lsum, st, n0, N, NT);
     }
 }
 
@@ -1105,16 +1110,20 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     hipStream_t s_ = (hipStream_t)stream;
     // BBDM_WINO_OUTPUT_LDS=0: the one-thread-per-window kernel for every m = 6 shape (A/B; see winograd_output6_lds_kernel)
     static const int two_phase = [] { const char* e = getenv("BBDM_WINO_OUTPUT_LDS"); return e ? atoi(e) : 1; }();
-    if (m == 6 && two_phase && Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
+    if (two_phase && Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
         static const int tpw = [] { const char* e = getenv("BBDM_WINO_OUTPUT_TPW"); return e ? atoi(e) : 2; }();
-#define BBDM_WINO_OUT6(RES_, TPW_)                                                                                                \
-    hipLaunchKernelGGL((winograd_output6_lds_kernel<RES_, TPW_>), dim3((unsigned)(((T + TPW_ - 1) / TPW_) * (size_t)(Cm / 128))), \
-                       dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, Cm / 128,        \
-                       (long long)T, st, ph)
-        if (tpw == 1) { if (residual) BBDM_WINO_OUT6(true, 1); else BBDM_WINO_OUT6(false, 1); }
-        else if (tpw == 4) { if (residual) BBDM_WINO_OUT6(true, 4); else BBDM_WINO_OUT6(false, 4); }
-        else { if (residual) BBDM_WINO_OUT6(true, 2); else BBDM_WINO_OUT6(false, 2); }
-#undef BBDM_WINO_OUT6
+#define BBDM_WINO_OUT(MO_, RES_, TPW_)                                                                                              \
+    hipLaunchKernelGGL((winograd_output_lds_kernel<MO_, RES_, TPW_>), dim3((unsigned)(((T + TPW_ - 1) / TPW_) * (size_t)(Cm / 128))), \
+                       dim3((MO_ + 2) * 64), 0, s_, M, Tp * (size_t)Cm, Cm, splits, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, \
+                       Cm / 128, (long long)T, st, ph)
+#define BBDM_WINO_OUT_M(MO_)                                                                                   \
+    do {                                                                                                       \
+        if (tpw == 1) { if (residual) BBDM_WINO_OUT(MO_, true, 1); else BBDM_WINO_OUT(MO_, false, 1); }        \
+        else { if (residual) BBDM_WINO_OUT(MO_, true, 2); else BBDM_WINO_OUT(MO_, false, 2); }                 \
+    } while (0)
+        if (m == 6) BBDM_WINO_OUT_M(6); else if (m == 4) BBDM_WINO_OUT_M(4); else BBDM_WINO_OUT_M(2);
+#undef BBDM_WINO_OUT_M
+#undef BBDM_WINO_OUT
         BBDM_CHECK_LAUNCH("winograd_output");
         return BBDM_OK;
     }
