@@ -32,6 +32,7 @@ void bbdm_set_error(const char* fmt, ...);
 // hipFuncSetAttribute applies to the CURRENT device: the "already raised the LDS limit" caches are kept per device
 // (a process may drive several GPUs: the reference's `main.py --gpu_ids 1` runs on cuda:1 without set_device).
 constexpr int BBDM_MAX_DEVICES = 64;
+constexpr int BBDM_MAX_CU_WORDS = 16;        // CU masks of up to 512 CUs (runtime.hip: partition streams)
 static inline int bbdm_device_slot() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BBDM_MAX_DEVICES) d = 0;
@@ -78,6 +79,9 @@ __device__ __forceinline__ float2 load_nt(const float2* p) {
 #define BBDM_NT_MSTORE 0
 #endif
 
+// runtime.hip: CUs the kernels enqueued on `stream` can run on (a CU-partition stream's share, else the whole device)
+extern "C" int bbdm_stream_cus(void* stream);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int ceil_pow2(int v) {
     int p = 1;
@@ -110,3 +114,31 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
                                   float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
 
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// ... of a channel pair: the multiplies and the add as packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32), only the two
+// v_exp_f32 and two v_rcp_f32 (quarter rate) per pair stay scalar; same values as silu_fast per element
+__device__ __forceinline__ float2 silu_fast2(float2 v) {
+    const f32x2 x = {v.x, v.y};
+    const f32x2 t = x * -0x1.715476p+0f;                        // exp(-v) = 2^(-v log2 e): v_exp_f32 IS 2^x (__expf's constant)
+    f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + 1.0f;
+    const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    const f32x2 o = x * r;
+    return make_float2(o.x, o.y);
+}
+
+// ---- division of a non-negative index by a launch constant (Granlund-Montgomery): q = (mulhi(n, mul) + n) >> sh for 0 <= n < 2^31.
+// A 32-bit division by a kernel ARGUMENT compiles to ~25 VALU instructions (float reciprocal + two correction steps); the input
+// transform did two per lane to find its tile's (image, row, column).
+struct FastDiv {
+    unsigned d, mul, sh;
+};
+static inline FastDiv fastdiv_make(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    unsigned L = 0;
+    while ((1ull << L) < d) ++L;
+    f.mul = (unsigned)((((1ull << L) - d) << 32) / d + 1);
+    f.sh = L;
+    return f;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.sh; }

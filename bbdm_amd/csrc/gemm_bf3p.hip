@@ -532,16 +532,11 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
         // persistent tiles (see gemm_bf3p_pipe_kernel): as many workgroups as the chip holds at once (LDS- and wave-limited per CU), a
         // multiple of 8 so that tile L keeps its XCD L % 8.  BBDM_BF3P_PERSIST=0: one tile per workgroup (A/B)
         static const int persist_env = [] { const char* e = getenv("BBDM_BF3P_PERSIST"); return e ? atoi(e) : 1; }();
-        static int cus_dev[BBDM_MAX_DEVICES] = {};
-        int& cus = cus_dev[bbdm_device_slot()];
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                      ? prop.multiProcessorCount : 256;
-            // BBDM_BF3P_CUS=n: walk the tiles with the workgroups of n CUs only (probe: is the tile GEMM CU-bound or power-bound?)
-            if (const char* e = getenv("BBDM_BF3P_CUS")) { const int v = atoi(e); if (v >= 8 && v < cus) cus = v; }
-        }
+        // the CUs of the launch stream: a CU-partition stream (runtime.hip) owns a share of every XCD, any other stream the device.
+        // BBDM_BF3P_CUS=n: walk the tiles with the workgroups of n CUs only (probe: is the tile GEMM CU-bound or power-bound?)
+        static const int cus_env = [] { const char* e = getenv("BBDM_BF3P_CUS"); return e ? atoi(e) : 0; }();
+        int cus = bbdm_stream_cus((void*)st);
+        if (cus_env >= 8 && cus_env < cus) cus = cus_env;
         const int by_lds = (int)((160 * 1024) / lds), by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
         const int per_cu = by_lds < by_waves ? by_lds : by_waves;
         const unsigned resident = (unsigned)(cus * (per_cu > 0 ? per_cu : 1)) / 8 * 8;

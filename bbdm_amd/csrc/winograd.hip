@@ -435,32 +435,44 @@ __device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][3], un
 // TR (training forward of a layer whose weight gradient is taken in the Winograd domain): the planes are ALSO written transposed,
 // Vt[xi][ci / 32][tile / 16][3][1 KB unit: rows = 32 channels, k = 16 tiles] -- the A operand of dU_xi = V_xi^T dM_xi as the SAME
 // gemm_bf3p kernel takes it (rows = ci, contraction over the tiles): see store_transposed().
-template <int MO, bool PRE, bool UP, bool TR>
+// What bounds it (round 3, profiles/r03_transform_bound.md): HBM, at the rate this chip gives a stream that is 73 % WRITES.  A
+// bare streaming kernel with one read and three write streams moves 3.5 - 5.2 TB/s (tools/microbench/hbm_mix.hip; a pure read stream
+// 6.3 - 6.5, a copy 4.9 - 5.7); this kernel moves 5.0.  Checked and ruled out: the VALU (the index arithmetic below cut its issue
+// slots per wave from ~630 to ~480: -3 %), load latency (a variant that walked 2 - 16 chunks per workgroup and requested chunk
+// k + 1's rows before transforming chunk k was 5 - 7 % SLOWER: fewer resident waves, nothing to hide), the `nt` store policy
+// (profiles/r03_nt_and_output_lds_ab.txt).  Fewer bytes is the only lever left: 6 B per transformed element is what the exact
+// three-way split costs.
+// Index arithmetic: the tile's (image, row, column) comes from two multiply-high divisions by launch constants (FastDiv, common.h)
+// instead of two 64-bit divisions by kernel arguments; a row address is ONE 24-bit multiply-add on a 32-bit element index (IDX64:
+// tensors of 2^32 elements or more, or a row pitch of 2^24 elements or more, keep 64-bit row addresses); SiLU evaluates a channel
+// pair with packed multiplies / adds around its two v_exp_f32 / v_rcp_f32.
+template <int MO, bool PRE, bool UP, bool TR, bool IDX64>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
                                                                               unsigned char* __restrict__ Vp,
                                                                               const float* __restrict__ sc, const float* __restrict__ bi,
                                                                               int pre_ld, int pre_silu, int N, int H, int W, int nchunks,
-                                                                              long long T, int TG, size_t plane,
+                                                                              unsigned T, int TG, size_t plane,
                                                                               unsigned char* __restrict__ Vt, size_t plane_t,
-                                                                              int tchunks) {
+                                                                              int tchunks, const FastDiv dTW, const FastDiv dTH,
+                                                                              const FastDiv dCH) {
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
-    const int L = (int)blockIdx.x, q = L >> 3;
+    const unsigned L = blockIdx.x, q = L >> 3;
     // the chunks of one tile group run on ONE XCD (block id % 8): the two 64-B halves of an input line meet in that L2
-    const int chunk = q % nchunks, tg = (q / nchunks) * 8 + (L & 7);
+    const unsigned qc = fastdiv(q, dCH);
+    const int chunk = (int)(q - qc * (unsigned)nchunks), tg = (int)(qc * 8 + (L & 7));
     if (tg >= TG) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const int TH = (int)dTH.d, TW = (int)dTW.d;
     const int tl = lane >> 3, cp = lane & 7;
-    const long long tile = (long long)tg * 8 + tl;
+    const unsigned tile = (unsigned)tg * 8 + tl;
     const int c = chunk * KC + cp * 2;
     {   // ---- phase A: column `wave` of the window ------------------------------------------------------------------------------
         const int jj = wave;
         float2 d[AL], col[AL];
         if (tile < T) {
-            const int tw = (int)(tile % TW);
-            const long long r = tile / TW;
-            const int th = (int)(r % TH), n = (int)(r / TH);
+            const unsigned r = fastdiv(tile, dTW), n = fastdiv(r, dTH);
+            const int tw = (int)(tile - r * (unsigned)TW), th = (int)(r - n * (unsigned)TH);
             float2 s2 = make_float2(1.f, 1.f), b2 = make_float2(0.f, 0.f);
             if (PRE) {
                 s2 = *reinterpret_cast<const float2*>(sc + (size_t)n * pre_ld + c);
@@ -471,20 +483,32 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
             const int wc = min(max(w, 0), W - 1);
             const int wsrc = UP ? wc >> 1 : wc;
             const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
+            const int h0 = MO * th - 1;
+            if (IDX64) {
 #pragma unroll
-            for (int i = 0; i < AL; ++i) {            // clamped addresses, out-of-image taps zeroed afterwards: the loads issue together
-                const int hc = min(max(MO * th - 1 + i, 0), H - 1);
-                const int hs = UP ? hc >> 1 : hc;
-                d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+                for (int i = 0; i < AL; ++i) {        // clamped addresses, out-of-image taps zeroed afterwards: the loads issue together
+                    const int hc = min(max(h0 + i, 0), H - 1);
+                    const int hs = UP ? hc >> 1 : hc;
+                    d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
+                }
+            } else {
+                const unsigned rowstride = (unsigned)Ws * (unsigned)ldx;                     // < 2^24 (host check)
+                const unsigned e0 = (n * (unsigned)Hs * (unsigned)Ws + (unsigned)wsrc) * (unsigned)ldx + (unsigned)c;
+#pragma unroll
+                for (int i = 0; i < AL; ++i) {
+                    const int hc = min(max(h0 + i, 0), H - 1);
+                    const unsigned hs = (unsigned)(UP ? hc >> 1 : hc);
+                    d[i] = *reinterpret_cast<const float2*>(x + (e0 + __umul24(hs, rowstride)));
+                }
             }
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                const int h = MO * th - 1 + i;
+                const int h = h0 + i;
                 const float mask = (h >= 0 && h < H) ? wmask : 0.f;
                 float2 v = d[i];
                 if (PRE) {
                     v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
-                    if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
+                    if (pre_silu) v = silu_fast2(v);
                 }
                 d[i] = make_float2(mask * v.x, mask * v.y);
             }
@@ -995,12 +1019,19 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
     static const int two_phase = [] { const char* e = getenv("BBDM_WINO_INPUT_LDS"); return e ? atoi(e) : 1; }();
     if (two_phase || Vt) {
         const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
-        BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
+        BBDM_REQUIRE(blocks < (1ll << 31) && Tp < (1ull << 31), "winograd_input_bf3p: too many workgroups / tiles");
         const dim3 g((unsigned)blocks);
-#define BBDM_WINO_INS2(MO, PRE, UP, TR)                                                                                      \
-    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
-                       pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (long long)T, TG, plane, (unsigned char*)Vt,   \
-                       plane_t, (int)(Tp / 16))
+        const int Hs = upsample ? H / 2 : H, Ws = upsample ? W / 2 : W;
+        // 32-bit element indices + 24-bit row multiplies where the tensor allows it (every shape of the reference's templates)
+        const bool idx64 = (unsigned long long)N * Hs * Ws * (unsigned long long)ldx >= (1ull << 32) ||
+                           (unsigned long long)Ws * (unsigned long long)ldx >= (1ull << 24) || Hs >= (1 << 24);
+        const FastDiv dTW = fastdiv_make((unsigned)((W + m - 1) / m)), dTH = fastdiv_make((unsigned)((H + m - 1) / m)),
+                      dCH = fastdiv_make((unsigned)nchunks);
+#define BBDM_WINO_INS2_I(MO, PRE, UP, TR, I64)                                                                                    \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
+                       pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, (unsigned char*)Vt,   \
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH)
+#define BBDM_WINO_INS2(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_I(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_I(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_M(MO)                                                                        \
     do {                                                                                            \
         if (Vt) { if (pre_scale) BBDM_WINO_INS2(MO, true, false, true); else BBDM_WINO_INS2(MO, false, false, true); }   \
@@ -1010,6 +1041,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else BBDM_WINO_INS2_M(6);
 #undef BBDM_WINO_INS2_M
 #undef BBDM_WINO_INS2
+#undef BBDM_WINO_INS2_I
         BBDM_CHECK_LAUNCH("winograd_input_bf3p");
         return BBDM_OK;
     }

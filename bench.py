@@ -584,6 +584,18 @@ def main():
     if traffic is not None and alg_n:
         traffic["algorithmic_bytes_per_launch"] = alg_bytes / alg_n
     ms_per_step = elapsed * 1e3 / args.steps
+    # two half-batch chains over CU-partitioned streams (bbdm_amd/unet.py: _DualPlan): the per-kernel times above are stream times of
+    # launches that run BESIDE launches of the other chain (their sum exceeds the step), and the dominant kernel's launches ran on
+    # the matrix partition's CUs only -- `frac` keeps the whole chip's peak as its denominator
+    dual_info = None
+    if hasattr(plan0, "halves"):
+        part = dict(model.denoise_fn.dual_partition)
+        dual_info = {"halves": [p.N for p in plan0.halves], "streaming_partition_cus": {("default" if k == 0 else f"{k} px/image"): v
+                                                                                           for k, v in sorted(part.items())},
+                     "device_cus": int(bbdm_amd._lib.load().bbdm_device_cus()),
+                     "note": "matrix launches (tile GEMMs, 1x1 GEMMs, attention) of one half of the batch run beside the streaming launches "
+                             "(Winograd transforms, GroupNorm) of the other half on disjoint CUs; kernel_ms_per_step are per-stream times "
+                             "and overlap"}
     devices = dist_utils.gather_device_info(dist, dev)          # per-rank device ids (+ RCCL version when world > 1)
     steps_per_s_job = dist_utils.aggregate_throughput(args.steps, elapsed, world)
 
@@ -627,6 +639,7 @@ def main():
                          "conv1x1_bf3_tflops": (c1x1[2] / (c1x1[1] * 1e-3) / 1e12) if c1x1[1] > 0 else None,
                          "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
+            "dual_chain": dual_info,
             "f32mfma_ms_per_step": f32mfma_ms,
         }
         if args.workload in FIRST_STAGE and not args.no_pipeline:

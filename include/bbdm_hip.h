@@ -36,6 +36,18 @@ extern "C" {
 int bbdm_version(void);                       /* ABI version, bumped on any signature change           */
 const char* bbdm_last_error(void);            /* text of the last error on the calling thread          */
 
+/* ---- CU-partitioned streams (csrc/runtime.hip) -------------------------------------------------------- */
+/* The reference runs every op of a sampling step on one stream (PyTorch's), one kernel at a time.  Here the HBM-bound
+ * launches of one half of a batch run beside the MFMA-bound launches of the other half on two streams that own
+ * DISJOINT sets of compute units (bbdm_amd/unet.py: _DualPlan; call site replaced: the op-by-op eager execution of
+ * UNetModel.forward, openaimodel.py:744-759).  A partition = a HIP stream restricted to the CU-mask bits
+ * [cu_begin, cu_end), both multiples of 8: bit i lives on XCD i % 8, so every XCD contributes (cu_end - cu_begin) / 8
+ * CUs.  The returned handle is a hipStream_t usable with every entry point (and torch.cuda.ExternalStream). */
+int bbdm_device_cus(void);                                   /* compute units of the current device (256)        */
+int bbdm_stream_create_partition(int cu_begin, int cu_end, void** stream);
+int bbdm_stream_destroy(void* stream);                       /* only handles of bbdm_stream_create_partition     */
+int bbdm_stream_cus(void* stream);                           /* CUs a stream's kernels can use (persistent grids) */
+
 /* ---- layout ------------------------------------------------------------------------------------------ */
 /* NCHW [N,Ca,H,W] (+ optional second NCHW [N,Cb,H,W]) -> NHWC [N,H,W,ldo], channels >= Ca+Cb zero-filled up to
  * Cpad.  Replaces th.cat([x, context], dim=1) + the implicit NCHW read of the first conv

@@ -236,3 +236,45 @@ def test_first_stage_plans_on_the_emulator():
     every switch the shared emitters read (a missing one surfaced only on the GPU box in round 3)."""
     import first_stage_cases as C
     C.encode_decode_parity(CPU, N=1, resolution=16, attn_resolutions=[8])
+
+
+@pytest.mark.parametrize("name", ["tiny_concat", "tiny_xattn"])
+def test_dual_chain_plan_equals_the_one_stream_plan(name):
+    """`_DualPlan` (two half-batch chains; on the GPU over CU-partitioned streams) computes per image what the one-stream plan
+    computes: same kernels, same per-image arithmetic -- the schedule is a permutation that keeps each half's op order -- and both
+    match the reference's golden output."""
+    from bbdm_amd.unet import _DualPlan
+    rec = load_case(name)
+    m = _build(rec)
+    unet = m.denoise_fn
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"]
+    x = torch.cat([rec["x0"], rec["x0"].flip(0)], 0) if rec["x0"].shape[0] % 2 else rec["x0"]
+    t = torch.cat([rec["t"], rec["t"].flip(0)], 0) if rec["x0"].shape[0] % 2 else rec["t"]
+    c = None if ctx is None else (torch.cat([ctx, ctx.flip(0)], 0) if rec["x0"].shape[0] % 2 else ctx)
+    outs = {}
+    for dual in (False, True):
+        unet.dual_chain = dual
+        with torch.no_grad():
+            outs[dual] = unet(x, timesteps=t, context=c).clone()
+        plan = next(reversed(unet._plans.values()))
+        assert isinstance(plan, _DualPlan) == dual
+    n = rec["x0"].shape[0]
+    assert rel_err(outs[False][:n], rec["unet_out"]) < M.STEP_TOL
+    assert rel_err(outs[True], outs[False]) < 2e-6
+    # the issue order keeps each half's own order, alternates the halves segment by segment, and links every stream change
+    order = plan.order
+    for h in (0, 1):
+        ks = [k for hh, k, _ in order if hh == h]
+        assert ks == list(range(len(plan.halves[h].ops)))
+    assert {h for h, _, _ in order[:len(order) // 4]} == {0, 1}
+    prev = {}
+    for i, (h, k, cls) in enumerate(order):
+        j = prev.get(h)
+        if j is not None and plan._stream_key[j] != plan._stream_key[i]:
+            assert plan._wait_on[i] == j and plan._records[j]
+        else:
+            assert plan._wait_on[i] is None
+        prev[h] = i
+    assert any(cls == "G" for _, _, cls in order) and any(cls == "T" for _, _, cls in order)
+    # packed weights exist once
+    assert all(a is b for a, b in zip(plan.halves[0].convs, plan.halves[1].convs))

@@ -53,6 +53,9 @@ struct hipDeviceProp_t { int multiProcessorCount; };
 // 8 "CUs": small enough that the test-sized by_batch GEMM launches walk several tiles per workgroup (gemm_bf3p.hip: persist)
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 8; return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+// CU-partition streams (runtime.hip): the emulator hands out distinct dummy handles; every launch is synchronous anyway
+static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = malloc(1); return *s ? hipSuccess : 1; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
@@ -101,7 +104,8 @@ static inline size_t min(size_t a, size_t b) { return a < b ? a : b; }
 static inline size_t max(size_t a, size_t b) { return a > b ? a : b; }
 static inline float min(float a, float b) { return fminf(a, b); }
 static inline float max(float a, float b) { return fmaxf(a, b); }
-#define __expf(v) expf(v)
+// HIP's __expf: v_exp_f32 (2^x) of log2(e) * x, the constant as the device header has it (__clang_hip_math.h)
+#define __expf(v) exp2f(0x1.715476p+0f * (v))
 #define __logf(v) logf(v)
 static inline float __frcp_rn(float v) { return 1.0f / v; }
 static inline float __fdividef(float a, float b) { return a / b; }
@@ -257,6 +261,8 @@ static inline void hipemu_wave_barrier() { int dummy = 0; hipemu::wave_publish(&
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_readfirstlane hipemu_readfirstlane
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 #define __builtin_amdgcn_rcpf(v) (1.0f / (v))
 #define __builtin_amdgcn_exp2f(v) exp2f(v)
 #define BBDM_KEEP_IN_BRANCH(v) ((void)0)
