@@ -603,7 +603,8 @@ class UNetModel(nn.Module):
         self.max_cached_plans = 4
         self._freqs: Optional[torch.Tensor] = None
         self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
-        self.hip_graph: Optional[bool] = None       # None = automatic (small latents), True / False = force
+        hg = os.environ.get("BBDM_HIP_GRAPH")       # None = automatic (small latents), True / False = force (BBDM_HIP_GRAPH=1 | 0)
+        self.hip_graph: Optional[bool] = None if hg is None else hg == "1"
         # BBDM_TRAIN_GRAPH=1: training plans replay their forward and each backward segment as hipGraphs.  Off by default: measured on the
         # LBBDM-f4 micro-step (C4) 74.7 vs 75.2 ms eager -- the GPU is not waiting for the host; what separates the 67 ms of plan
         # kernels from the step is dispatch latency between ~1300 dependent launches, which a graph replay pays as well.
@@ -2055,16 +2056,17 @@ class _Plan:
                 prof.append((opname, e0, e1, fl))
 
     def _want_graph(self) -> bool:
-        """hipGraph replay of the ~200-launch forward pays only when the launches are short (small latents); at the
-        256^2 pixel config one launch is milliseconds.  ``UNetModel.hip_graph`` = True / False overrides.  Training plans replay
-        their forward and each backward segment the same way on request (``UNetModel.train_graph`` / BBDM_TRAIN_GRAPH=1; measured
-        gain on C4: 0.6 %)."""
+        """Inference plans replay their ~200 launches as ONE hipGraph: at the small latents it removes most of the step (launch-bound),
+        at 256^2 / batch 16 -- launches of milliseconds -- still 1.4 ms of the 114 (the ~1.5 us boundaries between dependent launches and
+        the host's per-call work; measured round 3).  ``UNetModel.hip_graph`` = True / False overrides (BBDM_HIP_GRAPH=1 | 0).  Training
+        plans replay their forward and each backward segment the same way on request (``UNetModel.train_graph`` / BBDM_TRAIN_GRAPH=1;
+        measured gain on C4: 0.6 %)."""
         pref = self.m.hip_graph
         if pref is not None:
             return bool(pref)
         if self.device.type != "cuda" or (self.training and not self.m.train_graph):
             return False
-        return self.N * self.H * self.W <= 32 * 64 * 64
+        return True
 
     def run(self, x, t, ctx, out=None, borrow=False):
         with _lib.device_guard(self.device):        # NULL-stream launches follow the current device (see _lib.device_guard)

@@ -401,7 +401,7 @@ def main():
         state["img"] = step(i, state["img"])
     prof = []
     # Per-launch HIP events are recorded INSIDE the timed region unless the forward is replayed as a hipGraph (small
-    # latents: c1/c3/c5) -- there the timed region is the plain product path and the events come from a second,
+    # latents in rounds 1-2, every inference plan since round 3) -- there the timed region is the plain product path and the events come from a second,
     # eager pass of the same K steps.
     plan_graph = (not training) and next(iter(model.denoise_fn._plans.values()))._want_graph()
     model.denoise_fn.op_profile = None if (training or plan_graph) else prof
@@ -412,11 +412,16 @@ def main():
 
     # barrier + synchronize on both sides, MAX over ranks (bbdm_amd/dist_utils.py)
     elapsed = dist_utils.timed_region(timed, dist, dev)
+    eager_ms = None
     if plan_graph or training:
         # (training: the timed region is the plain product path as well; forward AND gradient-plan launches are timed here)
         model.denoise_fn.op_profile = prof
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
         timed()
+        eb.record()
         torch.cuda.synchronize(dev)
+        eager_ms = ea.elapsed_time(eb) / args.steps
     model.denoise_fn.op_profile = None
     img = state["img"]
     if not bool(torch.isfinite(img).all()):
@@ -453,7 +458,9 @@ def main():
         d[2] += fl
     if args.dump_ops and rank == 0:
         plan = next(iter(model.denoise_fn._plans.values()))
-        nops = len(plan.ops)
+        # (training: a profiled micro-step is the forward op list followed by the gradient plan's, bbdm_amd/unet.py: _backward_segment)
+        ops_all = list(plan.ops) + (list(plan.bops) if training else [])
+        nops = len(ops_all)
         agg = {}
         for j, (name, e0, e1, fl) in enumerate(prof):
             k = j % nops
@@ -463,7 +470,11 @@ def main():
             f.write("| # | op | shape | ms | TFLOP/s |\n|---|---|---|---|---|\n")
             for k in sorted(agg):
                 name, ms, fl = agg[k]
-                oargs = plan.ops[k][1]
+                oargs = ops_all[k][1]
+                bwd = name.endswith(":bwd")
+                name = name[:-4] if bwd else name
+                if str(ops_all[k][0]) != name:
+                    raise RuntimeError(f"--dump-ops: profile entry {k} is {name}, the plan's op is {ops_all[k][0]}")
                 if name == "bbdm_conv1x1_bf3_f32":
                     shp = "pixels{} {}->{} k1 (bf16x3)".format(*oargs[8:11])
                 elif name == "bbdm_conv2d_nhwc_f32":
@@ -484,7 +495,7 @@ def main():
                 else:
                     shp = ""
                 tf = fl / (ms * 1e-3) / 1e12 if ms > 0 and fl else 0.0
-                f.write(f"| {k} | {name.replace('bbdm_', '')} | {shp} | {ms:.3f} | {tf:.1f} |\n")
+                f.write(f"| {k} | {name.replace('bbdm_', '')}{':bwd' if bwd else ''} | {shp} | {ms:.3f} | {tf:.1f} |\n")
     # conv_igemm_f32 is launched by the direct convolutions and by the 16-GEMM stage of the Winograd layers; the
     # roofline counts the FLOPs the kernel EXECUTES (for a Winograd layer 4/9 of the direct-convolution FLOPs).
     def both(name):                 # forward launches + the same entry point launched by the gradient plan (":bwd")
@@ -613,6 +624,10 @@ def main():
                        "schedule_steps": nsteps_table, "parallelism": f"dp{world} (independent image-pair shards)"},
             "devices": devices,
             "hip_graph": bool(plan_graph),
+            # hip_graph: the timed region replays the forward as ONE hipGraph (the product path); the per-launch HIP events behind
+            # `roofline` / `kernel_ms_per_step` then come from a second, eager pass of the same K steps right after it, whose own
+            # step time (launch by launch, with two event records around every launch) is eager_profiled_ms_per_step
+            "eager_profiled_ms_per_step": eager_ms,
             "steps_per_sec_per_gpu": args.steps / elapsed,
             "img_steps_per_sec": steps_per_s_job * batch,
             "imgs_per_sec_whole_job": steps_per_s_job * batch / nsteps_table,
