@@ -508,15 +508,22 @@ extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_pl
     return BBDM_OK;
 }
 
+// Probe (exported, not part of the public header): v != 0 pads the 8-wave kernels' LDS request beyond half a CU's so that ONE workgroup
+// runs per CU -- half of the register file and 16 wave slots stay free for a streaming kernel on another stream (tools/partition_probe.py
+// --coreside: can the HBM-bound transforms run BESIDE the tile GEMM on the same CUs?)
+static int g_bf3p_one_per_cu = 0;
+extern "C" int bbdm_debug_set_bf3p_one_per_cu(int v) { const int old = g_bf3p_one_per_cu; g_bf3p_one_per_cu = v; return old; }
+
 // KIND 0: gemm_bf3p_kernel (two stages, front-end work after every barrier); KIND 1: gemm_bf3p_pipe_kernel (fragments one chunk ahead)
 template <int WM, int WN, int KIND, bool RES>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    if (g_bf3p_one_per_cu && WM * WN <= 8 && lds < 84 * 1024) lds = 84 * 1024;
     const void* fn = KIND == 0 ? reinterpret_cast<const void*>(gemm_bf3p_kernel<WM, WN, RES>)
                                : reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>);
-    if (!attr_set) {
+    if (!attr_set || g_bf3p_one_per_cu) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;

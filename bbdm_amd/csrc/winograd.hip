@@ -1023,7 +1023,9 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         const dim3 g((unsigned)blocks);
         const int Hs = upsample ? H / 2 : H, Ws = upsample ? W / 2 : W;
         // 32-bit element indices + 24-bit row multiplies where the tensor allows it (every shape of the reference's templates)
-        const bool idx64 = (unsigned long long)N * Hs * Ws * (unsigned long long)ldx >= (1ull << 32) ||
+        // (BBDM_WINO_IDX64=1 forces the 64-bit variant: the tests run both on ordinary shapes)
+        static const int idx64_env = [] { const char* e = getenv("BBDM_WINO_IDX64"); return e ? atoi(e) : 0; }();
+        const bool idx64 = idx64_env || (unsigned long long)N * Hs * Ws * (unsigned long long)ldx >= (1ull << 32) ||
                            (unsigned long long)Ws * (unsigned long long)ldx >= (1ull << 24) || Hs >= (1 << 24);
         const FastDiv dTW = fastdiv_make((unsigned)((W + m - 1) / m)), dTH = fastdiv_make((unsigned)((H + m - 1) / m)),
                       dCH = fastdiv_make((unsigned)nchunks);

@@ -214,3 +214,15 @@ def test_geglu_backward():
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 1, 7, 10, 32, 8), (6, 2, 12, 12, 64, 132)])
 def test_winograd_wgrad_bf3p(m, N, H, W, Cin, Cout):
     BK.test_winograd_wgrad_bf3p(CPU, m, N, H, W, Cin, Cout)
+
+
+def test_winograd_input_64bit_index_variant_in_subprocess():
+    """BBDM_WINO_IDX64=1 (read once per process): the 64-bit row-address instantiation of the input transform on the emulator."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BBDM_WINO_IDX64="1", BBDM_TESTS_SERIAL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_winograd_bf3p_stages",
+                        "-p", "no:xdist", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

@@ -446,6 +446,20 @@ def test_winograd_output_adds_upsampled_residual(dev, m, N, H, W, Cin, Cout):
     assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL[m]
 
 
+def test_winograd_input_64bit_index_variant_in_subprocess():
+    """The input transform addresses its rows with 32-bit element indices and 24-bit multiplies; tensors of 2^32 elements (16 GB)
+    or more take the IDX64 instantiation (csrc/winograd.hip: winograd_input_split2_kernel).  BBDM_WINO_IDX64=1 forces it on the
+    ordinary test shapes -- read once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BBDM_WINO_IDX64="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_winograd_bf3p_stages"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 3, 16, 24, 64, 96), (6, 1, 1, 2, 20, 12, 32, 136),
                                                       (4, 0, 1, 3, 16, 24, 64, 96), (4, 1, 0, 1, 8, 8, 16, 8),
                                                       (2, 1, 1, 3, 16, 24, 64, 96), (6, 0, 0, 5, 7, 9, 48, 260)])

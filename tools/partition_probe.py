@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--t", default="32,64,96")
     ap.add_argument("--shapes", default=None)
+    ap.add_argument("--coreside", action="store_true",
+                    help="no CU masks: two plain streams, the tile GEMM as ONE 8-wave workgroup per CU (256 x 128 tiles, LDS padded), the "
+                         "transforms co-resident on the same CUs")
     args = ap.parse_args()
     R = args.reps
     dev = torch.device("cuda:0")
@@ -57,7 +60,14 @@ def main():
     m, P = 6, 64
     ts = [int(v) for v in args.t.split(",")]
     parts = {}
-    for t in ts:
+    if args.coreside:
+        import ctypes as _ct
+        lib.bbdm_debug_set_bf3p_one_per_cu.restype = _ct.c_int
+        lib.bbdm_debug_set_bf3p_kernel.restype = _ct.c_int
+        ts = [0]
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        parts[0] = (sa, sa.cuda_stream, sb, sb.cuda_stream)
+    for t in ([] if args.coreside else ts):
         sT, hT = partition(lib, 0, t)
         sG, hG = partition(lib, t, cus)
         parts[t] = (sT, hT, sG, hG)
@@ -86,8 +96,14 @@ def main():
                   Cin, st0)
         torch.cuda.synchronize()
 
-        def gemm(st):
+        def gemm(st, one=False):
+            if one:                 # 256 x 128 pipe kernel, one workgroup per CU
+                lib.bbdm_debug_set_bf3p_kernel(5)
+                lib.bbdm_debug_set_bf3p_one_per_cu(1)
             _lib.call("bbdm_winograd_gemm_bf3p_f32", m, VpA.data_ptr(), Bp.data_ptr(), MA.data_ptr(), N, H, W, Cin, Cout, st)
+            if one:
+                lib.bbdm_debug_set_bf3p_kernel(6)
+                lib.bbdm_debug_set_bf3p_one_per_cu(0)
 
         def transf(st):
             _lib.call("bbdm_winograd_input_bf3p_f32", m, x.data_ptr(), Cin, VpB.data_ptr(), sc.data_ptr(), bi.data_ptr(), Cin, 1, 0,
@@ -116,7 +132,7 @@ def main():
 
             def only_gemm():
                 for _ in range(R):
-                    gemm(hG)
+                    gemm(hG, args.coreside)
 
             def only_transf():
                 for _ in range(R):
@@ -124,7 +140,7 @@ def main():
 
             def both():
                 for _ in range(R):
-                    gemm(hG)
+                    gemm(hG, args.coreside)
                     transf(hT)
 
             tg, tt, tb = wall(only_gemm), wall(only_transf), wall(both)
