@@ -576,6 +576,11 @@ extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_varian
 // even those do not give every CU a workgroup, split K: split z writes its partial sums to M[z][batch][T][ldo] and the consumer adds
 // the partials in order (bbdm_winograd_output_splitk_stats_f32) -- deterministic.
 namespace {
+// (A cost model that chose shape AND split count per launch -- rounds on the busiest XCD x (chunks + 3) / shape efficiency + the HBM
+// time of the extra partial sums -- was measured on every workload and deleted: it split the mid-size GEMMs of the latent models
+// (e.g. 36 x [512 x 1024 x 1024]: 2 rounds of 256 x 256 tiles -> 3 half-length rounds) and lost everywhere, C3 16.95 -> 17.43 ms,
+// C4 +2.4 ms: the last, partly filled round runs faster than the model assumes (fewer CUs share the power budget) and the split's
+// extra partial sums cost the output transform more than the GEMM gains.  profiles/r03_bf3p_tile_choice.txt.)
 int fwd_splits(int batch, long long rows, int CinPad, int Cout) {
     static const int target = [] { const char* e = getenv("BBDM_BF3P_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
     const int nchunks = CinPad / KC;
@@ -615,7 +620,9 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     BBDM_REQUIRE(a.ksplits == splits, "gemm_bf3p: %d splits of %d chunks leave an empty split", splits, a.nchunks);
     a.P = batch;
     const int nb = batch * splits;
-    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
+    // (2 = any batch of 8 entries or more -- the 36 transform points of F(4x4,3x3) too: the kernels return early for the padding entries
+    // of a batch % 8 != 0 -- measured on the LBBDM-f4 step: tile GEMMs 9.66 -> 9.39 ms; 1 = only multiples of 8, the round-2 rule)
+    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 2; }();
     a.batch = nb;
     a.by_batch = (by_batch_env && nb >= 8 && (nb % 8 == 0 || by_batch_env == 2 || splits > 1)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
