@@ -423,6 +423,222 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
 #undef BF3P_READ
 }
 
+// ---- the pipelined kernel with an fp32 A operand: every wave splits ITS share of the next-but-one chunk between its MFMAs -------------
+// gemm_bf3p_pipe_kernel needs A as planes (6 B per element, written by a producer that knows it); gemm_bf3.hip takes plain fp32 rows
+// and splits them while it stages -- on 8-wave workgroups that do load / MFMA / split + store / barrier in lock step (181 TFLOP/s).
+// This kernel keeps the pipe kernel's structure -- fragments of chunk c + 1 read and chunk c + 2 staged BETWEEN the MFMAs of chunk c,
+// B planes by LDS-DMA, 256-column tiles, one 16-wave workgroup per CU -- and stages A through registers: a thread requests its 16 B
+// of chunk c + 2 at the top of iteration c and, after the third term group, splits them (bf3_split.h: 22 VALU instructions) and
+// writes 3 x 8 B into the stage chunk c was read from.  One float4 + 22 VALU instructions per wave and chunk against its 24 MFMAs:
+// half of gemm_bf3.hip's split work per MFMA, and no wave waits for another's split.
+// A layouts: ROWS = fp32 rows with a pitch (the 1x1 convolutions: x NHWC); UNITS = fp32 row units [T / 32][nchunks][2 KB], element
+// (r, k) at byte (k >> 3) * 1024 + r * 32 + (k & 7) * 4 (written by the Winograd input transform: 256-byte runs).
+// Results bit-equal to the other bf16x3 kernels.
+// Register budget: the pipe kernel's 64 accumulators + 48 fragment registers leave no room for the staging registers and the split's
+// temporaries at 128 VGPRs (a 16-wave build spilled 194 registers and ran at 20 TFLOP/s): the workgroup is 3 x WN waves -- 192-row
+// tiles, THREE waves per SIMD, up to 168 VGPRs each (WN = 4: one 12-wave workgroup per CU; WN = 2: two 6-wave workgroups).
+template <int WM, int WN, bool RES, bool UNITS>
+__global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const Bf3pArgs a, const float* __restrict__ Af, int lda) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
+    constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
+    static_assert((BM * 4) % (NW * 64) == 0, "whole float4 slots of A per thread and chunk");
+    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
+    constexpr int KB = (NB + NW - 1) / NW;                                    // B copies per wave and chunk
+    constexpr int AS = (BM * 4 + NW * 64 - 1) / (NW * 64);                    // float4 of A per thread and chunk (1 at 16 waves, 2 at 8)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lane16 = lane * 16;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int tilesN = a.tilesN * 2 / WN;
+    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
+    int bid, bz;
+    if (a.by_batch) {
+        const int L = (int)blockIdx.x, j = L >> 3;
+        bz = (L & 7) + 8 * (j / a.tiles);
+        if (bz >= a.batch) return;
+        bid = j % a.tiles;
+    } else {
+        bz = (int)blockIdx.z;
+        bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
+    }
+    const int n_tile = bid % tilesN, m_tile = bid / tilesN;
+    const int row0 = m_tile * BM, cout0 = n_tile * BN;
+    const int n = a.nchunks;
+    float* M = a.M + (size_t)bz * a.mz;
+    const float* res = a.res + (size_t)bz * a.rz;
+    // ---- A staging: slot f = tid (+ NW * 64): row f >> 2 of the tile, k-quad q = f & 3 (k = 4 q .. 4 q + 3) -------------------------------
+    const float* asrc[AS];
+    unsigned adst[AS];
+    size_t astep;                                                             // floats between consecutive chunks of a slot
+#pragma unroll
+    for (int s = 0; s < AS; ++s) {
+        const int f = tid + s * NW * 64, row = f >> 2, q = f & 3;
+        const int grow = min(row0 + row, a.T - 1);                            // (a ragged last row tile re-reads the last row)
+        if (UNITS) {
+            // unit of (row group, chunk): [h = k >> 3][r][8 floats]
+            asrc[s] = Af + (size_t)bz * (a.az / 4) + ((size_t)(grow >> 5) * a.nchunks) * 512 + (q >> 1) * 256 + (grow & 31) * 8 + (q & 1) * 4;
+        } else {
+            asrc[s] = Af + (size_t)bz * (a.az / 4) + (size_t)grow * lda + q * 4;
+        }
+        // plane unit of row group (row >> 5): byte (k >> 3) * 512 + r * 16 + (k & 7) * 2, k = 4 q
+        adst[s] = (unsigned)(((row >> 5) * 3) * UNIT + (q >> 1) * 512 + (row & 31) * 16 + (q & 1) * 8);
+    }
+    astep = UNITS ? 512 : KC;
+    const unsigned char* bsrc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const int u = wave + k * NW;
+        bsrc[k] = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride + (size_t)(u / 3) * gstride + (u % 3) * UNIT;
+    }
+    auto issue_b = [&](int chunk, unsigned char* st) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int u = wave + k * NW;
+            if ((k + 1) * NW <= NB || u < NB) glds16(bsrc[k] + (size_t)chunk * (3 * UNIT), lane16, st + (NA + u) * UNIT);
+        }
+    };
+    float4 areg[AS];
+    auto load_a = [&](int chunk) {
+#pragma unroll
+        for (int s = 0; s < AS; ++s) areg[s] = *reinterpret_cast<const float4*>(asrc[s] + (size_t)chunk * astep);
+    };
+    auto store_a = [&](unsigned char* st) {
+#pragma unroll
+        for (int s = 0; s < AS; ++s) {
+            uint2 p1, p2, p3;
+            split4(areg[s], p1, p2, p3);
+            *reinterpret_cast<uint2*>(st + adst[s]) = p1;
+            *reinterpret_cast<uint2*>(st + adst[s] + UNIT) = p2;
+            *reinterpret_cast<uint2*>(st + adst[s] + 2 * UNIT) = p3;
+        }
+    };
+    float bv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+    const unsigned lds0 = lds_address(smem);
+    const unsigned aoff = (wm * 2) * 3 * UNIT + lane * 16;
+    const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
+    // prologue: chunks 0 and 1 staged, fragments of chunk 0 in registers
+    issue_b(0, smem);
+    load_a(0);
+    store_a(smem);
+    if (n > 1) {
+        issue_b(1, smem + STAGE);
+        load_a(1);
+        store_a(smem + STAGE);
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 fa[3][2], fb[3][2];                                                 // [plane][tile]
+#define BF3Q_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
+#define BF3Q_READ_A(p, base) do { BF3Q_READ(fa[p][0], base, p, 0); BF3Q_READ(fa[p][1], base, p, 1); } while (0)
+#define BF3Q_READ_B(p, base) do { BF3Q_READ(fb[p][0], base, p, 0); BF3Q_READ(fb[p][1], base, p, 1); } while (0)
+#define BF3Q_ALL_LANDED()                                                                                                      \
+    do {                                                                                                                        \
+        wait_vmcnt<0>();                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),          \
+                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1])           \
+                     :: "memory");                                                                                              \
+    } while (0)
+#define BF3Q_TERM(pa, pb)                                                                                                       \
+    do {                                                                                                                        \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][0], acc[0][0], 0, 0, 0);                          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][1], acc[0][1], 0, 0, 0);                          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][0], acc[1][0], 0, 0, 0);                          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][1], acc[1][1], 0, 0, 0);                          \
+    } while (0)
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(bv[0]), "v"(bv[1]));
+    asm volatile("s_barrier" ::: "memory");
+    {
+        const unsigned sa = lds0 + aoff, sb = lds0 + boff;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { BF3Q_READ_A(p, sa); BF3Q_READ_B(p, sb); }
+    }
+    BF3Q_ALL_LANDED();
+    asm volatile("s_barrier" ::: "memory");                                // everybody holds chunk 0: stage 0 may be overwritten
+    for (int chunk = 0; chunk < n; ++chunk) {
+        const bool has_next = chunk + 1 < n, stage2 = chunk + 2 < n;
+        const unsigned nxt = lds0 + ((chunk + 1) & 1) * STAGE;
+        const unsigned sa = nxt + aoff, sb = nxt + boff;
+        unsigned char* const st2 = smem + (chunk & 1) * STAGE;             // chunk + 2 goes where chunk was read from (one iteration ago)
+        __builtin_amdgcn_sched_barrier(0);
+        BF3Q_TERM(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (stage2) { issue_b(chunk + 2, st2); load_a(chunk + 2); }        // under the first MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        BF3Q_TERM(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3Q_READ_B(2, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3Q_TERM(2, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3Q_READ_A(2, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3Q_TERM(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3Q_READ_B(1, sb);
+        if (stage2) store_a(st2);                                          // (waits for this thread's A request; the split runs under the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        BF3Q_TERM(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) BF3Q_READ_A(1, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3Q_TERM(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) { BF3Q_READ_A(0, sa); BF3Q_READ_B(0, sb); }
+        BF3Q_ALL_LANDED();
+        asm volatile("s_barrier" ::: "memory");
+    }
+#undef BF3Q_TERM
+#undef BF3Q_ALL_LANDED
+#undef BF3Q_READ_B
+#undef BF3Q_READ_A
+#undef BF3Q_READ
+    // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float rv[8][2];
+            if (RES) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = r0 + rr;
+                    const int row = min(row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.T - 1);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                        rv[rr][j] = co < a.Cout ? res[(size_t)row * a.ldr + co] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = r0 + rr;
+                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float* dst = M + (size_t)row * a.ldo;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
+                    float v = acc[i][j][r] + bv[j];
+                    if (RES) v += rv[rr][j];
+                    if (co < a.Cout && row < a.T) dst[co] = v;
+                }
+            }
+        }
+}
+
 // byte offset of element (row r, k) inside a fragment unit
 __device__ __forceinline__ int unit_off(int r, int k) { return (k >> 3) * 512 + r * 16 + (k & 7) * 2; }
 
@@ -755,5 +971,87 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
     const int rc = sp.wn == 4 ? bf3p_launch<4, 4, 1, false>(a, nb, st) : bf3p_launch<4, 2, 1, false>(a, nb, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p_tn");
+    return BBDM_OK;
+}
+
+// ---- fp32 A operand on the pipelined kernel (gemm_bf3q_pipe_kernel) ---------------------------------------------------------------------
+namespace {
+template <int WM, int WN, bool RES, bool UNITS>
+int bf3q_launch(Bf3pArgs& a, const float* Af, int lda, int batch, hipStream_t st) {
+    static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_dev[bbdm_device_slot()];
+    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    const void* fn = reinterpret_cast<const void*>(gemm_bf3q_pipe_kernel<WM, WN, RES, UNITS>);
+    if (!attr_set) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            bbdm_set_error("gemm_bf3q: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    const long long blocks = (((long long)a.T + WM * 64 - 1) / (WM * 64)) * (a.tilesN * 2 / WN);
+    BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3q: too many tiles");
+    a.tiles = (int)blocks;
+    a.persist = 0;
+    const dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
+    hipLaunchKernelGGL((gemm_bf3q_pipe_kernel<WM, WN, RES, UNITS>), grid, dim3(WM * WN * 64), lds, st, a, Af, lda);
+    return BBDM_OK;
+}
+}  // namespace
+
+// out[pixels][ldo] = x[pixels][ldx] . W^T + bias (+ residual): the 1x1 convolutions / Linears of bbdm_conv1x1_bf3_f32 (same call
+// sites, same arithmetic bit for bit) on the pipelined kernel.  b_planes = bbdm_gemm_bf3p_pack_b_f32(batch = 1) of the buffer
+// bbdm_conv_pack_weight_f32(ks = 1) filled.  pixels a multiple of 32, CinPad a multiple of 16.
+extern "C" int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                     float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream) {
+    BBDM_REQUIRE(x && b_planes && out, "conv1x1_bf3q: null pointer");
+    BBDM_REQUIRE(pixels > 0 && pixels < (1ll << 31) && CinPad > 0 && CinPad % KC == 0 && Cout > 0 && Cout % 4 == 0,
+                 "conv1x1_bf3q: pixels=%lld CinPad=%d Cout=%d unsupported", pixels, CinPad, Cout);
+    BBDM_REQUIRE(ldx % 4 == 0 && ldx >= CinPad && ldo >= Cout && (!residual || ldr >= Cout) &&
+                     (((uintptr_t)x | (uintptr_t)b_planes) & 15) == 0,
+                 "conv1x1_bf3q: bad pitch / alignment");
+    Bf3pArgs a;
+    a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = out;
+    a.T = (int)pixels; a.Cout = Cout; a.nchunks = CinPad / KC;
+    const int CoutPad = cdiv(Cout, 128) * 128;
+    a.tilesN = CoutPad / 128;
+    a.az = 0; a.bz = 0; a.mz = 0; a.rz = 0;
+    a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    a.ksplits = 1; a.kps = a.nchunks; a.P = 1; a.batch = 1; a.by_batch = 0;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (CoutPad % 256 == 0) rc = residual ? bf3q_launch<3, 4, true, false>(a, x, ldx, 1, st) : bf3q_launch<3, 4, false, false>(a, x, ldx, 1, st);
+    else rc = residual ? bf3q_launch<3, 2, true, false>(a, x, ldx, 1, st) : bf3q_launch<3, 2, false, false>(a, x, ldx, 1, st);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("conv1x1_bf3q");
+    return BBDM_OK;
+}
+
+// M[b][T][ldo] = A_b . B_b with A as fp32 ROW UNITS [batch][T / 32][CinPad / 16][2 KB] (element (r, k) of a unit at byte
+// (k >> 3) * 1024 + r * 32 + (k & 7) * 4: what bbdm_winograd_input_bf3q_f32 writes -- 4 B per transformed element instead of the
+// planes' 6) and B as bbdm_gemm_bf3p_pack_b_f32 planes; T a multiple of 32.  Bit-equal to bbdm_gemm_bf3p_f32 on the same values.
+extern "C" size_t bbdm_gemm_bf3q_a_bytes(int batch, long long T, int CinPad) {
+    return (size_t)batch * (size_t)((T + 31) / 32 * 32) * (size_t)CinPad * 4;
+}
+extern "C" int bbdm_gemm_bf3q_f32(const void* a_units, const void* b_planes, float* M, int ldo, int batch, long long T, int CinPad,
+                                  int Cout, void* stream) {
+    BBDM_REQUIRE(a_units && b_planes && M && batch > 0, "gemm_bf3q: null pointer / bad batch");
+    BBDM_REQUIRE(T > 0 && T % 32 == 0 && T < (1ll << 31) && CinPad > 0 && CinPad % KC == 0 && Cout > 0 && Cout % 4 == 0,
+                 "gemm_bf3q: T=%lld CinPad=%d Cout=%d unsupported (T %% 32, CinPad %% 16)", T, CinPad, Cout);
+    BBDM_REQUIRE((((uintptr_t)a_units | (uintptr_t)b_planes) & 15) == 0 && ((uintptr_t)M & 3) == 0 && ldo >= Cout, "gemm_bf3q: alignment / pitch");
+    Bf3pArgs a;
+    a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = M;
+    a.T = (int)T; a.Cout = Cout; a.nchunks = CinPad / KC;
+    const int CoutPad = cdiv(Cout, 128) * 128;
+    a.tilesN = CoutPad / 128;
+    a.az = (size_t)T * CinPad * 4; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo; a.rz = 0;
+    a.ldo = ldo; a.ldr = 0; a.bias = nullptr; a.res = nullptr;
+    a.ksplits = 1; a.kps = a.nchunks; a.P = batch; a.batch = batch;
+    a.by_batch = batch >= 8 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = CoutPad % 256 == 0 ? bf3q_launch<3, 4, false, true>(a, (const float*)a_units, 0, batch, st)
+                                      : bf3q_launch<3, 2, false, true>(a, (const float*)a_units, 0, batch, st);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("gemm_bf3q");
     return BBDM_OK;
 }

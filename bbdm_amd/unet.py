@@ -334,18 +334,45 @@ class _PackedConvBf3(_PackedConv):
             self.key = key
 
 
+class _PackedConvBf3q(_PackedConv):
+    """A 1x1 conv / Linear weight as the B planes of csrc/gemm_bf3p.hip (``packed``; fragment-unit layout): the operand of
+    bbdm_conv1x1_bf3q_f32, the pipelined kernel that reads the fp32 activation as it lies in HBM."""
+
+    def __init__(self, weight, bias, cin_pad):
+        super().__init__(weight, bias, cin_pad)
+        self.packed_f32 = self.packed
+        self.packed = torch.empty(_lib.load().bbdm_gemm_bf3p_b_bytes(1, cin_pad, self.cout), dtype=torch.uint8, device=weight.device)
+        self.packed.cin_true = self.cin
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if key != self.key:
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
+                      self.cin_pad, 1, stream)
+            _lib.call("bbdm_gemm_bf3p_pack_b_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), 1, self.cin_pad, self.cout,
+                      stream)
+            self.key = key
+
+
 class _PackedDgradBf3:
     """The transposed weight of a 1x1 conv / Linear in the three-bf16-plane layout of csrc/gemm_bf3.hip: the data gradient
     dX = dY W as one more fp32-accurate GEMM on the BF16 matrix core (``packed``; the fp32 dgrad packing is the intermediate)."""
 
-    def __init__(self, weight: nn.Parameter, cout_in: int):
+    def __init__(self, weight: nn.Parameter, cout_in: int, planes: bool = False):
+        """``planes``: the B planes of csrc/gemm_bf3p.hip (for bbdm_conv1x1_bf3q_f32) instead of gemm_bf3.hip's layout."""
         self.weight = weight
         self.cout, self.cin = weight.shape[0], weight.shape[1]
-        self.cout_in = cout_in
+        self.cout_in, self.planes = cout_in, planes
         lib = _lib.load()
         self.packed_f32 = torch.empty(lib.bbdm_conv_packed_dgrad_floats(self.cout, self.cin, cout_in, 1), dtype=torch.float32,
                                       device=weight.device)
-        self.packed = torch.empty(lib.bbdm_gemm_bf3_packed_halfs(1, cout_in, self.cin), dtype=torch.int16, device=weight.device)
+        if planes:
+            self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(1, cout_in, self.cin), dtype=torch.uint8, device=weight.device)
+        else:
+            self.packed = torch.empty(lib.bbdm_gemm_bf3_packed_halfs(1, cout_in, self.cin), dtype=torch.int16, device=weight.device)
         self.key = None
 
     def refresh(self, stream):
@@ -354,8 +381,8 @@ class _PackedDgradBf3:
         if key != self.key:
             _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                       self.cout_in, 1, stream)
-            _lib.call("bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), 1, self.cout_in, self.cin,
-                      stream)
+            _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.planes else "bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(),
+                      self.packed.data_ptr(), 1, self.cout_in, self.cin, stream)
             self.key = key
 
 
@@ -400,7 +427,7 @@ class _PackedWinograd:
         self.out_ch = self.cin if dgrad else (4 * self.cout if phases else self.cout)
         n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
         self.packed_f32 = torch.empty(n, dtype=torch.float32, device=weight.device)
-        if bf3 == "p":
+        if bf3 in ("p", "q"):
             self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes((m + 2) ** 2, in_pad, self.out_ch), dtype=torch.uint8,
                                       device=weight.device)
         elif bf3:
@@ -425,7 +452,7 @@ class _PackedWinograd:
                 _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                           self.in_pad, 1 if self.dgrad else 0, stream)
             if self.bf3:
-                _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 == "p" else "bbdm_gemm_bf3_pack_f32",
+                _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 in ("p", "q") else "bbdm_gemm_bf3_pack_f32",
                           self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2, self.in_pad, self.out_ch, stream)
             self.key = key
 
@@ -630,6 +657,14 @@ class UNetModel(nn.Module):
         # loop is LDS-DMA copies + MFMAs); layers whose fp32 V the training backward re-reads keep the kernel above.  0: never.
         self.gemm_bf3p: bool = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
         self.bf3_min_tiles: int = 256       # 1x1 layers with fewer 256x128 output tiles keep the split-K f32 kernel (one wave of tiles)
+        # wide 1x1 layers whose Cout fills 256-column tiles on the pipelined fp32-A kernel (gemm_bf3q_pipe_kernel); BBDM_CONV1X1_PIPE=0:
+        # gemm_bf3.hip everywhere (A/B; bit-equal results)
+        self.conv1x1_pipe: bool = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
+        # Winograd layers of inference plans on fp32 row units of V + gemm_bf3q_pipe_kernel (see _Plan._use_bf3): 0 (default) = planes
+        # everywhere; 1 = where the per-layer micro-benchmark says the input transform gains more than the GEMM loses (Cout <= 512);
+        # 2 = every layer whose Cout fills 256-column tiles.  Inside the C2 step (profiles/r03_bf3q_bench.txt): 1 is a wash (input
+        # transforms -1.6 ms, tile GEMMs +1.6 ms), 2 loses 2.5 ms.  BBDM_GEMM_BF3Q.
+        self.gemm_bf3q: int = int(os.environ.get("BBDM_GEMM_BF3Q", "0"))
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
@@ -714,7 +749,7 @@ class UNetModel(nn.Module):
         dual = self._wants_dual(N, H, W, x.device, training)
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small, self.upsample_phases, dual and tuple(sorted(self.dual_partition.items())))
+               self.winograd_small, self.upsample_phases, dual and tuple(sorted(self.dual_partition.items())), self.conv1x1_pipe, self.gemm_bf3q)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1123,12 +1158,21 @@ class _Plan:
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
         split while staged), "p" = csrc/gemm_bf3p.hip (V written pre-split by the input transform; with ``keeps_V`` -- the training
-        backward contracts this layer's V again -- only where the weight-gradient GEMM takes the transposed planes too)."""
+        backward contracts this layer's V again -- only where the weight-gradient GEMM takes the transposed planes too), "q" = the
+        same file's gemm_bf3q_pipe_kernel on fp32 row units of V (4 B per element instead of 6: the input transform is bound by its
+        HBM writes; the kernel runs at 0.93 - 1.0 of the plane kernel's rate) -- where the transform's gain outweighs the GEMM's loss:
+        measured per layer (profiles/r03_bf3q_bench.txt), the transform saves 2 B x Cin per tile and point, i.e. a share of the GEMM's
+        time that only depends on Cout (Cout 512: 6 - 11 %, Cout 1024: 3 - 4 %) against a GEMM loss of 4 - 8 %."""
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
         if self.m.gemm_bf3p and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout) and \
                 (not keeps_V or self.lib.bbdm_gemm_bf3p_tn_supported(tiles, cin_pad, cout)):
+            cpad = -(-cout // 128) * 128
+            mode = self.m.gemm_bf3q
+            if (not self.training and wm == 6 and cpad % 256 == 0 and tiles >= 1024 and
+                    (mode == 2 or (mode == 1 and cpad <= 512))):
+                return "q"
             return "p"          # (keeps_V: the weight gradient then contracts the TRANSPOSED planes the input transform also writes)
         return bool(self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout))
 
@@ -1148,6 +1192,7 @@ class _Plan:
             flags |= 8
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
+        units = pw.bf3 == "q"          # V as fp32 row units (4 B per element), split by the GEMM's waves
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
         # small layers: split-K tile GEMMs, the partial sums M[z] are added by the output transform (csrc/gemm_bf3p.hip: fwd_splits)
         ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if (split and not pw.phases) else 1
@@ -1171,13 +1216,15 @@ class _Plan:
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_tr_f32"), wm, x, x.ld, vbuf,
                  *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt)
         else:
-            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else
+                         "bbdm_winograd_input_bf3q_f32" if units else "bbdm_winograd_input_f32"),
                  wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
         if ksplit > 1:
             emit(_OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_splitk_f32"), wm, vbuf, _TensorRef(pw.packed),
                  self._wino_m, N, H, W, cin_pad, cout, ksplit)
         else:
             gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
+                           "bbdm_winograd_gemm_bf3q_f32" if units else
                            "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
             emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
         ks_tail = (ksplit,) if ksplit > 1 else ()
@@ -1230,10 +1277,13 @@ class _Plan:
                 and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles):
             # wide 1x1 convolutions / Linears (skip connections, qkv / proj_out, transformer projections): the fp32-accurate
             # bf16x3 GEMM with bias + residual in its epilogue (csrc/gemm_bf3.hip); small problems keep the split-K f32 kernel
-            pb = self._packed(_PackedConvBf3, mod.weight, mod.bias, x.C)
+            # ... on the pipelined kernel (csrc/gemm_bf3p.hip: gemm_bf3q_pipe_kernel, 200 - 214 instead of 165 - 192 TFLOP/s) where
+            # Cout fills 256-column tiles; its 128-column form loses to gemm_bf3.hip's 8-wave workgroups
+            q = self.m.conv1x1_pipe and (-(-cout // 128) * 128) % 256 == 0
+            pb = self._packed(_PackedConvBf3q if q else _PackedConvBf3, mod.weight, mod.bias, x.C)
             self.convs.append(pb)
-            rec = self._op("bbdm_conv1x1_bf3_f32", x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
-                           residual, res_ld, dest, dest.ld, pixels, x.C, cout)
+            rec = self._op(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32") if q else "bbdm_conv1x1_bf3_f32", x, x.ld,
+                           _TensorRef(pb.packed), self._pref(pb.bias), residual, res_ld, dest, dest.ld, pixels, x.C, cout)
             self._note_writer(dest, rec, None)
             return
         pc = self._conv(mod, x.C)
@@ -1576,9 +1626,11 @@ class _Plan:
             pixels = x_in.N * x_in.H * x_in.W
             if (ks == 1 and m.gemm_bf3 and x_in.C == cin and lib.bbdm_gemm_bf3_supported(pixels, dy.C, x_in.C)
                     and (pixels // 256) * -(-x_in.C // 128) >= m.bf3_min_tiles):
-                pk = _PackedDgradBf3(w, dy.C)           # wide 1x1 layers: dX = dY W on the bf16x3 GEMM, like their forward
+                q = m.conv1x1_pipe and (-(-x_in.C // 128) * 128) % 256 == 0
+                pk = _PackedDgradBf3(w, dy.C, planes=q)  # wide 1x1 layers: dX = dY W on the bf16x3 GEMM, like their forward
                 self.dconvs.append(pk)
-                self._bop("bbdm_conv1x1_bf3_f32", dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx, dx.ld, pixels, dy.C, x_in.C)
+                self._bop(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32") if q else "bbdm_conv1x1_bf3_f32", dy, dy.ld,
+                          _TensorRef(pk.packed), None, None, 0, dx, dx.ld, pixels, dy.C, x_in.C)
                 return dx
             pk = _PackedDgrad(w, dy.C)
             self.dconvs.append(pk)

@@ -520,14 +520,16 @@ def main():
     # the GEMMs run on conv_igemm_f32 (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s) together with the direct convolutions.
     all_ops = list(plan0.ops) + (list(plan0.bops) if training else [])
     entries = [getattr(nm, "entry", "") for nm, _ in all_ops if nm == "bbdm_winograd_gemm_f32"]
-    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") for e in entries), sum(e.endswith("bf3_f32") for e in entries)
+    bf3q_ops = sum(e.endswith("bf3q_f32") for e in entries)        # (the same file's kernel on fp32 row units of V)
+    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") for e in entries) + bf3q_ops, sum(e.endswith("bf3_f32") for e in entries)
     use_bf3 = bf3p_ops + bf3_ops > 0
     if use_bf3:
         # the tile GEMMs run on csrc/gemm_bf3p.hip (both operands pre-split by their producers, LDS-DMA + MFMA main loop) where the
         # input transform writes the planes, else on csrc/gemm_bf3.hip (fp32 V split while staged): same arithmetic, bit for bit
         kname = ("gemm_bf3p_pipe_kernel" if bf3p_ops >= bf3_ops else "gemm_bf3_kernel")
         dom, dom_name = wino, (f"{kname} (v_mfma_f32_32x32x16_bf16 x 6 terms = one fp32-accurate product; {bf3p_ops} launches per "
-                               f"pass on gemm_bf3p, {bf3_ops} on gemm_bf3)")
+                               f"pass on gemm_bf3p.hip -- {bf3q_ops} of them on its fp32-operand kernel gemm_bf3q_pipe_kernel --, "
+                               f"{bf3_ops} on gemm_bf3)")
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
     else:
         dom, dom_name, peak = conv, "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
@@ -550,7 +552,7 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
-            hits = [v for k, v in pm["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in pm["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3q_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
             if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
                 nl = sum(v["launches"] for v in hits)
                 traffic = {"bytes_per_launch": sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in hits) / nl,
@@ -570,7 +572,7 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_mfma_util.json")))
         if cands:
             mu = json.load(open(cands[-1]))
-            hits = [v for k, v in mu["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in mu["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3q_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
             if hits:
                 best = max(hits, key=lambda v: v.get("launches", 0))
                 mfma_util = {"percent": best.get("MfmaUtil%"), "effective_clock_GHz": best.get("clock_GHz"),

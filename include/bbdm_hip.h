@@ -380,6 +380,22 @@ int bbdm_gemm_bf3p_pack_b_f32(const float* packed_f32, void* b_planes, int batch
 int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_planes, int batch, long long T, int CinPad, void* stream);
 int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr, float* M,
                        int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
+/* bbdm_conv1x1_bf3_f32 (1x1 convolutions / Linears: openaimodel.py:244,307,315; attention.py:162-169) on the PIPELINED kernel
+ * with an fp32 A operand (csrc/gemm_bf3p.hip: gemm_bf3q_pipe_kernel): x is read as it lies in HBM, every wave splits its 16 B of the
+ * next-but-one chunk between its MFMAs; b_planes = bbdm_gemm_bf3p_pack_b_f32(batch = 1) of bbdm_conv_pack_weight_f32(ks = 1)'s
+ * buffer.  Same arguments and results (bit for bit) as bbdm_conv1x1_bf3_f32; pixels need not be a multiple of 256. */
+int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                          float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream);
+/* ... and the Winograd tile GEMMs on the same kernel: V as fp32 "row units" [xi][tile / 32][CinPad / 16][32 rows x 16 k, 2 KB]
+ * (element (r, k) at byte (k>>3)*1024 + r*32 + (k&7)*4) -- 4 B per transformed element where the planes cost 6 (the input transform
+ * is bound by its HBM writes).  Arguments of bbdm_winograd_input_f32 / bbdm_winograd_gemm_f32; b_planes as for the bf3p entries. */
+size_t bbdm_gemm_bf3q_a_bytes(int batch, long long T, int CinPad);
+int bbdm_gemm_bf3q_f32(const void* a_units, const void* b_planes, float* M, int ldo, int batch, long long T, int CinPad, int Cout,
+                       void* stream);
+int bbdm_winograd_input_bf3q_f32(int m, const float* x, int ldx, void* Vf, const float* pre_scale, const float* pre_bias,
+                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
+int bbdm_winograd_gemm_bf3q_f32(int m, const void* Vf, const void* b_planes, float* M, int N, int H, int W, int CinPad, int Cout,
+                                void* stream);
 int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
 int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,

@@ -504,6 +504,25 @@ def vq_nearest(z: torch.Tensor, codebook: torch.Tensor):
     return idx, zq
 
 
+def conv1x1_bf3q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0) -> torch.Tensor:
+    """:func:`conv1x1_bf3` on the pipelined kernel with an fp32 A operand (bbdm_conv1x1_bf3q_f32; weights as bf3p B planes)."""
+    _chk(x, w, bias, residual)
+    cout = w.shape[0]
+    cin = cin or w.shape[1]
+    lib = _lib.load()
+    pf = torch.empty(lib.bbdm_conv_packed_floats(cout, cin, 1), dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), pf.data_ptr(), cout, w.shape[1], cin, 1, _st(x))
+    bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(1, cin, cout), dtype=torch.uint8, device=x.device)
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), 1, cin, cout, _st(x))
+    if out is None:
+        out = torch.empty(x.shape[0], cout, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv1x1_bf3q_f32", x.data_ptr() + 4 * x_off, x.shape[1], bp.data_ptr(), None if bias is None else bias.data_ptr(),
+              None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1],
+              out.data_ptr(), out.shape[1], x.shape[0], cin, cout, _st(x))
+    return out
+
+
 def conv1x1_bf3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0) -> torch.Tensor:
     """x: [pixels, ldx] (channels x_off .. x_off + cin are convolved), w: [Cout, cin] -> [pixels, Cout] on the bf16x3 kernel."""

@@ -226,3 +226,13 @@ def test_winograd_input_64bit_index_variant_in_subprocess():
                         "-p", "no:xdist", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (320, 48, 256, True), (96, 16, 8, False)])
+def test_conv1x1_bf3q_bitwise(pixels, Cin, Cout, res):
+    K.test_conv1x1_bf3q_bitwise(CPU, pixels, Cin, Cout, res)
+
+
+@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 2, 12, 12, 32, 256), (4, 1, 1, 1, 8, 8, 16, 136)])
+def test_winograd_bf3q_stages_bitwise(m, up, silu, N, H, W, Cin, Cout):
+    K.test_winograd_bf3q_stages_bitwise(CPU, m, up, silu, N, H, W, Cin, Cout)

@@ -446,6 +446,43 @@ def test_winograd_output_adds_upsampled_residual(dev, m, N, H, W, Cin, Cout):
     assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL[m]
 
 
+@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 3, 16, 24, 64, 256), (6, 1, 1, 2, 20, 12, 32, 136), (4, 0, 0, 3, 16, 24, 48, 512)])
+def test_winograd_bf3q_stages_bitwise(dev, m, up, silu, N, H, W, Cin, Cout):
+    """The Winograd path with V as fp32 row units (bbdm_winograd_input_bf3q_f32: 4 B per transformed element) and the tile GEMMs on
+    gemm_bf3q_pipe_kernel, whose waves split their share of V between their MFMAs: M is BIT-EQUAL, on every real tile, to the plane
+    pipeline (bbdm_winograd_input_bf3p_f32 + bbdm_winograd_gemm_bf3p_f32) -- the same input-transform kernel computes both, the split
+    is the same function, the GEMMs take the same six terms in the same order."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(77 + 2 * up + silu + m)
+    hs, ws_ = (H // 2, W // 2) if up else (H, W)
+    x = torch.randn(N, Cin, hs, ws_, generator=g)
+    sc, bi = torch.randn(N, Cin, generator=g), torch.randn(N, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    lib = _lib.load()
+    st = None if dev.type != "cuda" else torch.cuda.current_stream().cuda_stream
+    xg, scg, big = _nhwc(x).to(dev), sc.to(dev), bi.to(dev)
+    pw = ops.pack_winograd_weight(w.to(dev), m=m)
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    P = (m + 2) ** 2
+    Bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(P, Cin, Cout), dtype=torch.uint8, device=dev)
+    ops._lib.call("bbdm_gemm_bf3p_pack_b_f32", pw.data_ptr(), Bp.data_ptr(), P, Cin, Cout, st)
+    Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
+    Vf = torch.empty(lib.bbdm_gemm_bf3q_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
+    Mp = torch.zeros(P * tiles * Cout, device=dev)
+    Mq = torch.zeros(P * tiles * Cout, device=dev)
+    ops._lib.call("bbdm_winograd_input_bf3p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), scg.data_ptr(), big.data_ptr(), Cin, silu, up, N, H, W, Cin, st)
+    ops._lib.call("bbdm_winograd_input_bf3q_f32", m, xg.data_ptr(), Cin, Vf.data_ptr(), scg.data_ptr(), big.data_ptr(), Cin, silu, up, N, H, W, Cin, st)
+    ops._lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), Bp.data_ptr(), Mp.data_ptr(), N, H, W, Cin, Cout, st)
+    ops._lib.call("bbdm_winograd_gemm_bf3q_f32", m, Vf.data_ptr(), Bp.data_ptr(), Mq.data_ptr(), N, H, W, Cin, Cout, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    T_raw = N * -(-H // m) * -(-W // m)
+    a_, b_ = Mp.view(P, tiles, Cout)[:, :T_raw].cpu(), Mq.view(P, tiles, Cout)[:, :T_raw].cpu()
+    assert float(a_.abs().max()) > 0
+    assert torch.equal(a_, b_), (a_ - b_).abs().max()
+
+
 def test_winograd_input_64bit_index_variant_in_subprocess():
     """The input transform addresses its rows with 32-bit element indices and 24-bit multiplies; tensors of 2^32 elements (16 GB)
     or more take the IDX64 instantiation (csrc/winograd.hip: winograd_input_split2_kernel).  BBDM_WINO_IDX64=1 forces it on the
@@ -530,6 +567,30 @@ def test_conv1x1_bf3(dev, pixels, Cin, Cout, res):
     out = ops.conv1x1_bf3(wide.to(dev), w.to(dev), b.to(dev), residual=buf, out=buf, cin=Cin, x_off=16)
     torch.cuda.synchronize()
     assert rel_err(out.cpu(), ref) < 3e-6
+
+
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (1024, 1536, 512, True), (768, 48, 256, False),
+                                                 (2080, 256, 1024, True), (96, 16, 8, False)])
+def test_conv1x1_bf3q_bitwise(dev, pixels, Cin, Cout, res):
+    """The same 1x1 convolution on the pipelined kernel whose waves split the fp32 A operand between their MFMAs
+    (gemm_bf3q_pipe_kernel): bit-equal to bbdm_conv1x1_bf3_f32 where that kernel takes the shape (pixels % 256 == 0); ragged row
+    tiles (pixels 2080, 96), 256- and 128-column tiles, K from one chunk up."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(pixels + Cin)
+    wide = torch.randn(pixels, Cin + 16, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(pixels, Cout, generator=g) if res else None
+    ref = wide[:, 16:].double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    buf = r.clone().to(dev) if res else None
+    out = ops.conv1x1_bf3q(wide.to(dev), w.to(dev), b.to(dev), residual=buf, out=buf, cin=Cin, x_off=16).cpu()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert rel_err(out, ref) < 3e-6
+    if pixels % 256 == 0:
+        buf0 = r.clone().to(dev) if res else None
+        out0 = ops.conv1x1_bf3(wide.to(dev), w.to(dev), b.to(dev), residual=buf0, out=buf0, cin=Cin, x_off=16).cpu()
+        assert torch.equal(out, out0), (out - out0).abs().max()
 
 
 def _group_sums(y_nhwc, cpg, coff, ctot_groups=32):
