@@ -15,6 +15,9 @@ def pytest_cmdline_main(config):
     processes with pytest-xdist when it is installed and no -n was given (BBDM_TESTS_SERIAL=1 keeps one process).  The GPU suite
     always runs in one process (one device, timing-sensitive tests)."""
     opt = config.option
+    # (never inside an xdist worker: a worker that switched xdist on again would spawn workers of its own, recursively)
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None
     if getattr(opt, "numprocesses", None) or os.environ.get("BBDM_TESTS_SERIAL") or "not gpu" not in (opt.markexpr or ""):
         return None
     try:
