@@ -2134,17 +2134,27 @@ class _Plan:
             self.ctx_in.copy_(ctx)
         self.t_buf.copy_(t)
         prof = m.op_profile
-        if prof is None and self._want_graph():
+        if prof is None and self._want_graph() and not getattr(self, "_graph_failed", False):
             # weights / parameter pointers are checked above on every call; a change re-captures
             gkey = (self._param_key,) + tuple(p.data_ptr() for p in m.time_embed.parameters())
             if self._graph is None or self._graph_key != gkey:
                 self._launch_forward(stream)                     # eager warm-up (sets kernel attributes, fills caches)
                 torch.cuda.current_stream(self.device).synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._launch_forward(_lib.current_stream(self.device))
-                self._graph, self._graph_key = g, gkey
-            self._graph.replay()
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    # thread_local: other threads of the process may touch the runtime while this one captures (the RCCL watchdog of
+                    # a torch.distributed job polls its events: under the default mode that aborts the capture)
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._launch_forward(_lib.current_stream(self.device))
+                    self._graph, self._graph_key = g, gkey
+                except RuntimeError as e:          # capture refused (e.g. another thread inside the runtime): launch by launch, same kernels
+                    import warnings
+                    warnings.warn(f"bbdm_amd: hipGraph capture of the forward failed ({e}); launching kernel by kernel")
+                    self._graph, self._graph_failed = None, True
+                    torch.cuda.synchronize(self.device)
+                    self._launch_forward(stream)
+            if self._graph is not None:
+                self._graph.replay()
         else:
             self._launch_forward(stream, prof)
         if out is None:
