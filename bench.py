@@ -15,9 +15,15 @@ data-path collective ("weak" scaling); the timed region is bracketed by barrier 
 MAX over ranks is taken; value = steps all ranks completed / that time.
 
 Rank 0 prints ONE JSON line with, besides the contract fields,
-  roofline     : the dominant kernel (conv_igemm_f32, fp32 MFMA) -- algorithmic conv FLOPs per launch / average
-                 launch duration measured with HIP events on the launch stream inside the timed region, against
-                 the 157.3 TFLOP/s dense fp32-MFMA peak (MI355X_MICROARCH.md);
+  roofline     : the dominant kernel -- the Winograd tile GEMMs on gemm_bf3p_pipe_kernel (fp32-accurate products on the BF16
+                 matrix core: six bf16 MFMA terms per product) -- fp32-equivalent FLOPs per launch / average launch duration
+                 measured with HIP events on the launch stream, against the dense bf16 MFMA peak / 6 (MI355X_MICROARCH.md);
+                 `frac_step` = the whole step against the matrix peaks; `traffic` / `traffic_step` / `mfma_util` from the committed
+                 rocprofv3 PMC passes of this command (profiles/*_pmc_<workload>_*.json);
+  hip_graph    : the timed region replays the forward as one hipGraph (the product path); the per-launch events then come from an
+                 eager pass of the same K steps right after it (`eager_profiled_ms_per_step`);
+  f32mfma_ms_per_step : the same step with those GEMMs on the f32 MFMA (strict-fp32 A/B, 5 steps after the timed region);
+  parity       : image 0 of the benchmarked batch against the CPU path (c4: loss + named gradients against the oracle's autograd);
   cpu_baseline : the oracle (kind "port": oracle/bbdm_oracle.py, the validated restatement of the reference's CPU
                  path) timed on this box's host cores on a bounded sample of the same workload.
 """
