@@ -202,10 +202,11 @@ def test_c4_full_size_loss_and_all_gradients(dev, loss_type):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("workload", ["c3", "c5", "c1"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c5", "c1"])
 def test_benchmarked_plan_exactly(dev, workload):
-    """The plans bench.py times, not a smaller batch of the same model: C3 = LBBDM-f4 UNet, latent 3x64x64, batch 32, nocond; C5 =
-    the f16 UNet, 8x16x16, batch 32; C1 = pixel 64x64, batch 4 -- each replayed as a hipGraph as in the benchmark (tile choices,
+    """The plans bench.py times, not a smaller batch of the same model: C2 = the headline, pixel 256x256, batch 16 (bench.py's own
+    `parity` field compares image 0 of the timed batch; here images 0 AND 15); C3 = LBBDM-f4 UNet, latent 3x64x64, batch 32, nocond;
+    C5 = the f16 UNet, 8x16x16, batch 32; C1 = pixel 64x64, batch 4 -- each replayed as a hipGraph as in the benchmark (tile choices,
     split-K and the graph path depend on the batch).  One p_sample step through the graph-replayed plan, images 0 and N - 1 against
     the oracle."""
     import bench
