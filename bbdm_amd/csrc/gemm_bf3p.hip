@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
 // and splits them while it stages -- on 8-wave workgroups that do load / MFMA / split + store / barrier in lock step (181 TFLOP/s).
 // This kernel keeps the pipe kernel's structure -- fragments of chunk c + 1 read and chunk c + 2 staged BETWEEN the MFMAs of chunk c,
 // B planes by LDS-DMA, 256-column tiles, one 16-wave workgroup per CU -- and stages A through registers: a thread requests its 16 B
-// of chunk c + 2 at the top of iteration c and, after the third term group, splits them (bf3_split.h: 22 VALU instructions) and
+// of chunk c + 2 at the top of iteration c and, after the fourth term group, splits them (bf3_split.h: 22 VALU instructions) and
 // writes 3 x 8 B into the stage chunk c was read from.  One float4 + 22 VALU instructions per wave and chunk against its 24 MFMAs:
 // half of gemm_bf3.hip's split work per MFMA, and no wave waits for another's split.
 // A layouts: ROWS = fp32 rows with a pitch (the 1x1 convolutions: x NHWC); UNITS = fp32 row units [T / 32][nchunks][2 KB], element
