@@ -190,26 +190,47 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
-// 1x1 layers on the TN GEMM (winograd_wgrad.hip: gemm_tn_f32): dW[co][ci] = sum_z dU[z][ci][co] -- the K splits added in a
-// fixed order and the tile transposed through LDS (32 x 32, reads and writes both in 128-B segments).
-__global__ void __launch_bounds__(256) tn_finish_kernel(const float* __restrict__ dU, int splits, float* __restrict__ dw, int Cin,
-                                                        int Cout) {
-    __shared__ float tile[32][33];
+// 1x1 layers on the TN GEMM (winograd_wgrad.hip: gemm_tn_f32): dW[co][ci] = sum_z dU[z][ci][co], transposed through LDS.  The K
+// splits are spread over four z lanes per output quad (8 ci x 32 co per workgroup, 16-byte loads, four in flight per thread; lanes
+// combined in a fixed order -- deterministic): a 128 -> 256 layer has 256 splits x 128 KB to add, which one 4-byte load chain per
+// thread in 32 workgroups took 0.24 ms over.
+__global__ void __launch_bounds__(256) tn_finish4_kernel(const float* __restrict__ dU, int splits, float* __restrict__ dw, int Cin,
+                                                         int Cout) {
+    __shared__ float4 red[4][64];
+    __shared__ float tile[32][9];
     const int tilesCo = (Cout + 31) / 32;
-    const int co0 = (int)(blockIdx.x % tilesCo) * 32, ci0 = (int)(blockIdx.x / tilesCo) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int co0 = (int)(blockIdx.x % tilesCo) * 32, ci0 = (int)(blockIdx.x / tilesCo) * 8;
+    const int tid = threadIdx.x, o = tid & 63, q = o & 7, cil = o >> 3, zl = tid >> 6;
     const size_t per = (size_t)Cin * Cout;
-    for (int r = ty; r < 32; r += 8) {
-        float s = 0.f;
-        if (ci0 + r < Cin && co0 + tx < Cout) {
-            const float* p = dU + (size_t)(ci0 + r) * Cout + co0 + tx;
-            for (int z = 0; z < splits; ++z) s += p[z * per];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ci0 + cil < Cin && co0 + 4 * q < Cout) {
+        const float* p = dU + (size_t)(ci0 + cil) * Cout + co0 + 4 * q;
+        int z = zl;
+        for (; z + 12 < splits; z += 16) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)z * per);
+            const float4 b = *reinterpret_cast<const float4*>(p + (size_t)(z + 4) * per);
+            const float4 c = *reinterpret_cast<const float4*>(p + (size_t)(z + 8) * per);
+            const float4 d = *reinterpret_cast<const float4*>(p + (size_t)(z + 12) * per);
+            s.x += (a.x + b.x) + (c.x + d.x); s.y += (a.y + b.y) + (c.y + d.y);
+            s.z += (a.z + b.z) + (c.z + d.z); s.w += (a.w + b.w) + (c.w + d.w);
         }
-        tile[r][tx] = s;
+        for (; z < splits; z += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(p + (size_t)z * per);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+    }
+    red[zl][o] = s;
+    __syncthreads();
+    if (tid < 64) {
+        const float4 a = red[0][o], b = red[1][o], c = red[2][o], d = red[3][o];
+        tile[4 * q + 0][cil] = (a.x + b.x) + (c.x + d.x);
+        tile[4 * q + 1][cil] = (a.y + b.y) + (c.y + d.y);
+        tile[4 * q + 2][cil] = (a.z + b.z) + (c.z + d.z);
+        tile[4 * q + 3][cil] = (a.w + b.w) + (c.w + d.w);
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8)
-        if (co0 + r < Cout && ci0 + tx < Cin) dw[(size_t)(co0 + r) * Cin + ci0 + tx] = tile[tx][r];
+    const int c = tid >> 3, k = tid & 7;
+    if (co0 + c < Cout && ci0 + k < Cin) dw[(size_t)(co0 + c) * Cin + ci0 + k] = tile[c][k];
 }
 
 // db[c] = sum over rows of dy[M][ld]; fp64 per-thread accumulation + fp64 atomics (order-independent to fp32 rounding)
@@ -387,7 +408,7 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
         const int splits = bbdm_gemm_tn_splits(1, K, Cin, Cout);
         int rc = bbdm_gemm_tn_batched_f32(x, ldx, 0, dy, ldy, 0, ws, 1, K, Cin, Cout, stream);
         if (rc != BBDM_OK) return rc;
-        hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 32))), dim3(256), 0, st, ws, splits,
+        hipLaunchKernelGGL(tn_finish4_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 8))), dim3(256), 0, st, ws, splits,
                            dw_oihw, Cin, Cout);
         BBDM_CHECK_LAUNCH("conv_wgrad(tn)");
         if (dbias) {

@@ -210,56 +210,105 @@ __global__ void gn_bwd_params_kernel(const double* __restrict__ dgb, float* __re
 }
 
 // ---- kernel 3: dx ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a) {
-    const int n = blockIdx.y;
+// A thread keeps ONE channel quad for its whole pixel range (as the reduce pass does), so gamma / beta / FiLM / the group's
+// {rstd, mean, S1/cnt, S2/cnt} are loaded once per thread instead of once per element, there is no 64-bit div / mod per element,
+// and the un-resampled case has four pixels' loads in flight per trip (the one-quad-per-trip form ran at 2.4 TB/s).
+struct Chan4 {
+    float g[4], b[4], sc1[4], sh[4], gs[4];          // gamma, beta, 1 + FiLM scale, FiLM shift, gamma (1 + scale)
+    float rs[4], mu[4], s1[4], s2[4];
+};
+
+__device__ __forceinline__ Chan4 load_chan(const BwdArgs& a, int n, int c, int cpg) {
+    Chan4 k;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        k.g[e] = a.gamma[c + e];
+        k.b[e] = a.beta[c + e];
+        k.sc1[e] = a.film ? 1.f + a.film[(size_t)n * a.film_ld + c + e] : 1.f;
+        k.sh[e] = a.film ? a.film[(size_t)n * a.film_ld + a.C + c + e] : 0.f;
+        k.gs[e] = a.film ? k.g[e] * k.sc1[e] : k.g[e];
+        const float4 cf = a.coef[(size_t)n * a.G + (c + e) / cpg];
+        k.rs[e] = cf.x; k.mu[e] = cf.y; k.s1[e] = cf.z; k.s2[e] = cf.w;
+    }
+    return k;
+}
+
+__device__ __forceinline__ float4 apply_quad(const BwdArgs& a, const Chan4& k, float4 xv, float4 dz) {
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float dzs[4] = {dz.x, dz.y, dz.z, dz.w};
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - k.mu[e]) * k.rs[e];
+        float v = xh * k.g[e] + k.b[e];
+        if (a.film) v = v * k.sc1[e] + k.sh[e];
+        const float dv = a.silu ? dzs[e] * dsilu(v) : dzs[e];
+        out[e] = k.rs[e] * (k.gs[e] * dv - k.s1[e] - xh * k.s2[e]);
+    }
+    return make_float4(out[0], out[1], out[2], out[3]);
+}
+
+template <bool NORM>
+__global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int pix_per_block) {
+    const int n = blockIdx.y, tid = threadIdx.x;
     const int C4 = a.C >> 2, HW = a.H * a.W;
-    const long long units = (long long)HW * C4;
     const int cpg = a.G > 0 ? a.C / a.G : a.C;
     const int Ho = (a.resample == 1 || a.resample == 3) ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
     const int Wo = (a.resample == 1 || a.resample == 3) ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
-    const float* xb = a.x ? a.x + (size_t)n * HW * a.ldx : nullptr;
-    const float* dab = a.da ? a.da + (size_t)n * Ho * Wo * a.ldda : nullptr;
+    const float* xb = NORM ? a.x + (size_t)n * HW * a.ldx : nullptr;
+    const float* dab = NORM ? a.da + (size_t)n * Ho * Wo * a.ldda : nullptr;
     const float* addb = a.dadd ? a.dadd + (size_t)n * Ho * Wo * a.ldadd : nullptr;
     float* dxb = a.dx + (size_t)n * HW * a.lddx;
-    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-        const int c4 = (int)(u % C4), p = (int)(u / C4), c = c4 * 4;
-        const int h = p / a.W, w = p - h * a.W;
-        float out[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.gamma) {
-            Norm4 nm;
-            float s1[4], s2[4];
-            if ((cpg & 3) == 0) {                       // the quad lies in one group
-                const float4 cf = a.coef[(size_t)n * a.G + c / cpg];
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+    int PP, prow, c4base;
+    if (C4 <= 256) { PP = 256 / C4; prow = tid / C4; c4base = tid - prow * C4; if (prow >= PP) return; }
+    else { PP = 1; prow = 0; c4base = tid; }
+    for (int c4 = c4base; c4 < C4; c4 += 256) {
+        const int c = c4 * 4;
+        Chan4 k;
+        if (NORM) k = load_chan(a, n, c, cpg);
+        int p = p0 + prow;
+        if (a.resample == 0) {
+            for (; p + 3 * PP < p1; p += 4 * PP) {
+                float4 xv[4], dz[4], ad[4], old[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { nm.rs[e] = cf.x; nm.mu[e] = cf.y; s1[e] = cf.z; s2[e] = cf.w; }
-            } else {
+                for (int u = 0; u < 4; ++u) {
+                    const size_t q = (size_t)(p + u * PP);
+                    if (NORM) {
+                        xv[u] = *reinterpret_cast<const float4*>(xb + q * a.ldx + c);
+                        dz[u] = *reinterpret_cast<const float4*>(dab + q * a.ldda + c);
+                    }
+                    if (addb) ad[u] = *reinterpret_cast<const float4*>(addb + q * a.ldadd + c);
+                    if (a.accumulate) old[u] = *reinterpret_cast<const float4*>(dxb + q * a.lddx + c);
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float4 cf = a.coef[(size_t)n * a.G + (c + e) / cpg];
-                    nm.rs[e] = cf.x; nm.mu[e] = cf.y; s1[e] = cf.z; s2[e] = cf.w;
+                for (int u = 0; u < 4; ++u) {
+                    float4 o = NORM ? apply_quad(a, k, xv[u], dz[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (addb) { o.x += ad[u].x; o.y += ad[u].y; o.z += ad[u].z; o.w += ad[u].w; }
+                    if (a.accumulate) { o.x += old[u].x; o.y += old[u].y; o.z += old[u].z; o.w += old[u].w; }
+                    *reinterpret_cast<float4*>(dxb + (size_t)(p + u * PP) * a.lddx + c) = o;
                 }
             }
-            const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * a.ldx + c);
-            const float4 dz = gather_grad(dab, a.ldda, a.resample, h, w, a.H, a.W, c);
-            float xh[4], dv[4];
-            quad_dv(a, n, c, nm, xv, dz, xh, dv);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float gs = a.gamma[c + e];
-                if (a.film) gs *= 1.f + a.film[(size_t)n * a.film_ld + c + e];
-                out[e] = nm.rs[e] * (gs * dv[e] - s1[e] - xh[e] * s2[e]);
+        }
+        for (; p < p1; p += PP) {
+            const int h = p / a.W, w = p - h * a.W;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NORM) {
+                const float4 xv = *reinterpret_cast<const float4*>(xb + (size_t)p * a.ldx + c);
+                const float4 dz = gather_grad(dab, a.ldda, a.resample, h, w, a.H, a.W, c);
+                o = apply_quad(a, k, xv, dz);
             }
+            if (addb) {
+                const float4 ad = gather_grad(addb, a.ldadd, a.resample, h, w, a.H, a.W, c);
+                o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w;
+            }
+            float* op = dxb + (size_t)p * a.lddx + c;
+            if (a.accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(op);
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *reinterpret_cast<float4*>(op) = o;
         }
-        if (addb) {
-            const float4 ad = gather_grad(addb, a.ldadd, a.resample, h, w, a.H, a.W, c);
-            out[0] += ad.x; out[1] += ad.y; out[2] += ad.z; out[3] += ad.w;
-        }
-        float* o = dxb + (size_t)p * a.lddx + c;
-        if (a.accumulate) {
-            const float4 old = *reinterpret_cast<const float4*>(o);
-            out[0] += old.x; out[1] += old.y; out[2] += old.z; out[3] += old.w;
-        }
-        *reinterpret_cast<float4*>(o) = make_float4(out[0], out[1], out[2], out[3]);
     }
 }
 
@@ -314,11 +363,17 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
                            dfilm_ld, C, G, stats, coef, (double)HW * (C / G), eps);
         hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dgb, dgamma, dbeta, C);
     }
-    const long long units = (long long)HW * (C / 4);
-    long long blocks = (units + 255) / 256;
-    const long long cap = cdiv(8192, N) > 1 ? cdiv(8192, N) : 1;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)blocks, N), dim3(256), 0, st, a);
+    {
+        const int C4 = C / 4;
+        const int PP = C4 <= 256 ? 256 / C4 : 1;
+        int splits = cdiv(4096, N);                              // ~16 workgroups per CU over the batch
+        int ppb = cdiv(HW, splits);
+        if (ppb < PP * 4) ppb = PP * 4;
+        ppb = cdiv(ppb, PP * 4) * (PP * 4);                      // whole four-pixel trips
+        splits = cdiv(HW, ppb);
+        if (norm) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)splits, N), dim3(256), 0, st, a, ppb);
+        else hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)splits, N), dim3(256), 0, st, a, ppb);
+    }
     BBDM_CHECK_LAUNCH("gn_bwd");
     return BBDM_OK;
 }
