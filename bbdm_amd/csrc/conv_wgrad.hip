@@ -165,28 +165,182 @@ __global__ void __launch_bounds__(WI * 128, 1) conv_wgrad_f32(const WgradArgs a)
     if (do_bias && hi == 0) a.wsb[(size_t)blockIdx.z * a.CoutP + co0 + wo * 32 + l31] = accb[0];   // row 0 of the tile
 }
 
-// dW[co][ci][tap] = sum_splits ws[s][tap][ci][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, const float* __restrict__ wsb,
-                                    float* __restrict__ db, int splits, int taps, int Cin, int Cout, int CinP, int CoutP) {
-    const size_t total = (size_t)Cout * Cin * taps;
-    const size_t stride = (size_t)taps * CinP * CoutP;
-    if (db && blockIdx.x == 0) {
-        for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += wsb[(size_t)k * CoutP + co];
-            db[co] = s;
+// 3x3 layers with ONE thin side -- the stem (4 padded input channels) and the head (3 output channels) -- on the vector ALU: on the
+// kernel above they fill 4 of 64 ci rows (or 3 of 64 co columns) of every MFMA and took 0.23 / 0.19 ms of a training step for 0.9 /
+// 0.7 GFLOP.  MODE 0: thin = Cin (= 4), wide = Cout; MODE 1: thin = Cout (<= 4), wide = Cin.  A workgroup owns 128 wide channels (one
+// per lane, two pixel halves) of 8x8-pixel tiles: the wide tensor's tile sits in LDS channel-contiguous (conflict-free), the thin one
+// as one float4 per pixel (broadcast reads); 9 taps x 4 thin channels = 36 accumulators per thread.  Partial sums per K split go to the
+// same workspace layout [split][tap][CinP][CoutP] (CinP = 4 resp. CoutP = 4) and wgrad_reduce_kernel adds them in a fixed order.
+template <int MODE>
+__global__ void __launch_bounds__(256) conv_wgrad_thin_f32(const WgradArgs a) {
+    constexpr int PW = PTW + 2, PH = PTH + 2;
+    constexpr int WPIX = MODE == 0 ? PTH * PTW : PW * PH;         // pixels of the wide tile (dY tile | X halo patch)
+    constexpr int TPIX = MODE == 0 ? PW * PH : PTH * PTW;         // pixels of the thin tile
+    __shared__ __attribute__((aligned(16))) float wide[WPIX * 128];
+    __shared__ float4 thin[TPIX];
+    const int tid = threadIdx.x, wc = tid & 127, ph = tid >> 7;
+    const int c0 = blockIdx.x * 128;                              // first wide channel of this workgroup
+    const int Cw = MODE == 0 ? a.Cout : a.Cin;
+    const int t_begin = blockIdx.z * a.tiles_per_split;
+    const int t_end = min(a.ptiles, t_begin + a.tiles_per_split);
+    float acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+    float accb[4] = {0.f, 0.f, 0.f, 0.f};                         // bias gradient: MODE 0 uses [0] (own co), MODE 1 all (lane 0)
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int n = t / (a.tilesX * a.tilesY);
+        const int rem = t - n * (a.tilesX * a.tilesY);
+        const int ty = rem / a.tilesX, tx = rem - ty * a.tilesX;
+        const int h0 = ty * PTH, w0 = tx * PTW;
+        __syncthreads();                                          // the previous tile's readers are done
+        for (int f = tid; f < WPIX * 32; f += 256) {
+            const int pp = f >> 5, c = (f & 31) * 4;
+            int h, w;
+            if (MODE == 0) { h = h0 + pp / PTW; w = w0 + pp % PTW; }
+            else { h = h0 + pp / PW - 1; w = w0 + pp % PW - 1; }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h >= 0 && h < a.H && w >= 0 && w < a.W && c0 + c < Cw) {
+                const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+                v = *reinterpret_cast<const float4*>(MODE == 0 ? a.dy + pix * a.ldy + c0 + c : a.x + pix * a.ldx + c0 + c);
+            }
+            *reinterpret_cast<float4*>(&wide[pp * 128 + c]) = v;
+        }
+        if (tid < TPIX) {
+            int h, w;
+            if (MODE == 0) { h = h0 + tid / PW - 1; w = w0 + tid % PW - 1; }
+            else { h = h0 + tid / PTW; w = w0 + tid % PTW; }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h >= 0 && h < a.H && w >= 0 && w < a.W) {
+                const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+                if (MODE == 0) {
+                    v = *reinterpret_cast<const float4*>(a.x + pix * a.ldx);
+                } else {
+                    const float* p = a.dy + pix * a.ldy;
+                    v.x = p[0];
+                    if (a.Cout > 1) v.y = p[1];
+                    if (a.Cout > 2) v.z = p[2];
+                    if (a.Cout > 3) v.w = p[3];
+                }
+            }
+            thin[tid] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int q = 0; q < PTH * PTW / 2; ++q) {
+            const int pp = ph * (PTH * PTW / 2) + q, py = pp / PTW, px = pp % PTW;
+            if (MODE == 0) {
+                const float d = wide[pp * 128 + wc];
+                accb[0] += d;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float4 xv = thin[(py + tap / 3) * PW + px + tap % 3];
+                    acc[tap][0] = fmaf(xv.x, d, acc[tap][0]);
+                    acc[tap][1] = fmaf(xv.y, d, acc[tap][1]);
+                    acc[tap][2] = fmaf(xv.z, d, acc[tap][2]);
+                    acc[tap][3] = fmaf(xv.w, d, acc[tap][3]);
+                }
+            } else {
+                const float4 d = thin[pp];
+                accb[0] += d.x; accb[1] += d.y; accb[2] += d.z; accb[3] += d.w;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float xv = wide[((py + tap / 3) * PW + px + tap % 3) * 128 + wc];
+                    acc[tap][0] = fmaf(xv, d.x, acc[tap][0]);
+                    acc[tap][1] = fmaf(xv, d.y, acc[tap][1]);
+                    acc[tap][2] = fmaf(xv, d.z, acc[tap][2]);
+                    acc[tap][3] = fmaf(xv, d.w, acc[tap][3]);
+                }
+            }
         }
     }
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        // iterate with co fastest so that workspace reads are coalesced
-        const int co = (int)(i % Cout);
-        const size_t t = i / Cout;
-        const int ci = (int)(t % Cin);
-        const int tap = (int)(t / Cin);
-        const float* p = ws + ((size_t)tap * CinP + ci) * CoutP + co;
+    // the two pixel halves are added through LDS (upper half parks its sums), then the partial tile goes to the workspace
+    __syncthreads();
+    float* park = wide;                                           // [40][128]
+    if (ph == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) park[(t * 4 + c) * 128 + wc] = acc[t][c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) park[(36 + c) * 128 + wc] = accb[c];
+    }
+    __syncthreads();
+    if (ph == 1 || c0 + wc >= Cw) return;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] += park[(t * 4 + c) * 128 + wc];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accb[c] += park[(36 + c) * 128 + wc];
+    float* wsp = a.ws + (size_t)blockIdx.z * 9 * a.CinP * a.CoutP;
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wsp[((size_t)t * a.CinP + c) * a.CoutP + c0 + wc] = acc[t][c];
+        if (a.wsb) a.wsb[(size_t)blockIdx.z * a.CoutP + c0 + wc] = accb[0];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            *reinterpret_cast<float4*>(&wsp[((size_t)t * a.CinP + c0 + wc) * a.CoutP]) =
+                make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (a.wsb && c0 + wc == 0)
+            *reinterpret_cast<float4*>(&a.wsb[(size_t)blockIdx.z * a.CoutP]) = make_float4(accb[0], accb[1], accb[2], accb[3]);
+    }
+}
+
+// dW[co][ci][tap] = sum_splits ws[s][tap][ci][co] (+ db[co] = sum_splits wsb[s][co]).  16 outputs x 16 split lanes per workgroup,
+// lanes combined in a fixed order: a thread per output walking all splits was one dependent-latency chain of up to 384 loads
+// (0.23 ms for the stem's 4608 outputs).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           const float* __restrict__ wsb, float* __restrict__ db, int splits,
+                                                           int taps, int Cin, int Cout, int CinP, int CoutP) {
+    __shared__ float red[16][17];
+    const size_t total = (size_t)Cout * Cin * taps;
+    const size_t outputs = total + (db ? Cout : 0);
+    const size_t stride = (size_t)taps * CinP * CoutP;
+    const int o = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    for (size_t base = (size_t)blockIdx.x * 16; base < outputs; base += (size_t)gridDim.x * 16) {
+        const size_t i = base + o;
+        const float* p = nullptr;
+        size_t st = 0, dst = 0;
+        bool bias = false;
+        if (i < total) {                                   // co fastest: workspace reads are coalesced
+            const int co = (int)(i % Cout);
+            const size_t t = i / Cout;
+            const int ci = (int)(t % Cin);
+            const int tap = (int)(t / Cin);
+            p = ws + ((size_t)tap * CinP + ci) * CoutP + co;
+            st = stride;
+            dst = ((size_t)co * Cin + ci) * taps + tap;
+        } else if (i < outputs) {
+            p = wsb + (i - total);
+            st = CoutP;
+            dst = i - total;
+            bias = true;
+        }
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += p[k * stride];
-        dw[((size_t)co * Cin + ci) * taps + tap] = s;
+        if (p) {
+            int k = zl;
+            for (; k + 48 < splits; k += 64)
+                s += (p[(size_t)k * st] + p[(size_t)(k + 16) * st]) + (p[(size_t)(k + 32) * st] + p[(size_t)(k + 48) * st]);
+            for (; k < splits; k += 16) s += p[(size_t)k * st];
+        }
+        red[zl][o] = s;
+        __syncthreads();
+        if (zl == 0 && p) {
+            float v[16];
+#pragma unroll
+            for (int z = 0; z < 16; ++z) v[z] = red[z][o];
+            const float r = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                            (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+            if (bias) db[dst] = r;
+            else dw[dst] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -341,23 +495,37 @@ __global__ void pack_weight_dgrad_kernel(const float* __restrict__ w, float* __r
 
 }  // namespace
 
-// geometry shared by the workspace query and the launcher: ci tile 128 (8 waves) when Cin >= 128, else 64 (4 waves)
+// geometry shared by the workspace query and the launcher: ci tile 128 (8 waves) when Cin >= 128, else 64 (4 waves); thin 3x3
+// layers (conv_wgrad_thin_f32): mode 0 = 4 input channels, mode 1 = at most 4 output channels
 struct WgradGeom {
-    int cti, CinP, CoutP, ptiles, splits, tiles_per_split;
+    int cti, CinP, CoutP, ptiles, splits, tiles_per_split, thin;
 };
-static WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout) {
+static int wgrad_thin_mode(int Cin, int Cout, int ks) {
+    if (ks != 3) return -1;
+    if (Cout <= 4 && Cin % 4 == 0) return 1;
+    if (Cin == 4 && Cout % 4 == 0) return 0;
+    return -1;
+}
+static WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int thin) {
     WgradGeom g;
+    g.thin = thin;
     g.cti = Cin >= 128 ? 128 : 64;
     g.CinP = cdiv(Cin, g.cti) * g.cti;
     g.CoutP = cdiv(Cout, CT) * CT;
     g.ptiles = N * cdiv(H, PTH) * cdiv(W, PTW);
-    const int tiles = (g.CinP / g.cti) * (g.CoutP / CT);
-    int splits = cdiv(g.cti == 128 ? 512 : 768, tiles);
+    int tiles = (g.CinP / g.cti) * (g.CoutP / CT);
+    int want = g.cti == 128 ? 512 : 768;
+    if (thin == 0) { g.CinP = 4; tiles = cdiv(Cout, 128); want = 768; }
+    if (thin == 1) { g.CoutP = 4; tiles = cdiv(Cin, 128); want = 768; }
+    int splits = cdiv(want, tiles);
     if (splits > g.ptiles) splits = g.ptiles;
     if (splits < 1) splits = 1;
     g.tiles_per_split = cdiv(g.ptiles, splits);
     g.splits = cdiv(g.ptiles, g.tiles_per_split);
     return g;
+}
+static size_t wgrad_geom_floats(const WgradGeom& g, int ks) {
+    return (size_t)g.splits * ks * ks * g.CinP * g.CoutP + (size_t)g.splits * g.CoutP;
 }
 
 // 1x1 layers wide enough for 128-wide MFMA tiles take the TN GEMM of winograd_wgrad.hip (K = pixels): 100-117 TFLOP/s where
@@ -365,8 +533,12 @@ static WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout) {
 static bool wgrad_tn_path(int Cin, int Cout, int ks) { return ks == 1 && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 64 && Cout >= 64; }
 
 extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
-    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout);
-    size_t need = (size_t)g.splits * ks * ks * g.CinP * g.CoutP + (size_t)g.splits * g.CoutP;
+    size_t need = wgrad_geom_floats(wgrad_geom(N, H, W, Cin, Cout, -1), ks);      // the thin path may be refused at launch (pitches)
+    const int thin = wgrad_thin_mode(Cin, Cout, ks);
+    if (thin >= 0) {
+        const size_t t = wgrad_geom_floats(wgrad_geom(N, H, W, Cin, Cout, thin), ks);
+        if (t > need) need = t;
+    }
     if (wgrad_tn_path(Cin, Cout, ks)) {
         const size_t tn = (size_t)bbdm_gemm_tn_splits(1, (long long)N * H * W, Cin, Cout) * Cin * Cout + 2 * (size_t)Cout + 2;
         if (tn > need) need = tn;
@@ -417,7 +589,10 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
         }
         return rc;
     }
-    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout);
+    int thin = wgrad_thin_mode(Cin, Cout, ks);
+    if (thin == 0 && (ldy % 4 != 0 || ((uintptr_t)dy & 15) != 0)) thin = -1;      // float4 loads of the wide tensor
+    if (thin >= 0 && ((uintptr_t)ws & 15) != 0) thin = -1;
+    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout, thin);
     WgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.ldx = ldx; a.ldy = ldy;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -428,13 +603,19 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     a.tiles_per_split = g.tiles_per_split;
     const int splits = g.splits;
     a.wsb = dbias ? ws + (size_t)splits * ks * ks * a.CinP * a.CoutP : nullptr;
-    const dim3 grid(a.CinP / g.cti, a.CoutP / CT, splits);
-    int rc;
-    if (ks == 3) rc = g.cti == 128 ? launch_wgrad<9, 4>(a, grid, st) : launch_wgrad<9, 2>(a, grid, st);
-    else rc = g.cti == 128 ? launch_wgrad<1, 4>(a, grid, st) : launch_wgrad<1, 2>(a, grid, st);
+    int rc = 0;
+    if (thin == 0) {
+        hipLaunchKernelGGL((conv_wgrad_thin_f32<0>), dim3(cdiv(Cout, 128), 1, splits), dim3(256), 0, st, a);
+    } else if (thin == 1) {
+        hipLaunchKernelGGL((conv_wgrad_thin_f32<1>), dim3(cdiv(Cin, 128), 1, splits), dim3(256), 0, st, a);
+    } else {
+        const dim3 grid(a.CinP / g.cti, a.CoutP / CT, splits);
+        if (ks == 3) rc = g.cti == 128 ? launch_wgrad<9, 4>(a, grid, st) : launch_wgrad<9, 2>(a, grid, st);
+        else rc = g.cti == 128 ? launch_wgrad<1, 4>(a, grid, st) : launch_wgrad<1, 2>(a, grid, st);
+    }
     if (rc != 0) return rc;
     const size_t total = (size_t)Cout * Cin * ks * ks;
-    int rb = (int)((total + 255) / 256);
+    int rb = (int)((total + Cout + 15) / 16);
     if (rb > 4096) rb = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, st, ws, dw_oihw, a.wsb, dbias, splits, ks * ks, Cin,
                        Cout, a.CinP, a.CoutP);

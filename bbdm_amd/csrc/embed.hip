@@ -66,49 +66,62 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
     y[(size_t)n * Out + o] = acc;
 }
 
-// ---- backward of linear_kernel (training path; M = batch, so these are tiny) ---------------------------------------
-// dx_pre[n][i] = act_in'(x[n][i]) * sum_o dy[n][o] w[o][i].  grid = (In/256, o-chunks); each thread owns one input
-// column i for ALL rows n (<= 64 accumulators), so every weight element is read exactly once; the o-chunks write
-// partials that a second kernel sums in a fixed order (deterministic).
+// ---- backward of linear_kernel (training path; M = batch <= 64 rows) --------------------------------------------------------------
+// Both products run on the fp32 matrix core (v_mfma_f32_32x32x2f32, exact fp32 products, fp32 accumulate): they are skinny GEMMs
+// whose one large operand -- the 51 MB FiLM projection weight of the LBBDM-f4 UNet, or its gradient -- moves once, at HBM rate.
+//
+// dx_pre[n][i] = act_in'(x[n][i]) * sum_o dy[n][o] w[o][i].  grid = (In/128, o-chunks); a workgroup stages its chunk of dy in LDS
+// (pitch LB_PITCH: the A fragment's 64 lanes fall on 64 banks), each wave owns 32 input columns for all rows (two 32-row
+// accumulators) and streams its slice of w with eight 128-byte row segments in flight per half-wave; the o-chunks write partials
+// that a second kernel sums in a fixed order (deterministic).
 constexpr int LB_OCH = 256;      // outputs per chunk
+constexpr int LB_PITCH = LB_OCH + 2;
 
 __global__ void __launch_bounds__(256) linear_bwd_x_partial_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                    float* __restrict__ part, int N, int In, int Out) {
-    __shared__ __attribute__((aligned(16))) float dys[64 * LB_OCH];           // [n][o in chunk]
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float dys[];              // [32 or 64][LB_PITCH]: dy[n][o in chunk]; rows >= N zero
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     const int o0 = blockIdx.y * LB_OCH;
     const int on = min(LB_OCH, Out - o0);
-    for (int k = threadIdx.x; k < N * LB_OCH; k += 256) {
+    const int NT = N > 32 ? 2 : 1;
+    for (int k = tid; k < NT * 32 * LB_OCH; k += 256) {
         const int n = k / LB_OCH, o = k - n * LB_OCH;
-        dys[k] = o < on ? dy[(size_t)n * Out + o0 + o] : 0.f;
+        dys[n * LB_PITCH + o] = (n < N && o < on) ? dy[(size_t)n * Out + o0 + o] : 0.f;
     }
     __syncthreads();
-    if (i >= In) return;
-    float acc[64];
+    const int i0 = blockIdx.x * 128 + wave * 32;
+    if (i0 >= In) return;
+    const int i = i0 + l31;
+    const bool iv = i < In;
+    const float* wp = w + (size_t)o0 * In + (iv ? i : In - 1);
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int n = 0; n < 64; ++n) acc[n] = 0.f;
-    // four outputs per step: one broadcast ds_read_b128 of dy per row feeds four FMAs (one LDS read per FMA made this kernel
-    // LDS-issue-bound: 490 us for the 51 MB FiLM projection of the LBBDM-f4 UNet); same accumulation order as the scalar loop
-    int o = 0;
-    for (; o + 4 <= on; o += 4) {
-        const float w0 = w[(size_t)(o0 + o) * In + i], w1 = w[(size_t)(o0 + o + 1) * In + i];
-        const float w2 = w[(size_t)(o0 + o + 2) * In + i], w3 = w[(size_t)(o0 + o + 3) * In + i];
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    const int on2 = (on + 1) & ~1;                                            // dys is zero past `on`; w rows are clamped below
+    for (int k0 = 0; k0 < on2; k0 += 16) {
+        float b[8];
 #pragma unroll
-        for (int n = 0; n < 64; ++n)
-            if (n < N) {
-                const float4 d = *reinterpret_cast<const float4*>(&dys[n * LB_OCH + o]);
-                acc[n] = fmaf(d.w, w3, fmaf(d.z, w2, fmaf(d.y, w1, fmaf(d.x, w0, acc[n]))));
+        for (int u = 0; u < 8; ++u) {
+            const int o = k0 + 2 * u + hi;
+            const float v = wp[(size_t)(o < on ? o : on - 1) * In];           // clamped address + select (no branch between loads)
+            b[u] = (iv && o < on) ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int o = k0 + 2 * u + hi;
+            if (k0 + 2 * u < on2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[l31 * LB_PITCH + o], b[u], acc0, 0, 0, 0);
+                if (NT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dys[(32 + l31) * LB_PITCH + o], b[u], acc1, 0, 0, 0);
             }
+        }
     }
-    for (; o < on; ++o) {
-        const float wv = w[(size_t)(o0 + o) * In + i];
+    if (!iv) return;
 #pragma unroll
-        for (int n = 0; n < 64; ++n)
-            if (n < N) acc[n] = fmaf(dys[n * LB_OCH + o], wv, acc[n]);
+    for (int r = 0; r < 16; ++r) {
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (n < N) part[((size_t)blockIdx.y * N + n) * In + i] = acc0[r];
+        if (NT == 2 && 32 + n < N) part[((size_t)blockIdx.y * N + 32 + n) * In + i] = acc1[r];
     }
-#pragma unroll
-    for (int n = 0; n < 64; ++n)
-        if (n < N) part[((size_t)blockIdx.y * N + n) * In + i] = acc[n];
 }
 
 __global__ void linear_bwd_x_final_kernel(const float* __restrict__ part, const float* __restrict__ x_pre,
@@ -125,30 +138,55 @@ __global__ void linear_bwd_x_final_kernel(const float* __restrict__ part, const 
     dx[idx] = s;
 }
 
-// dw[o][i] = sum_n dy[n][o] act_in(x[n][i]),  db[o] = sum_n dy[n][o].  Block = 8 outputs x all inputs; x staged in LDS.
+// dw[o][i] = sum_n dy[n][o] act_in(x[n][i]),  db[o] = sum_n dy[n][o].  act_in(x) is staged in LDS once per workgroup (rows padded
+// with zeros to an even count); a workgroup walks 32-output tiles, its four waves take the 32-column input tiles in turn: the dy
+// fragment of the tile (K = batch) stays in registers, one ds_read + one MFMA per two batch rows, rows of dw leave as 128-byte runs.
 __global__ void __launch_bounds__(256) linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            float* __restrict__ dw, float* __restrict__ db, int N, int In,
                                                            int Out, int act_in) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];     // [N][In]
-    for (int k = threadIdx.x; k < N * In; k += 256) {
-        float v = x[k];
-        if (act_in) v = silu_f(v);
+    extern __shared__ __attribute__((aligned(16))) float xs[];     // [N2][In], N2 = N rounded up to even
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int N2 = (N + 1) & ~1;
+    for (int k = tid; k < N2 * In; k += 256) {
+        float v = 0.f;
+        if (k < N * In) {
+            v = x[k];
+            if (act_in) v = silu_f(v);
+        }
         xs[k] = v;
     }
     __syncthreads();
-    const int o0 = blockIdx.x * 8;
-    for (int oo = 0; oo < 8; ++oo) {
-        const int o = o0 + oo;
-        if (o >= Out) break;
-        for (int i = threadIdx.x; i < In; i += 256) {
-            float s = 0.f;
-            for (int n = 0; n < N; ++n) s = fmaf(dy[(size_t)n * Out + o], xs[n * In + i], s);
-            dw[(size_t)o * In + i] = s;
+    const int itiles = (In + 31) / 32, otiles = (Out + 31) / 32;
+    for (int ot = blockIdx.x; ot < otiles; ot += gridDim.x) {
+        const int o = ot * 32 + l31;
+        const bool ov = o < Out;
+        float a[32];
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const int n = 2 * kk + hi;
+            a[kk] = (kk * 2 < N2 && n < N && ov) ? dy[(size_t)n * Out + o] : 0.f;
         }
-        if (db && threadIdx.x == 0) {
+        if (db && wave == 0 && hi == 0 && ov) {
             float s = 0.f;
             for (int n = 0; n < N; ++n) s += dy[(size_t)n * Out + o];
             db[o] = s;
+        }
+        for (int it = wave; it < itiles; it += 4) {
+            const int i = it * 32 + l31;
+            const float* xp = xs + (i < In ? i : In - 1);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk)
+                if (kk * 2 < N2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], xp[(2 * kk + hi) * In], acc, 0, 0, 0);
+            if (i < In) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oo = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (oo < Out) dw[(size_t)oo * In + i] = acc[r];
+                }
+            }
         }
     }
 }
@@ -163,7 +201,7 @@ extern "C" int bbdm_linear_bwd_f32(const float* dy, const float* x, const float*
                                    float* ws, int N, int In, int Out, int act_in, void* stream) {
     BBDM_REQUIRE(dy && x && w && dw && ws && N > 0 && N <= 64 && In > 0 && Out > 0, "linear_bwd: bad args (N <= 64)");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)N * In * sizeof(float);
+    const size_t lds = (size_t)((N + 1) & ~1) * In * sizeof(float);
     BBDM_REQUIRE(lds <= 160 * 1024, "linear_bwd: N*In too large for LDS staging");
     static size_t lds_set_dev[BBDM_MAX_DEVICES] = {};
     size_t& lds_set = lds_set_dev[bbdm_device_slot()];
@@ -175,10 +213,22 @@ extern "C" int bbdm_linear_bwd_f32(const float* dy, const float* x, const float*
         }
         lds_set = lds;
     }
-    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(cdiv(Out, 8)), dim3(256), lds, st, dy, x, dw, db, N, In, Out, act_in);
+    const int otiles = cdiv(Out, 32);
+    hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(otiles < 512 ? otiles : 512), dim3(256), lds, st, dy, x, dw, db, N, In, Out, act_in);
     if (dx) {
         const int chunks = cdiv(Out, LB_OCH);
-        hipLaunchKernelGGL(linear_bwd_x_partial_kernel, dim3(cdiv(In, 256), chunks), dim3(256), 0, st, dy, w, ws, N, In, Out);
+        const size_t lds_x = (size_t)(N > 32 ? 64 : 32) * LB_PITCH * sizeof(float);
+        static bool x_attr_dev[BBDM_MAX_DEVICES] = {};
+        bool& x_attr = x_attr_dev[bbdm_device_slot()];
+        if (lds_x > 64 * 1024 && !x_attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bwd_x_partial_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x) != hipSuccess) {
+                bbdm_set_error("linear_bwd: hipFuncSetAttribute failed");
+                return BBDM_E_LAUNCH;
+            }
+            x_attr = true;
+        }
+        hipLaunchKernelGGL(linear_bwd_x_partial_kernel, dim3(cdiv(In, 128), chunks), dim3(256), lds_x, st, dy, w, ws, N, In, Out);
         hipLaunchKernelGGL(linear_bwd_x_final_kernel, dim3(cdiv(N * In, 256)), dim3(256), 0, st, ws, x, dx, chunks, N, In,
                            act_in);
     }

@@ -31,7 +31,10 @@ CONV_BWD = [(2, 16, 16, 32, 64, 3), (1, 24, 40, 64, 128, 3), (3, 8, 8, 128, 96, 
             (2, 16, 16, 1024, 1024, 3), (2, 16, 16, 2048, 1024, 3), (2, 32, 32, 1536, 512, 3), (2, 64, 64, 640, 128, 3),
             (2, 16, 16, 2048, 1024, 1), (2, 64, 64, 128, 128, 3), (2, 32, 32, 512, 512, 3),
             # more 1x1 weight gradients (TN GEMM over the pixels): ragged channel tiles, K splits, a short K
-            (4, 16, 16, 160, 132, 1), (32, 16, 16, 1024, 512, 1), (3, 8, 8, 96, 72, 1)]
+            (4, 16, 16, 160, 132, 1), (32, 16, 16, 1024, 512, 1), (3, 8, 8, 96, 72, 1),
+            # 3x3 layers with a thin side on the vector-ALU kernel (conv_wgrad_thin_f32): the stem / head of the UNet, ragged tiles,
+            # more than one 128-channel tile on the wide side, 1..4 output channels
+            (2, 64, 64, 4, 128, 3), (2, 64, 64, 128, 3, 3), (2, 20, 12, 4, 132, 3), (1, 9, 9, 260, 4, 3), (3, 8, 8, 16, 1, 3)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks", CONV_BWD)
