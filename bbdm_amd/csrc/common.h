@@ -39,6 +39,10 @@ static inline int bbdm_device_slot() {
     return d;
 }
 
+// winograd_wgrad.hip: bbdm_gemm_tn_batched_f32 + the column sums of B per K split (internal; conv_wgrad.hip's 1x1 path)
+int bbdm_gemm_tn_impl(const float* A, int lda, size_t a_stride, const float* B, int ldb, size_t b_stride, float* C, float* bias_part,
+                      int batch, long long K, int M, int N, void* stream);
+
 // Zero `bytes` (a multiple of 8, 8-byte aligned) on `st` with a KERNEL instead of hipMemsetAsync: the gradient plan is replayed as a
 // hipGraph, and a captured memset node does not reproduce the eager memset on this ROCm (the GroupNorm-backward accumulators kept
 // the previous replay's sums; found by bench.py's c4 parity check) -- kernel nodes do.

@@ -349,12 +349,31 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // combined in a fixed order -- deterministic): a 128 -> 256 layer has 256 splits x 128 KB to add, which one 4-byte load chain per
 // thread in 32 workgroups took 0.24 ms over.
 __global__ void __launch_bounds__(256) tn_finish4_kernel(const float* __restrict__ dU, int splits, float* __restrict__ dw, int Cin,
-                                                         int Cout) {
+                                                         int Cout, const float* __restrict__ bias_part, float* __restrict__ db,
+                                                         int bias_blocks) {
     __shared__ float4 red[4][64];
     __shared__ float tile[32][9];
-    const int tilesCo = (Cout + 31) / 32;
-    const int co0 = (int)(blockIdx.x % tilesCo) * 32, ci0 = (int)(blockIdx.x / tilesCo) * 8;
     const int tid = threadIdx.x, o = tid & 63, q = o & 7, cil = o >> 3, zl = tid >> 6;
+    if ((int)blockIdx.x < bias_blocks) {             // db[c] = sum_z bias_part[z][c]: 256 columns per workgroup, the same four z lanes
+        const int c = (int)blockIdx.x * 256 + o * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < Cout)
+            for (int z = zl; z < splits; z += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(bias_part + (size_t)z * Cout + c);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        red[zl][o] = s;
+        __syncthreads();
+        if (tid < 64 && c < Cout) {
+            const float4 a = red[0][o], b = red[1][o], cc = red[2][o], d = red[3][o];
+            *reinterpret_cast<float4*>(db + c) = make_float4((a.x + b.x) + (cc.x + d.x), (a.y + b.y) + (cc.y + d.y),
+                                                             (a.z + b.z) + (cc.z + d.z), (a.w + b.w) + (cc.w + d.w));
+        }
+        return;
+    }
+    const int bid = (int)blockIdx.x - bias_blocks;
+    const int tilesCo = (Cout + 31) / 32;
+    const int co0 = (bid % tilesCo) * 32, ci0 = (bid / tilesCo) * 8;
     const size_t per = (size_t)Cin * Cout;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ci0 + cil < Cin && co0 + 4 * q < Cout) {
@@ -540,7 +559,8 @@ extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin,
         if (t > need) need = t;
     }
     if (wgrad_tn_path(Cin, Cout, ks)) {
-        const size_t tn = (size_t)bbdm_gemm_tn_splits(1, (long long)N * H * W, Cin, Cout) * Cin * Cout + 2 * (size_t)Cout + 2;
+        const size_t sp = (size_t)bbdm_gemm_tn_splits(1, (long long)N * H * W, Cin, Cout);
+        const size_t tn = sp * Cin * Cout + 4 + (sp > 2 ? sp : 2) * (size_t)Cout + 2;      // partial tiles | per-split column sums
         if (tn > need) need = tn;
     }
     return need;
@@ -578,12 +598,17 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     if (wgrad_tn_path(Cin, Cout, ks) && ((uintptr_t)dy & 15) == 0 && ldy % 4 == 0 && ((uintptr_t)ws & 15) == 0) {
         const long long K = (long long)N * H * W;
         const int splits = bbdm_gemm_tn_splits(1, K, Cin, Cout);
-        int rc = bbdm_gemm_tn_batched_f32(x, ldx, 0, dy, ldy, 0, ws, 1, K, Cin, Cout, stream);
+        // the bias gradient rides along: per-split column sums of dY from the GEMM's B staging, added over the splits by the finish
+        // kernel (bbdm_colsum_f32 was three more launches and a second pass over dY per layer)
+        float* bias_part = nullptr;
+        if (dbias && ((uintptr_t)dbias & 15) == 0) bias_part = ws + (((size_t)splits * Cin * Cout + 3) & ~(size_t)3);
+        int rc = bbdm_gemm_tn_impl(x, ldx, 0, dy, ldy, 0, ws, bias_part, 1, K, Cin, Cout, stream);
         if (rc != BBDM_OK) return rc;
-        hipLaunchKernelGGL(tn_finish4_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 8))), dim3(256), 0, st, ws, splits,
-                           dw_oihw, Cin, Cout);
+        const int bias_blocks = bias_part ? cdiv(Cout, 256) : 0;
+        hipLaunchKernelGGL(tn_finish4_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 8) + bias_blocks)), dim3(256), 0, st, ws,
+                           splits, dw_oihw, Cin, Cout, bias_part, dbias, bias_blocks);
         BBDM_CHECK_LAUNCH("conv_wgrad(tn)");
-        if (dbias) {
+        if (dbias && !bias_part) {
             size_t off = ((size_t)splits * Cin * Cout + 1) & ~(size_t)1;        // 8-byte alignment of the fp64 scratch
             rc = bbdm_colsum_f32(dy, ldy, reinterpret_cast<double*>(ws + off), dbias, K, Cout, stream);
         }

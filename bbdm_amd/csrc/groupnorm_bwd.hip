@@ -5,7 +5,8 @@
 // Given dA (gradient of a), with dz = R^T(dA) and dv = dz * silu'(v):
 //   P[n,c] = sum_hw dv xh,   Q[n,c] = sum_hw dv                                   (kernel 1: reduce, fp64 sums)
 //   dgamma[c] = sum_n (1+sc) P,  dbeta[c] = sum_n (1+sc) Q,  dsc[n,c] = g P + b Q,  dsh[n,c] = Q,
-//   S1[n,G] = sum_{c in G} g (1+sc) Q,  S2[n,G] = sum_{c in G} g (1+sc) P          (kernel 2: finalize, tiny)
+//   S1[n,G] = sum_{c in G} g (1+sc) Q,  S2[n,G] = sum_{c in G} g (1+sc) P          (kernel 2: finalize, tiny; dgamma / dbeta leave
+//                                                                                    as fp32 in kernel 3's first workgroup)
 //   dx = r ( g (1+sc) dv - S1/cnt - xh S2/cnt )  [+ R^T(dAdd)]  [+ dx]             (kernel 3: apply)
 // dAdd carries the gradient of the skip path (x_upd / identity), which shares the same resampling.
 // All three are HBM-bound streaming kernels with float4 accesses along the channel axis.
@@ -24,6 +25,9 @@ struct BwdArgs {
     const double* sg;
     const float4* coef;          // [N][G] {rstd, mean, S1/cnt, S2/cnt} in fp32, written by the finalize kernel
     double* pq;
+    const double* dgb;           // [C][2] fp64 sums over n of dgamma / dbeta (finalize kernel), converted by the apply pass
+    float* dgamma;
+    float* dbeta;
     float* dx;
     int ldx, ldda, ldadd, lddx, film_ld;
     int H, W, C, G;
@@ -200,15 +204,6 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __re
     }
 }
 
-__global__ void gn_bwd_params_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                     int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        dgamma[c] = (float)dgb[2 * c];
-        dbeta[c] = (float)dgb[2 * c + 1];
-    }
-}
-
 // ---- kernel 3: dx ---------------------------------------------------------------------------------------------------
 // A thread keeps ONE channel quad for its whole pixel range (as the reduce pass does), so gamma / beta / FiLM / the group's
 // {rstd, mean, S1/cnt, S2/cnt} are loaded once per thread instead of once per element, there is no 64-bit div / mod per element,
@@ -251,6 +246,12 @@ __device__ __forceinline__ float4 apply_quad(const BwdArgs& a, const Chan4& k, f
 template <bool NORM>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int pix_per_block) {
     const int n = blockIdx.y, tid = threadIdx.x;
+    if (NORM && blockIdx.x == 0 && n == 0) {                     // dgamma / dbeta: the finalize kernel's fp64 sums over n, to fp32
+        for (int c = tid; c < a.C; c += 256) {
+            a.dgamma[c] = (float)a.dgb[2 * c];
+            a.dbeta[c] = (float)a.dgb[2 * c + 1];
+        }
+    }
     const int C4 = a.C >> 2, HW = a.H * a.W;
     const int cpg = a.G > 0 ? a.C / a.G : a.C;
     const int Ho = (a.resample == 1 || a.resample == 3) ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
@@ -339,7 +340,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.da = da; a.dadd = dadd; a.dx = dx;
     a.ldx = ldx; a.ldda = ldda; a.ldadd = ldadd; a.lddx = lddx; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample;
-    a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr;
+    a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr; a.dgb = nullptr; a.dgamma = nullptr; a.dbeta = nullptr;
     const int HW = H * W;
     if (norm) {
         double* pq = ws;
@@ -361,7 +362,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
         else hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, grid, dim3(256), lds, st, a, ppb);
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, pq, gamma, beta, film, film_ld, sg, dgb, dfilm,
                            dfilm_ld, C, G, stats, coef, (double)HW * (C / G), eps);
-        hipLaunchKernelGGL(gn_bwd_params_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dgb, dgamma, dbeta, C);
+        a.dgb = dgb; a.dgamma = dgamma; a.dbeta = dbeta;
     }
     {
         const int C4 = C / 4;

@@ -94,6 +94,7 @@ struct TnArgs {
     int batch, splits;
     int tilesM, tilesN;
     int items;                   // batch * splits
+    float* bias_part;            // [splits][batch][N] column sums of B over each split's K range (tiles mt == 0 write them), or null
 };
 
 template <int WM>
@@ -132,8 +133,15 @@ __global__ void __launch_bounds__(WM * 128, 2) gemm_tn_f32(const TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    float4 areg[ASLOTS], breg[BSLOTS];
-    auto load = [&](long long k0) {
+    // two stages of register prefetch: the rows of chunk c + 2 are requested while chunk c is multiplied and chunk c + 1 waits in
+    // the other register set for its turn in LDS -- with one set a workgroup's chunk took a full HBM round trip (the short-M/N
+    // layers of a training step, 256-512 workgroups on the chip, ran at a quarter of the MFMA rate)
+    float4 areg[2][ASLOTS], breg[2][BSLOTS];
+    // column sums of B (the bias gradient of a 1x1 layer: B = dY) ride along: a thread's B slots all hold the same column quad, so it
+    // adds them up as they pass through its registers -- no second pass over dY
+    const bool do_bias = a.bias_part != nullptr && mt == 0;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load = [&](long long k0, float4 (&ar)[ASLOTS], float4 (&br)[BSLOTS]) {
 #pragma unroll
         for (int s = 0; s < ASLOTS; ++s) {
             const int f = tid + s * NT;
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(WM * 128, 2) gemm_tn_f32(const TnArgs a) {
             const long long kr = k0 + k < a.K ? k0 + k : a.K - 1;
             const int mc = m0 + c < a.M ? m0 + c : a.M - 4;
             const float4 v = *reinterpret_cast<const float4*>(Ab + (size_t)kr * a.lda + mc);
-            areg[s] = (k0 + k < k_end && m0 + c < a.M) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            ar[s] = (k0 + k < k_end && m0 + c < a.M) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int s = 0; s < BSLOTS; ++s) {
@@ -152,31 +160,23 @@ __global__ void __launch_bounds__(WM * 128, 2) gemm_tn_f32(const TnArgs a) {
             const long long kr = k0 + k < a.K ? k0 + k : a.K - 1;
             const int nc = n0 + c < a.N ? n0 + c : a.N - 4;
             const float4 v = *reinterpret_cast<const float4*>(Bb + (size_t)kr * a.ldb + nc);
-            breg[s] = (k0 + k < k_end && n0 + c < a.N) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            br[s] = (k0 + k < k_end && n0 + c < a.N) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store = [&](float* st) {
+    auto store = [&](float* st, const float4 (&ar)[ASLOTS], const float4 (&br)[BSLOTS]) {
 #pragma unroll
         for (int s = 0; s < ASLOTS; ++s) {
             const int f = tid + s * NT;
-            *reinterpret_cast<float4*>(st + (f / (BM / 4)) * PA + (f % (BM / 4)) * 4) = areg[s];
+            *reinterpret_cast<float4*>(st + (f / (BM / 4)) * PA + (f % (BM / 4)) * 4) = ar[s];
         }
 #pragma unroll
         for (int s = 0; s < BSLOTS; ++s) {
             const int f = tid + s * NT;
-            *reinterpret_cast<float4*>(st + TKC * PA + (f / (TBN / 4)) * PB + (f % (TBN / 4)) * 4) = breg[s];
+            *reinterpret_cast<float4*>(st + TKC * PA + (f / (TBN / 4)) * PB + (f % (TBN / 4)) * 4) = br[s];
+            if (do_bias) { bsum.x += br[s].x; bsum.y += br[s].y; bsum.z += br[s].z; bsum.w += br[s].w; }
         }
     };
-
-    const int nchunks = (int)((k_end - k_begin + TKC - 1) / TKC);
-    if (nchunks > 0) {
-        load(k_begin);
-        store(smem);
-    }
-    __syncthreads();
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
-        if (more) load(k_begin + (long long)(chunk + 1) * TKC);
+    auto multiply = [&](int chunk) {
         const float* sA = smem + (chunk & 1) * STAGE + wm * 64 + l31;
         const float* sB = smem + (chunk & 1) * STAGE + TKC * PA + wn * 64 + l31;
 #pragma unroll
@@ -189,10 +189,41 @@ __global__ void __launch_bounds__(WM * 128, 2) gemm_tn_f32(const TnArgs a) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) store(smem + ((chunk + 1) & 1) * STAGE);
+    };
+
+    const int nchunks = (int)((k_end - k_begin + TKC - 1) / TKC);
+    if (nchunks > 0) {
+        load(k_begin, areg[0], breg[0]);
+        store(smem, areg[0], breg[0]);
+        if (nchunks > 1) load(k_begin + TKC, areg[1], breg[1]);
+    }
+    __syncthreads();
+    // chunk c is multiplied from LDS stage c & 1; chunk c + 1 sits in register set (c + 1) & 1; chunk c + 2 is requested into set c & 1
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        if (chunk + 2 < nchunks) load(k_begin + (long long)(chunk + 2) * TKC, areg[0], breg[0]);
+        multiply(chunk);
+        if (chunk + 1 < nchunks) store(smem + STAGE, areg[1], breg[1]);
+        __syncthreads();
+        if (chunk + 1 >= nchunks) break;
+        if (chunk + 3 < nchunks) load(k_begin + (long long)(chunk + 3) * TKC, areg[1], breg[1]);
+        multiply(chunk + 1);
+        if (chunk + 2 < nchunks) store(smem, areg[0], breg[0]);
         __syncthreads();
     }
 
+    if (do_bias) {                                   // (workgroup-uniform) the NT / 32 threads of a column quad, in a fixed order
+        float4* sb = reinterpret_cast<float4*>(smem);
+        sb[tid] = bsum;
+        __syncthreads();
+        if (tid < 32 && n0 + tid * 4 < a.N) {
+            float4 t = sb[tid];
+            for (int r = 1; r < NT / 32; ++r) {
+                const float4 v = sb[r * 32 + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            *reinterpret_cast<float4*>(a.bias_part + ((size_t)z * a.batch + b) * a.N + n0 + tid * 4) = t;
+        }
+    }
     float* __restrict__ Cb = a.C + ((size_t)z * a.batch + b) * (size_t)a.M * a.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -259,18 +290,51 @@ __global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restri
 // 128 x 128 layer gave that kernel 64 workgroups with one 4-byte load chain per thread (0.13 ms for 30 MB of partial sums); this one
 // puts ~4 MB in flight.  Phase 1: column sums over the K splits (fixed order) + G^T along xi -> LDS; phase 2: G^T along nu; the nine
 // taps of 4 ci leave as 144-byte runs.  Bit-identical to wgrad_finish_kernel (same operation order per (ci, co)).
+// The first `bias_blocks` workgroups instead sum the columns of dm11 [T][Cout] (the fp32 plane (1, 1) of dM = the tile sums of dY)
+// into db: 32 columns x 32 row lanes per workgroup, fp64 per-thread sums, lanes combined in a fixed order -- the bias gradient
+// without its own zeroing / summing / converting launches (bbdm_colsum_f32: three per layer, 25 us of a 64-launch-bound step).
 template <int MO>
 __global__ void __launch_bounds__(256) wgrad_finish_nu_kernel(const float* __restrict__ dU, int splits, float* __restrict__ dw,
-                                                              int Cin, int Cout) {
+                                                              int Cin, int Cout, const float* __restrict__ dm11, int T,
+                                                              float* __restrict__ db, int bias_blocks) {
     constexpr int AL = MO + 2;
     constexpr int FCI = 4, FCO = 32;
     __shared__ float hbuf[FCI][FCO][3][AL + 1];
     __shared__ float tile[FCO][FCI * 9 + 1];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < bias_blocks) {
+        __shared__ double red[32][8][4];                          // [row lane][column quad][4]
+        const int q = tid & 7, rl = tid >> 3, c = (int)blockIdx.x * 32 + 4 * q;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (c < Cout) {
+            const float* p = dm11 + c;
+            int r = rl;
+            for (; r + 224 < T; r += 256) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(r + 32 * u) * Cout);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+            }
+            for (; r < T; r += 32) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)r * Cout);
+                s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+            }
+        }
+        red[rl][q][0] = s0; red[rl][q][1] = s1; red[rl][q][2] = s2; red[rl][q][3] = s3;
+        __syncthreads();
+        if (tid < 32 && (int)blockIdx.x * 32 + tid < Cout) {
+            double t = 0.0;
+            for (int k = 0; k < 32; ++k) t += red[k][tid >> 2][tid & 3];
+            db[blockIdx.x * 32 + tid] = (float)t;
+        }
+        return;
+    }
     const size_t per = (size_t)Cin * Cout;
     const size_t zstride = (size_t)AL * AL * per;
     const int tilesCo = (Cout + FCO - 1) / FCO;
-    const int co0 = (int)(blockIdx.x % tilesCo) * FCO, ci0 = (int)(blockIdx.x / tilesCo) * FCI;
-    const int tid = threadIdx.x;
+    const int bid = (int)blockIdx.x - bias_blocks;
+    const int co0 = (bid % tilesCo) * FCO, ci0 = (bid / tilesCo) * FCI;
     const int q = tid & 7, nu = (tid >> 3) & 7, cil = tid >> 6;
     if (nu < AL && co0 + 4 * q < Cout && ci0 + cil < Cin) {
         const size_t i = (size_t)(ci0 + cil) * Cout + co0 + 4 * q;
@@ -324,8 +388,12 @@ TnGeom tn_geom(int batch, long long K, int M, int N) {
     g.tilesM = cdiv(M, g.wm * 64);
     g.tilesN = cdiv(N, TBN);
     const long long base = (long long)batch * g.tilesM * g.tilesN;
-    long long splits = (768 + base - 1) / base;                 // >= 3 workgroups per CU when K allows
-    const long long max_splits = K / 512 > 1 ? K / 512 : 1;     // >= 32 stages per workgroup
+    static const int target_env = getenv("BBDM_TN_TARGET") ? atoi(getenv("BBDM_TN_TARGET")) : 0;
+    static const int minK_env = getenv("BBDM_TN_MINK") ? atoi(getenv("BBDM_TN_MINK")) : 0;
+    const int target = target_env > 0 ? target_env : 768;
+    const int minK = minK_env > 0 ? minK_env : 512;
+    long long splits = (target + base - 1) / base;              // >= 3 workgroups per CU when K allows
+    const long long max_splits = K / minK > 1 ? K / minK : 1;   // >= 32 stages per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     long long kps = (K + splits - 1) / splits;
@@ -343,8 +411,15 @@ extern "C" int bbdm_gemm_tn_splits(int batch, long long K, int M, int N) {
 }
 
 // C[z][b][M][N] (z < bbdm_gemm_tn_splits: partial sums over disjoint K ranges, to be added in order by the consumer)
+int bbdm_gemm_tn_impl(const float* A, int lda, size_t a_stride, const float* B, int ldb, size_t b_stride, float* C, float* bias_part,
+                      int batch, long long K, int M, int N, void* stream);
 extern "C" int bbdm_gemm_tn_batched_f32(const float* A, int lda, size_t a_stride, const float* B, int ldb, size_t b_stride,
                                         float* C, int batch, long long K, int M, int N, void* stream) {
+    return bbdm_gemm_tn_impl(A, lda, a_stride, B, ldb, b_stride, C, nullptr, batch, K, M, N, stream);
+}
+// ... + bias_part[z][b][N] = the column sums of B over split z's K range (conv_wgrad.hip: the bias gradient of the 1x1 layers)
+int bbdm_gemm_tn_impl(const float* A, int lda, size_t a_stride, const float* B, int ldb, size_t b_stride, float* C, float* bias_part,
+                      int batch, long long K, int M, int N, void* stream) {
     BBDM_REQUIRE(A && B && C, "gemm_tn: null pointer");
     BBDM_REQUIRE(batch > 0 && K > 0 && M > 0 && N > 0 && M % 4 == 0 && N % 4 == 0, "gemm_tn: bad shape batch=%d K=%lld M=%d N=%d",
                  batch, K, M, N);
@@ -354,7 +429,8 @@ extern "C" int bbdm_gemm_tn_batched_f32(const float* A, int lda, size_t a_stride
     TnArgs a;
     a.A = A; a.B = B; a.C = C; a.a_stride = a_stride; a.b_stride = b_stride; a.lda = lda; a.ldb = ldb;
     a.M = M; a.N = N; a.K = K; a.k_per_split = g.k_per_split; a.batch = batch; a.splits = g.splits;
-    a.tilesM = g.tilesM; a.tilesN = g.tilesN; a.items = batch * g.splits;
+    a.tilesM = g.tilesM; a.tilesN = g.tilesN; a.items = batch * g.splits; a.bias_part = bias_part;
+    BBDM_REQUIRE(!bias_part || ((uintptr_t)bias_part & 15) == 0, "gemm_tn: bias_part alignment");
     const long long blocks = (long long)cdiv(a.items, 8) * 8 * g.tilesM * g.tilesN;
     BBDM_REQUIRE(blocks < (1ll << 31), "gemm_tn: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -390,29 +466,45 @@ extern "C" int bbdm_winograd_dy_transform_f32(int m, const float* dy, int ld, fl
     return BBDM_OK;
 }
 
-extern "C" int bbdm_winograd_wgrad_finish_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout,
-                                              void* stream) {
+static int wgrad_finish_launch(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, const float* dm11, int T,
+                               float* dbias, void* stream) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(dU && dw_oihw && splits > 0 && Cin > 0 && Cout > 0, "winograd_wgrad_finish: bad args");
     hipStream_t st = (hipStream_t)stream;
     const dim3 b(256);
-    if (Cout % 4 == 0 && ((uintptr_t)dU & 15) == 0) {
-        const long long blocks = (long long)cdiv(Cout, 32) * cdiv(Cin, 4);
+    if (Cout % 4 == 0 && ((uintptr_t)dU & 15) == 0 && (!dbias || ((uintptr_t)dm11 & 15) == 0)) {
+        const int bias_blocks = dbias ? cdiv(Cout, 32) : 0;
+        const long long blocks = (long long)cdiv(Cout, 32) * cdiv(Cin, 4) + bias_blocks;
         BBDM_REQUIRE(blocks < (1ll << 31), "winograd_wgrad_finish: grid too large");
         const dim3 g((unsigned)blocks);
-        if (m == 2) hipLaunchKernelGGL((wgrad_finish_nu_kernel<2>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
-        else if (m == 4) hipLaunchKernelGGL((wgrad_finish_nu_kernel<4>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
-        else hipLaunchKernelGGL((wgrad_finish_nu_kernel<6>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
-    } else {
-        const long long blocks = (long long)cdiv(Cout, 32) * cdiv(Cin, 8);
-        BBDM_REQUIRE(blocks < (1ll << 31), "winograd_wgrad_finish: grid too large");
-        const dim3 g((unsigned)blocks);
-        if (m == 2) hipLaunchKernelGGL((wgrad_finish_kernel<2>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
-        else if (m == 4) hipLaunchKernelGGL((wgrad_finish_kernel<4>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
-        else hipLaunchKernelGGL((wgrad_finish_kernel<6>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
+        if (m == 2) hipLaunchKernelGGL((wgrad_finish_nu_kernel<2>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
+        else if (m == 4) hipLaunchKernelGGL((wgrad_finish_nu_kernel<4>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
+        else hipLaunchKernelGGL((wgrad_finish_nu_kernel<6>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
+        BBDM_CHECK_LAUNCH("winograd_wgrad_finish");
+        return BBDM_OK;
     }
+    BBDM_REQUIRE(!dbias, "winograd_wgrad_finish_bias: Cout %% 4 == 0 and 16-byte aligned dU / dm11 required");
+    const long long blocks = (long long)cdiv(Cout, 32) * cdiv(Cin, 8);
+    BBDM_REQUIRE(blocks < (1ll << 31), "winograd_wgrad_finish: grid too large");
+    const dim3 g((unsigned)blocks);
+    if (m == 2) hipLaunchKernelGGL((wgrad_finish_kernel<2>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
+    else if (m == 4) hipLaunchKernelGGL((wgrad_finish_kernel<4>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
+    else hipLaunchKernelGGL((wgrad_finish_kernel<6>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
     BBDM_CHECK_LAUNCH("winograd_wgrad_finish");
     return BBDM_OK;
+}
+
+extern "C" int bbdm_winograd_wgrad_finish_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout,
+                                              void* stream) {
+    return wgrad_finish_launch(m, dU, splits, dw_oihw, Cin, Cout, nullptr, 0, nullptr, stream);
+}
+
+// ... and the bias gradient in the same launch: db[c] = sum_t dm11[t][c], t < T (dm11: the plane (1, 1) of dM, pitch Cout, as
+// bbdm_winograd_dy_transform_bf3p_f32 writes it -- the tile sums of dY).  Cout % 4 == 0, dU / dm11 16-byte aligned.
+extern "C" int bbdm_winograd_wgrad_finish_bias_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout,
+                                                   const float* dm11, long long T, float* dbias, void* stream) {
+    BBDM_REQUIRE(dm11 && dbias && T > 0 && T < (1ll << 31), "winograd_wgrad_finish_bias: bad dm11 / dbias / T");
+    return wgrad_finish_launch(m, dU, splits, dw_oihw, Cin, Cout, dm11, (int)T, dbias, stream);
 }
 
 // workspace of bbdm_conv3x3_winograd_wgrad_f32, in floats: V | dM | dU[splits] | fp64 column-sum scratch [Cout]

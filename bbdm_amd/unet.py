@@ -1585,9 +1585,13 @@ class _Plan:
                 dMt, dm11, dU = _TensorRef(self._ws_f, 0), _TensorRef(self._ws_f, 4 * o_dm11), _TensorRef(self._ws_f, 4 * o_du)
                 self._bop("bbdm_winograd_dy_transform_bf3p_f32", wgm, dy, dy.ld, dMt, dm11, N, x_in.H, x_in.W, cout)
                 self._bop("bbdm_gemm_bf3p_tn_f32", saved[0], dMt, dU, P, Tp, x_in.C, cout)
-                self._bop("bbdm_winograd_wgrad_finish_f32", wgm, dU, splits, dw_dst, x_in.C, cout)
-                if dbias is not None:       # column sums of dM's plane (1, 1) = the tile sums of dY
-                    self._bop("bbdm_colsum_f32", dm11, cout, _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
+                if dbias is not None and cout % 4 == 0:
+                    # ... + the bias gradient in the same launch: column sums of dM's plane (1, 1) = the tile sums of dY
+                    self._bop("bbdm_winograd_wgrad_finish_bias_f32", wgm, dU, splits, dw_dst, x_in.C, cout, dm11, T, dbias)
+                else:
+                    self._bop("bbdm_winograd_wgrad_finish_f32", wgm, dU, splits, dw_dst, x_in.C, cout)
+                    if dbias is not None:
+                        self._bop("bbdm_colsum_f32", dm11, cout, _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
             elif saved is not None and saved[1] == wgm:
                 # the forward kept this layer's V: dY transform -> TN GEMM -> finish (the stages bbdm_conv3x3_winograd_wgrad_f32 chains)
                 P, Tp = (wgm + 2) ** 2, lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)

@@ -174,7 +174,10 @@ int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float
  *   bbdm_winograd_dy_transform_f32 : dy NHWC (pitch ld) -> dM[(m+2)^2][bbdm_winograd_tiles()][Cout]
  *   bbdm_gemm_tn_batched_f32       : C[z][b][M][N] = sum_{k in K-range z} A[b][k][M] B[b][k][N] (fp32 MFMA; z <
  *                                    bbdm_gemm_tn_splits(batch, K, M, N) partial sums for the consumer to add in order)
- *   bbdm_winograd_wgrad_finish_f32 : dU[splits][(m+2)^2][Cin][Cout] -> dW OIHW. */
+ *   bbdm_winograd_wgrad_finish_f32 : dU[splits][(m+2)^2][Cin][Cout] -> dW OIHW.
+ *   bbdm_winograd_wgrad_finish_bias_f32 : the same + dbias[c] = sum_{t < T} dm11[t][c] in the same launch (dm11: the fp32 plane
+ *                                    (1, 1) of dM = the tile sums of dY, pitch Cout, from bbdm_winograd_dy_transform_bf3p_f32;
+ *                                    Cout % 4 == 0) -- the bias gradient autograd derives for nn.Conv2d (openaimodel.py:233,244). */
 size_t bbdm_winograd_wgrad_workspace_floats(int m, int N, int H, int W, int Cin, int Cout);
 int bbdm_conv3x3_winograd_wgrad_f32(int m, const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias,
                                     float* ws, int N, int H, int W, int Cin, int Cout, void* stream);
@@ -183,6 +186,8 @@ int bbdm_gemm_tn_splits(int batch, long long K, int M, int N);
 int bbdm_gemm_tn_batched_f32(const float* A, int lda, size_t a_stride, const float* B, int ldb, size_t b_stride, float* C,
                              int batch, long long K, int M, int N, void* stream);
 int bbdm_winograd_wgrad_finish_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, void* stream);
+int bbdm_winograd_wgrad_finish_bias_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, const float* dm11,
+                                        long long T, float* dbias, void* stream);
 /* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: fp64[C] scratch. */
 int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream);
 /* Per-image column sums out[n*ldo + c] = sum_{m < M} dy[(n*M + m)*ld + c] (gradient of a per-image broadcast add).

@@ -283,7 +283,7 @@ def conv3x3_winograd_wgrad(x: torch.Tensor, dy: torch.Tensor, cout: int, m: int,
 def conv3x3_winograd_wgrad_bf3p(x: torch.Tensor, dy: torch.Tensor, cout: int, m: int, with_bias: bool = False):
     """The Winograd-domain weight gradient with both GEMM operands as transposed bf16 planes (csrc/gemm_bf3p.hip TN entry): x [N,H,W,Cin]
     (Cin % 32 == 0), dy [N,H,W,ld >= cout] -> (dW OIHW, db or None).  Stages: bbdm_winograd_input_bf3p_tr_f32 (as the training forward
-    runs it), bbdm_winograd_dy_transform_bf3p_f32, bbdm_gemm_bf3p_tn_f32, bbdm_winograd_wgrad_finish_f32 (+ bbdm_colsum_f32 of dm11)."""
+    runs it), bbdm_winograd_dy_transform_bf3p_f32, bbdm_gemm_bf3p_tn_f32, bbdm_winograd_wgrad_finish_bias_f32 (dW + the column sums of dm11)."""
     _chk(x, dy)
     N, H, W, cin = x.shape
     lib = _lib.load()
@@ -301,8 +301,13 @@ def conv3x3_winograd_wgrad_bf3p(x: torch.Tensor, dy: torch.Tensor, cout: int, m:
     dU = torch.empty(splits * P * cin * cout, dtype=torch.float32, device=dev)
     _lib.call("bbdm_gemm_bf3p_tn_f32", Vt.data_ptr(), dMt.data_ptr(), dU.data_ptr(), P, Tp, cin, cout, _st(x))
     dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
-    _lib.call("bbdm_winograd_wgrad_finish_f32", m, dU.data_ptr(), splits, dw.data_ptr(), cin, cout, _st(x))
     db = None
+    if with_bias and cout % 4 == 0:             # as the gradient plan runs it: dW and db in one launch
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
+        _lib.call("bbdm_winograd_wgrad_finish_bias_f32", m, dU.data_ptr(), splits, dw.data_ptr(), cin, cout, dm11.data_ptr(), T,
+                  db.data_ptr(), _st(x))
+        return dw, db
+    _lib.call("bbdm_winograd_wgrad_finish_f32", m, dU.data_ptr(), splits, dw.data_ptr(), cin, cout, _st(x))
     if with_bias:
         acc = torch.empty(cout, dtype=torch.float64, device=dev)
         db = torch.empty(cout, dtype=torch.float32, device=dev)

@@ -214,7 +214,7 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     (m(x, timesteps=t, context=None) * dout).sum().backward()
     plan = m._plan_for(x, True)
     # (layers whose forward ran the same Winograd tile keep their V: the gradient plan then holds the stages, not the chained entry)
-    assert sum(str(n) in ("bbdm_conv3x3_winograd_wgrad_f32", "bbdm_winograd_wgrad_finish_f32") for n, _ in plan.bops) >= 4
+    assert sum(str(n) in ("bbdm_conv3x3_winograd_wgrad_f32", "bbdm_winograd_wgrad_finish_f32", "bbdm_winograd_wgrad_finish_bias_f32") for n, _ in plan.bops) >= 4
     # ... as TRANSPOSED bf16 planes, contracted by the bf16x3 GEMM (csrc/gemm_bf3p.hip: the tiles are its K loop)
     assert sum(str(n) == "bbdm_gemm_bf3p_tn_f32" for n, _ in plan.bops) >= 1
     assert any(getattr(n, "entry", "") == "bbdm_winograd_input_bf3p_tr_f32" for n, _ in plan.ops)
