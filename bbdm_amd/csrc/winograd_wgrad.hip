@@ -133,10 +133,7 @@ __global__ void __launch_bounds__(WM * 128, 2) gemm_tn_f32(const TnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
-    // two stages of register prefetch: the rows of chunk c + 2 are requested while chunk c is multiplied and chunk c + 1 waits in
-    // the other register set for its turn in LDS -- with one set a workgroup's chunk took a full HBM round trip (the short-M/N
-    // layers of a training step, 256-512 workgroups on the chip, ran at a quarter of the MFMA rate)
-    float4 areg[2][ASLOTS], breg[2][BSLOTS];
+    float4 areg[1][ASLOTS], breg[1][BSLOTS];
     // column sums of B (the bias gradient of a 1x1 layer: B = dY) ride along: a thread's B slots all hold the same column quad, so it
     // adds them up as they pass through its registers -- no second pass over dY
     const bool do_bias = a.bias_part != nullptr && mt == 0;
@@ -191,23 +188,19 @@ __global__ void __launch_bounds__(WM * 128, 2) gemm_tn_f32(const TnArgs a) {
         }
     };
 
+    // register prefetch of the next chunk + double-buffered LDS, one barrier per chunk.  (A second register set -- chunk c + 2 requested
+    // while c is multiplied -- was measured in round 3: 92 instead of 56 VGPRs and 15 % SLOWER on the training step's 1x1 layers.)
     const int nchunks = (int)((k_end - k_begin + TKC - 1) / TKC);
     if (nchunks > 0) {
         load(k_begin, areg[0], breg[0]);
         store(smem, areg[0], breg[0]);
-        if (nchunks > 1) load(k_begin + TKC, areg[1], breg[1]);
     }
     __syncthreads();
-    // chunk c is multiplied from LDS stage c & 1; chunk c + 1 sits in register set (c + 1) & 1; chunk c + 2 is requested into set c & 1
-    for (int chunk = 0; chunk < nchunks; chunk += 2) {
-        if (chunk + 2 < nchunks) load(k_begin + (long long)(chunk + 2) * TKC, areg[0], breg[0]);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) load(k_begin + (long long)(chunk + 1) * TKC, areg[0], breg[0]);
         multiply(chunk);
-        if (chunk + 1 < nchunks) store(smem + STAGE, areg[1], breg[1]);
-        __syncthreads();
-        if (chunk + 1 >= nchunks) break;
-        if (chunk + 3 < nchunks) load(k_begin + (long long)(chunk + 3) * TKC, areg[1], breg[1]);
-        multiply(chunk + 1);
-        if (chunk + 2 < nchunks) store(smem, areg[0], breg[0]);
+        if (more) store(smem + ((chunk + 1) & 1) * STAGE, areg[0], breg[0]);
         __syncthreads();
     }
 
