@@ -487,13 +487,12 @@ conv_igemm_f32(const ConvArgs a_in) {
 // The MFMA kernel pads Cout to a 128-wide tile: at Cout = 3 97 % of the matrix work is wasted (2.3 ms at 256x256, batch 16,
 // 3 TFLOP/s).  Here one thread owns one output pixel and all CO (<= 8) output channels; the 18 x 18 halo patch of a 16 x 16
 // pixel tile is staged in LDS per 16-channel chunk (fused GroupNorm -> SiLU coefficients applied while staging, as in the
-// MFMA kernel), the [9][16][CO] weight slab is read as LDS broadcasts.  FMA on the vector ALU: 2 * 9 * Cin * CO FLOP per
+// MFMA kernel), the [9][CO][16] weights of the chunk come through the scalar cache (wave-uniform addresses).  FMA on the vector ALU: 2 * 9 * Cin * CO FLOP per
 // pixel is small next to the 4 * Cin bytes the pixel reads, so the kernel is HBM / LDS bound, not ALU bound.
 template <int CO, bool PRE>
 __global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
     constexpr int TS = 16, PS = TS + 2, NPP = PS * PS;             // tile side, patch side, patch pixels
-    __shared__ __attribute__((aligned(16))) float patch[NPP * KP];   // [patch pixel][16 + 4 pad]
-    __shared__ __attribute__((aligned(16))) float wsm[9 * KC * CO];  // [tap][k][co]
+    __shared__ __attribute__((aligned(16))) float patch2[2][NPP * KP];   // double-buffered [patch pixel][16 + 4 pad]
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
     const int tilesX = (a.W + TS - 1) / TS;
@@ -504,33 +503,57 @@ __global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
     const size_t wChunk = (size_t)a.CoutPad * KC;                    // packed weights: [tap][chunk][CoutPad][16]
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    // register prefetch: the next chunk's patch is requested before this chunk's FMAs and lands in LDS after them (a single-buffered
+    // load -> barrier -> compute -> barrier loop left the loads of a workgroup exposed); SiLU of the fused producer on v_exp / v_rcp
+    // (silu_fast, as the Winograd input transform: the IEEE sequence cost as many VALU instructions as the chunk's 576 FMAs)
+    constexpr int SLOTS = (NPP * 4 + 255) / 256;
+    float4 xr[SLOTS];
+    auto request = [&](int chunk) {
         const int cbase = chunk * KC;
-        for (int f = tid; f < NPP * 4; f += 256) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int f = tid + s * 256;
             const int pp = f >> 2, c4 = f & 3;
             const int py = pp / PS, px = pp - py * PS;
             const int h = h0 + py, w = w0 + px, c = cbase + c4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin) {
+            if (f < NPP * 4 && h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin)
                 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + c);
-                if (PRE) {
-                    const float4 sc = *reinterpret_cast<const float4*>(a.pre_sc + (size_t)n * a.pre_ld + c);
-                    const float4 bi = *reinterpret_cast<const float4*>(a.pre_bi + (size_t)n * a.pre_ld + c);
-                    v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
-                    if (a.pre_silu) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
-                }
+            xr[s] = v;
+        }
+    };
+    auto land = [&](int chunk) {
+        const int cbase = chunk * KC;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int f = tid + s * 256;
+            if (f >= NPP * 4) continue;
+            const int pp = f >> 2, c4 = f & 3;
+            const int py = pp / PS, px = pp - py * PS;
+            const int h = h0 + py, w = w0 + px, c = cbase + c4 * 4;
+            float4 v = xr[s];
+            if (PRE && h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin) {      // (the zero padding stays zero)
+                const float4 sc = *reinterpret_cast<const float4*>(a.pre_sc + (size_t)n * a.pre_ld + c);
+                const float4 bi = *reinterpret_cast<const float4*>(a.pre_bi + (size_t)n * a.pre_ld + c);
+                v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+                if (a.pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
             }
-            *reinterpret_cast<float4*>(patch + pp * KP + c4 * 4) = v;
+            *reinterpret_cast<float4*>(patch2[chunk & 1] + pp * KP + c4 * 4) = v;
         }
-        for (int f = tid; f < 9 * KC * CO; f += 256) {
-            const int co = f % CO, k = (f / CO) % KC, tap = f / (CO * KC);
-            wsm[f] = co < a.Cout ? a.w[((size_t)tap * a.nchunks + chunk) * wChunk + (size_t)co * KC + k] : 0.f;
-        }
-        __syncthreads();
+    };
+    request(0);
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        land(chunk);
+        const float* patch = patch2[chunk & 1];
+        __syncthreads();                                             // one barrier per chunk: the other patch buffer is free again
+        if (chunk + 1 < a.nchunks) request(chunk + 1);
+        // the [tap][co][16] weights of this chunk are the same for every thread: read straight from the packed tensor with
+        // wave-uniform addresses (scalar loads, FMAs with an SGPR operand) -- no LDS slab, no second barrier
+        const float* __restrict__ wq = a.w + (size_t)chunk * wChunk;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float* P = patch + ((ty + tap / 3) * PS + tx + tap % 3) * KP;
-            const float* Wt = wsm + tap * KC * CO;
+            const float* __restrict__ Wt = wq + (size_t)tap * a.nchunks * wChunk;      // [co (CoutPad rows, zero past Cout)][16]
 #pragma unroll
             for (int k4 = 0; k4 < KC; k4 += 4) {
                 const float4 xv = *reinterpret_cast<const float4*>(P + k4);
@@ -538,10 +561,9 @@ __global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int c = 0; c < CO; ++c) acc[c] = fmaf(xs[e], Wt[(k4 + e) * CO + c], acc[c]);
+                    for (int c = 0; c < CO; ++c) acc[c] = fmaf(xs[e], Wt[c * KC + k4 + e], acc[c]);
             }
         }
-        __syncthreads();
     }
     const int h = tile_y * TS + ty, w = tile_x * TS + tx;
     if (h < a.H && w < a.W) {
@@ -834,7 +856,7 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     if (ks == 3 && Cout <= 8 && !residual && M >= 4096) {      // a few output channels: one thread per pixel (see above)
-        if (Cout <= 4) launch_narrow<4>(a, st); else launch_narrow<8>(a, st);
+        if (Cout <= 3) launch_narrow<3>(a, st); else if (Cout <= 4) launch_narrow<4>(a, st); else launch_narrow<8>(a, st);
         BBDM_CHECK_LAUNCH("conv2d(narrow)");
         return BBDM_OK;
     }

@@ -154,7 +154,7 @@ def test_bridge_arithmetic(objective):
 
 
 @pytest.mark.parametrize("N,H,W,C,Cout,ks,film,silu", [(2, 16, 16, 128, 64, 3, True, True), (3, 8, 8, 96, 128, 3, False, True),
-                                                        (1, 64, 64, 64, 3, 3, False, True)])
+                                                        (1, 64, 64, 64, 3, 3, False, True), (2, 72, 88, 32, 3, 3, True, True)])
 def test_conv_with_fused_groupnorm_producer(N, H, W, C, Cout, ks, film, silu):
     K.test_conv_with_fused_groupnorm_producer(CPU, N, H, W, C, Cout, ks, film, silu)
 

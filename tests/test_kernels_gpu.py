@@ -936,7 +936,8 @@ def test_layout_roundtrip(dev):
 
 @pytest.mark.parametrize("N,H,W,C,Cout,ks,film,silu", [(2, 16, 16, 128, 64, 3, True, True), (3, 8, 8, 96, 128, 3, False, True),
                                                         (1, 32, 32, 256, 128, 1, False, False), (20, 4, 4, 640, 256, 3, True, True),
-                                                        (1, 64, 64, 64, 3, 3, False, True)])       # narrow head + fused GN
+                                                        (1, 64, 64, 64, 3, 3, False, True),        # narrow head + fused GN
+                                                        (2, 72, 88, 32, 3, 3, True, True)])        # ... ragged 16x16 tiles, two chunks, FiLM
 def test_conv_with_fused_groupnorm_producer(dev, N, H, W, C, Cout, ks, film, silu):
     """GroupNorm -> [FiLM] -> [SiLU] -> conv with the normalisation applied while the patch is staged."""
     import kernel_ops as ops
