@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -38,6 +38,7 @@ SIGNATURES = {
     "bbdm_groupnorm_coeffs_f32": (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "bbdm_winograd_packed_floats": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_winograd_pack_weight_f32": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_winograd_pack_weight_bf3p_f32": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbdm_conv3x3_winograd_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, _P, c_int, c_int, _P,
                                            c_int, c_int, c_int, c_int, c_int, _P]),

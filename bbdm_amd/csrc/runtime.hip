@@ -13,7 +13,7 @@ void bbdm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int bbdm_version(void) { return 15; }
+extern "C" int bbdm_version(void) { return 16; }
 extern "C" const char* bbdm_last_error(void) { return g_err; }
 
 // ---- CU-partitioned streams ---------------------------------------------------------------------------------------------------------

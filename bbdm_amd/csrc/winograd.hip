@@ -858,6 +858,61 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
     }
 }
 
+// ... straight into the bf16 B planes of gemm_bf3p.hip, [xi][CoutPad / 32][chunk][3][1 KB]: the same transform for a PAIR of input
+// channels per thread, each U value pair split exactly and stored as bbdm_gemm_bf3p_pack_b_f32 stores it -- the same planes (up to
+// the compiler's FMA contraction of G g G^T in this kernel body: <= 1 ulp of U) without the fp32 U tensor in between (4x the weights for m = 4, written and read once per optimizer step and direction: the two
+// launches were 6 ms of every fourth training micro-step).
+template <int MO>
+__global__ void winograd_weight_planes_kernel(const float* __restrict__ w, unsigned char* __restrict__ dst, int Cout, int Cin,
+                                              int CoutPad, int nchunks, int dgrad) {
+    constexpr int AL = MO + 2;
+    const int O = dgrad ? Cin : Cout, I = dgrad ? Cout : Cin;
+    const size_t pairs = (size_t)nchunks * CoutPad * (KC / 2);
+    const size_t xi_stride = (size_t)(CoutPad / 32) * nchunks * 3 * 1024;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < pairs; idx += (size_t)gridDim.x * blockDim.x) {
+        const int kp = (int)(idx % (KC / 2));
+        size_t t = idx / (KC / 2);
+        const int o = (int)(t % CoutPad);
+        const int chunk = (int)(t / CoutPad);
+        float a[2][AL][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = chunk * KC + kp * 2 + e;
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx) {
+                float g[3], u[AL];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    float v = 0.f;
+                    if (o < O && i < I)
+                        v = dgrad ? w[((size_t)i * Cin + o) * 9 + (2 - r) * 3 + (2 - sx)] : w[((size_t)o * Cin + i) * 9 + r * 3 + sx];
+                    g[r] = v;
+                }
+                g_transform<MO>(g, u);
+#pragma unroll
+                for (int r = 0; r < AL; ++r) a[e][r][sx] = u[r];
+            }
+        }
+        unsigned char* d = dst + (((size_t)(o / 32) * nchunks + chunk) * 3) * 1024 + ((kp * 2) >> 3) * 512 + (o & 31) * 16 +
+                           ((kp * 2) & 7) * 2;
+#pragma unroll
+        for (int r = 0; r < AL; ++r) {
+            float u0[AL], u1[AL];
+            g_transform<MO>(a[0][r], u0);
+            g_transform<MO>(a[1][r], u1);
+#pragma unroll
+            for (int sx = 0; sx < AL; ++sx) {
+                unsigned p1, p2, p3;
+                split2(u0[sx], u1[sx], p1, p2, p3);
+                unsigned char* q = d + (size_t)(r * AL + sx) * xi_stride;
+                *reinterpret_cast<unsigned*>(q) = p1;
+                *reinterpret_cast<unsigned*>(q + 1024) = p2;
+                *reinterpret_cast<unsigned*>(q + 2048) = p3;
+            }
+        }
+    }
+}
+
 // conv3x3(nearest x2 (x)) as four 3x3 "phase" filters on x: output pixel (2i + a, 2j + b) reads the upsampled rows 2i + a - 1 .. 2i + a
 // + 1 = x rows {i - 1, i, i} (a = 0) or {i, i, i + 1} (a = 1), so along each axis the taps collapse to [w0, w1 + w2, 0] (phase 0) or
 // [0, w0 + w1, w2] (phase 1) at offsets (-1, 0, +1); zero padding of the upsampled image = zero padding of x.  w4 [4 Cout][Cin][3][3],
@@ -928,6 +983,33 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
         hipLaunchKernelGGL(winograd_weight_kernel<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
                            Cin, CoutPad, nchunks, dgrad);
     BBDM_CHECK_LAUNCH("winograd_pack");
+    return BBDM_OK;
+}
+
+// ... with the B planes of gemm_bf3p.hip as the destination (= bbdm_winograd_pack_weight_f32 + bbdm_gemm_bf3p_pack_b_f32 up to FMA contraction;
+// b_planes: bbdm_gemm_bf3p_b_bytes((m + 2)^2, InPad, O) bytes, InPad % 16 == 0)
+extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
+                                                  void* stream) {
+    BBDM_WINO_M(m);
+    BBDM_REQUIRE(w_oihw && b_planes && Cout > 0 && Cin > 0 && InPad % KC == 0, "winograd_pack_bf3p: bad args (InPad %% 16)");
+    BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack_bf3p: InPad too small");
+    BBDM_REQUIRE(((uintptr_t)b_planes & 15) == 0, "winograd_pack_bf3p: b_planes alignment");
+    const int O = dgrad ? Cin : Cout;
+    const int CoutPad = cdiv(O, 128) * 128, nchunks = InPad / KC;
+    const size_t pairs = (size_t)nchunks * CoutPad * (KC / 2);
+    int blocks = (int)((pairs + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    unsigned char* d = (unsigned char*)b_planes;
+    if (m == 2)
+        hipLaunchKernelGGL(winograd_weight_planes_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
+                           CoutPad, nchunks, dgrad);
+    else if (m == 4)
+        hipLaunchKernelGGL(winograd_weight_planes_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
+                           CoutPad, nchunks, dgrad);
+    else
+        hipLaunchKernelGGL(winograd_weight_planes_kernel<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
+                           CoutPad, nchunks, dgrad);
+    BBDM_CHECK_LAUNCH("winograd_pack_bf3p");
     return BBDM_OK;
 }
 

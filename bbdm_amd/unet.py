@@ -426,7 +426,9 @@ class _PackedWinograd:
         self.w4 = torch.empty(4 * self.cout, self.cin, 3, 3, dtype=torch.float32, device=weight.device) if phases else None
         self.out_ch = self.cin if dgrad else (4 * self.cout if phases else self.cout)
         n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
-        self.packed_f32 = torch.empty(n, dtype=torch.float32, device=weight.device)
+        # (the planes of gemm_bf3p.hip are written directly from the weights: no fp32 G g G^T tensor -- 4x the weights at m = 4 -- is kept)
+        self.fused_planes = bf3 in ("p", "q") and not phases and in_pad % 16 == 0
+        self.packed_f32 = None if self.fused_planes else torch.empty(n, dtype=torch.float32, device=weight.device)
         if bf3 in ("p", "q"):
             self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes((m + 2) ** 2, in_pad, self.out_ch), dtype=torch.uint8,
                                       device=weight.device)
@@ -448,6 +450,12 @@ class _PackedWinograd:
                 _lib.call("bbdm_upsample_phase_weights_f32", w.data_ptr(), self.w4.data_ptr(), self.cout, self.cin, stream)
                 _lib.call("bbdm_winograd_pack_weight_f32", self.m, self.w4.data_ptr(), self.packed_f32.data_ptr(), 4 * self.cout,
                           self.cin, self.in_pad, 0, stream)
+            elif self.fused_planes:
+                # G g G^T straight into the bf16 planes (the two launches below in one, without the fp32 tensor in between)
+                _lib.call("bbdm_winograd_pack_weight_bf3p_f32", self.m, w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
+                          self.in_pad, 1 if self.dgrad else 0, stream)
+                self.key = key
+                return
             else:
                 _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                           self.in_pad, 1 if self.dgrad else 0, stream)

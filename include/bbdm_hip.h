@@ -124,6 +124,11 @@ int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, c
 size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad);
 int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
                                   void* stream);
+/* The same transform written straight into gemm_bf3p's B planes (bbdm_winograd_pack_weight_f32 followed by bbdm_gemm_bf3p_pack_b_f32
+ * without the fp32 U tensor in between; the same values up to the FMA contraction of G g G^T, <= 1 ulp): the per-optimizer-step weight preparation of the training path
+ * (nn.Conv2d weights, openaimodel.py:207,233,244).  b_planes: bbdm_gemm_bf3p_b_bytes((m+2)^2, InPad, dgrad ? Cin : Cout); InPad % 16 == 0. */
+int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
+                                       void* stream);
 size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int CinPad, int Cout);
 int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packed_wino, const float* bias,
                               const float* residual, int ldr, float* out, int ldo, int flags, float* ws,

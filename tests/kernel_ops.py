@@ -545,3 +545,20 @@ def conv1x1_bf3(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
               None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1],
               out.data_ptr(), out.shape[1], x.shape[0], cin, cout, _st(x))
     return out
+
+
+def winograd_weight_planes(w: torch.Tensor, m: int, in_pad: int, dgrad: bool = False, fused: bool = True) -> torch.Tensor:
+    """B planes of gemm_bf3p.hip for the Winograd-domain weights of ``w`` [Cout, Cin, 3, 3]: ``fused`` = one launch
+    (bbdm_winograd_pack_weight_bf3p_f32), else bbdm_winograd_pack_weight_f32 + bbdm_gemm_bf3p_pack_b_f32."""
+    _chk(w)
+    lib = _lib.load()
+    cout, cin = w.shape[0], w.shape[1]
+    out_ch = cin if dgrad else cout
+    planes = torch.zeros(lib.bbdm_gemm_bf3p_b_bytes((m + 2) ** 2, in_pad, out_ch), dtype=torch.uint8, device=w.device)
+    if fused:
+        _lib.call("bbdm_winograd_pack_weight_bf3p_f32", m, w.data_ptr(), planes.data_ptr(), cout, cin, in_pad, 1 if dgrad else 0, _st(w))
+    else:
+        f32 = torch.empty(lib.bbdm_winograd_packed_floats(m, out_ch, in_pad), dtype=torch.float32, device=w.device)
+        _lib.call("bbdm_winograd_pack_weight_f32", m, w.data_ptr(), f32.data_ptr(), cout, cin, in_pad, 1 if dgrad else 0, _st(w))
+        _lib.call("bbdm_gemm_bf3p_pack_b_f32", f32.data_ptr(), planes.data_ptr(), (m + 2) ** 2, in_pad, out_ch, _st(w))
+    return planes

@@ -236,3 +236,8 @@ def test_conv1x1_bf3q_bitwise(pixels, Cin, Cout, res):
 @pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 2, 12, 12, 32, 256), (4, 1, 1, 1, 8, 8, 16, 136)])
 def test_winograd_bf3q_stages_bitwise(m, up, silu, N, H, W, Cin, Cout):
     K.test_winograd_bf3q_stages_bitwise(CPU, m, up, silu, N, H, W, Cin, Cout)
+
+
+@pytest.mark.parametrize("m,Cout,Cin,in_pad,dgrad", [(4, 96, 40, 48, False), (2, 24, 16, 32, True), (6, 40, 130, 144, False)])
+def test_winograd_weight_planes_fused_bitwise(m, Cout, Cin, in_pad, dgrad):
+    K.test_winograd_weight_planes_fused_bitwise(CPU, m, Cout, Cin, in_pad, dgrad)

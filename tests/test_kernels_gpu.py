@@ -961,3 +961,29 @@ def test_conv_with_fused_groupnorm_producer(dev, N, H, W, C, Cout, ks, film, sil
                           pre_silu=silu)
     torch.cuda.synchronize()
     assert rel_err(_nchw(out.cpu()), ref) < TOL
+
+
+@pytest.mark.parametrize("m,Cout,Cin,in_pad,dgrad", [(4, 96, 40, 48, False), (6, 128, 128, 128, False), (2, 24, 16, 32, True),
+                                                      (4, 200, 72, 208, True), (6, 40, 130, 144, False)])
+def test_winograd_weight_planes_fused_bitwise(dev, m, Cout, Cin, in_pad, dgrad):
+    """bbdm_winograd_pack_weight_bf3p_f32 (G g G^T straight into the bf16 planes) against the two launches it replaces: ragged
+    Cout / Cin (zero rows and k), the data-gradient orientation, padded input channels.  Same layout, same zeros; the fp32 value each
+    plane triple adds up to is the same up to the compiler's FMA contraction of G g G^T in the two kernel bodies (<= 1 ulp of the
+    largest term on the GPU; bit-identical on the emulator)."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(m + Cout + Cin)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3).to(dev)
+    a = ops.winograd_weight_planes(w, m, in_pad, dgrad, fused=True)
+    b = ops.winograd_weight_planes(w, m, in_pad, dgrad, fused=False)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+    def value(planes):                  # [units][3 planes][512 bf16] -> the fp32 numbers the three planes add up to
+        h = planes.cpu().view(torch.int16).view(-1, 3, 512).view(torch.bfloat16).float()
+        return (h[:, 0] + h[:, 1]) + h[:, 2]
+
+    va, vb = value(a), value(b)
+    assert torch.equal(va == 0, vb == 0)
+    assert float((va - vb).abs().max()) <= 2.0 ** -22 * float(vb.abs().max())
+    if dev.type != "cuda":
+        assert torch.equal(a.cpu(), b.cpu())
