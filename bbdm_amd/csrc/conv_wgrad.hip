@@ -16,6 +16,8 @@
 // gridDim.z; partial tiles go to a workspace and a second kernel sums the splits in a fixed order (deterministic)
 // while transposing to the parameter's OIHW layout.
 #include "common.h"
+#include "bf3_split.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -350,7 +352,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 // thread in 32 workgroups took 0.24 ms over.
 __global__ void __launch_bounds__(256) tn_finish4_kernel(const float* __restrict__ dU, int splits, float* __restrict__ dw, int Cin,
                                                          int Cout, const float* __restrict__ bias_part, float* __restrict__ db,
-                                                         int bias_blocks) {
+                                                         int bias_blocks, int bias_splits) {
     __shared__ float4 red[4][64];
     __shared__ float tile[32][9];
     const int tid = threadIdx.x, o = tid & 63, q = o & 7, cil = o >> 3, zl = tid >> 6;
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(256) tn_finish4_kernel(const float* __restrict
         const int c = (int)blockIdx.x * 256 + o * 4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < Cout)
-            for (int z = zl; z < splits; z += 4) {
+            for (int z = zl; z < bias_splits; z += 4) {
                 const float4 v = *reinterpret_cast<const float4*>(bias_part + (size_t)z * Cout + c);
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             }
@@ -404,6 +406,52 @@ __global__ void __launch_bounds__(256) tn_finish4_kernel(const float* __restrict
     __syncthreads();
     const int c = tid >> 3, k = tid & 7;
     if (co0 + c < Cout && ci0 + k < Cin) dw[(size_t)(co0 + c) * Cin + ci0 + k] = tile[c][k];
+}
+
+// ---- 1x1 weight gradients on the bf16x3 pipe kernel (bbdm_gemm_bf3p_tn_f32): its operands are TRANSPOSED bf16 planes, rows = channels,
+// k = pixels: [C / 32][KPad / 16][3][1 KB], element (r = c & 31, k = pixel & 15) at (k >> 3) * 512 + r * 16 + (k & 7) * 2.  This pass writes
+// them from a plain [pixels][C] fp32 tensor: a workgroup stages 16 pixels x 256 channels in LDS (coalesced rows), then thread c reads its
+// channel's 8 + 8 pixels (conflict-free), splits them exactly and stores 3 x 16 B per half -- 32 lanes = 512 contiguous bytes of a
+// plane.  Pixels >= K and channels >= C are written as zeros (they enter the contraction / pad the 128-column tiles).  `colsum`: the
+// workgroup also adds up its pixels per channel (fp64 per thread) and writes one partial row per pixel walker: the bias gradient of
+// the layer when the tensor is dY, added over the walkers by tn_finish4_kernel.
+__global__ void __launch_bounds__(256) tn_pack_planes_kernel(const float* __restrict__ src, int ld, long long K, int C, int CPad,
+                                                             long long KPad, unsigned char* __restrict__ dst,
+                                                             float* __restrict__ colsum) {
+    __shared__ __attribute__((aligned(16))) float tile[16][256 + 4];
+    const int tid = threadIdx.x, c0 = blockIdx.x * 256;
+    const long long kblocks = KPad / 16;
+    double acc = 0.0;
+    for (long long kb = blockIdx.y; kb < kblocks; kb += gridDim.y) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int f = tid + s * 256, row = f >> 6, c = (f & 63) * 4;
+            const long long p = kb * 16 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p < K && c0 + c < C) v = *reinterpret_cast<const float4*>(src + (size_t)p * ld + c0 + c);      // (C % 4 == 0)
+            *reinterpret_cast<float4*>(&tile[row][c]) = v;
+        }
+        __syncthreads();
+        if (c0 + tid < CPad) {
+            const int cb = (c0 + tid) >> 5, r = (c0 + tid) & 31;
+            unsigned char* d = dst + (((size_t)cb * kblocks + kb) * 3) * 1024 + r * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[8 * h + j][tid];
+                if (colsum) acc += (double)(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+                uint2 a1, a2, a3, b1, b2, b3;
+                split4(make_float4(v[0], v[1], v[2], v[3]), a1, a2, a3);
+                split4(make_float4(v[4], v[5], v[6], v[7]), b1, b2, b3);
+                *reinterpret_cast<uint4*>(d + h * 512) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+                *reinterpret_cast<uint4*>(d + 1024 + h * 512) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+                *reinterpret_cast<uint4*>(d + 2048 + h * 512) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+            }
+        }
+        __syncthreads();
+    }
+    if (colsum && c0 + tid < C) colsum[(size_t)blockIdx.y * C + c0 + tid] = (float)acc;
 }
 
 // db[c] = sum over rows of dy[M][ld]; fp64 per-thread accumulation + fp64 atomics (order-independent to fp32 rounding)
@@ -551,11 +599,46 @@ static size_t wgrad_geom_floats(const WgradGeom& g, int ks) {
 // conv_wgrad_f32<1, 4> (one 32x32 accumulator per wave, 21 FLOP per LDS byte) reaches ~70
 static bool wgrad_tn_path(int Cin, int Cout, int ks) { return ks == 1 && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 64 && Cout >= 64; }
 
+// ... and, where the plane layout takes the shape, on the bf16x3 pipe kernel behind a transposing split pass per operand (10 B per
+// element moved once, against a GEMM at 200+ instead of 60-100 TFLOP/s): BBDM_WGRAD1X1_BF3=0 keeps gemm_tn_f32 (A/B runs)
+struct TnPlanes {
+    long long KPad;
+    size_t at_bytes, bt_bytes;
+    int splits, walkers;
+};
+static bool wgrad_tn_planes(long long K, int Cin, int Cout, TnPlanes* g) {
+    static const int on = getenv("BBDM_WGRAD1X1_BF3") ? atoi(getenv("BBDM_WGRAD1X1_BF3")) : 1;
+    if (!on || Cin % 32 != 0 || Cout % 4 != 0 || K < 4096) return false;
+    // the split passes move 10 B per element of X and dY once: they pay where the GEMM has >= ~100 FLOP per such byte (measured on the
+    // LBBDM-f4 step, batch 32: 2048 -> 1024 0.42 -> 0.28 ms, 1024 -> 3072 0.48 -> 0.40; 128 -> 256 at 131072 pixels 0.12 -> 0.26);
+    // BBDM_WGRAD1X1_BF3=2 takes every shape the layout accepts (tests)
+    if (on < 2 && (long long)Cin * Cout < 512ll * (Cin + Cout)) return false;
+    const long long KPad = (K + 255) / 256 * 256;
+    if (!bbdm_gemm_bf3p_tn_supported(KPad, Cin, Cout)) return false;
+    if (g) {
+        g->KPad = KPad;
+        g->at_bytes = bbdm_gemm_bf3p_tn_at_bytes(1, KPad, Cin);
+        g->bt_bytes = bbdm_gemm_bf3p_tn_bt_bytes(1, KPad, Cout);
+        g->splits = bbdm_gemm_bf3p_tn_splits(1, KPad, Cin, Cout);
+        const long long kb = KPad / 16;
+        g->walkers = (int)(kb < 512 ? kb : 512);
+    }
+    return true;
+}
+static size_t wgrad_tn_planes_floats(const TnPlanes& g, int Cin, int Cout) {
+    return (g.at_bytes + g.bt_bytes) / 4 + (size_t)g.splits * Cin * Cout + 4 + (size_t)g.walkers * Cout + 4;
+}
+
 extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
     size_t need = wgrad_geom_floats(wgrad_geom(N, H, W, Cin, Cout, -1), ks);      // the thin path may be refused at launch (pitches)
     const int thin = wgrad_thin_mode(Cin, Cout, ks);
     if (thin >= 0) {
         const size_t t = wgrad_geom_floats(wgrad_geom(N, H, W, Cin, Cout, thin), ks);
+        if (t > need) need = t;
+    }
+    TnPlanes tp;
+    if (wgrad_tn_path(Cin, Cout, ks) && wgrad_tn_planes((long long)N * H * W, Cin, Cout, &tp)) {
+        const size_t t = wgrad_tn_planes_floats(tp, Cin, Cout);
         if (t > need) need = t;
     }
     if (wgrad_tn_path(Cin, Cout, ks)) {
@@ -597,6 +680,26 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_tn_path(Cin, Cout, ks) && ((uintptr_t)dy & 15) == 0 && ldy % 4 == 0 && ((uintptr_t)ws & 15) == 0) {
         const long long K = (long long)N * H * W;
+        TnPlanes tp;
+        if (wgrad_tn_planes(K, Cin, Cout, &tp) && ((uintptr_t)dw_oihw & 3) == 0 && (!dbias || ((uintptr_t)dbias & 15) == 0)) {
+            unsigned char* at = reinterpret_cast<unsigned char*>(ws);
+            unsigned char* bt = at + tp.at_bytes;
+            float* dU = reinterpret_cast<float*>(bt + tp.bt_bytes);
+            float* bias_part = dbias ? dU + (((size_t)tp.splits * Cin * Cout + 3) & ~(size_t)3) : nullptr;
+            const int CoutPad = cdiv(Cout, 128) * 128;
+            hipLaunchKernelGGL(tn_pack_planes_kernel, dim3(cdiv(Cin, 256), tp.walkers), dim3(256), 0, st, x, ldx, K, Cin, Cin, tp.KPad,
+                               at, (float*)nullptr);
+            hipLaunchKernelGGL(tn_pack_planes_kernel, dim3(cdiv(CoutPad, 256), tp.walkers), dim3(256), 0, st, dy, ldy, K, Cout,
+                               CoutPad, tp.KPad, bt, bias_part);
+            BBDM_CHECK_LAUNCH("conv_wgrad(tn planes: pack)");
+            int rc = bbdm_gemm_bf3p_tn_f32(at, bt, dU, 1, tp.KPad, Cin, Cout, stream);
+            if (rc != BBDM_OK) return rc;
+            const int bias_blocks = bias_part ? cdiv(Cout, 256) : 0;
+            hipLaunchKernelGGL(tn_finish4_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 8) + bias_blocks)), dim3(256), 0, st, dU,
+                               tp.splits, dw_oihw, Cin, Cout, bias_part, dbias, bias_blocks, tp.walkers);
+            BBDM_CHECK_LAUNCH("conv_wgrad(tn planes)");
+            return BBDM_OK;
+        }
         const int splits = bbdm_gemm_tn_splits(1, K, Cin, Cout);
         // the bias gradient rides along: per-split column sums of dY from the GEMM's B staging, added over the splits by the finish
         // kernel (bbdm_colsum_f32 was three more launches and a second pass over dY per layer)
@@ -606,7 +709,7 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
         if (rc != BBDM_OK) return rc;
         const int bias_blocks = bias_part ? cdiv(Cout, 256) : 0;
         hipLaunchKernelGGL(tn_finish4_kernel, dim3((unsigned)(cdiv(Cout, 32) * cdiv(Cin, 8) + bias_blocks)), dim3(256), 0, st, ws,
-                           splits, dw_oihw, Cin, Cout, bias_part, dbias, bias_blocks);
+                           splits, dw_oihw, Cin, Cout, bias_part, dbias, bias_blocks, splits);
         BBDM_CHECK_LAUNCH("conv_wgrad(tn)");
         if (dbias && !bias_part) {
             size_t off = ((size_t)splits * Cin * Cout + 1) & ~(size_t)1;        // 8-byte alignment of the fp64 scratch

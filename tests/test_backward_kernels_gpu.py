@@ -32,6 +32,10 @@ CONV_BWD = [(2, 16, 16, 32, 64, 3), (1, 24, 40, 64, 128, 3), (3, 8, 8, 128, 96, 
             (2, 16, 16, 2048, 1024, 1), (2, 64, 64, 128, 128, 3), (2, 32, 32, 512, 512, 3),
             # more 1x1 weight gradients (TN GEMM over the pixels): ragged channel tiles, K splits, a short K
             (4, 16, 16, 160, 132, 1), (32, 16, 16, 1024, 512, 1), (3, 8, 8, 96, 72, 1),
+            # 1x1 weight gradients on the bf16x3 pipe kernel behind the transposing split pass (K >= 4096 pixels, Cin % 32 == 0; the
+            # default takes it from ~100 FLOP per split byte: the last shape; all of them in the BBDM_WGRAD1X1_BF3=2 child below): Cout
+            # below / not a multiple of the 128-column tile, a pixel count that is not a multiple of 256 (zero rows enter the contraction)
+            (4, 32, 32, 64, 72, 1), (1, 72, 60, 96, 256, 1), (2, 64, 64, 256, 128, 1), (5, 32, 32, 1024, 1536, 1),
             # 3x3 layers with a thin side on the vector-ALU kernel (conv_wgrad_thin_f32): the stem / head of the UNet, ragged tiles,
             # more than one 128-channel tile on the wide side, 1..4 output channels
             (2, 64, 64, 4, 128, 3), (2, 64, 64, 128, 3, 3), (2, 20, 12, 4, 132, 3), (1, 9, 9, 260, 4, 3), (3, 8, 8, 16, 1, 3)]
@@ -61,6 +65,19 @@ def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), w.grad) < TOL
     assert rel_err(db.cpu(), b.grad) < TOL and rel_err(db2.cpu(), b.grad) < TOL
+
+
+def test_conv1x1_wgrad_planes_path_in_subprocess():
+    """BBDM_WGRAD1X1_BF3=2 (read once per process, hence the child): every 1x1 shape the plane layout accepts takes the transposing
+    split pass + bbdm_gemm_bf3p_tn_f32 instead of gemm_tn_f32 -- the small ragged cases of CONV_BWD included."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BBDM_WGRAD1X1_BF3="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv_backward and 1]"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
 
 
 # (m, N, H, W, Cin, Cout): the Winograd-domain weight gradient (csrc/winograd_wgrad.hip) incl. ragged m = 6 tiles, K splits,

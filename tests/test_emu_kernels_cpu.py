@@ -161,7 +161,7 @@ def test_conv_with_fused_groupnorm_producer(N, H, W, C, Cout, ks, film, silu):
 
 # ---- backward kernels -------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks", [(2, 16, 16, 32, 64, 3), (3, 8, 8, 128, 96, 3), (2, 16, 16, 64, 192, 1),
-                                               (1, 13, 9, 8, 3, 3), (2, 8, 8, 4, 32, 3), (1, 16, 16, 96, 68, 1)])
+                                               (1, 13, 9, 8, 3, 3), (2, 8, 8, 4, 32, 3), (1, 16, 16, 96, 68, 1), (1, 72, 60, 64, 68, 1)])
 def test_conv_backward(N, H, W, Cin, Cout, ks):
     BK.test_conv_backward(CPU, N, H, W, Cin, Cout, ks)
 
@@ -214,6 +214,19 @@ def test_geglu_backward():
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 1, 7, 10, 32, 8), (6, 2, 12, 12, 64, 132)])
 def test_winograd_wgrad_bf3p(m, N, H, W, Cin, Cout):
     BK.test_winograd_wgrad_bf3p(CPU, m, N, H, W, Cin, Cout)
+
+
+def test_conv1x1_wgrad_planes_path_in_subprocess():
+    """BBDM_WGRAD1X1_BF3=2 (read once per process): the 1x1 weight gradients on the transposing split pass + bbdm_gemm_bf3p_tn_f32,
+    on the emulator."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, BBDM_WGRAD1X1_BF3="2", BBDM_TESTS_SERIAL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv_backward and 1]",
+                        "-p", "no:xdist", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
 
 
 def test_winograd_input_64bit_index_variant_in_subprocess():
