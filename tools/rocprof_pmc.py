@@ -45,7 +45,7 @@ def main():
     totals = None
     if steps:
         allb = sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in kernels.values())
-        packb = sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for k, v in kernels.items() if "pack" in k or "weight_kernel" in k)
+        packb = sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for k, v in kernels.items() if "pack" in k or "weight_kernel" in k or "weight_planes_kernel" in k)
         totals = {"steps_profiled": steps, "all_kernels_bytes": allb, "one_time_weight_packing_bytes": packb,
                   "bytes_per_step_excl_packing": (allb - packb) / steps,
                   "algorithmic_bytes_per_step": float(sys.argv[5]) if len(sys.argv) > 5 else None}
