@@ -578,6 +578,122 @@ __global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
     }
 }
 
+// ---- 3x3 convolution with 8 (padded) input channels and 128 output channels (the UNet stem: concat(x_t, y) -> 128, -------------
+// openaimodel.py:524) on the f32 MFMA with K = 9 taps x 8 channels = 72 in ONE stage.  The implicit-GEMM kernel above walks K in
+// 16-channel chunks per tap -- half of every chunk is padding here, and nine staging rounds with a barrier each carry 8 k of work:
+// 0.72 ms at 256x256 / batch 16 for 19 GFLOP and a 537 MB result.  Here a persistent workgroup keeps the [72][128] weights in LDS,
+// stages the 18 x 18 x 8 halo patch of a 16 x 16 pixel tile channel-planar (the A fragment of k = (tap, ci), (tap, ci + 1) is two
+// conflict-free rows of one plane each, all offsets immediates), prefetches the next tile's patch into registers, and each wave
+// multiplies 64 pixels x 128 channels: 288 MFMAs per tile.  STATS: GroupNorm statistics of the output as conv_epilogue_stats.
+template <bool STATS>
+__global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, int tiles_total) {
+    constexpr int TS = 16, PR = 18, NPP = PR * PR, PLANE = 328, WP = 160, SLOTS = (NPP * 2 + 255) / 256;
+    __shared__ float patch[8 * PLANE];                           // [ci][py * 18 + px]
+    __shared__ float wsm[72 * WP];                               // [k = tap * 8 + ci][co], pitch = 32 (mod 64): k and k + 1 on disjoint banks
+    __shared__ double ls[128];                                   // [2 consumers][32 groups][2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    for (int i = tid; i < 72 * 128; i += 256) {
+        const int k = i >> 7, co = i & 127, tap = k >> 3, ci = k & 7;
+        wsm[k * WP + co] = a.w[((size_t)tap * a.nchunks * a.CoutPad + co) * KC + ci];
+    }
+    float bv[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) bv[cb] = a.bias ? a.bias[cb * 32 + l31] : 0.f;
+    const int tilesX = (a.W + TS - 1) / TS, tilesY = (a.H + TS - 1) / TS, per_img = tilesX * tilesY;
+    float4 xr[SLOTS];
+    auto request = [&](int t) {
+        const int n = t / per_img, rem = t - n * per_img, ty = rem / tilesX, tx = rem - ty * tilesX;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = tid + s * 256, pix = i >> 1, half = i & 1;
+            const int py = pix / PR, px = pix - py * PR;
+            const int h = ty * TS + py - 1, w = tx * TS + px - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NPP * 2 && h >= 0 && h < a.H && w >= 0 && w < a.W)
+                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + half * 4);
+            xr[s] = v;
+        }
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int i = tid + s * 256, pix = i >> 1, half = i & 1;
+            if (i < NPP * 2) {
+                float* d = patch + (half * 4) * PLANE + pix;
+                d[0] = xr[s].x; d[PLANE] = xr[s].y; d[2 * PLANE] = xr[s].z; d[3 * PLANE] = xr[s].w;
+            }
+        }
+    };
+    int t = blockIdx.x;
+    if (t < tiles_total) request(t);
+    const float* ab = patch + hi * PLANE + (wave * 4 + (l31 >> 4)) * PR + (l31 & 15);
+    const float* bb = wsm + hi * WP + l31;
+    for (; t < tiles_total; t += gridDim.x) {
+        land();
+        if (STATS && tid < 128) ls[tid] = 0.0;
+        __syncthreads();
+        if (t + (int)gridDim.x < tiles_total) request(t + gridDim.x);
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][cb][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp) {
+                const int ko = (2 * cp) * PLANE + (tap / 3) * PR + tap % 3;
+                const float a0 = ab[ko], a1 = ab[ko + 2 * PR];
+                const float* bk = bb + (tap * 8 + 2 * cp) * WP;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const float b = bk[cb * 32];
+                    acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][cb], 0, 0, 0);
+                    acc[1][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][cb], 0, 0, 0);
+                }
+            }
+        const int n = t / per_img, rem = t - n * per_img, ty = rem / tilesX, tx = rem - ty * tilesX;
+        double psum[4] = {0.0, 0.0, 0.0, 0.0}, psq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int h = ty * TS + wave * 4 + i * 2 + (m >> 4), w = tx * TS + (m & 15);
+                if (h < a.H && w < a.W) {
+                    float* o = a.out + ((size_t)(n * a.H + h) * a.W + w) * a.ldo + l31;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const float v = acc[i][cb][r] + bv[cb];
+                        o[cb * 32] = v;
+                        if (STATS) { psum[cb] += (double)v; psq[cb] += (double)v * v; }
+                    }
+                }
+            }
+        if (STATS) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int co = cb * 32 + l31;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (!a.st_s[k]) continue;
+                    const int g = (a.st_coff[k] + co) / a.st_cpg[k];
+                    atomicAdd(ls + (k * 32 + g) * 2, psum[cb]);
+                    atomicAdd(ls + (k * 32 + g) * 2 + 1, psq[cb]);
+                }
+            }
+        }
+        __syncthreads();                                         // patch readers done (and the tile's statistics complete)
+        if (STATS && tid < 128) {
+            const int k = tid >> 6;
+            const double v = ls[tid];
+            if (a.st_s[k] && v != 0.0) atomicAdd(a.st_s[k] + (size_t)n * 64 + (tid & 63), v);
+        }
+    }
+}
+
 template <int CO>
 void launch_narrow(const ConvArgs& a, hipStream_t st) {
     const dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16)), (unsigned)a.N);
@@ -858,6 +974,15 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
     if (ks == 3 && Cout <= 8 && !residual && M >= 4096) {      // a few output channels: one thread per pixel (see above)
         if (Cout <= 3) launch_narrow<3>(a, st); else if (Cout <= 4) launch_narrow<4>(a, st); else launch_narrow<8>(a, st);
         BBDM_CHECK_LAUNCH("conv2d(narrow)");
+        return BBDM_OK;
+    }
+    static const int stem_on = getenv("BBDM_CONV_STEM") ? atoi(getenv("BBDM_CONV_STEM")) : 1;
+    if (stem_on && ks == 3 && CinPad == 8 && Cout == 128 && !residual && !pre_scale && out_nchw == 0 && M >= 4096) {
+        const int tiles = N * cdiv(H, 16) * cdiv(W, 16);         // the stem: K = 72 in one stage (conv3x3_stem_kernel)
+        const dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
+        if (stats0 || stats1) hipLaunchKernelGGL((conv3x3_stem_kernel<true>), grid, dim3(256), 0, st, a, tiles);
+        else hipLaunchKernelGGL((conv3x3_stem_kernel<false>), grid, dim3(256), 0, st, a, tiles);
+        BBDM_CHECK_LAUNCH("conv2d(stem)");
         return BBDM_OK;
     }
     const ConvPlan plan = conv_plan(M, Cout, a.nchunks);

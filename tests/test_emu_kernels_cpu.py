@@ -107,6 +107,10 @@ def test_conv2d_accumulates_groupnorm_statistics():
     K.test_conv2d_accumulates_groupnorm_statistics(CPU)
 
 
+def test_stem_conv_accumulates_groupnorm_statistics():
+    K.test_stem_conv_accumulates_groupnorm_statistics(CPU)
+
+
 def test_conv_rejections_and_slices():
     K.test_conv3x3_winograd_rejects_bad_shapes(CPU)
     K.test_conv2d_channel_slices(CPU)

@@ -50,6 +50,8 @@ CONV_CASES = [
     (2, 8, 8, 640, 96, 3, False),        # split-K with ragged Cout
     (1, 64, 64, 32, 3, 3, False),        # the UNet head: few output channels -> one-thread-per-pixel kernel
     (2, 48, 50, 20, 8, 3, False),        # same, ragged tiles, Cin not a multiple of 16, Cout = 8
+    (1, 72, 60, 6, 128, 3, False),       # the UNet stem from 4096 pixels: K = 72 in one stage (conv3x3_stem_kernel), ragged 16x16 tiles
+    (3, 64, 64, 8, 128, 3, False),       # ... several images, whole tiles
 ]
 
 
@@ -673,6 +675,35 @@ def test_conv2d_accumulates_groupnorm_statistics(dev):
     with pytest.raises(_lib.BBDMHipError, match="statistics"):
         _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), None, None, 0, out.data_ptr(), Cout, 0, None,
                   0, None, None, 0, 0, 8, 4, 4, Cin, Cout, 3, s0.data_ptr(), 2, 0, None, 0, 0, st)
+
+
+def test_stem_conv_accumulates_groupnorm_statistics(dev):
+    """The stem kernel (8 padded input channels -> 128, conv3x3_stem_kernel) with the GroupNorm statistics of its output for two
+    consumers, ragged tiles, more tiles than one workgroup round would need per image."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    N, H, W, Cin, Cout = 2, 40, 56, 8, 128
+    assert lib.bbdm_conv_stats_fusable(N, H, W, Cin, Cout, 3) == 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
+    pk = ops.pack_conv_weight(w.to(dev), cin_pad=Cin)
+    out = torch.empty(N, H, W, Cout, device=dev)
+    s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    st = None if dev.type != "cuda" else torch.cuda.current_stream().cuda_stream
+    _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), b.to(dev).data_ptr(), None, 0, out.data_ptr(),
+              Cout, 0, None, 0, None, None, 0, 0, N, H, W, Cin, Cout, 3, s0.data_ptr(), 4, 0, s1.data_ptr(), 8, 64, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    y = out.cpu()
+    assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < TOL
+    for got, cpg, coff in ((s0, 4, 0), (s1, 8, 64)):
+        want = _group_sums(y, cpg, coff)
+        assert float((got.cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
 
 
 def test_conv3x3_winograd_rejects_bad_shapes(dev):
