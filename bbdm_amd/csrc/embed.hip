@@ -66,6 +66,77 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
     y[(size_t)n * Out + o] = acc;
 }
 
+// The same product on the f32 matrix core (In % 8 == 0): the rows of w are the B operand straight from global memory -- lane (o, half)
+// streams ITS row, 16 bytes per four MFMA steps (the k pair of a step is (8 q + e, 8 q + 4 + e): both halves read contiguous float4s) --
+// and act_in(x) is the A operand from LDS (pitch In + 1).  A wave owns 32 outputs for all rows; the 51 MB FiLM projection of the
+// LBBDM-f4 / pixel UNets moves once at HBM rate (linear_kernel: one load instruction per 2 weight rows, 0.14 ms at batch 32).
+template <int MB>
+__global__ void __launch_bounds__(256) linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y, int N, int In,
+                                                          int Out, int act_in, int act_out) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [MB * 32][In + 1], rows >= N zero
+    const int pitch = In + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    for (int k = tid; k < MB * 32 * In; k += 256) {
+        const int n = k / In, i = k - n * In;
+        float v = 0.f;
+        if (n < N) {
+            v = x[(size_t)n * In + i];
+            if (act_in) v = silu_f(v);
+        }
+        xs[n * pitch + i] = v;
+    }
+    __syncthreads();
+    const int otiles = (Out + 31) / 32, nq = In / 8;
+    const float* a0p = xs + l31 * pitch + 4 * hi;
+    for (int ot = blockIdx.x * 4 + wave; ot < otiles; ot += gridDim.x * 4) {
+        const int o = ot * 32 + l31;
+        const bool ov = o < Out;
+        const float* wr = w + (size_t)(ov ? o : Out - 1) * In + 4 * hi;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+        for (int q = 0; q < nq; q += 4) {
+            float4 wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q + u < nq ? q + u : nq - 1;                    // clamped address + select: no branch between the loads
+                const float4 v = *reinterpret_cast<const float4*>(wr + qq * 8);
+                wv[u] = (ov && q + u < nq) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (q + u < nq) {
+                    const float* ap = a0p + (q + u) * 8;
+                    const float bs[4] = {wv[u].x, wv[u].y, wv[u].z, wv[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[e], bs[e], acc0, 0, 0, 0);
+                        if (MB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[32 * pitch + e], bs[e], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (ov) {
+            const float bo = b ? b[o] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n < N) {
+                    float v = acc0[r] + bo;
+                    if (act_out) v = silu_f(v);
+                    y[(size_t)n * Out + o] = v;
+                }
+                if (MB == 2 && 32 + n < N) {
+                    float v = acc1[r] + bo;
+                    if (act_out) v = silu_f(v);
+                    y[(size_t)(32 + n) * Out + o] = v;
+                }
+            }
+        }
+    }
+}
+
 // ---- backward of linear_kernel (training path; M = batch <= 64 rows) --------------------------------------------------------------
 // Both products run on the fp32 matrix core (v_mfma_f32_32x32x2f32, exact fp32 products, fp32 accumulate): they are skinny GEMMs
 // whose one large operand -- the 51 MB FiLM projection weight of the LBBDM-f4 UNet, or its gradient -- moves once, at HBM rate.
@@ -249,12 +320,34 @@ extern "C" int bbdm_linear_f32(const float* x, const float* w, const float* b, f
                                int act_in, int act_out, void* stream) {
     BBDM_REQUIRE(x && w && y && N > 0 && In > 0 && Out > 0, "linear: bad args");
     BBDM_REQUIRE(N <= 64, "linear: N=%d rows > 64 (chunk the batch on the host)", N);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        const int MB = N > 32 ? 2 : 1;
+        const size_t lds_m = (size_t)MB * 32 * (In + 1) * sizeof(float);
+        if (In % 8 == 0 && In >= 64 && Out >= 32 && (((uintptr_t)w & 15) == 0) && lds_m <= 160 * 1024) {
+            static size_t lds_m_dev[BBDM_MAX_DEVICES][2] = {};
+            size_t& have = lds_m_dev[bbdm_device_slot()][MB - 1];
+            if (lds_m > 64 * 1024 && lds_m > have) {
+                const void* f = MB == 2 ? reinterpret_cast<const void*>(linear_mfma_kernel<2>) : reinterpret_cast<const void*>(linear_mfma_kernel<1>);
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m) != hipSuccess) {
+                    bbdm_set_error("linear: hipFuncSetAttribute(%zu) failed", lds_m);
+                    return BBDM_E_LAUNCH;
+                }
+                have = lds_m;
+            }
+            const int otiles = cdiv(Out, 32);
+            const dim3 grid(cdiv(otiles, 4) < 256 ? cdiv(otiles, 4) : 256);
+            if (MB == 2) hipLaunchKernelGGL(linear_mfma_kernel<2>, grid, dim3(256), lds_m, st, x, w, b, y, N, In, Out, act_in, act_out);
+            else hipLaunchKernelGGL(linear_mfma_kernel<1>, grid, dim3(256), lds_m, st, x, w, b, y, N, In, Out, act_in, act_out);
+            BBDM_CHECK_LAUNCH("linear(mfma)");
+            return BBDM_OK;
+        }
+    }
     const size_t lds = (size_t)N * (In + 4) * sizeof(float);
     BBDM_REQUIRE(lds <= 160 * 1024, "linear: N*In too large for LDS staging (%zu B)", lds);
     const int NBl = ilog2(ceil_pow2(N));
     const int outs_per_block = 256 >> NBl;
     const bool vec = (In % 4 == 0) && (((uintptr_t)w & 15) == 0);
-    hipStream_t st = (hipStream_t)stream;
     static size_t lds_set_dev[BBDM_MAX_DEVICES][2] = {};
     size_t (&lds_set)[2] = lds_set_dev[bbdm_device_slot()];
     if (lds > 64 * 1024 && lds > lds_set[vec]) {

@@ -909,6 +909,25 @@ def test_embedding_path(dev, N):
     assert rel_err(y2.cpu(), F.linear(x2, w2)) < TOL
 
 
+@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(5, 512, 1000, True, False), (33, 512, 520, True, True), (64, 64, 96, False, True),
+                                                      (16, 128, 40, False, False), (32, 512, 4096, True, False)])
+def test_linear_on_the_matrix_core(dev, N, In, Out, act_in, act_out):
+    """bbdm_linear_f32 with In % 8 == 0 (linear_mfma_kernel): one and two 32-row blocks, ragged 32-output tiles, a K that is not a
+    multiple of the four-float4 prefetch group, both activations."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(N + In + Out)
+    x = torch.randn(N, In, generator=g)
+    w = torch.randn(Out, In, generator=g) * 0.05
+    b = torch.randn(Out, generator=g) * 0.1
+    ref = F.linear(F.silu(x) if act_in else x, w, b)
+    if act_out:
+        ref = F.silu(ref)
+    y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act_in=act_in, act_out=act_out)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert rel_err(y.cpu(), ref) < TOL
+
+
 @pytest.mark.parametrize("objective", ["grad", "noise", "ysubx"])
 def test_bridge_arithmetic(dev, objective):
     """q_sample / predict_x0 / p_sample update / loss against the oracle formulas: bit-exact or 1 ulp."""
