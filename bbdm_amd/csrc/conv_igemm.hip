@@ -578,22 +578,22 @@ __global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
     }
 }
 
-// ---- 3x3 convolution with 8 (padded) input channels and 128 output channels (the UNet stem: concat(x_t, y) -> 128, -------------
-// openaimodel.py:524) on the f32 MFMA with K = 9 taps x 8 channels = 72 in ONE stage.  The implicit-GEMM kernel above walks K in
+// ---- 3x3 convolution with 4 or 8 (padded) input channels and 128 output channels (the UNet stem: concat(x_t, y) -> 128, ------
+// openaimodel.py:524; the latent UNets' 3 -> 128; the VQGAN encoder's first layer) on the f32 MFMA with K = 9 taps x CIN in ONE stage.  The implicit-GEMM kernel above walks K in
 // 16-channel chunks per tap -- half of every chunk is padding here, and nine staging rounds with a barrier each carry 8 k of work:
 // 0.72 ms at 256x256 / batch 16 for 19 GFLOP and a 537 MB result.  Here a persistent workgroup keeps the [72][128] weights in LDS,
 // stages the 18 x 18 x 8 halo patch of a 16 x 16 pixel tile channel-planar (the A fragment of k = (tap, ci), (tap, ci + 1) is two
 // conflict-free rows of one plane each, all offsets immediates), prefetches the next tile's patch into registers, and each wave
 // multiplies 64 pixels x 128 channels: 288 MFMAs per tile.  STATS: GroupNorm statistics of the output as conv_epilogue_stats.
-template <bool STATS>
+template <int CIN, bool STATS>
 __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, int tiles_total) {
-    constexpr int TS = 16, PR = 18, NPP = PR * PR, PLANE = 328, WP = 160, SLOTS = (NPP * 2 + 255) / 256;
-    __shared__ float patch[8 * PLANE];                           // [ci][py * 18 + px]
-    __shared__ float wsm[72 * WP];                               // [k = tap * 8 + ci][co], pitch = 32 (mod 64): k and k + 1 on disjoint banks
+    constexpr int TS = 16, PR = 18, NPP = PR * PR, PLANE = 328, WP = 160, Q = CIN / 4, SLOTS = (NPP * Q + 255) / 256;
+    __shared__ float patch[CIN * PLANE];                         // [ci][py * 18 + px]
+    __shared__ float wsm[9 * CIN * WP];                          // [k = tap * CIN + ci][co], pitch = 32 (mod 64): k and k + 1 on disjoint banks
     __shared__ double ls[128];                                   // [2 consumers][32 groups][2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    for (int i = tid; i < 72 * 128; i += 256) {
-        const int k = i >> 7, co = i & 127, tap = k >> 3, ci = k & 7;
+    for (int i = tid; i < 9 * CIN * 128; i += 256) {
+        const int k = i >> 7, co = i & 127, tap = k / CIN, ci = k % CIN;
         wsm[k * WP + co] = a.w[((size_t)tap * a.nchunks * a.CoutPad + co) * KC + ci];
     }
     float bv[4];
@@ -605,11 +605,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
         const int n = t / per_img, rem = t - n * per_img, ty = rem / tilesX, tx = rem - ty * tilesX;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int i = tid + s * 256, pix = i >> 1, half = i & 1;
+            const int i = tid + s * 256, pix = i / Q, half = i % Q;
             const int py = pix / PR, px = pix - py * PR;
             const int h = ty * TS + py - 1, w = tx * TS + px - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < NPP * 2 && h >= 0 && h < a.H && w >= 0 && w < a.W)
+            if (i < NPP * Q && h >= 0 && h < a.H && w >= 0 && w < a.W)
                 v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + half * 4);
             xr[s] = v;
         }
@@ -617,8 +617,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
     auto land = [&]() {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            const int i = tid + s * 256, pix = i >> 1, half = i & 1;
-            if (i < NPP * 2) {
+            const int i = tid + s * 256, pix = i / Q, half = i % Q;
+            if (i < NPP * Q) {
                 float* d = patch + (half * 4) * PLANE + pix;
                 d[0] = xr[s].x; d[PLANE] = xr[s].y; d[2 * PLANE] = xr[s].z; d[3 * PLANE] = xr[s].w;
             }
@@ -643,10 +643,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int cp = 0; cp < 4; ++cp) {
+            for (int cp = 0; cp < CIN / 2; ++cp) {
                 const int ko = (2 * cp) * PLANE + (tap / 3) * PR + tap % 3;
                 const float a0 = ab[ko], a1 = ab[ko + 2 * PR];
-                const float* bk = bb + (tap * 8 + 2 * cp) * WP;
+                const float* bk = bb + (tap * CIN + 2 * cp) * WP;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     const float b = bk[cb * 32];
@@ -977,11 +977,17 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
         return BBDM_OK;
     }
     static const int stem_on = getenv("BBDM_CONV_STEM") ? atoi(getenv("BBDM_CONV_STEM")) : 1;
-    if (stem_on && ks == 3 && CinPad == 8 && Cout == 128 && !residual && !pre_scale && out_nchw == 0 && M >= 4096) {
-        const int tiles = N * cdiv(H, 16) * cdiv(W, 16);         // the stem: K = 72 in one stage (conv3x3_stem_kernel)
+    if (stem_on && ks == 3 && (CinPad == 8 || CinPad == 4) && Cout == 128 && !residual && !pre_scale && out_nchw == 0 && M >= 4096) {
+        const int tiles = N * cdiv(H, 16) * cdiv(W, 16);         // the stem: K = 72 / 36 in one stage (conv3x3_stem_kernel)
         const dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
-        if (stats0 || stats1) hipLaunchKernelGGL((conv3x3_stem_kernel<true>), grid, dim3(256), 0, st, a, tiles);
-        else hipLaunchKernelGGL((conv3x3_stem_kernel<false>), grid, dim3(256), 0, st, a, tiles);
+        const bool stats = stats0 || stats1;
+        if (CinPad == 8) {
+            if (stats) hipLaunchKernelGGL((conv3x3_stem_kernel<8, true>), grid, dim3(256), 0, st, a, tiles);
+            else hipLaunchKernelGGL((conv3x3_stem_kernel<8, false>), grid, dim3(256), 0, st, a, tiles);
+        } else {
+            if (stats) hipLaunchKernelGGL((conv3x3_stem_kernel<4, true>), grid, dim3(256), 0, st, a, tiles);
+            else hipLaunchKernelGGL((conv3x3_stem_kernel<4, false>), grid, dim3(256), 0, st, a, tiles);
+        }
         BBDM_CHECK_LAUNCH("conv2d(stem)");
         return BBDM_OK;
     }

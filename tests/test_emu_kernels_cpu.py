@@ -107,8 +107,9 @@ def test_conv2d_accumulates_groupnorm_statistics():
     K.test_conv2d_accumulates_groupnorm_statistics(CPU)
 
 
-def test_stem_conv_accumulates_groupnorm_statistics():
-    K.test_stem_conv_accumulates_groupnorm_statistics(CPU)
+@pytest.mark.parametrize("Cin", [8, 4])
+def test_stem_conv_accumulates_groupnorm_statistics(Cin):
+    K.test_stem_conv_accumulates_groupnorm_statistics(CPU, Cin)
 
 
 def test_conv_rejections_and_slices():

@@ -52,6 +52,7 @@ CONV_CASES = [
     (2, 48, 50, 20, 8, 3, False),        # same, ragged tiles, Cin not a multiple of 16, Cout = 8
     (1, 72, 60, 6, 128, 3, False),       # the UNet stem from 4096 pixels: K = 72 in one stage (conv3x3_stem_kernel), ragged 16x16 tiles
     (3, 64, 64, 8, 128, 3, False),       # ... several images, whole tiles
+    (2, 72, 40, 3, 128, 3, False),       # ... the latent UNets' / the VQGAN encoder's 3 -> 128 (4 padded channels, K = 36)
 ]
 
 
@@ -677,13 +678,14 @@ def test_conv2d_accumulates_groupnorm_statistics(dev):
                   0, None, None, 0, 0, 8, 4, 4, Cin, Cout, 3, s0.data_ptr(), 2, 0, None, 0, 0, st)
 
 
-def test_stem_conv_accumulates_groupnorm_statistics(dev):
-    """The stem kernel (8 padded input channels -> 128, conv3x3_stem_kernel) with the GroupNorm statistics of its output for two
+@pytest.mark.parametrize("Cin", [8, 4])
+def test_stem_conv_accumulates_groupnorm_statistics(dev, Cin):
+    """The stem kernel (8 or 4 padded input channels -> 128, conv3x3_stem_kernel) with the GroupNorm statistics of its output for two
     consumers, ragged tiles, more tiles than one workgroup round would need per image."""
     from bbdm_amd import _lib
     import kernel_ops as ops
     lib = _lib.load()
-    N, H, W, Cin, Cout = 2, 40, 56, 8, 128
+    N, H, W, Cout = 2, 40, 56, 128
     assert lib.bbdm_conv_stats_fusable(N, H, W, Cin, Cout, 3) == 1
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, Cin, H, W, generator=g)
