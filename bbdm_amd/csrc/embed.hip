@@ -4,6 +4,7 @@
 // and every ResBlock's emb_layers = SiLU -> Linear (openaimodel.py:221-227,267).  The 21 per-block projections
 // share one input, so the host concatenates their weights once and issues ONE call ([N,512] x [512, sum 2*Cout]).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -335,7 +336,8 @@ extern "C" int bbdm_linear_f32(const float* x, const float* w, const float* b, f
     {
         const int MB = N > 32 ? 2 : 1;
         const size_t lds_m = (size_t)MB * 32 * (In + 1) * sizeof(float);
-        if (In % 8 == 0 && In >= 64 && Out >= 32 && (((uintptr_t)w & 15) == 0) && lds_m <= 160 * 1024) {
+        static const int mfma_on = getenv("BBDM_LINEAR_MFMA") ? atoi(getenv("BBDM_LINEAR_MFMA")) : 1;
+        if (mfma_on && In % 8 == 0 && In >= 64 && Out >= 32 && (((uintptr_t)w & 15) == 0) && lds_m <= 160 * 1024) {
             static size_t lds_m_dev[BBDM_MAX_DEVICES][2] = {};
             size_t& have = lds_m_dev[bbdm_device_slot()][MB - 1];
             if (lds_m > 64 * 1024 && lds_m > have) {
