@@ -694,8 +694,112 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
     }
 }
 
+// The same for small images (below 65536 output pixels: the heads of the latent UNets and of the 64x64 pixel model): 16 x 16 tiles
+// leave 32 - 64 workgroups on 256 CUs, each walking all channel chunks alone (0.12 ms for the 8192 pixels of the LBBDM-f16 head).
+// Here a workgroup owns an 8 x 8 tile and its four waves split the chunks (wave w: chunks w, w + 4, ...; its own double-buffered
+// 10 x 10 patch), the four partial sums meet in LDS in a fixed order: 16 x the parallelism.
+template <int CO, bool PRE>
+__global__ void __launch_bounds__(256) conv3x3_narrow_small_kernel(const ConvArgs a) {
+    constexpr int TS = 8, PS = TS + 2, NPP = PS * PS, SLOTS = (NPP * 4 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float patchw[4][2][NPP * KP];   // [wave][buffer][patch pixel][16 + 4 pad]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = lane & 7, ty = lane >> 3;
+    const int tilesX = (a.W + TS - 1) / TS;
+    const int tile_y = blockIdx.x / tilesX, tile_x = blockIdx.x - tile_y * tilesX;
+    const int n = blockIdx.y;
+    const int h0 = tile_y * TS - 1, w0 = tile_x * TS - 1;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    const size_t wChunk = (size_t)a.CoutPad * KC;
+    float4 xr[SLOTS];
+    auto request = [&](int chunk) {
+        const int cbase = chunk * KC;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int f = lane + s * 64;
+            const int pp = f >> 2, c4 = f & 3;
+            const int py = pp / PS, px = pp - py * PS;
+            const int h = h0 + py, w = w0 + px, c = cbase + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (chunk < a.nchunks && f < NPP * 4 && h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin)
+                v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + h) * a.W + w) * a.ldx + c);
+            xr[s] = v;
+        }
+    };
+    auto land = [&](int chunk, float* patch) {
+        const int cbase = chunk * KC;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int f = lane + s * 64;
+            if (f >= NPP * 4) continue;
+            const int pp = f >> 2, c4 = f & 3;
+            const int py = pp / PS, px = pp - py * PS;
+            const int h = h0 + py, w = w0 + px, c = cbase + c4 * 4;
+            float4 v = xr[s];
+            if (PRE && chunk < a.nchunks && h >= 0 && h < a.H && w >= 0 && w < a.W && c < a.Cin) {
+                const float4 sc = *reinterpret_cast<const float4*>(a.pre_sc + (size_t)n * a.pre_ld + c);
+                const float4 bi = *reinterpret_cast<const float4*>(a.pre_bi + (size_t)n * a.pre_ld + c);
+                v.x = v.x * sc.x + bi.x; v.y = v.y * sc.y + bi.y; v.z = v.z * sc.z + bi.z; v.w = v.w * sc.w + bi.w;
+                if (a.pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+            }
+            *reinterpret_cast<float4*>(patch + pp * KP + c4 * 4) = v;
+        }
+    };
+    const int rounds = (a.nchunks + 3) / 4;                       // every wave runs every round (the barriers are workgroup-wide)
+    request(wave);
+    for (int r = 0; r < rounds; ++r) {
+        const int chunk = r * 4 + wave;
+        float* patch = patchw[wave][r & 1];
+        land(chunk, patch);
+        __syncthreads();
+        if (r + 1 < rounds) request(chunk + 4);
+        if (chunk < a.nchunks) {
+            const float* __restrict__ wq = a.w + (size_t)chunk * wChunk;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float* P = patch + ((ty + tap / 3) * PS + tx + tap % 3) * KP;
+                const float* __restrict__ Wt = wq + (size_t)tap * a.nchunks * wChunk;
+#pragma unroll
+                for (int k4 = 0; k4 < KC; k4 += 4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(P + k4);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < CO; ++c) acc[c] = fmaf(xs[e], Wt[c * KC + k4 + e], acc[c]);
+                }
+            }
+        }
+    }
+    __syncthreads();                                              // the patches are free: the partial sums meet in them
+    float* red = &patchw[0][0][0];                                // [4 waves][64 pixels][CO]
+#pragma unroll
+    for (int c = 0; c < CO; ++c) red[(wave * 64 + lane) * CO + c] = acc[c];
+    __syncthreads();
+    const int h = tile_y * TS + ty, w = tile_x * TS + tx;
+    if (wave == 0 && h < a.H && w < a.W) {
+        const size_t pix = (size_t)(n * a.H + h) * a.W + w;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            if (c >= a.Cout) continue;
+            const float v = ((red[lane * CO + c] + red[(64 + lane) * CO + c]) + (red[(128 + lane) * CO + c] + red[(192 + lane) * CO + c])) +
+                            (a.bias ? a.bias[c] : 0.f);
+            if (a.out_nchw & 1) a.out[((size_t)(n * a.Cout + c) * a.H + h) * a.W + w] = v;
+            else a.out[pix * a.ldo + c] = v;
+        }
+    }
+}
+
 template <int CO>
 void launch_narrow(const ConvArgs& a, hipStream_t st) {
+    if ((long long)a.N * a.H * a.W < 65536) {                    // small images: 8 x 8 tiles, the chunks split over the four waves
+        const dim3 grid8((unsigned)(cdiv(a.W, 8) * cdiv(a.H, 8)), (unsigned)a.N);
+        if (a.pre_sc) hipLaunchKernelGGL((conv3x3_narrow_small_kernel<CO, true>), grid8, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv3x3_narrow_small_kernel<CO, false>), grid8, dim3(256), 0, st, a);
+        return;
+    }
     const dim3 grid((unsigned)(cdiv(a.W, 16) * cdiv(a.H, 16)), (unsigned)a.N);
     if (a.pre_sc) hipLaunchKernelGGL((conv3x3_narrow_kernel<CO, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_narrow_kernel<CO, false>), grid, dim3(256), 0, st, a);
@@ -971,7 +1075,8 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
     a.st_s[1] = stats1; a.st_cpg[1] = cpg1 > 0 ? cpg1 : 1; a.st_coff[1] = coff1;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
-    if (ks == 3 && Cout <= 8 && !residual && M >= 4096) {      // a few output channels: one thread per pixel (see above)
+    static const long long narrow_min = getenv("BBDM_CONV_NARROW_MIN") ? atoll(getenv("BBDM_CONV_NARROW_MIN")) : 4096;
+    if (ks == 3 && Cout <= 8 && !residual && M >= narrow_min) {      // a few output channels: one thread per pixel (see above)
         if (Cout <= 3) launch_narrow<3>(a, st); else if (Cout <= 4) launch_narrow<4>(a, st); else launch_narrow<8>(a, st);
         BBDM_CHECK_LAUNCH("conv2d(narrow)");
         return BBDM_OK;

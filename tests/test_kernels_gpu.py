@@ -53,6 +53,7 @@ CONV_CASES = [
     (1, 72, 60, 6, 128, 3, False),       # the UNet stem from 4096 pixels: K = 72 in one stage (conv3x3_stem_kernel), ragged 16x16 tiles
     (3, 64, 64, 8, 128, 3, False),       # ... several images, whole tiles
     (2, 72, 40, 3, 128, 3, False),       # ... the latent UNets' / the VQGAN encoder's 3 -> 128 (4 padded channels, K = 36)
+    (5, 40, 24, 144, 4, 3, False),       # small-image head (8x8 tiles, chunks split over the waves): 9 chunks = a ragged last round
 ]
 
 
