@@ -146,11 +146,12 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
     const float* xb = a.x + (size_t)n * a.H * a.W * a.ldx;
     float* yb = a.y + (size_t)n * Ho * Wo * a.ldy;
 
-    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < units; u += (long long)gridDim.x * 256) {
-        const int c4 = (int)(u % C4);
-        const int pu = (int)(u / C4);
-        const int c = c4 * 4;
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), bi = make_float4(0.f, 0.f, 0.f, 0.f);
+    // x * sc + bi of channel quad c (fp64 mean / rstd per group: ~100 instructions).  The launcher sizes the grid so that its stride is a
+    // multiple of C / 4 wherever it can: the quad of a thread is then the same for all its units and the coefficients are computed ONCE
+    // per thread instead of once per float4 (the pass is HBM-bound only without that arithmetic).
+    auto coeffs = [&](int c, float4& sc, float4& bi) {
+        sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        bi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.norm) {
             float rs[4], mu[4];
             const int ng = (cpg & 3) ? 4 : 1;      // a quad may span several groups unless cpg % 4 == 0
@@ -178,6 +179,17 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
                                  bi.w * (1.f + fs.w) + fb.w);
             }
         }
+    };
+    const long long stride = (long long)gridDim.x * 256;
+    const bool fixed_quad = stride % C4 == 0;
+    float4 sc0 = make_float4(1.f, 1.f, 1.f, 1.f), bi0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (fixed_quad) coeffs((int)((blockIdx.x * 256ll + threadIdx.x) % C4) * 4, sc0, bi0);
+    for (long long u = blockIdx.x * 256ll + threadIdx.x; u < units; u += stride) {
+        const int c4 = (int)(u % C4);
+        const int pu = (int)(u / C4);
+        const int c = c4 * 4;
+        float4 sc = sc0, bi = bi0;
+        if (!fixed_quad) coeffs(c, sc, bi);
         if (a.resample == 0) {
             const float4 v = *reinterpret_cast<const float4*>(xb + (size_t)pu * a.ldx + c);
             *reinterpret_cast<float4*>(yb + (size_t)pu * a.ldy + c) = gn_xform(a, v, sc, bi);
@@ -311,6 +323,12 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     long long blocks = (units + 255) / 256;
     const long long cap = cdiv(8192, N) > 1 ? cdiv(8192, N) : 1;
     if (blocks > cap) blocks = cap;
+    {   // grid stride = a multiple of C / 4: every thread keeps one channel quad (gn_apply_kernel computes its coefficients once)
+        int g = 256, r = C / 4;
+        while (r) { const int t = g % r; g = r; r = t; }
+        const int m = (C / 4) / g;
+        if (blocks >= m) blocks = blocks / m * m;
+    }
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, a);
     BBDM_CHECK_LAUNCH("gn_apply");
     return BBDM_OK;
