@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -20,9 +20,6 @@ SIGNATURES = {
     "bbdm_version": (c_int, []),
     "bbdm_last_error": (c_char_p, []),
     "bbdm_device_cus": (c_int, []),
-    "bbdm_stream_create_partition": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
-    "bbdm_stream_destroy": (c_int, [_P]),
-    "bbdm_stream_cus": (c_int, [_P]),
     "bbdm_nchw_to_nhwc_f32": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_nhwc_to_nchw_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_conv_packed_floats": (c_size_t, [c_int, c_int, c_int]),
@@ -104,10 +101,6 @@ SIGNATURES = {
     "bbdm_gemm_bf3p_split_rows_f32": (c_int, [_P, c_int, _P, c_int, ctypes.c_longlong, c_int, _P]),
     "bbdm_gemm_bf3p_f32": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_conv1x1_bf3q_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
-    "bbdm_gemm_bf3q_a_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
-    "bbdm_gemm_bf3q_f32": (c_int, [_P, _P, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),
-    "bbdm_winograd_input_bf3q_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "bbdm_winograd_gemm_bf3q_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_input_bf3p_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_gemm_bf3p_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_gemm_bf3p_fwd_splits": (c_int, [c_int, ctypes.c_longlong, c_int, c_int]),
@@ -127,6 +120,7 @@ SIGNATURES = {
     "bbdm_opt_chunk_elems": (c_int, []),
     "bbdm_adam_ema_step_f32": (c_int, [_P, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                        ctypes.c_longlong, c_int, c_double, _P]),
+    "bbdm_debug_set_bf3p_kernel": (c_int, [c_int]),             # test hook (header: "test hooks")
 }
 
 _lib = None
@@ -163,7 +157,7 @@ def load():
     return _lib
 
 
-# ---- the three places the package touches the HIP runtime through torch (device memory / streams are torch's) ---------
+# ---- the places the package touches the HIP runtime through torch (device memory / streams are torch's) ---------
 def require_gpu(*tensors):
     """No CPU fallback by design: every tensor handed to the kernels must live on a GPU."""
     for t in tensors:
@@ -176,29 +170,6 @@ def current_stream(device) -> int:
     """Raw ``hipStream_t`` of torch's current stream on ``device`` (the kernels are enqueued there)."""
     import torch
     return torch.cuda.current_stream(device).cuda_stream
-
-
-_partitions = {}
-
-
-def partition_streams(device, t_cus: int):
-    """The two CU-partition streams of ``device`` for a split of ``t_cus`` CUs (streaming launches) : the rest (matrix launches) --
-    csrc/runtime.hip.  Returns ((torch stream, raw handle) for T, the same for G); created once per (device, split) and kept for the
-    life of the process.  Raises BBDMHipError where the runtime refuses CU masks (callers fall back to the one-stream plan)."""
-    import torch
-    key = (torch.device(device).index or 0, int(t_cus))
-    hit = _partitions.get(key)
-    if hit is None:
-        lib = load()
-        with torch.cuda.device(device):
-            cus = lib.bbdm_device_cus()
-            hs = []
-            for lo, hi in ((0, t_cus), (t_cus, cus)):
-                h = c_void_p()
-                check(lib.bbdm_stream_create_partition(lo, hi, ctypes.byref(h)), "bbdm_stream_create_partition")
-                hs.append((torch.cuda.ExternalStream(h.value, device=device), h.value))
-        hit = _partitions[key] = tuple(hs)
-    return hit
 
 
 def device_guard(device):

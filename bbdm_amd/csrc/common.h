@@ -32,7 +32,6 @@ void bbdm_set_error(const char* fmt, ...);
 // hipFuncSetAttribute applies to the CURRENT device: the "already raised the LDS limit" caches are kept per device
 // (a process may drive several GPUs: the reference's `main.py --gpu_ids 1` runs on cuda:1 without set_device).
 constexpr int BBDM_MAX_DEVICES = 64;
-constexpr int BBDM_MAX_CU_WORDS = 16;        // CU masks of up to 512 CUs (runtime.hip: partition streams)
 static inline int bbdm_device_slot() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BBDM_MAX_DEVICES) d = 0;
@@ -83,8 +82,6 @@ __device__ __forceinline__ float2 load_nt(const float2* p) {
 #define BBDM_NT_MSTORE 0
 #endif
 
-// runtime.hip: CUs the kernels enqueued on `stream` can run on (a CU-partition stream's share, else the whole device)
-extern "C" int bbdm_stream_cus(void* stream);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int ceil_pow2(int v) {
@@ -113,10 +110,6 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 // hardware v_exp_f32 + v_rcp_f32 (~2 ulp; __frcp_rn would expand to the full IEEE division sequence): for kernels where the exact-division form above would make an HBM-bound pass
 // ALU-bound (the Winograd input transform evaluates each activation (m+2)^2/m^2 times)
-// gemm_bf3p.hip (declared here for winograd.hip; also part of the public header)
-extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr,
-                                  float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
-
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 // ... of a channel pair: the multiplies and the add as packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32), only the two
 // v_exp_f32 and two v_rcp_f32 (quarter rate) per pair stay scalar; same values as silu_fast per element

@@ -52,7 +52,6 @@ struct ConvArgs {
     // batched GEMM mode (gridDim.z = batch): per-batch element offsets of x / packed weights / out.  Used by the
     // Winograd path (16 transformed-domain GEMMs in one launch); bias, residual and split-K are off in this mode.
     int batch;
-    long long* dbg;
     size_t xz, wz, oz;
     // GroupNorm statistics of the output accumulated by this launch (VAR bit 3; see winograd.hip: StatArgs): fp64 [N][32][2]
     // accumulators of up to two consumers, their group width and the channel offset of `out` in their tensor
@@ -239,8 +238,6 @@ conv_igemm_f32(const ConvArgs a_in) {
     a.x += (size_t)blockIdx.z * a.xz;
     a.w += (size_t)blockIdx.z * a.wz;
     a.out += (size_t)blockIdx.z * a.oz;
-    long long tdbg0 = 0, tdbg1 = 0, tdbg2 = 0;
-    if (a.dbg) tdbg0 = wall_clock64();
     constexpr int NTHR = WM * WN * 64;
     constexpr int MT = BM / WM / 32;     // 32-row MFMA tiles per wave (M)
     constexpr int NTL = BN / WN / 32;    // 32-col MFMA tiles per wave (N)
@@ -392,7 +389,6 @@ conv_igemm_f32(const ConvArgs a_in) {
 
     const int nphase = chunk_end * a.taps;
     int chunk = chunk_begin, tap = 0;
-    if (a.dbg) tdbg1 = wall_clock64();
     auto mfma_phase = [&](const float* P, const float* Wb) {
 #pragma unroll
         for (int kg = 0; kg < KC / 8; ++kg) {
@@ -468,19 +464,10 @@ conv_igemm_f32(const ConvArgs a_in) {
         if (last_tap) { tap = 0; ++chunk; } else { ++tap; }
     }
 
-    if (a.dbg) tdbg2 = wall_clock64();
     if constexpr (STATS)
         conv_epilogue_stats<BM, BN, WM, WN>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, smem);
     else
         conv_epilogue<BM, BN, WM, WN, SPLIT>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane);
-    if (a.dbg && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        long long* d = a.dbg + (size_t)lin * 8;
-        d[0] = tdbg0; d[1] = tdbg1; d[2] = tdbg2; d[3] = wall_clock64();
-        d[4] = __builtin_amdgcn_s_getreg(63492);     // HW_ID
-        d[5] = __builtin_amdgcn_s_getreg(63508);     // XCC_ID
-    }
 }
 
 // ---- 3x3 convolution with a handful of output channels (the UNet head: 128 -> 3, openaimodel.py:687-691) -----------------
@@ -1000,9 +987,6 @@ extern "C" size_t bbdm_conv_splitk_workspace_floats(int N, int H, int W, int Cin
 
 // Batched 1x1 "convolution" = `batch` independent GEMMs [pixels x CinPad] x [CinPad x Cout] in one launch (used by the
 // Winograd path; declared in common.h).  x / packed_w / out advance by xz / wz / oz floats per batch element.
-static long long* g_conv_trace = nullptr;
-extern "C" void bbdm_debug_conv_trace(long long* p) { g_conv_trace = p; }
-
 int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed_w, size_t wz, float* out, int ldo, size_t oz,
                          int batch, int H, int W, int CinPad, int Cout, hipStream_t st) {
     ConvArgs a;
@@ -1015,7 +999,6 @@ int bbdm_conv1x1_batched(const float* x, int ldx, size_t xz, const float* packed
     a.pre_sc = nullptr; a.pre_bi = nullptr; a.pre_ld = 0; a.pre_silu = 0;
     a.batch = batch; a.xz = xz; a.wz = wz; a.oz = oz;
     a.st_s[0] = a.st_s[1] = nullptr; a.st_cpg[0] = a.st_cpg[1] = 1; a.st_coff[0] = a.st_coff[1] = 0;
-    a.dbg = g_conv_trace;
     a.splits = 1;
     int rc = launch_conv<256, 128, 4, 2, 2, 2>(a, st);
     if (rc == 1) {
@@ -1065,7 +1048,7 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
     BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
                  "conv2d: pre_ld / alignment of the fused-producer coefficients");
     a.pre_sc = pre_scale; a.pre_bi = pre_bias; a.pre_ld = pre_ld; a.pre_silu = pre_silu;
-    a.batch = 1; a.xz = a.wz = a.oz = 0; a.dbg = nullptr;
+    a.batch = 1; a.xz = a.wz = a.oz = 0;
     BBDM_REQUIRE((!stats0 && !stats1) || bbdm_conv_stats_fusable(N, H, W, CinPad, Cout, ks),
                  "conv2d: GroupNorm statistics cannot be accumulated for this shape (bbdm_conv_stats_fusable)");
     BBDM_REQUIRE((!stats0 || (cpg0 > 0 && coff0 >= 0 && (coff0 + Cout - 1) / cpg0 < 32)) &&

@@ -17,12 +17,11 @@
 //   B (U planes): [batch][CoutPad / 32 col groups][nchunks][3 planes][1 KB]
 // The chunks of one row group are contiguous: a workgroup streams its 8 row groups as 8 sequential 3 KB-per-chunk streams.
 //
-// Kernels: workgroup = WM x WN waves of 64 x 64 outputs (2 x 2 MFMA tiles, 64 accumulator VGPRs), K walked 16 at a time (one MFMA
+// Kernel: workgroup = WM x WN waves of 64 x 64 outputs (2 x 2 MFMA tiles, 64 accumulator VGPRs), K walked 16 at a time (one MFMA
 // K-step): per chunk and wave 12 fragment reads, 24 MFMAs and its share of the next chunks' unit copies into the other LDS stage.
-//   * gemm_bf3p_kernel: reads, copy issue, MFMAs, ONE wait + barrier per chunk -- the plain structure (kept as the A/B baseline);
-//   * gemm_bf3p_pipe_kernel (the default): the fragments of chunk c + 1 are read and the copies of chunk c + 2 issued BETWEEN the
-//     MFMAs of chunk c, so that after the barrier every wave continues with MFMAs at once; 256 x 256 tiles (16 waves, one
-//     workgroup per CU: a third less L2 -> LDS traffic per FLOP than 256 x 128) where Cout fills them.
+// gemm_bf3p_pipe_kernel: the fragments of chunk c + 1 are read and the copies of chunk c + 2 issued BETWEEN the MFMAs of chunk c, so
+// that after the barrier every wave continues with MFMAs at once; 256 x 256 tiles (16 waves, one workgroup per CU: a third less
+// L2 -> LDS traffic per FLOP than 256 x 128) where Cout fills them.
 // Measured (MI355X, the 42 Winograd layers of the C2 step): 216 TFLOP/s fp32-equivalent = 1.30 PFLOP/s of bf16 MFMA = 0.52 of the
 // 416.7 (2500 / 6) peak, MfmaUtil 75 % at the 1.77 GHz the chip sustains under this load; gemm_bf3.hip: 181 = 0.43, MfmaUtil 54 %.
 #include "bf3_split.h"
@@ -79,137 +78,9 @@ __device__ __forceinline__ void glds16(const unsigned char* unit, unsigned lane1
 // LDS byte address of a __shared__ object (the operand of a hand-written ds_read)
 __device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p; }
 
-// WM x WN waves, each 64 x 64.  RES: add a residual row in the epilogue (compile-time, see gemm_bf3.hip).
-template <int WM, int WN, bool RES>
-__global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_kernel(const Bf3pArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
-    constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
-    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
-    constexpr int KMAX = (NU + NW - 1) / NW;                                  // copies per wave and chunk (the last may be partial)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned lane16 = lane * 16;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    int bid, bz;
-    if (a.by_batch) {        // XCD c owns the batch entries c, c + 8, ...: an entry's operands cross the fabric into ONE L2
-        const int L = (int)blockIdx.x, j = L >> 3;
-        bz = (L & 7) + 8 * (j / a.tiles);
-        if (bz >= a.batch) return;
-        bid = j % a.tiles;
-    } else {
-        bz = (int)blockIdx.z;
-        bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
-    }
-    const int tilesN = a.tilesN * 2 / WN;                                     // a.tilesN counts 128-column tiles
-    const int n_tile = bid % tilesN, m_tile = bid / tilesN;
-    const int row0 = m_tile * BM, cout0 = n_tile * BN;
-    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;                       // bytes of one row / col group (all chunks)
-    const unsigned char* A = a.A + (size_t)bz * a.az + (size_t)m_tile * (WM * 2) * gstride;
-    const unsigned char* B = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride;
-    float* M = a.M + (size_t)bz * a.mz;
-    const float* res = a.res + (size_t)bz * a.rz;
-
-    // ---- this wave's share of a stage: units wave, wave + NW, ... of [A: (row group i, plane p) | B: (col group j, plane p)] ----
-    const unsigned char* src[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int u = wave + k * NW;
-        const int ub = u - NA;
-        src[k] = (u < NA ? A + (size_t)(u / 3) * gstride + (u % 3) * UNIT
-                         : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
-    }
-    auto issue = [&](int chunk, unsigned char* st) {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            const int u = wave + k * NW;
-            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + u * UNIT);
-        }
-    };
-
-    // ---- fragment addresses: unit (2 wm + t, p) of A, unit (2 wn + t, p) of B, one 16-B slot per lane ----------------------
-    const int aoff = (wm * 2) * 3 * UNIT + lane * 16;
-    const int boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // bias before the main loop: its load is long complete when the epilogue uses it (hipcc does not see the counted waits of the
-    // loop and would otherwise re-wait vmcnt(0) in front of every store)
-    float bv[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-        bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-    }
-    issue(0, smem);
-    wait_vmcnt<0>();
-    __syncthreads();
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        const unsigned char* st = smem + (chunk & 1) * STAGE;
-        bf16x8 af[2][3], bf[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                af[t][p] = *reinterpret_cast<const bf16x8*>(st + aoff + (t * 3 + p) * UNIT);
-                bf[t][p] = *reinterpret_cast<const bf16x8*>(st + boff + (t * 3 + p) * UNIT);
-            }
-        __builtin_amdgcn_sched_barrier(0);          // the copies below are issued AFTER the reads (no LDS read while a copy is in flight)
-        if (chunk + 1 < a.nchunks) issue(chunk + 1, smem + ((chunk + 1) & 1) * STAGE);
-        // term-major, tile-minor: consecutive MFMAs go to different accumulators; smallest terms first (gemm_bf3.hip)
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][BF3_TA[t]], bf[j][BF3_TB[t]], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the register-only MFMAs below the barrier)
-        wait_vmcnt<0>();                            // this wave's copies of the next stage have landed ...
-        __syncthreads();                            // ... and so have everybody else's; everybody is done reading this stage
-    }
-
-    // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8) {
-            float rv[8][2];
-            if (RES) {
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = r0 + rr;
-                    const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                        rv[rr][j] = co < a.Cout ? res[(size_t)row * a.ldr + co] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = r0 + rr;
-                const int row = row0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float* dst = M + (size_t)row * a.ldo;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                    float v = acc[i][j][r] + bv[j];
-                    if (RES) v += rv[rr][j];
-                    if (co < a.Cout) dst[co] = v;
-                }
-            }
-        }
-}
-
 // ---- software-pipelined variant: the fragments of chunk c + 1 are read WHILE the MFMAs of chunk c run ------------------------------
-// In the two kernels above every wave does its front-end work (fragment reads, copy issue) right after the barrier -- all waves at
+// (The plain two-stage structure -- reads, copy issue, MFMAs, ONE wait + barrier per chunk -- measured 181 - 204 TFLOP/s against this
+// kernel's 211 - 216 on the C2 layers, profiles/r03_bf3p_variants.txt, and is no longer built.)  There every wave did its front-end work (fragment reads, copy issue) right after the barrier -- all waves at
 // once, the matrix pipe idle meanwhile (measured: ~12 % of the kernel with one 16-wave workgroup per CU).  Here a wave enters an
 // iteration with the fragments of its chunk already in registers and issues, between the six term groups of its 24 MFMAs, the
 // copies of chunk c + 2 and the reads of chunk c + 1 -- each fragment register is re-loaded right after the last term that uses
@@ -431,13 +302,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
 // of chunk c + 2 at the top of iteration c and, after the fourth term group, splits them (bf3_split.h: 22 VALU instructions) and
 // writes 3 x 8 B into the stage chunk c was read from.  One float4 + 22 VALU instructions per wave and chunk against its 24 MFMAs:
 // half of gemm_bf3.hip's split work per MFMA, and no wave waits for another's split.
-// A layouts: ROWS = fp32 rows with a pitch (the 1x1 convolutions: x NHWC); UNITS = fp32 row units [T / 32][nchunks][2 KB], element
-// (r, k) at byte (k >> 3) * 1024 + r * 32 + (k & 7) * 4 (written by the Winograd input transform: 256-byte runs).
+// A = fp32 rows with a pitch (the 1x1 convolutions: x NHWC).  (Round 3 also fed it the Winograd V as fp32 row units, 4 B per element
+// instead of the planes' 6: input transforms -3.7 ms, tile GEMMs +3.9 ms on the C2 step, profiles/r03_bf3q_bench.txt; removed.)
 // Results bit-equal to the other bf16x3 kernels.
 // Register budget: the pipe kernel's 64 accumulators + 48 fragment registers leave no room for the staging registers and the split's
 // temporaries at 128 VGPRs (a 16-wave build spilled 194 registers and ran at 20 TFLOP/s): the workgroup is 3 x WN waves -- 192-row
 // tiles, THREE waves per SIMD, up to 168 VGPRs each (WN = 4: one 12-wave workgroup per CU; WN = 2: two 6-wave workgroups).
-template <int WM, int WN, bool RES, bool UNITS>
+template <int WM, int WN, bool RES>
 __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const Bf3pArgs a, const float* __restrict__ Af, int lda) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
@@ -474,16 +345,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
     for (int s = 0; s < AS; ++s) {
         const int f = tid + s * NW * 64, row = f >> 2, q = f & 3;
         const int grow = min(row0 + row, a.T - 1);                            // (a ragged last row tile re-reads the last row)
-        if (UNITS) {
-            // unit of (row group, chunk): [h = k >> 3][r][8 floats]
-            asrc[s] = Af + (size_t)bz * (a.az / 4) + ((size_t)(grow >> 5) * a.nchunks) * 512 + (q >> 1) * 256 + (grow & 31) * 8 + (q & 1) * 4;
-        } else {
-            asrc[s] = Af + (size_t)bz * (a.az / 4) + (size_t)grow * lda + q * 4;
-        }
+        asrc[s] = Af + (size_t)bz * (a.az / 4) + (size_t)grow * lda + q * 4;
         // plane unit of row group (row >> 5): byte (k >> 3) * 512 + r * 16 + (k & 7) * 2, k = 4 q
         adst[s] = (unsigned)(((row >> 5) * 3) * UNIT + (q >> 1) * 512 + (row & 31) * 16 + (q & 1) * 8);
     }
-    astep = UNITS ? 512 : KC;
+    astep = KC;
     const unsigned char* bsrc[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
@@ -724,42 +590,29 @@ extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_pl
     return BBDM_OK;
 }
 
-// Probe (exported, not part of the public header): v != 0 pads the 8-wave kernels' LDS request beyond half a CU's so that ONE workgroup
-// runs per CU -- half of the register file and 16 wave slots stay free for a streaming kernel on another stream (tools/partition_probe.py
-// --coreside: can the HBM-bound transforms run BESIDE the tile GEMM on the same CUs?)
-static int g_bf3p_one_per_cu = 0;
-extern "C" int bbdm_debug_set_bf3p_one_per_cu(int v) { const int old = g_bf3p_one_per_cu; g_bf3p_one_per_cu = v; return old; }
-
-// KIND 0: gemm_bf3p_kernel (two stages, front-end work after every barrier); KIND 1: gemm_bf3p_pipe_kernel (fragments one chunk ahead)
-template <int WM, int WN, int KIND, bool RES>
+template <int WM, int WN, bool RES>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
-    if (g_bf3p_one_per_cu && WM * WN <= 8 && lds < 84 * 1024) lds = 84 * 1024;
-    const void* fn = KIND == 0 ? reinterpret_cast<const void*>(gemm_bf3p_kernel<WM, WN, RES>)
-                               : reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>);
-    if (!attr_set || g_bf3p_one_per_cu) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
         }
         attr_set = true;
     }
-    const long long blocks = (((long long)a.T + WM * 64 - 1) / (WM * 64)) * (a.tilesN * 2 / WN);     // (a ragged last row tile: KIND 1 only)
+    const long long blocks = (((long long)a.T + WM * 64 - 1) / (WM * 64)) * (a.tilesN * 2 / WN);     // (the last row tile may be ragged)
     BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3p: too many tiles");
     a.tiles = (int)blocks;
     dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
     a.persist = 0;
-    if (KIND == 1 && a.by_batch) {
+    if (a.by_batch) {
         // persistent tiles (see gemm_bf3p_pipe_kernel): as many workgroups as the chip holds at once (LDS- and wave-limited per CU), a
         // multiple of 8 so that tile L keeps its XCD L % 8.  BBDM_BF3P_PERSIST=0: one tile per workgroup (A/B)
         static const int persist_env = [] { const char* e = getenv("BBDM_BF3P_PERSIST"); return e ? atoi(e) : 1; }();
-        // the CUs of the launch stream: a CU-partition stream (runtime.hip) owns a share of every XCD, any other stream the device.
-        // BBDM_BF3P_CUS=n: walk the tiles with the workgroups of n CUs only (probe: is the tile GEMM CU-bound or power-bound?)
-        static const int cus_env = [] { const char* e = getenv("BBDM_BF3P_CUS"); return e ? atoi(e) : 0; }();
-        int cus = bbdm_stream_cus((void*)st);
-        if (cus_env >= 8 && cus_env < cus) cus = cus_env;
+        const int cus = bbdm_device_cus();
         const int by_lds = (int)((160 * 1024) / lds), by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
         const int per_cu = by_lds < by_waves ? by_lds : by_waves;
         const unsigned resident = (unsigned)(cus * (per_cu > 0 ? per_cu : 1)) / 8 * 8;
@@ -768,20 +621,17 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
             grid = dim3(resident);
         }
     }
-    if (KIND == 0)
-        hipLaunchKernelGGL((gemm_bf3p_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
-    else
-        hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
     return BBDM_OK;
 }
 
-// Kernel choice (A/B runs; exported, not part of the public header; env BBDM_BF3P_KERNEL).  Measured on the 42 Winograd layers of
-// the C2 step, launch-weighted fp32-equivalent TFLOP/s (profiles/r03_bf3p_variants.txt; gemm_bf3.hip on the same GEMMs: 181):
-//   0 = gemm_bf3p_kernel 256 x 128, two workgroups per CU            181      3 = gemm_bf3p_kernel 256 x 256, 16 waves      194-204
-//   4 = pipe kernel 256 x 256 (512 x 128 where Cout < 256)         213-214    5 = pipe kernel 256 x 128, two per CU         204-210
-//   6 (default) = pipe kernel 256 x 256 where Cout fills 256-column tiles, else 256 x 128                                  211-216
-// (a 3-stage LDS ring with counted vmcnt waits for the non-pipelined kernel measured 185-191 and was deleted: what it hides --
-// copy latency -- was not the bound; the front-end bubble after each barrier was.)
+// Tile choice (env BBDM_BF3P_KERNEL / bbdm_debug_set_bf3p_kernel, the header's test-hook section): 6 (default) = 256 x 256 tiles where
+// Cout fills 256-column tiles and the launch quantises well, else 256 x 128, 128 x 128 for the small layers; forced shapes for the
+// A/B and for the tests (small test problems would otherwise only ever reach the 128 x 128 instantiation): 4 = 256 x 256 (256 x 128
+// where Cout does not fill 256 columns), 5 = 256 x 128, 7 = 128 x 128.  Measured on the 42 Winograd layers of the C2 step,
+// launch-weighted fp32-equivalent TFLOP/s (profiles/r03_bf3p_variants.txt; gemm_bf3.hip on the same GEMMs: 181): 5: 204 - 210,
+// 4: 213 - 214, 6: 211 - 216.  (The non-pipelined two-stage kernel, 181 - 204, and a 3-stage LDS ring with counted vmcnt waits,
+// 185 - 191, were measured in round 3 and deleted.)
 static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 6; }();
 extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_variant; g_bf3p_variant = v; return old; }
 
@@ -847,14 +697,10 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     static const int small_wg = [] { const char* e = getenv("BBDM_BF3P_SMALL_WG"); return e ? atoi(e) : 200; }();
     auto wgs = [&](int bm, int bn) { return (long long)nb * cdiv((int)rows, bm) * cdiv(CoutPad, bn); };
     int rc;
-#define BBDM_BF3P_GO(WM, WN, KIND) (residual ? bf3p_launch<WM, WN, KIND, true>(a, nb, st) : bf3p_launch<WM, WN, KIND, false>(a, nb, st))
-    const bool plain = rows == T && splits == 1;                 // (the A/B kernels have neither ragged rows nor split-K)
-    if (g_bf3p_variant == 0 && plain) rc = BBDM_BF3P_GO(4, 2, 0);
-    else if (g_bf3p_variant == 3 && plain) rc = wide ? BBDM_BF3P_GO(4, 4, 0) : BBDM_BF3P_GO(4, 2, 0);
-    else if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(8, 2, 1);
-    else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2, 1);
-    else if (g_bf3p_variant == 7) rc = BBDM_BF3P_GO(2, 2, 1);
-    else if (wgs(256, 128) < small_wg) rc = BBDM_BF3P_GO(2, 2, 1);
+#define BBDM_BF3P_GO(WM, WN) (residual ? bf3p_launch<WM, WN, true>(a, nb, st) : bf3p_launch<WM, WN, false>(a, nb, st))
+    if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4) : BBDM_BF3P_GO(4, 2);
+    else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2);
+    else if (g_bf3p_variant == 7 || wgs(256, 128) < small_wg) rc = BBDM_BF3P_GO(2, 2);
     else {
         // 256 x 256 (one workgroup per CU) vs 256 x 128 (two per CU): the CU that gets the most workgroups sets the time.  Mid-size
         // problems (the 16x16 / 32x32 levels of the latent models: 288 ... 1152 tiles of 256 x 256 on 256 CUs) lose up to half a
@@ -865,7 +711,7 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
             return a.by_batch ? (double)((per_entry * ((nb + 7) / 8) + 31) / 32) : (double)((per_entry * nb + 255) / 256);
         };
         const double t44 = wide ? rounds(256, 256) : 1e30, t42 = rounds(256, 128) * 0.5 / 0.94;
-        rc = t44 <= t42 ? BBDM_BF3P_GO(4, 4, 1) : BBDM_BF3P_GO(4, 2, 1);
+        rc = t44 <= t42 ? BBDM_BF3P_GO(4, 4) : BBDM_BF3P_GO(4, 2);
     }
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;
@@ -968,7 +814,7 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
     a.batch = nb;
     a.by_batch = (by_batch_env && nb >= 8) ? 1 : 0;              // (the pipe kernel returns early for the padding entries of a batch % 8 != 0)
     hipStream_t st = (hipStream_t)stream;
-    const int rc = sp.wn == 4 ? bf3p_launch<4, 4, 1, false>(a, nb, st) : bf3p_launch<4, 2, 1, false>(a, nb, st);
+    const int rc = sp.wn == 4 ? bf3p_launch<4, 4, false>(a, nb, st) : bf3p_launch<4, 2, false>(a, nb, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p_tn");
     return BBDM_OK;
@@ -976,12 +822,12 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
 
 // ---- fp32 A operand on the pipelined kernel (gemm_bf3q_pipe_kernel) ---------------------------------------------------------------------
 namespace {
-template <int WM, int WN, bool RES, bool UNITS>
+template <int WM, int WN, bool RES>
 int bf3q_launch(Bf3pArgs& a, const float* Af, int lda, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
     const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
-    const void* fn = reinterpret_cast<const void*>(gemm_bf3q_pipe_kernel<WM, WN, RES, UNITS>);
+    const void* fn = reinterpret_cast<const void*>(gemm_bf3q_pipe_kernel<WM, WN, RES>);
     if (!attr_set) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3q: hipFuncSetAttribute(%zu B LDS) failed", lds);
@@ -994,14 +840,15 @@ int bf3q_launch(Bf3pArgs& a, const float* Af, int lda, int batch, hipStream_t st
     a.tiles = (int)blocks;
     a.persist = 0;
     const dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
-    hipLaunchKernelGGL((gemm_bf3q_pipe_kernel<WM, WN, RES, UNITS>), grid, dim3(WM * WN * 64), lds, st, a, Af, lda);
+    hipLaunchKernelGGL((gemm_bf3q_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a, Af, lda);
     return BBDM_OK;
 }
 }  // namespace
 
 // out[pixels][ldo] = x[pixels][ldx] . W^T + bias (+ residual): the 1x1 convolutions / Linears of bbdm_conv1x1_bf3_f32 (same call
 // sites, same arithmetic bit for bit) on the pipelined kernel.  b_planes = bbdm_gemm_bf3p_pack_b_f32(batch = 1) of the buffer
-// bbdm_conv_pack_weight_f32(ks = 1) filled.  pixels a multiple of 32, CinPad a multiple of 16.
+// bbdm_conv_pack_weight_f32(ks = 1) filled.  Any pixel count (a ragged last row tile re-reads the last row and masks its stores), CinPad a
+// multiple of 16.
 extern "C" int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
                                      float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream) {
     BBDM_REQUIRE(x && b_planes && out, "conv1x1_bf3q: null pointer");
@@ -1020,38 +867,9 @@ extern "C" int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_plan
     a.ksplits = 1; a.kps = a.nchunks; a.P = 1; a.batch = 1; a.by_batch = 0;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (CoutPad % 256 == 0) rc = residual ? bf3q_launch<3, 4, true, false>(a, x, ldx, 1, st) : bf3q_launch<3, 4, false, false>(a, x, ldx, 1, st);
-    else rc = residual ? bf3q_launch<3, 2, true, false>(a, x, ldx, 1, st) : bf3q_launch<3, 2, false, false>(a, x, ldx, 1, st);
+    if (CoutPad % 256 == 0) rc = residual ? bf3q_launch<3, 4, true>(a, x, ldx, 1, st) : bf3q_launch<3, 4, false>(a, x, ldx, 1, st);
+    else rc = residual ? bf3q_launch<3, 2, true>(a, x, ldx, 1, st) : bf3q_launch<3, 2, false>(a, x, ldx, 1, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("conv1x1_bf3q");
-    return BBDM_OK;
-}
-
-// M[b][T][ldo] = A_b . B_b with A as fp32 ROW UNITS [batch][T / 32][CinPad / 16][2 KB] (element (r, k) of a unit at byte
-// (k >> 3) * 1024 + r * 32 + (k & 7) * 4: what bbdm_winograd_input_bf3q_f32 writes -- 4 B per transformed element instead of the
-// planes' 6) and B as bbdm_gemm_bf3p_pack_b_f32 planes; T a multiple of 32.  Bit-equal to bbdm_gemm_bf3p_f32 on the same values.
-extern "C" size_t bbdm_gemm_bf3q_a_bytes(int batch, long long T, int CinPad) {
-    return (size_t)batch * (size_t)((T + 31) / 32 * 32) * (size_t)CinPad * 4;
-}
-extern "C" int bbdm_gemm_bf3q_f32(const void* a_units, const void* b_planes, float* M, int ldo, int batch, long long T, int CinPad,
-                                  int Cout, void* stream) {
-    BBDM_REQUIRE(a_units && b_planes && M && batch > 0, "gemm_bf3q: null pointer / bad batch");
-    BBDM_REQUIRE(T > 0 && T % 32 == 0 && T < (1ll << 31) && CinPad > 0 && CinPad % KC == 0 && Cout > 0 && Cout % 4 == 0,
-                 "gemm_bf3q: T=%lld CinPad=%d Cout=%d unsupported (T %% 32, CinPad %% 16)", T, CinPad, Cout);
-    BBDM_REQUIRE((((uintptr_t)a_units | (uintptr_t)b_planes) & 15) == 0 && ((uintptr_t)M & 3) == 0 && ldo >= Cout, "gemm_bf3q: alignment / pitch");
-    Bf3pArgs a;
-    a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = M;
-    a.T = (int)T; a.Cout = Cout; a.nchunks = CinPad / KC;
-    const int CoutPad = cdiv(Cout, 128) * 128;
-    a.tilesN = CoutPad / 128;
-    a.az = (size_t)T * CinPad * 4; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo; a.rz = 0;
-    a.ldo = ldo; a.ldr = 0; a.bias = nullptr; a.res = nullptr;
-    a.ksplits = 1; a.kps = a.nchunks; a.P = batch; a.batch = batch;
-    a.by_batch = batch >= 8 ? 1 : 0;
-    hipStream_t st = (hipStream_t)stream;
-    const int rc = CoutPad % 256 == 0 ? bf3q_launch<3, 4, false, true>(a, (const float*)a_units, 0, batch, st)
-                                      : bf3q_launch<3, 2, false, true>(a, (const float*)a_units, 0, batch, st);
-    if (rc != BBDM_OK) return rc;
-    BBDM_CHECK_LAUNCH("gemm_bf3q");
     return BBDM_OK;
 }

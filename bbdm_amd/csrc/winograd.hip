@@ -454,9 +454,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                                                                               unsigned T, int TG, size_t plane,
                                                                               unsigned char* __restrict__ Vt, size_t plane_t,
                                                                               int tchunks, const FastDiv dTW, const FastDiv dTH,
-                                                                              const FastDiv dCH, int out32) {
-    // out32: write V as fp32 row units (gemm_bf3q_pipe_kernel: 4 B per element, split by the GEMM's waves between their MFMAs) instead
-    // of the three bf16 planes; `plane` is then the byte size of an fp32 transform point
+                                                                              const FastDiv dCH) {
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
     const unsigned L = blockIdx.x, q = L >> 3;
@@ -530,17 +528,6 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
         for (int jj = 0; jj < AL; ++jj) t[jj] = lds[(i * AL + jj) * 64 + lane];
         bt_transform<MO>(t, row);
         const int g = (int)(tile >> 5), rl = (int)(tile & 31);
-        if (!TR && out32) {
-            // fp32 row unit: element (r, k) at byte (k >> 3) * 1024 + r * 32 + (k & 7) * 4, k = 2 cp: a wave writes rows 8 w .. 8 w + 7 of
-            // both k-halves = two runs of 256 contiguous bytes per transform point
-            unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 2048 + (cp >> 2) * 1024 + rl * 32 + (cp & 3) * 8;
-#pragma unroll
-            for (int jj = 0; jj < AL; ++jj) {
-                *reinterpret_cast<float2*>(o) = row[jj];
-                o += plane;
-            }
-            return;
-        }
         // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
         unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
         unsigned pl[AL][3];
@@ -1094,7 +1081,7 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 // bbdm_gemm_bf3p_a_bytes((m+2)^2, tiles, CinPad) bytes; CinPad a multiple of 16), and the tile GEMMs on them: b_planes =
 // bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
-                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream, int out32 = 0) {
+                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
@@ -1106,14 +1093,13 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
                  "winograd_input_bf3p: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const int nchunks = CinPad / KC, RG = (int)(Tp / 32), TG = (int)(Tp / 8);
-    const size_t plane = Tp * (size_t)CinPad * (out32 ? 4 : 6);    // bytes of one transform point
+    const size_t plane = Tp * (size_t)CinPad * 6;                  // bytes of one transform point
     const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * 6;       // ... of the transposed copy (whole 32-channel row groups)
     BBDM_REQUIRE(!Vt || (!upsample && ((uintptr_t)Vt & 15) == 0), "winograd_input_bf3p: the transposed copy needs upsample = 0, 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
     // BBDM_WINO_INPUT_LDS=0: the one-thread-per-window kernel (A/B; see winograd_input_split2_kernel)
     static const int two_phase = [] { const char* e = getenv("BBDM_WINO_INPUT_LDS"); return e ? atoi(e) : 1; }();
-    BBDM_REQUIRE(!out32 || !Vt, "winograd_input: the fp32 row units have no transposed copy");
-    if (two_phase || Vt || out32) {
+    if (two_phase || Vt) {
         const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
         BBDM_REQUIRE(blocks < (1ll << 31) && Tp < (1ull << 31), "winograd_input_bf3p: too many workgroups / tiles");
         const dim3 g((unsigned)blocks);
@@ -1128,7 +1114,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_I(MO, PRE, UP, TR, I64)                                                                                    \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
                        pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, (unsigned char*)Vt,   \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, out32)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH)
 #define BBDM_WINO_INS2(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_I(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_I(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_M(MO)                                                                        \
     do {                                                                                            \
@@ -1165,24 +1151,6 @@ extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void
                                             const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
                                             int CinPad, void* stream) {
     return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream);
-}
-
-// The same input transform writing V as fp32 ROW UNITS (4 B per element; csrc/gemm_bf3p.hip: gemm_bf3q_pipe_kernel splits them
-// between its MFMAs), and the tile GEMMs on them.  Vf holds bbdm_gemm_bf3q_a_bytes((m+2)^2, bbdm_winograd_tiles(...), CinPad) bytes;
-// b_planes as for bbdm_winograd_gemm_bf3p_f32.
-extern "C" int bbdm_winograd_input_bf3q_f32(int m, const float* x, int ldx, void* Vf, const float* pre_scale,
-                                            const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
-                                            int CinPad, void* stream) {
-    return winograd_input_planes(m, x, ldx, Vf, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream, 1);
-}
-extern "C" int bbdm_gemm_bf3q_f32(const void* a_units, const void* b_planes, float* M, int ldo, int batch, long long T, int CinPad,
-                                  int Cout, void* stream);
-extern "C" int bbdm_winograd_gemm_bf3q_f32(int m, const void* Vf, const void* b_planes, float* M, int N, int H, int W, int CinPad,
-                                           int Cout, void* stream) {
-    BBDM_WINO_M(m);
-    BBDM_REQUIRE(Vf && b_planes && M && N > 0, "winograd_gemm_bf3q: null pointer / bad N");
-    BBDM_WINO_HW(m, H, W);
-    return bbdm_gemm_bf3q_f32(Vf, b_planes, M, Cout, planes(m), (long long)tiles_padded(N, H, W, m), CinPad, Cout, stream);
 }
 
 // ... and, for the training forward, ALSO the transposed planes Vt (bbdm_gemm_bf3p_tn_at_bytes((m+2)^2, tiles, CinPad) bytes): the A

@@ -53,7 +53,6 @@ class _Flags:
         self.fuse_stats = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
         self.bf3_min_tiles = 256
         self.conv1x1_pipe = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
-        self.gemm_bf3q = int(os.environ.get("BBDM_GEMM_BF3Q", "0"))
         self.winograd_wgrad = 0             # (inference plans only)
         self.hip_graph = False
         self.op_profile = None

@@ -427,9 +427,9 @@ class _PackedWinograd:
         self.out_ch = self.cin if dgrad else (4 * self.cout if phases else self.cout)
         n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
         # (the planes of gemm_bf3p.hip are written directly from the weights: no fp32 G g G^T tensor -- 4x the weights at m = 4 -- is kept)
-        self.fused_planes = bf3 in ("p", "q") and not phases and in_pad % 16 == 0
+        self.fused_planes = bf3 == "p" and not phases and in_pad % 16 == 0
         self.packed_f32 = None if self.fused_planes else torch.empty(n, dtype=torch.float32, device=weight.device)
-        if bf3 in ("p", "q"):
+        if bf3 == "p":
             self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes((m + 2) ** 2, in_pad, self.out_ch), dtype=torch.uint8,
                                       device=weight.device)
         elif bf3:
@@ -460,21 +460,9 @@ class _PackedWinograd:
                 _lib.call("bbdm_winograd_pack_weight_f32", self.m, w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                           self.in_pad, 1 if self.dgrad else 0, stream)
             if self.bf3:
-                _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 in ("p", "q") else "bbdm_gemm_bf3_pack_f32",
+                _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 == "p" else "bbdm_gemm_bf3_pack_f32",
                           self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2, self.in_pad, self.out_ch, stream)
             self.key = key
-
-
-def _parse_partition(spec: str) -> Dict[int, int]:
-    """"64" or "64,65536:96,4096:32" -> {0: 64, 65536: 96, 4096: 32} (pixels per image of a UNet level -> CUs of the streaming
-    partition; 0 = default)."""
-    out: Dict[int, int] = {}
-    for part in spec.split(","):
-        k, _, v = part.strip().rpartition(":")
-        out[int(k) if k else 0] = int(v)
-    if 0 not in out:
-        raise ValueError(f"dual partition spec {spec!r} has no default entry")
-    return out
 
 
 def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True) -> int:
@@ -668,27 +656,12 @@ class UNetModel(nn.Module):
         # wide 1x1 layers whose Cout fills 256-column tiles on the pipelined fp32-A kernel (gemm_bf3q_pipe_kernel); BBDM_CONV1X1_PIPE=0:
         # gemm_bf3.hip everywhere (A/B; bit-equal results)
         self.conv1x1_pipe: bool = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
-        # Winograd layers of inference plans on fp32 row units of V + gemm_bf3q_pipe_kernel (see _Plan._use_bf3): 0 (default) = planes
-        # everywhere; 1 = where the per-layer micro-benchmark says the input transform gains more than the GEMM loses (Cout <= 512);
-        # 2 = every layer whose Cout fills 256-column tiles.  Inside the C2 step (profiles/r03_bf3q_bench.txt): 1 is a wash (input
-        # transforms -1.6 ms, tile GEMMs +1.6 ms), 2 loses 2.5 ms.  BBDM_GEMM_BF3Q.
-        self.gemm_bf3q: int = int(os.environ.get("BBDM_GEMM_BF3Q", "0"))
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
         # Training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
         # BBDM_WINOGRAD_WGRAD=0: the direct kernel (conv_wgrad.hip) everywhere.
         self.winograd_wgrad: int = int(os.environ.get("BBDM_WINOGRAD_WGRAD", "6"))
-        # A batch as two half-batch chains whose HBM-bound and MFMA-bound launches overlap on CU-partitioned streams (`_DualPlan`).
-        # OFF by default: measured on the C2 step (profiles/r03_partition_probe.txt) every static split LOSES -- the transforms are
-        # VALU-issue bound, not HBM bound (a quarter of the CUs takes 2.4x as long), and the chip's power budget is shared (both streams
-        # together run slower than the slower one alone): 149 ms (64 : 192 CUs) / 141 ms (96 : 160) against 115 ms on one stream.
-        # True / BBDM_DUAL_CHAIN=1 forces it (kept as a tested scheduling mode and for A/B runs on other parts).
-        # dual_partition: CUs (a multiple of 8: that many / 8 on every XCD) of the streaming partition, per UNet level -- key = pixels
-        # per image of the level, 0 = every other level.  BBDM_DUAL_T="64" or "64,65536:96,4096:32".
-        dc = os.environ.get("BBDM_DUAL_CHAIN")
-        self.dual_chain: Optional[bool] = dc == "1"
-        self.dual_partition: Dict[int, int] = _parse_partition(os.environ.get("BBDM_DUAL_T", "64"))
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -736,36 +709,18 @@ class UNetModel(nn.Module):
         t = timesteps.to(device=x.device, dtype=torch.int64).contiguous()
         return plan.run(x, t, ctx, out, borrow)
 
-    def _wants_dual(self, N: int, H: int, W: int, device, training: bool) -> bool:
-        """Run this batch as two half-batch chains over CU-partitioned streams (`_DualPlan`)?  Inference only, on request
-        (``dual_chain`` True; None = automatic from 2^19 pixels per batch up), where the device accepts CU masks."""
-        if training or N < 2 or N % 2 or self.dual_chain is False:
-            return False
-        if self.dual_chain is None and (device.type != "cuda" or N * H * W < (1 << 19)):
-            return False
-        try:
-            for t in set(self.dual_partition.values()):
-                _lib.partition_streams(device, t)
-        except _lib.BBDMHipError:
-            if self.dual_chain:
-                raise
-            return False
-        return True
-
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
-        dual = self._wants_dual(N, H, W, x.device, training)
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small, self.upsample_phases, dual and tuple(sorted(self.dual_partition.items())), self.conv1x1_pipe, self.gemm_bf3q)
+               self.winograd_small, self.upsample_phases, self.conv1x1_pipe)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
             # few shapes a run alternates between (train batch, validation batch, the runner's 4-image sample), drop the rest
             while len(self._plans) >= self.max_cached_plans:
                 self._plans.pop(next(iter(self._plans)))
-            plan = (_DualPlan(self, N, H, W, x.device, x.shape[1]) if dual else
-                    _Plan(self, N, H, W, x.device, x.shape[1], training=training))
+            plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
         self._plans[key] = plan                       # most recently used last
         return plan
 
@@ -827,8 +782,6 @@ class _Plan:
         # consumer can ask the producer to accumulate its statistics (bbdm_*_stats_f32) instead of re-reading the tensor
         self._writers: Dict[tuple, dict] = {}
         self.fused_stats = 0
-        self._packed_cache: Optional[dict] = None    # packed weights shared with a sibling plan (_DualPlan's two halves)
-        self.op_hw: List[int] = []                   # per op: pixels per image of the largest activation it touches (its UNet level)
 
     def _allocate(self):
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -847,11 +800,8 @@ class _Plan:
         self._graph, self._graph_key = None, None
         self.op_flops = [self._algorithmic_flops(name, args) for name, args in self.ops]
 
-    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int, training: bool = False, io=None, packed=None):
-        """``io`` = (x_in, ctx_in, out_nchw): input / output tensors owned by the caller (a _DualPlan hands each half its slice of the
-        batch); ``packed``: a dict through which sibling plans share one packed copy per weight."""
+    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int, training: bool = False):
         self._init_state(m, N, device, training)
-        self._packed_cache = packed
         self.H, self.W, self.cx = H, W, cx
         mc = m.model_channels
         ted = 4 * mc
@@ -880,12 +830,9 @@ class _Plan:
         # ---- input / output --------------------------------------------------------------------------------------
         cin = m.in_channels
         cpad = _round4(cin)
-        if io is not None:
-            self.x_in, self.ctx_in, self.out_nchw = io
-        else:
-            self.x_in = torch.empty(N, cx, H, W, **f32)
-            self.ctx_in = torch.empty(N, cin - cx, H, W, **f32) if cin > cx else None
-            self.out_nchw = torch.empty(N, m.out_channels, H, W, **f32)
+        self.x_in = torch.empty(N, cx, H, W, **f32)
+        self.ctx_in = torch.empty(N, cin - cx, H, W, **f32) if cin > cx else None
+        self.out_nchw = torch.empty(N, m.out_channels, H, W, **f32)
         x0 = self._new(N, H, W, cpad)
         self._op("bbdm_nchw_to_nhwc_f32", _TensorRef(self.x_in), cx,
                  _TensorRef(self.ctx_in) if self.ctx_in is not None else None, cin - cx, x0, x0.ld, cpad, N, H, W)
@@ -1034,21 +981,10 @@ class _Plan:
     def _op(self, name, *args):
         rec = (name, list(args))          # a list: a later consumer may patch statistics targets into its producer
         self.ops.append(rec)
-        hw = [a.H * a.W for a in args if isinstance(a, _View)]
-        self.op_hw.append(max(hw) if hw else (self.op_hw[-1] if self.op_hw else 0))     # (tile GEMMs: the level of their input transform)
         return rec
 
     def _packed(self, cls, weight, *args, **kw):
-        """``cls(weight, *args, **kw)`` -- one object per (weight, layout) among the plans that share ``_packed_cache``."""
-        cache = self._packed_cache
-        if cache is None:
-            return cls(weight, *args, **kw)
-        key = (cls.__name__, id(weight)) + tuple(id(a) if isinstance(a, torch.Tensor) else a for a in args) + \
-            tuple(sorted(kw.items()))
-        obj = cache.get(key)
-        if obj is None:
-            obj = cache[key] = cls(weight, *args, **kw)
-        return obj
+        return cls(weight, *args, **kw)
 
     def _conv(self, mod, cin_pad) -> _PackedConv:
         pc = self._packed(_PackedConv, mod.weight, mod.bias, cin_pad)
@@ -1166,21 +1102,14 @@ class _Plan:
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
         split while staged), "p" = csrc/gemm_bf3p.hip (V written pre-split by the input transform; with ``keeps_V`` -- the training
-        backward contracts this layer's V again -- only where the weight-gradient GEMM takes the transposed planes too), "q" = the
-        same file's gemm_bf3q_pipe_kernel on fp32 row units of V (4 B per element instead of 6: the input transform is bound by its
-        HBM writes; the kernel runs at 0.93 - 1.0 of the plane kernel's rate) -- where the transform's gain outweighs the GEMM's loss:
-        measured per layer (profiles/r03_bf3q_bench.txt), the transform saves 2 B x Cin per tile and point, i.e. a share of the GEMM's
-        time that only depends on Cout (Cout 512: 6 - 11 %, Cout 1024: 3 - 4 %) against a GEMM loss of 4 - 8 %."""
+        backward contracts this layer's V again -- only where the weight-gradient GEMM takes the transposed planes too).  (Round 3
+        also measured V as fp32 row units split by the GEMM's own waves, 4 B per element instead of 6: the input transforms gain what
+        the tile GEMMs lose, profiles/r03_bf3q_bench.txt; that mode is gone.)"""
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
         if self.m.gemm_bf3p and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout) and \
                 (not keeps_V or self.lib.bbdm_gemm_bf3p_tn_supported(tiles, cin_pad, cout)):
-            cpad = -(-cout // 128) * 128
-            mode = self.m.gemm_bf3q
-            if (not self.training and wm == 6 and cpad % 256 == 0 and tiles >= 1024 and
-                    (mode == 2 or (mode == 1 and cpad <= 512))):
-                return "q"
             return "p"          # (keeps_V: the weight gradient then contracts the TRANSPOSED planes the input transform also writes)
         return bool(self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout))
 
@@ -1200,7 +1129,6 @@ class _Plan:
             flags |= 8
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
-        units = pw.bf3 == "q"          # V as fp32 row units (4 B per element), split by the GEMM's waves
         self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
         # small layers: split-K tile GEMMs, the partial sums M[z] are added by the output transform (csrc/gemm_bf3p.hip: fwd_splits)
         ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if (split and not pw.phases) else 1
@@ -1224,15 +1152,13 @@ class _Plan:
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_tr_f32"), wm, x, x.ld, vbuf,
                  *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt)
         else:
-            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else
-                         "bbdm_winograd_input_bf3q_f32" if units else "bbdm_winograd_input_f32"),
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
                  wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
         if ksplit > 1:
             emit(_OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_splitk_f32"), wm, vbuf, _TensorRef(pw.packed),
                  self._wino_m, N, H, W, cin_pad, cout, ksplit)
         else:
             gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
-                           "bbdm_winograd_gemm_bf3q_f32" if units else
                            "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
             emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
         ks_tail = (ksplit,) if ksplit > 1 else ()
@@ -2169,194 +2095,6 @@ class _Plan:
                 self._graph.replay()
         else:
             self._launch_forward(stream, prof)
-        if out is None:
-            return self.out_nchw if borrow else self.out_nchw.clone()
-        out.copy_(self.out_nchw)
-        return out
-
-
-# --------------------------------------------------------------------------------------------------------------
-# two half-batch chains over CU-partitioned streams
-# --------------------------------------------------------------------------------------------------------------
-class _DualPlan:
-    """One forward of a batch as TWO chains -- the two halves of the batch -- over streams that own disjoint compute units.
-
-    A sampling step alternates MFMA-bound launches (Winograd tile GEMMs, 1x1 GEMMs, attention) with HBM-bound ones (Winograd
-    transforms, GroupNorm passes).  Run one after the other on the whole chip, each kind leaves the other resource idle -- and the
-    matrix kernels are partly POWER-bound (profiles/r03_gemm_cu_partition_probe.txt), so the CUs they give up cost them less than
-    their share.  Images are independent through the whole UNet (GroupNorm statistics are per image; the reference's batch is just a
-    leading dimension, openaimodel.py:744-759), so the batch is cut in two halves with a plan each (`_Plan` for N / 2: own
-    activations, statistics and Winograd scratch; packed weights shared), and every op goes to one of two streams by what bounds it:
-    "G" (matrix) or "T" (streaming).  The streams are CU partitions (csrc/runtime.hip: t CUs of every XCD for T, the rest for G), so a
-    half's transforms stream through HBM on their CUs while the other half's GEMMs keep the matrix cores of theirs busy.  A chain is
-    totally ordered: consecutive ops of a half on different streams are linked by an event, so each half computes exactly what its
-    one-stream plan computes.  The issue order interleaves the chains segment by segment (a segment = a run of T ops followed by a
-    run of G ops): T sees T_A(k), T_B(k), T_A(k+1), ... and G sees G_A(k), G_B(k), ..., i.e. while G works on A's layer k the T
-    stream prepares B's layer k, then A's layer k + 1 -- neither stream waits as long as a half's T segment is shorter than the
-    other half's G segment.
-    The split t may differ per UNet level (``UNetModel.dual_partition``: the 256^2 level with its 128-channel layers is
-    transform-heavy, the 64^2 level with 1024 channels GEMM-heavy); a chain that moves to another level's streams is linked by the
-    same events."""
-
-    MATRIX_OPS = ("bbdm_winograd_gemm_f32", "bbdm_conv1x1_bf3_f32", "bbdm_attention_f32", "bbdm_cross_attention_f32")
-    training = False
-
-    def __init__(self, m: UNetModel, N: int, H: int, W: int, device, cx: int):
-        assert N >= 2
-        self.m, self.N, self.H, self.W, self.cx, self.device = m, N, H, W, cx, device
-        f32 = dict(dtype=torch.float32, device=device)
-        cin = m.in_channels
-        self.x_in = torch.empty(N, cx, H, W, **f32)
-        self.ctx_in = torch.empty(N, cin - cx, H, W, **f32) if cin > cx else None
-        self.out_nchw = torch.empty(N, m.out_channels, H, W, **f32)
-        self.t_buf = torch.zeros(N, dtype=torch.int64, device=device)
-        n0 = N // 2
-        shared: dict = {}
-        self.halves: List[_Plan] = []
-        self.bounds = ((0, n0), (n0, N))
-        for a, b in self.bounds:
-            io = (self.x_in[a:b], self.ctx_in[a:b] if self.ctx_in is not None else None, self.out_nchw[a:b])
-            self.halves.append(_Plan(m, b - a, H, W, device, cx, training=False, io=io, packed=shared))
-        self.sync = device.type == "cuda"
-        self._partition = dict(m.dual_partition)
-        self._schedule()
-        self.generation = 0
-
-    # ---- what the tests / bench.py read from a plan --------------------------------------------------------------------------------
-    @property
-    def ops(self):
-        """The op records in ISSUE order (both halves)."""
-        return [self.halves[h].ops[k] for h, k, _ in self.order]
-
-    @property
-    def op_flops(self):
-        return [self.halves[h].op_flops[k] for h, k, _ in self.order]
-
-    @property
-    def fused_stats(self):
-        return self.halves[0].fused_stats
-
-    def activation_bytes(self):
-        return sum(p.activation_bytes() for p in self.halves)
-
-    def _want_graph(self) -> bool:
-        return False            # (a captured graph replays on ONE stream: the CU partitions would be lost)
-
-    # ---- schedule --------------------------------------------------------------------------------------------------------------
-    def _is_matrix(self, name, args) -> bool:
-        if name in self.MATRIX_OPS:
-            return True
-        # direct convolutions: MFMA-bound, except the few-channel head (one thread per pixel, HBM-bound: conv3x3_narrow_kernel)
-        return name == "bbdm_conv2d_nhwc_f32" and args[19] > 8
-
-    def _split_for(self, hw: int) -> int:
-        p = self._partition
-        return int(p.get(hw, p.get(0)))
-
-    def _schedule(self):
-        chains = []
-        for h, plan in enumerate(self.halves):
-            segs, cur, last = [], [], None
-            for k, (name, args) in enumerate(plan.ops):
-                cls = "G" if self._is_matrix(name, args) else "T"
-                if cls == "T" and last == "G":
-                    segs.append(cur)
-                    cur = []
-                cur.append((h, k, cls))
-                last = cls
-            segs.append(cur)
-            chains.append(segs)
-        self.order = []
-        for i in range(max(len(c) for c in chains)):
-            for c in chains:
-                if i < len(c):
-                    self.order.extend(c[i])
-        # streams per op; an event wherever a chain changes stream
-        self._splits = sorted({self._split_for(hw) for plan in self.halves for hw in plan.op_hw})
-        self._stream_key = [(self._split_for(self.halves[h].op_hw[k]), cls) for h, k, cls in self.order]
-        prev = {}                           # half -> index (in self.order) of its previous op
-        self._wait_on = [None] * len(self.order)      # index of the op whose completion event this op waits for
-        self._records = [False] * len(self.order)
-        for i, (h, k, cls) in enumerate(self.order):
-            j = prev.get(h)
-            if j is not None and self._stream_key[j] != self._stream_key[i]:
-                self._wait_on[i] = j
-                self._records[j] = True
-            prev[h] = i
-        self._last = dict(prev)
-        self._first = {}
-        for i, (h, k, cls) in enumerate(self.order):
-            self._first.setdefault(h, i)
-        self._events = None
-
-    def _streams(self):
-        """(split, class) -> (torch stream or None, raw handle or None)."""
-        out = {}
-        for t in self._splits:
-            (st, ht), (sg, hg) = _lib.partition_streams(self.device, t)
-            out[(t, "T")], out[(t, "G")] = (st, ht), (sg, hg)
-        return out
-
-    # ---- execution ---------------------------------------------------------------------------------------------------------------
-    def run(self, x, t, ctx, out=None, borrow=False):
-        with _lib.device_guard(self.device):
-            return self._run(x, t, ctx, out, borrow)
-
-    def _run(self, x, t, ctx, out=None, borrow=False):
-        m = self.m
-        self.generation += 1
-        cur_stream = _lib.current_stream(self.device)
-        for plan in self.halves:
-            plan._refresh_weights(cur_stream)
-        self.x_in.copy_(x)
-        if self.ctx_in is not None:
-            self.ctx_in.copy_(ctx)
-        self.t_buf.copy_(t)
-        for plan, (a, b) in zip(self.halves, self.bounds):
-            plan.t_buf.copy_(self.t_buf[a:b])
-        streams = self._streams()
-        sync = self.sync
-        prof = m.op_profile
-        if sync:
-            cur = torch.cuda.current_stream(self.device)
-            if self._events is None:
-                self._events = [torch.cuda.Event() if r else None for r in self._records]
-                self._ev_start = torch.cuda.Event()
-                self._ev_end = [torch.cuda.Event() for _ in self.halves]
-            self._ev_start.record(cur)
-        # prologues (statistics reset, embedding path) on the stream of each chain's first op
-        for h, plan in enumerate(self.halves):
-            s_obj, s_h = streams[self._stream_key[self._first[h]]]
-            if sync:
-                s_obj.wait_event(self._ev_start)
-                with torch.cuda.stream(s_obj):
-                    plan._launch_embedding(s_h)
-            else:
-                plan._launch_embedding(s_h)
-        check = _lib.check
-        bound = [plan._bound for plan in self.halves]
-        for i, (h, k, cls) in enumerate(self.order):
-            fn, args = bound[h][k]
-            s_obj, s_h = streams[self._stream_key[i]]
-            if sync and self._wait_on[i] is not None:
-                s_obj.wait_event(self._events[self._wait_on[i]])
-            if prof is None or not sync:
-                rc = fn(*args, s_h)
-            else:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(s_obj)
-                rc = fn(*args, s_h)
-                e1.record(s_obj)
-                prof.append((self.halves[h]._bound_names[k], e0, e1, self.halves[h].op_flops[k]))
-            if rc != 0:
-                check(rc, fn.__name__)
-            if sync and self._records[i]:
-                self._events[i].record(s_obj)
-        if sync:
-            for h in range(len(self.halves)):
-                s_obj, _ = streams[self._stream_key[self._last[h]]]
-                self._ev_end[h].record(s_obj)
-                cur.wait_event(self._ev_end[h])
         if out is None:
             return self.out_nchw if borrow else self.out_nchw.clone()
         out.copy_(self.out_nchw)

@@ -181,6 +181,22 @@ def _time_cpu_steps(path, x_t, y, ctx, eps, n_timed, i0=1):
     return ts[len(ts) // 2], ts
 
 
+def _parity_record(g_a, g_b, a_ref, b_ref, i_par, kind):
+    """Both metrics of SURVEY.md §8c on image 0 of the benchmarked batch (every `rel_err*` entry is held against `bar`)."""
+    def rel(a, b):
+        a, b = a.double().cpu(), b.double()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+    def l2(a, b):
+        a, b = a.double().cpu(), b.double()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+    return {"rel_err_x_tminus": rel(g_a, a_ref[0]), "rel_err_x0_recon": rel(g_b, b_ref[0]),
+            "rel_err_l2_x_tminus": l2(g_a, a_ref[0]), "rel_err_l2_x0_recon": l2(g_b, b_ref[0]), "bar": 1e-3,
+            "metric": "max|gpu - cpu| / max|cpu| and ||gpu - cpu||_2 / ||cpu||_2 (rel_err_l2_*) on image 0 of the benchmarked batch, "
+                      f"one p_sample step (schedule index {i_par}), same weights / inputs / step noise",
+            "against": kind}
+
+
 def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
     """the reference's CPU path (imported from /root/reference when mounted -> kind "reference", else
     the validated restatement oracle/bbdm_oracle.py -> kind "port") timed on this box's host cores.
@@ -207,13 +223,7 @@ def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
     a_ref, b_ref = path.p_sample(x_t, y, ctx, i_par, eps)
     warm = time.perf_counter() - t0
     if parity_inputs is not None:
-        def rel(a, b):
-            a, b = a.double().cpu(), b.double()
-            return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-        parity = {"rel_err_x_tminus": rel(g_a, a_ref[0]), "rel_err_x0_recon": rel(g_b, b_ref[0]), "bar": 1e-3,
-                  "metric": "max|gpu - cpu| / max|cpu| on image 0 of the benchmarked batch, one p_sample step "
-                            f"(schedule index {i_par}), same weights / inputs / step noise",
-                  "against": path.kind}
+        parity = _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
     n_timed = max(3, min(20, int((budget_s - warm) / max(warm, 1e-3))))
     med, ts = _time_cpu_steps(path, x_t, y, ctx, eps, n_timed)
     out = {"value": 1.0 / (med * batch), "unit": "steps/s", "cores": threads, "kind": path.kind,
@@ -228,10 +238,20 @@ def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
         x1, y1 = make_inputs(batch1, ch1, size1)
         e1 = torch.randn(x1.shape, generator=torch.Generator().manual_seed(98))
         p1.p_sample(x1, y1, y1, 0, e1)
+        # a 64x64 batch-4 step is small: all host threads oversubscribe it (round 3: 2.70 s on 128 threads of a 256-CPU box against
+        # 1.5 s on 8 cores at survey time).  One step per candidate thread count, the 5 timed steps at the best one.
+        sweep = {}
+        for nt in sorted({t for t in (8, 16, 32, 64, 128, threads) if 1 <= t <= (os.cpu_count() or 1)}):
+            torch.set_num_threads(nt)
+            sweep[nt] = _time_cpu_steps(p1, x1, y1, y1, e1, 1)[0]
+        best_nt = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_nt)
         med1, ts1 = _time_cpu_steps(p1, x1, y1, y1, e1, 5)
+        torch.set_num_threads(threads)
         out["c1_exact"] = {"config": d1, "s_per_step_median": med1, "steps_per_s": 1.0 / med1,
                            "img_steps_per_s": batch1 / med1, "full_1000_step_sample_min": 1000 * med1 / 60.0,
-                           "timed_steps": 5, "warmup": 1, "kind": p1.kind}
+                           "timed_steps": 5, "warmup": 1, "kind": p1.kind, "threads": best_nt,
+                           "thread_sweep_s_per_step": {str(k): v for k, v in sweep.items()}}
     return out, parity
 
 
@@ -243,14 +263,7 @@ def parity_only(workload, sd, parity_inputs):
     x_t, y, eps = x_t[:1].cpu(), y[:1].cpu(), eps[:1].cpu()
     ctx = None if up["condition_key"] == "nocond" else y
     a_ref, b_ref = path.p_sample(x_t, y, ctx, i_par, eps)
-
-    def rel(a, b):
-        a, b = a.double().cpu(), b.double()
-        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
-    return {"rel_err_x_tminus": rel(g_a, a_ref[0]), "rel_err_x0_recon": rel(g_b, b_ref[0]), "bar": 1e-3,
-            "metric": "max|gpu - cpu| / max|cpu| on image 0 of the benchmarked batch, one p_sample step "
-                      f"(schedule index {i_par}), same weights / inputs / step noise",
-            "against": path.kind}
+    return _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
 
 
 def training_parity(model, sd, up, skip, sstep, x0, y, dev):
@@ -304,7 +317,7 @@ def training_parity(model, sd, up, skip, sstep, x0, y, dev):
             "against": "port (oracle autograd)", "cpu_seconds": secs}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)      # >= 20 steps after 3 warm-ups
@@ -321,7 +334,17 @@ def main():
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
     ap.add_argument("--no-f32mfma", action="store_true", help="c2: skip the strict-f32-MFMA A/B steps after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked batch against the oracle")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true",
+                    help="headline run (c2, one GPU): do not time the other BASELINE.json configs (c1, c3, c5, c4) after it")
+    return ap.parse_args(argv)
+
+
+# the other BASELINE.json configs, timed after the headline in the default run: (workload, warm-up, timed steps)
+EXTRA_WORKLOADS = (("c1", 5, 20), ("c3", 5, 20), ("c5", 5, 20), ("c4", 1, 8))
+
+
+def main():
+    args = parse_args()
 
     if args.cpu_only:                      # build-container check of the cpu_baseline leg (no GPU needed)
         import bbdm_amd
@@ -346,7 +369,39 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = dist_utils.init(backend="nccl")      # RCCL over xGMI; None when single-process
+    env = (rank, local_rank, world, dev, dist)
 
+    line = run_workload(args, env)
+    # The default run (`python bench.py --gpus 1`) also times the other four BASELINE.json configs after the headline, so that every
+    # configuration's step time, whole-step roofline fraction and parity sample are in the ONE line the driver records (they were
+    # builder-run numbers in rounds 1-3).  Same code path as `--workload cN`; the cpu_baseline timing leg is the headline's only.
+    if args.workload == "c2" and world == 1 and not args.no_extras and line is not None:
+        line["workloads"] = {}
+        for w, wu, st in EXTRA_WORKLOADS:
+            torch.cuda.empty_cache()
+            sub = argparse.Namespace(**vars(args))
+            sub.workload, sub.warmup, sub.steps, sub.no_cpu, sub.dump_ops = w, wu, st, True, None
+            t0 = time.perf_counter()
+            r = run_workload(sub, env)
+            line["workloads"][w] = {
+                "config": r["config"]["workload"], "metric": r["metric"], "value": r["value"], "unit": r["unit"],
+                "ms_per_step": r["ms_per_step"], "steps": st, "warmup": wu, "prime_steps": r["prime_steps"],
+                "hip_graph": r["hip_graph"], "frac_step": r["roofline"]["frac_step"],
+                "dominant_kernel_frac": r["roofline"]["frac"], "dominant_kernel_tflops": r["roofline"]["achieved"],
+                "kernel_ms_per_step": r["kernel_ms_per_step"], "parity": r["parity"], "pipeline": r.get("pipeline"),
+                "training": r.get("training"), "wall_s": time.perf_counter() - t0}
+    if rank == 0 and line is not None:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_workload(args, env):
+    """Time one workload on this rank's GPU; rank 0 returns the record (the JSON line of `--workload <name>`), other ranks None."""
+    import bbdm_amd
+    from bbdm_amd import dist_utils
+    rank, local_rank, world, dev, dist = env
     desc, up, ch, size, batch, skip, sstep = WORKLOADS[args.workload]
     cfg = _ns({"BB": {"params": dict(BB, skip_sample=skip, sample_step=sstep, UNetParams=up)}})
     model = bbdm_amd.BrownianBridgeModel(cfg)
@@ -383,19 +438,24 @@ def main():
             ema = EMA(0.995)
             ema.register(model)
 
+        sync_every = [bool(args.sync_every_micro_step)]      # (flipped for the A/B pass after the timed region when world > 1)
+        opt_events = []                                       # HIP events around optimizer.step() + zero_grad() of the timed steps
+
         def step(i, img):
             gstep = i + 1                                     # the runner's 1-based global_step
-            ctx_mgr = (dist_utils.accumulation_sync(net, gstep, accumulate) if not args.sync_every_micro_step
-                       else dist_utils.accumulation_sync(net, gstep, 1))
-            with ctx_mgr:
+            with dist_utils.accumulation_sync(net, gstep, 1 if sync_every[0] else accumulate):
                 loss, _ = net(x_t, y)
                 loss.backward()
             if gstep % accumulate == 0:
+                eo = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                eo[0].record()
                 if ema is not None and gstep % (ema_every * accumulate) == 0:
                     opt.step(ema=ema, ema_with_decay=False)   # before start_ema_step (30000): shadow = weights
                 else:
                     opt.step()
                 opt.zero_grad(set_to_none=True)
+                eo[1].record()
+                opt_events.append(eo)
             return loss.detach().reshape(1)
     else:
         def step(i, img):
@@ -417,12 +477,47 @@ def main():
     plan_graph = (not training) and next(iter(model.denoise_fn._plans.values()))._want_graph()
     model.denoise_fn.op_profile = None if (training or plan_graph) else prof
 
-    def timed():
+    marks = []          # training: a HIP event after every timed micro-step (boundary vs non-boundary step time, see `training` below)
+
+    def timed(collect=None):
+        if collect is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            collect.append((0, e))
         for i in range(args.steps):
             state["img"] = step(prime + args.warmup + i, state["img"])
+            if collect is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                collect.append((prime + args.warmup + i + 1, e))
 
     # barrier + synchronize on both sides, MAX over ranks (bbdm_amd/dist_utils.py)
-    elapsed = dist_utils.timed_region(timed, dist, dev)
+    if training:
+        opt_events.clear()
+    elapsed = dist_utils.timed_region((lambda: timed(marks)) if training else timed, dist, dev)
+    training_info = None
+    if training:
+        # Per-micro-step times from the events: the accumulation BOUNDARY micro-step carries the gradient all-reduce (DDP; the other
+        # micro-steps run under no_sync) and the optimizer step; what the all-reduce adds beyond the backward it overlaps is
+        # boundary - non-boundary - optimizer.  With --gpus N > 1 a second pass of the same K steps reduces on EVERY micro-step (the
+        # reference's behaviour, runners/BaseRunner.py:412-417) for the A/B.
+        durs = [(g, a.elapsed_time(b)) for (_, a), (g, b) in zip(marks[:-1], marks[1:])]
+        bnd = [d for g, d in durs if g % args.accumulate == 0]
+        non = [d for g, d in durs if g % args.accumulate != 0]
+        opt_ms = [a.elapsed_time(b) for a, b in opt_events]
+        mean = lambda v: (sum(v) / len(v)) if v else None
+        training_info = {"accumulate_grad_batches": args.accumulate,
+                         "gradient_sync": "every micro-step" if sync_every[0] else "accumulation boundary only (no_sync on the others)",
+                         "boundary_micro_step_ms": mean(bnd), "non_boundary_micro_step_ms": mean(non),
+                         "optimizer_step_ms": mean(opt_ms),
+                         "allreduce_exposed_ms": (mean(bnd) - mean(non) - (mean(opt_ms) or 0.0)) if (bnd and non and world > 1) else None,
+                         "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None}
+        if world > 1 and not sync_every[0]:
+            sync_every[0] = True
+            for i in range(args.accumulate):
+                state["img"] = step(prime + args.warmup + args.steps + i, state["img"])
+            training_info["sync_every_micro_step_ms_per_step"] = dist_utils.timed_region(timed, dist, dev) * 1e3 / args.steps
+            sync_every[0] = False
     eager_ms = None
     if plan_graph or training:
         # (training: the timed region is the plain product path as well; forward AND gradient-plan launches are timed here)
@@ -531,16 +626,14 @@ def main():
     # the GEMMs run on conv_igemm_f32 (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s) together with the direct convolutions.
     all_ops = list(plan0.ops) + (list(plan0.bops) if training else [])
     entries = [getattr(nm, "entry", "") for nm, _ in all_ops if nm == "bbdm_winograd_gemm_f32"]
-    bf3q_ops = sum(e.endswith("bf3q_f32") for e in entries)        # (the same file's kernel on fp32 row units of V)
-    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") for e in entries) + bf3q_ops, sum(e.endswith("bf3_f32") for e in entries)
+    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") for e in entries), sum(e.endswith("bf3_f32") for e in entries)
     use_bf3 = bf3p_ops + bf3_ops > 0
     if use_bf3:
         # the tile GEMMs run on csrc/gemm_bf3p.hip (both operands pre-split by their producers, LDS-DMA + MFMA main loop) where the
         # input transform writes the planes, else on csrc/gemm_bf3.hip (fp32 V split while staged): same arithmetic, bit for bit
         kname = ("gemm_bf3p_pipe_kernel" if bf3p_ops >= bf3_ops else "gemm_bf3_kernel")
         dom, dom_name = wino, (f"{kname} (v_mfma_f32_32x32x16_bf16 x 6 terms = one fp32-accurate product; {bf3p_ops} launches per "
-                               f"pass on gemm_bf3p.hip -- {bf3q_ops} of them on its fp32-operand kernel gemm_bf3q_pipe_kernel --, "
-                               f"{bf3_ops} on gemm_bf3)")
+                               f"pass on gemm_bf3p.hip, {bf3_ops} on gemm_bf3)")
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
     else:
         dom, dom_name, peak = conv, "conv_igemm_f32 (v_mfma_f32_32x32x2_f32)", PEAK_FP32_MFMA_TFLOPS
@@ -551,7 +644,14 @@ def main():
     achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
     # whole step against the matrix peaks: time-at-peak of every MFMA kernel's work / step time
     c1x1 = both("bbdm_conv1x1_bf3_f32")                             # wide 1x1 convs / Linears on the same bf16x3 kernel
-    bf3_flops = ((wino[2] if use_bf3 else 0.0) + c1x1[2]) / max(1, args.steps)
+    # the attention FORWARD issues v_mfma_f32_32x32x16_bf16 as well (csrc/attention.hip, BBDM_ATTN_BF3: 1 = Q K^T and P V -- head
+    # widths 32 / 64 --, 2 or head width 16 = only Q K^T, 0 = f32 MFMA): its FLOPs are priced at the peak of the datatype it issues
+    # (round 3 priced them at the f32 peak, which overstated frac_step by 4 points); the attention backward is on the f32 MFMA.
+    attn = by.get("bbdm_attention_f32", [0, 0.0, 0.0])
+    attn_mode = int(os.environ.get("BBDM_ATTN_BF3", "1"))
+    attn_ch = next((oa[8] for nm, oa in plan0.ops if nm == "bbdm_attention_f32"), 64)
+    attn_bf3_share = 0.0 if attn_mode == 0 else (1.0 if (attn_mode == 1 and attn_ch in (32, 64)) else 0.5)
+    bf3_flops = ((wino[2] if use_bf3 else 0.0) + c1x1[2] + attn_bf3_share * attn[2]) / max(1, args.steps)
     t_at_peak = (executed_flops_per_step - bf3_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
         bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12)
     # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
@@ -563,7 +663,7 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
-            hits = [v for k, v in pm["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3q_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in pm["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
             if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
                 nl = sum(v["launches"] for v in hits)
                 traffic = {"bytes_per_launch": sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in hits) / nl,
@@ -583,10 +683,14 @@ def main():
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_mfma_util.json")))
         if cands:
             mu = json.load(open(cands[-1]))
-            hits = [v for k, v in mu["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3q_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in mu["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for v in hits if v.get("MfmaUtil%") is not None]
             if hits:
-                best = max(hits, key=lambda v: v.get("launches", 0))
-                mfma_util = {"percent": best.get("MfmaUtil%"), "effective_clock_GHz": best.get("clock_GHz"),
+                wt = [v.get("launches", 0) * v.get("avg_us", 0.0) for v in hits]          # time each instantiation ran
+                tot_w = sum(wt) or 1.0
+                mfma_util = {"percent": sum(w * v["MfmaUtil%"] for w, v in zip(wt, hits)) / tot_w,
+                             "effective_clock_GHz": sum(w * (v.get("clock_GHz") or 0.0) for w, v in zip(wt, hits)) / tot_w,
+                             "weighting": "time-weighted over the kernel's instantiations",
                              "source": os.path.basename(cands[-1]),
                              "note": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): share of the kernel's cycles the "
                                      "matrix pipes are busy, at the clock the chip sustains under this load"}
@@ -608,18 +712,6 @@ def main():
     if traffic is not None and alg_n:
         traffic["algorithmic_bytes_per_launch"] = alg_bytes / alg_n
     ms_per_step = elapsed * 1e3 / args.steps
-    # two half-batch chains over CU-partitioned streams (bbdm_amd/unet.py: _DualPlan): the per-kernel times above are stream times of
-    # launches that run BESIDE launches of the other chain (their sum exceeds the step), and the dominant kernel's launches ran on
-    # the matrix partition's CUs only -- `frac` keeps the whole chip's peak as its denominator
-    dual_info = None
-    if hasattr(plan0, "halves"):
-        part = dict(model.denoise_fn.dual_partition)
-        dual_info = {"halves": [p.N for p in plan0.halves], "streaming_partition_cus": {("default" if k == 0 else f"{k} px/image"): v
-                                                                                           for k, v in sorted(part.items())},
-                     "device_cus": int(bbdm_amd._lib.load().bbdm_device_cus()),
-                     "note": "matrix launches (tile GEMMs, 1x1 GEMMs, attention) of one half of the batch run beside the streaming launches "
-                             "(Winograd transforms, GroupNorm) of the other half on disjoint CUs; kernel_ms_per_step are per-stream times "
-                             "and overlap"}
     devices = dist_utils.gather_device_info(dist, dev)          # per-rank device ids (+ RCCL version when world > 1)
     steps_per_s_job = dist_utils.aggregate_throughput(args.steps, elapsed, world)
 
@@ -653,8 +745,10 @@ def main():
                                       "fp32-input MFMA peak (MI355X_MICROARCH.md)",
                          "executed_bf16_tflops": 6.0 * achieved if use_bf3 else None,
                          "frac_step": t_at_peak / (ms_per_step * 1e-3),
-                         "frac_step_note": "whole step: time the MFMA work of every kernel would take at its matrix peak "
-                                           "(bf16x6 for the tile GEMMs, f32 MFMA for the rest) / step time",
+                         "frac_step_note": "whole step: time the MFMA work of every kernel would take at the matrix peak of the "
+                                           "datatype it issues (bf16 / 6 for the tile GEMMs, the wide 1x1 layers and the attention "
+                                           "forward; f32 MFMA for the rest) / step time",
+                         "attention_bf3_share": attn_bf3_share,
                          "traffic": traffic, "traffic_step": traffic_step, "mfma_util": mfma_util,
                          "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
@@ -667,8 +761,8 @@ def main():
                          "conv1x1_bf3_tflops": (c1x1[2] / (c1x1[1] * 1e-3) / 1e12) if c1x1[1] > 0 else None,
                          "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
-            "dual_chain": dual_info,
             "f32mfma_ms_per_step": f32mfma_ms,
+            "training": training_info,
         }
         if args.workload in FIRST_STAGE and not args.no_pipeline:
             line["pipeline"] = first_stage_pipeline(args.workload, batch, dev, ms_per_step, nsteps_table)
@@ -698,10 +792,8 @@ def main():
         par = line["parity"]
         if par is not None and not all(v < par["bar"] for k, v in par.items() if k.startswith("rel_err")):
             raise RuntimeError(f"bench parity check failed: {par}")
-        print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return line
+    return None
 
 
 if __name__ == "__main__":

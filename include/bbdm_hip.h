@@ -36,17 +36,7 @@ extern "C" {
 int bbdm_version(void);                       /* ABI version, bumped on any signature change           */
 const char* bbdm_last_error(void);            /* text of the last error on the calling thread          */
 
-/* ---- CU-partitioned streams (csrc/runtime.hip) -------------------------------------------------------- */
-/* The reference runs every op of a sampling step on one stream (PyTorch's), one kernel at a time.  Here the HBM-bound
- * launches of one half of a batch run beside the MFMA-bound launches of the other half on two streams that own
- * DISJOINT sets of compute units (bbdm_amd/unet.py: _DualPlan; call site replaced: the op-by-op eager execution of
- * UNetModel.forward, openaimodel.py:744-759).  A partition = a HIP stream restricted to the CU-mask bits
- * [cu_begin, cu_end), both multiples of 8: bit i lives on XCD i % 8, so every XCD contributes (cu_end - cu_begin) / 8
- * CUs.  The returned handle is a hipStream_t usable with every entry point (and torch.cuda.ExternalStream). */
-int bbdm_device_cus(void);                                   /* compute units of the current device (256)        */
-int bbdm_stream_create_partition(int cu_begin, int cu_end, void** stream);
-int bbdm_stream_destroy(void* stream);                       /* only handles of bbdm_stream_create_partition     */
-int bbdm_stream_cus(void* stream);                           /* CUs a stream's kernels can use (persistent grids) */
+int bbdm_device_cus(void);                    /* compute units of the current device (256): persistent grids */
 
 /* ---- layout ------------------------------------------------------------------------------------------ */
 /* NCHW [N,Ca,H,W] (+ optional second NCHW [N,Cb,H,W]) -> NHWC [N,H,W,ldo], channels >= Ca+Cb zero-filled up to
@@ -396,16 +386,6 @@ int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* 
  * buffer.  Same arguments and results (bit for bit) as bbdm_conv1x1_bf3_f32; pixels need not be a multiple of 256. */
 int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
                           float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream);
-/* ... and the Winograd tile GEMMs on the same kernel: V as fp32 "row units" [xi][tile / 32][CinPad / 16][32 rows x 16 k, 2 KB]
- * (element (r, k) at byte (k>>3)*1024 + r*32 + (k&7)*4) -- 4 B per transformed element where the planes cost 6 (the input transform
- * is bound by its HBM writes).  Arguments of bbdm_winograd_input_f32 / bbdm_winograd_gemm_f32; b_planes as for the bf3p entries. */
-size_t bbdm_gemm_bf3q_a_bytes(int batch, long long T, int CinPad);
-int bbdm_gemm_bf3q_f32(const void* a_units, const void* b_planes, float* M, int ldo, int batch, long long T, int CinPad, int Cout,
-                       void* stream);
-int bbdm_winograd_input_bf3q_f32(int m, const float* x, int ldx, void* Vf, const float* pre_scale, const float* pre_bias,
-                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
-int bbdm_winograd_gemm_bf3q_f32(int m, const void* Vf, const void* b_planes, float* M, int N, int H, int W, int CinPad, int Cout,
-                                void* stream);
 int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
 int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
@@ -485,6 +465,13 @@ int bbdm_adam_ema_step_f32(const BbdmOptChunk* table, int nchunks, int do_adam, 
  * operation rounded separately in fp32, so the bytes equal the reference's.  One launch for the whole batch. */
 int bbdm_images_to_u8_f32(const float* x_nchw, unsigned char* out_nhwc, int N, int C, int H, int W, int to_normal,
                           void* stream);
+
+/* ---- test hooks (no reference counterpart; not used by the product path) --------------------------------------------- */
+/* Force the tile shape of the pre-split bf16x3 GEMM (csrc/gemm_bf3p.hip: 6 = the library's own choice, 4 = 256 x 256,
+ * 5 = 256 x 128, 7 = 128 x 128 workgroup tiles) so that the parity tests reach every instantiation on small problems;
+ * returns the previous setting.  Process-wide and unsynchronised: tests / A-B runs only (env BBDM_BF3P_KERNEL sets the
+ * initial value). */
+int bbdm_debug_set_bf3p_kernel(int id);
 
 #ifdef __cplusplus
 }

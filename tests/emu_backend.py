@@ -18,17 +18,16 @@ from bbdm_amd import _lib
 def emulated_backend():
     emu = ops.use_emulator()
     saved = (_lib._lib, _lib.require_gpu, _lib.current_stream, _lib.device_guard, torch.cuda.synchronize,
-             torch.cuda.current_stream, _lib.partition_streams)
+             torch.cuda.current_stream)
     _lib._lib = emu
     _lib.require_gpu = lambda *ts: None
     _lib.current_stream = lambda device=None: None
     _lib.device_guard = lambda device=None: contextlib.nullcontext()
-    _lib.partition_streams = lambda device, t_cus: ((None, None), (None, None))     # (every emulated launch is synchronous)
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=None, synchronize=lambda: None)
     try:
         yield emu
     finally:
         (_lib._lib, _lib.require_gpu, _lib.current_stream, _lib.device_guard, torch.cuda.synchronize,
-         torch.cuda.current_stream, _lib.partition_streams) = saved
+         torch.cuda.current_stream) = saved
         ops.use_emulator(False)

@@ -1,4 +1,5 @@
 """Helpers shared by the tests: load a golden fixture and rebuild its weights (test infrastructure)."""
+import contextlib
 import os
 
 import torch
@@ -31,7 +32,32 @@ def oracle_model(rec):
                         objective=bb["objective"])
 
 
+@contextlib.contextmanager
+def few_threads(n=32):
+    """Run the CPU oracle on at most ``n`` threads: its small problems (one 64x64 image, tiny golden models) are SLOWER on the 128
+    default threads of the GPU box than on a few (oversubscription), and they dominated the GPU suite's wall time."""
+    old = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(old, n)))
+    try:
+        yield
+    finally:
+        torch.set_num_threads(old)
+
+
 def rel_err(a, b):
-    """max|a-b| / max|b|  (SURVEY.md §8c per-step parity metric)."""
+    """max|a-b| / max|b|  (SURVEY.md §8c per-step parity metric, max-norm form)."""
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2  (SURVEY.md §8c per-step parity metric, L2 form: an error spread over many small-magnitude
+    elements passes the max-norm form unnoticed)."""
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def parity_err(a, b):
+    """BOTH metrics of SURVEY.md §8c as one number, the larger of max|a-b| / max|b| and ||a-b||_2 / ||b||_2:
+    ``parity_err(a, b) < tol`` asserts each of them against the bar."""
+    return max(rel_err(a, b), rel_l2(a, b))

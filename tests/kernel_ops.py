@@ -51,7 +51,7 @@ def use_emulator(on: bool = True):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         sys.path.insert(0, os.path.join(root, "tools", "hipemu"))
         import build as hipemu_build
-        _EMU = _real.bind(hipemu_build.build())
+        _EMU = _real.bind(hipemu_build.build(asan=os.environ.get("HIPEMU_ASAN") == "1"))
     return _EMU
 
 

@@ -63,7 +63,7 @@ def test_winograd_output_adds_upsampled_residual(m, N, H, W, Cin, Cout):
     K.test_winograd_output_adds_upsampled_residual(CPU, m, N, H, W, Cin, Cout)
 
 
-@pytest.mark.parametrize("kernel", [0, 3, 4, 5, 7])
+@pytest.mark.parametrize("kernel", [4, 5, 7])
 @pytest.mark.parametrize("batch,T,Cin,Cout", [(1, 256, 16, 256), (1, 256, 32, 256), (8, 256, 80, 260), (2, 512, 64, 256),
                                               (1, 768, 48, 128)])
 def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):
@@ -249,11 +249,6 @@ def test_winograd_input_64bit_index_variant_in_subprocess():
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (320, 48, 256, True), (96, 16, 8, False)])
 def test_conv1x1_bf3q_bitwise(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3q_bitwise(CPU, pixels, Cin, Cout, res)
-
-
-@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 2, 12, 12, 32, 256), (4, 1, 1, 1, 8, 8, 16, 136)])
-def test_winograd_bf3q_stages_bitwise(m, up, silu, N, H, W, Cin, Cout):
-    K.test_winograd_bf3q_stages_bitwise(CPU, m, up, silu, N, H, W, Cin, Cout)
 
 
 @pytest.mark.parametrize("m,Cout,Cin,in_pad,dgrad", [(4, 96, 40, 48, False), (2, 24, 16, 32, True), (6, 40, 130, 144, False)])

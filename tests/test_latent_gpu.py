@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from fixtures import load_case, oracle_model, rel_err
+from fixtures import few_threads, load_case, oracle_model, parity_err, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -79,9 +79,10 @@ def test_latent_wrapper_sample_and_train(normalize):
     finally:
         torch.randn_like = orig
     ora = oracle_model(rec)
-    lat = ora.p_sample_loop(z.cpu(), None, clip_denoised=False, noises=[eps] * len(ora.steps))
+    with few_threads(8):                # (an 8x8 latent through a tiny UNet: all host threads only get in each other's way)
+        lat = ora.p_sample_loop(z.cpu(), None, clip_denoised=False, noises=[eps] * len(ora.steps))
     want = m.decode(lat.to(dev), cond=False)
-    assert out.shape == (3, 3, 32, 32) and rel_err(out.cpu(), want.cpu()) < 2e-3
+    assert out.shape == (3, 3, 32, 32) and parity_err(out.cpu(), want.cpu()) < 2e-3
     assert len(mids) == len(m.steps) + 1 and len(ones) == len(m.steps) and mids[-1].device.type == "cpu"
     # training step through the wrapper: loss is differentiable w.r.t. the UNet only
     m.train()

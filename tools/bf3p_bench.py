@@ -3,9 +3,9 @@
 
   old: bbdm_winograd_input_f32 (fp32 V)            -> bbdm_winograd_gemm_bf3_f32  (csrc/gemm_bf3.hip: V split while staged)
   new: bbdm_winograd_input_bf3p_f32 (3 bf16 planes) -> bbdm_winograd_gemm_bf3p_f32 (csrc/gemm_bf3p.hip: LDS-DMA copies + MFMAs)
-       for every kernel of gemm_bf3p.hip (bbdm_debug_set_bf3p_kernel 0..3)
+       for every kernel of gemm_bf3p.hip (bbdm_debug_set_bf3p_kernel: forced tile shapes 5, 4 and the default 6)
 
-    python tools/bf3p_bench.py [--reps 10] [--kernels 0,1,2,3]
+    python tools/bf3p_bench.py [--reps 10] [--kernels 5,4,6]
 Prints ms and fp32-equivalent TFLOP/s (HIP events on the launch stream), checks that M is bit-equal between the paths, and a
 launch-weighted C2 total (weights = how often the shape occurs in the 256^2 / batch-16 step)."""
 import argparse
@@ -71,7 +71,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--m", type=int, default=6)
-    ap.add_argument("--kernels", default="0,1,2,3")
+    ap.add_argument("--kernels", default="5,4,6")
     ap.add_argument("--shapes", default=None, help="indices into SHAPES, comma separated")
     ap.add_argument("--set", default="c2", choices=("c2", "c3"), help="layer shapes of the C2 step (all m = --m) or of the C3 step")
     args = ap.parse_args()
@@ -121,7 +121,7 @@ def main():
             eq = torch.equal(M0.view(P, tiles, Cout)[:, :T_raw], M1.view(P, tiles, Cout)[:, :T_raw])
             tot[f"g{k}"] += cnt * t
             line += f" k{k} {t:6.3f} ms {fl / t / 1e9:6.1f} TF {'==' if eq else '!= MISMATCH'} |"
-        lib.bbdm_debug_set_bf3p_kernel(0)
+        lib.bbdm_debug_set_bf3p_kernel(6)
         print(line, flush=True)
         del x, V, Vp, M0, M1, pw, pk, Bp
     print("C2-weighted totals (ms per step): " + "  ".join(f"{k} {v:.2f}" for k, v in tot.items()))

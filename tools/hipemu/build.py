@@ -37,7 +37,17 @@ def rewrite(src: str) -> str:
     return src
 
 
-def build(force=False) -> str:
+def asan_runtime() -> str:
+    """The shared AddressSanitizer runtime of the ROCm clang (LD_PRELOAD it into the python that loads the --asan build)."""
+    return subprocess.check_output([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+
+
+def build(force=False, asan=False) -> str:
+    """``asan``: the same sources with -fsanitize=address,undefined into _build_asan/libbbdm_emu_asan.so (tools/run_asan_emu.sh;
+    tests/kernel_ops.use_emulator() picks it when HIPEMU_ASAN=1).  CPU build only: no GPU sanitizer runs on this pool."""
+    global OUT, LIB
+    if asan:
+        OUT, LIB = os.path.join(HERE, "_build_asan"), os.path.join(HERE, "_build_asan", "libbbdm_emu_asan.so")
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "*.cpp")) + \
@@ -46,6 +56,9 @@ def build(force=False) -> str:
         return LIB
     flags = ["-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unknown-pragmas",
              "-Wno-unknown-attributes", "-Wno-pass-failed", "-I", HERE, "-I", CSRC]
+    san = ["-fsanitize=address,undefined", "-fno-sanitize=float-cast-overflow", "-fno-sanitize-recover=undefined", "-shared-libasan",
+           "-fno-omit-frame-pointer", "-g", "-O1"] if asan else []
+    flags += san
     objs, procs = [], []
     for s in srcs:
         base = os.path.splitext(os.path.basename(s))[0]
@@ -62,9 +75,10 @@ def build(force=False) -> str:
     bad = [n for n, p in procs if p.wait() != 0]
     if bad:
         raise RuntimeError("hipemu build failed for " + ", ".join(bad))
-    subprocess.check_call([CLANG, "-shared", "-fPIC"] + objs + [rt, "-o", LIB])
+    subprocess.check_call([CLANG, "-shared", "-fPIC"] + (["-fsanitize=address,undefined", "-shared-libasan"] if asan else []) +
+                          objs + [rt, "-o", LIB])
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, asan="--asan" in sys.argv))

@@ -5,6 +5,16 @@
 #include <vector>
 #include "hip/hip_runtime.h"
 
+// AddressSanitizer build (tools/hipemu/build.py --asan): the fiber switches are announced to the runtime, which otherwise takes a
+// thread that continues on another stack for a stack overflow, and a re-used fiber stack is unpoisoned before its next thread.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HIPEMU_ASAN 1
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
 extern "C" void hipemu_switch(void** save_sp, void* new_sp);
 extern "C" void hipemu_fiber_entry();
 
@@ -21,7 +31,13 @@ struct Fiber {
     void* sp = nullptr;
     char* stack = nullptr;
     int state = DONE;
+    void* fake = nullptr;        // ASAN: the fiber's fake-stack handle while it is switched out
 };
+#ifdef HIPEMU_ASAN
+void* g_sched_fake = nullptr;
+const void* g_sched_bottom = nullptr;
+size_t g_sched_size = 0;
+#endif
 std::vector<Fiber> g_fibers;
 void* g_sched_sp = nullptr;
 int g_cur = -1;
@@ -56,13 +72,22 @@ hipemu_switch:
 void yield_to_scheduler(int state) {
     Fiber& f = g_fibers[g_cur];
     f.state = state;
+#ifdef HIPEMU_ASAN
+    __sanitizer_start_switch_fiber(state == DONE ? nullptr : &f.fake, g_sched_bottom, g_sched_size);
+#endif
     hipemu_switch(&f.sp, g_sched_sp);
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(f.fake, nullptr, nullptr);
+#endif
 }
 
 struct PendingCopy { const char* src; char* dst; int size; };
 std::vector<std::vector<PendingCopy>> g_pending;       // LDS-DMA copies in flight, per thread of the block
 bool dma_outstanding(int t) { return t < (int)g_pending.size() && !g_pending[t].empty(); }
 void fiber_main() {
+#ifdef HIPEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &g_sched_bottom, &g_sched_size);      // first entry: learn the scheduler's stack
+#endif
     g_fn(g_ctx);
     if (dma_outstanding(g_cur)) {
         fprintf(stderr, "hipemu: a thread finished with LDS-DMA copies it never waited for\n");
@@ -79,6 +104,10 @@ void prepare(Fiber& f) {
         f.stack = (char*)mmap(nullptr, STACK, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (f.stack == MAP_FAILED) { perror("hipemu: mmap"); abort(); }
     }
+#ifdef HIPEMU_ASAN
+    __asan_unpoison_memory_region(f.stack, STACK);   // the previous thread on this stack never unwound its frames
+    f.fake = nullptr;
+#endif
     uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
     void** p = (void**)(top - 16);                 // return-address slot (16-byte aligned -> rsp % 16 == 8 at entry)
     p[0] = (void*)&hipemu_fiber_entry;
@@ -109,7 +138,13 @@ void run_block(int nthr) {
             Fiber& f = g_fibers[t];
             if (f.state != RUNNABLE) continue;
             set_ids(t);
+#ifdef HIPEMU_ASAN
+            __sanitizer_start_switch_fiber(&g_sched_fake, f.stack, STACK);
+#endif
             hipemu_switch(&g_sched_sp, f.sp);
+#ifdef HIPEMU_ASAN
+            __sanitizer_finish_switch_fiber(g_sched_fake, nullptr, nullptr);
+#endif
             ran = true;
         }
         // every fiber is now DONE, AT_WAVE or AT_BLOCK
