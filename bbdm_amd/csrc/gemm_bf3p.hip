@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
         const unsigned char* A = a.A + (size_t)ent * a.az + koff;
         const unsigned char* B = a.B + (size_t)ent * a.bz + koff + (size_t)n_tile * (WN * 2) * gstride;
         M = a.M + (size_t)bz * a.mz;
-        res = a.res + (size_t)bz * a.rz;
+        res = RES ? a.res + (size_t)bz * a.rz : nullptr;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int u = wave + k * NW;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
     const int row0 = m_tile * BM, cout0 = n_tile * BN;
     const int n = a.nchunks;
     float* M = a.M + (size_t)bz * a.mz;
-    const float* res = a.res + (size_t)bz * a.rz;
+    const float* res = RES ? a.res + (size_t)bz * a.rz : nullptr;
     // ---- A staging: slot f = tid (+ NW * 64): row f >> 2 of the tile, k-quad q = f & 3 (k = 4 q .. 4 q + 3) -------------------------------
     const float* asrc[AS];
     unsigned adst[AS];
