@@ -57,6 +57,8 @@ SIGNATURES = {
     "bbdm_winograd_wgrad_finish_bias_f32": (c_int, [c_int, _P, c_int, _P, c_int, c_int, _P, ctypes.c_longlong, _P, _P]),
     "bbdm_colsum_f32": (c_int, [_P, c_int, _P, _P, ctypes.c_longlong, c_int, _P]),
     "bbdm_colsum_batched_f32": (c_int, [_P, c_int, _P, _P, c_int, c_int, ctypes.c_longlong, c_int, _P]),
+    "bbdm_groupnorm_stats_bytes": (c_size_t, [c_int, c_int]),
+    "bbdm_groupnorm_stats_read_f64": (c_int, [_P, _P, c_int, c_int, _P]),
     "bbdm_groupnorm_stats_f32": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_groupnorm_apply_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_float, c_int, c_int, _P]),

@@ -22,6 +22,7 @@
 //     blocks share a CU (<=75 KB LDS, <=128 VGPR each): 4 waves per SIMD cover each other's barriers.
 #include <stdlib.h>
 #include "common.h"
+#include "stats_acc.h"
 
 namespace {
 
@@ -55,7 +56,7 @@ struct ConvArgs {
     size_t xz, wz, oz;
     // GroupNorm statistics of the output accumulated by this launch (VAR bit 3; see winograd.hip: StatArgs): fp64 [N][32][2]
     // accumulators of up to two consumers, their group width and the channel offset of `out` in their tensor
-    double* st_s[2];
+    unsigned long long* st_s[2];
     int st_cpg[2], st_coff[2];
 };
 
@@ -140,7 +141,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16 (&a
 }
 
 // Epilogue + GroupNorm statistics of the stored values (modes 0-2, one image per workgroup: the host checks that): per-lane
-// fp64 partials -> LDS (the pipeline's buffers are idle by now) -> one fp64 atomic per touched (image, group).
+// fp64 partials -> exact limb accumulators in LDS (the pipeline's buffers are idle by now) -> one cell add per touched (image, group).
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, f32x16 (&acc)[BM / WM / 32][BN / WN / 32], int tile_x,
                                                     int tile_y, int img0, int cout0, int wm, int wn, int lane, float* smem) {
@@ -154,27 +155,36 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, f32x16 (&
         conv_epilogue_rows<BM, BN, WM, WN, 2, true>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, psum, psq);
     else
         conv_epilogue_rows<BM, BN, WM, WN, 1, true>(a, acc, tile_x, tile_y, img0, cout0, wm, wn, lane, psum, psq);
-    double* ls = reinterpret_cast<double*>(smem);            // [2 consumers][32 groups][2]
+    // exact limb accumulators (stats_acc.h: integer atomics, order-independent) in LDS, then one cell per touched (image, group)
+    unsigned long long* ls = reinterpret_cast<unsigned long long*>(smem);            // [2 consumers][32 groups][2][SA_W]
     const int tid = threadIdx.x;
-    if (tid < 128) ls[tid] = 0.0;
+    for (int i = tid; i < 128 * SA_W; i += WM * WN * 64) ls[i] = 0ull;
     __syncthreads();
+    // lanes l and l + 32 hold the same channel (other rows): add the halves, then the lanes of a group (consecutive channels) meet in
+    // the group's last lane by a segmented scan -- one LDS cell add per group instead of one per lane (same-address LDS atomics serialise)
 #pragma unroll
     for (int nt = 0; nt < NTL; ++nt) {
         const int co = cout0 + wn * (BN / WN) + nt * 32 + (lane & 31);
-        if (co >= a.Cout) continue;
+        const bool live = co < a.Cout;
+        const double hs = (live ? psum[nt] : 0.0) + __shfl_xor(live ? psum[nt] : 0.0, 32);
+        const double hq = (live ? psq[nt] : 0.0) + __shfl_xor(live ? psq[nt] : 0.0, 32);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (!a.st_s[k]) continue;
-            const int g = (a.st_coff[k] + co) / a.st_cpg[k];
-            atomicAdd(ls + (k * 32 + g) * 2, psum[nt]);
-            atomicAdd(ls + (k * 32 + g) * 2 + 1, psq[nt]);
+            const int g = live ? (a.st_coff[k] + co) / a.st_cpg[k] : -1;
+            double vs = hs, vq = hq;
+            sa_seg_scan2(vs, vq, g, lane, a.st_cpg[k] < 32 ? a.st_cpg[k] : 32, 32);
+            const bool tail = sa_seg_tail(g, lane, 32);            // (a cross-lane op: every lane of the wave executes it)
+            if (lane < 32 && live && tail) {
+                sa_add(ls + (size_t)((k * 32 + g) * 2) * SA_W, vs);
+                sa_add(ls + (size_t)((k * 32 + g) * 2 + 1) * SA_W, vq);
+            }
         }
     }
     __syncthreads();
     if (tid < 128) {
         const int k = tid >> 6;
-        const double v = ls[tid];
-        if (a.st_s[k] && v != 0.0) atomicAdd(a.st_s[k] + (size_t)img0 * 64 + (tid & 63), v);
+        if (a.st_s[k]) sa_add_cell(a.st_s[k] + ((size_t)img0 * 64 + (tid & 63)) * SA_W, ls + (size_t)tid * SA_W);
     }
 }
 
@@ -577,7 +587,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
     constexpr int TS = 16, PR = 18, NPP = PR * PR, PLANE = 328, WP = 160, Q = CIN / 4, SLOTS = (NPP * Q + 255) / 256;
     __shared__ float patch[CIN * PLANE];                         // [ci][py * 18 + px]
     __shared__ float wsm[9 * CIN * WP];                          // [k = tap * CIN + ci][co], pitch = 32 (mod 64): k and k + 1 on disjoint banks
-    __shared__ double ls[128];                                   // [2 consumers][32 groups][2]
+    __shared__ unsigned long long ls[128 * SA_W];                // [2 consumers][32 groups][2] exact limb accumulators (stats_acc.h)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     for (int i = tid; i < 9 * CIN * 128; i += 256) {
         const int k = i >> 7, co = i & 127, tap = k / CIN, ci = k % CIN;
@@ -611,13 +621,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
             }
         }
     };
+    if (STATS) for (int i = tid; i < 128 * SA_W; i += 256) ls[i] = 0ull;      // (the first barrier of the tile loop orders it)
     int t = blockIdx.x;
     if (t < tiles_total) request(t);
     const float* ab = patch + hi * PLANE + (wave * 4 + (l31 >> 4)) * PR + (l31 & 15);
     const float* bb = wsm + hi * WP + l31;
     for (; t < tiles_total; t += gridDim.x) {
         land();
-        if (STATS && tid < 128) ls[tid] = 0.0;
         __syncthreads();
         if (t + (int)gridDim.x < tiles_total) request(t + gridDim.x);
         f32x16 acc[2][4];
@@ -660,23 +670,32 @@ __global__ void __launch_bounds__(256, 2) conv3x3_stem_kernel(const ConvArgs a, 
                 }
             }
         if (STATS) {
+            // as conv_epilogue_stats: the two halves of the wave (same channels, other pixels), then the lanes of a group by a
+            // segmented scan, then ONE exact LDS add per group and wave
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 const int co = cb * 32 + l31;
+                const double hs = psum[cb] + __shfl_xor(psum[cb], 32), hq = psq[cb] + __shfl_xor(psq[cb], 32);
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     if (!a.st_s[k]) continue;
                     const int g = (a.st_coff[k] + co) / a.st_cpg[k];
-                    atomicAdd(ls + (k * 32 + g) * 2, psum[cb]);
-                    atomicAdd(ls + (k * 32 + g) * 2 + 1, psq[cb]);
+                    double vs = hs, vq = hq;
+                    sa_seg_scan2(vs, vq, g, lane, a.st_cpg[k] < 32 ? a.st_cpg[k] : 32, 32);
+                    const bool tail = sa_seg_tail(g, lane, 32);
+                    if (lane < 32 && tail) {
+                        sa_add(ls + (size_t)((k * 32 + g) * 2) * SA_W, vs);
+                        sa_add(ls + (size_t)((k * 32 + g) * 2 + 1) * SA_W, vq);
+                    }
                 }
             }
         }
         __syncthreads();                                         // patch readers done (and the tile's statistics complete)
         if (STATS && tid < 128) {
             const int k = tid >> 6;
-            const double v = ls[tid];
-            if (a.st_s[k] && v != 0.0) atomicAdd(a.st_s[k] + (size_t)n * 64 + (tid & 63), v);
+            if (a.st_s[k]) sa_add_cell(a.st_s[k] + ((size_t)n * 64 + (tid & 63)) * SA_W, ls + (size_t)tid * SA_W);
+#pragma unroll
+            for (int i = 0; i < SA_W; ++i) ls[(size_t)tid * SA_W + i] = 0ull;      // ready for the next tile (the same thread reads and clears)
         }
     }
 }
@@ -1025,8 +1044,8 @@ extern "C" int bbdm_conv_stats_fusable(int N, int H, int W, int CinPad, int Cout
 extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, const float* bias,
                                           const float* residual, int ldr, float* out, int ldo, int out_nchw, float* ws,
                                           size_t ws_floats, const float* pre_scale, const float* pre_bias, int pre_ld,
-                                          int pre_silu, int N, int H, int W, int CinPad, int Cout, int ks, double* stats0,
-                                          int cpg0, int coff0, double* stats1, int cpg1, int coff1, void* stream) {
+                                          int pre_silu, int N, int H, int W, int CinPad, int Cout, int ks, void* stats0,
+                                          int cpg0, int coff0, void* stats1, int cpg1, int coff1, void* stream) {
     BBDM_REQUIRE(x && packed_w && out, "conv2d: null pointer");
     BBDM_REQUIRE(ks == 1 || ks == 3, "conv2d: ks=%d unsupported (1 or 3)", ks);
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0 && CinPad > 0, "conv2d: bad shape");
@@ -1054,8 +1073,8 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
     BBDM_REQUIRE((!stats0 || (cpg0 > 0 && coff0 >= 0 && (coff0 + Cout - 1) / cpg0 < 32)) &&
                      (!stats1 || (cpg1 > 0 && coff1 >= 0 && (coff1 + Cout - 1) / cpg1 < 32)),
                  "conv2d: statistics targets need (coff + Cout) / cpg <= 32");
-    a.st_s[0] = stats0; a.st_cpg[0] = cpg0 > 0 ? cpg0 : 1; a.st_coff[0] = coff0;
-    a.st_s[1] = stats1; a.st_cpg[1] = cpg1 > 0 ? cpg1 : 1; a.st_coff[1] = coff1;
+    a.st_s[0] = (unsigned long long*)stats0; a.st_cpg[0] = cpg0 > 0 ? cpg0 : 1; a.st_coff[0] = coff0;
+    a.st_s[1] = (unsigned long long*)stats1; a.st_cpg[1] = cpg1 > 0 ? cpg1 : 1; a.st_coff[1] = coff1;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
     static const long long narrow_min = getenv("BBDM_CONV_NARROW_MIN") ? atoll(getenv("BBDM_CONV_NARROW_MIN")) : 4096;

@@ -8,6 +8,7 @@
 // Both passes are HBM-bound streaming kernels: 16-byte (float4) accesses along the contiguous channel
 // axis, one wave covers 1 KiB of consecutive bytes, many small blocks so that all 256 CUs stream.
 #include "common.h"
+#include "stats_acc.h"
 
 namespace {
 
@@ -16,14 +17,14 @@ namespace {
 // pixels with stride PP = 256 / C4; its accumulators therefore always belong to one group per quad.
 // ---------------------------------------------------------------------------------------------------------
 template <int JMAX>
-__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int ldx, double* __restrict__ stats,
+__global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__ x, int ldx, unsigned long long* __restrict__ stats,
                                                        int HW, int C, int G, int pix_per_block) {
-    __shared__ double lsum[64 * 2];      // G <= 64
+    __shared__ unsigned long long lsum[64 * 2 * SA_W];      // G <= 64; exact limb accumulators (stats_acc.h)
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int C4 = C >> 2;
     const int cpg = C / G;
-    if (tid < 2 * G) lsum[tid] = 0.0;
+    for (int i = tid; i < 2 * G * SA_W; i += 256) lsum[i] = 0ull;
     __syncthreads();
 
     const int p0 = blockIdx.x * pix_per_block;
@@ -64,25 +65,25 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
             const int c4 = c4base + j * 256;
             if (c4 < C4) {
                 const int g = (c4 * 4) / cpg;     // cpg % 4 == 0 -> a quad never straddles two groups
-                atomicAdd(&lsum[2 * g], s[j]);
-                atomicAdd(&lsum[2 * g + 1], ss[j]);
+                sa_add(lsum + (size_t)(2 * g) * SA_W, s[j]);
+                sa_add(lsum + (size_t)(2 * g + 1) * SA_W, ss[j]);
             }
         }
     }
     __syncthreads();
-    if (tid < 2 * G) atomicAdd(&stats[(size_t)n * G * 2 + tid], lsum[tid]);
+    if (tid < 2 * G) sa_add_cell(stats + ((size_t)n * G * 2 + tid) * SA_W, lsum + (size_t)tid * SA_W);
 }
 
 // Scalar variant for channels-per-group not a multiple of 4 (e.g. C = 32, 96, 192 with 32 groups: only the tiny
 // test configurations; every reference template has cpg % 4 == 0).  One thread per element, LDS fp64 atomics per group.
 __global__ void __launch_bounds__(256) gn_stats_scalar_kernel(const float* __restrict__ x, int ldx,
-                                                              double* __restrict__ stats, int HW, int C, int G,
+                                                              unsigned long long* __restrict__ stats, int HW, int C, int G,
                                                               int pix_per_block) {
-    __shared__ double lsum[64 * 2];
+    __shared__ unsigned long long lsum[64 * 2 * SA_W];
     const int tid = threadIdx.x;
     const int n = blockIdx.y;
     const int cpg = C / G;
-    if (tid < 2 * G) lsum[tid] = 0.0;
+    for (int i = tid; i < 2 * G * SA_W; i += 256) lsum[i] = 0ull;
     __syncthreads();
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(HW, p0 + pix_per_block);
@@ -91,11 +92,11 @@ __global__ void __launch_bounds__(256) gn_stats_scalar_kernel(const float* __res
     for (long long i = tid; i < total; i += 256) {
         const int p = p0 + (int)(i / C), c = (int)(i % C);
         const double v = xb[(size_t)p * ldx + c];
-        atomicAdd(&lsum[2 * (c / cpg)], v);
-        atomicAdd(&lsum[2 * (c / cpg) + 1], v * v);
+        sa_add(lsum + (size_t)(2 * (c / cpg)) * SA_W, v);
+        sa_add(lsum + (size_t)(2 * (c / cpg) + 1) * SA_W, v * v);
     }
     __syncthreads();
-    if (tid < 2 * G) atomicAdd(&stats[(size_t)n * G * 2 + tid], lsum[tid]);
+    if (tid < 2 * G) sa_add_cell(stats + ((size_t)n * G * 2 + tid) * SA_W, lsum + (size_t)tid * SA_W);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256) gn_stats_scalar_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------
 struct ApplyArgs {
     const float* x;
-    const double* stats;
+    const unsigned long long* stats;     // exact limb accumulators (stats_acc.h): sa_load folds a cell into its fp64 sum
     const float* gamma;
     const float* beta;
     const float* film;
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
             const int ng = (cpg & 3) ? 4 : 1;      // a quad may span several groups unless cpg % 4 == 0
             for (int e = 0; e < ng; ++e) {
                 const int g = (c + e) / cpg;
-                const double s = a.stats[((size_t)n * a.G + g) * 2], ss = a.stats[((size_t)n * a.G + g) * 2 + 1];
+                const double s = sa_load(a.stats + (((size_t)n * a.G + g) * 2) * SA_W), ss = sa_load(a.stats + (((size_t)n * a.G + g) * 2 + 1) * SA_W);
                 const double mean = s / cnt;
                 double var = ss / cnt - mean * mean;
                 var = var > 0.0 ? var : 0.0;
@@ -226,7 +227,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const ApplyArgs a) {
 
 // Per-image, per-channel coefficients of the fused apply:  GN(x)[*(1+scale)+shift] == x * sc[n][c] + bi[n][c].
 // Same expressions (and therefore the same roundings) as gn_apply_kernel.
-__global__ void gn_coeffs_kernel(const double* __restrict__ stats, const float* __restrict__ gamma,
+__global__ void gn_coeffs_kernel(const unsigned long long* __restrict__ stats, const float* __restrict__ gamma,
                                  const float* __restrict__ beta, const float* __restrict__ film, int film_ld,
                                  float* __restrict__ sc_out, float* __restrict__ bi_out, int ld, int N, int HW, int C, int G,
                                  float eps) {
@@ -235,7 +236,7 @@ __global__ void gn_coeffs_kernel(const double* __restrict__ stats, const float* 
     const int n = i / C, c = i - n * C;
     const int cpg = C / G, g = c / cpg;
     const double cnt = (double)HW * cpg;
-    const double s = stats[((size_t)n * G + g) * 2], ss = stats[((size_t)n * G + g) * 2 + 1];
+    const double s = sa_load(stats + (((size_t)n * G + g) * 2) * SA_W), ss = sa_load(stats + (((size_t)n * G + g) * 2 + 1) * SA_W);
     const double mean = s / cnt;
     double var = ss / cnt - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -254,19 +255,39 @@ __global__ void gn_coeffs_kernel(const double* __restrict__ stats, const float* 
 
 }  // namespace
 
-extern "C" int bbdm_groupnorm_coeffs_f32(const double* stats, const float* gamma, const float* beta, const float* film,
+extern "C" int bbdm_groupnorm_coeffs_f32(const void* stats, const float* gamma, const float* beta, const float* film,
                                          int film_ld, float* scale_out, float* bias_out, int ld, int N, int HW, int C, int G,
                                          float eps, void* stream) {
     BBDM_REQUIRE(stats && gamma && beta && scale_out && bias_out, "gn_coeffs: null pointer");
     BBDM_REQUIRE(N > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && ld >= C, "gn_coeffs: bad shape");
-    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, film,
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)stats, gamma, beta, film,
                        film_ld, scale_out, bias_out, ld, N, HW, C, G, eps);
     BBDM_CHECK_LAUNCH("gn_coeffs");
     return BBDM_OK;
 }
 
-extern "C" int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int HW, int C, int G,
+// ---- the accumulator itself (layout: stats_acc.h) -------------------------------------------------------------------------------
+extern "C" size_t bbdm_groupnorm_stats_bytes(int N, int G) {
+    return N > 0 && G > 0 ? (size_t)N * G * 2 * SA_W * sizeof(unsigned long long) : 0;
+}
+namespace {
+__global__ void gn_stats_read_kernel(const unsigned long long* __restrict__ acc, double* __restrict__ out, int cells) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cells) out[i] = sa_load(acc + (size_t)i * SA_W);
+}
+}  // namespace
+extern "C" int bbdm_groupnorm_stats_read_f64(const void* stats, double* sums_out, int N, int G, void* stream) {
+    BBDM_REQUIRE(stats && sums_out && N > 0 && G > 0, "gn_stats_read: bad args");
+    const int cells = N * G * 2;
+    hipLaunchKernelGGL(gn_stats_read_kernel, dim3(cdiv(cells, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)stats, sums_out, cells);
+    BBDM_CHECK_LAUNCH("gn_stats_read");
+    return BBDM_OK;
+}
+
+extern "C" int bbdm_groupnorm_stats_f32(const float* x, int ldx, void* stats_, int N, int HW, int C, int G,
                                         void* stream) {
+    unsigned long long* stats = (unsigned long long*)stats_;
     BBDM_REQUIRE(x && stats, "gn_stats: null pointer");
     BBDM_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= 64 && C % G == 0, "gn_stats: bad shape C=%d G=%d", C, G);
     BBDM_REQUIRE(ldx >= C, "gn_stats: ldx < C");
@@ -301,7 +322,7 @@ extern "C" int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, 
     return BBDM_OK;
 }
 
-extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const float* gamma,
+extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const void* stats, const float* gamma,
                                         const float* beta, const float* film, int film_ld, float* y, int ldy, int N,
                                         int H, int W, int C, int G, float eps, int silu, int resample, void* stream) {
     BBDM_REQUIRE(x && y, "gn_apply: null pointer");
@@ -316,7 +337,7 @@ extern "C" int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* s
     BBDM_REQUIRE(!film || film_ld % 4 == 0, "gn_apply: film_ld %% 4");
     BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "gn_apply: x / y must be 16-byte aligned");
     ApplyArgs a;
-    a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.y = y;
+    a.x = x; a.stats = (const unsigned long long*)stats; a.gamma = gamma; a.beta = beta; a.film = film; a.y = y;
     a.ldx = ldx; a.ldy = ldy; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample; a.norm = norm;
     const long long units = (long long)((resample == 1 || resample >= 3) ? (H / 2) * (W / 2) : H * W) * (C / 4);

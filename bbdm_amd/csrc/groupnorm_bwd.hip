@@ -11,12 +11,13 @@
 // dAdd carries the gradient of the skip path (x_upd / identity), which shares the same resampling.
 // All three are HBM-bound streaming kernels with float4 accesses along the channel axis.
 #include "common.h"
+#include "stats_acc.h"
 
 namespace {
 
 struct BwdArgs {
     const float* x;
-    const double* stats;
+    const unsigned long long* stats;     // exact limb accumulators (stats_acc.h)
     const float* gamma;
     const float* beta;
     const float* film;
@@ -74,7 +75,7 @@ __device__ __forceinline__ Norm4 load_norm(const BwdArgs& a, int n, int c, int c
     const int ng = (cpg & 3) ? 4 : 1;
     for (int e = 0; e < ng; ++e) {
         const int g = (c + e) / cpg;
-        const double s = a.stats[((size_t)n * a.G + g) * 2], ss = a.stats[((size_t)n * a.G + g) * 2 + 1];
+        const double s = sa_load(a.stats + (((size_t)n * a.G + g) * 2) * SA_W), ss = sa_load(a.stats + (((size_t)n * a.G + g) * 2 + 1) * SA_W);
         const double mean = s / cnt;
         double var = ss / cnt - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -170,7 +171,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __re
                                                               const float* __restrict__ beta, const float* __restrict__ film,
                                                               int film_ld, double* __restrict__ sg, double* __restrict__ dgb,
                                                               float* __restrict__ dfilm, int dfilm_ld, int C, int G,
-                                                              const double* __restrict__ stats, float4* __restrict__ coef,
+                                                              const unsigned long long* __restrict__ stats, float4* __restrict__ coef,
                                                               double cnt, float eps) {
     // grid = N; dgb: fp64 [C][2] accumulators (zeroed by the launcher) for dgamma / dbeta over n
     __shared__ double s12[64 * 2];
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __re
     // what the apply pass needs per (image, group), once, in fp32 -- it used to redo these fp64 divisions / square roots for
     // every channel quad of every pixel, which made an HBM-bound pass ALU-bound (2.5 TB/s)
     if (tid < G) {
-        const double sm = stats[((size_t)n * G + tid) * 2], ss = stats[((size_t)n * G + tid) * 2 + 1];
+        const double sm = sa_load(stats + (((size_t)n * G + tid) * 2) * SA_W), ss = sa_load(stats + (((size_t)n * G + tid) * 2 + 1) * SA_W);
         const double mean = sm / cnt;
         double var = ss / cnt - mean * mean;
         var = var > 0.0 ? var : 0.0;
@@ -320,7 +321,7 @@ extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
     return (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2 + (size_t)N * G * 2;
 }
 
-extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
+extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats_, const float* gamma, const float* beta,
                                       const float* film, int film_ld, const float* da, int ldda, const float* dadd,
                                       int ldadd, float* dx, int lddx, int accumulate, float* dgamma, float* dbeta,
                                       float* dfilm, int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps,
@@ -328,6 +329,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* sta
     BBDM_REQUIRE(dx, "gn_bwd: null dx");
     const int norm = gamma != nullptr;
     BBDM_REQUIRE(norm || dadd, "gn_bwd: nothing to do (no norm, no dadd)");
+    const unsigned long long* stats = (const unsigned long long*)stats_;
     BBDM_REQUIRE(!norm || (x && stats && beta && da && dgamma && dbeta && ws), "gn_bwd: missing pointer for the norm path");
     BBDM_REQUIRE(resample >= 0 && resample <= 3 && ((resample != 1 && resample != 3) || (H % 2 == 0 && W % 2 == 0)),
                  "gn_bwd: resample");

@@ -21,6 +21,7 @@
 #include "winograd_math.h"
 #include <stdlib.h>
 #include "bf3_split.h"
+#include "stats_acc.h"
 
 namespace {
 
@@ -96,42 +97,44 @@ __global__ void __launch_bounds__(256) winograd_input_kernel(const float* __rest
 
 // ---- (3) output transform: one thread = one (tile, output-channel quad) ---------------------------------------------
 // GroupNorm statistics of the tensor being written, accumulated by its PRODUCER (openaimodel.py:205,229,306,688: every 3x3
-// conv output of the UNet is normalised next): per (image, group) sum / sum of squares in fp64, up to two consumers with
+// conv output of the UNet is normalised next): per (image, group) sum / sum of squares, up to two consumers with
 // their own group width and channel offset (a block output is normalised by the next block as [C] and, through the concat,
 // by an output block as a slice of [C + C']).  This removes the separate statistics pass -- a full re-read of every
-// activation (25.8 GB and 5.3 ms per 256x256 / batch-16 step).  A workgroup owns a contiguous run of `iters` x 256
-// (tile, channel-group) units, i.e. a few consecutive tiles of at most ST_IMGS images: its partial sums meet in LDS
-// (ds_add_f64) and reach HBM as one fp64 atomic per touched (image, group) -- a few hundred atomics per address per launch.
+// activation (25.8 GB and 5.3 ms per 256x256 / batch-16 step).  The sums are EXACT integer-limb accumulators (stats_acc.h): fp64
+// partial sums of a thread are cut into limbs and added with integer atomics, in LDS and in HBM, so the result does not depend on
+// the order in which waves and workgroups finish -- a sampling step is bitwise reproducible.  A workgroup owns a contiguous run of
+// `iters` x 256 (tile, channel-group) units, i.e. a few consecutive tiles of at most ST_IMGS images: its partial sums meet in an
+// LDS table and reach HBM as one cell (<= 3 integer atomics) per touched (image, group, sum | sum of squares).
 struct StatArgs {
-    double* s[2];        // [N][32][2] fp64 accumulators (zeroed by the caller), or null
-    int cpg[2];          // channels per group of that consumer (a multiple of the kernel's channel vector)
-    int coff[2];         // channel offset of this tensor inside the consumer's tensor
+    unsigned long long* s[2];   // [N][32][2][SA_W] limb accumulators (zeroed by the caller), or null
+    int cpg[2];                 // channels per group of that consumer (a multiple of the kernel's channel vector)
+    int coff[2];                // channel offset of this tensor inside the consumer's tensor
 };
 constexpr int ST_IMGS = 4;
-constexpr int ST_DOUBLES = 2 * ST_IMGS * 32 * 2;
+constexpr int ST_CELLS = 2 * ST_IMGS * 32 * 2;          // [consumer][image][group][sum | sq]
+constexpr int ST_WORDS = ST_CELLS * SA_W;
 
-__device__ __forceinline__ void stat_add(double* lsum, const StatArgs& st, int n_local, int n, int c, double sum, double sq) {
+__device__ __forceinline__ void stat_add(unsigned long long* lsum, const StatArgs& st, int n_local, int n, int c, double sum, double sq) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (!st.s[k]) continue;
         const int g = (st.coff[k] + c) / st.cpg[k];
         if (n_local < ST_IMGS) {
-            double* d = lsum + ((size_t)(k * ST_IMGS + n_local) * 32 + g) * 2;
-            atomicAdd(d, sum);
-            atomicAdd(d + 1, sq);
+            unsigned long long* d = lsum + ((size_t)((k * ST_IMGS + n_local) * 32 + g) * 2) * SA_W;
+            sa_add(d, sum);
+            sa_add(d + SA_W, sq);
         } else {                           // a run spanning more than ST_IMGS images (tiny images): straight to HBM
-            double* d = st.s[k] + ((size_t)n * 32 + g) * 2;
-            atomicAdd(d, sum);
-            atomicAdd(d + 1, sq);
+            unsigned long long* d = st.s[k] + ((size_t)(n * 32 + g) * 2) * SA_W;
+            sa_add(d, sum);
+            sa_add(d + SA_W, sq);
         }
     }
 }
-__device__ __forceinline__ void stat_flush(const double* lsum, const StatArgs& st, int n0, int N, int nthreads = 256) {
-    for (int i = threadIdx.x; i < ST_DOUBLES; i += nthreads) {
+__device__ __forceinline__ void stat_flush(const unsigned long long* lsum, const StatArgs& st, int n0, int N, int nthreads = 256) {
+    for (int i = threadIdx.x; i < ST_CELLS; i += nthreads) {
         const int k = i / (ST_IMGS * 64), rem = i - k * (ST_IMGS * 64);
         const int n = n0 + rem / 64;
-        const double v = lsum[i];
-        if (st.s[k] && n < N && v != 0.0) atomicAdd(st.s[k] + (size_t)n * 64 + (rem & 63), v);
+        if (st.s[k] && n < N) sa_add_cell(st.s[k] + ((size_t)n * 64 + (rem & 63)) * SA_W, lsum + (size_t)i * SA_W);
     }
 }
 
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
                                                               float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
                                                               int iters, const StatArgs st, int ph) {
     constexpr int AL = MO + 2;          // ph: see winograd_output6_kernel
-    __shared__ double lsum[ST_DOUBLES];
+    __shared__ unsigned long long lsum[ST_WORDS];
     const int C4 = (ph ? 4 * Cout : Cout) >> 2;
     const int TH = H / MO, TW = W / MO;
     const long long total = (long long)N * TH * TW * C4;
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(256) winograd_output_kernel(const float* __res
     const int n0 = (int)((base / C4) / ((long long)TH * TW));
     const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
     if (stats) {
-        for (int i = threadIdx.x; i < ST_DOUBLES; i += 256) lsum[i] = 0.0;
+        for (int i = threadIdx.x; i < ST_WORDS; i += 256) lsum[i] = 0ull;
         __syncthreads();
     }
     for (int it = 0; it < iters; ++it) {
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
     // ph (BBDM_CONV_OUT_PHASES): M carries 4 Cout channels, channel (2 pa + pb) Cout + co of the tile grid position (oh, ow) is the
     // output pixel (2 oh + pa, 2 ow + pb), channel co, of a [N, 2H, 2W] image (the four phase filters of conv3x3(nearest x2(x)))
     constexpr int MO = 6, AL = 8;
-    __shared__ double lsum[ST_DOUBLES];
+    __shared__ unsigned long long lsum[ST_WORDS];
     const int C2 = (ph ? 4 * Cout : Cout) >> 1;
     const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
     const long long total = (long long)N * TH * TW * C2;
@@ -629,7 +632,7 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
     const int n0 = (int)((base / C2) / ((long long)TH * TW));
     const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
     if (stats) {
-        for (int i = threadIdx.x; i < ST_DOUBLES; i += 256) lsum[i] = 0.0;
+        for (int i = threadIdx.x; i < ST_WORDS; i += 256) lsum[i] = 0ull;
         __syncthreads();
     }
     for (int it = 0; it < iters; ++it) {
@@ -720,25 +723,27 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(cons
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ res, int ldr, int res_per_image,
                                                                    float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
-                                                                   int cblocks, long long T, const StatArgs st, int ph) {
-    // TPW tiles (consecutive, same channel block) per workgroup, the intermediate double-buffered: the waves that finish phase B of a
+                                                                   int cblocks, long long T, const StatArgs st, int ph, int tpw) {
+    // tpw tiles (TPW = 1: one; TPW = 2: any number; consecutive, same channel block) per workgroup, the intermediate double-buffered: the waves that finish phase B of a
     // tile early -- and the two that have no output row -- already load the next tile's columns
     constexpr int AL = MO + 2, NT = AL * 64, NBUF = TPW > 1 ? 2 : 1;
-    __shared__ float2 lds[NBUF * MO * AL * 64];
-    __shared__ double lsum[ST_DOUBLES];
+    constexpr int GL = 33;                                       // groups a 128-channel block can touch (cpg >= 4, unaligned start)
+    constexpr int TAB = MO * 2 * 2 * GL * 2;                     // statistics table (doubles), parked in the transform buffer at the end
+    constexpr int XF = NBUF * MO * AL * 64;
+    __shared__ float2 lds[XF > TAB ? XF : TAB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cb = (int)(blockIdx.x % (unsigned)cblocks);
-    const long long tile0 = (long long)(blockIdx.x / (unsigned)cblocks) * TPW;
+    const long long tile0 = (long long)(blockIdx.x / (unsigned)cblocks) * tpw;
     const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
     const int n0 = (int)(tile0 / ((long long)TH * TW));
     const int cm = cb * 128 + 2 * lane;                       // channel of M
     const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;    // phase filter, output channel
     const bool stats = st.s[0] != nullptr || st.s[1] != nullptr;
-    if (stats)
-        for (int i = threadIdx.x; i < ST_DOUBLES; i += NT) lsum[i] = 0.0;
+    // GroupNorm statistics: a thread keeps the fp64 sums of what it stores in registers -- its tpw consecutive tiles lie in at most two
+    // images (slot = n - n0) -- and the workgroup reduces them ONCE, after its last tile (see below)
+    double acc_s[2] = {0.0, 0.0}, acc_q[2] = {0.0, 0.0};
     const float2 b2 = bias ? *reinterpret_cast<const float2*>(bias + c) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
+    for (int k = 0; k < tpw; ++k) {
         const long long tile = tile0 + k;
         if (tile >= T) break;
         float2* buf = lds + (k & (NBUF - 1)) * (MO * AL * 64);
@@ -795,13 +800,52 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(cons
                         }
                     }
                 }
-                if (stats) stat_add(lsum, st, n - n0, n, c, psum, psq);
+                if (stats) {
+                    if (n == n0) { acc_s[0] += psum; acc_q[0] += psq; } else { acc_s[1] += psum; acc_q[1] += psq; }
+                }
             }
         }
     }
     if (stats) {
+        // Reduction in a FIXED order (run-to-run reproducible, and free of the same-address LDS atomics that cost this kernel a third
+        // of its LDS cycles in round 3): the lanes of a wave that share a group are neighbours (lane = channel pair), so a segmented
+        // inclusive scan over the lanes (__shfl_up; log2(cpg / 2) steps) leaves a group's sum in its last lane; that lane parks it in
+        // LDS [wave][consumer][slot][group of this channel block][sum | sq] (the transform buffer is idle by now); after a barrier one
+        // thread per cell adds the MO waves' values in wave order and hands the total to the exact HBM accumulator (stats_acc.h).
+        double* tab = reinterpret_cast<double*>(lds);            // [MO][2][2][GL][2] doubles <= 6 * 264 * 8 B = 12.4 KB
+        static_assert(sizeof(double) == sizeof(float2), "the table is parked in the float2 transform buffer");
+        const int c_first = c - 2 * lane;                        // first output channel of this 128-channel block (lane 0's)
+        __syncthreads();                                         // every wave is done with the transform buffer
+        if (wave < MO) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!st.s[k]) continue;
+                const int g = (st.coff[k] + c) / st.cpg[k], g_first = (st.coff[k] + c_first) / st.cpg[k];
+                const bool tail = sa_seg_tail(g, lane);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    double vs = acc_s[sl], vq = acc_q[sl];
+                    sa_seg_scan2(vs, vq, g, lane, st.cpg[k] >> 1);      // (cpg / 2 lanes per group: lane = channel pair)
+                    if (tail) {
+                        double* t = tab + ((((size_t)wave * 2 + k) * 2 + sl) * GL + (g - g_first)) * 2;
+                        t[0] = vs; t[1] = vq;
+                    }
+                }
+            }
+        }
         __syncthreads();
-        stat_flush(lsum, st, n0, N, NT);
+        for (int i = threadIdx.x; i < 2 * 2 * GL * 2; i += NT) {
+            const int which = i & 1, gl = (i >> 1) % GL, sl = ((i >> 1) / GL) & 1, k = (i >> 1) / (2 * GL);
+            if (!st.s[k]) continue;
+            const int n = n0 + sl;
+            const int g_first = (st.coff[k] + c_first) / st.cpg[k], g_last = (st.coff[k] + c_first + 127) / st.cpg[k];
+            const int g = g_first + gl;
+            if (n >= N || g > g_last) continue;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < MO; ++w) v += tab[((((size_t)w * 2 + k) * 2 + sl) * GL + gl) * 2 + which];
+            sa_add(st.s[k] + ((size_t)(n * 32 + g) * 2 + which) * SA_W, v);
+        }
     }
 }
 
@@ -1188,8 +1232,8 @@ extern "C" int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_
 // to two consumers of `out`; cpg = channels per group of that consumer (a multiple of 4), coff = channel offset of `out` in
 // the consumer's tensor.  The caller zeroes them; the kernel ADDS (several producers may fill one consumer's statistics).
 extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
-                                                     float* out, int ldo, int flags, int N, int H, int W, int Cout, double* stats0,
-                                                     int cpg0, int coff0, double* stats1, int cpg1, int coff1, int splits,
+                                                     float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stats0,
+                                                     int cpg0, int coff0, void* stats1, int cpg1, int coff1, int splits,
                                                      void* stream) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(splits >= 1 && (splits == 1 || m != 6), "winograd_output: splits=%d (m = 6 layers are never split)", splits);
@@ -1211,8 +1255,8 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
                      (!stats1 || (cpg1 > 0 && cpg1 % 4 == 0 && coff1 >= 0 && (coff1 + Cout - 1) / cpg1 < 32)),
                  "winograd_output: statistics targets need cpg %% 4 == 0 and (coff + Cout) / cpg <= 32");
     StatArgs st;
-    st.s[0] = stats0; st.cpg[0] = cpg0 > 0 ? cpg0 : 1; st.coff[0] = coff0;
-    st.s[1] = stats1; st.cpg[1] = cpg1 > 0 ? cpg1 : 1; st.coff[1] = coff1;
+    st.s[0] = (unsigned long long*)stats0; st.cpg[0] = cpg0 > 0 ? cpg0 : 1; st.coff[0] = coff0;
+    st.s[1] = (unsigned long long*)stats1; st.cpg[1] = cpg1 > 0 ? cpg1 : 1; st.coff[1] = coff1;
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const long long units = (long long)T * (Cm / (m == 6 ? 2 : 4));
     // contiguous runs of iters x 256 units per workgroup: >= ~6000 workgroups (the chip holds ~1000 at a time: a 1536-workgroup
@@ -1227,11 +1271,30 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     // BBDM_WINO_OUTPUT_LDS=0: the one-thread-per-window kernel for every m = 6 shape (A/B; see winograd_output6_lds_kernel)
     static const int two_phase = [] { const char* e = getenv("BBDM_WINO_OUTPUT_LDS"); return e ? atoi(e) : 1; }();
     if (two_phase && Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
-        static const int tpw = [] { const char* e = getenv("BBDM_WINO_OUTPUT_TPW"); return e ? atoi(e) : 2; }();
+        // Tiles per workgroup.  Two (double-buffered) by default; MORE where the layer is narrow: a 128-channel block of a layer with
+        // 4 channels per group touches 32 groups = 64 accumulator cells, i.e. >= 128 integer atomics per workgroup whatever its tile
+        // count -- at two tiles that was one atomic per 72 stored values and cost the 128-channel layers of the 256^2 level 20 %
+        // (measured round 4).  8 cells per tile is the budget; a run of tiles must not span more than two images (the kernel keeps two
+        // register accumulators) and the launch keeps >= 2048 workgroups.  BBDM_WINO_OUTPUT_TPW forces a count (A/B).
+        static const int tpw_env = [] { const char* e = getenv("BBDM_WINO_OUTPUT_TPW"); return e ? atoi(e) : 0; }();
+        int tpw = 2;
+        if (tpw_env > 0) tpw = tpw_env;
+        else if (stats0 || stats1) {
+            int cells = 0;
+            if (stats0) cells += 2 * (128 / st.cpg[0] + 1);
+            if (stats1) cells += 2 * (128 / st.cpg[1] + 1);
+            tpw = cells / 8;
+            if (tpw < 2) tpw = 2;
+            if (tpw > 8) tpw = 8;
+            while (tpw > 2 && ((long long)((T + tpw - 1) / tpw) * (Cm / 128) < 2048)) --tpw;
+        }
+        const long long per_image = (long long)((H + m - 1) / m) * ((W + m - 1) / m);
+        if (tpw > per_image) tpw = (int)per_image;
+        if (tpw < 1) tpw = 1;
 #define BBDM_WINO_OUT(MO_, RES_, TPW_)                                                                                              \
-    hipLaunchKernelGGL((winograd_output_lds_kernel<MO_, RES_, TPW_>), dim3((unsigned)(((T + TPW_ - 1) / TPW_) * (size_t)(Cm / 128))), \
+    hipLaunchKernelGGL((winograd_output_lds_kernel<MO_, RES_, TPW_>), dim3((unsigned)(((T + tpw - 1) / tpw) * (size_t)(Cm / 128))), \
                        dim3((MO_ + 2) * 64), 0, s_, M, Tp * (size_t)Cm, Cm, splits, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, \
-                       Cm / 128, (long long)T, st, ph)
+                       Cm / 128, (long long)T, st, ph, tpw)
 #define BBDM_WINO_OUT_M(MO_)                                                                                   \
     do {                                                                                                       \
         if (tpw == 1) { if (residual) BBDM_WINO_OUT(MO_, true, 1); else BBDM_WINO_OUT(MO_, false, 1); }        \
@@ -1260,8 +1323,9 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
 }
 
 extern "C" int bbdm_winograd_output_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
-                                              float* out, int ldo, int flags, int N, int H, int W, int Cout, double* stats0,
-                                              int cpg0, int coff0, double* stats1, int cpg1, int coff1, void* stream) {
+                                              float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stats0,
+                                              int cpg0, int coff0, void* stats1, int cpg1, int coff1,
+                                              void* stream) {
     return bbdm_winograd_output_splitk_stats_f32(m, M, bias, residual, ldr, out, ldo, flags, N, H, W, Cout, stats0, cpg0, coff0,
                                                  stats1, cpg1, coff1, 1, stream);
 }

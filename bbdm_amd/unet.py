@@ -652,7 +652,8 @@ class UNetModel(nn.Module):
         # ... with the A operand split into its three bf16 planes by the Winograd input transform (csrc/gemm_bf3p.hip: the GEMM's main
         # loop is LDS-DMA copies + MFMAs); layers whose fp32 V the training backward re-reads keep the kernel above.  0: never.
         self.gemm_bf3p: bool = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
-        self.bf3_min_tiles: int = 256       # 1x1 layers with fewer 256x128 output tiles keep the split-K f32 kernel (one wave of tiles)
+        # 1x1 layers with fewer 256x128 output tiles keep the split-K f32 kernel (one wave of tiles); BBDM_BF3_MIN_TILES for the A/B
+        self.bf3_min_tiles: int = int(os.environ.get("BBDM_BF3_MIN_TILES", "256"))
         # wide 1x1 layers whose Cout fills 256-column tiles on the pipelined fp32-A kernel (gemm_bf3q_pipe_kernel); BBDM_CONV1X1_PIPE=0:
         # gemm_bf3.hip everywhere (A/B; bit-equal results)
         self.conv1x1_pipe: bool = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
@@ -794,7 +795,10 @@ class _Plan:
         self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
         for b in self.bufs:
             b.tensor = torch.empty(max(1, b.numel), **f32)
-        self.stats = torch.zeros(max(1, self._gn_count) * self.N * self.GROUPS * 2, dtype=torch.float64, device=self.device)
+        # GroupNorm statistics: one exact integer-limb accumulator per GroupNorm (csrc/stats_acc.h: order-independent sums, so a step is
+        # bitwise reproducible), all zeroed by ONE fill per forward
+        self._stats_slot_bytes = int(self.lib.bbdm_groupnorm_stats_bytes(self.N, self.GROUPS))
+        self.stats = torch.zeros(max(1, self._gn_count) * self._stats_slot_bytes // 8, dtype=torch.int64, device=self.device)
         self._param_key = None
         self._bound: List[tuple] = []
         self._graph, self._graph_key = None, None
@@ -970,7 +974,7 @@ class _Plan:
 
         def resolve(self):
             p = self.plan
-            return p.stats.data_ptr() + 8 * self.slot * p.N * p.GROUPS * 2
+            return p.stats.data_ptr() + self.slot * p._stats_slot_bytes
 
     def _pref(self, p):
         if p is None:
@@ -1078,6 +1082,9 @@ class _Plan:
         sc = _TensorRef(self._coeff_bufs[k % 2][0])
         bi = _TensorRef(self._coeff_bufs[k % 2][1])
         film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
+        # (One small launch per fused GroupNorm: 41 x ~6.6 us per forward.  Folding it into the launch that completes the statistics --
+        # last-workgroup ticket + the fold there, coefficients formed by the consumer -- was built and measured in round 4 and LOST at
+        # every size: profiles/r04_stats_tail_negative.md.)
         self._op("bbdm_groupnorm_coeffs_f32", ref, self._pref(gn.weight), self._pref(gn.bias), film, self.film_total, sc, bi,
                  x.C, N, x.H * x.W, x.C, self.GROUPS, float(gn.eps))
         return x, (sc, bi, x.C, silu)
@@ -1456,12 +1463,23 @@ class _Plan:
         """
         m, N, lib, dev = self.m, self.N, self.lib, self.device
         G = self.GROUPS
-        # parameter -> offset in the flat gradient buffer (order of m.parameters())
+        # parameter -> offset in the flat gradient buffer.  The FiLM projections (every ResBlock's emb_layers.1) come FIRST, weights then
+        # biases, in the order of the concatenated [film_total x 4 mc] GEMM that computes their gradients (_backward_embedding): that GEMM
+        # then writes the parameter gradients in place (round 3 copied 2 x 21 slices out of a scratch tensor per micro-step); the other
+        # parameters follow in m.parameters() order.
         self.param_list = list(m.parameters())
         self.grad_off, off = {}, 0
+        for rb in self.resblocks:
+            self.grad_off[id(rb.emb_layers[1].weight)] = off
+            off += rb.emb_layers[1].weight.numel()
+        self._film_b_off = off
+        for rb in self.resblocks:
+            self.grad_off[id(rb.emb_layers[1].bias)] = off
+            off += rb.emb_layers[1].bias.numel()
         for p in self.param_list:
-            self.grad_off[id(p)] = off
-            off += p.numel()
+            if id(p) not in self.grad_off:
+                self.grad_off[id(p)] = off
+                off += p.numel()
         self.grad_total = off
         self._flat_grad = None
         gref = lambda p: _Plan._GradRef(self, self.grad_off[id(p)])
@@ -1751,8 +1769,6 @@ class _Plan:
         self._ws_d2.t = torch.empty(ws_doubles[0], dtype=torch.float64, device=dev)
         # embedding-path backward scratch
         ted = 4 * m.model_channels
-        self.dfilm_w = torch.empty(self.film_total, ted, **f32)
-        self.dfilm_b = torch.empty(self.film_total, **f32)
         self.d_emb = torch.empty(N, ted, **f32)
         self.d_e1 = torch.empty(N, ted, **f32)
         self._lin_ws = torch.empty(max(lib.bbdm_linear_bwd_workspace_floats(min(N, self.emb_rows), ted, self.film_total),
@@ -1942,10 +1958,13 @@ class _Plan:
         te0, te2 = m.time_embed[0], m.time_embed[2]
         first = True
         R = self.emb_rows
+        # (the FiLM gradients land in the flat buffer itself: its first film_total x (4 mc + 1) floats, see _emit_backward)
+        dfilm_w = flat[: self.film_total * ted].view(self.film_total, ted)
+        dfilm_b = flat[self._film_b_off: self._film_b_off + self.film_total]
         for r0 in range(0, N, R):
             r = min(R, N - r0)
-            tgt_w = self.dfilm_w if first else torch.empty_like(self.dfilm_w)
-            tgt_b = self.dfilm_b if first else torch.empty_like(self.dfilm_b)
+            tgt_w = dfilm_w if first else torch.empty_like(dfilm_w)
+            tgt_b = dfilm_b if first else torch.empty_like(dfilm_b)
             call("bbdm_linear_bwd_f32", self.dfilm.data_ptr() + 4 * r0 * self.film_total,
                  self.emb.data_ptr() + 4 * r0 * ted, self.film_w.data_ptr(), self.d_emb.data_ptr() + 4 * r0 * ted,
                  tgt_w.data_ptr(), tgt_b.data_ptr(), self._lin_ws.data_ptr(), r, ted, self.film_total, 1, stream)
@@ -1960,17 +1979,10 @@ class _Plan:
                  te0.weight.data_ptr(), None, g0w.data_ptr(), g0b.data_ptr(), self._lin_ws.data_ptr(), r, mc, ted, 0,
                  stream)
             if not first:                      # batch > 64: sum the per-chunk weight gradients
-                self.dfilm_w += tgt_w; self.dfilm_b += tgt_b
+                dfilm_w += tgt_w; dfilm_b += tgt_b
                 gslice(te2.weight).add_(g2w); gslice(te2.bias).add_(g2b)
                 gslice(te0.weight).add_(g0w); gslice(te0.bias).add_(g0b)
             first = False
-        off = 0
-        for rb in self.resblocks:
-            lin = rb.emb_layers[1]
-            n = lin.out_features
-            gslice(lin.weight).copy_(self.dfilm_w[off:off + n])
-            gslice(lin.bias).copy_(self.dfilm_b[off:off + n])
-            off += n
         dx_in = None
         if need_dx:
             v = self.dx0

@@ -32,6 +32,9 @@ extern "C" {
 #define BBDM_E_BADARG (-1)   /* unsupported shape / misaligned pointer / bad enum */
 #define BBDM_E_LAUNCH (-2)   /* hipLaunchKernel reported an error             */
 
+/* GroupNorm statistics accumulator (layout and rationale: the GroupNorm section below, csrc/stats_acc.h) */
+typedef void bbdm_stats_t;
+
 /* ---- library ---------------------------------------------------------------------------------------- */
 int bbdm_version(void);                       /* ABI version, bumped on any signature change           */
 const char* bbdm_last_error(void);            /* text of the last error on the calling thread          */
@@ -86,7 +89,7 @@ int bbdm_conv2d_nhwc_f32(const float* x, int ldx, const float* packed_w, const f
 
 /* The same convolution with the GroupNorm statistics of its OUTPUT accumulated in the epilogue (every conv output of the
  * UNet is normalised next: openaimodel.py:205,229,306,688) instead of by a separate bbdm_groupnorm_stats_f32 pass that
- * re-reads the tensor.  stats0 / stats1 (either may be NULL): fp64 [N][32][2] accumulators (sum, sum of squares per image
+ * re-reads the tensor.  stats0 / stats1 (either may be NULL): accumulators (bbdm_stats_t, G = 32: sum, sum of squares per image
  * and 32-group index) of up to two consumers of `out` -- the next block's GroupNorm and, through the copy-free concat, an
  * output block's; cpg = channels per group of that consumer, coff = channel offset of `out` inside the consumer's tensor.
  * The caller zeroes them; the kernel adds.  Only where bbdm_conv_stats_fusable() says so (no split-K, one image per tile). */
@@ -94,8 +97,8 @@ int bbdm_conv_stats_fusable(int N, int H, int W, int CinPad, int Cout, int ks);
 int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, const float* bias,
                                const float* residual, int ldr, float* out, int ldo, int flags, float* ws, size_t ws_floats,
                                const float* pre_scale, const float* pre_bias, int pre_ld, int pre_silu,
-                               int N, int H, int W, int CinPad, int Cout, int ks, double* stats0, int cpg0, int coff0,
-                               double* stats1, int cpg1, int coff1, void* stream);
+                               int N, int H, int W, int CinPad, int Cout, int ks, bbdm_stats_t* stats0, int cpg0, int coff0,
+                               bbdm_stats_t* stats1, int cpg1, int coff1, void* stream);
 
 /* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2 or 4 [6: experimental] (same call sites, wide layers) */
 /* Y = A^T[(G g G^T) (.) (B^T d B)]A: (m+2)^2 multiplies per m^2 outputs instead of 9 m^2 -- 2.25x (m = 2) or 4x (m = 4)
@@ -142,8 +145,8 @@ int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed_wino, floa
                            int Cout, void* stream);
 /* stage (3) with the output's GroupNorm statistics accumulated (see bbdm_conv2d_nhwc_stats_f32; cpg % 4 == 0) */
 int bbdm_winograd_output_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
-                                   int ldo, int flags, int N, int H, int W, int Cout, double* stats0, int cpg0, int coff0,
-                                   double* stats1, int cpg1, int coff1, void* stream);
+                                   int ldo, int flags, int N, int H, int W, int Cout, bbdm_stats_t* stats0, int cpg0, int coff0,
+                                   bbdm_stats_t* stats1, int cpg1, int coff1, void* stream);
 int bbdm_winograd_output_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
                              int ldo, int flags, int N, int H, int W, int Cout, void* stream);
 
@@ -191,12 +194,19 @@ int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, float* out, in
                             void* stream);
 
 /* ---- GroupNorm (util.py:199-216; sites openaimodel.py:205,229,306,688) -------------------------------- */
-/* Accumulate per-(n, group) sum and sum-of-squares of x into stats[N][G][2] (fp64, must be zeroed by the
- * caller, e.g. one hipMemsetAsync per forward for all GroupNorms). */
-int bbdm_groupnorm_stats_f32(const float* x, int ldx, double* stats, int N, int HW, int C, int G, void* stream);
+/* GroupNorm statistics live in an EXACT, order-independent accumulator (csrc/stats_acc.h): per (image, group) the sum and the
+ * sum of squares as integer limbs, [N][G][2][4] 64-bit words = bbdm_groupnorm_stats_bytes(N, G) bytes, zeroed by the caller
+ * (one memset per forward for all GroupNorms).  Producers add with integer atomics, so the value does not depend on the
+ * order in which their workgroups finish (the reference pins its kernels with cudnn.deterministic, main.py:57-65);
+ * consumers fold the limbs back into fp64.  `stats` arguments below are pointers to such accumulators (`bbdm_stats_t`). */
+size_t bbdm_groupnorm_stats_bytes(int N, int G);
+/* sums_out[N][G][2] (fp64: sum, sum of squares) = the accumulated values (tests, diagnostics). */
+int bbdm_groupnorm_stats_read_f64(const bbdm_stats_t* stats, double* sums_out, int N, int G, void* stream);
+/* Accumulate per-(n, group) sum and sum-of-squares of x into stats. */
+int bbdm_groupnorm_stats_f32(const float* x, int ldx, bbdm_stats_t* stats, int N, int HW, int C, int G, void* stream);
 /* scale_out / bias_out [N][ld]: GN(x)[n,:,:,c] [* (1 + film scale) + film shift] == x * scale_out[n][c] + bias_out[n][c],
  * from the statistics above -- the coefficients bbdm_conv2d_nhwc_f32 applies on the fly (pre_scale / pre_bias). */
-int bbdm_groupnorm_coeffs_f32(const double* stats, const float* gamma, const float* beta, const float* film, int film_ld,
+int bbdm_groupnorm_coeffs_f32(const bbdm_stats_t* stats, const float* gamma, const float* beta, const float* film, int film_ld,
                               float* scale_out, float* bias_out, int ld, int N, int HW, int C, int G, float eps,
                               void* stream);
 /* y = resample( act( GN(x) [* (1 + scale) + shift] ) )  --  the fused run
@@ -206,7 +216,7 @@ int bbdm_groupnorm_coeffs_f32(const double* stats, const float* gamma, const flo
  * silu: 0/1.  resample: 0 none, 1 avg-pool 2x2 (H, W even), 2 nearest x2, 3 keep the even positions (turns a stride-1
  * conv output into the stride-2, pad-1 conv of Downsample(use_conv=True), openaimodel.py:153-156), 4 keep the odd positions
  * (the stride-2 conv on a (0,1,0,1)-padded input of the VQGAN's Downsample, model/VQGAN/model.py:68-72).  H, W are INPUT dims. */
-int bbdm_groupnorm_apply_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
+int bbdm_groupnorm_apply_f32(const float* x, int ldx, const bbdm_stats_t* stats, const float* gamma, const float* beta,
                              const float* film, int film_ld, float* y, int ldy, int N, int H, int W, int C, int G,
                              float eps, int silu, int resample, void* stream);
 
@@ -281,7 +291,7 @@ int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gs
  *   dgamma / dbeta [C] are overwritten; dfilm (may be NULL) receives [N][dfilm_ld] d scale at [c], d shift at [C+c]
  *   ws   : bbdm_groupnorm_bwd_workspace_doubles() fp64 elements of scratch. */
 size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G);
-int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const double* stats, const float* gamma, const float* beta,
+int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const bbdm_stats_t* stats, const float* gamma, const float* beta,
                            const float* film, int film_ld, const float* da, int ldda, const float* dadd, int ldadd,
                            float* dx, int lddx, int accumulate, float* dgamma, float* dbeta, float* dfilm,
                            int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
@@ -411,8 +421,8 @@ int bbdm_winograd_gemm_bf3p_splits(int m, int N, int H, int W, int CinPad, int C
 int bbdm_winograd_gemm_bf3p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
                                        int Cout, int splits, void* stream);
 int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr, float* out,
-                                          int ldo, int flags, int N, int H, int W, int Cout, double* stats0, int cpg0, int coff0,
-                                          double* stats1, int cpg1, int coff1, int splits, void* stream);
+                                          int ldo, int flags, int N, int H, int W, int Cout, bbdm_stats_t* stats0, int cpg0, int coff0,
+                                          bbdm_stats_t* stats1, int cpg1, int coff1, int splits, void* stream);
 
 /* ---- Winograd-domain weight gradient on the same bf16x3 GEMM (training; csrc/gemm_bf3p.hip, csrc/winograd.hip) --------- */
 /* Replaces bbdm_gemm_tn_batched_f32 (f32 MFMA) in dW = G^T [ sum_tiles V_xi^T dM_xi ] G (autograd of nn.Conv2d 3x3 at

@@ -171,10 +171,26 @@ def groupnorm_coeffs(stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tenso
     return sc, bi
 
 
+def new_stats(N: int, groups: int = 32, device=None) -> torch.Tensor:
+    """A zeroed GroupNorm statistics accumulator (csrc/stats_acc.h: [N][G][2][4] 64-bit words, exact integer limbs)."""
+    nbytes = _lib.load().bbdm_groupnorm_stats_bytes(N, groups)
+    assert nbytes == N * groups * 2 * 4 * 8
+    return torch.zeros(N, groups, 2, 4, dtype=torch.int64, device=device)
+
+
+def read_stats(acc: torch.Tensor) -> torch.Tensor:
+    """The accumulated (sum, sum of squares) of an accumulator as fp64 [N, G, 2] (bbdm_groupnorm_stats_read_f64)."""
+    N, G = acc.shape[0], acc.shape[1]
+    out = torch.empty(N, G, 2, dtype=torch.float64, device=acc.device)
+    _lib.call("bbdm_groupnorm_stats_read_f64", acc.data_ptr(), out.data_ptr(), N, G, _st(acc))
+    return out
+
+
 def groupnorm_stats(x: torch.Tensor, groups: int = 32) -> torch.Tensor:
+    """-> the statistics ACCUMULATOR of x (read_stats() gives the fp64 sums)."""
     _chk(x)
     N, H, W, C = x.shape
-    stats = torch.zeros(N, groups, 2, dtype=torch.float64, device=x.device)
+    stats = new_stats(N, groups, x.device)
     _lib.call("bbdm_groupnorm_stats_f32", x.data_ptr(), C, stats.data_ptr(), N, H * W, C, groups, _st(x))
     return stats
 

@@ -358,7 +358,7 @@ def test_winograd_splitk_stages(dev, m, N, H, W, Cin, Cout, splits):
     M = torch.full((ks * P * tiles * Cout,), float("nan"), device=dev)
     out = torch.empty(N, H, W, Cout, device=dev)
     cpg = Cout // 8 if Cout % 32 == 0 else 0
-    stats = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    stats = ops.new_stats(N, 32, dev)
     _lib.call("bbdm_winograd_input_bf3p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), None, None, 0, 0, 0, N, H, W, Cin, st)
     _lib.call("bbdm_winograd_gemm_bf3p_splitk_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, ks, st)
     _lib.call("bbdm_winograd_output_splitk_stats_f32", m, M.data_ptr(), bg.data_ptr(), rg.data_ptr(), Cout, out.data_ptr(), Cout, 0,
@@ -371,7 +371,7 @@ def test_winograd_splitk_stages(dev, m, N, H, W, Cin, Cout, splits):
     assert e < WINO_TOL[m]
     if cpg:
         s_ref = o.double().reshape(N, 8, -1).sum(-1)
-        assert float((stats.cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
+        assert float((ops.read_stats(stats).cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout,pre", [(6, 2, 12, 20, 32, 40, 1), (4, 1, 8, 16, 16, 24, 0), (2, 3, 4, 6, 16, 8, 1),
@@ -413,7 +413,7 @@ def test_upsample_conv_as_phase_filters(dev, m, N, H, W, Cin, Cout, pre):
     out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device=dev)
     xg, scg, big, bg = _nhwc(x).to(dev), sc.to(dev), bi.to(dev), b.to(dev)
     cpg = Cout // 8 if Cout % 32 == 0 else 0
-    stats = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    stats = ops.new_stats(N, 32, dev)
     _lib.call("bbdm_winograd_input_bf3p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), scg.data_ptr() if pre else None,
               big.data_ptr() if pre else None, Cin, pre, 0, N, H, W, Cin, st)
     _lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cin, 4 * Cout, st)
@@ -428,7 +428,7 @@ def test_upsample_conv_as_phase_filters(dev, m, N, H, W, Cin, Cout, pre):
     assert e < WINO_TOL[m]
     if cpg:
         s_ref = o.double().reshape(N, 8, -1).sum(-1)
-        assert float((stats.cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
+        assert float((ops.read_stats(stats).cpu()[:, :8, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72),
@@ -595,8 +595,8 @@ def test_winograd_output_accumulates_groupnorm_statistics(dev, m, N, H, W, Cin, 
     out = r.clone().to(dev)                                       # in-place residual
     cpg0, coff1 = Cout // 32 * 4 if Cout >= 128 else 4, 64                   # consumer 1: a [64 + Cout]-channel concat
     cpg1 = max(8, (-(-(coff1 + Cout) // 32) + 3) // 4 * 4)
-    s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
-    s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    s0 = ops.new_stats(N, 32, dev)
+    s1 = ops.new_stats(N, 32, dev)
     _lib.call("bbdm_winograd_input_f32", m, xg.data_ptr(), Cin, V.data_ptr(), None, None, 0, 0, 0, N, H, W, Cin, st)
     _lib.call("bbdm_winograd_gemm_f32", m, V.data_ptr(), pw.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, st)
     _lib.call("bbdm_winograd_output_stats_f32", m, M.data_ptr(), b.to(dev).data_ptr(), out.data_ptr(), Cout, out.data_ptr(),
@@ -607,7 +607,7 @@ def test_winograd_output_accumulates_groupnorm_statistics(dev, m, N, H, W, Cin, 
     assert rel_err(y, ref.float()) < WINO_TOL[m]
     for got, cpg, coff in ((s0, cpg0, 0), (s1, cpg1, coff1)):
         want = _group_sums(y, cpg, coff)
-        assert float((got.cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
+        assert float((ops.read_stats(got).cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
 
 
 def test_conv2d_accumulates_groupnorm_statistics(dev):
@@ -625,8 +625,8 @@ def test_conv2d_accumulates_groupnorm_statistics(dev):
     xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
     pk = ops.pack_conv_weight(w.to(dev), cin_pad=Cin)
     out = torch.empty(N, H, W, Cout, device=dev)
-    s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
-    s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    s0 = ops.new_stats(N, 32, dev)
+    s1 = ops.new_stats(N, 32, dev)
     st = None if dev.type != "cuda" else torch.cuda.current_stream().cuda_stream
     _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), b.to(dev).data_ptr(), None, 0, out.data_ptr(),
               Cout, 0, None, 0, None, None, 0, 0, N, H, W, Cin, Cout, 3, s0.data_ptr(), 2, 0, s1.data_ptr(), 4, 32, st)
@@ -635,7 +635,7 @@ def test_conv2d_accumulates_groupnorm_statistics(dev):
     assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < TOL
     for got, cpg, coff in ((s0, 2, 0), (s1, 4, 32)):
         want = _group_sums(y, cpg, coff)
-        assert float((got.cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
+        assert float((ops.read_stats(got).cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
     with pytest.raises(_lib.BBDMHipError, match="statistics"):
         _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), None, None, 0, out.data_ptr(), Cout, 0, None,
                   0, None, None, 0, 0, 8, 4, 4, Cin, Cout, 3, s0.data_ptr(), 2, 0, None, 0, 0, st)
@@ -657,8 +657,8 @@ def test_stem_conv_accumulates_groupnorm_statistics(dev, Cin):
     xg = ops.nchw_to_nhwc(x.to(dev), cpad=Cin)
     pk = ops.pack_conv_weight(w.to(dev), cin_pad=Cin)
     out = torch.empty(N, H, W, Cout, device=dev)
-    s0 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
-    s1 = torch.zeros(N, 32, 2, dtype=torch.float64, device=dev)
+    s0 = ops.new_stats(N, 32, dev)
+    s1 = ops.new_stats(N, 32, dev)
     st = None if dev.type != "cuda" else torch.cuda.current_stream().cuda_stream
     _lib.call("bbdm_conv2d_nhwc_stats_f32", xg.data_ptr(), Cin, pk.data_ptr(), b.to(dev).data_ptr(), None, 0, out.data_ptr(),
               Cout, 0, None, 0, None, None, 0, 0, N, H, W, Cin, Cout, 3, s0.data_ptr(), 4, 0, s1.data_ptr(), 8, 64, st)
@@ -668,7 +668,7 @@ def test_stem_conv_accumulates_groupnorm_statistics(dev, Cin):
     assert rel_err(_nchw(y), F.conv2d(x, w, b, padding=1)) < TOL
     for got, cpg, coff in ((s0, 4, 0), (s1, 8, 64)):
         want = _group_sums(y, cpg, coff)
-        assert float((got.cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
+        assert float((ops.read_stats(got).cpu() - want).abs().max()) < 1e-9 * max(1.0, float(want.abs().max()))
 
 
 def test_conv3x3_winograd_rejects_bad_shapes(dev):

@@ -178,7 +178,7 @@ def main():
                     M = torch.randn(P * (tiles * C + PAD_BYTES // 4), device=dev)
                     b = torch.randn(C, device=dev)
                     y = torch.empty_like(x)
-                    stats = torch.zeros(N * 64, dtype=torch.float64, device=dev)
+                    stats = torch.zeros(N * 64 * 4, dtype=torch.int64, device=dev)      # exact limb accumulator (csrc/stats_acc.h)
                     fn = lambda: lib.bbdm_winograd_output_stats_f32(m, M.data_ptr(), b.data_ptr(), x.data_ptr(), C, y.data_ptr(), C, 0, N, H,
                                                                     W, C, stats.data_ptr(), max(4, C // 32), 0, None, 0, 0, st)
                     gb = (P * tiles * C * 4 + 2 * x.numel() * 4) / 1e9
