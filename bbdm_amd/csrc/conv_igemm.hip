@@ -575,6 +575,9 @@ __global__ void __launch_bounds__(256) conv3x3_narrow_kernel(const ConvArgs a) {
     }
 }
 
+// CONTRACT of this kernel and of the few-output-channel kernels above: the channels of x between the true and the padded input width must
+// be ZERO (not merely multiplied by zero weights: 0 x NaN propagates).  bbdm_nchw_to_nhwc_f32 writes them as zeros; every other producer
+// of these kernels' inputs writes whole 4-channel groups of real data.
 // ---- 3x3 convolution with 4 or 8 (padded) input channels and 128 output channels (the UNet stem: concat(x_t, y) -> 128, ------
 // openaimodel.py:524; the latent UNets' 3 -> 128; the VQGAN encoder's first layer) on the f32 MFMA with K = 9 taps x CIN in ONE stage.  The implicit-GEMM kernel above walks K in
 // 16-channel chunks per tap -- half of every chunk is padding here, and nine staging rounds with a barrier each carry 8 k of work:

@@ -1836,6 +1836,13 @@ class _Plan:
         ``torch.autograd.grad`` or kept by the caller across ``zero_grad(set_to_none=True)``, no DDP bucket view."""
         use_count = getattr(torch._C, "_storage_Use_Count", None)
         if use_count is None:
+            # a private torch symbol: without it no buffer is ever recycled (correct, but every backward allocates and zero-fills a
+            # fresh 0.95 GB gradient buffer) -- say so once instead of silently doubling the training step's memory traffic
+            if not getattr(_Plan, "_warned_use_count", False):
+                _Plan._warned_use_count = True
+                import warnings
+                warnings.warn("bbdm_amd: torch._C._storage_Use_Count is not available in this torch build; the flat gradient "
+                              "buffer of the training plan is re-allocated on every backward pass instead of being recycled")
             return False                                   # cannot tell: never recycle
         return use_count(t.untyped_storage()._cdata) <= 2  # t + the temporary storage handle of this query
 

@@ -598,6 +598,12 @@ def run_workload(args, env):
                     shp = "N{} {}x{} C{} silu{} rs{}".format(oargs[9], oargs[10], oargs[11], oargs[12], oargs[15], oargs[16])
                 elif name == "bbdm_groupnorm_stats_f32":
                     shp = "N{} HW{} C{}".format(oargs[3], oargs[4], oargs[5])
+                elif name == "bbdm_conv_wgrad_f32":
+                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[7:13])
+                elif name == "bbdm_gemm_bf3p_tn_f32":
+                    shp = "P{} tiles{} {}x{}".format(*oargs[3:7])
+                elif name == "bbdm_groupnorm_bwd_f32":
+                    shp = "N{} {}x{} C{} silu{} rs{}".format(oargs[19], oargs[20], oargs[21], oargs[22], oargs[25], oargs[26])
                 else:
                     shp = ""
                 tf = fl / (ms * 1e-3) / 1e12 if ms > 0 and fl else 0.0

@@ -4,12 +4,14 @@
 # traffic_step, and the SQ pass behind roofline.mfma_util.
 #   bash tools/run_round_measurements.sh r03        -> gpurun_out/<tag>/..., summaries to copy into profiles/
 set -u
-TAG=${1:-r03f}
+TAG=${1:-r04}
 O=gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-( timeout 600 python bench.py --steps 20 --warmup 5 --dump-ops $O/c2_per_launch.md > $O/bench_c2.json 2> $O/bench_c2.err )
+# the driver's own command first (c2 headline + the four other configs in `workloads`), then c2 alone with the per-launch table
+( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err )
+( timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --dump-ops $O/c2_per_launch.md > $O/bench_c2.json 2> $O/bench_c2.err )
 for w in c1 c3 c5; do ( timeout 300 python bench.py --workload $w --no-cpu > $O/bench_$w.json 2> $O/bench_$w.err ); done
 ( timeout 600 python bench.py --workload c4 --no-cpu --dump-ops $O/c4_per_launch.md > $O/bench_c4.json 2> $O/bench_c4.err )
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c2 -o c2 -- env BBDM_HIP_GRAPH=0 python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/prof_c2.log 2>&1 )
@@ -30,6 +32,7 @@ head -14 $O/c2_kernel_stats.md; head -16 $O/c4_kernel_stats.md; python -c "
 import json
 for w in ('c2','c1','c3','c5','c4'):
     d=json.load(open('$O/bench_%s.json' % w)); print(w, round(d['ms_per_step'],2), 'ms', round(d['value'],3), 'frac', round(d['roofline']['frac'],3), 'frac_step', round(d['roofline']['frac_step'],3), {k:v for k,v in (d['parity'] or {}).items() if k.startswith('rel_err')})
+d=json.load(open('$O/bench_default.json')); print('default line:', round(d['ms_per_step'],2), {w: (round(v['ms_per_step'],3), round(v['frac_step'],3)) for w, v in d['workloads'].items()})
 d=json.load(open('$O/pmc_c2_traffic.json')); print({k: round(v['fabric_bytes_per_launch_corrected']/1e9,3) for k,v in d['kernels'].items() if v['fabric_bytes_per_launch_corrected']>1e8}); print(d['totals'])
 d=json.load(open('$O/pmc_c2_mfma_util.json')); print({k[:40]: (round(v['MfmaUtil%'],1) if v.get('MfmaUtil%') else None, v.get('clock_GHz')) for k,v in d['kernels'].items() if v.get('MfmaUtil%')})"
 tail -3 $O/pmc_err.log
