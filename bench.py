@@ -665,11 +665,14 @@ def run_workload(args, env):
     traffic = None
     traffic_step = None
     import glob
+    # kernel-name prefix of the dominant kernel in the rocprofv3 tables (gemm_bf3_kernel also serves the few narrow 1x1 layers: only
+    # counted where it IS the tile-GEMM kernel)
+    dom_prefix = ("gemm_bf3p_" if bf3p_ops >= bf3_ops else "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32"
     try:
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
-            hits = [v for k, v in pm["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in pm["kernels"].items() if k.startswith(dom_prefix)]
             if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
                 nl = sum(v["launches"] for v in hits)
                 traffic = {"bytes_per_launch": sum(v["fabric_bytes_per_launch_corrected"] * v["launches"] for v in hits) / nl,
@@ -689,7 +692,7 @@ def run_workload(args, env):
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_mfma_util.json")))
         if cands:
             mu = json.load(open(cands[-1]))
-            hits = [v for k, v in mu["kernels"].items() if k.startswith(("gemm_bf3p_", "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32")]
+            hits = [v for k, v in mu["kernels"].items() if k.startswith(dom_prefix)]
             hits = [v for v in hits if v.get("MfmaUtil%") is not None]
             if hits:
                 wt = [v.get("launches", 0) * v.get("avg_us", 0.0) for v in hits]          # time each instantiation ran
