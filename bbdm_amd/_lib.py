@@ -75,7 +75,7 @@ SIGNATURES = {
     "bbdm_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_bb_q_sample_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "bbdm_bb_p_sample_step_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_int,
-                                          _P, _P, c_int, c_int, _P]),
+                                          _P, _P, _P, c_int, c_int, _P]),
     "bbdm_bb_predict_x0_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "bbdm_bb_loss_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
     "bbdm_gemm_packed_b_floats": (c_size_t, [c_int, c_int]),

@@ -48,7 +48,8 @@ __global__ void predict_x0_kernel(const float* __restrict__ x_t, const float* __
 __global__ void p_step_kernel(const float* __restrict__ x_t, const float* __restrict__ y, const float* __restrict__ pred,
                               const float* __restrict__ noise, const float* __restrict__ m_tab,
                               const float* __restrict__ var_tab, int t, int t_next, int is_last, float eta, int clip,
-                              int objective, float* __restrict__ x_next, float* __restrict__ x0_recon, size_t total) {
+                              int objective, float* __restrict__ x_next, float* __restrict__ x0_recon,
+                              float* __restrict__ x_next_alias, size_t total) {
     const float m_t = m_tab[t], var_t = var_tab[t];
     const float sig_obj = sqrtf(var_t);
     float m_nt = 0.f, sigma_t = 0.f, coef = 0.f;
@@ -69,10 +70,13 @@ __global__ void p_step_kernel(const float* __restrict__ x_t, const float* __rest
         x0_recon[i] = x0r;
         if (is_last) {
             x_next[i] = x0r;
+            if (x_next_alias) x_next_alias[i] = x0r;
         } else {
             // (1 - m_nt) x0 + m_nt y + sqrt((var_nt - sigma2)/var_t) (x_t - (1 - m_t) x0 - m_t y) + sigma_t eps
             const float mean = (1.f - m_nt) * x0r + m_nt * yy + coef * (xt - (1.f - m_t) * x0r - m_t * yy);
-            x_next[i] = mean + sigma_t * noise[i];
+            const float xn = mean + sigma_t * noise[i];
+            x_next[i] = xn;
+            if (x_next_alias) x_next_alias[i] = xn;        // second copy: the caller's input buffer of the NEXT step (see the header)
         }
     }
 }
@@ -166,15 +170,15 @@ extern "C" int bbdm_bb_predict_x0_f32(const float* x_t, const float* y, const fl
 
 extern "C" int bbdm_bb_p_sample_step_f32(const float* x_t, const float* y, const float* pred, const float* noise,
                                          const float* m_t, const float* variance_t, int t, int t_next, int is_last,
-                                         float eta, int clip, int objective, float* x_next, float* x0_recon, int N,
-                                         int per_sample, void* stream) {
+                                         float eta, int clip, int objective, float* x_next, float* x0_recon,
+                                         float* x_next_alias, int N, int per_sample, void* stream) {
     BBDM_REQUIRE(x_t && y && pred && m_t && variance_t && x_next && x0_recon, "p_sample_step: null pointer");
     BBDM_REQUIRE(is_last || noise, "p_sample_step: noise required unless is_last");
     BBDM_REQUIRE(N > 0 && per_sample > 0 && objective >= 0 && objective <= 2 && t >= 0 && (is_last || t_next >= 0),
                  "p_sample_step: bad args");
     const size_t total = (size_t)N * per_sample;
     hipLaunchKernelGGL(p_step_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x_t, y, pred, noise,
-                       m_t, variance_t, t, t_next, is_last, eta, clip, objective, x_next, x0_recon, total);
+                       m_t, variance_t, t, t_next, is_last, eta, clip, objective, x_next, x0_recon, x_next_alias, total);
     BBDM_CHECK_LAUNCH("p_sample_step");
     return BBDM_OK;
 }

@@ -221,20 +221,27 @@ class BrownianBridgeModel(nn.Module):
             # BrownianBridgeModel.py:74-77); the kernels read the tables unchecked, so the check lives here
             raise IndexError(f"timestep {max(step, nxt)} is out of range for the {self.num_timesteps}-entry schedule")
         x_t, y = _f32c(x_t), _f32c(y)
-        t = torch.full((x_t.shape[0],), step, device=x_t.device, dtype=torch.long)
         fn = self.denoise_fn
-        if isinstance(fn, UNetModel):       # the prediction is consumed by the fused kernel below at once: no per-step copy of it
-            objective_recon = fn.infer(x_t, t, context, borrow=True)
+        plan = None
+        if isinstance(fn, UNetModel):
+            # the prediction is consumed by the fused kernel below at once (no per-step copy of it); the timestep is a host integer
+            # (one fill of the plan's buffer instead of torch.full + copy); the plan skips the copies of inputs it already holds
+            objective_recon, plan = fn.infer_step(x_t, step, context)
         else:
+            t = torch.full((x_t.shape[0],), step, device=x_t.device, dtype=torch.long)
             objective_recon = fn(x_t, timesteps=t, context=context)
         is_last = step == 0
         noise = None if is_last else torch.randn_like(x_t)
         x_next, x0_recon = torch.empty_like(x_t), torch.empty_like(x_t)
+        # the loop feeds x_next back as the next x_t (BrownianBridgeModel.py:218-220): the step writes it into the plan's input buffer too
+        alias = None if (plan is None or is_last) else plan.x_in
         _launch(x_t, "bbdm_bb_p_sample_step_f32", x_t.data_ptr(), y.data_ptr(), objective_recon.data_ptr(),
                   None if noise is None else noise.data_ptr(), self.m_t.data_ptr(), self.variance_t.data_ptr(),
                   step, 0 if is_last else steps[i + 1], 1 if is_last else 0, float(self.eta),
                   1 if clip_denoised else 0, _OBJECTIVES[self.objective], x_next.data_ptr(), x0_recon.data_ptr(),
-                  x_t.shape[0], x_t[0].numel())
+                  None if alias is None else alias.data_ptr(), x_t.shape[0], x_t[0].numel())
+        if alias is not None:
+            plan.holds_input(x_next)
         if is_last:
             return x0_recon, x0_recon
         return x_next, x0_recon

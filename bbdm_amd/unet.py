@@ -686,6 +686,14 @@ class UNetModel(nn.Module):
             return unet_apply(self, x, timesteps, context)
         return self.infer(x, timesteps, context)
 
+    @torch.no_grad()
+    def infer_step(self, x, step: int, context=None):
+        """One sampling step's UNet call (BrownianBridgeModel.p_sample): every image at timestep ``step``.  Returns (the plan's own output
+        buffer -- valid until the next call with this input shape --, the plan)."""
+        x, ctx = self._check_inputs(x, context)
+        plan = self._plan_for(x, training=False)
+        return plan.run(x, int(step), ctx, None, True), plan
+
     def _check_inputs(self, x, context):
         _lib.require_gpu(x, context)
         if x.dtype != torch.float32:
@@ -2077,6 +2085,10 @@ class _Plan:
             return False
         return True
 
+    def holds_input(self, x: torch.Tensor):
+        """``x_in`` now holds the value of ``x`` (the fused bridge kernel wrote x_next there as well: csrc/bridge.hip)."""
+        self._x_src = (x, x._version)
+
     def run(self, x, t, ctx, out=None, borrow=False):
         with _lib.device_guard(self.device):        # NULL-stream launches follow the current device (see _lib.device_guard)
             return self._run(x, t, ctx, out, borrow)
@@ -2086,10 +2098,22 @@ class _Plan:
         self.generation = getattr(self, "generation", 0) + 1
         stream = _lib.current_stream(self.device)
         self._refresh_weights(stream)
-        self.x_in.copy_(x)
+        # Inputs: skip the copy of a tensor this plan already holds -- the x_next the previous sampling step also wrote into x_in
+        # (holds_input), the conditioning image that does not change during a sampling loop.  Identity AND version are checked and the
+        # source is kept alive, so neither an in-place edit nor a recycled allocation can be mistaken for it.
+        src = getattr(self, "_x_src", None)
+        if not (src is not None and src[0] is x and src[1] == x._version):
+            self.x_in.copy_(x)
+        self._x_src = None
         if self.ctx_in is not None:
-            self.ctx_in.copy_(ctx)
-        self.t_buf.copy_(t)
+            csrc = getattr(self, "_ctx_src", None)
+            if not (csrc is not None and csrc[0] is ctx and csrc[1] == ctx._version):
+                self.ctx_in.copy_(ctx)
+                self._ctx_src = (ctx, ctx._version)
+        if isinstance(t, int):
+            self.t_buf.fill_(t)                                   # (p_sample: one timestep for the whole batch)
+        else:
+            self.t_buf.copy_(t)
         prof = m.op_profile
         if prof is None and self._want_graph() and not getattr(self, "_graph_failed", False):
             # weights / parameter pointers are checked above on every call; a change re-captures

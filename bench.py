@@ -334,6 +334,8 @@ def parse_args(argv=None):
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
     ap.add_argument("--no-f32mfma", action="store_true", help="c2: skip the strict-f32-MFMA A/B steps after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked batch against the oracle")
+    ap.add_argument("--no-op-profile", action="store_true",
+                    help="skip the eager per-launch-event pass after the timed region (rocprofv3 traces of the graph replay alone)")
     ap.add_argument("--no-extras", action="store_true",
                     help="headline run (c2, one GPU): do not time the other BASELINE.json configs (c1, c3, c5, c4) after it")
     return ap.parse_args(argv)
@@ -519,7 +521,7 @@ def run_workload(args, env):
             training_info["sync_every_micro_step_ms_per_step"] = dist_utils.timed_region(timed, dist, dev) * 1e3 / args.steps
             sync_every[0] = False
     eager_ms = None
-    if plan_graph or training:
+    if (plan_graph or training) and not args.no_op_profile:
         # (training: the timed region is the plain product path as well; forward AND gradient-plan launches are timed here)
         model.denoise_fn.op_profile = prof
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

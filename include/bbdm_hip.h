@@ -261,10 +261,13 @@ int bbdm_bb_q_sample_f32(const float* x0, const float* y, const float* noise, co
                          int N, int per_sample, int objective, void* stream);
 /* One reverse step after the UNet call (BBM.py:186-201, and the steps[i]==0 branch :174-180):
  * x0_recon = predict_x0(x_t, y, t, pred) [clamped to +-1 if clip]; if last: x_next = x0_recon, else the
- * posterior mean + sigma_t * noise.  t / t_next are the scalar table indices steps[i], steps[i+1]. */
+ * posterior mean + sigma_t * noise.  t / t_next are the scalar table indices steps[i], steps[i+1].
+ * x_next_alias (may be NULL): a second destination for x_next -- the sampling loop feeds x_next straight back as the next
+ * step's x_t (BBM.py:218-220), so the step writes it into the UNet plan's input buffer as well and the next call skips its
+ * input copy (one launch less outside the replayed graph per step). */
 int bbdm_bb_p_sample_step_f32(const float* x_t, const float* y, const float* pred, const float* noise,
                               const float* m_t, const float* variance_t, int t, int t_next, int is_last,
-                              float eta, int clip, int objective, float* x_next, float* x0_recon,
+                              float eta, int clip, int objective, float* x_next, float* x0_recon, float* x_next_alias,
                               int N, int per_sample, void* stream);
 /* predict_x0_from_objective alone (BBM.py:148-160), per-sample t (used by p_losses :121). */
 int bbdm_bb_predict_x0_f32(const float* x_t, const float* y, const float* pred, const int64_t* t,

@@ -236,3 +236,9 @@ def test_first_stage_plans_on_the_emulator():
     every switch the shared emitters read (a missing one surfaced only on the GPU box in round 3)."""
     import first_stage_cases as C
     C.encode_decode_parity(CPU, N=1, resolution=16, attn_resolutions=[8])
+
+
+def test_sampling_loop_skips_input_copies_safely(monkeypatch):
+    """tests/test_model_gpu.py's check of the x_next hand-over through the plan's input buffer, on the emulated kernels."""
+    monkeypatch.setattr(M, "build", lambda rec, dev: _build(rec))
+    M.test_sampling_loop_skips_input_copies_safely(CPU)

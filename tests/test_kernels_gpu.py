@@ -924,13 +924,15 @@ def test_bridge_arithmetic(dev, objective):
             a_ref, b_ref = O.p_sample_update(bufs, steps, i, x_t_ref, y, pred, eps, objective, 0.8, bool(clip))
             xg, yg, pg, eg = (z.to(dev) for z in (x_t_ref, y, pred, eps))
             a, b = torch.empty_like(xg), torch.empty_like(xg)
+            alias = torch.full_like(xg, float("nan")) if clip else None      # the second x_next destination (the next step's input buffer)
             last = int(steps[i]) == 0
             _lib.call("bbdm_bb_p_sample_step_f32", xg.data_ptr(), yg.data_ptr(), pg.data_ptr(), eg.data_ptr(),
                       m.m_t.data_ptr(), m.variance_t.data_ptr(), int(steps[i]), 0 if last else int(steps[i + 1]),
                       int(last), 0.8, clip, {"grad": 0, "noise": 1, "ysubx": 2}[objective], a.data_ptr(),
-                      b.data_ptr(), N, C * S * S, st)
+                      b.data_ptr(), None if alias is None else alias.data_ptr(), N, C * S * S, st)
             torch.cuda.synchronize()
             assert rel_err(a.cpu(), a_ref) < 2e-6 and rel_err(b.cpu(), b_ref) < 2e-6, (i, clip)
+            assert alias is None or torch.equal(alias, a)
     for lt in ("l1", "l2"):
         m.loss_type = lt
         got = float(m._loss(tgt_ref.to(dev), pred.to(dev)))

@@ -183,3 +183,42 @@ def test_full_size_step_batch16_direct_and_winograd(dev):
             assert ea < 1e-3 and eb < 1e-3
     finally:
         torch.randn_like = orig
+
+
+def test_sampling_loop_skips_input_copies_safely(dev):
+    """p_sample hands x_next to the next step through the UNet plan's own input buffer (csrc/bridge.hip: x_next_alias) and does not
+    re-copy a conditioning image it already holds.  Same bits as feeding every step fresh clones (which forces both copies); an in-place
+    edit of x_next or of the conditioning image between steps is seen; a DIFFERENT tensor is never mistaken for the held one."""
+    rec = load_case("tiny_concat")
+    m = build(rec, dev)
+    y = rec["y"].to(dev)
+    eps = rec["p_eps"].to(dev)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps
+    try:
+        def run(fresh, edit=None):
+            img, yy = y.clone(), y.clone()
+            outs = []
+            for i in range(4):
+                if edit == "x" and i == 2:
+                    img.mul_(0.5)                              # in place: version bump, same storage
+                if edit == "y" and i == 2:
+                    yy.add_(0.25)
+                a, b = m.p_sample(img.clone() if fresh else img, yy.clone() if fresh else yy,
+                                  yy.clone() if fresh else yy, i, clip_denoised=True)
+                outs.append((a.clone(), b.clone()))
+                img = a
+            torch.cuda.synchronize()
+            return outs
+        for edit in (None, "x", "y"):
+            want, got = run(True, edit), run(False, edit)
+            for (a0, b0), (a1, b1) in zip(want, got):
+                assert torch.equal(a0, a1) and torch.equal(b0, b1), edit
+        # a different tensor with the same shape right after a step: the held x_next must not be used for it
+        a, _ = m.p_sample(y, y, y, 0, clip_denoised=True)
+        other = torch.randn_like(y) * 0 + 0.3
+        r1, _ = m.p_sample(other, y, y, 1, clip_denoised=True)
+        r2, _ = m.p_sample(other.clone(), y.clone(), y.clone(), 1, clip_denoised=True)
+        assert torch.equal(r1, r2)
+    finally:
+        torch.randn_like = orig
