@@ -160,7 +160,9 @@ int bbdm_conv_pack_weight_dgrad_f32(const float* w_oihw, float* packed, int Cout
 /* Weight gradient dW[co][ci][r][s] = sum_{n,h,w} dY[n,h,w,co] X[n,h+r-p,w+s-p,ci], written in OIHW (overwrite), and
  * (dbias != NULL) the bias gradient dbias[co] = sum_{n,h,w} dY[n,h,w,co] from the same pass over dY.
  * x: NHWC pitch ldx (Cin % 4 == 0); dy: NHWC pitch ldy; ws: bbdm_conv_wgrad_workspace_floats() floats of scratch
- * (split-K partials, reduced in a fixed order: deterministic). */
+ * (split-K partials, reduced in a fixed order: deterministic).  CONTRACT: the launcher does not receive the size of ws -- it must
+ * be the value the query returns IN THIS PROCESS for these very dimensions (the query covers every path the launcher can take,
+ * incl. the bf16-plane path of wide 1x1 layers; both latch BBDM_WGRAD1X1_BF3 once, at first use). */
 size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks);
 int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* ws,
                         int N, int H, int W, int Cin, int Cout, int ks, void* stream);
