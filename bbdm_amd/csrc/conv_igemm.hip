@@ -992,7 +992,9 @@ static ConvPlan conv_plan(long long M, int Cout, int nchunks) {
     p.big = false;
     p.splits = 1;
     if (b128 < 256 && nchunks >= 4) {
-        int want = (int)cdiv(512, (int)b128);
+        // as many splits as keep every workgroup resident at once (two 8-wave workgroups per CU = 512): rounding UP gave the qkv
+        // projections of the latent models (512 x 1024 -> 3072: 96 tiles x 6 = 576 workgroups) a second, nearly empty round
+        int want = 512 / (int)b128;
         if (want > nchunks / 2) want = nchunks / 2;
         if (want > 32) want = 32;
         p.splits = want > 1 ? want : 1;

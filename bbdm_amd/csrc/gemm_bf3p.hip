@@ -58,6 +58,9 @@ __device__ __forceinline__ int xcd_block_p(int nblk, int x, int off) {
     return start + ((x - ((c - off) & 7)) >> 3);
 }
 
+typedef int frag_t __attribute__((ext_vector_type(4)));       // one lane's 8 bf16 of an MFMA operand, as the registers it occupies
+#define BF3P_BF(x) __builtin_bit_cast(bf16x8, x)
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -93,12 +96,24 @@ __device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uin
 // launch would have given it -- and issues the first two chunk copies of its NEXT tile before it stores the current tile's
 // accumulators: the workgroup turnover (drain the stores, free 96 KB of LDS, launch, first copy latency: ~7 us of a ~145 us
 // K = 1024 tile, from the K = 1024 / K = 2048 timings) shrinks to the store issue.
-template <int WM, int WN, bool RES>
-__global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const Bf3pArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
+// NS = LDS stages (round 4).  Two serve the large problems: sixteen waves per CU and operands that mostly come from L2 keep the matrix
+// pipe fed although every iteration ends with vmcnt(0), i.e. a chunk's copies get ONE chunk of MFMAs (~0.4 us) to land.  With NS > 2
+// chunk c + NS is requested during chunk c and the iteration only waits for chunk c + 2 (counted vmcnt: the NS - 2 younger chunks stay
+// in flight; vmcnt retires in order).  The launcher (bf3p_forward) uses it for SMALL problems whose workgroups all fit the chip at once
+// with the larger LDS footprint.  Register budget: the ring's addressing does not fit the 128 VGPRs of the four-waves-per-SIMD build
+// (it spilled ~200 registers, and scratch traffic shares vmcnt with the copies: wrong results on hardware) -- NS > 2 is compiled for
+// the occupancy its LDS footprint allows anyway (NS = 3: two 4-wave workgroups per CU, deeper: one).  The same builds showed two codegen
+// traps that cost more than the ring gained until they were removed: fragments held as <8 x bf16> across the has_next branches are
+// legalised element-wise (120 v_perm / v_lshrrev per iteration), and with the branches kept the register allocator copies the whole
+// fragment set around each of them (108 v_mov_b64 per iteration) -- hence frag_t and the unconditional reads below.
+template <int WM, int WN, bool RES, int NS = 2>
+__global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) gemm_bf3p_pipe_kernel(const Bf3pArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][STAGE]
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
     constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
     constexpr int KMAX = (NU + NW - 1) / NW;
+    static_assert(NS == 2 || NU % NW == 0, "counted waits need the same number of copies per wave and chunk");
+    static_assert(NS >= 2 && (NS - 2) * KMAX <= 60, "vmcnt is a 6-bit counter");
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned lane16 = lane * 16;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,27 +180,34 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
     if (!setup(L)) return;
     float bv[2];
     load_bias(bv);
-    issue(0, smem);
-    if (n > 1) issue(1, smem + STAGE);
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+        if (k < n) issue(k, smem + k * STAGE);
 
-    bf16x8 fa[3][2], fb[3][2];                                                 // [plane][tile]
+    // (held as 4 x 32-bit: a <8 x bf16> value that lives across the has_next branches is legalised ELEMENT-wise by the compiler --
+    // 120 v_lshrrev / v_perm per iteration in the NS > 2 builds; a bit-cast at the MFMA is free)
+    frag_t fa[3][2], fb[3][2];                                                 // [plane][tile]
 #define BF3P_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
 #define BF3P_READ_A(p, base) do { BF3P_READ(fa[p][0], base, p, 0); BF3P_READ(fa[p][1], base, p, 1); } while (0)
 #define BF3P_READ_B(p, base) do { BF3P_READ(fb[p][0], base, p, 0); BF3P_READ(fb[p][1], base, p, 1); } while (0)
-#define BF3P_ALL_LANDED()                                                                                                      \
+#define BF3P_READS_RETURNED()                                                                                                  \
     do {                                                                                                                        \
-        wait_vmcnt<0>();                                                                                                        \
         asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
                      : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),          \
                        "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1])           \
                      :: "memory");                                                                                              \
     } while (0)
+#define BF3P_ALL_LANDED()                                                                                                      \
+    do {                                                                                                                        \
+        wait_vmcnt<0>();                                                                                                        \
+        BF3P_READS_RETURNED();                                                                                                  \
+    } while (0)
 #define BF3P_TERM(pa, pb)                                                                                                       \
     do {                                                                                                                        \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][0], acc[0][0], 0, 0, 0);                          \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][1], acc[0][1], 0, 0, 0);                          \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][0], acc[1][0], 0, 0, 0);                          \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][1], acc[1][1], 0, 0, 0);                          \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][0]), BF3P_BF(fb[pb][0]), acc[0][0], 0, 0, 0);                          \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][0]), BF3P_BF(fb[pb][1]), acc[0][1], 0, 0, 0);                          \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][1]), BF3P_BF(fb[pb][0]), acc[1][0], 0, 0, 0);                          \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][1]), BF3P_BF(fb[pb][1]), acc[1][1], 0, 0, 0);                          \
     } while (0)
     for (;;) {
         f32x16 acc[2][2];
@@ -207,13 +229,16 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
         BF3P_ALL_LANDED();
         asm volatile("s_barrier" ::: "memory");                                // everybody holds chunk 0: stage 0 may be overwritten
         for (int chunk = 0; chunk < n; ++chunk) {
-            const bool has_next = chunk + 1 < n;
-            const unsigned nxt = lds0 + ((chunk + 1) & 1) * STAGE;
+            // (NS > 2: the reads are unconditional -- in the last iteration they fetch a stale stage into registers nobody uses; with the
+            // branches the compiler, given the larger register budget of those builds, copied the whole fragment set around each of them:
+            // 108 v_mov_b64 per iteration)
+            const bool has_next = NS > 2 || chunk + 1 < n;
+            const unsigned nxt = lds0 + ((chunk + 1) % NS) * STAGE;
             const unsigned sa = nxt + aoff, sb = nxt + boff;
             __builtin_amdgcn_sched_barrier(0);
             BF3P_TERM(1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (chunk + 2 < n) issue(chunk + 2, smem + (chunk & 1) * STAGE);   // under the first MFMAs; stage free since the last barrier
+            if (chunk + NS < n) issue(chunk + NS, smem + (chunk % NS) * STAGE);   // under the first MFMAs; stage free since the last barrier
             __builtin_amdgcn_sched_barrier(0);
             BF3P_TERM(0, 2);
             __builtin_amdgcn_sched_barrier(0);
@@ -234,7 +259,11 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
             BF3P_TERM(0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
-            BF3P_ALL_LANDED();                                                 // my copies of chunk + 2 have landed, my reads of chunk + 1 returned
+            // my copies of chunk + 2 have landed (NS > 2: those of chunks chunk + 3 .. chunk + NS, issued after them, may stay in flight;
+            // in the last iterations fewer are behind them: wait for all), my reads of chunk + 1 returned
+            if (NS > 2 && chunk + NS < n) wait_vmcnt<(NS - 2) * KMAX>();
+            else wait_vmcnt<0>();
+            BF3P_READS_RETURNED();
             asm volatile("s_barrier" ::: "memory");                            // ... everybody's
         }
         // ---- the next tile's first copies go out before this tile's stores (both LDS stages are free: the last barrier is behind) --
@@ -245,8 +274,9 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
         L += (int)gridDim.x;
         const bool more = a.persist && setup(L);
         if (more) {
-            issue(0, smem);
-            if (n > 1) issue(1, smem + STAGE);
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (k < n) issue(k, smem + k * STAGE);
             load_bias(bv);
         }
         // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------
@@ -289,6 +319,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 4) gemm_bf3p_pipe_kernel(const B
     }
 #undef BF3P_TERM
 #undef BF3P_ALL_LANDED
+#undef BF3P_READS_RETURNED
 #undef BF3P_READ_B
 #undef BF3P_READ_A
 #undef BF3P_READ
@@ -590,13 +621,13 @@ extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_pl
     return BBDM_OK;
 }
 
-template <int WM, int WN, bool RES>
+template <int WM, int WN, bool RES, int NS = 2>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    const size_t lds = NS * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES, NS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
@@ -621,7 +652,7 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
             grid = dim3(resident);
         }
     }
-    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES, NS>), grid, dim3(WM * WN * 64), lds, st, a);
     return BBDM_OK;
 }
 
@@ -698,9 +729,20 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     auto wgs = [&](int bm, int bn) { return (long long)nb * cdiv((int)rows, bm) * cdiv(CoutPad, bn); };
     int rc;
 #define BBDM_BF3P_GO(WM, WN) (residual ? bf3p_launch<WM, WN, true>(a, nb, st) : bf3p_launch<WM, WN, false>(a, nb, st))
+#define BBDM_BF3P_GO_NS(WM, WN, NS) (residual ? bf3p_launch<WM, WN, true, NS>(a, nb, st) : bf3p_launch<WM, WN, false, NS>(a, nb, st))
     if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4) : BBDM_BF3P_GO(4, 2);
     else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2);
-    else if (g_bf3p_variant == 7 || wgs(256, 128) < small_wg) rc = BBDM_BF3P_GO(2, 2);
+    else if (g_bf3p_variant == 7 || wgs(256, 128) < small_wg || rows <= 128) {        // (<= 128 rows: a 256-row tile would be half padding)
+        // LDS stages of the 128 x 128 kernel: three when every workgroup of the launch gets a CU to itself -- nobody else's copies cover
+        // the wait for its own, and two stages expose an HBM round trip per chunk (measured per layer, profiles/r04_small_gemm_ring.md:
+        // 16 x [256 x 1024 x 1024] 61 -> 49 us, 16 x [512 x 512 x 512] 35 -> 30 us); with two or three workgroups per CU the third stage
+        // loses 5 - 8 % (one workgroup's copies already overlap the other's MFMAs, and the ring's prologue waits for one chunk more),
+        // and five stages never beat three.  BBDM_BF3P_SMALL_STAGES=2: round 3's kernel everywhere (A/B).
+        static const int max_stages = [] { const char* e = getenv("BBDM_BF3P_SMALL_STAGES"); return e ? atoi(e) : 3; }();
+        const long long w = (long long)cdiv((int)rows, 128) * cdiv(CoutPad, 128) * (a.by_batch ? (nb + 7) / 8 * 8 : nb);
+        if (max_stages >= 3 && a.nchunks / splits >= 8 && w <= bbdm_device_cus()) rc = BBDM_BF3P_GO_NS(2, 2, 3);
+        else rc = BBDM_BF3P_GO(2, 2);
+    }
     else {
         // 256 x 256 (one workgroup per CU) vs 256 x 128 (two per CU): the CU that gets the most workgroups sets the time.  Mid-size
         // problems (the 16x16 / 32x32 levels of the latent models: 288 ... 1152 tiles of 256 x 256 on 256 CUs) lose up to half a
@@ -713,6 +755,7 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
         const double t44 = wide ? rounds(256, 256) : 1e30, t42 = rounds(256, 128) * 0.5 / 0.94;
         rc = t44 <= t42 ? BBDM_BF3P_GO(4, 4) : BBDM_BF3P_GO(4, 2);
     }
+#undef BBDM_BF3P_GO_NS
 #undef BBDM_BF3P_GO
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p");
