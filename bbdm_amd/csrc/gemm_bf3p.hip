@@ -536,6 +536,203 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         }
 }
 
+// ---- small 1x1 layers: 64 x 64 tiles, 64 channels per iteration, fp32 A split at the fragment read (round 4) -------------------------
+// The 1x1 convolutions of the SMALL configurations (latent / 64^2-pixel models: qkv / proj_out of the attention blocks, the skip
+// projections; a few hundred to a few thousand pixels, K up to 2048) ran on the split-K f32-MFMA kernel (conv_igemm.hip): 96 ... 512
+// workgroups that each walk a chain of 16-channel chunks, a wait + barrier per chunk, then a second launch that adds the partial sums
+// (512 x 1024 -> 3072: 56 us; 1 ms of the 3.4 ms LBBDM-f16 step for all of them).  Such a launch is bound by the LENGTH of that chain
+// (an iteration cannot be shorter than a barrier-synchronised LDS round trip plus whatever memory latency it exposes), not by the
+// matrix pipe.  This kernel shortens the chain 4x and hides the memory latency inside the workgroup:
+//   * one iteration = FOUR chunks (64 channels): K = 1024 is 16 iterations, no split-K, bias / residual in the epilogue, one launch;
+//   * 64 x 64 output tiles (4 waves of 32 x 32) so that even 512 x 1024 gives 128 workgroups;
+//   * everything arrives by LDS-DMA into a THREE-stage ring, requested two iterations ahead (counted vmcnt waits: no register loads
+//     the compiler would guard with vmcnt(0)): B as pre-split planes (bbdm_gemm_bf3p_pack_b_f32: 12 KB contiguous per 32 couts and
+//     iteration), A as the fp32 rows lie in HBM (256 B per row and iteration);
+//   * A is split when a wave reads its fragment: a lane's 8 channels of one row = two ds_read_b128, 44 VALU instructions (bf3_split.h)
+//     that issue between the chunk's six MFMAs.  The raw tile is stored [4 rows][16 pieces of 16 B] per 1 KB copy with the piece index
+//     XOR-ed by the row (row % 16): the copy reads whole 256-B row segments from HBM, and the 16 lanes of a fragment read that sit
+//     on consecutive rows hit 16 different bank groups.
+//   * XCD-aware tile order where Cout gives a multiple of 8 column tiles: XCD c owns the column tiles c, c + 8, ... for every row
+//     tile, so a weight byte enters exactly one L2.
+// 120 KB of LDS, one workgroup per CU.  K a multiple of 64.  Arithmetic: the six product terms per 16-channel chunk in BF3_TA / BF3_TB
+// order, chunks in ascending order -- bit-equal to bbdm_conv1x1_bf3_f32 / bbdm_conv1x1_bf3q_f32.
+template <bool RES, int NS>
+__global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, const float* __restrict__ Af, int lda) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][ASTAGE + BSTAGE]
+    constexpr int CH = 4;                                                       // chunks per iteration
+    constexpr int ASTAGE = 64 * CH * KC * 4;                                    // 64 rows x 64 channels fp32 = 16 KB
+    constexpr int BSTAGE = 2 * CH * 3 * UNIT;                                   // 2 row groups x 4 chunks x 3 planes x 1 KB = 24 KB
+    constexpr int STAGE = ASTAGE + BSTAGE;
+    constexpr int KA = ASTAGE / UNIT / 4, KB = BSTAGE / UNIT / 4;               // copies per wave and iteration: 4 of A, 6 of B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned lane16 = lane * 16;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tilesM = (a.T + 63) / 64, tilesN = (a.Cout + 63) / 64;
+    int m_tile, n_tile;
+    if (a.by_batch) {                                                           // (here: "XCD-owned column tiles", see above)
+        const int L = (int)blockIdx.x, j = L >> 3;
+        n_tile = (L & 7) + 8 * (j / tilesM);
+        m_tile = j % tilesM;
+    } else {
+        m_tile = (int)blockIdx.x % tilesM;
+        n_tile = (int)blockIdx.x / tilesM;
+    }
+    if (n_tile >= tilesN) return;
+    const int row0 = m_tile * 64, cout0 = n_tile * 64;
+    const int n = a.nchunks / CH;                                               // iterations
+    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
+    // ---- A copies: copy j = wave + 4 k covers rows 4 j .. 4 j + 3 of the tile; lane = (row in copy, slot), slot holds piece slot ^ (row % 16)
+    const unsigned char* asrc[KA];
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        const int row = (wave + 4 * k) * 4 + (lane >> 4), piece = (lane & 15) ^ (row & 15);
+        const int grow = min(row0 + row, a.T - 1);                              // (a ragged last row tile re-reads the last row)
+        asrc[k] = reinterpret_cast<const unsigned char*>(Af + (size_t)grow * lda) + piece * 16;
+    }
+    // ---- B copies: the 24 units of an iteration = 2 row groups x (4 chunks x 3 planes: contiguous in HBM) --------------------------------
+    const unsigned char* bsrc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const int u = wave + k * 4, g = u / (CH * 3), v = u % (CH * 3);
+        bsrc[k] = a.B + (size_t)(n_tile * 2 + g) * gstride + (size_t)v * UNIT;
+    }
+    auto issue = [&](int it, unsigned char* st) {
+#pragma unroll
+        for (int k = 0; k < KA; ++k)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[k] + (size_t)it * (CH * KC * 4)),
+                                             (__attribute__((address_space(3))) void*)(st + (wave + 4 * k) * UNIT), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < KB; ++k) glds16(bsrc[k] + (size_t)it * (CH * 3 * UNIT), lane16, st + ASTAGE + (wave + k * 4) * UNIT);
+    };
+    // ---- fragment reads: lane = (row r = lane % 32 of the wave's 32 rows, half h = lane / 32: channels 8 h .. 8 h + 7 of a chunk) ------
+    const int R = wm * 32 + (lane & 31), h = lane >> 5;
+    const unsigned abase = (unsigned)((R >> 2) * UNIT + (R & 3) * 256);
+    unsigned aoff[CH][2];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        aoff[c][0] = abase + (unsigned)((((4 * c + 2 * h) ^ (R & 15))) * 16);
+        aoff[c][1] = abase + (unsigned)((((4 * c + 2 * h + 1) ^ (R & 15))) * 16);
+    }
+    const unsigned boff = (unsigned)(ASTAGE + (wn * CH * 3) * UNIT) + lane16;
+    float bv = 0.f;
+    {
+        const int co = cout0 + wn * 32 + (lane & 31);
+        bv = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // counted wait: iteration `it` has landed, the (at most NS - 2) younger ones that were requested may stay in flight
+    auto landed = [&](int it) {
+        const int younger = min(NS - 2, n - 1 - it);
+        if (NS >= 4 && younger >= 2) wait_vmcnt<2 * (KA + KB)>();
+        else if (younger >= 1) wait_vmcnt<KA + KB>();
+        else wait_vmcnt<0>();
+    };
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k)
+        if (k < n) issue(k, smem + k * STAGE);
+    landed(0);
+    asm volatile("" :: "v"(bv));                                                // (the bias load is older than the copies: it has returned)
+    asm volatile("s_barrier" ::: "memory");
+    // (hand-written ds_reads, as in the kernels above: the compiler guards a plain LDS load that follows an LDS-DMA copy with
+    // vmcnt(0), i.e. it would wait for the copies requested a moment ago.)
+    // Software pipeline over the four chunks of an iteration: while the six MFMAs of chunk c issue (32 matrix-pipe cycles each), the
+    // wave splits the A fragment of chunk c + 1 (46 VALU instructions: ~8 per MFMA, requested from the scheduler as 1 MFMA : 8 VALU
+    // groups) and the reads of chunk c + 2 are in flight -- three register sets.  (Without it MFMAs and splits alternated: ~1.05 us per
+    // iteration measured against 0.4 of MFMAs.)
+    const unsigned lds0 = lds_address(smem);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 ra[3][2];
+    frag_t rb[3][3];
+    frag_t fa[2][3];
+#define BF3S_READ(set, c, base)                                                                                                 \
+    do {                                                                                                                        \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ra[set][0]) : "v"((base) + aoff[c][0]));                                      \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(ra[set][1]) : "v"((base) + aoff[c][1]));                                      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][0]) : "v"((base) + boff), "n"(((c) * 3 + 0) * UNIT));       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][1]) : "v"((base) + boff), "n"(((c) * 3 + 1) * UNIT));       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][2]) : "v"((base) + boff), "n"(((c) * 3 + 2) * UNIT));       \
+    } while (0)
+    // the reads of `set` have returned; NEWER = 5: the five reads of one younger set may stay in flight (LDS returns in order)
+#define BF3S_RETURNED(set, NEWER)                                                                                               \
+    do {                                                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(" #NEWER ")"                                                                            \
+                     : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2]) :: "memory");   \
+    } while (0)
+#define BF3S_SPLIT(set, dst)                                                                                                    \
+    do {                                                                                                                        \
+        uint2 p1, p2, p3, q1, q2, q3;                                                                                           \
+        split4(make_float4(ra[set][0][0], ra[set][0][1], ra[set][0][2], ra[set][0][3]), p1, p2, p3);                            \
+        split4(make_float4(ra[set][1][0], ra[set][1][1], ra[set][1][2], ra[set][1][3]), q1, q2, q3);                            \
+        fa[dst][0] = frag_t{(int)p1.x, (int)p1.y, (int)q1.x, (int)q1.y};                                                        \
+        fa[dst][1] = frag_t{(int)p2.x, (int)p2.y, (int)q2.x, (int)q2.y};                                                        \
+        fa[dst][2] = frag_t{(int)p3.x, (int)p3.y, (int)q3.x, (int)q3.y};                                                        \
+    } while (0)
+#define BF3S_MFMAS(src, set)                                                                                                    \
+    do {                                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                                           \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[src][BF3_TA[t]]), BF3P_BF(rb[set][BF3_TB[t]]), acc, 0, 0, 0); \
+    } while (0)
+#define BF3S_INTERLEAVE()                                                                                                       \
+    do {                                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                                  \
+        }                                                                                                                       \
+    } while (0)
+    for (int i = 0; i < n; ++i) {
+        if (i + NS - 1 < n) issue(i + NS - 1, smem + ((i + NS - 1) % NS) * STAGE);   // the stage iteration i - 1 was read from: free since the barrier
+        const unsigned st = lds0 + (unsigned)((i % NS) * STAGE);
+        BF3S_READ(0, 0, st);
+        BF3S_READ(1, 1, st);
+        BF3S_RETURNED(0, 5);
+        BF3S_SPLIT(0, 0);
+        BF3S_READ(2, 2, st);
+        BF3S_RETURNED(1, 5);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3S_MFMAS(0, 0);                                                       // chunk 0 | split of chunk 1
+        BF3S_SPLIT(1, 1);
+        BF3S_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        BF3S_READ(0, 3, st);
+        BF3S_RETURNED(2, 5);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3S_MFMAS(1, 1);                                                       // chunk 1 | split of chunk 2
+        BF3S_SPLIT(2, 0);
+        BF3S_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        BF3S_RETURNED(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        BF3S_MFMAS(0, 2);                                                       // chunk 2 | split of chunk 3
+        BF3S_SPLIT(0, 1);
+        BF3S_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        BF3S_MFMAS(1, 0);                                                       // chunk 3
+        // iteration i + 1 landed (younger requests may stay in flight); everybody is done reading iteration i
+        landed(i + 1);
+        asm volatile("s_barrier" ::: "memory");
+    }
+#undef BF3S_INTERLEAVE
+#undef BF3S_MFMAS
+#undef BF3S_SPLIT
+#undef BF3S_RETURNED
+#undef BF3S_READ
+    // ---- epilogue: + bias (+ residual); 32 lanes x 4 B = one 128-B line per store instruction ------------------------------------------
+    const int co = cout0 + wn * 32 + (lane & 31);
+    const float* res = RES ? a.res : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < a.Cout && row < a.T) {
+            float v = acc[r] + bv;
+            if (RES) v += res[(size_t)row * a.ldr + co];
+            a.M[(size_t)row * a.ldo + co] = v;
+        }
+    }
+}
+
 // byte offset of element (row r, k) inside a fragment unit
 __device__ __forceinline__ int unit_off(int r, int k) { return (k >> 3) * 512 + r * 16 + (k & 7) * 2; }
 
@@ -914,5 +1111,47 @@ extern "C" int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_plan
     else rc = residual ? bf3q_launch<3, 2, true>(a, x, ldx, 1, st) : bf3q_launch<3, 2, false>(a, x, ldx, 1, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("conv1x1_bf3q");
+    return BBDM_OK;
+}
+
+// The same product for SMALL problems (gemm_bf3s_kernel above: 64 x 64 tiles, 64 channels per iteration, one launch, no split-K):
+// same arguments, same b_planes, same bits as bbdm_conv1x1_bf3q_f32.  The caller chooses (unet.py: below BBDM_BF3_MIN_TILES tiles of
+// 256 x 128); any pixel count, CinPad a multiple of 64.
+extern "C" int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                     float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream) {
+    BBDM_REQUIRE(x && b_planes && out, "conv1x1_bf3s: null pointer");
+    BBDM_REQUIRE(pixels > 0 && pixels < (1ll << 31) && CinPad > 0 && CinPad % 64 == 0 && Cout > 0 && Cout % 4 == 0,
+                 "conv1x1_bf3s: pixels=%lld CinPad=%d Cout=%d unsupported (CinPad %% 64)", pixels, CinPad, Cout);
+    BBDM_REQUIRE(ldx % 4 == 0 && ldx >= CinPad && ldo >= Cout && (!residual || ldr >= Cout) &&
+                     (((uintptr_t)x | (uintptr_t)b_planes) & 15) == 0,
+                 "conv1x1_bf3s: bad pitch / alignment");
+    Bf3pArgs a;
+    a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = out;
+    a.T = (int)pixels; a.Cout = Cout; a.nchunks = CinPad / KC;
+    a.tilesN = cdiv(Cout, 128);
+    a.az = 0; a.bz = 0; a.mz = 0; a.rz = 0;
+    a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    a.ksplits = 1; a.kps = a.nchunks; a.P = 1; a.batch = 1; a.persist = 0; a.tiles = 0;
+    const int tilesM = cdiv((int)pixels, 64), tilesN = cdiv(Cout, 64);
+    a.by_batch = tilesN % 8 == 0 ? 1 : 0;
+    constexpr int NS = 3;      // (four stages = all 160 KB of LDS, measured: no faster -- the chain is bound by what one CU's LDS-DMA path moves,
+                               // ~40 GB/s, not by the distance of the prefetch: profiles/r04_small_1x1.md)
+    const size_t lds = NS * (size_t)(64 * 64 * 4 + 2 * 4 * 3 * UNIT);
+    static bool attr_set_dev[BBDM_MAX_DEVICES][2] = {};
+    bool& attr_set = attr_set_dev[bbdm_device_slot()][residual ? 1 : 0];
+    if (!attr_set) {
+        const void* fn = residual ? reinterpret_cast<const void*>(gemm_bf3s_kernel<true, NS>) : reinterpret_cast<const void*>(gemm_bf3s_kernel<false, NS>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            bbdm_set_error("conv1x1_bf3s: hipFuncSetAttribute(%zu B LDS) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    BBDM_REQUIRE((long long)tilesM * tilesN < (1ll << 31), "conv1x1_bf3s: too many tiles");
+    const dim3 grid((unsigned)(tilesM * tilesN));
+    hipStream_t st = (hipStream_t)stream;
+    if (residual) hipLaunchKernelGGL((gemm_bf3s_kernel<true, NS>), grid, dim3(256), lds, st, a, x, ldx);
+    else hipLaunchKernelGGL((gemm_bf3s_kernel<false, NS>), grid, dim3(256), lds, st, a, x, ldx);
+    BBDM_CHECK_LAUNCH("conv1x1_bf3s");
     return BBDM_OK;
 }

@@ -657,6 +657,10 @@ class UNetModel(nn.Module):
         # wide 1x1 layers whose Cout fills 256-column tiles on the pipelined fp32-A kernel (gemm_bf3q_pipe_kernel); BBDM_CONV1X1_PIPE=0:
         # gemm_bf3.hip everywhere (A/B; bit-equal results)
         self.conv1x1_pipe: bool = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
+        # 1x1 layers BELOW bf3_min_tiles (the latent / 64^2-pixel configurations: qkv / proj_out, skip projections) on the small-problem
+        # bf16x3 kernel (csrc/gemm_bf3p.hip: gemm_bf3s_kernel, one launch, 64 channels per step) instead of the split-K f32-MFMA kernel
+        # + its reduction pass; BBDM_CONV1X1_SMALL=0: round 3's path (A/B)
+        self.conv1x1_small: bool = os.environ.get("BBDM_CONV1X1_SMALL", "1") != "0"
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
@@ -722,7 +726,7 @@ class UNetModel(nn.Module):
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small, self.upsample_phases, self.conv1x1_pipe)
+               self.winograd_small, self.upsample_phases, self.conv1x1_pipe, self.conv1x1_small)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1233,6 +1237,16 @@ class _Plan:
             self.convs.append(pb)
             rec = self._op(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32") if q else "bbdm_conv1x1_bf3_f32", x, x.ld,
                            _TensorRef(pb.packed), self._pref(pb.bias), residual, res_ld, dest, dest.ld, pixels, x.C, cout)
+            self._note_writer(dest, rec, None)
+            return
+        if (ks == 1 and self.m.gemm_bf3 and self.m.conv1x1_small and (pre is None or pre[0] is None) and flags == 0
+                and x.C % 64 == 0 and cout % 4 == 0):
+            # small 1x1 convolutions / Linears: bound by the length of a workgroup's chain of K steps, not by the matrix pipe -- the
+            # small-problem bf16x3 kernel (64 channels per step, one launch) instead of the split-K f32 kernel + its reduction pass
+            pb = self._packed(_PackedConvBf3q, mod.weight, mod.bias, x.C)
+            self.convs.append(pb)
+            rec = self._op(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3s_f32"), x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
+                           residual, res_ld, dest, dest.ld, pixels, x.C, cout)
             self._note_writer(dest, rec, None)
             return
         pc = self._conv(mod, x.C)

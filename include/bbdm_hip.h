@@ -401,6 +401,13 @@ int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, const float* 
  * buffer.  Same arguments and results (bit for bit) as bbdm_conv1x1_bf3_f32; pixels need not be a multiple of 256. */
 int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
                           float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream);
+/* The same product for SMALL problems -- the 1x1 convolutions / Linears of the latent and 64^2-pixel configurations (a few hundred
+ * to a few thousand pixels: qkv / proj_out, skip projections), which are bound by the length of a workgroup's chain of K steps, not
+ * by the matrix pipe (csrc/gemm_bf3p.hip: gemm_bf3s_kernel -- 64 x 64 tiles, 64 channels per step, x and the weight planes by
+ * LDS-DMA two steps ahead, x split when a wave reads its fragment; one launch, no split-K workspace).  Same arguments, same b_planes,
+ * same results bit for bit as bbdm_conv1x1_bf3q_f32; CinPad a multiple of 64, any pixel count. */
+int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                          float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream);
 int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
 int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,

@@ -526,8 +526,9 @@ def vq_nearest(z: torch.Tensor, codebook: torch.Tensor):
 
 
 def conv1x1_bf3q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
-                 out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0) -> torch.Tensor:
-    """:func:`conv1x1_bf3` on the pipelined kernel with an fp32 A operand (bbdm_conv1x1_bf3q_f32; weights as bf3p B planes)."""
+                 out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0, small: bool = False) -> torch.Tensor:
+    """:func:`conv1x1_bf3` on the pipelined kernel with an fp32 A operand (bbdm_conv1x1_bf3q_f32; weights as bf3p B planes);
+    ``small``: on the small-problem kernel (bbdm_conv1x1_bf3s_f32: same arguments, cin a multiple of 64)."""
     _chk(x, w, bias, residual)
     cout = w.shape[0]
     cin = cin or w.shape[1]
@@ -538,7 +539,7 @@ def conv1x1_bf3q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
     _lib.call("bbdm_gemm_bf3p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), 1, cin, cout, _st(x))
     if out is None:
         out = torch.empty(x.shape[0], cout, dtype=torch.float32, device=x.device)
-    _lib.call("bbdm_conv1x1_bf3q_f32", x.data_ptr() + 4 * x_off, x.shape[1], bp.data_ptr(), None if bias is None else bias.data_ptr(),
+    _lib.call("bbdm_conv1x1_bf3s_f32" if small else "bbdm_conv1x1_bf3q_f32", x.data_ptr() + 4 * x_off, x.shape[1], bp.data_ptr(), None if bias is None else bias.data_ptr(),
               None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1],
               out.data_ptr(), out.shape[1], x.shape[0], cin, cout, _st(x))
     return out

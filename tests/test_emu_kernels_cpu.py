@@ -251,6 +251,11 @@ def test_conv1x1_bf3q_bitwise(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3q_bitwise(CPU, pixels, Cin, Cout, res)
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(128, 256, 132, True), (96, 128, 8, False), (100, 192, 520, True), (64, 64, 64, False)])
+def test_conv1x1_bf3s_bitwise(pixels, Cin, Cout, res):
+    K.test_conv1x1_bf3s_bitwise(CPU, pixels, Cin, Cout, res)
+
+
 @pytest.mark.parametrize("m,Cout,Cin,in_pad,dgrad", [(4, 96, 40, 48, False), (2, 24, 16, 32, True), (6, 40, 130, 144, False)])
 def test_winograd_weight_planes_fused_bitwise(m, Cout, Cin, in_pad, dgrad):
     K.test_winograd_weight_planes_fused_bitwise(CPU, m, Cout, Cin, in_pad, dgrad)

@@ -559,6 +559,29 @@ def test_conv1x1_bf3q_bitwise(dev, pixels, Cin, Cout, res):
         assert torch.equal(out, out0), (out - out0).abs().max()
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(512, 1024, 3072, False), (512, 64, 132, True), (96, 128, 8, False), (2080, 256, 1024, True),
+                                                 (100, 192, 72, True), (64, 64, 64, False)])
+def test_conv1x1_bf3s_bitwise(dev, pixels, Cin, Cout, res):
+    """The small-problem 1x1 kernel (gemm_bf3s_kernel: 64 x 64 tiles, 64 channels per step, everything by LDS-DMA two steps ahead,
+    the fp32 operand split at the fragment read): bit-equal to bbdm_conv1x1_bf3q_f32 -- one step (K = 64) to sixteen, ragged row and
+    column tiles, the XCD-owned tile order (Cout / 64 a multiple of 8) and the plain one, in-place residual."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(pixels + Cin)
+    wide = torch.randn(pixels, Cin + 16, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(pixels, Cout, generator=g) if res else None
+    ref = wide[:, 16:].double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    buf = r.clone().to(dev) if res else None
+    out = ops.conv1x1_bf3q(wide.to(dev), w.to(dev), b.to(dev), residual=buf, out=buf, cin=Cin, x_off=16, small=True).cpu()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert rel_err(out, ref) < 3e-6
+    buf0 = r.clone().to(dev) if res else None
+    out0 = ops.conv1x1_bf3q(wide.to(dev), w.to(dev), b.to(dev), residual=buf0, out=buf0, cin=Cin, x_off=16).cpu()
+    assert torch.equal(out, out0), (out - out0).abs().max()
+
+
 def _group_sums(y_nhwc, cpg, coff, ctot_groups=32):
     """fp64 [N][32][2] (sum, sum of squares) of the channels of y placed at offset coff in a tensor with groups of cpg."""
     N, H, W, C = y_nhwc.shape

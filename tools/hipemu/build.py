@@ -28,6 +28,8 @@ def rewrite(src: str) -> str:
     # with lds_address(p) = byte offset of p inside the emulated dynamic LDS allocation
     src = re.sub(r'asm volatile\("ds_read_b128 %0, %1 offset:%2"\s*:\s*"=v"\((.+?)\)\s*:\s*"v"\((.+?)\),\s*"n"\((.+?)\)\);',
                  r"\1 = *reinterpret_cast<const __typeof__(\1)*>((const char*)hipemu::dyn_smem() + (\2) + (\3));", src)
+    src = re.sub(r'asm volatile\("ds_read_b128 %0, %1"\s*:\s*"=v"\((.+?)\)\s*:\s*"v"\((.+?)\)\);',
+                 r"\1 = *reinterpret_cast<const __typeof__(\1)*>((const char*)hipemu::dyn_smem() + (\2));", src)
     src = re.sub(r'return \(unsigned\)\(uintptr_t\)\(__attribute__\(\(address_space\(3\)\)\) void\*\)p;',
                  "return (unsigned)((const char*)p - (const char*)hipemu::dyn_smem());", src)
     # counted waits for LDS-DMA copies: template form `"s_waitcnt vmcnt(%0)" ::"n"(N)` and literal form `"s_waitcnt vmcnt(3)"`

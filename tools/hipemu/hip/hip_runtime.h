@@ -269,6 +269,7 @@ static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu)
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0

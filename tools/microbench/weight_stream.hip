@@ -27,6 +27,7 @@ struct Args {
     const unsigned char* B;   // [16 points][32 row groups][nfull][3][UNIT] (read once)
     int nfull, n;             // chunks of the full contraction, chunks one workgroup walks (split-K: nfull / n splits)
     int with_a, barrier, mfma;
+    int hot;                  // every workgroup reads the SAME units (point 0, column tile 0): L2 hits -- what one CU can pull, not HBM
     unsigned* sink;
 };
 
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(NW * 64, 1) stream_lds(const Args a) {
     const unsigned lane16 = lane * 16;
     const int g = blockIdx.x;
     const int ctiles = 32 / RG;
-    const int p = g % 16, ct = (g / 16) % ctiles, z = g / (16 * ctiles);
+    const int p = a.hot ? 0 : g % 16, ct = a.hot ? 0 : (g / 16) % ctiles, z = g / (16 * ctiles);
     const size_t gstride = (size_t)a.nfull * 3 * UNIT;
     const unsigned char* src[KMAX];
     bool live[KMAX];
@@ -124,6 +125,139 @@ __global__ void __launch_bounds__(NW * 64, 1) stream_lds(const Args a) {
     if ((x[0] ^ x[1] ^ x[2] ^ x[3]) == 0x12345678 && s == 1.25f) a.sink[0] = 1;
 }
 
+// ... with the work SPLIT BY WAVE: waves 0 - 3 only request the copies and wait for them, waves 4 - 7 (the second wave of each SIMD) only
+// read fragments and issue the 24 MFMAs per chunk -- does a wave's own MFMA stream hold up the LDS-DMA copies IT requested?
+template <int NS, int RG, int WORK>
+__global__ void __launch_bounds__(512, 1) stream_lds_spec(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NA = RG * 3, NU = 2 * NA, STAGE = NU * UNIT, KMAX = NU / 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave < 4;
+    const int pw = wave & 3;
+    const unsigned lane16 = lane * 16;
+    const int g = blockIdx.x, ctiles = 32 / RG;
+    const int p = a.hot ? 0 : g % 16, ct = a.hot ? 0 : (g / 16) % ctiles, z = g / (16 * ctiles);
+    const size_t gstride = (size_t)a.nfull * 3 * UNIT;
+    const unsigned char* src[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int u = pw + k * 4, ub = u - NA;
+        src[k] = (u < NA ? a.A + ((size_t)(p * 4 + (u / 3) % 4)) * gstride + (u % 3) * UNIT
+                         : a.B + ((size_t)(p * 32 + ct * RG + ub / 3)) * gstride + (ub % 3) * UNIT) +
+                 (size_t)z * a.n * 3 * UNIT;
+    }
+    auto issue = [&](int chunk, unsigned char* st) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + (pw + k * 4) * UNIT);
+    };
+    const int n = a.n;
+    if (producer) {
+#pragma unroll
+        for (int k = 0; k < NS - 1; ++k)
+            if (k < n) issue(k, smem + k * STAGE);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 fa, fb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fa[j] = (__bf16)(float)(lane + j); fb[j] = (__bf16)(float)(lane - j); }
+    i32x4 x = {0, 0, 0, 0};
+    for (int chunk = 0; chunk < n; ++chunk) {
+        if (producer) {
+            const int younger = min(n - 1 - chunk, NS - 2);
+            if (younger >= 3) wait_vmcnt<3 * KMAX>();
+            else if (younger == 2) wait_vmcnt<2 * KMAX>();
+            else if (younger == 1) wait_vmcnt<1 * KMAX>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (producer) {
+            if (chunk + NS - 1 < n) issue(chunk + NS - 1, smem + ((chunk + NS - 1) % NS) * STAGE);
+        } else {
+            const i32x4 v = *(const i32x4*)(smem + (chunk % NS) * STAGE + ((pw * 3) % NU) * UNIT + lane16);
+            x ^= v;
+            if (WORK == 1) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += acc[i][j];
+    if ((x[0] ^ x[1] ^ x[2] ^ x[3]) == 0x12345678 && sum == 1.25f) a.sink[0] = 1;
+}
+
+// the same movement through REGISTERS: a thread requests its 16-B pieces of the chunks c .. c + D - 1 with global_load_dwordx4,
+// writes chunk c to LDS with ds_write_b128 when it arrives, barrier, one fragment read -- is the LDS-DMA path what limits a CU?
+template <int D, int RG, int WORK = 0>
+__global__ void __launch_bounds__(256, 1) stream_regs(const Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NU = 2 * RG * 3, STAGE = NU * UNIT, PER = STAGE / 16 / 256;      // 16-B pieces per thread and chunk (6 at RG = 4)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = blockIdx.x, ctiles = 32 / RG;
+    const int p = a.hot ? 0 : g % 16, ct = a.hot ? 0 : (g / 16) % ctiles, z = g / (16 * ctiles);
+    const size_t gstride = (size_t)a.nfull * 3 * UNIT;
+    const unsigned char* src[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int u = wave + k * 4, ub = u - RG * 3;                            // unit of the stage, as in stream_lds
+        src[k] = (u < RG * 3 ? a.A + ((size_t)(p * 4 + (u / 3) % 4)) * gstride + (u % 3) * UNIT
+                             : a.B + ((size_t)(p * 32 + ct * RG + ub / 3)) * gstride + (ub % 3) * UNIT) +
+                 (size_t)z * a.n * 3 * UNIT + lane * 16;
+    }
+    i32x4 r[D][PER];
+    const int n = a.n;
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 fa, fb;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fa[j] = (__bf16)(float)(lane + j); fb[j] = (__bf16)(float)(lane - j); }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int k = 0; k < PER; ++k) r[d][k] = d < n ? *(const i32x4*)(src[k] + (size_t)d * 3 * UNIT) : i32x4{0, 0, 0, 0};
+    i32x4 x = {0, 0, 0, 0};
+    for (int c0 = 0; c0 < n; c0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int chunk = c0 + d;
+            if (chunk < n) {
+                unsigned char* st = smem + (chunk & 1) * STAGE;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) *(i32x4*)(st + (wave + k * 4) * UNIT + lane * 16) = r[d][k];
+#pragma unroll
+                for (int k = 0; k < PER; ++k)
+                    if (chunk + D < n) r[d][k] = *(const i32x4*)(src[k] + (size_t)(chunk + D) * 3 * UNIT);
+                __syncthreads();
+                x ^= *(const i32x4*)(st + ((wave * 3) % NU) * UNIT + lane * 16);
+                if (WORK == 1) {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += acc[i][j];
+    if ((x[0] ^ x[1] ^ x[2] ^ x[3]) == 0x12345678 && sum == 1.25f) a.sink[0] = 1;
+}
+
 // the ceiling: every thread of a full-chip grid walks the buffer with coalesced 16-byte loads, DEPTH loads in flight per thread
 template <int DEPTH>
 __global__ void __launch_bounds__(256) stream_reg(const i32x4* __restrict__ b, size_t count, unsigned* sink) {
@@ -153,7 +287,7 @@ int main() {
     CK(hipMalloc(&sink, 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("weights per launch: %.1f MB (read once), A operand %.1f MB (re-read by 8 column tiles)\n", bbytes / 1e6, abytes / 1e6);
+    printf("weights per launch: %.1f MB (read once), A operand %.1f MB (re-read by 8 column tiles); work: 0 none, 1 = 24 MFMAs per wave and chunk, 2 sleep, 3 valu\n", bbytes / 1e6, abytes / 1e6);
 
     auto time_it = [&](const char* name, auto launch, double bytes) {
         for (int i = 0; i < NBUF; ++i) launch(i);
@@ -168,6 +302,34 @@ int main() {
         const double us = ms * 1e3 / reps;
         printf("%-72s %7.1f us  %5.2f TB/s of weights\n", name, us, bytes / us / 1e6);
     };
+    int hot_mode = 0;
+#define REG_CASE(D, RG, splits) REG_CASE_W(D, RG, splits, 0)
+#define REG_CASE_W(D, RG, splits, mf)                                                                                                     \
+    do {                                                                                                                            \
+        const size_t lds = (size_t)2 * 2 * RG * 3 * UNIT;                                                                           \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_regs<D, RG, mf>), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                               (int)lds));                                                                                          \
+        char nm[160];                                                                                                               \
+        snprintf(nm, sizeof nm, "%sregister-staged, %d chunks in flight, %3d-col tiles, %d split(s) = %4d wgs, work %d", hot_mode ? "HOT " : "", \
+                 D, RG * 32, splits, 16 * (32 / RG) * splits, mf);                                                                      \
+        time_it(nm, [&](int i) {                                                                                                    \
+            Args a{A, B[i], nfull, nfull / splits, 1, 1, 0, hot_mode, sink};                                                        \
+            hipLaunchKernelGGL((stream_regs<D, RG, mf>), dim3(16 * (32 / RG) * splits), dim3(256), lds, 0, a);                          \
+        }, (double)bbytes);                                                                                                         \
+    } while (0)
+#define SPEC_CASE(NS, RG, splits, mf)                                                                                               \
+    do {                                                                                                                            \
+        const size_t lds = (size_t)NS * 2 * RG * 3 * UNIT;                                                                          \
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_lds_spec<NS, RG, mf>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)lds));                                                                                          \
+        char nm[160];                                                                                                               \
+        snprintf(nm, sizeof nm, "%sLDS-DMA ring %d, 4 copy waves + 4 MFMA waves, %3d-col tiles, %d split(s) = %4d wgs, work %d",    \
+                 hot_mode ? "HOT " : "", NS, RG * 32, splits, 16 * (32 / RG) * splits, mf);                                         \
+        time_it(nm, [&](int i) {                                                                                                    \
+            Args a{A, B[i], nfull, nfull / splits, 1, 1, mf, hot_mode, sink};                                                       \
+            hipLaunchKernelGGL((stream_lds_spec<NS, RG, mf>), dim3(16 * (32 / RG) * splits), dim3(512), lds, 0, a);                 \
+        }, (double)bbytes);                                                                                                         \
+    } while (0)
 #define LDS_CASE(NS, NW, RG, splits, wa, bar, mf) LDS_CASE_W(NS, NW, RG, splits, wa, bar, mf)
 #define LDS_CASE_W(NS, NW, RG, splits, wa, bar, mf)                                                                                   \
     do {                                                                                                                            \
@@ -175,10 +337,10 @@ int main() {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_lds<NS, NW, RG, mf>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                (int)lds));                                                                                          \
         char nm[160];                                                                                                               \
-        snprintf(nm, sizeof nm, "LDS-DMA ring %d, %2d waves, %3d-col tiles, %d split(s) = %4d wgs, A %d barrier %d work %d (0 none, 1 mfma, 2 sleep, 3 valu)", NS, NW, \
+        snprintf(nm, sizeof nm, "%sLDS-DMA ring %d, %2d waves, %3d-col tiles, %d split(s) = %4d wgs, A %d barrier %d work %d", hot_mode ? "HOT " : "", NS, NW, \
                  RG * 32, splits, 16 * (32 / RG) * splits, wa, bar, mf);                                                            \
         time_it(nm, [&](int i) {                                                                                                    \
-            Args a{A, B[i], nfull, nfull / splits, wa, bar, mf, sink};                                                              \
+            Args a{A, B[i], nfull, nfull / splits, wa, bar, mf, hot_mode, sink};                                                              \
             hipLaunchKernelGGL((stream_lds<NS, NW, RG, mf>), dim3(16 * (32 / RG) * splits), dim3(NW * 64), lds, 0, a);                  \
         }, (double)bbytes);                                                                                                         \
     } while (0)
@@ -208,6 +370,29 @@ int main() {
     LDS_CASE(3, 8, 8, 4, 1, 1, 1);
     LDS_CASE(3, 8, 8, 2, 1, 1, 1);
     LDS_CASE(3, 16, 8, 4, 1, 1, 1);
+    // the same movement staged through registers; then everything again on L2-resident data (every workgroup reads the same units):
+    // what ONE CU can pull per chunk, by LDS-DMA and through registers
+    REG_CASE(2, 4, 2);
+    REG_CASE(3, 4, 2);
+    REG_CASE(4, 4, 2);
+    hot_mode = 1;
+    LDS_CASE(3, 4, 4, 2, 1, 1, 0);
+    LDS_CASE(5, 4, 4, 2, 1, 1, 0);
+    LDS_CASE(5, 4, 4, 2, 1, 1, 1);
+    REG_CASE(2, 4, 2);
+    REG_CASE(3, 4, 2);
+    REG_CASE(4, 4, 2);
+    SPEC_CASE(3, 4, 2, 0);
+    SPEC_CASE(3, 4, 2, 1);
+    SPEC_CASE(5, 4, 2, 1);
+    REG_CASE_W(3, 4, 2, 1);
+    REG_CASE_W(4, 4, 2, 1);
+    hot_mode = 0;
+    REG_CASE_W(3, 4, 2, 1);
+    REG_CASE_W(4, 4, 2, 1);
+    SPEC_CASE(3, 4, 2, 0);
+    SPEC_CASE(3, 4, 2, 1);
+    SPEC_CASE(5, 4, 2, 1);
     // the ceiling: coalesced register loads, full chip
     for (int wgs : {256, 512, 1024, 2048, 4096}) {
         char nm[160];
