@@ -140,6 +140,36 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert fwd_wino > 0 and bwd_wino > 0                  # forward and data-gradient convolutions both take it
 
 
+def test_1x1_layers_take_the_kernel_their_size_asks_for():
+    """1x1 convolutions / Linears of the forward plan: from BBDM_BF3_MIN_TILES output tiles of 256 x 128 on the wide bf16x3 kernels
+    (bbdm_conv1x1_bf3_f32 / _bf3q_f32), below it on the small-problem kernel (bbdm_conv1x1_bf3s_f32: K a multiple of 64, plain NHWC
+    output, no fused producer) -- same planes, same bits -- and with conv1x1_small off on the split-K f32 kernel as in round 3."""
+    def one_by_ones(plan):
+        out = []
+        for name, a in plan.ops:
+            if name == "bbdm_conv1x1_bf3_f32":
+                out.append((getattr(name, "entry", name), a[8], a[9], a[10]))               # entry, pixels, cin, cout
+            elif name == "bbdm_conv2d_nhwc_f32" and a[20] == 1:
+                out.append((name, a[15] * a[16] * a[17], a[18], a[19]))
+        return out
+    m, plan = _plan("c5", 32)
+    layers = one_by_ones(plan)
+    assert len(layers) >= 20
+    for entry, pixels, cin, cout in layers:
+        tiles = (pixels // 256) * -(-cout // 128)
+        if tiles >= m.bf3_min_tiles:
+            assert entry in ("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32"), (entry, pixels, cin, cout)
+        else:
+            assert entry == "bbdm_conv1x1_bf3s_f32" and cin % 64 == 0 and cout % 4 == 0, (entry, pixels, cin, cout)
+    assert any(e == "bbdm_conv1x1_bf3s_f32" and (px, ci, co) == (512, 1024, 3072) for e, px, ci, co in layers)     # the qkv projections
+    m0 = unet.UNetModel(**bench.WORKLOADS["c5"][1])
+    m0.winograd, m0.conv1x1_small = 4, False
+    plan0 = m0._plan_for(torch.zeros(32, bench.WORKLOADS["c5"][1]["in_channels"], 16, 16), False)
+    layers0 = one_by_ones(plan0)
+    assert len(layers0) == len(layers) and not any(e == "bbdm_conv1x1_bf3s_f32" for e, *_ in layers0)
+    assert [l[1:] for l in layers0] == [l[1:] for l in layers]
+
+
 def test_flop_accounting_direct_equivalent_matches_the_direct_plan():
     """bench.py reports `tflops_executed` (what the MFMA runs) and `tflops_algorithmic` (SURVEY.md §8d's direct
     count): a Winograd GEMM executing F FLOP stands for F * 9 m^2 / (m+2)^2 FLOP of direct convolution."""
