@@ -449,7 +449,22 @@ __device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][3], un
 // instead of two 64-bit divisions by kernel arguments; a row address is ONE 24-bit multiply-add on a 32-bit element index (IDX64:
 // tensors of 2^32 elements or more, or a row pitch of 2^24 elements or more, keep 64-bit row addresses); SiLU evaluates a channel
 // pair with packed multiplies / adds around its two v_exp_f32 / v_rcp_f32.
-template <int MO, bool PRE, bool UP, bool TR, bool IDX64>
+// GNC (round 4, small problems only): the kernel forms the fused-producer coefficients ITSELF from the GroupNorm statistics, gamma,
+// beta and the FiLM vector -- the expressions of gn_coeffs_kernel (groupnorm.hip), hence the same bits -- instead of reading sc / bi
+// that a separate launch wrote: one launch fewer per fused GroupNorm (41 per forward, ~6 us each where every launch is ~10 us).
+// Every thread folds the limbs of its (image, group) and does the fp64 division / square root for its channel pair: free where the
+// launch is latency-bound, not where the transform is HBM-bound with tens of thousands of workgroups (measured in round 4 with a
+// table of (mean, rstd): +2.3 ms on the C2 step) -- the caller chooses (unet.py: BBDM_GN_IN_TRANSFORM).
+struct GnFold {
+    const unsigned long long* stats;      // [N][G][2][SA_W] limbs (stats_acc.h)
+    const float* gamma;                   // [C]
+    const float* beta;                    // [C]
+    const float* film;                    // [N][film_ld]: scale at c, shift at C + c; or null
+    int film_ld, C, G, cpg;               // cpg = C / G, even
+    double cnt;                           // values per (image, group): HW * cpg
+    float eps;
+};
+template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
                                                                               unsigned char* __restrict__ Vp,
                                                                               const float* __restrict__ sc, const float* __restrict__ bi,
@@ -457,7 +472,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                                                                               unsigned T, int TG, size_t plane,
                                                                               unsigned char* __restrict__ Vt, size_t plane_t,
                                                                               int tchunks, const FastDiv dTW, const FastDiv dTH,
-                                                                              const FastDiv dCH) {
+                                                                              const FastDiv dCH, const GnFold gn) {
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
     const unsigned L = blockIdx.x, q = L >> 3;
@@ -477,7 +492,27 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
             const unsigned r = fastdiv(tile, dTW), n = fastdiv(r, dTH);
             const int tw = (int)(tile - r * (unsigned)TW), th = (int)(r - n * (unsigned)TH);
             float2 s2 = make_float2(1.f, 1.f), b2 = make_float2(0.f, 0.f);
-            if (PRE) {
+            if (PRE && GNC) {
+                // gn_coeffs_kernel's expressions, for channels c and c + 1 (same group: cpg is even)
+                const unsigned long long* cell = gn.stats + (((size_t)n * gn.G + c / gn.cpg) * 2) * SA_W;
+                const double s = sa_load(cell), ss = sa_load(cell + SA_W);
+                const double mean = s / gn.cnt;
+                double var = ss / gn.cnt - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                const float rstd = (float)(1.0 / sqrt(var + (double)gn.eps));
+                const float fmean = (float)mean;
+                const float2 ga = *reinterpret_cast<const float2*>(gn.gamma + c), be = *reinterpret_cast<const float2*>(gn.beta + c);
+                float sc0 = rstd * ga.x, sc1 = rstd * ga.y;
+                float bi0 = be.x - fmean * sc0, bi1 = be.y - fmean * sc1;
+                if (gn.film) {
+                    const float2 fs = *reinterpret_cast<const float2*>(gn.film + (size_t)n * gn.film_ld + c);
+                    const float2 fb = *reinterpret_cast<const float2*>(gn.film + (size_t)n * gn.film_ld + gn.C + c);
+                    sc0 = sc0 * (1.f + fs.x); sc1 = sc1 * (1.f + fs.y);
+                    bi0 = bi0 * (1.f + fs.x) + fb.x; bi1 = bi1 * (1.f + fs.y) + fb.y;
+                }
+                s2 = make_float2(sc0, sc1);
+                b2 = make_float2(bi0, bi1);
+            } else if (PRE) {
                 s2 = *reinterpret_cast<const float2*>(sc + (size_t)n * pre_ld + c);
                 b2 = *reinterpret_cast<const float2*>(bi + (size_t)n * pre_ld + c);
             }
@@ -1125,7 +1160,8 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 // bbdm_gemm_bf3p_a_bytes((m+2)^2, tiles, CinPad) bytes; CinPad a multiple of 16), and the tile GEMMs on them: b_planes =
 // bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
-                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream) {
+                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
+                                 const GnFold* fold = nullptr) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
@@ -1155,10 +1191,29 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
                            (unsigned long long)Ws * (unsigned long long)ldx >= (1ull << 24) || Hs >= (1 << 24);
         const FastDiv dTW = fastdiv_make((unsigned)((W + m - 1) / m)), dTH = fastdiv_make((unsigned)((H + m - 1) / m)),
                       dCH = fastdiv_make((unsigned)nchunks);
+        const GnFold gn = fold ? *fold : GnFold{};
+        if (fold) {                       // the kernel forms the coefficients (small problems; 32-bit indices, no transposed copy)
+            BBDM_REQUIRE(!idx64 && !Vt, "winograd_input_bf3p_gn: tensor too large for the coefficient-folding variant");
+#define BBDM_WINO_INS2_G(MO)                                                                                                      \
+    do {                                                                                                                          \
+        if (upsample)                                                                                                             \
+            hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, true, false, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                               (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn);                                              \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, false, false, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                               (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn);                                              \
+    } while (0)
+            if (m == 2) BBDM_WINO_INS2_G(2); else if (m == 4) BBDM_WINO_INS2_G(4); else BBDM_WINO_INS2_G(6);
+#undef BBDM_WINO_INS2_G
+            BBDM_CHECK_LAUNCH("winograd_input_bf3p_gn");
+            return BBDM_OK;
+        }
 #define BBDM_WINO_INS2_I(MO, PRE, UP, TR, I64)                                                                                    \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
                        pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, (unsigned char*)Vt,   \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn)
 #define BBDM_WINO_INS2(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_I(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_I(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_M(MO)                                                                        \
     do {                                                                                            \
@@ -1173,6 +1228,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         BBDM_CHECK_LAUNCH("winograd_input_bf3p");
         return BBDM_OK;
     }
+    BBDM_REQUIRE(!fold, "winograd_input_bf3p_gn: needs the two-phase transform (BBDM_WINO_INPUT_LDS=1)");
     const long long blocks = 8ll * ((RG + 7) / 8) * nchunks;
     BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
     const dim3 g((unsigned)blocks), b(256);
@@ -1195,6 +1251,29 @@ extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void
                                             const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
                                             int CinPad, void* stream) {
     return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream);
+}
+
+// The same transform with GroupNorm [-> FiLM] [-> SiLU] folded in FROM THE STATISTICS (util.py:214-216 + openaimodel.py:258-278): the
+// kernel forms x * sc[n][c] + bi[n][c] from stats (the accumulator slot of this GroupNorm, [N][G][2] values in the layout of
+// bbdm_groupnorm_stats_bytes), gamma / beta [C] and the FiLM vector film[n][c] (scale), film[n][C + c] (shift) (null: none) -- the
+// expressions and therefore the bits of bbdm_groupnorm_coeffs_f32 followed by bbdm_winograd_input_bf3p_f32, one launch instead of
+// two.  For SMALL problems (every thread repeats the fp64 fold for its channel pair).  Argument order of bbdm_winograd_input_bf3p_f32
+// with (stats, unused) in place of (pre_scale, pre_bias) and C in place of pre_ld; the GroupNorm's parameters follow CinPad.
+// C == CinPad, C / G even, HW = pixels per image of the NORMALISED tensor (x's own H * W, also when upsample = 1).
+extern "C" int bbdm_winograd_input_bf3p_gn_f32(int m, const float* x, int ldx, void* Vp, const void* stats, const void* unused, int C,
+                                               int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma,
+                                               const float* beta, const float* film, int film_ld, int HW, int G, float eps,
+                                               void* stream) {
+    (void)unused;
+    BBDM_REQUIRE(stats && gamma && beta, "winograd_input_bf3p_gn: null pointer");
+    BBDM_REQUIRE(C == CinPad && G > 0 && C % G == 0 && (C / G) % 2 == 0 && HW > 0 && (!film || film_ld >= 2 * C),
+                 "winograd_input_bf3p_gn: C=%d CinPad=%d G=%d HW=%d film_ld=%d", C, CinPad, G, HW, film_ld);
+    BBDM_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)film) & 7) == 0 && (!film || film_ld % 2 == 0),
+                 "winograd_input_bf3p_gn: gamma / beta / film must be 8-byte aligned");
+    GnFold f;
+    f.stats = (const unsigned long long*)stats; f.gamma = gamma; f.beta = beta; f.film = film;
+    f.film_ld = film_ld; f.C = C; f.G = G; f.cpg = C / G; f.cnt = (double)HW * (double)(C / G); f.eps = eps;
+    return winograd_input_planes(m, x, ldx, Vp, nullptr, nullptr, nullptr, C, pre_silu, upsample, N, H, W, CinPad, stream, &f);
 }
 
 // ... and, for the training forward, ALSO the transposed planes Vt (bbdm_gemm_bf3p_tn_at_bytes((m+2)^2, tiles, CinPad) bytes): the A

@@ -281,6 +281,18 @@ class _OpName(str):
         return o
 
 
+class _GnPre(tuple):
+    """Fused-producer arguments of a Winograd input transform that forms the GroupNorm coefficients itself
+    (bbdm_winograd_input_bf3p_gn_f32): (stats reference, None, C, silu) in the positions of (pre_scale, pre_bias, pre_ld, pre_silu),
+    the GroupNorm's parameters in ``tail`` (appended after CinPad)."""
+    tail: tuple = ()
+
+    def __new__(cls, head, tail):
+        o = super().__new__(cls, head)
+        o.tail = tuple(tail)
+        return o
+
+
 def _round4(c):
     return (c + 3) // 4 * 4
 
@@ -661,6 +673,12 @@ class UNetModel(nn.Module):
         # bf16x3 kernel (csrc/gemm_bf3p.hip: gemm_bf3s_kernel, one launch, 64 channels per step) instead of the split-K f32-MFMA kernel
         # + its reduction pass; BBDM_CONV1X1_SMALL=0: round 3's path (A/B)
         self.conv1x1_small: bool = os.environ.get("BBDM_CONV1X1_SMALL", "1") != "0"
+        # inference plans: a Winograd layer of at most this many tiles forms its fused GroupNorm coefficients INSIDE its input
+        # transform (bbdm_winograd_input_bf3p_gn_f32) instead of reading what a bbdm_groupnorm_coeffs_f32 launch wrote -- one launch
+        # fewer per GroupNorm, the same bits: C5 3.25 -> 3.22 ms, C1 3.84 -> 3.80 (a coefficient launch costs ~2 us inside the replayed
+        # graph, the fold ~1 us of extra latency in its consumer); above it every thread repeating the fp64 fold costs the HBM-bound
+        # transforms more than the launch (round 4: +2.3 ms on the C2 step).  BBDM_GN_IN_TRANSFORM=0: always the separate launch (A/B)
+        self.gn_in_transform: int = int(os.environ.get("BBDM_GN_IN_TRANSFORM", "1024"))
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
@@ -726,7 +744,7 @@ class UNetModel(nn.Module):
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small, self.upsample_phases, self.conv1x1_pipe, self.conv1x1_small)
+               self.winograd_small, self.upsample_phases, self.conv1x1_pipe, self.conv1x1_small, self.gn_in_transform)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1088,18 +1106,43 @@ class _Plan:
         ref = _Plan._StatsRef(self, self._gn_count)
         self._gn_count += 1
         self._emit_stats(x, ref)
+        film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
+        if self._gn_folds_into_transform(consumer, x, up):
+            # small problem: the consumer's input transform forms the coefficients from the statistics (one launch fewer)
+            return x, _GnPre((ref, None, x.C, silu), (self._pref(gn.weight), self._pref(gn.bias), film, self.film_total,
+                                                       x.H * x.W, self.GROUPS, float(gn.eps)))
         k = self._n_coeffs
         self._n_coeffs += 1
         self._coeff_need = max(self._coeff_need, N * x.C)
         sc = _TensorRef(self._coeff_bufs[k % 2][0])
         bi = _TensorRef(self._coeff_bufs[k % 2][1])
-        film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
         # (One small launch per fused GroupNorm: 41 x ~6.6 us per forward.  Folding it into the launch that completes the statistics --
         # last-workgroup ticket + the fold there, coefficients formed by the consumer -- was built and measured in round 4 and LOST at
         # every size: profiles/r04_stats_tail_negative.md.)
         self._op("bbdm_groupnorm_coeffs_f32", ref, self._pref(gn.weight), self._pref(gn.bias), film, self.film_total, sc, bi,
                  x.C, N, x.H * x.W, x.C, self.GROUPS, float(gn.eps))
         return x, (sc, bi, x.C, silu)
+
+    def _gn_folds_into_transform(self, consumer, x: _View, up: int) -> bool:
+        """Will ``consumer`` (a 3x3 conv on GN(x), nearest-upsampled ``up`` x) run as a Winograd layer on the pre-split planes, small
+        enough for its input transform to form the GroupNorm coefficients itself?  Mirrors the choices of :meth:`_emit_conv`."""
+        m = self.m
+        if self.training or consumer is None or not m.gn_in_transform or not (m.gemm_bf3 and m.gemm_bf3p):
+            return False
+        H, W, cout = up * x.H, up * x.W, consumer.weight.shape[0]
+        wm = self._winograd_ok(consumer, H, W, x.C)
+        if not wm or x.C % 16 or (x.C // self.GROUPS) % 2 or consumer.weight.shape[1] != x.C:
+            return False
+        small = bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)
+        cands = [(wm, H, W, cout)]
+        if up == 2 and m.upsample_phases:         # conv3x3(nearest x2 (x)) may run as four phase filters on x itself
+            wl = winograd_tile(self.N, x.H, x.W, x.C, 4 * cout, m.winograd, small=small)
+            if wl >= wm:
+                cands = [(wl, x.H, x.W, 4 * cout)]
+        for w_, h_, ww_, co_ in cands:
+            if self._use_bf3(w_, h_, ww_, x.C, co_) != "p" or self.lib.bbdm_winograd_tiles(w_, self.N, h_, ww_) > m.gn_in_transform:
+                return False
+        return True
 
     def _train_keeps_V(self, consumer, x: _View) -> bool:
         """Will the training forward of conv ``consumer`` on ``x`` keep its transformed input for the weight gradient?"""
@@ -1170,6 +1213,10 @@ class _Plan:
             self._saved_V[id(pw.weight)] = (vt, wm, "tr")
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_tr_f32"), wm, x, x.ld, vbuf,
                  *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt)
+        elif isinstance(pre, _GnPre):
+            assert split and not bwd, "the coefficient-folding input transform exists for the pre-split planes only"
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_gn_f32"), wm, x, x.ld, vbuf, *pre,
+                 1 if upsample else 0, N, H, W, cin_pad, *pre.tail)
         else:
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
                  wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)

@@ -410,6 +410,16 @@ int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_planes, const f
                           float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream);
 int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream);
+/* bbdm_winograd_input_bf3p_f32 with GroupNorm [-> FiLM] [-> SiLU] folded in FROM THE STATISTICS (util.py:214-216,
+ * openaimodel.py:258-278): the kernel forms x * sc[n][c] + bi[n][c] itself from `stats` (this GroupNorm's accumulator slot,
+ * bbdm_groupnorm_stats_bytes layout), gamma / beta [C] and the FiLM vector (film[n][c] scale, film[n][C + c] shift; null: none) --
+ * the expressions, hence the bits, of bbdm_groupnorm_coeffs_f32 followed by bbdm_winograd_input_bf3p_f32, in one launch.  For SMALL
+ * problems (every thread repeats the fp64 fold of its channel pair).  Same argument order with (stats, unused) for (pre_scale,
+ * pre_bias) and C for pre_ld; C == CinPad, C / G even, HW = pixels per image of the normalised tensor (x's own H * W, also with
+ * upsample = 1). */
+int bbdm_winograd_input_bf3p_gn_f32(int m, const float* x, int ldx, void* Vp, const void* stats, const void* unused, int C,
+                                    int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma,
+                                    const float* beta, const float* film, int film_ld, int HW, int G, float eps, void* stream);
 int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
                                 int Cout, void* stream);
 

@@ -251,6 +251,11 @@ def test_conv1x1_bf3q_bitwise(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3q_bitwise(CPU, pixels, Cin, Cout, res)
 
 
+@pytest.mark.parametrize("m,up,silu,film,N,H,W,C", [(2, 0, 1, True, 3, 4, 4, 64), (4, 1, 1, False, 2, 16, 8, 64), (6, 0, 0, True, 2, 14, 20, 64)])
+def test_winograd_input_forms_groupnorm_coefficients_bitwise(m, up, silu, film, N, H, W, C):
+    K.test_winograd_input_forms_groupnorm_coefficients_bitwise(CPU, m, up, silu, film, N, H, W, C)
+
+
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(128, 256, 132, True), (96, 128, 8, False), (100, 192, 520, True), (64, 64, 64, False)])
 def test_conv1x1_bf3s_bitwise(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3s_bitwise(CPU, pixels, Cin, Cout, res)

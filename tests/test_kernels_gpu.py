@@ -559,6 +559,40 @@ def test_conv1x1_bf3q_bitwise(dev, pixels, Cin, Cout, res):
         assert torch.equal(out, out0), (out - out0).abs().max()
 
 
+@pytest.mark.parametrize("m,up,silu,film,N,H,W,C", [(2, 0, 1, True, 3, 4, 4, 64), (4, 0, 1, True, 2, 16, 16, 128), (4, 1, 1, False, 2, 16, 8, 64),
+                                                    (6, 0, 0, True, 2, 14, 20, 192), (2, 1, 1, True, 5, 8, 8, 256)])
+def test_winograd_input_forms_groupnorm_coefficients_bitwise(dev, m, up, silu, film, N, H, W, C):
+    """bbdm_winograd_input_bf3p_gn_f32 (the input transform forms sc / bi from the GroupNorm statistics, gamma, beta and the FiLM
+    vector itself) writes the SAME planes, bit for bit, as bbdm_groupnorm_coeffs_f32 followed by bbdm_winograd_input_bf3p_f32 --
+    with and without FiLM / SiLU / nearest upsampling, F(2) / F(4) / F(6), ragged tile grids."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(7 * m + up + 3 * silu + C)
+    hs, ws_ = (H // 2, W // 2) if up else (H, W)
+    x = (torch.randn(N, hs, ws_, C, generator=g) * 1.7 + 0.3).to(dev)
+    gamma, beta = (torch.randn(C, generator=g) * 0.5 + 1).to(dev), torch.randn(C, generator=g).to(dev)
+    fv = torch.randn(N, 2 * C + 8, generator=g).to(dev) * 0.3 if film else None
+    lib = _lib.load()
+    st = ops._st(x)
+    stats = ops.groupnorm_stats(x)
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    P = (m + 2) ** 2
+    nbytes = lib.bbdm_gemm_bf3p_a_bytes(P, tiles, C)
+    sc = torch.empty(N, C, device=dev)
+    bi = torch.empty(N, C, device=dev)
+    _lib.call("bbdm_groupnorm_coeffs_f32", stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None if fv is None else fv.data_ptr(),
+              0 if fv is None else fv.shape[1], sc.data_ptr(), bi.data_ptr(), C, N, hs * ws_, C, 32, 1e-5, st)
+    V0 = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    V1 = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    _lib.call("bbdm_winograd_input_bf3p_f32", m, x.data_ptr(), C, V0.data_ptr(), sc.data_ptr(), bi.data_ptr(), C, silu, up, N, H, W, C, st)
+    _lib.call("bbdm_winograd_input_bf3p_gn_f32", m, x.data_ptr(), C, V1.data_ptr(), stats.data_ptr(), None, C, silu, up, N, H, W, C,
+              gamma.data_ptr(), beta.data_ptr(), None if fv is None else fv.data_ptr(), 0 if fv is None else fv.shape[1], hs * ws_, 32,
+              1e-5, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert V0.any() and torch.equal(V0.cpu(), V1.cpu())
+
+
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(512, 1024, 3072, False), (512, 64, 132, True), (96, 128, 8, False), (2080, 256, 1024, True),
                                                  (100, 192, 72, True), (64, 64, 64, False)])
 def test_conv1x1_bf3s_bitwise(dev, pixels, Cin, Cout, res):

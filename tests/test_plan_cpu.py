@@ -111,7 +111,10 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         entry = getattr(ops[k + 1][0], "entry", "")
         if "bf3p" in entry:                     # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
             in_entry = getattr(ops[k][0], "entry", "")
-            assert in_entry in ("bbdm_winograd_input_bf3p_f32", "bbdm_winograd_input_bf3p_tr_f32")
+            assert in_entry in ("bbdm_winograd_input_bf3p_f32", "bbdm_winograd_input_bf3p_tr_f32", "bbdm_winograd_input_bf3p_gn_f32")
+            if in_entry.endswith("_gn_f32"):        # small inference layer: the transform forms the GroupNorm coefficients itself
+                assert not training and tiles <= m.gn_in_transform and i[5] is None and i[6] == cin and len(i) == 20
+                assert i[17] == src.H * src.W and i[18] == 32 and cin % 64 == 0            # HW of the normalised tensor, groups
             if in_entry.endswith("_tr_f32"):        # training forward of a layer whose weight gradient contracts the transposed planes
                 assert training and i[8] == 0 and i[13].t.numel() == lib.bbdm_gemm_bf3p_tn_at_bytes(P, tiles, cin)
                 assert lib.bbdm_gemm_bf3p_tn_supported(tiles, cin, cout)
@@ -133,6 +136,12 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             assert ks == lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin, cout) > 1
             assert getattr(ops[k + 2][0], "entry", "") == "bbdm_winograd_output_splitk_stats_f32" and ops[k + 2][1][-1] == ks
             assert plan._wino_m.t.numel() >= ks * (wm + 2) ** 2 * tiles * cout
+    fused_gn = sum(1 for n, a in ops if n == "bbdm_winograd_input_f32" and a[4] is not None)
+    folded = sum(1 for n, a in ops if getattr(n, "entry", "") == "bbdm_winograd_input_bf3p_gn_f32")
+    # every fused GroupNorm has its coefficients from exactly one place: a bbdm_groupnorm_coeffs_f32 launch or its consumer's transform
+    assert names["bbdm_groupnorm_coeffs_f32"] + folded >= fused_gn and (training or folded > 0 or workload in ("c2", "c3"))
+    if (workload, batch, training) == ("c5", 32, False):
+        assert folded == fused_gn > 0 and names["bbdm_groupnorm_coeffs_f32"] == 1       # (the head's direct kernel keeps its launch)
     if training:
         assert names["bbdm_conv_wgrad_f32"] > 0
         fwd_wino = sum(n == "bbdm_winograd_gemm_f32" for n, _ in plan.ops)
@@ -168,6 +177,23 @@ def test_1x1_layers_take_the_kernel_their_size_asks_for():
     layers0 = one_by_ones(plan0)
     assert len(layers0) == len(layers) and not any(e == "bbdm_conv1x1_bf3s_f32" for e, *_ in layers0)
     assert [l[1:] for l in layers0] == [l[1:] for l in layers]
+
+
+def test_first_stage_flags_cover_every_switch_the_plan_emitters_read():
+    """The VQGAN plans reuse _Plan's emitters with first_stage_hip._Flags standing in for the UNetModel: every switch an emitter reads
+    (``self.m.<name>`` / ``m.<name>`` in unet.py's _Plan) must exist there, or the first plan of a first stage dies on a GPU box only."""
+    import inspect
+    import re
+    from bbdm_amd import first_stage_hip
+    src = inspect.getsource(unet._Plan)
+    read = set(re.findall(r"self\.m\.([a-z_0-9]+)", src)) | set(re.findall(r"(?<![\w.])m\.([a-z_0-9]+)", src))
+    switches = {n for n in read if hasattr(unet.UNetModel(**bench.WORKLOADS["c5"][1]), n)
+                and not callable(getattr(unet.UNetModel, n, None)) and not isinstance(getattr(unet.UNetModel, n, None), property)}
+    flags = first_stage_hip._Flags()
+    model_only = {"out", "input_blocks", "middle_block", "output_blocks", "time_embed", "model_channels", "out_channels", "in_channels",
+                  "context_dim", "training", "dtype", "num_heads", "num_head_channels"}
+    missing = sorted(n for n in switches - model_only if not hasattr(flags, n) and not isinstance(getattr(unet.UNetModel(**bench.WORKLOADS["c5"][1]), n), torch.nn.Module))
+    assert not missing, missing
 
 
 def test_flop_accounting_direct_equivalent_matches_the_direct_plan():
