@@ -24,6 +24,10 @@
 // L2 -> LDS traffic per FLOP than 256 x 128) where Cout fills them.
 // Measured (MI355X, the 42 Winograd layers of the C2 step): 216 TFLOP/s fp32-equivalent = 1.30 PFLOP/s of bf16 MFMA = 0.52 of the
 // 416.7 (2500 / 6) peak, MfmaUtil 75 % at the 1.77 GHz the chip sustains under this load; gemm_bf3.hip: 181 = 0.43, MfmaUtil 54 %.
+// Also in this file (same layouts, same bits): gemm_bf3q_pipe_kernel -- the pipelined kernel with an fp32 A operand split by the waves
+// between their MFMAs (wide 1x1 layers); gemm_bf3s_kernel -- the small-problem 1x1 kernel (64 x 64 tiles, 64 channels per step,
+// both operands by LDS-DMA two steps ahead, fp32 A split at the fragment read: round 4); the NS = 3 build of the pipe kernel for
+// small launches whose workgroups have a CU to themselves (round 4).
 #include "bf3_split.h"
 #include <stdlib.h>
 
