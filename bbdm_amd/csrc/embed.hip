@@ -67,6 +67,35 @@ __global__ void __launch_bounds__(256) linear_kernel(const float* __restrict__ x
     y[(size_t)n * Out + o] = acc;
 }
 
+// act_in(x) [rows x In] -> LDS (pitch floats per row; rows >= N zero), by the 256 threads of the workgroup.  Every workgroup of a
+// launch stages the same x: 16-byte loads where In allows (the scalar loop was 64 dependent-free loads + 64 SiLUs per thread and a
+// third of the FiLM projection's 47 us at batch 32).
+__device__ __forceinline__ void stage_rows(const float* __restrict__ x, float* xs, int rows, int N, int In, int pitch, int act_in, int tid) {
+    if ((In & 3) == 0 && (((uintptr_t)x & 15) == 0)) {
+        const int In4 = In >> 2;
+        for (int k = tid; k < rows * In4; k += 256) {
+            const int n = k / In4, i = (k - n * In4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N) {
+                v = *reinterpret_cast<const float4*>(x + (size_t)n * In + i);
+                if (act_in) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            }
+            float* d = xs + n * pitch + i;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        return;
+    }
+    for (int k = tid; k < rows * In; k += 256) {
+        const int n = k / In, i = k - n * In;
+        float v = 0.f;
+        if (n < N) {
+            v = x[(size_t)n * In + i];
+            if (act_in) v = silu_f(v);
+        }
+        xs[n * pitch + i] = v;
+    }
+}
+
 // The same product on the f32 matrix core (In % 8 == 0): the rows of w are the B operand straight from global memory -- lane (o, half)
 // streams ITS row, 16 bytes per four MFMA steps (the k pair of a step is (8 q + e, 8 q + 4 + e): both halves read contiguous float4s) --
 // and act_in(x) is the A operand from LDS (pitch In + 1).  A wave owns 32 outputs for all rows; the 51 MB FiLM projection of the
@@ -78,15 +107,7 @@ __global__ void __launch_bounds__(256) linear_mfma_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) float xs[];   // [MB * 32][In + 1], rows >= N zero
     const int pitch = In + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    for (int k = tid; k < MB * 32 * In; k += 256) {
-        const int n = k / In, i = k - n * In;
-        float v = 0.f;
-        if (n < N) {
-            v = x[(size_t)n * In + i];
-            if (act_in) v = silu_f(v);
-        }
-        xs[n * pitch + i] = v;
-    }
+    stage_rows(x, xs, MB * 32, N, In, pitch, act_in, tid);
     __syncthreads();
     const int otiles = (Out + 31) / 32, nq = In / 8;
     const float* a0p = xs + l31 * pitch + 4 * hi;
@@ -144,6 +165,100 @@ __global__ void __launch_bounds__(256) linear_mfma_kernel(const float* __restric
                     if (act_out) v = silu_f(v);
                     y[(size_t)(32 + n) * Out + o] = v;
                 }
+            }
+        }
+    }
+}
+
+// ---- the same product on PACKED weights (inference plans: the weights are packed once, round 4) ---------------------------------------
+// linear_mfma_kernel lets every lane stream its own weight row: 25 000 concurrent 2-KB rows, 32 B at a time each -- the 51 MB FiLM
+// projection moves at 1.0 TB/s (51 us per forward of every configuration; 36 us average over the three linears of an LBBDM-f16 step).
+// Here the weights are packed into 4 KB blocks [32 outputs x 32 k] that are already the LDS image the B fragments are read from
+// ([q = k / 8][half][output] x 16 B: the 64 lanes of a fragment read sit on consecutive 16-B slots), one block after the other per
+// output tile: a wave streams ITS tile's blocks as ONE sequential stream of 1 KB LDS-DMA copies, four blocks deep, into LDS it shares
+// with nobody (no barrier in the loop: counted vmcnt only).  Same MFMA steps in the same order as linear_mfma_kernel: the same bits.
+__device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p; }
+constexpr int LP_KB = 32;                      // k per block
+constexpr int LP_BLOCK = 32 * LP_KB * 4;       // bytes per block
+constexpr int LP_NS = 4;                       // blocks in the ring of one wave
+
+__global__ void linear_pack_kernel(const float* __restrict__ w, float* __restrict__ p, int Out, int In, int otiles) {
+    const int nkb = In / LP_KB;
+    const size_t total = (size_t)otiles * nkb * (LP_BLOCK / 16);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int slot = (int)(i % (LP_BLOCK / 16));                  // 16-B slot inside the block: ((q * 2 + half) * 32 + output)
+        const size_t blk = i / (LP_BLOCK / 16);
+        const int kb = (int)(blk % nkb), ot = (int)(blk / nkb);
+        const int o = ot * 32 + (slot & 31), half = (slot >> 5) & 1, q = slot >> 6;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (o < Out) v = *reinterpret_cast<const float4*>(w + (size_t)o * In + kb * LP_KB + q * 8 + half * 4);
+        *reinterpret_cast<float4*>(p + i * 4) = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) linear_packed_kernel(const float* __restrict__ x, const unsigned char* __restrict__ wp,
+                                                            const float* __restrict__ b, float* __restrict__ y, int N, int In, int Out,
+                                                            int act_in, int act_out) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [32][In + 1] (rows >= N zero), then [4 waves][LP_NS][LP_BLOCK]
+    const int pitch = In + 1;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int otiles = (Out + 31) / 32, nkb = In / LP_KB;
+    const int ot = (int)blockIdx.x * 4 + wave;
+    unsigned char* const ring = reinterpret_cast<unsigned char*>(xs) + (((size_t)32 * pitch * 4 + 15) & ~(size_t)15) + (size_t)wave * (LP_NS * LP_BLOCK);
+    const unsigned char* const src = wp + (size_t)(ot < otiles ? ot : otiles - 1) * nkb * LP_BLOCK + lane * 16;
+    auto issue = [&](int kb, unsigned char* st) {
+#pragma unroll
+        for (int c = 0; c < LP_BLOCK / 1024; ++c)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)kb * LP_BLOCK + c * 1024),
+                                             (__attribute__((address_space(3))) void*)(st + c * 1024), 16, 0, 0);
+    };
+    // the first blocks are requested before x is staged: their latency hides under the staging
+#pragma unroll
+    for (int k = 0; k < LP_NS - 1; ++k)
+        if (k < nkb) issue(k, ring + k * LP_BLOCK);
+    stage_rows(x, xs, 32, N, In, pitch, act_in, tid);
+    __syncthreads();
+    if (ot >= otiles) {                                   // (a padding wave of the last workgroup: its copies must land before it ends)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* a0p = xs + l31 * pitch + 4 * hi;
+    const unsigned ring0 = lds_address(ring) + lane * 16;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    for (int kb = 0; kb < nkb; ++kb) {
+        // block kb has landed (the younger ones that were requested may stay in flight)
+        const int younger = min(LP_NS - 2, nkb - 1 - kb);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned st = ring0 + (unsigned)((kb % LP_NS) * LP_BLOCK);
+        f32x4 wv[LP_KB / 8];
+#pragma unroll
+        for (int q = 0; q < LP_KB / 8; ++q)               // (hand-written: a plain LDS load after an LDS-DMA copy is guarded with vmcnt(0))
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(st), "n"(q * 1024));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]) :: "memory");
+        if (kb + LP_NS - 1 < nkb) issue(kb + LP_NS - 1, ring + ((kb + LP_NS - 1) % LP_NS) * LP_BLOCK);   // the stage block kb - 1 was read from
+#pragma unroll
+        for (int q = 0; q < LP_KB / 8; ++q) {
+            const float* ap = a0p + kb * LP_KB + q * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[e], wv[q][e], acc, 0, 0, 0);
+        }
+    }
+    const int o = ot * 32 + l31;
+    if (o < Out) {
+        const float bo = b ? b[o] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (n < N) {
+                float v = acc[r] + bo;
+                if (act_out) v = silu_f(v);
+                y[(size_t)n * Out + o] = v;
             }
         }
     }
@@ -377,5 +492,45 @@ extern "C" int bbdm_linear_f32(const float* x, const float* w, const float* b, f
     else
         hipLaunchKernelGGL(linear_kernel<0>, grid, dim3(256), lds, st, x, w, b, y, N, In, Out, NBl, act_in, act_out);
     BBDM_CHECK_LAUNCH("linear");
+    return BBDM_OK;
+}
+
+// bbdm_linear_f32 on weights packed once (inference: static weights).  packed = bbdm_linear_pack_f32(w) holds
+// bbdm_linear_packed_bytes(Out, In) bytes; N <= 32 rows, In a multiple of 32 (<= 8192).  Same results bit for bit.
+extern "C" size_t bbdm_linear_packed_bytes(int Out, int In) { return (size_t)((Out + 31) / 32) * 32 * (size_t)In * 4; }
+extern "C" int bbdm_linear_packed_supported(int N, int In, int Out) {
+    return N > 0 && N <= 32 && In > 0 && In % LP_KB == 0 && Out > 0 &&
+           (size_t)32 * (In + 1) * 4 + 16 + (size_t)4 * LP_NS * LP_BLOCK <= 160 * 1024;
+}
+extern "C" int bbdm_linear_pack_f32(const float* w, void* packed, int Out, int In, void* stream) {
+    BBDM_REQUIRE(w && packed && Out > 0 && In > 0 && In % LP_KB == 0 && (((uintptr_t)w | (uintptr_t)packed) & 15) == 0, "linear_pack: bad args");
+    const int otiles = (Out + 31) / 32;
+    const size_t total = (size_t)otiles * (In / LP_KB) * (LP_BLOCK / 16);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(linear_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (float*)packed, Out, In, otiles);
+    BBDM_CHECK_LAUNCH("linear_pack");
+    return BBDM_OK;
+}
+extern "C" int bbdm_linear_packed_f32(const float* x, const void* packed, const float* b, float* y, int N, int In, int Out, int act_in,
+                                      int act_out, void* stream) {
+    BBDM_REQUIRE(x && packed && y, "linear_packed: null pointer");
+    BBDM_REQUIRE(bbdm_linear_packed_supported(N, In, Out) && ((uintptr_t)packed & 15) == 0, "linear_packed: N=%d In=%d Out=%d unsupported",
+                 N, In, Out);
+    const size_t lds = (((size_t)32 * (In + 1) * 4 + 15) & ~(size_t)15) + (size_t)4 * LP_NS * LP_BLOCK;
+    static size_t lds_dev[BBDM_MAX_DEVICES] = {};
+    size_t& have = lds_dev[bbdm_device_slot()];
+    if (lds > 64 * 1024 && lds > have) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            bbdm_set_error("linear_packed: hipFuncSetAttribute(%zu) failed", lds);
+            return BBDM_E_LAUNCH;
+        }
+        have = lds;
+    }
+    const int otiles = (Out + 31) / 32;
+    hipLaunchKernelGGL(linear_packed_kernel, dim3((unsigned)((otiles + 3) / 4)), dim3(256), lds, (hipStream_t)stream, x,
+                       (const unsigned char*)packed, b, y, N, In, Out, act_in, act_out);
+    BBDM_CHECK_LAUNCH("linear_packed");
     return BBDM_OK;
 }

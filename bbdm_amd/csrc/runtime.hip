@@ -11,7 +11,7 @@ void bbdm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int bbdm_version(void) { return 19; }
+extern "C" int bbdm_version(void) { return 20; }
 extern "C" const char* bbdm_last_error(void) { return g_err; }
 
 namespace {

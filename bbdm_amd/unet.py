@@ -808,7 +808,7 @@ class _Plan:
         self._wino_v_need = self._wino_m_need = 0
         self._saved_V: Dict[int, tuple] = {}         # training: id(conv weight) -> (V kept by the forward, tile m)
         self._fused_train = set()                    # training: id(conv weight) of layers whose GN->SiLU input was never materialised
-        self.film, self.film_total, self.resblocks, self._film_key = None, 0, [], None
+        self.film, self.film_total, self.resblocks, self._film_key, self.film_wp = None, 0, [], None, None
         # (id(buffer), channel offset) -> record of the conv op that LAST wrote that channel slice: where a GroupNorm
         # consumer can ask the producer to accumulate its statistics (bbdm_*_stats_f32) instead of re-reading the tensor
         self._writers: Dict[tuple, dict] = {}
@@ -860,6 +860,13 @@ class _Plan:
         self.film_w = torch.empty(off, ted, **f32)        # concatenation of every emb_layers.1 weight / bias
         self.film_b = torch.empty(off, **f32)
         self._film_key = None
+        # inference: the concatenated FiLM weight is also kept PACKED (csrc/embed.hip: linear_packed_kernel streams it sequentially,
+        # 51 MB at HBM rate instead of 1 TB/s); repacked whenever the weights change.  Training plans (new weights every step) and
+        # BBDM_LINEAR_PACKED=0 keep bbdm_linear_f32.
+        self.film_wp = None
+        if (off and not training and os.environ.get("BBDM_LINEAR_PACKED", "1") != "0"
+                and self.lib.bbdm_linear_packed_supported(min(N, 32), ted, off)):
+            self.film_wp = torch.empty(self.lib.bbdm_linear_packed_bytes(off, ted), dtype=torch.uint8, device=device)
 
         # ---- input / output --------------------------------------------------------------------------------------
         cin = m.in_channels
@@ -2089,6 +2096,9 @@ class _Plan:
                 self.film_w[off:off + n].copy_(lin.weight.detach())
                 self.film_b[off:off + n].copy_(lin.bias.detach())
                 off += n
+            if self.film_wp is not None:
+                _lib.call("bbdm_linear_pack_f32", self.film_w.data_ptr(), self.film_wp.data_ptr(), self.film_total,
+                          self.film_w.shape[1], stream)
             self._film_key = fkey
 
     def _launch_embedding(self, stream):
@@ -2109,9 +2119,14 @@ class _Plan:
                  self.e1.data_ptr() + 4 * r0 * ted, r, mc, ted, 0, 0, stream)
             call("bbdm_linear_f32", self.e1.data_ptr() + 4 * r0 * ted, te2.weight.data_ptr(), te2.bias.data_ptr(),
                  self.emb.data_ptr() + 4 * r0 * ted, r, ted, ted, 1, 0, stream)
-            call("bbdm_linear_f32", self.emb.data_ptr() + 4 * r0 * ted, self.film_w.data_ptr(),
-                 self.film_b.data_ptr(), self.film.data_ptr() + 4 * r0 * self.film_total, r, ted, self.film_total,
-                 1, 0, stream)
+            if self.film_wp is None:
+                call("bbdm_linear_f32", self.emb.data_ptr() + 4 * r0 * ted, self.film_w.data_ptr(),
+                     self.film_b.data_ptr(), self.film.data_ptr() + 4 * r0 * self.film_total, r, ted, self.film_total,
+                     1, 0, stream)
+        if self.film_wp is not None:
+            for r0 in range(0, N, 32):      # (<= 32 rows per call of the packed kernel)
+                call("bbdm_linear_packed_f32", self.emb.data_ptr() + 4 * r0 * ted, self.film_wp.data_ptr(), self.film_b.data_ptr(),
+                     self.film.data_ptr() + 4 * r0 * self.film_total, min(32, N - r0), ted, self.film_total, 1, 0, stream)
 
     def _launch_forward(self, stream, prof=None):
         """Enqueue one forward (statistics reset, embedding path, the op list) on ``stream``."""

@@ -247,6 +247,16 @@ int bbdm_timestep_embedding_f32(const int64_t* t, const float* freqs, float* emb
 int bbdm_linear_f32(const float* x, const float* w, const float* b, float* y, int N, int In, int Out,
                     int act_in, int act_out, void* stream);
 
+/* bbdm_linear_f32 on weights packed ONCE (inference plans: static weights; the 51 MB FiLM projection of the UNets moves at 1 TB/s
+ * when every lane streams its own 2 KB row).  packed = bbdm_linear_pack_f32(w [Out][In]): bbdm_linear_packed_bytes(Out, In) bytes,
+ * 4 KB blocks [32 outputs x 32 k] in the order the B fragments are read from LDS, streamed sequentially per output tile
+ * (csrc/embed.hip: linear_packed_kernel).  N <= 32 rows, In a multiple of 32 (bbdm_linear_packed_supported); results identical to
+ * bbdm_linear_f32 bit for bit. */
+size_t bbdm_linear_packed_bytes(int Out, int In);
+int bbdm_linear_packed_supported(int N, int In, int Out);
+int bbdm_linear_pack_f32(const float* w, void* packed, int Out, int In, void* stream);
+int bbdm_linear_packed_f32(const float* x, const void* packed, const float* b, float* y, int N, int In, int Out, int act_in,
+                           int act_out, void* stream);
 /* Backward of bbdm_linear_f32 (training): dw[o][i] = sum_n dy[n][o] act_in(x[n][i]); db[o] = sum_n dy[n][o] (db may be
  * NULL); dx[n][i] = act_in'(x[n][i]) sum_o dy[n][o] w[o][i] (dx may be NULL).  x is the PRE-activation input.
  * ws: bbdm_linear_bwd_workspace_floats() floats.  N <= 64. */

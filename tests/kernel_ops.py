@@ -253,6 +253,22 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act_in: 
     return y
 
 
+def linear_packed(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act_in: bool = False,
+                  act_out: bool = False) -> torch.Tensor:
+    """:func:`linear` on weights packed once (bbdm_linear_pack_f32 + bbdm_linear_packed_f32; N <= 32 rows, In % 32 == 0)."""
+    _chk(x, w, b)
+    N, In = x.shape
+    Out = w.shape[0]
+    lib = _lib.load()
+    assert lib.bbdm_linear_packed_supported(N, In, Out)
+    wp = torch.empty(lib.bbdm_linear_packed_bytes(Out, In), dtype=torch.uint8, device=x.device)
+    _lib.call("bbdm_linear_pack_f32", w.data_ptr(), wp.data_ptr(), Out, In, _st(x))
+    y = torch.empty(N, Out, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_linear_packed_f32", x.data_ptr(), wp.data_ptr(), None if b is None else b.data_ptr(), y.data_ptr(), N, In, Out,
+              1 if act_in else 0, 1 if act_out else 0, _st(x))
+    return y
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # backward (training path)
 # ---------------------------------------------------------------------------------------------------------------

@@ -269,3 +269,9 @@ def test_winograd_weight_planes_fused_bitwise(m, Cout, Cin, in_pad, dgrad):
 @pytest.mark.parametrize("N,In,Out,act_in,act_out", [(5, 512, 200, True, False), (33, 64, 72, True, True), (16, 128, 40, False, False)])
 def test_linear_on_the_matrix_core(N, In, Out, act_in, act_out):
     K.test_linear_on_the_matrix_core(CPU, N, In, Out, act_in, act_out)
+
+
+@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(4, 512, 200, True, False), (17, 64, 40, False, True), (32, 96, 33, True, True),
+                                                     (1, 32, 32, False, False)])
+def test_linear_on_packed_weights_bitwise(N, In, Out, act_in, act_out):
+    K.test_linear_on_packed_weights_bitwise(CPU, N, In, Out, act_in, act_out)

@@ -950,6 +950,29 @@ def test_linear_on_the_matrix_core(dev, N, In, Out, act_in, act_out):
     assert rel_err(y.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(32, 512, 25088, True, False), (4, 512, 1000, True, False), (17, 64, 40, False, True),
+                                                     (32, 96, 33, True, True), (1, 32, 32, False, False)])
+def test_linear_on_packed_weights_bitwise(dev, N, In, Out, act_in, act_out):
+    """bbdm_linear_packed_f32 (weights packed once into 4 KB blocks that a wave streams sequentially by LDS-DMA, four deep, into LDS of
+    its own) against F.linear and, bit for bit, against bbdm_linear_f32 -- the FiLM projection of the reference UNets (512 -> 25088),
+    ragged output tiles, one K block and many, a padding wave in the last workgroup, both activations."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(N + In + Out)
+    x = torch.randn(N, In, generator=g)
+    w = torch.randn(Out, In, generator=g) * 0.05
+    b = torch.randn(Out, generator=g) * 0.1
+    ref = F.linear(F.silu(x) if act_in else x, w, b)
+    if act_out:
+        ref = F.silu(ref)
+    y = ops.linear_packed(x.to(dev), w.to(dev), b.to(dev), act_in=act_in, act_out=act_out).cpu()
+    y0 = ops.linear(x.to(dev), w.to(dev), b.to(dev), act_in=act_in, act_out=act_out).cpu()
+    assert rel_err(y, ref) < TOL
+    if In % 8 == 0 and In >= 64 and Out >= 32:          # bbdm_linear_f32 takes its matrix-core kernel: the same MFMA steps in the same order
+        assert torch.equal(y, y0), (y - y0).abs().max()
+    else:
+        assert rel_err(y, y0) < TOL
+
+
 @pytest.mark.parametrize("objective", ["grad", "noise", "ysubx"])
 def test_bridge_arithmetic(dev, objective):
     """q_sample / predict_x0 / p_sample update / loss against the oracle formulas: bit-exact or 1 ulp."""
