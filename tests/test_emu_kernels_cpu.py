@@ -266,7 +266,7 @@ def test_winograd_weight_planes_fused_bitwise(m, Cout, Cin, in_pad, dgrad):
     K.test_winograd_weight_planes_fused_bitwise(CPU, m, Cout, Cin, in_pad, dgrad)
 
 
-@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(5, 512, 200, True, False), (33, 64, 72, True, True), (16, 128, 40, False, False)])
+@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(5, 128, 2090, True, False), (33, 64, 2056, True, True), (16, 128, 40, False, False)])
 def test_linear_on_the_matrix_core(N, In, Out, act_in, act_out):
     K.test_linear_on_the_matrix_core(CPU, N, In, Out, act_in, act_out)
 

@@ -931,11 +931,11 @@ def test_embedding_path(dev, N):
     assert rel_err(y2.cpu(), F.linear(x2, w2)) < TOL
 
 
-@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(5, 512, 1000, True, False), (33, 512, 520, True, True), (64, 64, 96, False, True),
-                                                      (16, 128, 40, False, False), (32, 512, 4096, True, False)])
+@pytest.mark.parametrize("N,In,Out,act_in,act_out", [(5, 512, 2090, True, False), (33, 512, 2100, True, True), (64, 64, 2050, False, True),
+                                                      (16, 128, 40, False, False), (32, 512, 4096, True, False), (32, 512, 512, True, False)])
 def test_linear_on_the_matrix_core(dev, N, In, Out, act_in, act_out):
-    """bbdm_linear_f32 with In % 8 == 0 (linear_mfma_kernel): one and two 32-row blocks, ragged 32-output tiles, a K that is not a
-    multiple of the four-float4 prefetch group, both activations."""
+    """bbdm_linear_f32 with In % 8 == 0 and >= 2048 outputs (linear_mfma_kernel): one and two 32-row blocks, ragged 32-output tiles, a K
+    that is not a multiple of the four-float4 prefetch group, both activations; below 2048 outputs the thread-per-output kernel."""
     import kernel_ops as ops
     g = torch.Generator().manual_seed(N + In + Out)
     x = torch.randn(N, In, generator=g)
@@ -967,7 +967,7 @@ def test_linear_on_packed_weights_bitwise(dev, N, In, Out, act_in, act_out):
     y = ops.linear_packed(x.to(dev), w.to(dev), b.to(dev), act_in=act_in, act_out=act_out).cpu()
     y0 = ops.linear(x.to(dev), w.to(dev), b.to(dev), act_in=act_in, act_out=act_out).cpu()
     assert rel_err(y, ref) < TOL
-    if In % 8 == 0 and In >= 64 and Out >= 32:          # bbdm_linear_f32 takes its matrix-core kernel: the same MFMA steps in the same order
+    if In % 8 == 0 and In >= 64 and Out >= 2048:        # bbdm_linear_f32 takes its matrix-core kernel: the same MFMA steps in the same order
         assert torch.equal(y, y0), (y - y0).abs().max()
     else:
         assert rel_err(y, y0) < TOL

@@ -4,7 +4,7 @@ import kernel_ops as ops
 from bbdm_amd import _lib
 dev = torch.device("cuda")
 lib = _lib.load()
-for (N, In, Out) in ((32, 512, 25088), (4, 512, 25088)):
+for (N, In, Out) in ((32, 512, 25088), (4, 512, 25088), (32, 512, 512), (32, 128, 512), (4, 512, 512)):
     x = torch.randn(N, In, device=dev); w = torch.randn(Out, In, device=dev) * 0.05; b = torch.randn(Out, device=dev)
     y = torch.empty(N, Out, device=dev)
     wp = torch.empty(lib.bbdm_linear_packed_bytes(Out, In), dtype=torch.uint8, device=dev)
