@@ -26,6 +26,28 @@ from . import _lib
 __all__ = ["UNetModel"]
 
 
+class _NoVersion:
+    """Stands in for the version of a tensor that has no version counter: never equal to anything.  (A FRESH instance per read:
+    container comparisons short-cut on identity.)"""
+
+    def __eq__(self, other):
+        return False
+
+    __hash__ = object.__hash__
+
+
+def _ver(t: torch.Tensor):
+    """``t._version``, or a :class:`_NoVersion` for inference tensors (``torch.inference_mode()``: no version counter).  The version
+    only tracks writes made through torch ops on ``t`` or its views -- a raw-pointer kernel or a DLPack consumer does not bump it --
+    so every cache keyed on it must tolerate a miss: a key containing a ``_NoVersion`` never matches, i.e. the copy / re-pack runs."""
+    if t.is_inference():
+        return _NoVersion()
+    try:
+        return t._version
+    except RuntimeError:
+        return _NoVersion()
+
+
 # --------------------------------------------------------------------------------------------------------------
 # parameter-holder modules (names follow the reference so that class-name based init hooks match)
 # --------------------------------------------------------------------------------------------------------------
@@ -313,7 +335,7 @@ class _PackedConv:
 
     def refresh(self, stream):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), _ver(w))
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
@@ -335,7 +357,7 @@ class _PackedConvBf3(_PackedConv):
 
     def refresh(self, stream):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), _ver(w))
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
@@ -358,7 +380,7 @@ class _PackedConvBf3q(_PackedConv):
 
     def refresh(self, stream):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), _ver(w))
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
@@ -389,7 +411,7 @@ class _PackedDgradBf3:
 
     def refresh(self, stream):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), _ver(w))
         if key != self.key:
             _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                       self.cout_in, 1, stream)
@@ -412,7 +434,7 @@ class _PackedDgrad:
 
     def refresh(self, stream):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), _ver(w))
         if key != self.key:
             _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
                       self.cout_in, self.ks, stream)
@@ -454,7 +476,7 @@ class _PackedWinograd:
 
     def refresh(self, stream):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), _ver(w))
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
@@ -2086,8 +2108,8 @@ class _Plan:
             self._param_key = key
         for pc in self.convs:
             pc.refresh(stream)
-        fkey = tuple((rb.emb_layers[1].weight.data_ptr(), rb.emb_layers[1].weight._version,
-                      rb.emb_layers[1].bias.data_ptr(), rb.emb_layers[1].bias._version) for rb in self.resblocks)
+        fkey = tuple((rb.emb_layers[1].weight.data_ptr(), _ver(rb.emb_layers[1].weight),
+                      rb.emb_layers[1].bias.data_ptr(), _ver(rb.emb_layers[1].bias)) for rb in self.resblocks)
         if fkey != self._film_key:
             off = 0
             for rb in self.resblocks:
@@ -2163,7 +2185,8 @@ class _Plan:
 
     def holds_input(self, x: torch.Tensor):
         """``x_in`` now holds the value of ``x`` (the fused bridge kernel wrote x_next there as well: csrc/bridge.hip)."""
-        self._x_src = (x, x._version)
+        v = _ver(x)
+        self._x_src = None if isinstance(v, _NoVersion) else (x, v)
 
     def run(self, x, t, ctx, out=None, borrow=False):
         with _lib.device_guard(self.device):        # NULL-stream launches follow the current device (see _lib.device_guard)
@@ -2178,14 +2201,15 @@ class _Plan:
         # (holds_input), the conditioning image that does not change during a sampling loop.  Identity AND version are checked and the
         # source is kept alive, so neither an in-place edit nor a recycled allocation can be mistaken for it.
         src = getattr(self, "_x_src", None)
-        if not (src is not None and src[0] is x and src[1] == x._version):
+        if not (src is not None and src[0] is x and src[1] == _ver(x)):
             self.x_in.copy_(x)
         self._x_src = None
         if self.ctx_in is not None:
             csrc = getattr(self, "_ctx_src", None)
-            if not (csrc is not None and csrc[0] is ctx and csrc[1] == ctx._version):
+            if not (csrc is not None and csrc[0] is ctx and csrc[1] == _ver(ctx)):
                 self.ctx_in.copy_(ctx)
-                self._ctx_src = (ctx, ctx._version)
+                v = _ver(ctx)
+                self._ctx_src = None if isinstance(v, _NoVersion) else (ctx, v)
         if isinstance(t, int):
             self.t_buf.fill_(t)                                   # (p_sample: one timestep for the whole batch)
         else:

@@ -242,3 +242,9 @@ def test_sampling_loop_skips_input_copies_safely(monkeypatch):
     """tests/test_model_gpu.py's check of the x_next hand-over through the plan's input buffer, on the emulated kernels."""
     monkeypatch.setattr(M, "build", lambda rec, dev: _build(rec))
     M.test_sampling_loop_skips_input_copies_safely(CPU)
+
+
+def test_sampling_under_inference_mode(monkeypatch):
+    """tests/test_model_gpu.py's inference-mode sampling check (tensors without a version counter) on the emulated kernels."""
+    monkeypatch.setattr(M, "build", lambda rec, dev: _build(rec))
+    M.test_sampling_under_inference_mode(CPU)

@@ -222,3 +222,39 @@ def test_sampling_loop_skips_input_copies_safely(dev):
         assert torch.equal(r1, r2)
     finally:
         torch.randn_like = orig
+
+
+def test_sampling_under_inference_mode(dev):
+    """``p_sample`` / ``sample`` under ``torch.inference_mode()``: inference tensors carry no version counter, so the input-copy
+    skip of the plan must fall back to copying (round-4 advisor finding: ``x._version`` raised at the first step).  Same bits as
+    under ``no_grad``, in-place edits of an inference tensor between steps included."""
+    rec = load_case("tiny_concat")
+    m = build(rec, dev)
+    y = rec["y"].to(dev)
+    eps = rec["p_eps"].to(dev)
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: eps
+    try:
+        def run():
+            img, yy = y.clone(), y.clone()
+            outs = []
+            for i in range(3):
+                if i == 2:
+                    yy.add_(0.25)
+                    img.mul_(0.5)
+                a, b = m.p_sample(img, yy, yy, i, clip_denoised=True)
+                outs.append((a.clone(), b.clone()))
+                img = a
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
+            return outs
+        with torch.no_grad():
+            want = run()
+        with torch.inference_mode():
+            got = run()
+            full = m.sample(y, clip_denoised=True)
+        for (a0, b0), (a1, b1) in zip(want, got):
+            assert torch.equal(a0, a1) and torch.equal(b0, b1)
+        assert torch.isfinite(full).all()
+    finally:
+        torch.randn_like = orig
