@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -47,7 +47,7 @@ SIGNATURES = {
     "bbdm_conv_packed_dgrad_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "bbdm_conv_pack_weight_dgrad_f32": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "bbdm_conv_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "bbdm_conv_wgrad_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "bbdm_conv_wgrad_f32": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "bbdm_conv3x3_winograd_wgrad_f32": (c_int, [c_int, _P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_winograd_dy_transform_f32": (c_int, [c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, _P]),
@@ -129,7 +129,8 @@ SIGNATURES = {
     "bbdm_opt_chunk_elems": (c_int, []),
     "bbdm_adam_ema_step_f32": (c_int, [_P, c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                        ctypes.c_longlong, c_int, c_double, _P]),
-    "bbdm_debug_set_bf3p_kernel": (c_int, [c_int]),             # test hook (header: "test hooks")
+    "bbdm_set_option": (c_int, [c_char_p, c_int]),              # header: "options" (tests / tools A-B runs)
+    "bbdm_get_option": (c_int, [c_char_p, _P]),
 }
 
 _lib = None
@@ -195,6 +196,31 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().bbdm_last_error()
         raise BBDMHipError(f"{what or 'bbdm call'} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+class option:
+    """``with _lib.option("bf3p_kernel", 4): ...`` -- set one of the library's integer options (include/bbdm_hip.h "options") for the
+    block and restore the previous value.  Tests and tools/ A-B runs; the product path never changes an option."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        old = ctypes.c_int(0)
+        call("bbdm_get_option", self.name, ctypes.byref(old))
+        self.old = old.value
+        call("bbdm_set_option", self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        call("bbdm_set_option", self.name, self.old)
+        return False
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int(0)
+    call("bbdm_get_option", name.encode(), ctypes.byref(v))
+    return v.value
 
 
 def call(name: str, *args):

@@ -319,18 +319,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
 static int launch_attention(const float* q, int ldq, int hsq, const float* k, const float* v, int ldkv, int hskv, float* out,
                             int ldo, float* lse, int N, int Tq, int Tk, int heads, int ch, float qscale, float kscale,
                             hipStream_t st) {
-    // Q K^T and P V on the bf16x3 path (BBDM_ATTN_BF3=0: both on the f32 MFMA; 2: only Q K^T, the round-2 kernel -- for the A/B)
-    static const int bq = [] { const char* e = getenv("BBDM_ATTN_BF3"); return e ? atoi(e) : 1; }();
-    // 4 waves (128 queries) per workgroup, three workgroups per CU; BBDM_ATTN_WAVES=8: 256 queries, K / V staged once per 256 (A/B)
-    static const int nw_env = [] { const char* e = getenv("BBDM_ATTN_WAVES"); return e ? atoi(e) : 4; }();
-    const int nw = (nw_env == 8 && Tq > 128) ? 8 : 4;
+    // Q K^T and P V on the bf16x3 path (option attn_bf3 = 0: both on the f32 MFMA; 2: only Q K^T, the round-2 kernel -- for the A/B)
+    const int bq = bbdm_option(BBDM_OPT_ATTN_BF3);
+    // 4 waves (128 queries) per workgroup, three workgroups per CU (an 8-wave / 256-query form, K / V staged once per 256 queries,
+    // measured 6.55 against 6.16 ms at C2 in round 3 and is gone)
+    const int nw = 4;
     const int qblocks = (Tq + nw * 32 - 1) / (nw * 32);
     const int nht = N * heads;
     const dim3 grid((unsigned)(8ll * ((nht + 7) / 8) * qblocks));
 #define BBDM_ATTN_FWD(CH, BQ, BV, NW)                                                                                      \
     hipLaunchKernelGGL((attn_fwd_kernel<CH, BQ, BV, NW>), grid, dim3(NW * 64), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, \
                        lse, Tq, Tk, heads, nht, qscale, kscale)
-#define BBDM_ATTN_FWD_NW(CH, BQ, BV) do { if (nw == 8) BBDM_ATTN_FWD(CH, BQ, BV, 8); else BBDM_ATTN_FWD(CH, BQ, BV, 4); } while (0)
+#define BBDM_ATTN_FWD_NW(CH, BQ, BV) BBDM_ATTN_FWD(CH, BQ, BV, 4)
     if (ch == 64) { if (bq == 1) BBDM_ATTN_FWD_NW(64, true, true); else if (bq) BBDM_ATTN_FWD_NW(64, true, false); else BBDM_ATTN_FWD_NW(64, false, false); }
     else if (ch == 32) { if (bq == 1) BBDM_ATTN_FWD_NW(32, true, true); else if (bq) BBDM_ATTN_FWD_NW(32, true, false); else BBDM_ATTN_FWD_NW(32, false, false); }
     else { if (bq) BBDM_ATTN_FWD_NW(16, true, false); else BBDM_ATTN_FWD_NW(16, false, false); }

@@ -1082,14 +1082,13 @@ extern "C" int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* 
     a.st_s[1] = (unsigned long long*)stats1; a.st_cpg[1] = cpg1 > 0 ? cpg1 : 1; a.st_coff[1] = coff1;
     hipStream_t st = (hipStream_t)stream;
     const long long M = (long long)N * H * W;
-    static const long long narrow_min = getenv("BBDM_CONV_NARROW_MIN") ? atoll(getenv("BBDM_CONV_NARROW_MIN")) : 4096;
+    const long long narrow_min = 4096;       // (below: the general implicit GEMM; measured slower from 8192 pixels)
     if (ks == 3 && Cout <= 8 && !residual && M >= narrow_min) {      // a few output channels: one thread per pixel (see above)
         if (Cout <= 3) launch_narrow<3>(a, st); else if (Cout <= 4) launch_narrow<4>(a, st); else launch_narrow<8>(a, st);
         BBDM_CHECK_LAUNCH("conv2d(narrow)");
         return BBDM_OK;
     }
-    static const int stem_on = getenv("BBDM_CONV_STEM") ? atoi(getenv("BBDM_CONV_STEM")) : 1;
-    if (stem_on && ks == 3 && (CinPad == 8 || CinPad == 4) && Cout == 128 && !residual && !pre_scale && out_nchw == 0 && M >= 4096) {
+    if (ks == 3 && (CinPad == 8 || CinPad == 4) && Cout == 128 && !residual && !pre_scale && out_nchw == 0 && M >= 4096) {
         const int tiles = N * cdiv(H, 16) * cdiv(W, 16);         // the stem: K = 72 / 36 in one stage (conv3x3_stem_kernel)
         const dim3 grid((unsigned)(tiles < 512 ? tiles : 512));
         const bool stats = stats0 || stats1;

@@ -600,18 +600,18 @@ static size_t wgrad_geom_floats(const WgradGeom& g, int ks) {
 static bool wgrad_tn_path(int Cin, int Cout, int ks) { return ks == 1 && Cin % 4 == 0 && Cout % 4 == 0 && Cin >= 64 && Cout >= 64; }
 
 // ... and, where the plane layout takes the shape, on the bf16x3 pipe kernel behind a transposing split pass per operand (10 B per
-// element moved once, against a GEMM at 200+ instead of 60-100 TFLOP/s): BBDM_WGRAD1X1_BF3=0 keeps gemm_tn_f32 (A/B runs)
+// element moved once, against a GEMM at 200+ instead of 60-100 TFLOP/s): option wgrad1x1_bf3 = 0 keeps gemm_tn_f32 (A/B runs)
 struct TnPlanes {
     long long KPad;
     size_t at_bytes, bt_bytes;
     int splits, walkers;
 };
 static bool wgrad_tn_planes(long long K, int Cin, int Cout, TnPlanes* g) {
-    static const int on = getenv("BBDM_WGRAD1X1_BF3") ? atoi(getenv("BBDM_WGRAD1X1_BF3")) : 1;
+    const int on = bbdm_option(BBDM_OPT_WGRAD1X1_BF3);
     if (!on || Cin % 32 != 0 || Cout % 4 != 0 || K < 4096) return false;
     // the split passes move 10 B per element of X and dY once: they pay where the GEMM has >= ~100 FLOP per such byte (measured on the
     // LBBDM-f4 step, batch 32: 2048 -> 1024 0.42 -> 0.28 ms, 1024 -> 3072 0.48 -> 0.40; 128 -> 256 at 131072 pixels 0.12 -> 0.26);
-    // BBDM_WGRAD1X1_BF3=2 takes every shape the layout accepts (tests)
+    // wgrad1x1_bf3 = 2 takes every shape the layout accepts (tests)
     if (on < 2 && (long long)Cin * Cout < 512ll * (Cin + Cout)) return false;
     const long long KPad = (K + 255) / 256 * 256;
     if (!bbdm_gemm_bf3p_tn_supported(KPad, Cin, Cout)) return false;
@@ -629,6 +629,11 @@ static size_t wgrad_tn_planes_floats(const TnPlanes& g, int Cin, int Cout) {
     return (g.at_bytes + g.bt_bytes) / 4 + (size_t)g.splits * Cin * Cout + 4 + (size_t)g.walkers * Cout + 4;
 }
 
+static size_t wgrad_tn_floats(long long K, int Cin, int Cout) {
+    const size_t sp = (size_t)bbdm_gemm_tn_splits(1, K, Cin, Cout);
+    return sp * Cin * Cout + 4 + (sp > 2 ? sp : 2) * (size_t)Cout + 2;      // partial tiles | per-split column sums / fp64 colsum scratch
+}
+
 extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
     size_t need = wgrad_geom_floats(wgrad_geom(N, H, W, Cin, Cout, -1), ks);      // the thin path may be refused at launch (pitches)
     const int thin = wgrad_thin_mode(Cin, Cout, ks);
@@ -642,8 +647,7 @@ extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin,
         if (t > need) need = t;
     }
     if (wgrad_tn_path(Cin, Cout, ks)) {
-        const size_t sp = (size_t)bbdm_gemm_tn_splits(1, (long long)N * H * W, Cin, Cout);
-        const size_t tn = sp * Cin * Cout + 4 + (sp > 2 ? sp : 2) * (size_t)Cout + 2;      // partial tiles | per-split column sums
+        const size_t tn = wgrad_tn_floats((long long)N * H * W, Cin, Cout);
         if (tn > need) need = tn;
     }
     return need;
@@ -669,7 +673,7 @@ static int launch_wgrad(const WgradArgs& a, dim3 grid, hipStream_t st) {
 }
 
 extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias,
-                                   float* ws, int N, int H, int W, int Cin, int Cout, int ks, void* stream) {
+                                   float* ws, size_t ws_floats, int N, int H, int W, int Cin, int Cout, int ks, void* stream) {
     BBDM_REQUIRE(x && dy && dw_oihw && ws, "conv_wgrad: null pointer");
     BBDM_REQUIRE(ks == 1 || ks == 3, "conv_wgrad: ks=%d", ks);
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv_wgrad: bad shape");
@@ -681,7 +685,9 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     if (wgrad_tn_path(Cin, Cout, ks) && ((uintptr_t)dy & 15) == 0 && ldy % 4 == 0 && ((uintptr_t)ws & 15) == 0) {
         const long long K = (long long)N * H * W;
         TnPlanes tp;
-        if (wgrad_tn_planes(K, Cin, Cout, &tp) && ((uintptr_t)dw_oihw & 3) == 0 && (!dbias || ((uintptr_t)dbias & 15) == 0)) {
+        // (a workspace too small for the plane path -- sized under another wgrad1x1_bf3 setting, say -- takes the TN GEMM below)
+        if (wgrad_tn_planes(K, Cin, Cout, &tp) && ws_floats >= wgrad_tn_planes_floats(tp, Cin, Cout) && ((uintptr_t)dw_oihw & 3) == 0 &&
+            (!dbias || ((uintptr_t)dbias & 15) == 0)) {
             unsigned char* at = reinterpret_cast<unsigned char*>(ws);
             unsigned char* bt = at + tp.at_bytes;
             float* dU = reinterpret_cast<float*>(bt + tp.bt_bytes);
@@ -700,6 +706,8 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
             BBDM_CHECK_LAUNCH("conv_wgrad(tn planes)");
             return BBDM_OK;
         }
+        BBDM_REQUIRE(ws_floats >= wgrad_tn_floats(K, Cin, Cout), "conv_wgrad: workspace of %zu floats, the TN-GEMM path needs %zu",
+                     ws_floats, wgrad_tn_floats(K, Cin, Cout));
         const int splits = bbdm_gemm_tn_splits(1, K, Cin, Cout);
         // the bias gradient rides along: per-split column sums of dY from the GEMM's B staging, added over the splits by the finish
         // kernel (bbdm_colsum_f32 was three more launches and a second pass over dY per layer)
@@ -721,6 +729,8 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     if (thin == 0 && (ldy % 4 != 0 || ((uintptr_t)dy & 15) != 0)) thin = -1;      // float4 loads of the wide tensor
     if (thin >= 0 && ((uintptr_t)ws & 15) != 0) thin = -1;
     const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout, thin);
+    BBDM_REQUIRE(ws_floats >= wgrad_geom_floats(g, ks), "conv_wgrad: workspace of %zu floats, this shape needs %zu", ws_floats,
+                 wgrad_geom_floats(g, ks));
     WgradArgs a;
     a.x = x; a.dy = dy; a.ws = ws; a.ldx = ldx; a.ldy = ldy;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;

@@ -451,11 +451,10 @@ extern "C" int bbdm_linear_f32(const float* x, const float* w, const float* b, f
     {
         const int MB = N > 32 ? 2 : 1;
         const size_t lds_m = (size_t)MB * 32 * (In + 1) * sizeof(float);
-        static const int mfma_on = getenv("BBDM_LINEAR_MFMA") ? atoi(getenv("BBDM_LINEAR_MFMA")) : 1;
         // (from 2048 outputs: below, the launch has too few 32-output tiles for the chip -- 512 -> 512 is 4 workgroups whose waves each
         // walk the whole K -- and the thread-per-(row, output) kernel below wins: 21.8 -> 12.9 us at batch 32, 16.1 -> 6.7 at batch 4)
-        static const int mfma_min_out = getenv("BBDM_LINEAR_MFMA_MIN_OUT") ? atoi(getenv("BBDM_LINEAR_MFMA_MIN_OUT")) : 2048;
-        if (mfma_on && In % 8 == 0 && In >= 64 && Out >= mfma_min_out && (((uintptr_t)w & 15) == 0) && lds_m <= 160 * 1024) {
+        const int mfma_min_out = 2048;
+        if (In % 8 == 0 && In >= 64 && Out >= mfma_min_out && (((uintptr_t)w & 15) == 0) && lds_m <= 160 * 1024) {
             static size_t lds_m_dev[BBDM_MAX_DEVICES][2] = {};
             size_t& have = lds_m_dev[bbdm_device_slot()][MB - 1];
             if (lds_m > 64 * 1024 && lds_m > have) {

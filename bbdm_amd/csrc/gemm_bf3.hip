@@ -291,7 +291,7 @@ static int bf3_run(Bf3Args& a, int batch, hipStream_t st) {
     a.uz = (size_t)a.nchunks * 3 * a.CoutPad * KC;
     const long long blocks = ((long long)a.T / BM) * a.tilesN;
     BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3: too many tiles");
-    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
+    const int by_batch_env = 1;       // batched launches: each XCD owns whole batch entries (multiples of 8)
     a.tiles = (int)blocks;
     a.batch = batch;
     a.by_batch = (by_batch_env && batch >= 8 && (batch % 8 == 0 || by_batch_env == 2)) ? 1 : 0;

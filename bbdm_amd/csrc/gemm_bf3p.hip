@@ -842,8 +842,8 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     a.persist = 0;
     if (a.by_batch) {
         // persistent tiles (see gemm_bf3p_pipe_kernel): as many workgroups as the chip holds at once (LDS- and wave-limited per CU), a
-        // multiple of 8 so that tile L keeps its XCD L % 8.  BBDM_BF3P_PERSIST=0: one tile per workgroup (A/B)
-        static const int persist_env = [] { const char* e = getenv("BBDM_BF3P_PERSIST"); return e ? atoi(e) : 1; }();
+        // multiple of 8 so that tile L keeps its XCD L % 8
+        const int persist_env = 1;
         const int cus = bbdm_device_cus();
         const int by_lds = (int)((160 * 1024) / lds), by_waves = 16 / (WM * WN) > 0 ? 16 / (WM * WN) : 1;
         const int per_cu = by_lds < by_waves ? by_lds : by_waves;
@@ -864,8 +864,7 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
 // launch-weighted fp32-equivalent TFLOP/s (profiles/r03_bf3p_variants.txt; gemm_bf3.hip on the same GEMMs: 181): 5: 204 - 210,
 // 4: 213 - 214, 6: 211 - 216.  (The non-pipelined two-stage kernel, 181 - 204, and a 3-stage LDS ring with counted vmcnt waits,
 // 185 - 191, were measured in round 3 and deleted.)
-static int g_bf3p_variant = [] { const char* e = getenv("BBDM_BF3P_KERNEL"); return e ? atoi(e) : 6; }();
-extern "C" int bbdm_debug_set_bf3p_kernel(int v) { const int old = g_bf3p_variant; g_bf3p_variant = v; return old; }
+#define g_bf3p_variant bbdm_option(BBDM_OPT_BF3P_KERNEL)
 
 // ---- forward GEMMs: tile and split-K choice -------------------------------------------------------------------------------------
 // Large problems (every Winograd layer of the 256^2 step) take 256 x 256 tiles, one 16-wave workgroup per CU.  SMALL problems -- the
@@ -880,7 +879,7 @@ namespace {
 // C4 +2.4 ms: the last, partly filled round runs faster than the model assumes (fewer CUs share the power budget) and the split's
 // extra partial sums cost the output transform more than the GEMM gains.  profiles/r03_bf3p_tile_choice.txt.)
 int fwd_splits(int batch, long long rows, int CinPad, int Cout) {
-    static const int target = [] { const char* e = getenv("BBDM_BF3P_SPLIT_TARGET"); return e ? atoi(e) : 256; }();
+    const int target = 256;
     const int nchunks = CinPad / KC;
     const long long base = (long long)batch * cdiv((int)rows, 128) * cdiv(Cout, 128);       // workgroups with the smallest tile
     if (target <= 0 || base * 2 > target) return 1;
@@ -920,13 +919,13 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     const int nb = batch * splits;
     // (2 = any batch of 8 entries or more -- the 36 transform points of F(4x4,3x3) too: the kernels return early for the padding entries
     // of a batch % 8 != 0 -- measured on the LBBDM-f4 step: tile GEMMs 9.66 -> 9.39 ms; 1 = only multiples of 8, the round-2 rule)
-    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 2; }();
+    const int by_batch_env = 2;
     a.batch = nb;
     a.by_batch = (by_batch_env && nb >= 8 && (nb % 8 == 0 || by_batch_env == 2 || splits > 1)) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = CoutPad % 256 == 0;
     // workgroups a tile shape gives; below ~one per CU the next smaller shape takes over (pipe kernel only: it masks ragged row tiles)
-    static const int small_wg = [] { const char* e = getenv("BBDM_BF3P_SMALL_WG"); return e ? atoi(e) : 200; }();
+    const int small_wg = 200;
     auto wgs = [&](int bm, int bn) { return (long long)nb * cdiv((int)rows, bm) * cdiv(CoutPad, bn); };
     int rc;
 #define BBDM_BF3P_GO(WM, WN) (residual ? bf3p_launch<WM, WN, true>(a, nb, st) : bf3p_launch<WM, WN, false>(a, nb, st))
@@ -938,8 +937,8 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
         // the wait for its own, and two stages expose an HBM round trip per chunk (measured per layer, profiles/r04_small_gemm_ring.md:
         // 16 x [256 x 1024 x 1024] 61 -> 49 us, 16 x [512 x 512 x 512] 35 -> 30 us); with two or three workgroups per CU the third stage
         // loses 5 - 8 % (one workgroup's copies already overlap the other's MFMAs, and the ring's prologue waits for one chunk more),
-        // and five stages never beat three.  BBDM_BF3P_SMALL_STAGES=2: round 3's kernel everywhere (A/B).
-        static const int max_stages = [] { const char* e = getenv("BBDM_BF3P_SMALL_STAGES"); return e ? atoi(e) : 3; }();
+        // and five stages never beat three.
+        const int max_stages = 3;
         const long long w = (long long)cdiv((int)rows, 128) * cdiv(CoutPad, 128) * (a.by_batch ? (nb + 7) / 8 * 8 : nb);
         if (max_stages >= 3 && a.nchunks / splits >= 8 && w <= bbdm_device_cus()) rc = BBDM_BF3P_GO_NS(2, 2, 3);
         else rc = BBDM_BF3P_GO(2, 2);
@@ -1054,7 +1053,7 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
     a.ldo = N; a.ldr = 0; a.bias = nullptr; a.res = nullptr;
     a.ksplits = sp.splits; a.kps = sp.kps; a.P = batch;
     const int nb = batch * sp.splits;
-    static const int by_batch_env = [] { const char* e = getenv("BBDM_BF3_BY_BATCH"); return e ? atoi(e) : 1; }();
+    const int by_batch_env = 1;
     a.batch = nb;
     a.by_batch = (by_batch_env && nb >= 8) ? 1 : 0;              // (the pipe kernel returns early for the padding entries of a batch % 8 != 0)
     hipStream_t st = (hipStream_t)stream;

@@ -1,5 +1,6 @@
 // runtime.hip -- library-level entry points (version, per-thread error text, device properties).
 #include <stdarg.h>
+#include <string.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -11,7 +12,39 @@ void bbdm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int bbdm_version(void) { return 20; }
+extern "C" int bbdm_version(void) { return 21; }
+
+// ---- options: the few integer switches tests and tools/ flip (kernel A/B inside ONE process).  Not read from the environment, not
+// latched: a launcher reads its option at every call.  Everything else the library decides from the shapes it is given.
+namespace {
+struct Option { const char* name; int value; };
+Option g_options[BBDM_OPT_COUNT] = {
+    {"wgrad1x1_bf3", 1},      // 1x1 weight gradients: 1 = the bf16x3 planes path from ~100 FLOP per split byte, 0 = always gemm_tn_f32,
+                              // 2 = every shape the plane layout takes (tests)
+    {"wino_idx64", 0},        // 1 = force the 64-bit row-address variant of the Winograd input transform (tests)
+    {"bf3p_kernel", 6},       // tile shape of the pre-split GEMM: 6 = the library's choice, 4 / 5 / 7 = force 256x256 / 256x128 / 128x128
+    {"attn_bf3", 1},          // attention forward: 1 = Q K^T and P V on the bf16x3 path, 2 = only Q K^T, 0 = both on the f32 MFMA (A/B)
+};
+int option_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < BBDM_OPT_COUNT; ++i)
+        if (strcmp(name, g_options[i].name) == 0) return i;
+    return -1;
+}
+}  // namespace
+int bbdm_option(int id) { return g_options[id].value; }
+extern "C" int bbdm_set_option(const char* name, int value) {
+    const int i = option_index(name);
+    BBDM_REQUIRE(i >= 0, "bbdm_set_option: unknown option '%s'", name ? name : "(null)");
+    g_options[i].value = value;
+    return BBDM_OK;
+}
+extern "C" int bbdm_get_option(const char* name, int* value) {
+    const int i = option_index(name);
+    BBDM_REQUIRE(i >= 0 && value, "bbdm_get_option: unknown option '%s' / null result", name ? name : "(null)");
+    *value = g_options[i].value;
+    return BBDM_OK;
+}
 extern "C" const char* bbdm_last_error(void) { return g_err; }
 
 namespace {

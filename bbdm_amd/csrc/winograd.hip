@@ -292,93 +292,9 @@ __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __res
 // ---- (1') input transform that writes the three bf16 planes gemm_bf3p.hip consumes -----------------------------------------
 // Same arithmetic as the kernels above (B^T d B in fp32, GroupNorm -> FiLM -> SiLU / nearest x2 folded in), followed by the
 // exact three-way bf16 split of every transformed value (bf3_split.h): the GEMM's main loop then copies and multiplies, nothing
-// else.  Output = the A-plane layout of gemm_bf3p.hip, [xi][tile / 32][chunk][3][1 KB fragment unit].
-// One thread = one (tile, channel PAIR) for every m; a workgroup = 32 consecutive tiles (one row group) x 8 pairs (one 16-channel
-// chunk), thread = tile_local * 8 + pair: a wave reads 8 tiles x 64 B per load and writes, per plane and transform point, rows
-// 8 w .. 8 w + 7 of the unit's two k-halves = two full 128-B lines per store instruction.  Workgroups are dealt so that the
-// chunks of one row group run on ONE XCD (block id % 8): the two 64-B halves of an input line meet in that L2.
-// Rows between the real tile count and the padded one (whole 256-row GEMM tiles) are written as zeros.
-template <int MO, bool PRE, bool UP>
-__global__ void __launch_bounds__(256) winograd_input_split_kernel(const float* __restrict__ x, int ldx,
-                                                                   unsigned char* __restrict__ Vp, const float* __restrict__ sc,
-                                                                   const float* __restrict__ bi, int pre_ld, int pre_silu, int N,
-                                                                   int H, int W, int nchunks, long long T, int RG, size_t plane) {
-    constexpr int AL = MO + 2;
-    const int L = (int)blockIdx.x, j = L >> 3;
-    // (giving each XCD a CONTIGUOUS run of row groups, so that the window rows shared with the tiles below are found in its L2,
-    // measured no gain: 21.8 vs 21.1 ms per C2 step -- gpurun_out/r03c; the halo re-reads are Infinity-Cache hits already)
-    const int chunk = j % nchunks, g = (j / nchunks) * 8 + (L & 7);
-    if (g >= RG) return;
-    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
-    const int rl = threadIdx.x >> 3, cp = threadIdx.x & 7;
-    const long long tile = (long long)g * 32 + rl;
-    const int c = chunk * KC + cp * 2;
-    // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
-    unsigned char* o = Vp + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
-    if (tile >= T) {
-        for (int xi = 0; xi < AL * AL; ++xi) {
-            *reinterpret_cast<unsigned*>(o) = 0u;
-            *reinterpret_cast<unsigned*>(o + 1024) = 0u;
-            *reinterpret_cast<unsigned*>(o + 2048) = 0u;
-            o += plane;
-        }
-        return;
-    }
-    const int tw = (int)(tile % TW);
-    const long long r = tile / TW;
-    const int th = (int)(r % TH), n = (int)(r / TH);
-    float2 s2 = make_float2(1.f, 1.f), b2 = make_float2(0.f, 0.f);
-    if (PRE) {
-        s2 = *reinterpret_cast<const float2*>(sc + (size_t)n * pre_ld + c);
-        b2 = *reinterpret_cast<const float2*>(bi + (size_t)n * pre_ld + c);
-    }
-    const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
-    float2 t[AL][AL];
-#pragma unroll
-    for (int jj = 0; jj < AL; ++jj) {       // one column of the window at a time, its loads issued together (see winograd_input6_kernel)
-        const int w = MO * tw - 1 + jj;
-        const int wc = min(max(w, 0), W - 1);
-        const int wsrc = UP ? wc >> 1 : wc;
-        const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
-        float2 d[AL], col[AL];
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            const int hc = min(max(MO * th - 1 + i, 0), H - 1);
-            const int hs = UP ? hc >> 1 : hc;
-            d[i] = *reinterpret_cast<const float2*>(x + ((size_t)(n * Hs + hs) * Ws + wsrc) * ldx + c);
-        }
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            const int h = MO * th - 1 + i;
-            const float mask = (h >= 0 && h < H) ? wmask : 0.f;
-            float2 v = d[i];
-            if (PRE) {
-                v.x = v.x * s2.x + b2.x; v.y = v.y * s2.y + b2.y;
-                if (pre_silu) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); }
-            }
-            d[i] = make_float2(mask * v.x, mask * v.y);
-        }
-        bt_transform<MO>(d, col);
-#pragma unroll
-        for (int i = 0; i < AL; ++i) t[i][jj] = col[i];
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-        float2 row[AL];
-        bt_transform<MO>(t[i], row);
-#pragma unroll
-        for (int jj = 0; jj < AL; ++jj) {
-            unsigned p1, p2, p3;
-            split2(row[jj].x, row[jj].y, p1, p2, p3);
-            *reinterpret_cast<unsigned*>(o) = p1;
-            *reinterpret_cast<unsigned*>(o + 1024) = p2;
-            *reinterpret_cast<unsigned*>(o + 2048) = p3;
-            o += plane;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
+// else.  Output = the A-plane layout of gemm_bf3p.hip, [xi][tile / 32][chunk][3][1 KB fragment unit].  (The first version -- one
+// thread per (tile, channel pair) holding the whole window: 174 VGPRs at m = 6 -- was removed in round 5; the two-phase kernel
+// below replaced it in round 3.)
 
 // The lanes of a wave hold, for AL transform points xi = (i, 0 .. AL-1) and the three bf16 planes, one dword each = the channel pair
 // 2 cp, 2 cp + 1 of tile tl (lane = tl * 8 + cp: 8 consecutive tiles x 16 channels).  Write them TRANSPOSED: per (xi, plane) the
@@ -1172,21 +1088,19 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
     BBDM_REQUIRE(!pre_scale || (pre_ld % 2 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 7) == 0),
                  "winograd_input_bf3p: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
-    const int nchunks = CinPad / KC, RG = (int)(Tp / 32), TG = (int)(Tp / 8);
+    const int nchunks = CinPad / KC, TG = (int)(Tp / 8);
     const size_t plane = Tp * (size_t)CinPad * 6;                  // bytes of one transform point
     const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * 6;       // ... of the transposed copy (whole 32-channel row groups)
     BBDM_REQUIRE(!Vt || (!upsample && ((uintptr_t)Vt & 15) == 0), "winograd_input_bf3p: the transposed copy needs upsample = 0, 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
-    // BBDM_WINO_INPUT_LDS=0: the one-thread-per-window kernel (A/B; see winograd_input_split2_kernel)
-    static const int two_phase = [] { const char* e = getenv("BBDM_WINO_INPUT_LDS"); return e ? atoi(e) : 1; }();
-    if (two_phase || Vt) {
+    {
         const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
         BBDM_REQUIRE(blocks < (1ll << 31) && Tp < (1ull << 31), "winograd_input_bf3p: too many workgroups / tiles");
         const dim3 g((unsigned)blocks);
         const int Hs = upsample ? H / 2 : H, Ws = upsample ? W / 2 : W;
         // 32-bit element indices + 24-bit row multiplies where the tensor allows it (every shape of the reference's templates)
-        // (BBDM_WINO_IDX64=1 forces the 64-bit variant: the tests run both on ordinary shapes)
-        static const int idx64_env = [] { const char* e = getenv("BBDM_WINO_IDX64"); return e ? atoi(e) : 0; }();
+        // (option wino_idx64 = 1 forces the 64-bit variant: the tests run both on ordinary shapes)
+        const int idx64_env = bbdm_option(BBDM_OPT_WINO_IDX64);
         const bool idx64 = idx64_env || (unsigned long long)N * Hs * Ws * (unsigned long long)ldx >= (1ull << 32) ||
                            (unsigned long long)Ws * (unsigned long long)ldx >= (1ull << 24) || Hs >= (1 << 24);
         const FastDiv dTW = fastdiv_make((unsigned)((W + m - 1) / m)), dTH = fastdiv_make((unsigned)((H + m - 1) / m)),
@@ -1228,23 +1142,6 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         BBDM_CHECK_LAUNCH("winograd_input_bf3p");
         return BBDM_OK;
     }
-    BBDM_REQUIRE(!fold, "winograd_input_bf3p_gn: needs the two-phase transform (BBDM_WINO_INPUT_LDS=1)");
-    const long long blocks = 8ll * ((RG + 7) / 8) * nchunks;
-    BBDM_REQUIRE(blocks < (1ll << 31), "winograd_input_bf3p: too many workgroups");
-    const dim3 g((unsigned)blocks), b(256);
-#define BBDM_WINO_INS(MO, PRE, UP)                                                                                          \
-    hipLaunchKernelGGL((winograd_input_split_kernel<MO, PRE, UP>), g, b, 0, st, x, ldx, (unsigned char*)Vp, pre_scale, pre_bias, \
-                       pre_ld, pre_silu, N, H, W, nchunks, (long long)T, RG, plane)
-#define BBDM_WINO_INS_M(MO)                                                                       \
-    do {                                                                                          \
-        if (pre_scale) { if (upsample) BBDM_WINO_INS(MO, true, true); else BBDM_WINO_INS(MO, true, false); }   \
-        else           { if (upsample) BBDM_WINO_INS(MO, false, true); else BBDM_WINO_INS(MO, false, false); } \
-    } while (0)
-    if (m == 2) BBDM_WINO_INS_M(2); else if (m == 4) BBDM_WINO_INS_M(4); else BBDM_WINO_INS_M(6);
-#undef BBDM_WINO_INS_M
-#undef BBDM_WINO_INS
-    BBDM_CHECK_LAUNCH("winograd_input_bf3p");
-    return BBDM_OK;
 }
 
 extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale,
@@ -1347,18 +1244,15 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     const int rpi = (flags & BBDM_CONV_RES_PER_IMAGE) ? 1 : (flags & BBDM_CONV_RES_UPSAMPLE) ? 2 : 0;     // residual addressing mode
     const dim3 g((unsigned)blocks), b(256);
     hipStream_t s_ = (hipStream_t)stream;
-    // BBDM_WINO_OUTPUT_LDS=0: the one-thread-per-window kernel for every m = 6 shape (A/B; see winograd_output6_lds_kernel)
-    static const int two_phase = [] { const char* e = getenv("BBDM_WINO_OUTPUT_LDS"); return e ? atoi(e) : 1; }();
-    if (two_phase && Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
+    // the two-phase LDS kernel wherever the channel blocks allow it; other shapes keep the one-thread-per-window kernels
+    if (Cm % 128 == 0 && (!ph || Cout % 128 == 0) && (long long)T * (Cm / 128) < (1ll << 31)) {
         // Tiles per workgroup.  Two (double-buffered) by default; MORE where the layer is narrow: a 128-channel block of a layer with
         // 4 channels per group touches 32 groups = 64 accumulator cells, i.e. >= 128 integer atomics per workgroup whatever its tile
         // count -- at two tiles that was one atomic per 72 stored values and cost the 128-channel layers of the 256^2 level 20 %
         // (measured round 4).  8 cells per tile is the budget; a run of tiles must not span more than two images (the kernel keeps two
-        // register accumulators) and the launch keeps >= 2048 workgroups.  BBDM_WINO_OUTPUT_TPW forces a count (A/B).
-        static const int tpw_env = [] { const char* e = getenv("BBDM_WINO_OUTPUT_TPW"); return e ? atoi(e) : 0; }();
+        // register accumulators) and the launch keeps >= 2048 workgroups.
         int tpw = 2;
-        if (tpw_env > 0) tpw = tpw_env;
-        else if (stats0 || stats1) {
+        if (stats0 || stats1) {
             int cells = 0;
             if (stats0) cells += 2 * (128 / st.cpg[0] + 1);
             if (stats1) cells += 2 * (128 / st.cpg[1] + 1);

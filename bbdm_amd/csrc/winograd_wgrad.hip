@@ -381,10 +381,7 @@ TnGeom tn_geom(int batch, long long K, int M, int N) {
     g.tilesM = cdiv(M, g.wm * 64);
     g.tilesN = cdiv(N, TBN);
     const long long base = (long long)batch * g.tilesM * g.tilesN;
-    static const int target_env = getenv("BBDM_TN_TARGET") ? atoi(getenv("BBDM_TN_TARGET")) : 0;
-    static const int minK_env = getenv("BBDM_TN_MINK") ? atoi(getenv("BBDM_TN_MINK")) : 0;
-    const int target = target_env > 0 ? target_env : 768;
-    const int minK = minK_env > 0 ? minK_env : 512;
+    const int target = 768, minK = 512;       // (swept in round 3, tools/wgrad1x1_bench.py: the best of 384 ... 1536 / 256 ... 2048)
     long long splits = (target + base - 1) / base;              // >= 3 workgroups per CU when K allows
     const long long max_splits = K / minK > 1 ? K / minK : 1;   // >= 32 stages per workgroup
     if (splits > max_splits) splits = max_splits;

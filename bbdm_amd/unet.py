@@ -1664,8 +1664,8 @@ class _Plan:
                 self._bop("bbdm_conv3x3_winograd_wgrad_f32", wgm, x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N,
                           x_in.H, x_in.W, x_in.C, cout)
             else:
-                self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N, x_in.H, x_in.W,
-                          x_in.C, cout, ks)
+                self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, self._ws_f_floats, N, x_in.H,
+                          x_in.W, x_in.C, cout, ks)
             if not need_dx:
                 return None
             dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
@@ -1708,6 +1708,7 @@ class _Plan:
         self.dconvs: List[_PackedDgrad] = []
         self._padded_wgrads: List[tuple] = []
         self._ws_f = _LateTensor()
+        self._ws_f_floats = _LateInt()
         self._ws_d = _LateTensor()
         self._ws_d2 = _LateTensor()
         self.dout_nchw = torch.empty_like(self.out_nchw)
@@ -1863,6 +1864,7 @@ class _Plan:
             rec_ends.append(len(self.bops))
         self._segment_backward(rec_ends)
         self._ws_f.t = torch.empty(ws_floats[0], **f32)
+        self._ws_f_floats.v = ws_floats[0]
         self._ws_d.t = torch.empty(colsum_c[0], dtype=torch.float64, device=dev)
         self._ws_d2.t = torch.empty(ws_doubles[0], dtype=torch.float64, device=dev)
         # embedding-path backward scratch

@@ -393,6 +393,16 @@ def main():
                 "kernel_ms_per_step": r["kernel_ms_per_step"], "parity": r["parity"], "pipeline": r.get("pipeline"),
                 "training": r.get("training"), "wall_s": time.perf_counter() - t0}
     if rank == 0 and line is not None:
+        # LAST key of the line (the driver's stored record keeps the tail of stdout): every configuration's step time, whole-step
+        # roofline fraction and worst parity error in <= 400 characters -- [ms_per_step, frac_step, worst rel_err]
+        def _brief(r, frac):
+            par = r.get("parity") or {}
+            errs = [v for k, v in par.items() if k.startswith("rel_err")]
+            return [round(r["ms_per_step"], 3), round(frac, 3), float(f"{max(errs):.2g}") if errs else None]
+        line["summary"] = {args.workload: _brief(line, line["roofline"]["frac_step"])}
+        for w, r in (line.get("workloads") or {}).items():
+            line["summary"][w] = _brief(r, r["frac_step"])
+        line["summary"]["units"] = "[ms_per_step, frac_step, worst parity rel_err]"
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

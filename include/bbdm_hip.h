@@ -159,13 +159,13 @@ int bbdm_conv_pack_weight_dgrad_f32(const float* w_oihw, float* packed, int Cout
                                     void* stream);
 /* Weight gradient dW[co][ci][r][s] = sum_{n,h,w} dY[n,h,w,co] X[n,h+r-p,w+s-p,ci], written in OIHW (overwrite), and
  * (dbias != NULL) the bias gradient dbias[co] = sum_{n,h,w} dY[n,h,w,co] from the same pass over dY.
- * x: NHWC pitch ldx (Cin % 4 == 0); dy: NHWC pitch ldy; ws: bbdm_conv_wgrad_workspace_floats() floats of scratch
- * (split-K partials, reduced in a fixed order: deterministic).  CONTRACT: the launcher does not receive the size of ws -- it must
- * be the value the query returns IN THIS PROCESS for these very dimensions (the query covers every path the launcher can take,
- * incl. the bf16-plane path of wide 1x1 layers; both latch BBDM_WGRAD1X1_BF3 once, at first use). */
+ * x: NHWC pitch ldx (Cin % 4 == 0); dy: NHWC pitch ldy; ws: ws_floats floats of scratch (split-K partials, reduced in a fixed
+ * order: deterministic).  bbdm_conv_wgrad_workspace_floats() covers every path the launcher can take for these dimensions; the
+ * launcher CHECKS ws_floats against the path it takes (ABI 21): the bf16-plane path of wide 1x1 layers falls back to the TN GEMM when
+ * ws is too small for it, every other shortfall returns BBDM_E_BADARG without launching anything. */
 size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks);
 int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int ldy, float* dw_oihw, float* dbias, float* ws,
-                        int N, int H, int W, int Cin, int Cout, int ks, void* stream);
+                        size_t ws_floats, int N, int H, int W, int Cin, int Cout, int ks, void* stream);
 /* The same weight gradient for ks = 3, stride 1 in the Winograd domain (csrc/winograd_wgrad.hip): dU_xi = V_xi^T dM_xi over
  * the tiles with V = B^T d B (bbdm_winograd_input_f32) and dM = A dY A^T, then dW = G^T dU G -- (m+2)^2 / (9 m^2) of the
  * direct FLOPs.  m = 2, 4 (H, W multiples of m) or 6 (any H, W); Cin % 4 == 0, Cout % 4 == 0.  Deterministic (K splits are
@@ -508,12 +508,18 @@ int bbdm_adam_ema_step_f32(const BbdmOptChunk* table, int nchunks, int do_adam, 
 int bbdm_images_to_u8_f32(const float* x_nchw, unsigned char* out_nhwc, int N, int C, int H, int W, int to_normal,
                           void* stream);
 
-/* ---- test hooks (no reference counterpart; not used by the product path) --------------------------------------------- */
-/* Force the tile shape of the pre-split bf16x3 GEMM (csrc/gemm_bf3p.hip: 6 = the library's own choice, 4 = 256 x 256,
- * 5 = 256 x 128, 7 = 128 x 128 workgroup tiles) so that the parity tests reach every instantiation on small problems;
- * returns the previous setting.  Process-wide and unsynchronised: tests / A-B runs only (env BBDM_BF3P_KERNEL sets the
- * initial value). */
-int bbdm_debug_set_bf3p_kernel(int id);
+/* ---- options (no reference counterpart): the library's few integer switches, for tests and tools/ A-B runs ----------------- */
+/* Nothing in the library reads the environment, and no launcher latches a setting: an option is read at every call, so one
+ * process can run both sides of an A/B.  Process-wide and unsynchronised.  Names (default):
+ *   "wgrad1x1_bf3" (1)  1x1 weight gradients: 1 = the bf16x3 planes path from ~100 FLOP per split byte, 0 = always the f32-MFMA
+ *                       TN GEMM, 2 = every shape the plane layout accepts (tests);
+ *   "wino_idx64"   (0)  1 = force the 64-bit row-address variant of the Winograd input transform (tests);
+ *   "bf3p_kernel"  (6)  tile shape of the pre-split bf16x3 GEMM: 6 = the library's choice, 4 = 256 x 256, 5 = 256 x 128,
+ *                       7 = 128 x 128 workgroup tiles (the parity tests reach every instantiation on small problems);
+ *   "attn_bf3"     (1)  attention forward: 1 = Q K^T and P V on the bf16x3 path, 2 = only Q K^T, 0 = both on the f32 MFMA.
+ * Unknown names return BBDM_E_BADARG. */
+int bbdm_set_option(const char* name, int value);
+int bbdm_get_option(const char* name, int* value);
 
 #ifdef __cplusplus
 }

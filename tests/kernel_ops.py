@@ -284,17 +284,18 @@ def pack_conv_weight_dgrad(w: torch.Tensor, cout_in: Optional[int] = None) -> to
     return packed
 
 
-def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, cin: int, cout: int, ks: int, with_bias: bool = False):
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, cin: int, cout: int, ks: int, with_bias: bool = False, ws_floats=None):
     """x: [N,H,W,CinPad], dy: [N,H,W,>=cout] -> dW [cout, cin, ks, ks] (cin = true, unpadded input channels);
     with_bias also returns db [cout] computed in the same pass."""
     _chk(x, dy)
     N, H, W, cin_pad = x.shape
     lib = _lib.load()
-    ws = torch.empty(lib.bbdm_conv_wgrad_workspace_floats(N, H, W, cin_pad, cout, ks), dtype=torch.float32, device=x.device)
+    need = lib.bbdm_conv_wgrad_workspace_floats(N, H, W, cin_pad, cout, ks)
+    ws = torch.empty(need if ws_floats is None else max(1, ws_floats), dtype=torch.float32, device=x.device)   # (ws_floats: tests of the size check)
     dw = torch.empty(cout, cin_pad, ks, ks, dtype=torch.float32, device=x.device)
     db = torch.empty(cout, dtype=torch.float32, device=x.device) if with_bias else None
     _lib.call("bbdm_conv_wgrad_f32", x.data_ptr(), cin_pad, dy.data_ptr(), dy.shape[-1], dw.data_ptr(),
-              None if db is None else db.data_ptr(), ws.data_ptr(), N, H, W, cin_pad, cout, ks, _st(x))
+              None if db is None else db.data_ptr(), ws.data_ptr(), ws.numel(), N, H, W, cin_pad, cout, ks, _st(x))
     dw = dw if cin == cin_pad else dw[:, :cin].contiguous()
     return (dw, db) if with_bias else dw
 

@@ -67,17 +67,40 @@ def test_conv_backward(dev, N, H, W, Cin, Cout, ks):
     assert rel_err(db.cpu(), b.grad) < TOL and rel_err(db2.cpu(), b.grad) < TOL
 
 
-def test_conv1x1_wgrad_planes_path_in_subprocess():
-    """BBDM_WGRAD1X1_BF3=2 (read once per process, hence the child): every 1x1 shape the plane layout accepts takes the transposing
-    split pass + bbdm_gemm_bf3p_tn_f32 instead of gemm_tn_f32 -- the small ragged cases of CONV_BWD included."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, BBDM_WGRAD1X1_BF3="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv_backward and 1]"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks", [c for c in CONV_BWD if c[5] == 1])
+def test_conv1x1_wgrad_planes_path(dev, N, H, W, Cin, Cout, ks):
+    """Option "wgrad1x1_bf3" = 2 (read at every call): every 1x1 shape the plane layout accepts takes the transposing split pass +
+    bbdm_gemm_bf3p_tn_f32 instead of gemm_tn_f32 -- the small ragged cases of CONV_BWD included; 0: always gemm_tn_f32."""
+    from bbdm_amd import _lib
+    for mode in (2, 0):
+        with _lib.option("wgrad1x1_bf3", mode):
+            test_conv_backward(dev, N, H, W, Cin, Cout, ks)
+
+
+def test_conv_wgrad_checks_its_workspace(dev):
+    """bbdm_conv_wgrad_f32 receives the size of its workspace (ABI 21).  A workspace sized for the TN GEMM but too small for the
+    bf16-plane path (a caller that sized it under another "wgrad1x1_bf3" setting) falls back to the TN GEMM with the same result;
+    any other shortfall is refused before anything is launched."""
+    import kernel_ops as ops
+    from bbdm_amd import _lib
+    lib = _lib.load()
+    N, H, W, Cin, Cout = 5, 32, 32, 1024, 1536                 # takes the plane path by default
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(dev)
+    with _lib.option("wgrad1x1_bf3", 0):
+        small = lib.bbdm_conv_wgrad_workspace_floats(N, H, W, Cin, Cout, 1)
+        want, wantb = ops.conv_wgrad(x, dy, Cin, Cout, 1, with_bias=True)
+    full = lib.bbdm_conv_wgrad_workspace_floats(N, H, W, Cin, Cout, 1)
+    assert small < full, (small, full)
+    got, gotb = ops.conv_wgrad(x, dy, Cin, Cout, 1, with_bias=True, ws_floats=small)       # planes refused -> TN GEMM
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(gotb, wantb)
+    with pytest.raises(_lib.BBDMHipError, match="workspace"):
+        ops.conv_wgrad(x, dy, Cin, Cout, 1, ws_floats=64)
+    with pytest.raises(_lib.BBDMHipError, match="workspace"):
+        ops.conv_wgrad(x[:1, :8, :8, :64].contiguous(), dy[:1, :8, :8, :32].contiguous(), 64, 32, 3, ws_floats=16)
 
 
 # (m, N, H, W, Cin, Cout): the Winograd-domain weight gradient (csrc/winograd_wgrad.hip) incl. ragged m = 6 tiles, K splits,

@@ -221,29 +221,40 @@ def test_winograd_wgrad_bf3p(m, N, H, W, Cin, Cout):
     BK.test_winograd_wgrad_bf3p(CPU, m, N, H, W, Cin, Cout)
 
 
-def test_conv1x1_wgrad_planes_path_in_subprocess():
-    """BBDM_WGRAD1X1_BF3=2 (read once per process): the 1x1 weight gradients on the transposing split pass + bbdm_gemm_bf3p_tn_f32,
-    on the emulator."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, BBDM_WGRAD1X1_BF3="2", BBDM_TESTS_SERIAL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_conv_backward and 1]",
-                        "-p", "no:xdist", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1800)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks", [(4, 32, 32, 64, 72, 1), (1, 72, 60, 96, 256, 1)])
+def test_conv1x1_wgrad_planes_path(N, H, W, Cin, Cout, ks):
+    """Option "wgrad1x1_bf3" = 2 / 0: the 1x1 weight gradients on the transposing split pass + bbdm_gemm_bf3p_tn_f32, and always on
+    gemm_tn_f32, on the emulator."""
+    BK.test_conv1x1_wgrad_planes_path(CPU, N, H, W, Cin, Cout, ks)
 
 
-def test_winograd_input_64bit_index_variant_in_subprocess():
-    """BBDM_WINO_IDX64=1 (read once per process): the 64-bit row-address instantiation of the input transform on the emulator."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, BBDM_WINO_IDX64="1", BBDM_TESTS_SERIAL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_winograd_bf3p_stages",
-                        "-p", "no:xdist", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1800)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+def test_conv_wgrad_checks_its_workspace():
+    """A short workspace: fall back from the plane path / refuse, on the emulator (ABI 21)."""
+    import kernel_ops as ops
+    from bbdm_amd import _lib
+    N, H, W, Cin, Cout = 4, 32, 32, 64, 72
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    lib = _lib.load()
+    with _lib.option("wgrad1x1_bf3", 0):
+        small = lib.bbdm_conv_wgrad_workspace_floats(N, H, W, Cin, Cout, 1)
+        want, wantb = ops.conv_wgrad(x, dy, Cin, Cout, 1, with_bias=True)
+    with _lib.option("wgrad1x1_bf3", 2):
+        full = lib.bbdm_conv_wgrad_workspace_floats(N, H, W, Cin, Cout, 1)
+        assert small < full
+        got, gotb = ops.conv_wgrad(x, dy, Cin, Cout, 1, with_bias=True, ws_floats=small)
+        assert torch.equal(got, want) and torch.equal(gotb, wantb)
+        with pytest.raises(_lib.BBDMHipError, match="workspace"):
+            ops.conv_wgrad(x, dy, Cin, Cout, 1, ws_floats=64)
+    with pytest.raises(_lib.BBDMHipError, match="workspace"):
+        ops.conv_wgrad(x[:1, :8, :8].contiguous(), dy[:1, :8, :8, :32].contiguous(), 64, 32, 3, ws_floats=16)
+
+
+@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 1, 1, 2, 20, 12, 32, 136), (4, 1, 0, 1, 8, 8, 16, 8)])
+def test_winograd_input_64bit_index_variant(m, up, silu, N, H, W, Cin, Cout):
+    """Option "wino_idx64": the 64-bit row-address instantiation of the input transform on the emulator."""
+    K.test_winograd_input_64bit_index_variant(CPU, m, up, silu, N, H, W, Cin, Cout)
 
 
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (320, 48, 256, True), (96, 16, 8, False)])

@@ -247,18 +247,14 @@ def test_gemm_bf3_accuracy(dev, batch, T, Cin, Cout):
 @pytest.mark.parametrize("batch,T,Cin,Cout", [(2, 512, 16, 256), (1, 256, 32, 512), (8, 256, 80, 260), (3, 768, 1024, 256),
                                               (2, 768, 48, 128), (8, 1280, 128, 72)])
 def test_gemm_bf3p_kernel_variants(dev, kernel, batch, T, Cin, Cout):
-    """Every tile shape of csrc/gemm_bf3p.hip's kernel (bbdm_debug_set_bf3p_kernel, the header's test hook: 4 / 5 / 7 = 256 x 256,
+    """Every tile shape of csrc/gemm_bf3p.hip's kernel (option "bf3p_kernel" of the header's options section: 4 / 5 / 7 = 256 x 256,
     256 x 128, 128 x 128 workgroup tiles; the default picks among them by the number of workgroups they give, which on test-size
     problems is always the smallest) is bit-equal to csrc/gemm_bf3.hip; Cin = 16 / 32 are the one- and two-chunk edge cases of the prologues, Cout = 260 falls back
     from the 256-column tiles, T = 768 / 1280 leave the 512-row tiles a ragged last row tile."""
     from bbdm_amd import _lib
-    lib = _lib.load()
-    old = lib.bbdm_debug_set_bf3p_kernel(kernel)
-    try:
+    with _lib.option("bf3p_kernel", kernel):
         test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, 0)
         test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, 2)
-    finally:
-        lib.bbdm_debug_set_bf3p_kernel(old)
 
 
 @pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(2, 256, 48, 72, 0), (1, 512, 256, 128, 1), (3, 256, 1024, 260, 2),
@@ -449,20 +445,6 @@ def test_winograd_output_adds_upsampled_residual(dev, m, N, H, W, Cin, Cout):
     assert rel_err(_nchw(out.cpu()), ref.float()) < WINO_TOL[m]
 
 
-def test_winograd_input_64bit_index_variant_in_subprocess():
-    """The input transform addresses its rows with 32-bit element indices and 24-bit multiplies; tensors of 2^32 elements (16 GB)
-    or more take the IDX64 instantiation (csrc/winograd.hip: winograd_input_split2_kernel).  BBDM_WINO_IDX64=1 forces it on the
-    ordinary test shapes -- read once per process, hence the child."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, BBDM_WINO_IDX64="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "test_winograd_bf3p_stages"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
-
-
 @pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 3, 16, 24, 64, 96), (6, 1, 1, 2, 20, 12, 32, 136),
                                                       (4, 0, 1, 3, 16, 24, 64, 96), (4, 1, 0, 1, 8, 8, 16, 8),
                                                       (2, 1, 1, 3, 16, 24, 64, 96), (6, 0, 0, 5, 7, 9, 48, 260)])
@@ -516,6 +498,17 @@ def test_winograd_bf3p_stages(dev, m, up, silu, N, H, W, Cin, Cout):
     T_raw = N * -(-H // m) * -(-W // m)
     a_, b_ = M.view(P, tiles, Cout)[:, :T_raw].cpu(), M0.view(P, tiles, Cout)[:, :T_raw].cpu()
     assert rel_err(a_, b_) < 2e-6, rel_err(a_, b_)
+
+
+@pytest.mark.parametrize("m,up,silu,N,H,W,Cin,Cout", [(6, 0, 1, 3, 16, 24, 64, 96), (6, 1, 1, 2, 20, 12, 32, 136), (4, 1, 0, 1, 8, 8, 16, 8),
+                                                      (2, 1, 1, 3, 16, 24, 64, 96)])
+def test_winograd_input_64bit_index_variant(dev, m, up, silu, N, H, W, Cin, Cout):
+    """The input transform addresses its rows with 32-bit element indices and 24-bit multiplies; tensors of 2^32 elements (16 GB)
+    or more take the IDX64 instantiation (csrc/winograd.hip: winograd_input_split2_kernel).  Option "wino_idx64" (read at every
+    call) forces it on the ordinary test shapes."""
+    from bbdm_amd import _lib
+    with _lib.option("wino_idx64", 1):
+        test_winograd_bf3p_stages(dev, m, up, silu, N, H, W, Cin, Cout)
 
 
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (1024, 1536, 512, True)])

@@ -3,7 +3,7 @@
 
   old: bbdm_winograd_input_f32 (fp32 V)            -> bbdm_winograd_gemm_bf3_f32  (csrc/gemm_bf3.hip: V split while staged)
   new: bbdm_winograd_input_bf3p_f32 (3 bf16 planes) -> bbdm_winograd_gemm_bf3p_f32 (csrc/gemm_bf3p.hip: LDS-DMA copies + MFMAs)
-       for every kernel of gemm_bf3p.hip (bbdm_debug_set_bf3p_kernel: forced tile shapes 5, 4 and the default 6)
+       for every kernel of gemm_bf3p.hip (option bf3p_kernel: forced tile shapes 5, 4 and the default 6)
 
     python tools/bf3p_bench.py [--reps 10] [--kernels 5,4,6]
 Prints ms and fp32-equivalent TFLOP/s (HIP events on the launch stream), checks that M is bit-equal between the paths, and a
@@ -115,13 +115,13 @@ def main():
         tot["g_old"] += cnt * t_old
         tot_fl += cnt * fl
         for k in kernels:
-            lib.bbdm_debug_set_bf3p_kernel(k)
+            lib.bbdm_set_option(b"bf3p_kernel", k)
             M1.zero_()
             t = _time(g_new, args.reps)
             eq = torch.equal(M0.view(P, tiles, Cout)[:, :T_raw], M1.view(P, tiles, Cout)[:, :T_raw])
             tot[f"g{k}"] += cnt * t
             line += f" k{k} {t:6.3f} ms {fl / t / 1e9:6.1f} TF {'==' if eq else '!= MISMATCH'} |"
-        lib.bbdm_debug_set_bf3p_kernel(6)
+        lib.bbdm_set_option(b"bf3p_kernel", 6)
         print(line, flush=True)
         del x, V, Vp, M0, M1, pw, pk, Bp
     print("C2-weighted totals (ms per step): " + "  ".join(f"{k} {v:.2f}" for k, v in tot.items()))
