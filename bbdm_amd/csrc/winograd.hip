@@ -380,7 +380,11 @@ struct GnFold {
     double cnt;                           // values per (image, group): HW * cpg
     float eps;
 };
-template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false>
+// F32 (round 5): the same two phases, the transformed values stored as fp32 rows V[xi][tile][Cin] (4 B per element instead of the
+// planes' 6) for the layers whose tile GEMM is HBM-bound (Cout = 128 at the 256^2 level: 10 B of operands per 256 FLOP) -- there
+// gemm_bf3.hip splits V under its own idle matrix pipe and both launches move a third fewer operand bytes.  Per transform point a wave
+// writes 8 tiles x 64 B; the other 16-channel chunks of the tile group run on the same XCD (see below) and complete the lines in its L2.
+template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false, bool F32 = false>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
                                                                               unsigned char* __restrict__ Vp,
                                                                               const float* __restrict__ sc, const float* __restrict__ bi,
@@ -481,6 +485,15 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
 #pragma unroll
         for (int jj = 0; jj < AL; ++jj) t[jj] = lds[(i * AL + jj) * 64 + lane];
         bt_transform<MO>(t, row);
+        if (F32) {
+            float* of = reinterpret_cast<float*>(Vp + (size_t)(i * AL) * plane) + (size_t)tile * ((size_t)nchunks * KC) + c;
+#pragma unroll
+            for (int jj = 0; jj < AL; ++jj) {
+                *reinterpret_cast<float2*>(of) = row[jj];
+                of += plane >> 2;
+            }
+            return;
+        }
         const int g = (int)(tile >> 5), rl = (int)(tile & 31);
         // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
         unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
@@ -1004,6 +1017,10 @@ extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int
     return (size_t)planes(m) * tiles_padded(N, H, W, m) * ((size_t)CinPad + (size_t)Cout);
 }
 
+static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
+                                 int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
+                                 const GnFold* fold, bool f32out);
+
 extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale,
                                        const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
                                        int CinPad, void* stream) {
@@ -1017,6 +1034,11 @@ extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V,
     BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
                  "winograd_input: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
+    // whole 16-channel chunks: the two-phase LDS kernel, storing fp32 rows (round 5; rows of padding tiles are written as zeros); other
+    // channel counts keep the one-thread-per-window kernels below
+    if (CinPad % KC == 0 && Tp < (1ull << 31))
+        return winograd_input_planes(m, x, ldx, V, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream,
+                                     nullptr, true);
     const size_t vplane = Tp * (size_t)CinPad;
     const long long units = (long long)T * (CinPad / (m == 6 ? 2 : 4));
     long long blocks = (units + 255) / 256;
@@ -1077,7 +1099,7 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 // bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
-                                 const GnFold* fold = nullptr) {
+                                 const GnFold* fold, bool f32out) {
     BBDM_WINO_M(m);
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
@@ -1089,7 +1111,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
                  "winograd_input_bf3p: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const int nchunks = CinPad / KC, TG = (int)(Tp / 8);
-    const size_t plane = Tp * (size_t)CinPad * 6;                  // bytes of one transform point
+    const size_t plane = Tp * (size_t)CinPad * (f32out ? 4 : 6);  // bytes of one transform point
     const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * 6;       // ... of the transposed copy (whole 32-channel row groups)
     BBDM_REQUIRE(!Vt || (!upsample && ((uintptr_t)Vt & 15) == 0), "winograd_input_bf3p: the transposed copy needs upsample = 0, 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
@@ -1124,6 +1146,25 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
             BBDM_CHECK_LAUNCH("winograd_input_bf3p_gn");
             return BBDM_OK;
         }
+        if (f32out) {                     // fp32 rows instead of planes (no transposed copy, no coefficient folding)
+            BBDM_REQUIRE(!Vt, "winograd_input: the fp32 form has no transposed copy");
+#define BBDM_WINO_INS2_F(MO, PRE, UP, I64)                                                                                        \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, false, I64, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                       (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr, \
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn)
+#define BBDM_WINO_INS2_FI(MO, PRE, UP) do { if (idx64) BBDM_WINO_INS2_F(MO, PRE, UP, true); else BBDM_WINO_INS2_F(MO, PRE, UP, false); } while (0)
+#define BBDM_WINO_INS2_FM(MO)                                                                                                     \
+    do {                                                                                                                          \
+        if (pre_scale) { if (upsample) BBDM_WINO_INS2_FI(MO, true, true); else BBDM_WINO_INS2_FI(MO, true, false); }              \
+        else           { if (upsample) BBDM_WINO_INS2_FI(MO, false, true); else BBDM_WINO_INS2_FI(MO, false, false); }            \
+    } while (0)
+            if (m == 2) BBDM_WINO_INS2_FM(2); else if (m == 4) BBDM_WINO_INS2_FM(4); else BBDM_WINO_INS2_FM(6);
+#undef BBDM_WINO_INS2_FM
+#undef BBDM_WINO_INS2_FI
+#undef BBDM_WINO_INS2_F
+            BBDM_CHECK_LAUNCH("winograd_input(fp32 rows, two-phase)");
+            return BBDM_OK;
+        }
 #define BBDM_WINO_INS2_I(MO, PRE, UP, TR, I64)                                                                                    \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
                        pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, (unsigned char*)Vt,   \
@@ -1147,7 +1188,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 extern "C" int bbdm_winograd_input_bf3p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale,
                                             const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
                                             int CinPad, void* stream) {
-    return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream);
+    return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream, nullptr, false);
 }
 
 // The same transform with GroupNorm [-> FiLM] [-> SiLU] folded in FROM THE STATISTICS (util.py:214-216 + openaimodel.py:258-278): the
@@ -1170,7 +1211,7 @@ extern "C" int bbdm_winograd_input_bf3p_gn_f32(int m, const float* x, int ldx, v
     GnFold f;
     f.stats = (const unsigned long long*)stats; f.gamma = gamma; f.beta = beta; f.film = film;
     f.film_ld = film_ld; f.C = C; f.G = G; f.cpg = C / G; f.cnt = (double)HW * (double)(C / G); f.eps = eps;
-    return winograd_input_planes(m, x, ldx, Vp, nullptr, nullptr, nullptr, C, pre_silu, upsample, N, H, W, CinPad, stream, &f);
+    return winograd_input_planes(m, x, ldx, Vp, nullptr, nullptr, nullptr, C, pre_silu, upsample, N, H, W, CinPad, stream, &f, false);
 }
 
 // ... and, for the training forward, ALSO the transposed planes Vt (bbdm_gemm_bf3p_tn_at_bytes((m+2)^2, tiles, CinPad) bytes): the A
@@ -1180,7 +1221,7 @@ extern "C" int bbdm_winograd_input_bf3p_tr_f32(int m, const float* x, int ldx, v
                                                const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
                                                int CinPad, void* Vt, void* stream) {
     BBDM_REQUIRE(Vt && !upsample, "winograd_input_bf3p_tr: null pointer / upsample != 0");
-    return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream);
+    return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream, nullptr, false);
 }
 
 // splits > 1 (small layers, bbdm_winograd_gemm_bf3p_splits): the partial sums of split z go to M[z][(m+2)^2][tiles][Cout] and

@@ -704,6 +704,11 @@ class UNetModel(nn.Module):
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
         # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
         self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
+        # inference: Winograd layers whose tile GEMM is HBM-bound -- at most this many output channels and >= 512 MB of plane bytes, i.e.
+        # the Cout = 128 layers of the 256^2 level (10 - 17 B of operands per 256 FLOP) -- keep V as fp32 rows (4 B per element instead
+        # of the planes' 6; gemm_bf3.hip splits them under its idle matrix pipe): a third fewer operand bytes in both the input
+        # transform and the GEMM (round 5).  0 = planes everywhere.
+        self.fp32_v_max_cout: int = 128
         # Training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
         # BBDM_WINOGRAD_WGRAD=0: the direct kernel (conv_wgrad.hip) everywhere.
         self.winograd_wgrad: int = int(os.environ.get("BBDM_WINOGRAD_WGRAD", "6"))
@@ -1199,6 +1204,9 @@ class _Plan:
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
+        if (not self.training and cout <= self.m.fp32_v_max_cout and (wm + 2) ** 2 * tiles * cin_pad * 6 >= (512 << 20)
+                and self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout)):
+            return True         # HBM-bound tile GEMM: fp32 V (see UNetModel.fp32_v_max_cout)
         if self.m.gemm_bf3p and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout) and \
                 (not keeps_V or self.lib.bbdm_gemm_bf3p_tn_supported(tiles, cin_pad, cout)):
             return "p"          # (keeps_V: the weight gradient then contracts the TRANSPOSED planes the input transform also writes)

@@ -332,6 +332,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
     ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
+    ap.add_argument("--set", action="append", default=[], metavar="ATTR=INT",
+                    help="A/B runs: set a planner attribute of UNetModel (e.g. fp32_v_max_cout=0) before the first plan is built")
     ap.add_argument("--no-f32mfma", action="store_true", help="c2: skip the strict-f32-MFMA A/B steps after the timed region")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked batch against the oracle")
     ap.add_argument("--no-op-profile", action="store_true",
@@ -420,6 +422,11 @@ def run_workload(args, env):
     sd = synth_state(model.denoise_fn)
     model.denoise_fn.load_state_dict(sd, strict=True)
     model.denoise_fn.fuse_groupnorm = bool(args.fuse_gn)
+    for kv in args.set:
+        k, v = kv.split("=")
+        if not hasattr(model.denoise_fn, k):
+            raise SystemExit(f"bench.py --set: UNetModel has no attribute {k}")
+        setattr(model.denoise_fn, k, type(getattr(model.denoise_fn, k))(int(v)) if getattr(model.denoise_fn, k) is not None else int(v))
     model = model.to(dev).eval()
     nparams = sum(p.numel() for p in model.denoise_fn.parameters())
 

@@ -25,9 +25,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NFRAG = 4;            // distinct A and B fragments per wave, rotated so that consecutive MFMAs see different operands
 
-// One wave: `iters` rounds of 16 MFMAs (4 accumulators x 4 fragment pairs), nothing else in the loop.
-__global__ void __launch_bounds__(256) mfma_stream(const bf16x8* __restrict__ frags, float* __restrict__ sink, long iters,
-                                                   unsigned long long* __restrict__ clocks) {
+// One wave: `iters` rounds of 4 x NACC MFMAs (NACC accumulators x 4 fragment pairs), nothing else in the loop.
+// clocks[0..1]: shader cycles / 100 MHz ticks of block 0's loop; clocks[2] / clocks[3]: earliest loop start / latest loop end over ALL
+// waves (atomicMin / atomicMax on the chip-wide 100 MHz counter): the burst as the chip saw it, launch overheads excluded.
+template <int NACC>
+__global__ void __launch_bounds__(256) mfma_stream_t(const bf16x8* __restrict__ frags, float* __restrict__ sink, long iters,
+                                                     unsigned long long* __restrict__ clocks) {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 63;      // 64 fragment sets in memory
     bf16x8 a[NFRAG], b[NFRAG];
@@ -36,9 +39,9 @@ __global__ void __launch_bounds__(256) mfma_stream(const bf16x8* __restrict__ fr
         a[i] = frags[((wave * 2 + 0) * NFRAG + i) * 64 + lane];
         b[i] = frags[((wave * 2 + 1) * NFRAG + i) * 64 + lane];
     }
-    f32x16 acc[4];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
@@ -46,17 +49,24 @@ __global__ void __launch_bounds__(256) mfma_stream(const bf16x8* __restrict__ fr
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(f + i) % NFRAG], b[f], acc[i], 0, 0, 0);
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(f + i) % NFRAG], b[f], acc[i], 0, 0, 0);
         }
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += acc[i][j];
     if (s == 123456.789f) sink[0] = s;                      // keep the accumulators live
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&clocks[2], w0); atomicMax(&clocks[3], w1); }
+}
+#define mfma_stream mfma_stream_t<4>
+
+// a float4 copy at full HBM rate (the "transform" phase of the step between two GEMM bursts)
+__global__ void __launch_bounds__(256) copy_stream(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 static uint16_t f2bf(float x) {              // round-to-nearest-even bf16
@@ -69,7 +79,10 @@ static float gauss() {
     return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
 }
 
+static int burst_main(int argc, char** argv);
+
 int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "burst") == 0) return burst_main(argc - 1, argv + 1);
     const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
     const int waves_per_simd = argc > 2 ? atoi(argv[2]) : 3;
     hipDeviceProp_t prop;
@@ -79,7 +92,7 @@ int main(int argc, char** argv) {
     const size_t nfr = 64 * 2 * NFRAG * 64;                 // fragments of 8 bf16
     std::vector<uint16_t> h(nfr * 8);
     bf16x8* d; float* sink; unsigned long long* clocks;
-    CK(hipMalloc(&d, nfr * 16)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&clocks, 16));
+    CK(hipMalloc(&d, nfr * 16)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&clocks, 32));
     const int blocks = cus * waves_per_simd;                // 256 threads = 4 waves = one per SIMD; waves_per_simd blocks per CU
     const double flop_per_wave_iter = 16.0 * 2.0 * 32 * 32 * 16;
     const char* names[3] = {"zero operands", "random N(0,1) bf16 operands", "random operands, bf16x3 plane magnitudes (1, 2^-8, 2^-16)"};
@@ -120,5 +133,130 @@ int main(int argc, char** argv) {
         printf("%-62s %7.1f TFLOP/s mean (%7.1f best) over %d launches of %.0f ms  shader clock %.3f GHz  %.1f cycles per MFMA and SIMD  "
                "= %.3f of 2500\n", names[mode], tf, best, launches, last_ms, ghz, cyc_per_mfma, tf / 2500.0);
     }
+    return 0;
+}
+
+
+// ---- burst mode (round 5):  ./mfma_peak burst [seconds]
+// The continuous stream above is one duty cycle; the C2 step is another: 0.5 - 4.5 ms of tile GEMM between HBM-bound transforms that
+// draw a third of the power.  Rows:
+//   (i)   back-to-back MFMA launches of 0.5 / 1.5 / 5 / 50 ms (random operands) for `seconds`;
+//   (ii)  ALTERNATING: a ~1.5 ms MFMA burst, then a ~0.5 ms float4 copy at full HBM rate, for `seconds`; TFLOP/s INSIDE the bursts from
+//         the chip-wide 100 MHz counter (earliest loop start to latest loop end over all waves), first / middle / last thirds separately;
+//   (iii) the same alternating schedule at 1, 2, 3 waves per SIMD and with 8 accumulators per wave.
+// Shader clock of a burst = block 0's s_memtime cycles / its 100 MHz ticks.
+template <int NACC>
+static void launch_mfma(int blocks, const bf16x8* d, float* sink, long iters, unsigned long long* clk) {
+    hipLaunchKernelGGL(mfma_stream_t<NACC>, dim3(blocks), dim3(256), 0, 0, d, sink, iters, clk);
+}
+struct BurstStat { double tf_mean, tf_min, tf_max, ghz, tf_third[3], burst_ms, gap_ms; int n; long iters; };
+
+static BurstStat run_schedule(int cus, int wps, int nacc, const bf16x8* d, float* sink, unsigned long long* clk_dev, int max_bursts,
+                              double burst_ms, double copy_ms, double seconds, float4* csrc, float4* cdst, size_t copy_elems_per_ms) {
+    const int blocks = cus * wps;
+    const double flop_iter = (double)nacc * 4.0 * 2.0 * 32 * 32 * 16;           // per wave and loop iteration
+    auto go = [&](long iters, unsigned long long* c) { if (nacc == 8) launch_mfma<8>(blocks, d, sink, iters, c); else launch_mfma<4>(blocks, d, sink, iters, c); };
+    // calibrate iterations for the burst length on a warm chip (a few launches, event-timed)
+    long iters = 2000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int pass = 0; pass < 3; ++pass) {
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < 4; ++r) go(iters, clk_dev);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        iters = (long)fmax(16.0, iters * burst_ms / (ms / 4));
+    }
+    const size_t copy_n = (size_t)(copy_elems_per_ms * copy_ms);
+    int n = (int)fmin((double)max_bursts, seconds * 1e3 / (burst_ms + copy_ms));
+    if (n < 3) n = 3;
+    std::vector<unsigned long long> init((size_t)n * 4);
+    for (int l = 0; l < n; ++l) { init[l * 4] = 0; init[l * 4 + 1] = 0; init[l * 4 + 2] = ~0ull; init[l * 4 + 3] = 0; }
+    CK(hipMemcpy(clk_dev, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+    for (int l = 0; l < n; ++l) {                       // everything queued up front: no host round trip between a burst and its copy
+        go(iters, clk_dev + (size_t)l * 4);
+        if (copy_n) hipLaunchKernelGGL(copy_stream, dim3(cus * 8), dim3(256), 0, 0, csrc, cdst, copy_n);
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h((size_t)n * 4);
+    CK(hipMemcpy(h.data(), clk_dev, h.size() * 8, hipMemcpyDeviceToHost));
+    BurstStat st{};
+    st.tf_min = 1e30; st.n = n; st.iters = iters;
+    double third_sum[3] = {0, 0, 0}; int third_n[3] = {0, 0, 0};
+    for (int l = 0; l < n; ++l) {
+        const double sec = (double)(h[l * 4 + 3] - h[l * 4 + 2]) / 100e6;
+        const double tf = flop_iter * iters * blocks * 4 / sec / 1e12;
+        st.tf_mean += tf / n; st.tf_min = fmin(st.tf_min, tf); st.tf_max = fmax(st.tf_max, tf);
+        st.ghz += (double)h[l * 4] / ((double)h[l * 4 + 1] / 100e6) / 1e9 / n;
+        st.burst_ms += sec * 1e3 / n;
+        if (l + 1 < n) st.gap_ms += (double)(h[(l + 1) * 4 + 2] - h[l * 4 + 3]) / 100e6 * 1e3 / (n - 1);
+        const int t = l * 3 / n;
+        third_sum[t] += tf; third_n[t]++;
+    }
+    for (int t = 0; t < 3; ++t) st.tf_third[t] = third_n[t] ? third_sum[t] / third_n[t] : 0;
+    return st;
+}
+
+static int burst_main(int argc, char** argv) {
+    const double seconds = argc > 1 ? atof(argv[1]) : 3.0;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("burst mode: device %s  CUs %d  %.1f s per row; random N(0,1) bf16 operands unless stated\n", prop.gcnArchName, cus, seconds);
+    const size_t nfr = 64 * 2 * NFRAG * 64;
+    std::vector<uint16_t> h(nfr * 8);
+    bf16x8* d; float* sink; unsigned long long* clk;
+    const int max_bursts = 8192;
+    CK(hipMalloc(&d, nfr * 16)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&clk, (size_t)max_bursts * 32));
+    const size_t cbytes = 2ull << 30;                           // 2 GiB source + 2 GiB destination: far beyond the 256 MB Infinity Cache
+    float4 *csrc, *cdst;
+    CK(hipMalloc(&csrc, cbytes)); CK(hipMalloc(&cdst, cbytes));
+    CK(hipMemset(csrc, 1, cbytes));
+    // copy rate: elements per ms (event-timed on a warm chip)
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const size_t call_n = cbytes / 16;
+    double copy_ms = 0;
+    for (int r = 0; r < 3; ++r) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL(copy_stream, dim3(cus * 8), dim3(256), 0, 0, csrc, cdst, call_n);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        copy_ms = ms;
+    }
+    const size_t elems_per_ms = (size_t)(call_n / copy_ms);
+    printf("float4 copy: %.2f TB/s (read + write) -> %.0f MB copied per ms\n", 2.0 * cbytes / (copy_ms * 1e-3) / 1e12, elems_per_ms * 16 / 1e6);
+    auto fill = [&](int mode) {
+        srand(1234);
+        for (size_t i = 0; i < nfr; ++i)
+            for (int k = 0; k < 8; ++k) h[i * 8 + k] = mode == 0 ? 0 : f2bf(gauss());
+        CK(hipMemcpy(d, h.data(), nfr * 16, hipMemcpyHostToDevice));
+    };
+    auto row = [&](const char* name, int wps, int nacc, double bms, double cms) {
+        const BurstStat s = run_schedule(cus, wps, nacc, d, sink, clk, max_bursts, bms, cms, seconds, csrc, cdst, elems_per_ms);
+        const double cyc = s.ghz * 1e9 * (s.burst_ms * 1e-3) / ((double)wps * nacc * 4.0 * s.iters);      // one SIMD issues wps x 4 nacc x iters MFMAs per burst
+        printf("%-44s w/SIMD %d acc %d | %5d bursts of %6.3f ms, gap %6.3f ms | in-burst TFLOP/s mean %7.1f (min %7.1f max %7.1f; thirds %7.1f %7.1f %7.1f) "
+               "| %.3f GHz, %.1f cycles per MFMA and SIMD | %.3f of 2500\n", name, wps, nacc, s.n, s.burst_ms, s.gap_ms, s.tf_mean, s.tf_min, s.tf_max,
+               s.tf_third[0], s.tf_third[1], s.tf_third[2], s.ghz, cyc, s.tf_mean / 2500.0);
+        fflush(stdout);
+    };
+    fill(1);
+    // (i) back-to-back launches of one length
+    for (double bms : {0.5, 1.5, 5.0, 50.0}) row("(i) back-to-back MFMA launches", 2, 4, bms, 0.0);
+    // (ii) the step's duty cycle
+    row("(ii) 1.5 ms MFMA / 0.5 ms copy", 2, 4, 1.5, 0.5);
+    row("(ii) 1.5 ms MFMA / 1.5 ms copy", 2, 4, 1.5, 1.5);
+    row("(ii) 0.5 ms MFMA / 0.5 ms copy", 2, 4, 0.5, 0.5);
+    row("(ii) 4.5 ms MFMA / 1.5 ms copy", 2, 4, 4.5, 1.5);
+    // (iii) occupancy / accumulator rows on the 1.5 / 0.5 schedule
+    row("(iii) 1.5 / 0.5", 1, 4, 1.5, 0.5);
+    row("(iii) 1.5 / 0.5", 1, 8, 1.5, 0.5);
+    row("(iii) 1.5 / 0.5", 2, 8, 1.5, 0.5);
+    row("(iii) 1.5 / 0.5", 3, 4, 1.5, 0.5);
+    row("(iii) 1.5 / 0.5", 4, 4, 1.5, 0.5);
+    fill(0);
+    row("zero operands: (i) 1.5 ms back to back", 2, 4, 1.5, 0.0);
+    row("zero operands: (ii) 1.5 / 0.5", 2, 4, 1.5, 0.5);
+    row("zero operands: (iii) 1 wave, 8 acc, 1.5 / 0.5", 1, 8, 1.5, 0.5);
     return 0;
 }

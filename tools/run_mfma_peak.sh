@@ -15,13 +15,17 @@ smi > $O/smi_mfma_peak.txt & SMI=$!
 ./tools/microbench/mfma_peak 3 3 > $O/mfma_peak.txt 2>&1
 ./tools/microbench/mfma_peak 3 2 >> $O/mfma_peak.txt 2>&1
 kill $SMI
+# burst mode (round 5): the step's duty cycle instead of a continuous stream -- see burst_main() in mfma_peak.hip
+smi > $O/smi_mfma_burst.txt & SMI=$!
+./tools/microbench/mfma_peak burst 3 > $O/mfma_burst.txt 2>&1
+kill $SMI
 smi > $O/smi_bench_c2.txt & SMI=$!
 python bench.py --steps 20 --warmup 5 --no-cpu --no-parity --no-f32mfma --no-extras > $O/bench_c2.json 2> $O/bench_c2.err
 kill $SMI
-cat $O/mfma_peak.txt
+cat $O/mfma_peak.txt $O/mfma_burst.txt
 python - <<P
 import re, json
-for f in ("smi_mfma_peak", "smi_bench_c2"):
+for f in ("smi_mfma_peak", "smi_mfma_burst", "smi_bench_c2"):
     pw, ck = [], []
     for ln in open("$O/%s.txt" % f):
         m = re.search(r"Power[^;]*?:\s*([0-9.]+)", ln); c = re.search(r"sclk[^;]*?\(([0-9.]+)Mhz\)", ln)
