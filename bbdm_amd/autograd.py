@@ -82,7 +82,7 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, target, pred, loss_type):
         t, p = target.contiguous().float(), pred.contiguous().float()
-        partial = torch.zeros(1, dtype=torch.float64, device=p.device)
+        partial = torch.zeros(4, dtype=torch.float64, device=p.device)        # one exact limb cell (csrc/stats_acc.h)
         out = torch.empty(1, dtype=torch.float32, device=p.device)
         with _lib.device_guard(p.device):
             _lib.call("bbdm_bb_loss_f32", t.data_ptr(), p.data_ptr(), partial.data_ptr(), out.data_ptr(), p.numel(),

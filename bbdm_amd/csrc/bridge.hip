@@ -5,6 +5,7 @@
 // directly), th.cat([x, context], 1) (openaimodel.py:742) and the NCHW<->NHWC hand-over at the UNet boundary.
 // Compiled with -ffp-contract=off: the reference evaluates these formulas as separate fp32 tensor ops.
 #include "common.h"
+#include "stats_acc.h"
 
 namespace {
 
@@ -82,7 +83,7 @@ __global__ void p_step_kernel(const float* __restrict__ x_t, const float* __rest
 }
 
 __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                           double* __restrict__ partial, size_t count, int loss_type) {
+                                                           unsigned long long* __restrict__ partial, size_t count, int loss_type) {
     __shared__ double red[4];
     double s = 0.0;
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
@@ -93,11 +94,11 @@ __global__ void __launch_bounds__(256) loss_partial_kernel(const float* __restri
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(partial, (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) sa_add(partial, (red[0] + red[1]) + (red[2] + red[3]));      // exact limb cell: any block order, same bits
 }
 
-__global__ void loss_final_kernel(const double* __restrict__ partial, float* __restrict__ out, double inv_count) {
-    out[0] = (float)(partial[0] * inv_count);
+__global__ void loss_final_kernel(const unsigned long long* __restrict__ partial, float* __restrict__ out, double inv_count) {
+    out[0] = (float)(sa_load(partial) * inv_count);
 }
 
 // d loss / d pred (same NCHW layout as pred):  l1: sign(pred - target) / count ; l2: 2 (pred - target) / count ;
@@ -188,9 +189,10 @@ extern "C" int bbdm_bb_loss_f32(const float* a, const float* b, double* partial,
     BBDM_REQUIRE(a && b && partial && out && count > 0 && (loss_type == 0 || loss_type == 1), "loss: bad args");
     size_t blocks = (count + 256 * 8 - 1) / (256 * 8);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, partial,
+    unsigned long long* cell = reinterpret_cast<unsigned long long*>(partial);     // 4 x 8 bytes (stats_acc.h), zeroed by the caller
+    hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, cell,
                        count, loss_type);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, partial, out, 1.0 / (double)count);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, cell, out, 1.0 / (double)count);
     BBDM_CHECK_LAUNCH("loss");
     return BBDM_OK;
 }

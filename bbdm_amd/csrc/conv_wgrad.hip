@@ -16,6 +16,7 @@
 // gridDim.z; partial tiles go to a workspace and a second kernel sums the splits in a fixed order (deterministic)
 // while transposing to the parameter's OIHW layout.
 #include "common.h"
+#include "stats_acc.h"
 #include "bf3_split.h"
 #include <stdlib.h>
 
@@ -454,8 +455,9 @@ __global__ void __launch_bounds__(256) tn_pack_planes_kernel(const float* __rest
     if (colsum && c0 + tid < C) colsum[(size_t)blockIdx.y * C + c0 + tid] = (float)acc;
 }
 
-// db[c] = sum over rows of dy[M][ld]; fp64 per-thread accumulation + fp64 atomics (order-independent to fp32 rounding)
-__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc,
+// db[c] = sum over rows of dy[M][ld]; fp64 per-thread accumulation, then exact integer-limb cells (stats_acc.h: any order of the
+// atomics leaves the same limbs -- the bias gradients are bitwise reproducible)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dy, int ld, unsigned long long* __restrict__ acc,
                                                      long long M, int C, int rows_per_block) {
     const int tid = threadIdx.x;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -469,15 +471,15 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ d
         if (c < C && rl < RL) {
             double s = 0.0;
             for (long long r = r0 + rl; r < r1; r += RL) s += (double)dy[(size_t)r * ld + c];
-            atomicAdd(&acc[c], s);
+            sa_add(acc + (size_t)c * SA_W, s);
         }
     }
 }
 
 // vectorised variant (C % 4 == 0, 16-byte aligned rows): a workgroup owns 256 columns (64 lanes x float4) of a row range, its
 // four waves take every fourth row with four loads in flight each; fp64 per-lane accumulators, one LDS reduction over the
-// waves, then fp64 atomics.  (The scalar kernel above keeps ONE 4-byte load in flight per thread: 0.23 ms for a 268 MB dY.)
-__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc, long long M,
+// waves, then the limb cells.  (The scalar kernel above keeps ONE 4-byte load in flight per thread: 0.23 ms for a 268 MB dY.)
+__global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ dy, int ld, unsigned long long* __restrict__ acc, long long M,
                                                       int C, int rows_per_block) {
     __shared__ double red[4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -508,12 +510,12 @@ __global__ void __launch_bounds__(256) colsum4_kernel(const float* __restrict__ 
     if (wave == 0 && c < C) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            atomicAdd(&acc[c + j], (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]));
+            sa_add(acc + (size_t)(c + j) * SA_W, (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]));
     }
 }
 
 // per-image variant: grid.y = image
-__global__ void __launch_bounds__(256) colsum_batched_kernel(const float* __restrict__ dy, int ld, double* __restrict__ acc,
+__global__ void __launch_bounds__(256) colsum_batched_kernel(const float* __restrict__ dy, int ld, unsigned long long* __restrict__ acc,
                                                              long long M, int C, int rows_per_block) {
     const int tid = threadIdx.x, n = blockIdx.y;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
@@ -526,19 +528,19 @@ __global__ void __launch_bounds__(256) colsum_batched_kernel(const float* __rest
         if (c < C && rl < RL) {
             double s = 0.0;
             for (long long r = r0 + rl; r < r1; r += RL) s += (double)base[(size_t)r * ld + c];
-            atomicAdd(&acc[(size_t)n * C + c], s);
+            sa_add(acc + ((size_t)n * C + c) * SA_W, s);
         }
     }
 }
 
-__global__ void colsum_batched_final_kernel(const double* __restrict__ acc, float* __restrict__ out, int ldo, int N, int C) {
+__global__ void colsum_batched_final_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ out, int ldo, int N, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N * C) out[(size_t)(i / C) * ldo + i % C] = (float)acc[i];
+    if (i < N * C) out[(size_t)(i / C) * ldo + i % C] = (float)sa_load(acc + (size_t)i * SA_W);
 }
 
-__global__ void colsum_final_kernel(const double* __restrict__ acc, float* __restrict__ db, int C) {
+__global__ void colsum_final_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ db, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) db[c] = (float)acc[c];
+    if (c < C) db[c] = (float)sa_load(acc + (size_t)c * SA_W);
 }
 
 // packed weights for the data-gradient conv: Wd[ci_out][co_in][r][s] = W[co_in][ci_out][K-1-r][K-1-s]
@@ -631,7 +633,7 @@ static size_t wgrad_tn_planes_floats(const TnPlanes& g, int Cin, int Cout) {
 
 static size_t wgrad_tn_floats(long long K, int Cin, int Cout) {
     const size_t sp = (size_t)bbdm_gemm_tn_splits(1, K, Cin, Cout);
-    return sp * Cin * Cout + 4 + (sp > 2 ? sp : 2) * (size_t)Cout + 2;      // partial tiles | per-split column sums / fp64 colsum scratch
+    return sp * Cin * Cout + 4 + (sp > 2 * SA_W ? sp : 2 * SA_W) * (size_t)Cout + 2;      // partial tiles | per-split column sums / colsum limb cells
 }
 
 extern "C" size_t bbdm_conv_wgrad_workspace_floats(int N, int H, int W, int Cin, int Cout, int ks) {
@@ -761,10 +763,11 @@ extern "C" int bbdm_conv_wgrad_f32(const float* x, int ldx, const float* dy, int
     return BBDM_OK;
 }
 
-extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream) {
-    BBDM_REQUIRE(dy && acc && out && M > 0 && C > 0 && ld >= C, "colsum: bad args");
+extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc_, float* out, long long M, int C, void* stream) {
+    BBDM_REQUIRE(dy && acc_ && out && M > 0 && C > 0 && ld >= C && ((uintptr_t)acc_ & 7) == 0, "colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
-    bbdm_zero_async(acc, sizeof(double) * C, st);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_);       // [C][SA_W] limb cells
+    bbdm_zero_async(acc, 8 * (size_t)C * SA_W, st);
     long long blocks = (M + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     const int rpb = (int)((M + blocks - 1) / blocks);
@@ -785,11 +788,12 @@ extern "C" int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out,
     return BBDM_OK;
 }
 
-extern "C" int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, float* out, int ldo, int N, long long M, int C,
+extern "C" int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc_, float* out, int ldo, int N, long long M, int C,
                                        void* stream) {
-    BBDM_REQUIRE(dy && acc && out && N > 0 && M > 0 && C > 0 && ld >= C && ldo >= C, "colsum_batched: bad args");
+    BBDM_REQUIRE(dy && acc_ && out && N > 0 && M > 0 && C > 0 && ld >= C && ldo >= C && ((uintptr_t)acc_ & 7) == 0, "colsum_batched: bad args");
     hipStream_t st = (hipStream_t)stream;
-    bbdm_zero_async(acc, sizeof(double) * N * C, st);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(acc_);       // [N][C][SA_W] limb cells
+    bbdm_zero_async(acc, 8 * (size_t)N * C * SA_W, st);
     long long blocks = (M + 255) / 256;
     const long long cap = cdiv(1024, N) > 1 ? cdiv(1024, N) : 1;
     if (blocks > cap) blocks = cap;

@@ -25,8 +25,8 @@ struct BwdArgs {
     const float* dadd;
     const double* sg;
     const float4* coef;          // [N][G] {rstd, mean, S1/cnt, S2/cnt} in fp32, written by the finalize kernel
-    double* pq;
-    const double* dgb;           // [C][2] fp64 sums over n of dgamma / dbeta (finalize kernel), converted by the apply pass
+    unsigned long long* pq;      // [N][C][2][SA_W] exact limb cells (stats_acc.h): P, Q summed over the pixel blocks in ANY order
+    const unsigned long long* dgb;   // [C][2][SA_W] limb cells: sums over n of dgamma / dbeta (finalize kernel), folded by the apply pass
     float* dgamma;
     float* dbeta;
     float* dx;
@@ -103,12 +103,14 @@ __device__ __forceinline__ void quad_dv(const BwdArgs& a, int n, int c, const No
 // ---- kernel 1: P, Q ----------------------------------------------------------------------------------------------
 template <int JMAX>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int pix_per_block) {
-    extern __shared__ double lacc[];          // [C][2]
+    // Deterministic (round 5): the pixel rows of a workgroup meet in LDS in a FIXED order (no LDS atomics), the workgroups of an image
+    // meet in exact integer-limb cells (any order of the atomics leaves the same limbs)
+    __shared__ double lacc[256 * 8];          // [thread][P0..3, Q0..3]
     const int tid = threadIdx.x, n = blockIdx.y;
     const int C4 = a.C >> 2, cpg = a.C / a.G, HW = a.H * a.W;
     const double cnt = (double)HW * cpg;
-    for (int i = tid; i < 2 * a.C; i += 256) lacc[i] = 0.0;
-    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lacc[tid * 8 + e] = 0.0;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     const int Ho = (a.resample == 1 || a.resample == 3) ? a.H >> 1 : (a.resample == 2 ? a.H * 2 : a.H);
     const int Wo = (a.resample == 1 || a.resample == 3) ? a.W >> 1 : (a.resample == 2 ? a.W * 2 : a.W);
@@ -155,44 +157,60 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { P[e] += (double)dv[e] * xh[e]; Q[e] += (double)dv[e]; }
             }
+            if (JMAX == 1 && C4 <= 256) {        // several pixel rows per channel quad: through LDS (below)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&lacc[2 * (c + e)], P[e]);
-                atomicAdd(&lacc[2 * (c + e) + 1], Q[e]);
+                for (int e = 0; e < 4; ++e) { lacc[tid * 8 + e] = P[e]; lacc[tid * 8 + 4 + e] = Q[e]; }
+            } else {                             // one thread per channel quad: straight to the cells
+                unsigned long long* cell = a.pq + ((size_t)n * a.C + c) * 2 * SA_W;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sa_add(cell + (2 * e) * SA_W, P[e]); sa_add(cell + (2 * e + 1) * SA_W, Q[e]); }
             }
         }
     }
-    __syncthreads();
-    for (int i = tid; i < 2 * a.C; i += 256) atomicAdd(&a.pq[(size_t)n * a.C * 2 + i], lacc[i]);
+    if (JMAX == 1 && C4 <= 256) {
+        __syncthreads();
+        for (int i = tid; i < 2 * a.C; i += 256) {               // value i = (channel, P | Q): its PP rows added in row order
+            const int c = i >> 1, which = i & 1, c4 = c >> 2, e = c & 3;
+            double v = 0.0;
+            for (int r = 0; r < PP; ++r) v += lacc[(r * C4 + c4) * 8 + which * 4 + e];
+            sa_add(a.pq + ((size_t)n * a.C * 2 + i) * SA_W, v);
+        }
+    }
 }
 
 // ---- kernel 2: finalize (one block per image) --------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __restrict__ pq, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const unsigned long long* __restrict__ pq, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ film,
-                                                              int film_ld, double* __restrict__ sg, double* __restrict__ dgb,
+                                                              int film_ld, double* __restrict__ sg, unsigned long long* __restrict__ dgb,
                                                               float* __restrict__ dfilm, int dfilm_ld, int C, int G,
                                                               const unsigned long long* __restrict__ stats, float4* __restrict__ coef,
                                                               double cnt, float eps) {
-    // grid = N; dgb: fp64 [C][2] accumulators (zeroed by the launcher) for dgamma / dbeta over n
+    // grid = N; dgb: [C][2] limb cells (zeroed by the launcher) for dgamma / dbeta over n; the group sums S1, S2 in LDS limb cells
+    // (integer atomics: order-independent)
+    __shared__ unsigned long long s12c[64 * 2 * SA_W];
     __shared__ double s12[64 * 2];
     const int n = blockIdx.x, tid = threadIdx.x, cpg = C / G;
-    if (tid < 2 * G) s12[tid] = 0.0;
+    for (int i = tid; i < 2 * G * SA_W; i += 256) s12c[i] = 0ull;
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
-        const double P = pq[((size_t)n * C + c) * 2], Q = pq[((size_t)n * C + c) * 2 + 1];
+        const double P = sa_load(pq + (((size_t)n * C + c) * 2) * SA_W), Q = sa_load(pq + (((size_t)n * C + c) * 2 + 1) * SA_W);
         const double g = gamma[c], b = beta[c];
         const double one_sc = film ? 1.0 + (double)film[(size_t)n * film_ld + c] : 1.0;
-        atomicAdd(&dgb[2 * c], one_sc * P);
-        atomicAdd(&dgb[2 * c + 1], one_sc * Q);
+        sa_add(dgb + (size_t)(2 * c) * SA_W, one_sc * P);
+        sa_add(dgb + (size_t)(2 * c + 1) * SA_W, one_sc * Q);
         if (dfilm) {
             dfilm[(size_t)n * dfilm_ld + c] = (float)(g * P + b * Q);       // d scale
             dfilm[(size_t)n * dfilm_ld + C + c] = (float)Q;                 // d shift
         }
-        atomicAdd(&s12[2 * (c / cpg)], g * one_sc * Q);
-        atomicAdd(&s12[2 * (c / cpg) + 1], g * one_sc * P);
+        sa_add(&s12c[(2 * (c / cpg)) * SA_W], g * one_sc * Q);
+        sa_add(&s12c[(2 * (c / cpg) + 1) * SA_W], g * one_sc * P);
     }
     __syncthreads();
-    if (tid < 2 * G) sg[(size_t)n * G * 2 + tid] = s12[tid];
+    if (tid < 2 * G) {
+        s12[tid] = sa_load(&s12c[tid * SA_W]);
+        sg[(size_t)n * G * 2 + tid] = s12[tid];
+    }
+    __syncthreads();
     // what the apply pass needs per (image, group), once, in fp32 -- it used to redo these fp64 divisions / square roots for
     // every channel quad of every pixel, which made an HBM-bound pass ALU-bound (2.5 TB/s)
     if (tid < G) {
@@ -249,8 +267,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
     const int n = blockIdx.y, tid = threadIdx.x;
     if (NORM && blockIdx.x == 0 && n == 0) {                     // dgamma / dbeta: the finalize kernel's fp64 sums over n, to fp32
         for (int c = tid; c < a.C; c += 256) {
-            a.dgamma[c] = (float)a.dgb[2 * c];
-            a.dbeta[c] = (float)a.dgb[2 * c + 1];
+            a.dgamma[c] = (float)sa_load(a.dgb + (size_t)(2 * c) * SA_W);
+            a.dbeta[c] = (float)sa_load(a.dgb + (size_t)(2 * c + 1) * SA_W);
         }
     }
     const int C4 = a.C >> 2, HW = a.H * a.W;
@@ -316,9 +334,10 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
 
 }  // namespace
 
-// Workspace (fp64 elements): pq [N][C][2] + sg [N][G][2] + dgb [C][2] + coef [N][G] float4 (= 2 doubles each)
+// Workspace (8-byte elements): pq [N][C][2][SA_W] limb cells + dgb [C][2][SA_W] limb cells + sg [N][G][2] fp64 + coef [N][G] float4
+// (= 2 doubles each)
 extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
-    return (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2 + (size_t)N * G * 2;
+    return (size_t)N * C * 2 * SA_W + (size_t)C * 2 * SA_W + (size_t)N * G * 2 + (size_t)N * G * 2;
 }
 
 extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats_, const float* gamma, const float* beta,
@@ -345,11 +364,11 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
     a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr; a.dgb = nullptr; a.dgamma = nullptr; a.dbeta = nullptr;
     const int HW = H * W;
     if (norm) {
-        double* pq = ws;
-        double* sg = ws + (size_t)N * C * 2;
-        double* dgb = sg + (size_t)N * G * 2;
-        float4* coef = reinterpret_cast<float4*>(dgb + (size_t)C * 2);
-        bbdm_zero_async(ws, sizeof(double) * ((size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)C * 2), st);
+        unsigned long long* pq = reinterpret_cast<unsigned long long*>(ws);
+        unsigned long long* dgb = pq + (size_t)N * C * 2 * SA_W;
+        double* sg = reinterpret_cast<double*>(dgb + (size_t)C * 2 * SA_W);
+        float4* coef = reinterpret_cast<float4*>(sg + (size_t)N * G * 2);
+        bbdm_zero_async(ws, 8 * ((size_t)N * C * 2 * SA_W + (size_t)C * 2 * SA_W), st);
         a.pq = pq; a.sg = sg; a.coef = coef;
         const int C4 = C / 4;
         const int PP = C4 <= 256 ? 256 / C4 : 1;
@@ -357,11 +376,10 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
         int ppb = cdiv(HW, splits);
         if (ppb < PP * 8) ppb = PP * 8;
         splits = cdiv(HW, ppb);
-        const size_t lds = sizeof(double) * 2 * C;
         const dim3 grid(splits, N);
-        if (C4 <= 256) hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, grid, dim3(256), lds, st, a, ppb);
-        else if (C4 <= 512) hipLaunchKernelGGL(gn_bwd_reduce_kernel<2>, grid, dim3(256), lds, st, a, ppb);
-        else hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, grid, dim3(256), lds, st, a, ppb);
+        if (C4 <= 256) hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, a, ppb);
+        else if (C4 <= 512) hipLaunchKernelGGL(gn_bwd_reduce_kernel<2>, grid, dim3(256), 0, st, a, ppb);
+        else hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, a, ppb);
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, pq, gamma, beta, film, film_ld, sg, dgb, dfilm,
                            dfilm_ld, C, G, stats, coef, (double)HW * (C / G), eps);
         a.dgb = dgb; a.dgamma = dgamma; a.dbeta = dbeta;

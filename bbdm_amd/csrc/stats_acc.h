@@ -9,10 +9,13 @@
 //   an fp64 partial sum v is cut into three signed integer limbs of 40 value bits, v * 2^70 = l2 * 2^80 + l1 * 2^40 + l0 (+ the bits
 //   of v below 2^-70, dropped -- a fixed function of v), and the limbs are added with 64-bit INTEGER atomics (LDS: ds_add_u64, HBM:
 //   global_atomic_add_x2).  Integer addition is associative and commutative, so every order of the atomics leaves the same limbs;
-//   a reader folds them back into one double in a fixed order.  Window: |v| < 2^72 with a resolution of 2^-70 (a sum of squares of
-//   1e21, or an activation of 1e-10, are both far outside what a UNet produces); 24 spare bits per limb take 16 M additions before a
-//   limb could wrap.  A non-finite or out-of-window partial bumps a fourth word, and the reader returns NaN for that cell, as the fp64
-//   sum would have.
+//   a reader folds them back into one double in a fixed order.  Window: |v| < 2^50 with a resolution of 2^-70 (a per-thread partial
+//   sum of squares of 1e15, or an activation of 1e-10, are both far outside what a UNet produces): every limb then holds at most 40
+//   value bits, and the 23 spare bits take 8 M additions before a limb could wrap -- the top limb included (round 4 accepted |v| < 2^72,
+//   which left the top limb one or two spare bits: a few huge partials would have wrapped it silently).  A non-finite or
+//   out-of-window partial bumps a fourth word, and the reader returns NaN for that cell, as a diverged fp64 sum would have shown.
+//   The same cells carry the training backward's order-dependent sums (GroupNorm / LayerNorm parameter gradients, bias gradients,
+//   the loss): round 5, so that a training micro-step is bitwise reproducible too (the reference: cudnn.deterministic, main.py:57-65).
 //
 // Layout of one statistics slot: [N][G][2 (sum, sum of squares)][SA_W] 64-bit words, zeroed by the caller before the producers run.
 #pragma once
@@ -23,7 +26,7 @@ constexpr int SA_W = 4;                    // words per accumulated value: limbs
 // v -> limbs (see above).  Every step is exact: t = v * 2^70 is a power-of-two scaling; h = trunc(t * 2^-80) takes t's leading bits, so
 // t - h * 2^80 is the rest of t's significand, representable; likewise for the middle limb.
 __device__ __forceinline__ bool sa_split(double v, long long (&l)[3]) {
-    if (!(fabs(v) < 0x1p72)) {            // NaN, Inf, or outside the window
+    if (!(fabs(v) < 0x1p50)) {            // NaN, Inf, or outside the window
         l[0] = l[1] = l[2] = 0;
         return false;
     }

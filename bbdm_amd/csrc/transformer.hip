@@ -5,6 +5,7 @@
 // Tokens are the pixels of the NHWC activation ('b c h w -> b (h w) c' is a no-op in this layout).  Both are HBM-bound
 // streaming passes; the linear layers around them are 1x1 convolutions on the matrix core (csrc/conv_igemm.hip).
 #include "common.h"
+#include "stats_acc.h"
 
 namespace {
 
@@ -72,15 +73,16 @@ __global__ void __launch_bounds__(256) geglu_kernel(const float* __restrict__ a,
 // LayerNorm: with xh = (x - mean) rstd and g = dy gamma:  dx = rstd (g - mean(g) - xh mean(g xh)) [+ dadd: the residual
 // branch's gradient, x = f(norm(x)) + x in BasicTransformerBlock._forward, attention.py:215-218];
 // dgamma[c] = sum_rows dy xh, dbeta[c] = sum_rows dy.  One wavefront per token (statistics recomputed: x is re-read anyway),
-// a workgroup's waves walk rows with a grid stride and add their dy xh / dy into an LDS [2][C] table (ds_add_f32), which
-// leaves as fp64 atomics -- the per-channel sums are order-independent to fp32 rounding.
+// a workgroup's waves walk rows with a grid stride and add their dy xh / dy into per-WAVE LDS [4][2][C] tables (no atomics: a lane owns
+// its channels), which the workgroup adds in wave order and hands to exact integer-limb cells (stats_acc.h) -- bitwise reproducible.
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                                             const float* __restrict__ dy, int lddy,
                                                             const float* __restrict__ dadd, int ldadd, float* __restrict__ dx,
-                                                            int lddx, double* __restrict__ ws, long long rows, int C, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float lsum[];        // [2][C]
+                                                            int lddx, unsigned long long* __restrict__ ws, long long rows, int C, float eps) {
+    extern __shared__ __attribute__((aligned(16))) float lsum_all[];    // [4 waves][2][C]
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lsum[i] = 0.f;
+    float* lsum = lsum_all + (size_t)(threadIdx.x >> 6) * 2 * C;       // this wave's table
+    for (int i = threadIdx.x; i < 8 * C; i += 256) lsum_all[i] = 0.f;
     __syncthreads();
     const float invC = 1.0f / (float)C;
     for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
@@ -112,10 +114,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
             const float g0 = d.x * g.x, g1 = d.y * g.y, g2 = d.z * g.z, g3 = d.w * g.w;
             sg += (g0 + g1) + (g2 + g3);
             sgx += (g0 * h0 + g1 * h1) + (g2 * h2 + g3 * h3);
-            atomicAdd(&lsum[c + 0], d.x * h0); atomicAdd(&lsum[c + 1], d.y * h1);
-            atomicAdd(&lsum[c + 2], d.z * h2); atomicAdd(&lsum[c + 3], d.w * h3);
-            atomicAdd(&lsum[C + c + 0], d.x); atomicAdd(&lsum[C + c + 1], d.y);
-            atomicAdd(&lsum[C + c + 2], d.z); atomicAdd(&lsum[C + c + 3], d.w);
+            lsum[c + 0] += d.x * h0; lsum[c + 1] += d.y * h1;           // (lane-private slots: row after row, in order)
+            lsum[c + 2] += d.z * h2; lsum[c + 3] += d.w * h3;
+            lsum[C + c + 0] += d.x; lsum[C + c + 1] += d.y;
+            lsum[C + c + 2] += d.z; lsum[C + c + 3] += d.w;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -141,15 +143,16 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&ws[i], (double)lsum[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        sa_add(ws + (size_t)i * SA_W, ((double)lsum_all[i] + (double)lsum_all[2 * C + i]) + ((double)lsum_all[4 * C + i] + (double)lsum_all[6 * C + i]));
 }
 
-__global__ void layernorm_bwd_final_kernel(const double* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
+__global__ void layernorm_bwd_final_kernel(const unsigned long long* __restrict__ ws, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                            int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
-        dgamma[c] = (float)ws[c];
-        dbeta[c] = (float)ws[C + c];
+        dgamma[c] = (float)sa_load(ws + (size_t)c * SA_W);
+        dbeta[c] = (float)sa_load(ws + (size_t)(C + c) * SA_W);
     }
 }
 
@@ -206,18 +209,19 @@ extern "C" int bbdm_geglu_f32(const float* a, int lda, float* y, int ldy, long l
 
 // dx (overwritten; + dadd when given), dgamma, dbeta (overwritten) of bbdm_layernorm_f32.  ws: 2*C doubles of scratch.
 extern "C" int bbdm_layernorm_bwd_f32(const float* x, int ldx, const float* gamma, const float* dy, int lddy, const float* dadd,
-                                      int ldadd, float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long rows,
+                                      int ldadd, float* dx, int lddx, float* dgamma, float* dbeta, double* ws_, long long rows,
                                       int C, float eps, void* stream) {
-    BBDM_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws && rows > 0 && C > 0, "layernorm_bwd: bad args");
-    BBDM_REQUIRE(C % 4 == 0 && C <= 8192 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldx >= C && lddy >= C && lddx >= C &&
+    BBDM_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws_ && rows > 0 && C > 0 && ((uintptr_t)ws_ & 7) == 0, "layernorm_bwd: bad args");
+    unsigned long long* ws = reinterpret_cast<unsigned long long*>(ws_);         // [2][C][SA_W] limb cells (stats_acc.h)
+    BBDM_REQUIRE(C % 4 == 0 && C <= 2048 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ldx >= C && lddy >= C && lddx >= C &&
                      (!dadd || (ldadd % 4 == 0 && ldadd >= C)), "layernorm_bwd: C=%d ldx=%d lddy=%d lddx=%d", C, ldx, lddy, lddx);
     BBDM_REQUIRE((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)dadd) & 15) == 0,
                  "layernorm_bwd: 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
-    bbdm_zero_async(ws, sizeof(double) * 2 * C, st);
+    bbdm_zero_async(ws, 8 * (size_t)2 * C * SA_W, st);
     long long blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 2 * C, st, x, ldx, gamma, dy, lddy,
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), sizeof(float) * 8 * C, st, x, ldx, gamma, dy, lddy,
                        dadd, ldadd, dx, lddx, ws, rows, C, eps);
     hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, ws, dgamma, dbeta, C);
     BBDM_CHECK_LAUNCH("layernorm_bwd");

@@ -384,7 +384,9 @@ struct GnFold {
 // planes' 6) for the layers whose tile GEMM is HBM-bound (Cout = 128 at the 256^2 level: 10 B of operands per 256 FLOP) -- there
 // gemm_bf3.hip splits V under its own idle matrix pipe and both launches move a third fewer operand bytes.  Per transform point a wave
 // writes 8 tiles x 64 B; the other 16-channel chunks of the tile group run on the same XCD (see below) and complete the lines in its L2.
-template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false, bool F32 = false>
+// ST (round 5): the tile stride.  ST = 7 with MO = 6 is the input side of F(7x7, 2x2) (the phase filters of an up-sampling conv,
+// winograd_math.h): the same 8 x 8 window and B^T, windows 7 pixels apart (window rows 7 t - 1 .. 7 t + 6).
+template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false, bool F32 = false, int ST = MO>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
                                                                               unsigned char* __restrict__ Vp,
                                                                               const float* __restrict__ sc, const float* __restrict__ bi,
@@ -437,11 +439,11 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                 b2 = *reinterpret_cast<const float2*>(bi + (size_t)n * pre_ld + c);
             }
             const int Hs = UP ? H >> 1 : H, Ws = UP ? W >> 1 : W;
-            const int w = MO * tw - 1 + jj;
+            const int w = ST * tw - 1 + jj;
             const int wc = min(max(w, 0), W - 1);
             const int wsrc = UP ? wc >> 1 : wc;
             const float wmask = (w >= 0 && w < W) ? 1.f : 0.f;
-            const int h0 = MO * th - 1;
+            const int h0 = ST * th - 1;
             if (IDX64) {
 #pragma unroll
                 for (int i = 0; i < AL; ++i) {        // clamped addresses, out-of-image taps zeroed afterwards: the loads issue together
@@ -682,15 +684,17 @@ __global__ void __launch_bounds__(256) winograd_output6_kernel(const float* __re
 // ~50 VGPRs, 24 KB of LDS: four workgroups = 32 waves per CU.  Needs Cm % 128 == 0 (and Cout % 128 == 0 with the phase filters, so
 // that a channel block lies inside one phase); other shapes keep the one-thread-per-window kernels.  m = 4 / m = 2 (the latent
 // configurations) run the same code with 6 / 4 waves; `splits` partial sums of a split-K tile GEMM are added in order while loading.
-template <int MO, bool RES, int TPW>
-__global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(const float* __restrict__ M, size_t plane, int ldm, int splits,
+// MO = 7 (AL = 8, round 5): the output side of F(7x7, 2x2), phase filters only (ph != 0): 7 x 7 outputs per tile from the same 8 x 8
+// transform points (at_transform7); the outputs of phase (pa, pb) sit at x-grid rows 7 th + a - pa, columns 7 tw + b - pb.
+template <int MO, bool RES, int TPW, int AL = MO + 2>
+__global__ void __launch_bounds__(AL * 64) winograd_output_lds_kernel(const float* __restrict__ M, size_t plane, int ldm, int splits,
                                                                    const float* __restrict__ bias,
                                                                    const float* __restrict__ res, int ldr, int res_per_image,
                                                                    float* __restrict__ y, int ldy, int N, int H, int W, int Cout,
                                                                    int cblocks, long long T, const StatArgs st, int ph, int tpw) {
     // tpw tiles (TPW = 1: one; TPW = 2: any number; consecutive, same channel block) per workgroup, the intermediate double-buffered: the waves that finish phase B of a
     // tile early -- and the two that have no output row -- already load the next tile's columns
-    constexpr int AL = MO + 2, NT = AL * 64, NBUF = TPW > 1 ? 2 : 1;
+    constexpr int NT = AL * 64, NBUF = TPW > 1 ? 2 : 1;
     constexpr int GL = 33;                                       // groups a 128-channel block can touch (cpg >= 4, unaligned start)
     constexpr int TAB = MO * 2 * 2 * GL * 2;                     // statistics table (doubles), parked in the transform buffer at the end
     constexpr int XF = NBUF * MO * AL * 64;
@@ -698,7 +702,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cb = (int)(blockIdx.x % (unsigned)cblocks);
     const long long tile0 = (long long)(blockIdx.x / (unsigned)cblocks) * tpw;
-    const int TH = (H + MO - 1) / MO, TW = (W + MO - 1) / MO;
+    const int TH = wino_tdim(H, MO), TW = wino_tdim(W, MO);
     const int n0 = (int)(tile0 / ((long long)TH * TW));
     const int cm = cb * 128 + 2 * lane;                       // channel of M
     const int pq = ph ? cm / Cout : 0, c = cm - pq * Cout;    // phase filter, output channel
@@ -721,7 +725,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(cons
 #pragma unroll
                 for (int i = 0; i < AL; ++i)
                     v[i] = v[i] + load_nt(reinterpret_cast<const float2*>(m + ((size_t)z * (AL * AL) + i * AL) * plane));
-            at_transform<MO>(v, sj);
+            if constexpr (MO == 7) at_transform7(v, sj); else at_transform<MO>(v, sj);
 #pragma unroll
             for (int a = 0; a < MO; ++a) buf[(a * AL + j) * 64 + lane] = sj[a];
         }
@@ -734,8 +738,8 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(cons
             float2 t[AL], o[MO];
 #pragma unroll
             for (int j = 0; j < AL; ++j) t[j] = buf[(a * AL + j) * 64 + lane];
-            const int oh = MO * th + a;
-            if (oh < H) {
+            const int oh = MO == 7 ? MO * th + a - (pq >> 1) : MO * th + a;
+            if (oh < H && (MO != 7 || oh >= 0)) {
                 float2 rv[MO];
                 if (RES) {     // the residuals of the row are fetched together (clamped addresses for the masked edge pixels)
 #pragma unroll
@@ -747,12 +751,12 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_output_lds_kernel(cons
                         rv[b] = *reinterpret_cast<const float2*>(rp);
                     }
                 }
-                at_transform<MO>(t, o);
+                if constexpr (MO == 7) at_transform7(t, o); else at_transform<MO>(t, o);
                 double psum = 0.0, psq = 0.0;
 #pragma unroll
                 for (int b = 0; b < MO; ++b) {
-                    const int ow = MO * tw + b;
-                    if (ow < W) {
+                    const int ow = MO == 7 ? MO * tw + b - (pq & 1) : MO * tw + b;
+                    if (ow < W && (MO != 7 || ow >= 0)) {
                         float2 val = o[b] + b2;
                         if (RES) val = val + rv[b];
                         const size_t pix = ph ? (size_t)(n * 2 * H + 2 * oh + (pq >> 1)) * (2 * W) + 2 * ow + (pq & 1)
@@ -849,6 +853,39 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
             g_transform<MO>(a[r], u);
 #pragma unroll
             for (int s = 0; s < AL; ++s) p[(size_t)(r * AL + s) * per + idx] = u[s];
+        }
+    }
+}
+
+// F(7x7, 2x2) of the four phase filters (m = 7): w4 is bbdm_upsample_phase_weights_f32's [4 Cout][Cin][3][3] tensor, whose phase
+// (pa, pb) = o / Cout filter has its non-zero taps at rows pa, pa + 1 and columns pb, pb + 1: U = G g2 G^T with the 8 x 2 matrix G
+// (g_transform72), same packed layout, 64 planes.
+__global__ void winograd_weight72_kernel(const float* __restrict__ w4, float* __restrict__ p, int Cout4, int Cin, int CoutPad, int nchunks) {
+    const int Cout = Cout4 >> 2;
+    const size_t per = (size_t)nchunks * CoutPad * KC;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = idx % KC;
+        size_t t = idx / KC;
+        const int o = t % CoutPad;
+        const int chunk = t / CoutPad;
+        const int i = chunk * KC + k;
+        const int pq = o < Cout4 ? o / Cout : 0, pa = pq >> 1, pb = pq & 1;
+        float a[8][2];                    // a = G g2 (columns of g2 transformed)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float g[2], u[8];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) g[r] = (o < Cout4 && i < Cin) ? w4[((size_t)o * Cin + i) * 9 + (pa + r) * 3 + (pb + s)] : 0.f;
+            g_transform72(g, u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r][s] = u[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float u[8];
+            g_transform72(a[r], u);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) p[(size_t)(r * 8 + s) * per + idx] = u[s];
         }
     }
 }
@@ -960,15 +997,20 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
                                              int dgrad, void* stream) {
     // forward: conv Cin -> Cout, input tensor carries InPad >= Cin channels.
     // dgrad  : conv Cout -> Cin, its input (dY) carries InPad >= Cout channels.
-    BBDM_WINO_M(m);
+    // m = 7  : w_oihw = the [Cout = 4 C][Cin][3][3] phase filters bbdm_upsample_phase_weights_f32 wrote; packed = G g2 G^T of F(7x7, 2x2)
+    BBDM_WINO_M7(m);
     BBDM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && InPad % 4 == 0, "winograd_pack: bad args");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack: InPad too small");
+    BBDM_REQUIRE(m != 7 || (!dgrad && Cout % 4 == 0), "winograd_pack: m = 7 takes the 4 C phase filters of a forward conv");
     const int O = dgrad ? Cin : Cout;
     const int CoutPad = cdiv(O, 128) * 128, nchunks = cdiv(InPad, KC);
     const size_t per = (size_t)nchunks * CoutPad * KC;
     int blocks = (int)((per + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (m == 2)
+    if (m == 7)
+        hipLaunchKernelGGL(winograd_weight72_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin,
+                           CoutPad, nchunks);
+    else if (m == 2)
         hipLaunchKernelGGL(winograd_weight_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
                            Cin, CoutPad, nchunks, dgrad);
     else if (m == 4)
@@ -1009,7 +1051,7 @@ extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, vo
 }
 
 extern "C" size_t bbdm_winograd_tiles(int m, int N, int H, int W) {
-    return (m == 2 || m == 4 || m == 6) ? tiles_padded(N, H, W, m) : 0;
+    return (m == 2 || m == 4 || m == 6 || m == 7) ? tiles_padded(N, H, W, m) : 0;
 }
 
 extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int CinPad, int Cout) {
@@ -1100,7 +1142,8 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
                                  const GnFold* fold, bool f32out) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M7(m);
+    BBDM_REQUIRE(m != 7 || (!upsample && !Vt && !fold && !f32out), "winograd_input_bf3p: m = 7 (phase filters) takes x itself, planes only");
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "winograd_input_bf3p: upsample needs even H, W");
@@ -1125,9 +1168,20 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         const int idx64_env = bbdm_option(BBDM_OPT_WINO_IDX64);
         const bool idx64 = idx64_env || (unsigned long long)N * Hs * Ws * (unsigned long long)ldx >= (1ull << 32) ||
                            (unsigned long long)Ws * (unsigned long long)ldx >= (1ull << 24) || Hs >= (1 << 24);
-        const FastDiv dTW = fastdiv_make((unsigned)((W + m - 1) / m)), dTH = fastdiv_make((unsigned)((H + m - 1) / m)),
+        const FastDiv dTW = fastdiv_make((unsigned)wino_tdim(W, m)), dTH = fastdiv_make((unsigned)wino_tdim(H, m)),
                       dCH = fastdiv_make((unsigned)nchunks);
         const GnFold gn = fold ? *fold : GnFold{};
+        if (m == 7) {                     // F(7x7, 2x2): the m = 6 kernel with windows 7 pixels apart
+#define BBDM_WINO_INS2_7(PRE, I64)                                                                                                \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<6, PRE, false, false, I64, false, false, 7>), g, dim3(8 * 64), 0, st, x, ldx,   \
+                       (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr,  \
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn)
+            if (pre_scale) { if (idx64) BBDM_WINO_INS2_7(true, true); else BBDM_WINO_INS2_7(true, false); }
+            else           { if (idx64) BBDM_WINO_INS2_7(false, true); else BBDM_WINO_INS2_7(false, false); }
+#undef BBDM_WINO_INS2_7
+            BBDM_CHECK_LAUNCH("winograd_input_bf3p(m = 7)");
+            return BBDM_OK;
+        }
         if (fold) {                       // the kernel forms the coefficients (small problems; 32-bit indices, no transposed copy)
             BBDM_REQUIRE(!idx64 && !Vt, "winograd_input_bf3p_gn: tensor too large for the coefficient-folding variant");
 #define BBDM_WINO_INS2_G(MO)                                                                                                      \
@@ -1234,7 +1288,7 @@ extern "C" int bbdm_winograd_gemm_bf3p_splits(int m, int N, int H, int W, int Ci
 }
 extern "C" int bbdm_winograd_gemm_bf3p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
                                                   int CinPad, int Cout, int splits, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M7(m);
     BBDM_REQUIRE(Vp && b_planes && M && N > 0, "winograd_gemm_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     return bbdm_gemm_bf3p_splitk_f32(Vp, b_planes, M, Cout, planes(m), (long long)tiles_padded(N, H, W, m),
@@ -1252,8 +1306,10 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
                                                      float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stats0,
                                                      int cpg0, int coff0, void* stats1, int cpg1, int coff1, int splits,
                                                      void* stream) {
-    BBDM_WINO_M(m);
-    BBDM_REQUIRE(splits >= 1 && (splits == 1 || m != 6), "winograd_output: splits=%d (m = 6 layers are never split)", splits);
+    BBDM_WINO_M7(m);
+    BBDM_REQUIRE(splits >= 1 && (splits == 1 || m < 6), "winograd_output: splits=%d (m = 6 / 7 layers are never split)", splits);
+    BBDM_REQUIRE(m != 7 || ((flags & BBDM_CONV_OUT_PHASES) && Cout % 128 == 0),
+                 "winograd_output: m = 7 is the phase-filter form (BBDM_CONV_OUT_PHASES, Cout %% 128 == 0)");
     BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldo % 4 == 0 && ldo >= Cout, "winograd_output: Cout=%d ldo=%d", Cout, ldo);
@@ -1302,9 +1358,20 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
             if (tpw > 8) tpw = 8;
             while (tpw > 2 && ((long long)((T + tpw - 1) / tpw) * (Cm / 128) < 2048)) --tpw;
         }
-        const long long per_image = (long long)((H + m - 1) / m) * ((W + m - 1) / m);
+        const long long per_image = (long long)wino_tdim(H, m) * wino_tdim(W, m);
         if (tpw > per_image) tpw = (int)per_image;
         if (tpw < 1) tpw = 1;
+        if (m == 7) {
+            if (tpw == 1)
+                hipLaunchKernelGGL((winograd_output_lds_kernel<7, false, 1, 8>), dim3((unsigned)(T * (size_t)(Cm / 128))), dim3(512), 0, s_, M,
+                                   Tp * (size_t)Cm, Cm, 1, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, Cm / 128, (long long)T, st, ph, 1);
+            else
+                hipLaunchKernelGGL((winograd_output_lds_kernel<7, false, 2, 8>), dim3((unsigned)(((T + tpw - 1) / tpw) * (size_t)(Cm / 128))),
+                                   dim3(512), 0, s_, M, Tp * (size_t)Cm, Cm, 1, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, Cm / 128,
+                                   (long long)T, st, ph, tpw);
+            BBDM_CHECK_LAUNCH("winograd_output(m = 7)");
+            return BBDM_OK;
+        }
 #define BBDM_WINO_OUT(MO_, RES_, TPW_)                                                                                              \
     hipLaunchKernelGGL((winograd_output_lds_kernel<MO_, RES_, TPW_>), dim3((unsigned)(((T + tpw - 1) / tpw) * (size_t)(Cm / 128))), \
                        dim3((MO_ + 2) * 64), 0, s_, M, Tp * (size_t)Cm, Cm, splits, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, \
@@ -1320,6 +1387,7 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
         BBDM_CHECK_LAUNCH("winograd_output");
         return BBDM_OK;
     }
+    BBDM_REQUIRE(m != 7, "winograd_output: m = 7 launch too large for the two-phase kernel");
     if (m == 6 && residual)
         hipLaunchKernelGGL(winograd_output6_kernel<true>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out,
                            ldo, N, H, W, Cout, (int)iters, st, ph);
@@ -1395,8 +1463,27 @@ extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int l
 // test-suite can check the hand-factored formulas against the transform matrices (tests/test_winograd_math_cpu.py).
 // which: 0 = B^T (m+2 -> m+2), 1 = A^T (m+2 -> m), 2 = G (3 -> m+2), 3 = A (m -> m+2), 4 = G^T (m+2 -> 3).
 extern "C" int bbdm_debug_winograd_transform_1d(int m, int which, const float* in, float* out) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M7(m);
     BBDM_REQUIRE(in && out && which >= 0 && which <= 4, "winograd_transform_1d: bad args");
+    if (m == 7) {                      // F(7x7, 2x2): B^T is m = 6's (8 -> 8), A^T 8 -> 7, G 2 -> 8
+        BBDM_REQUIRE(which <= 2, "winograd_transform_1d: m = 7 has no weight-gradient side");
+        if (which == 0) {
+            float d[8], t[8];
+            for (int i = 0; i < 8; ++i) d[i] = in[i];
+            bt_transform<6>(d, t);
+            for (int i = 0; i < 8; ++i) out[i] = t[i];
+        } else if (which == 1) {
+            float v[8], r[7];
+            for (int i = 0; i < 8; ++i) v[i] = in[i];
+            at_transform7(v, r);
+            for (int i = 0; i < 7; ++i) out[i] = r[i];
+        } else {
+            float g[2] = {in[0], in[1]}, u[8];
+            g_transform72(g, u);
+            for (int i = 0; i < 8; ++i) out[i] = u[i];
+        }
+        return BBDM_OK;
+    }
 #define BBDM_WINO_1D(MO)                                                             \
     do {                                                                             \
         if (which == 0) {                                                            \

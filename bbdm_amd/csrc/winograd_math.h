@@ -67,6 +67,32 @@ __host__ __device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&
         s[5] = m12 + 32.f * m34 + 0.03125f * m56 + m[7];
     }
 }
+// ---- F(7x7, 2x2) on the SAME eight points (round 5): a 2-tap filter needs m + 1 points, so the 8-point transform yields 7 outputs
+// per tile instead of 6.  B^T depends on the points only: bt_transform<6> serves both; G (8 x 2) and A^T (7 x 8) are below.  Used for
+// the four phase filters of conv3x3(nearest x2 (x)) (csrc/winograd.hip: each phase reads 2 x 2 pixels of x): 64 / 49 = 1.31
+// multiplies per output instead of 64 / 36 = 1.78.  y[o] = g[0] d[o] + g[1] d[o + 1], o = 0 .. 6.
+template <typename T>
+__host__ __device__ __forceinline__ void at_transform7(const T (&m)[8], T (&s)[7]) {
+    const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4], p56 = m[5] + m[6], m56 = m[5] - m[6];
+    s[0] = m[0] + p12 + p34 + p56;
+    s[1] = m12 + 2.f * m34 + 0.5f * m56;
+    s[2] = p12 + 4.f * p34 + 0.25f * p56;
+    s[3] = m12 + 8.f * m34 + 0.125f * m56;
+    s[4] = p12 + 16.f * p34 + 0.0625f * p56;
+    s[5] = m12 + 32.f * m34 + 0.03125f * m56;
+    s[6] = p12 + 64.f * p34 + 0.015625f * p56 + m[7];
+}
+__host__ __device__ __forceinline__ void g_transform72(const float (&g)[2], float (&u)[8]) {
+    u[0] = g[0];
+    u[1] = (-2.f / 9.f) * (g[0] + g[1]);
+    u[2] = (-2.f / 9.f) * (g[0] - g[1]);
+    u[3] = (1.f / 90.f) * g[0] + (1.f / 45.f) * g[1];
+    u[4] = (1.f / 90.f) * g[0] - (1.f / 45.f) * g[1];
+    u[5] = (32.f / 45.f) * g[0] + (16.f / 45.f) * g[1];
+    u[6] = (32.f / 45.f) * g[0] - (16.f / 45.f) * g[1];
+    u[7] = g[1];
+}
+
 // u = G g
 template <int MO>
 __host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
@@ -146,16 +172,22 @@ __host__ __device__ __forceinline__ void gt_transform(const float (&u)[MO + 2], 
     }
 }
 
-inline size_t wino_tiles_raw(int N, int H, int W, int m) { return (size_t)N * cdiv(H, m) * cdiv(W, m); }
+// tiles along one axis.  m = 7 (the phase-filter form, F(7x7, 2x2)): tile t covers the window rows 7 t - 1 .. 7 t + 6 of x; phase 0
+// takes its 7 outputs at rows 7 t .. 7 t + 6, phase 1 at rows 7 t - 1 .. 7 t + 5 -- row H - 1 of phase 1 needs 7 t + 5 >= H - 1.
+__host__ __device__ inline int wino_tdim(int H, int m) { return m == 7 ? (H + 7) / 7 : (H + m - 1) / m; }
+inline size_t wino_tiles_raw(int N, int H, int W, int m) { return (size_t)N * wino_tdim(H, m) * wino_tdim(W, m); }
 inline size_t wino_tiles_padded(int N, int H, int W, int m) {
     return (wino_tiles_raw(N, H, W, m) + 255) / 256 * 256;      // whole 8x32 GEMM tiles
 }
-inline int wino_planes(int m) { return (m + 2) * (m + 2); }
+inline int wino_planes(int m) { return m == 7 ? 64 : (m + 2) * (m + 2); }
 
 }  // namespace
 
 #define BBDM_WINO_M(m) \
     BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6, "winograd: output tile m=%d unsupported (2, 4 or 6)", (m))
+// ... entry points of the phase-filter form also take m = 7 = F(7x7, 2x2) on the 8-point transform (see wino_tdim)
+#define BBDM_WINO_M7(m) \
+    BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6 || (m) == 7, "winograd: output tile m=%d unsupported (2, 4, 6 or 7)", (m))
 #define BBDM_WINO_HW(m, H, W)                                                                                          \
-    BBDM_REQUIRE((H) > 0 && (W) > 0 && ((m) == 6 || ((H) % (m) == 0 && (W) % (m) == 0)),                                \
+    BBDM_REQUIRE((H) > 0 && (W) > 0 && ((m) >= 6 || ((H) % (m) == 0 && (W) % (m) == 0)),                                \
                  "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)

@@ -502,7 +502,7 @@ extern "C" size_t bbdm_winograd_wgrad_workspace_floats(int m, int N, int H, int 
     if ((m != 2 && m != 4 && m != 6) || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
     const size_t P = wino_planes(m), Tp = wino_tiles_padded(N, H, W, m);
     const TnGeom g = tn_geom((int)P, (long long)wino_tiles_raw(N, H, W, m), Cin, Cout);
-    return P * Tp * ((size_t)Cin + Cout) + (size_t)g.splits * P * Cin * Cout + 2 * (size_t)Cout + 2;
+    return P * Tp * ((size_t)Cin + Cout) + (size_t)g.splits * P * Cin * Cout + 8 * (size_t)Cout + 2;      // (+ the colsum's limb cells)
 }
 
 // dW (OIHW, overwritten) and, when dbias != NULL, db of y = conv3x3(x, w) + b from x [N,H,W,Cin] (pitch ldx) and

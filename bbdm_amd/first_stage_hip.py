@@ -56,6 +56,7 @@ class _Flags:
         self.conv1x1_small = os.environ.get("BBDM_CONV1X1_SMALL", "1") != "0"
         self.gn_in_transform = int(os.environ.get("BBDM_GN_IN_TRANSFORM", "1024"))
         self.fp32_v_max_cout = 128
+        self.upsample_f72 = True
         self.winograd_wgrad = 0             # (inference plans only)
         self.hip_graph = False
         self.op_profile = None

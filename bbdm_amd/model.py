@@ -163,7 +163,7 @@ class BrownianBridgeModel(nn.Module):
     def _loss(self, a, b):
         _need_gpu(a, b)
         a, b = _f32c(a), _f32c(b)
-        partial_ = torch.zeros(1, dtype=torch.float64, device=a.device)
+        partial_ = torch.zeros(4, dtype=torch.float64, device=a.device)       # one exact limb cell (csrc/stats_acc.h)
         out = torch.empty(1, dtype=torch.float32, device=a.device)
         _launch(a, "bbdm_bb_loss_f32", a.data_ptr(), b.data_ptr(), partial_.data_ptr(), out.data_ptr(), a.numel(),
                   _LOSSES[self.loss_type])

@@ -464,10 +464,10 @@ class _PackedWinograd:
         self.fused_planes = bf3 == "p" and not phases and in_pad % 16 == 0
         self.packed_f32 = None if self.fused_planes else torch.empty(n, dtype=torch.float32, device=weight.device)
         if bf3 == "p":
-            self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes((m + 2) ** 2, in_pad, self.out_ch), dtype=torch.uint8,
+            self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(wino_planes(m), in_pad, self.out_ch), dtype=torch.uint8,
                                       device=weight.device)
         elif bf3:
-            nh = lib.bbdm_gemm_bf3_packed_halfs((m + 2) ** 2, in_pad, self.out_ch)
+            nh = lib.bbdm_gemm_bf3_packed_halfs(wino_planes(m), in_pad, self.out_ch)
             self.packed = torch.empty(nh, dtype=torch.int16, device=weight.device)
         else:
             self.packed = self.packed_f32
@@ -495,8 +495,31 @@ class _PackedWinograd:
                           self.in_pad, 1 if self.dgrad else 0, stream)
             if self.bf3:
                 _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.bf3 == "p" else "bbdm_gemm_bf3_pack_f32",
-                          self.packed_f32.data_ptr(), self.packed.data_ptr(), (self.m + 2) ** 2, self.in_pad, self.out_ch, stream)
+                          self.packed_f32.data_ptr(), self.packed.data_ptr(), wino_planes(self.m), self.in_pad, self.out_ch, stream)
             self.key = key
+
+
+def wino_planes(m: int) -> int:
+    """Transform points of Winograd tile ``m``: (m + 2)^2 for F(m x m, 3x3); m = 7 is F(7x7, 2x2) on the 8-point transform."""
+    return 64 if m == 7 else (m + 2) ** 2
+
+
+def wino_tiles(m: int, N: int, H: int, W: int) -> int:
+    """Real (unpadded) tiles of an [N, H, W] image (csrc/winograd_math.h: wino_tdim)."""
+    if m == 7:
+        return N * ((H + 7) // 7) * ((W + 7) // 7)
+    return N * -(-H // m) * -(-W // m)
+
+
+def phase_filter_tile(N: int, H: int, W: int, cin: int, cout4: int, max_m: int, small: bool, f72: bool = True) -> int:
+    """Winograd tile for conv3x3(nearest x2 (x)) run as four phase filters on x [N, H, W] (Cin -> cout4 = 4 Cout).  Each phase filter
+    reads 2 x 2 pixels of x, so where the layer earns the 8-point transform it runs as F(7x7, 2x2) -- 49 outputs per 64 multiplies
+    instead of 36 (round 5: -17 % tile GEMM work at 64^2, -25 % at 128^2 incl. the edge tiles) -- as long as the coarser tile grid does
+    not eat the gain and the output transform's 128-channel blocks lie inside one phase."""
+    wl = winograd_tile(N, H, W, cin, cout4, max_m, small=small)
+    if f72 and wl == 6 and (cout4 // 4) % 128 == 0 and cin % 16 == 0 and wino_tiles(7, N, H, W) <= 0.9 * wino_tiles(6, N, H, W):
+        return 7
+    return wl
 
 
 def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True) -> int:
@@ -709,6 +732,9 @@ class UNetModel(nn.Module):
         # of the planes' 6; gemm_bf3.hip splits them under its idle matrix pipe): a third fewer operand bytes in both the input
         # transform and the GEMM (round 5).  0 = planes everywhere.
         self.fp32_v_max_cout: int = 128
+        # inference: the four phase filters of an up-sampling conv as 2 x 2 filters, F(7x7, 2x2) on the 8-point transform, where the
+        # layer would take F(6x6, 3x3) (see phase_filter_tile); False = F(6x6, 3x3) on the zero-padded 3 x 3 phase filters (A/B)
+        self.upsample_f72: bool = True
         # Training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
         # BBDM_WINOGRAD_WGRAD=0: the direct kernel (conv_wgrad.hip) everywhere.
         self.winograd_wgrad: int = int(os.environ.get("BBDM_WINOGRAD_WGRAD", "6"))
@@ -771,7 +797,8 @@ class UNetModel(nn.Module):
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small, self.upsample_phases, self.conv1x1_pipe, self.conv1x1_small, self.gn_in_transform)
+               self.winograd_small, self.upsample_phases, self.conv1x1_pipe, self.conv1x1_small, self.gn_in_transform,
+               self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -988,7 +1015,7 @@ class _Plan:
         if name == "bbdm_winograd_gemm_f32":        # the (m+2)^2 GEMMs actually executed: 2 (m+2)^2 tiles Cin Cout
             wm, N, H, W, cin_pad, cout = args[0], *args[4:9]
             cin = args[2].t.cin_true if hasattr(args[2].t, "cin_true") else cin_pad
-            return 2.0 * (wm + 2) ** 2 * N * -(-H // wm) * -(-W // wm) * cin * cout
+            return 2.0 * wino_planes(wm) * wino_tiles(wm, N, H, W) * cin * cout
         if name == "bbdm_attention_f32":
             N, T, heads, ch = args[5:9]
             return 2.0 * 2.0 * N * heads * T * T * ch
@@ -998,7 +1025,7 @@ class _Plan:
             return 2.0 * N * H * W * cout * cin * ks * ks
         if name == "bbdm_conv3x3_winograd_wgrad_f32":   # the (m+2)^2 TN GEMMs actually executed
             wm, (N, H, W, cin, cout) = args[0], args[8:13]
-            return 2.0 * (wm + 2) ** 2 * N * -(-H // wm) * -(-W // wm) * cin * cout
+            return 2.0 * wino_planes(wm) * wino_tiles(wm, N, H, W) * cin * cout
         if name == "bbdm_gemm_tn_batched_f32":          # (the Winograd-domain weight gradient on a V kept by the forward)
             batch, K, M, Nn = args[7:11]
             return 2.0 * batch * K * M * Nn
@@ -1170,8 +1197,10 @@ class _Plan:
         small = bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)
         cands = [(wm, H, W, cout)]
         if up == 2 and m.upsample_phases:         # conv3x3(nearest x2 (x)) may run as four phase filters on x itself
-            wl = winograd_tile(self.N, x.H, x.W, x.C, 4 * cout, m.winograd, small=small)
+            wl = phase_filter_tile(self.N, x.H, x.W, x.C, 4 * cout, m.winograd, small, m.upsample_f72 and not self.training)
             if wl >= wm:
+                if wl == 7:
+                    return False                  # (F(7x7, 2x2): large layers only, no coefficient-folding input transform)
                 cands = [(wl, x.H, x.W, 4 * cout)]
         for w_, h_, ww_, co_ in cands:
             if self._use_bf3(w_, h_, ww_, x.C, co_) != "p" or self.lib.bbdm_winograd_tiles(w_, self.N, h_, ww_) > m.gn_in_transform:
@@ -1204,7 +1233,7 @@ class _Plan:
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
-        if (not self.training and cout <= self.m.fp32_v_max_cout and (wm + 2) ** 2 * tiles * cin_pad * 6 >= (512 << 20)
+        if (not self.training and cout <= self.m.fp32_v_max_cout and wino_planes(wm) * tiles * cin_pad * 6 >= (512 << 20)
                 and self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout)):
             return True         # HBM-bound tile GEMM: fp32 V (see UNetModel.fp32_v_max_cout)
         if self.m.gemm_bf3p and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout) and \
@@ -1228,24 +1257,24 @@ class _Plan:
             flags |= 8
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
-        self._wino_v_need = max(self._wino_v_need, (wm + 2) ** 2 * tiles * cin_pad * (3 if split else 2) // 2)
+        self._wino_v_need = max(self._wino_v_need, wino_planes(wm) * tiles * cin_pad * (3 if split else 2) // 2)
         # small layers: split-K tile GEMMs, the partial sums M[z] are added by the output transform (csrc/gemm_bf3p.hip: fwd_splits)
         ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if (split and not pw.phases) else 1
-        self._wino_m_need = max(self._wino_m_need, ksplit * (wm + 2) ** 2 * tiles * cout)
+        self._wino_m_need = max(self._wino_m_need, ksplit * wino_planes(wm) * tiles * cout)
         vbuf = self._wino_v
         keeps = self._keeps_V(wm, H, W, cin_pad, pw.cin, cout, upsample, bwd)
         if keeps and not split:
             # training: this layer's weight gradient contracts the SAME transformed input (csrc/winograd_wgrad.hip) -- keep V
             # in a buffer of its own instead of re-running the input transform in the backward pass (memory: (m+2)^2/m^2 x
             # the activation, ~8 GB over the LBBDM-f4 UNet at batch 32, of the 288 GB)
-            b = _Buf((wm + 2) ** 2 * tiles * cin_pad)
+            b = _Buf(wino_planes(wm) * tiles * cin_pad)
             self.bufs.append(b)
             vbuf = _View(b, 0, cin_pad, 1, 1, 1, cin_pad)
             self._saved_V[id(pw.weight)] = (vbuf, wm)
         if keeps and split:
             # ... as bf16 planes: the forward GEMM reads the shared scratch copy, the weight gradient the TRANSPOSED copy (rows =
             # channels, contraction index = tiles) that the same input-transform launch writes -- 6 B per element kept
-            vt = _TensorRef(torch.empty(self.lib.bbdm_gemm_bf3p_tn_at_bytes((wm + 2) ** 2, tiles, cin_pad), dtype=torch.uint8,
+            vt = _TensorRef(torch.empty(self.lib.bbdm_gemm_bf3p_tn_at_bytes(wino_planes(wm), tiles, cin_pad), dtype=torch.uint8,
                                         device=self.device))
             self._saved_V[id(pw.weight)] = (vt, wm, "tr")
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_tr_f32"), wm, x, x.ld, vbuf,
@@ -1292,8 +1321,11 @@ class _Plan:
         if wm and upsample and self.m.upsample_phases and residual is None and flags == 0 and mod.weight.shape[1] == x.C:
             # conv3x3(nearest x2 (x)) = four phase filters on x (Cin -> 4 Cout): same GEMM work, the input transform and the GEMM's
             # A operand shrink 4x -- taken where x's own tile grid earns the same Winograd tile as the upsampled one
-            wl = winograd_tile(self.N, x.H, x.W, x.C, 4 * cout, self.m.winograd,
-                               small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small))
+            wl = phase_filter_tile(self.N, x.H, x.W, x.C, 4 * cout, self.m.winograd,
+                                   bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small),
+                                   self.m.upsample_f72 and not self.training)
+            if wl == 7 and self._use_bf3(7, x.H, x.W, x.C, 4 * cout) != "p":
+                wl = 6                            # (F(7x7, 2x2) exists on the pre-split planes only)
             if wl >= wm:
                 pw = self._packed(_PackedWinograd, mod.weight, mod.bias, x.C, wl, bf3=self._use_bf3(wl, x.H, x.W, x.C, 4 * cout),
                                   phases=True)
@@ -1632,14 +1664,14 @@ class _Plan:
             if saved is not None and saved[1] == wgm and len(saved) > 2:
                 # the forward kept the TRANSPOSED bf16 planes of V: dY transform (transposed planes of dM + the fp32 plane (1, 1)) ->
                 # the bf16x3 GEMM with the tiles as its K loop -> finish (csrc/gemm_bf3p.hip: bbdm_gemm_bf3p_tn_f32)
-                P, Tp = (wgm + 2) ** 2, lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
-                T = N * -(-x_in.H // wgm) * -(-x_in.W // wgm)
+                P, Tp = wino_planes(wgm), lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
+                T = wino_tiles(wgm, N, x_in.H, x_in.W)
                 splits = lib.bbdm_gemm_bf3p_tn_splits(P, Tp, x_in.C, cout)
                 n_dmt = (lib.bbdm_gemm_bf3p_tn_bt_bytes(P, Tp, cout) + 3) // 4          # floats
                 o_dm11 = n_dmt
                 o_du = o_dm11 + Tp * cout
                 o_acc = (o_du + splits * P * x_in.C * cout + 1) & ~1
-                ws_floats[0] = max(ws_floats[0], o_acc + 2 * cout + 2)
+                ws_floats[0] = max(ws_floats[0], o_acc + 8 * cout + 2)        # (+ the column sums' limb cells: 4 x 8 B per channel)
                 dMt, dm11, dU = _TensorRef(self._ws_f, 0), _TensorRef(self._ws_f, 4 * o_dm11), _TensorRef(self._ws_f, 4 * o_du)
                 self._bop("bbdm_winograd_dy_transform_bf3p_f32", wgm, dy, dy.ld, dMt, dm11, N, x_in.H, x_in.W, cout)
                 self._bop("bbdm_gemm_bf3p_tn_f32", saved[0], dMt, dU, P, Tp, x_in.C, cout)
@@ -1652,12 +1684,12 @@ class _Plan:
                         self._bop("bbdm_colsum_f32", dm11, cout, _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
             elif saved is not None and saved[1] == wgm:
                 # the forward kept this layer's V: dY transform -> TN GEMM -> finish (the stages bbdm_conv3x3_winograd_wgrad_f32 chains)
-                P, Tp = (wgm + 2) ** 2, lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
-                T = N * -(-x_in.H // wgm) * -(-x_in.W // wgm)
+                P, Tp = wino_planes(wgm), lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
+                T = wino_tiles(wgm, N, x_in.H, x_in.W)
                 splits = lib.bbdm_gemm_tn_splits(P, T, x_in.C, cout)
                 o_du = P * Tp * cout
                 o_acc = (o_du + splits * P * x_in.C * cout + 1) & ~1
-                ws_floats[0] = max(ws_floats[0], o_acc + 2 * cout + 2)
+                ws_floats[0] = max(ws_floats[0], o_acc + 8 * cout + 2)        # (+ the column sums' limb cells: 4 x 8 B per channel)
                 dM, dU = _TensorRef(self._ws_f, 0), _TensorRef(self._ws_f, 4 * o_du)
                 self._bop("bbdm_winograd_dy_transform_f32", wgm, dy, dy.ld, dM, N, x_in.H, x_in.W, cout)
                 self._bop("bbdm_gemm_tn_batched_f32", saved[0], x_in.C, Tp * x_in.C, dM, cout, Tp * cout, dU, P, T, x_in.C, cout)
@@ -1749,7 +1781,7 @@ class _Plan:
                     gn_bwd(rb.out_layers[0], h1, s2, self.film_off[id(rb)], da2, None, 1, 0, dh1, 0)
                 else:           # d emb_out[n, c] = sum_hw d(h + emb_out)
                     gn_bwd(rb.out_layers[0], h1, s2, None, da2, None, 1, 0, dh1, 0)
-                    colsum_c[0] = max(colsum_c[0], N * h1.C)
+                    colsum_c[0] = max(colsum_c[0], 4 * N * h1.C)        # limb cells (csrc/stats_acc.h): 4 words per sum
                     self._bop("bbdm_colsum_batched_f32", dh1, dh1.ld, self._ws_d,
                               _TensorRef(self.dfilm, 4 * self.film_off[id(rb)]), self.film_total, N, h1.H * h1.W, h1.C)
                 da = conv_bwd(rb.in_layers[2], a, dh1, True, "DA")
@@ -1788,7 +1820,7 @@ class _Plan:
                               acc, None, None, None, 0, None, src.N, src.H, src.W, src.C, 1, 0.0, 0, 0)
 
                 def ln_bwd(ln_mod, xin: _View, dy: _View, dadd: _View) -> _View:
-                    ws_doubles[0] = max(ws_doubles[0], 2 * xin.C)
+                    ws_doubles[0] = max(ws_doubles[0], 8 * xin.C)      # [2][C] limb cells of 4 words
                     dxv = next_dh()
                     self._bop("bbdm_layernorm_bwd_f32", xin, xin.ld, self._pref(ln_mod.weight), dy, dy.ld, dadd, dadd.ld, dxv,
                               dxv.ld, gref(ln_mod.weight), gref(ln_mod.bias), self._ws_d2, rows, xin.C, float(ln_mod.eps))

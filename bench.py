@@ -605,7 +605,9 @@ def run_workload(args, env):
                 elif name == "bbdm_conv2d_nhwc_f32":
                     shp = "N{} {}x{} {}->{} k{}".format(*oargs[15:21])
                 elif name == "bbdm_winograd_gemm_f32":
-                    shp = "N{} {}x{} {}->{} F({m}x{m},3x3) {p} GEMMs".format(*oargs[4:9], m=oargs[0], p=(oargs[0] + 2) ** 2)
+                    from bbdm_amd.unet import wino_planes
+                    shp = "N{} {}x{} {}->{} F({m}x{m},{r}x{r}) {p} GEMMs".format(*oargs[4:9], m=oargs[0], r=2 if oargs[0] == 7 else 3,
+                                                                                 p=wino_planes(oargs[0]))
                 elif name == "bbdm_winograd_input_f32":
                     shp = "F{} N{} {}x{} C{} up{} fusedGN{}".format(oargs[0], oargs[9], oargs[10], oargs[11], oargs[12],
                                                                     oargs[8], int(oargs[4] is not None))
@@ -729,7 +731,8 @@ def run_workload(args, env):
     for nm, oa in plan0.ops:
         if nm == "bbdm_winograd_gemm_f32":
             wm, gN, gH, gW, gci, gco = oa[0], *oa[4:9]
-            P, T = (wm + 2) ** 2, gN * -(-gH // wm) * -(-gW // wm)
+            from bbdm_amd.unet import wino_planes, wino_tiles
+            P, T = wino_planes(wm), wino_tiles(wm, gN, gH, gW)
             a_bytes = 6.0 if getattr(nm, "entry", "").endswith("bf3p_f32") else 4.0     # V as three bf16 planes / fp32
             alg_bytes += P * T * (a_bytes * gci + 4.0 * gco) + (6.0 if use_bf3 else 4.0) * P * gci * gco
             alg_n += 1

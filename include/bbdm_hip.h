@@ -188,10 +188,11 @@ int bbdm_gemm_tn_batched_f32(const float* A, int lda, size_t a_stride, const flo
 int bbdm_winograd_wgrad_finish_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, void* stream);
 int bbdm_winograd_wgrad_finish_bias_f32(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, const float* dm11,
                                         long long T, float* dbias, void* stream);
-/* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: fp64[C] scratch. */
+/* Column sums out[c] = sum_m dy[m][c] (bias gradients, per-channel reductions).  acc: 4 * C 8-byte words of scratch (exact
+ * integer-limb cells, csrc/stats_acc.h: the sums do not depend on the order in which workgroups finish -- ABI 21). */
 int bbdm_colsum_f32(const float* dy, int ld, double* acc, float* out, long long M, int C, void* stream);
 /* Per-image column sums out[n*ldo + c] = sum_{m < M} dy[(n*M + m)*ld + c] (gradient of a per-image broadcast add).
- * acc: fp64[N*C] scratch. */
+ * acc: 4 * N * C 8-byte words of scratch (limb cells, as above). */
 int bbdm_colsum_batched_f32(const float* dy, int ld, double* acc, float* out, int ldo, int N, long long M, int C,
                             void* stream);
 
@@ -285,7 +286,8 @@ int bbdm_bb_p_sample_step_f32(const float* x_t, const float* y, const float* pre
 int bbdm_bb_predict_x0_f32(const float* x_t, const float* y, const float* pred, const int64_t* t,
                            const float* m_t, const float* variance_t, float* x0_recon,
                            int N, int per_sample, int objective, void* stream);
-/* loss (BBM.py:114-117): loss_type 0 'l1' mean|a-b|, 1 'l2' mean (a-b)^2.  partial: fp64[1] zeroed by caller;
+/* loss (BBM.py:114-117): loss_type 0 'l1' mean|a-b|, 1 'l2' mean (a-b)^2.  partial: 4 x 8 bytes zeroed by the caller (one exact
+ * integer-limb cell, csrc/stats_acc.h: bitwise reproducible whatever the block order -- ABI 21);
  * out[0] = float(partial / count) is written by a tail kernel on the same stream. */
 int bbdm_bb_loss_f32(const float* a, const float* b, double* partial, float* out, size_t count, int loss_type,
                      void* stream);
@@ -351,7 +353,7 @@ int bbdm_layernorm_f32(const float* x, int ldx, const float* gamma, const float*
 /* GEGLU (attention.py:38-46): y[r][c] = a[r][c] * gelu(a[r][inner + c]), exact (erf) GELU; a = proj(x) with 2*inner columns. */
 int bbdm_geglu_f32(const float* a, int lda, float* y, int ldy, long long rows, int inner, void* stream);
 /* Their gradients (training through SpatialTransformer blocks).  layernorm_bwd: dx = d/dx of the LayerNorm (+ dadd when given:
- * the residual branch of BasicTransformerBlock, attention.py:215-218), dgamma / dbeta overwritten; ws: 2*C doubles.
+ * the residual branch of BasicTransformerBlock, attention.py:215-218), dgamma / dbeta overwritten; ws: 8*C 8-byte words ([2][C] limb cells, C <= 2048).
  * geglu_bwd: da[rows][2*inner] from the forward input a and dy[rows][inner]. */
 int bbdm_layernorm_bwd_f32(const float* x, int ldx, const float* gamma, const float* dy, int lddy, const float* dadd, int ldadd,
                            float* dx, int lddx, float* dgamma, float* dbeta, double* ws, long long rows, int C, float eps,

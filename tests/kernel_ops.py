@@ -368,7 +368,7 @@ def colsum(dy: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
     ld = dy.shape[-1]
     C = C or ld
     M = dy.numel() // ld
-    acc = torch.empty(C, dtype=torch.float64, device=dy.device)
+    acc = torch.empty(4 * C, dtype=torch.float64, device=dy.device)       # limb cells
     out = torch.empty(C, dtype=torch.float32, device=dy.device)
     _lib.call("bbdm_colsum_f32", dy.data_ptr(), ld, acc.data_ptr(), out.data_ptr(), M, C, _st(dy))
     return out
@@ -514,7 +514,7 @@ def layernorm_bwd(x, gamma, dy, eps: float = 1e-5, dadd=None):
     dx = torch.empty_like(x)
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+    ws = torch.empty(8 * C, dtype=torch.float64, device=x.device)       # [2][C] limb cells
     _lib.call("bbdm_layernorm_bwd_f32", x.data_ptr(), C, gamma.data_ptr(), dy.data_ptr(), C,
               None if dadd is None else dadd.data_ptr(), C, dx.data_ptr(), C, dg.data_ptr(), db.data_ptr(), ws.data_ptr(), rows, C,
               eps, _st(x))

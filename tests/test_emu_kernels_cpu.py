@@ -71,7 +71,8 @@ def test_gemm_bf3p_kernel_variants(kernel, batch, T, Cin, Cout):
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout,pre", [(6, 1, 7, 11, 16, 40, 1), (4, 1, 8, 8, 16, 32, 0), (2, 2, 4, 6, 16, 8, 1),
-                                                  (6, 1, 7, 11, 16, 128, 1)])
+                                                  (6, 1, 7, 11, 16, 128, 1), (7, 1, 7, 11, 16, 128, 1), (7, 2, 6, 13, 16, 128, 0),
+                                                  (7, 1, 14, 8, 32, 128, 1)])
 def test_upsample_conv_as_phase_filters(m, N, H, W, Cin, Cout, pre):
     K.test_upsample_conv_as_phase_filters(CPU, m, N, H, W, Cin, Cout, pre)
 

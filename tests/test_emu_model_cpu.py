@@ -248,3 +248,22 @@ def test_sampling_under_inference_mode(monkeypatch):
     """tests/test_model_gpu.py's inference-mode sampling check (tensors without a version counter) on the emulated kernels."""
     monkeypatch.setattr(M, "build", lambda rec, dev: _build(rec))
     M.test_sampling_under_inference_mode(CPU)
+
+
+@pytest.mark.parametrize("name", ["tiny_nocond", "tiny_xattn"])
+def test_training_step_is_bitwise_reproducible(name):
+    """Two training micro-steps from the same state give the same bits in the loss and every gradient (emulated kernels: the fibers of
+    a block run in a fixed order, so this checks the plumbing of the limb accumulators -- buffer sizes, zeroing, the fold -- not the
+    order-independence itself, which the -m gpu test of the same name covers)."""
+    rec = load_case(name)
+    m = _build(rec, train=True)
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"]
+    runs = []
+    for rep in range(2):
+        for p in m.parameters():
+            p.grad = None
+        loss, _ = m.p_losses(rec["x0"], rec["y"], ctx, rec["t"], rec["noise"])
+        loss.backward()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert all(torch.equal(g, runs[1][1][k]) for k, g in runs[0][1].items())

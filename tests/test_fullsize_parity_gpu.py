@@ -265,13 +265,14 @@ def test_c4_benchmarked_training_plan_batch32(dev):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("workload", ["c3", "c5"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c5"])
 def test_step_is_bitwise_reproducible(dev, workload):
     """The reference seeds everything and sets cudnn.deterministic (main.py:57-65): a sampling step must give the SAME BITS for the same
     inputs.  The only order-dependent reductions of the sampling path are the GroupNorm statistics, which many workgroups of the
     producing kernels add up: they are accumulated as integer limbs (csrc/stats_acc.h: integer addition is associative, so the order of
-    the atomics cannot change the sum), which makes the step bitwise reproducible by construction.  C3 / C5 plans at their benchmarked
-    batch: the eager warm-up call, the call that captures the hipGraph and two replays must agree bit for bit."""
+    the atomics cannot change the sum), which makes the step bitwise reproducible by construction.  C2 (the headline plan: T = 4096
+    attention, F(6x6) everywhere, batch 16 at 256x256) / C3 / C5 plans at their benchmarked batch: the eager warm-up call, the call that
+    captures the hipGraph and two replays must agree bit for bit."""
     import bench
     desc, up, ch, size, batch, skip, sstep = bench.WORKLOADS[workload]
     bb = dict(BB, skip_sample=skip, sample_step=sstep)
@@ -281,14 +282,47 @@ def test_step_is_bitwise_reproducible(dev, workload):
     y = torch.randn(batch, ch, size, size, generator=g).clamp(-1, 1)
     x_t = torch.randn(batch, ch, size, size, generator=g).clamp(-1, 1)
     eps = torch.randn(batch, ch, size, size, generator=g)
-    outs = [_p_sample(m, x_t, y, None, 57, eps, dev) for _ in range(4)]
+    ctx = None if up["condition_key"] == "nocond" else y
+    outs = [_p_sample(m, x_t, y, ctx, 57, eps, dev) for _ in range(4)]
     for k, (a, b) in enumerate(outs[1:], 1):
         assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1]), \
             (k, float((a - outs[0][0]).abs().max()), float((b - outs[0][1]).abs().max()))
     # ... and with the launches issued one by one instead of replayed (same kernels, other timing)
     m.denoise_fn.hip_graph = False
-    a, b = _p_sample(m, x_t, y, None, 57, eps, dev)
+    a, b = _p_sample(m, x_t, y, ctx, 57, eps, dev)
     assert torch.equal(a, outs[0][0]) and torch.equal(b, outs[0][1])
+    m.denoise_fn._plans = {}
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("loss_type", ["l1", "l2"])
+def test_training_step_is_bitwise_reproducible(dev, loss_type):
+    """The reference sets cudnn.deterministic for training as well (main.py:57-65).  BASELINE.json configs[3] at the benchmarked plan
+    (LBBDM-f4 UNet, latent 3x64x64, batch 32): three micro-steps from the same state -- same seed for the timesteps and the noise --
+    must give the same bits in the loss and in EVERY parameter gradient.  The backward's order-dependent sums (GroupNorm dgamma / dbeta
+    and the per-group sums, bias gradients, the loss) are accumulated as integer limbs (csrc/stats_acc.h) or in a fixed order; split-K
+    partial sums of the weight-gradient GEMMs were added in a fixed order already."""
+    import bench
+    desc, up, ch, size, batch, skip, sstep = bench.WORKLOADS["c4"]
+    bb = dict(BB, skip_sample=skip, sample_step=sstep, loss_type=loss_type)
+    m, sd = _model(up, bb, 4242, dev)
+    m.train()
+    x0, y = bench.make_inputs(batch, ch, size, seed=77)
+    x0, y = x0.to(dev), y.to(dev)
+    runs = []
+    for rep in range(3):
+        for p in m.parameters():
+            p.grad = None
+        torch.manual_seed(1234)
+        loss, _ = m(x0, y)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    assert len(runs[0][1]) == 248
+    for rep in (1, 2):
+        assert torch.equal(runs[rep][0], runs[0][0]), (rep, float(runs[rep][0]), float(runs[0][0]))
+        bad = [k for k, g in runs[rep][1].items() if not torch.equal(g, runs[0][1][k])]
+        assert not bad, (rep, len(bad), bad[:8])
     m.denoise_fn._plans = {}
     torch.cuda.empty_cache()
 

@@ -30,6 +30,54 @@ MATS = {
 }
 
 
+# F(7x7, 2x2) on the same eight points (round 5: the phase filters of conv3x3(nearest x2 (x)) read 2 x 2 pixels each): B^T is m = 6's,
+# G is 8 x 2 with the same row scalings, A^T gains the x^6 row and moves the point-at-infinity column there.
+_PTS = [0, 1, -1, 2, -2, .5, -.5]
+_F = [1, -2 / 9, -2 / 9, 1 / 90, 1 / 90, 32 / 45, 32 / 45]
+MATS72 = (MATS[6][0],
+          torch.tensor([[_F[j], _F[j] * _PTS[j]] for j in range(7)] + [[0, 1.]], dtype=torch.float64),
+          torch.tensor([[_PTS[j] ** i for j in range(7)] + [1. if i == 6 else 0.] for i in range(7)], dtype=torch.float64))
+
+
+def test_f72_exact_in_fp64_and_as_upsample_phases():
+    """y[a][b] = sum_{r,s < 2} g[r][s] d[a + r][b + s] for a, b < 7 from one 8 x 8 window; and the four phase filters of
+    conv3x3(nearest x2 (x)) evaluated this way -- phase (pa, pb) of tile (th, tw) lands at x-grid rows 7 th + a - pa, columns
+    7 tw + b - pb (csrc/winograd_math.h: wino_tdim) -- reproduce the convolution of the upsampled image."""
+    BT, G, AT = MATS72
+    g = torch.Generator().manual_seed(72)
+    D = torch.randn(8, 8, generator=g, dtype=torch.float64)
+    K = torch.randn(2, 2, generator=g, dtype=torch.float64)
+    Y = AT @ ((G @ K @ G.T) * (BT @ D @ BT.T)) @ AT.T
+    ref = torch.stack([torch.stack([(K * D[a:a + 2, b:b + 2]).sum() for b in range(7)]) for a in range(7)])
+    assert float((Y - ref).abs().max()) < 1e-12
+    N, C, Ko, H, W = 2, 3, 4, 9, 15
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Ko, C, 3, 3, generator=g, dtype=torch.float64)
+    want = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    out = torch.full((N, Ko, 2 * H, 2 * W), float("nan"), dtype=torch.float64)
+    TH, TW = (H + 7) // 7, (W + 7) // 7
+    xp = F.pad(x, (1, 7 * TW + 7 - W, 1, 7 * TH + 7 - H))                        # window rows 7 t - 1 .. 7 t + 6 -> padded index 7 t ..
+    for pa in range(2):
+        rows = [w[:, :, 0], w[:, :, 1] + w[:, :, 2]] if pa == 0 else [w[:, :, 0] + w[:, :, 1], w[:, :, 2]]     # [r][K, C, kx]
+        for pb in range(2):
+            g2 = torch.stack([torch.stack([r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if pb == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]], -1)
+                              for r in rows], -2)                              # [K, C, 2, 2]
+            U = torch.einsum("ij,kcjl,ml->kcim", G, g2, G)
+            for th in range(TH):
+                for tw in range(TW):
+                    d = xp[:, :, 7 * th:7 * th + 8, 7 * tw:7 * tw + 8]
+                    V = torch.einsum("ij,ncjk,lk->ncil", BT, d, BT)
+                    Mx = torch.einsum("ncil,kcil->nkil", V, U)
+                    Yt = torch.einsum("ij,nkjl,ml->nkim", AT, Mx, AT)
+                    for a in range(7):
+                        for b in range(7):
+                            oh, ow = 7 * th + a - pa, 7 * tw + b - pb
+                            if 0 <= oh < H and 0 <= ow < W:
+                                out[:, :, 2 * oh + pa, 2 * ow + pb] = Yt[:, :, a, b]
+    assert not bool(torch.isnan(out).any())
+    assert float((out - want).abs().max()) < 1e-11
+
+
 def winograd_conv(x, w, m, dtype):
     """x [N,C,H,W], w [K,C,3,3] -> [N,K,H,W]; every stage in `dtype` (the HIP path: fp32)."""
     BT, G, AT = (t.to(dtype) for t in MATS[m])
@@ -109,7 +157,7 @@ def test_fp32_rounding_levels():
     assert e2 < e4 < e6                            # each step up in tile size costs accuracy: ~10x, then ~2x
 
 
-@pytest.mark.parametrize("m", [2, 4, 6])
+@pytest.mark.parametrize("m", [2, 4, 6, 7])
 def test_hip_source_transforms_match_the_matrices(m):
     """csrc/winograd.hip evaluates B^T, A^T and G as hand-factored adds / multiplies; the same template code compiled
     for the host (bbdm_debug_winograd_transform_1d, an exported test hook) must agree with the matrices above on random
@@ -121,9 +169,10 @@ def test_hip_source_transforms_match_the_matrices(m):
     fn = lib.bbdm_debug_winograd_transform_1d
     fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     fn.restype = ctypes.c_int
-    BT, G, AT = (t.numpy() for t in MATS[m])
+    BT, G, AT = (t.numpy() for t in (MATS72 if m == 7 else MATS[m]))
     rng = np.random.RandomState(m)
-    for which, mat in ((0, BT), (1, AT), (2, G), (3, AT.T), (4, G.T)):      # 3, 4: the weight-gradient side (winograd_math.h)
+    sides = ((0, BT), (1, AT), (2, G)) if m == 7 else ((0, BT), (1, AT), (2, G), (3, AT.T), (4, G.T))
+    for which, mat in sides:      # 3, 4: the weight-gradient side (winograd_math.h)
         rows, cols = mat.shape
         vecs = [rng.randn(cols).astype(np.float32) for _ in range(8)] + list(np.eye(cols, dtype=np.float32))
         for v in vecs:

@@ -64,6 +64,57 @@ __global__ void __launch_bounds__(256) mfma_stream_t(const bf16x8* __restrict__ 
 }
 #define mfma_stream mfma_stream_t<4>
 
+// The same stream WITH the operand traffic of csrc/gemm_bf3p.hip's main loop: per 24 MFMAs a wave re-reads its 12 fragments from LDS
+// (ds_read_b128 at lane * 16) and the workgroup's 16 waves together deposit 48 KB by LDS-DMA (global_load_lds_dwordx4, 3 per wave) from
+// an L2-resident buffer.  TRAFFIC: 0 = none (registers only), 1 = the LDS reads, 2 = LDS reads + LDS-DMA copies.
+template <int TRAFFIC>
+__global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __restrict__ frags, const unsigned char* __restrict__ src,
+                                                            float* __restrict__ sink, long iters, unsigned long long* __restrict__ clocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];            // 96 KB: two 48 KB stages
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 96 * 1024 / 16; i += 1024) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(frags)[i & 8191];
+    __syncthreads();
+    bf16x8 f[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) f[i] = *reinterpret_cast<const bf16x8*>(lds + (wave * 12 + i) * 256 % (48 * 1024) + lane * 16);
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (long it = 0; it < iters; ++it) {
+        const int stage = (int)(it & 1) * 48 * 1024;
+        if (TRAFFIC >= 2) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {           // 3 KB per wave and iteration: 16 waves x 3 = the 48 KB stage
+                const unsigned char* g = src + (size_t)((blockIdx.x * 48 + wave * 3 + q) & 4095) * 1024 + lane * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lds + (stage ^ (48 * 1024)) + (wave * 3 + q) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {               // six term groups of four MFMAs, two fragment reloads behind each
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[(2 * t + (i >> 1)) % 12], f[(2 * t + 6 + (i & 1)) % 12], acc[i], 0, 0, 0);
+            if (TRAFFIC >= 1) {
+                f[2 * t] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t) * 1024) % (48 * 1024) + lane * 16);
+                f[2 * t + 1] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t + 1) * 1024) % (48 * 1024) + lane * 16);
+            }
+        }
+        if (TRAFFIC >= 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    if (s == 123456.789f) sink[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
+    if (lane == 0) { atomicMin(&clocks[2], w0); atomicMax(&clocks[3], w1); }
+}
+
 // a float4 copy at full HBM rate (the "transform" phase of the step between two GEMM bursts)
 __global__ void __launch_bounds__(256) copy_stream(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
@@ -151,11 +202,22 @@ static void launch_mfma(int blocks, const bf16x8* d, float* sink, long iters, un
 }
 struct BurstStat { double tf_mean, tf_min, tf_max, ghz, tf_third[3], burst_ms, gap_ms; int n; long iters; };
 
+// traffic < 0: the register-only stream (wps 256-thread blocks per CU); traffic 0 / 1 / 2: mfma_traffic_stream<traffic>, ONE 16-wave
+// workgroup per CU (4 waves per SIMD, 24 MFMAs per wave and iteration) -- the geometry of the 256 x 256 tile GEMM
 static BurstStat run_schedule(int cus, int wps, int nacc, const bf16x8* d, float* sink, unsigned long long* clk_dev, int max_bursts,
-                              double burst_ms, double copy_ms, double seconds, float4* csrc, float4* cdst, size_t copy_elems_per_ms) {
-    const int blocks = cus * wps;
-    const double flop_iter = (double)nacc * 4.0 * 2.0 * 32 * 32 * 16;           // per wave and loop iteration
-    auto go = [&](long iters, unsigned long long* c) { if (nacc == 8) launch_mfma<8>(blocks, d, sink, iters, c); else launch_mfma<4>(blocks, d, sink, iters, c); };
+                              double burst_ms, double copy_ms, double seconds, float4* csrc, float4* cdst, size_t copy_elems_per_ms,
+                              int traffic = -1) {
+    const int blocks = traffic >= 0 ? cus * 4 : cus * wps;                       // (x 4 waves below: 16 waves per CU in traffic mode)
+    const double flop_iter = traffic >= 0 ? 24.0 * 2.0 * 32 * 32 * 16 : (double)nacc * 4.0 * 2.0 * 32 * 32 * 16;           // per wave and loop iteration
+    auto go = [&](long iters, unsigned long long* c) {
+        if (traffic >= 0) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(csrc);          // first 4 MB: L2 / MALL resident
+            if (traffic == 0) hipLaunchKernelGGL(mfma_traffic_stream<0>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c);
+            else if (traffic == 1) hipLaunchKernelGGL(mfma_traffic_stream<1>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c);
+            else hipLaunchKernelGGL(mfma_traffic_stream<2>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c);
+        } else if (nacc == 8) launch_mfma<8>(blocks, d, sink, iters, c);
+        else launch_mfma<4>(blocks, d, sink, iters, c);
+    };
     // calibrate iterations for the burst length on a warm chip (a few launches, event-timed)
     long iters = 2000;
     hipEvent_t e0, e1;
@@ -167,7 +229,8 @@ static BurstStat run_schedule(int cus, int wps, int nacc, const bf16x8* d, float
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         iters = (long)fmax(16.0, iters * burst_ms / (ms / 4));
     }
-    const size_t copy_n = (size_t)(copy_elems_per_ms * copy_ms);
+    const size_t copy_total = (size_t)(copy_elems_per_ms * copy_ms);       // elements; launched in pieces of at most the buffer
+    const size_t copy_cap = (size_t)1 << 27;                               // 2 GiB / 16 B
     int n = (int)fmin((double)max_bursts, seconds * 1e3 / (burst_ms + copy_ms));
     if (n < 3) n = 3;
     std::vector<unsigned long long> init((size_t)n * 4);
@@ -175,7 +238,8 @@ static BurstStat run_schedule(int cus, int wps, int nacc, const bf16x8* d, float
     CK(hipMemcpy(clk_dev, init.data(), init.size() * 8, hipMemcpyHostToDevice));
     for (int l = 0; l < n; ++l) {                       // everything queued up front: no host round trip between a burst and its copy
         go(iters, clk_dev + (size_t)l * 4);
-        if (copy_n) hipLaunchKernelGGL(copy_stream, dim3(cus * 8), dim3(256), 0, 0, csrc, cdst, copy_n);
+        for (size_t done = 0; done < copy_total; done += copy_cap)
+            hipLaunchKernelGGL(copy_stream, dim3(cus * 8), dim3(256), 0, 0, csrc, cdst, copy_total - done < copy_cap ? copy_total - done : copy_cap);
     }
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> h((size_t)n * 4);
@@ -232,8 +296,12 @@ static int burst_main(int argc, char** argv) {
             for (int k = 0; k < 8; ++k) h[i * 8 + k] = mode == 0 ? 0 : f2bf(gauss());
         CK(hipMemcpy(d, h.data(), nfr * 16, hipMemcpyHostToDevice));
     };
-    auto row = [&](const char* name, int wps, int nacc, double bms, double cms) {
-        const BurstStat s = run_schedule(cus, wps, nacc, d, sink, clk, max_bursts, bms, cms, seconds, csrc, cdst, elems_per_ms);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    auto row = [&](const char* name, int wps, int nacc, double bms, double cms, int traffic = -1) {
+        const BurstStat s = run_schedule(cus, wps, nacc, d, sink, clk, max_bursts, bms, cms, seconds, csrc, cdst, elems_per_ms, traffic);
+        if (traffic >= 0) { wps = 4; nacc = 6; }                                                            // 4 waves per SIMD, 24 MFMAs per iteration
         const double cyc = s.ghz * 1e9 * (s.burst_ms * 1e-3) / ((double)wps * nacc * 4.0 * s.iters);      // one SIMD issues wps x 4 nacc x iters MFMAs per burst
         printf("%-44s w/SIMD %d acc %d | %5d bursts of %6.3f ms, gap %6.3f ms | in-burst TFLOP/s mean %7.1f (min %7.1f max %7.1f; thirds %7.1f %7.1f %7.1f) "
                "| %.3f GHz, %.1f cycles per MFMA and SIMD | %.3f of 2500\n", name, wps, nacc, s.n, s.burst_ms, s.gap_ms, s.tf_mean, s.tf_min, s.tf_max,
@@ -254,6 +322,11 @@ static int burst_main(int argc, char** argv) {
     row("(iii) 1.5 / 0.5", 2, 8, 1.5, 0.5);
     row("(iii) 1.5 / 0.5", 3, 4, 1.5, 0.5);
     row("(iii) 1.5 / 0.5", 4, 4, 1.5, 0.5);
+    // (iv) what the tile GEMM's operand traffic costs: the same MFMA count with its LDS fragment reads / LDS-DMA copies, 16 waves per CU
+    row("(iv) GEMM geometry, registers only, 1.5 / 0.5", 4, 6, 1.5, 0.5, 0);
+    row("(iv) + 12 ds_read_b128 per 24 MFMAs, 1.5 / 0.5", 4, 6, 1.5, 0.5, 1);
+    row("(iv) + reads + 48 KB LDS-DMA per iter, 1.5 / 0.5", 4, 6, 1.5, 0.5, 2);
+    row("(iv) + reads + LDS-DMA, back to back 1.5 ms", 4, 6, 1.5, 0.0, 2);
     fill(0);
     row("zero operands: (i) 1.5 ms back to back", 2, 4, 1.5, 0.0);
     row("zero operands: (ii) 1.5 / 0.5", 2, 4, 1.5, 0.5);
