@@ -187,6 +187,42 @@ def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):
     assert parity_err(outs[True], ref) < M.STEP_TOL
 
 
+def test_upsampling_conv_as_f72_phase_filters(monkeypatch):
+    """The up-sampling ResBlock's first conv as four 2 x 2 phase filters on F(7x7, 2x2) (round 5; unet.phase_filter_tile chooses it where
+    the layer earns the 8-point transform -- forced here on an 8x8 model): same result as the F(m x m, 3x3) phase filters and as the
+    oracle's explicit upsample + conv (openaimodel.py:259-264)."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    wt = lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
+    monkeypatch.setattr(bbdm_amd.unet, "winograd_tile", wt)
+    monkeypatch.setattr(bbdm_amd.unet, "phase_filter_tile",
+                        lambda N, H, W, cin, cout4, max_m, small, f72=True:
+                        7 if (f72 and (cout4 // 4) % 128 == 0 and cin % 16 == 0) else wt(N, H, W, cin, cout4, max_m, small))
+    up = dict(image_size=8, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 48)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.eval()
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(6, 4, 8, 8, generator=g)
+    t = torch.arange(6) * 17 + 5
+    outs = {}
+    for f72 in (True, False):
+        m.upsample_f72 = f72
+        with torch.no_grad():
+            outs[f72] = m(x, timesteps=t, context=None).clone()
+        plan = m._plan_for(x, False)
+        tiles7 = [a for n, a in plan.ops if str(n) == "bbdm_winograd_output_f32" and a[0] == 7 and a[7] == 8]
+        assert len(tiles7) == (1 if f72 else 0)
+    assert parity_err(outs[True], outs[False]) < 2e-5
+    ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
+    assert parity_err(outs[True], ref) < M.STEP_TOL
+
+
 def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     """Training plan of a UNet with enough tiles (16 images of 16x16 = 256 4x4 tiles, 64 channels) for the 3x3 layers' weight
     gradients to take the Winograd-domain path (csrc/winograd_wgrad.hip), with the 1x1 skip convolutions (forward and data

@@ -92,9 +92,14 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert (n2, n3) == ("bbdm_winograd_gemm_f32", "bbdm_winograd_output_f32")       # emitted as a triple
         wm = i[0]
         N, H, W, cin = i[9:13]
-        assert wm in (2, 4, 6) and g[0] == wm and o[0] == wm
-        assert (wm == 6 or (H % wm == 0 and W % wm == 0)) and cin % 4 == 0
+        assert wm in (2, 4, 6, 7) and g[0] == wm and o[0] == wm
+        assert (wm >= 6 or (H % wm == 0 and W % wm == 0)) and cin % 4 == 0
         phases = bool(o[7] & 8)          # conv3x3(nearest x2 (x)) as four phase filters on x: the GEMMs produce 4 Cout channels
+        # m = 7 = F(7x7, 2x2): only the phase filters of an up-sampling conv, inference, on the pre-split planes, whole 128-channel
+        # blocks per phase, and only where the coarser tile grid still saves GEMM work
+        assert wm != 7 or (phases and not training and (g[8] // 4) % 128 == 0 and cin % 16 == 0 and
+                           "bf3p" in getattr(ops[k + 1][0], "entry", "") and
+                           unet.wino_tiles(7, N, H, W) <= 0.9 * unet.wino_tiles(6, N, H, W))
         assert tuple(g[4:8]) == (N, H, W, cin) and tuple(o[8:11]) == (N, H, W) and (4 if phases else 1) * o[11] == g[8]
         cout = g[8]
         up = i[8]
@@ -105,8 +110,8 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             assert not up and not training and (dst.H, dst.W, dst.C) == (2 * H, 2 * W, cout // 4) and o[3] is None
             assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) >= unet.winograd_tile(N, 2 * H, 2 * W, cin, cout // 4, m.winograd)
         tiles = lib.bbdm_winograd_tiles(wm, N, H, W)
-        P = (wm + 2) ** 2
-        assert tiles % 256 == 0 and tiles >= N * -(-H // wm) * -(-W // wm)
+        P = unet.wino_planes(wm)
+        assert tiles % 256 == 0 and tiles >= unet.wino_tiles(wm, N, H, W)
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
         entry = getattr(ops[k + 1][0], "entry", "")
         if "bf3p" in entry:                     # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
@@ -126,11 +131,12 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             assert not any(v[0] is i[3] for v in plan._saved_V.values())
         elif entry.endswith("bf3_f32"):
             assert getattr(ops[k][0], "entry", "bbdm_winograd_input_f32") == "bbdm_winograd_input_f32"
-            assert g[2].t.dtype == torch.int16 and g[2].t.numel() == lib.bbdm_gemm_bf3_packed_halfs((wm + 2) ** 2, cin, cout)
+            assert g[2].t.dtype == torch.int16 and g[2].t.numel() == lib.bbdm_gemm_bf3_packed_halfs(P, cin, cout)
             assert lib.bbdm_gemm_bf3_supported(tiles, cin, cout)
         else:
             assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
-        assert unet.winograd_tile(N, H, W, cin, cout, m.winograd, small=bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)) == wm
+        small = bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)
+        assert (unet.phase_filter_tile(N, H, W, cin, cout, m.winograd, small) if phases else unet.winograd_tile(N, H, W, cin, cout, m.winograd, small=small)) == wm
         if entry.endswith("splitk_f32"):        # small layer: split-K partials, added by the output transform of the same count
             ks = g[-1]
             assert ks == lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin, cout) > 1
