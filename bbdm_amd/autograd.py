@@ -50,7 +50,11 @@ class _UNetSeg(torch.autograd.Function):
         need_x = link == 0 and ctx.needs_input_grad[3]
         need_ctx = link == 0 and ctx.needs_input_grad[5]
         dx_in = plan.backward_segment(seg, need_x or need_ctx)
-        grads = [plan.grad_view(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(plan.bsegs[seg][2])]
+        params = plan.bsegs[seg][2]
+        if plan.m.grad_in_place and _accumulate_in_place(plan, params, [ctx.needs_input_grad[7 + i] for i in range(len(params))]):
+            grads = [None] * len(params)            # already added to the .grad tensors
+        else:
+            grads = [plan.grad_view(p) if ctx.needs_input_grad[7 + i] else None for i, p in enumerate(params)]
         dx = dctx = None
         if dx_in is not None:
             nchw = dx_in.permute(0, 3, 1, 2)
@@ -63,6 +67,47 @@ class _UNetSeg(torch.autograd.Function):
                     dctx = dctx + via_attention
         dtoken = None if link == 0 else torch.zeros(1, dtype=torch.float32, device=plan.device)
         return (None, None, None, dx, None, dctx, dtoken, *grads)
+
+
+def _accumulate_in_place(plan, params, needed) -> bool:
+    """Gradient accumulation without autograd's per-parameter adds (UNetModel.grad_in_place, set by dist_utils.accumulation_sync).
+
+    After the first micro-step of an accumulation cycle every ``p.grad`` is a view of ONE of the plan's two flat gradient buffers
+    (autograd adopts the views :meth:`_Plan.grad_view` hands out), at the parameter's own offset; this micro-step's gradients lie at
+    the same offsets of the OTHER flat buffer.  When that holds for every parameter of the segment, the segment's gradients are added
+    with one ``add_`` per contiguous run of offsets (a handful per segment) and autograd receives None for them -- 248 ``AccumulateGrad``
+    launches per micro-step become ~10.  Anything else (first micro-step, a foreign ``.grad``, a parameter with tensor hooks) returns
+    False and the caller hands the views to autograd as before."""
+    new = plan._flat_grad
+    runs = []
+    base = None
+    for q, need in zip(params, needed):
+        if not need:
+            return False
+        g = q.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != q.shape or q._backward_hooks:
+            return False
+        off = plan.grad_off[id(q)]
+        b = g.data_ptr() - 4 * off
+        if base is None:
+            base = b
+        if b != base or b == new.data_ptr():
+            return False
+        runs.append((off, off + q.numel()))
+    old = next((fb for fb in getattr(plan, "_flat_bufs", []) if fb.data_ptr() == base), None)
+    if old is None or old.numel() != new.numel():
+        return False
+    runs.sort()
+    merged = [list(runs[0])]
+    for a, b in runs[1:]:
+        if a == merged[-1][1]:
+            merged[-1][1] = b
+        else:
+            merged.append([a, b])
+    with torch.no_grad():
+        for a, b in merged:
+            old[a:b].add_(new[a:b])
+    return True
 
 
 def unet_apply(model, x, timesteps, context):

@@ -115,9 +115,29 @@ def accumulation_sync(net, micro_step: int, accumulate_grad_batches: int):
     with no ``no_sync()``) although the optimizer only steps every ``accumulate_grad_batches``-th one.  Skipping the
     collective on the non-boundary micro-steps (``net.no_sync()``) and reducing the locally accumulated sum on the boundary
     step gives the same averaged gradient -- a sum of means is the mean of sums -- with 1/accumulate_grad_batches of the
-    RCCL traffic.  ``micro_step`` is the runner's 1-based ``global_step``; non-DDP modules get a null context."""
+    RCCL traffic.  ``micro_step`` is the runner's 1-based ``global_step``; non-DDP modules get no ``no_sync``.
+
+    Inside the context the UNet may also add a micro-step's parameter gradients to the ``.grad`` tensors IN PLACE -- one fused add
+    per backward segment instead of one ``AccumulateGrad`` add per parameter (248 launches per micro-step, bbdm_amd/autograd.py) --
+    whenever no gradient hook has to observe them: every micro-step of a plain module, the non-boundary micro-steps of a DDP one
+    (under ``no_sync`` DDP's reducer ignores its hooks; on the boundary step they must fire, so that step takes autograd's path)."""
     import contextlib
     boundary = accumulate_grad_batches <= 1 or micro_step % accumulate_grad_batches == 0
-    if boundary or not hasattr(net, "no_sync"):
-        return contextlib.nullcontext()
-    return net.no_sync()
+    ddp = hasattr(net, "no_sync")
+
+    @contextlib.contextmanager
+    def ctx():
+        from .unet import UNetModel
+        unets = [m for m in net.modules() if isinstance(m, UNetModel)] if (not ddp or not boundary) else []
+        for m in unets:
+            m.grad_in_place = True
+        try:
+            if ddp and not boundary:
+                with net.no_sync():
+                    yield
+            else:
+                yield
+        finally:
+            for m in unets:
+                m.grad_in_place = False
+    return ctx()

@@ -735,6 +735,9 @@ class UNetModel(nn.Module):
         # inference: the four phase filters of an up-sampling conv as 2 x 2 filters, F(7x7, 2x2) on the 8-point transform, where the
         # layer would take F(6x6, 3x3) (see phase_filter_tile); False = F(6x6, 3x3) on the zero-padded 3 x 3 phase filters (A/B)
         self.upsample_f72: bool = True
+        # training: set by dist_utils.accumulation_sync for the micro-steps whose parameter gradients no hook has to observe -- the
+        # backward then adds them to the existing ``.grad`` tensors itself (bbdm_amd/autograd.py: _accumulate_in_place)
+        self.grad_in_place: bool = False
         # Training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
         # BBDM_WINOGRAD_WGRAD=0: the direct kernel (conv_wgrad.hip) everywhere.
         self.winograd_wgrad: int = int(os.environ.get("BBDM_WINOGRAD_WGRAD", "6"))
@@ -1021,7 +1024,7 @@ class _Plan:
             return 2.0 * 2.0 * N * heads * T * T * ch
         # training (gradient plan)
         if name == "bbdm_conv_wgrad_f32":
-            N, H, W, cin, cout, ks = args[7:13]
+            N, H, W, cin, cout, ks = args[8:14]
             return 2.0 * N * H * W * cout * cin * ks * ks
         if name == "bbdm_conv3x3_winograd_wgrad_f32":   # the (m+2)^2 TN GEMMs actually executed
             wm, (N, H, W, cin, cout) = args[0], args[8:13]

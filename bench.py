@@ -620,7 +620,7 @@ def run_workload(args, env):
                 elif name == "bbdm_groupnorm_stats_f32":
                     shp = "N{} HW{} C{}".format(oargs[3], oargs[4], oargs[5])
                 elif name == "bbdm_conv_wgrad_f32":
-                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[7:13])
+                    shp = "N{} {}x{} {}->{} k{}".format(*oargs[8:14])
                 elif name == "bbdm_gemm_bf3p_tn_f32":
                     shp = "P{} tiles{} {}x{}".format(*oargs[3:7])
                 elif name == "bbdm_groupnorm_bwd_f32":

@@ -303,3 +303,15 @@ def test_training_step_is_bitwise_reproducible(name):
         runs.append((loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
     assert torch.equal(runs[0][0], runs[1][0])
     assert all(torch.equal(g, runs[1][1][k]) for k, g in runs[0][1].items())
+
+
+def test_accumulation_in_place_matches_autograd(monkeypatch):
+    """tests/test_training_gpu.py's check of the in-place gradient accumulation under dist_utils.accumulation_sync, emulated kernels."""
+    real = T.build
+
+    def build(rec, dev):
+        m = real(rec, CPU)
+        m.denoise_fn.hip_graph = False
+        return m
+    monkeypatch.setattr(T, "build", build)
+    T.test_accumulation_in_place_matches_autograd(CPU, "tiny_nocond")

@@ -185,6 +185,17 @@ def test_1x1_layers_take_the_kernel_their_size_asks_for():
     assert [l[1:] for l in layers0] == [l[1:] for l in layers]
 
 
+def test_flop_accounting_evaluates_on_every_op_of_a_training_plan():
+    """bench.py's per-launch pass calls _Plan._algorithmic_flops on every forward and gradient-plan op with the op's UNRESOLVED argument
+    list: an entry point whose signature grew (bbdm_conv_wgrad_f32 gained ws_floats in ABI 21) shifts the indices it reads -- found on
+    the GPU box in round 5, caught here since."""
+    m, plan = _plan("c3", 32, True, winograd=6)
+    for name, args in list(plan.ops) + list(plan.bops):
+        fl = plan._algorithmic_flops(str(name), args)
+        assert isinstance(fl, (int, float)) and fl >= 0, (name, fl)
+    assert any(str(n) == "bbdm_conv_wgrad_f32" for n, _ in plan.bops)
+
+
 def test_first_stage_flags_cover_every_switch_the_plan_emitters_read():
     """The VQGAN plans reuse _Plan's emitters with first_stage_hip._Flags standing in for the UNetModel: every switch an emitter reads
     (``self.m.<name>`` / ``m.<name>`` in unet.py's _Plan) must exist there, or the first plan of a first stage dies on a GPU box only."""

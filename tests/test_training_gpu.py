@@ -99,6 +99,56 @@ def test_gradient_accumulation_and_input_grad(dev, name):
         assert rel_err(p.grad, 2 * g1[k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("name", ["tiny_nocond", "tiny_xattn"])
+def test_accumulation_in_place_matches_autograd(dev, name):
+    """dist_utils.accumulation_sync lets the UNet add a micro-step's gradients to the ``.grad`` tensors itself (one add per contiguous
+    run of the flat gradient buffer instead of one AccumulateGrad launch per parameter): same bits as autograd's accumulation over
+    three micro-steps, ``.grad`` keeps its storage, and the boundary micro-step of a DDP-like module (``no_sync`` present) goes
+    through autograd so that reducer hooks would fire."""
+    import contextlib
+    from bbdm_amd import dist_utils
+    rec = load_case(name)
+    x0, y, t, nz = (rec[k].to(dev) for k in ("x0", "y", "t", "noise"))
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else y
+
+    def run(wrap):
+        m = build(rec, dev).train()
+        net = wrap(m)
+        ptrs = None
+        for step in (1, 2, 3):
+            with dist_utils.accumulation_sync(net, step, 4) if wrap is not _plain else contextlib.nullcontext():
+                loss, _ = m.p_losses(x0 * (1.0 / step), y, ctx, t, nz)
+                loss.backward()
+            if step == 1:
+                ptrs = {k: p.grad.data_ptr() for k, p in m.named_parameters()}
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        return m, ptrs
+
+    _plain = lambda m: m
+    want, _ = run(_plain)
+
+    class _Sync:                                   # a module without no_sync: every micro-step may accumulate in place
+        def __init__(self, m): self.m = m
+        def modules(self): return self.m.modules()
+    got, ptrs = run(_Sync)
+    for (k, p), (_, q) in zip(got.named_parameters(), want.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+        assert p.grad.data_ptr() == ptrs[k], k                 # accumulated in place: .grad never re-pointed
+    adds = []
+
+    class _DDPLike(_Sync):                         # has no_sync: in-place only under it (non-boundary micro-steps)
+        @contextlib.contextmanager
+        def no_sync(self):
+            adds.append(1)
+            yield
+    got2, _ = run(_DDPLike)
+    assert len(adds) == 3                          # micro-steps 1..3 of 4 are non-boundary
+    for (k, p), (_, q) in zip(got2.named_parameters(), want.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    assert not got2.denoise_fn.grad_in_place and not got.denoise_fn.grad_in_place
+
+
 def test_gradients_handed_out_are_never_overwritten(dev):
     """The parameter gradients are views of a recycled flat buffer: tensors returned by torch.autograd.grad, or a .grad the caller
     keeps across zero_grad(set_to_none=True), must survive the next backward pass (gradient penalties, logging, manual

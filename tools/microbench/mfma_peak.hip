@@ -66,10 +66,13 @@ __global__ void __launch_bounds__(256) mfma_stream_t(const bf16x8* __restrict__ 
 
 // The same stream WITH the operand traffic of csrc/gemm_bf3p.hip's main loop: per 24 MFMAs a wave re-reads its 12 fragments from LDS
 // (ds_read_b128 at lane * 16) and the workgroup's 16 waves together deposit 48 KB by LDS-DMA (global_load_lds_dwordx4, 3 per wave) from
-// an L2-resident buffer.  TRAFFIC: 0 = none (registers only), 1 = the LDS reads, 2 = LDS reads + LDS-DMA copies.
+// an L2-resident buffer.  TRAFFIC: 0 = none (registers only), 1 = the LDS reads, 2 = LDS reads + LDS-DMA copies, 3 = as 2 but one
+// copy in three streams from a 2 GiB buffer (HBM: 16 KB of 48 KB per iteration, the tile GEMM's V share) and every wave stores
+// 256 B per iteration to a streaming destination (the M tile's share) -- the HBM traffic of the real kernel, ~1.5 - 2 TB/s.
 template <int TRAFFIC>
 __global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __restrict__ frags, const unsigned char* __restrict__ src,
-                                                            float* __restrict__ sink, long iters, unsigned long long* __restrict__ clocks) {
+                                                            float* __restrict__ sink, long iters, unsigned long long* __restrict__ clocks,
+                                                            float* __restrict__ stream_dst) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];            // 96 KB: two 48 KB stages
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 96 * 1024 / 16; i += 1024) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(frags)[i & 8191];
@@ -88,7 +91,9 @@ __global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __rest
         if (TRAFFIC >= 2) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {           // 3 KB per wave and iteration: 16 waves x 3 = the 48 KB stage
-                const unsigned char* g = src + (size_t)((blockIdx.x * 48 + wave * 3 + q) & 4095) * 1024 + lane * 16;
+                const unsigned char* g = (TRAFFIC >= 3 && q == 0)
+                    ? src + ((((size_t)it * gridDim.x + blockIdx.x) * 16 + wave) & ((1u << 21) - 1)) * 1024 + lane * 16      // 2 GiB, streamed once
+                    : src + (size_t)((blockIdx.x * 48 + wave * 3 + q) & 4095) * 1024 + lane * 16;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                  (__attribute__((address_space(3))) void*)(lds + (stage ^ (48 * 1024)) + (wave * 3 + q) * 1024), 16, 0, 0);
             }
@@ -102,6 +107,8 @@ __global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __rest
                 f[2 * t + 1] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t + 1) * 1024) % (48 * 1024) + lane * 16);
             }
         }
+        if (TRAFFIC >= 3)
+            __builtin_nontemporal_store(acc[it & 3][0], stream_dst + (((((size_t)it * gridDim.x + blockIdx.x) * 16 + wave) * 64 + lane) & ((1u << 29) - 1)));
         if (TRAFFIC >= 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
@@ -212,9 +219,11 @@ static BurstStat run_schedule(int cus, int wps, int nacc, const bf16x8* d, float
     auto go = [&](long iters, unsigned long long* c) {
         if (traffic >= 0) {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(csrc);          // first 4 MB: L2 / MALL resident
-            if (traffic == 0) hipLaunchKernelGGL(mfma_traffic_stream<0>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c);
-            else if (traffic == 1) hipLaunchKernelGGL(mfma_traffic_stream<1>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c);
-            else hipLaunchKernelGGL(mfma_traffic_stream<2>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c);
+            float* sd = reinterpret_cast<float*>(cdst);
+            if (traffic == 0) hipLaunchKernelGGL(mfma_traffic_stream<0>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c, sd);
+            else if (traffic == 1) hipLaunchKernelGGL(mfma_traffic_stream<1>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c, sd);
+            else if (traffic == 2) hipLaunchKernelGGL(mfma_traffic_stream<2>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c, sd);
+            else hipLaunchKernelGGL(mfma_traffic_stream<3>, dim3(cus), dim3(1024), 96 * 1024, 0, d, src, sink, iters, c, sd);
         } else if (nacc == 8) launch_mfma<8>(blocks, d, sink, iters, c);
         else launch_mfma<4>(blocks, d, sink, iters, c);
     };
@@ -299,6 +308,7 @@ static int burst_main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(mfma_traffic_stream<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     auto row = [&](const char* name, int wps, int nacc, double bms, double cms, int traffic = -1) {
         const BurstStat s = run_schedule(cus, wps, nacc, d, sink, clk, max_bursts, bms, cms, seconds, csrc, cdst, elems_per_ms, traffic);
         if (traffic >= 0) { wps = 4; nacc = 6; }                                                            // 4 waves per SIMD, 24 MFMAs per iteration
@@ -327,6 +337,8 @@ static int burst_main(int argc, char** argv) {
     row("(iv) + 12 ds_read_b128 per 24 MFMAs, 1.5 / 0.5", 4, 6, 1.5, 0.5, 1);
     row("(iv) + reads + 48 KB LDS-DMA per iter, 1.5 / 0.5", 4, 6, 1.5, 0.5, 2);
     row("(iv) + reads + LDS-DMA, back to back 1.5 ms", 4, 6, 1.5, 0.0, 2);
+    row("(iv) + reads + DMA (1/3 from HBM) + stores, 1.5 / 0.5", 4, 6, 1.5, 0.5, 3);
+    row("(iv) + reads + DMA (1/3 from HBM) + stores, back to back", 4, 6, 1.5, 0.0, 3);
     fill(0);
     row("zero operands: (i) 1.5 ms back to back", 2, 4, 1.5, 0.0);
     row("zero operands: (ii) 1.5 / 0.5", 2, 4, 1.5, 0.5);
