@@ -25,7 +25,7 @@ struct BwdArgs {
     const float* dadd;
     const double* sg;
     const float4* coef;          // [N][G] {rstd, mean, S1/cnt, S2/cnt} in fp32, written by the finalize kernel
-    unsigned long long* pq;      // [N][C][2][SA_W] exact limb cells (stats_acc.h): P, Q summed over the pixel blocks in ANY order
+    double* pq;                  // [N][splits][C][2] per-workgroup partial sums of P, Q (plain stores; the finalize kernel adds the splits in order)
     const unsigned long long* dgb;   // [C][2][SA_W] limb cells: sums over n of dgamma / dbeta (finalize kernel), folded by the apply pass
     float* dgamma;
     float* dbeta;
@@ -103,8 +103,9 @@ __device__ __forceinline__ void quad_dv(const BwdArgs& a, int n, int c, const No
 // ---- kernel 1: P, Q ----------------------------------------------------------------------------------------------
 template <int JMAX>
 __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int pix_per_block) {
-    // Deterministic (round 5): the pixel rows of a workgroup meet in LDS in a FIXED order (no LDS atomics), the workgroups of an image
-    // meet in exact integer-limb cells (any order of the atomics leaves the same limbs)
+    // Deterministic (round 5): the pixel rows of a workgroup meet in LDS in a FIXED order (no LDS atomics); every workgroup STORES its
+    // partial sums and the finalize kernel adds the workgroups of an image in index order (no global atomics: limb cells here -- three
+    // integer atomics per value and workgroup -- doubled this pass)
     __shared__ double lacc[256 * 8];          // [thread][P0..3, Q0..3]
     const int tid = threadIdx.x, n = blockIdx.y;
     const int C4 = a.C >> 2, cpg = a.C / a.G, HW = a.H * a.W;
@@ -160,10 +161,10 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
             if (JMAX == 1 && C4 <= 256) {        // several pixel rows per channel quad: through LDS (below)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { lacc[tid * 8 + e] = P[e]; lacc[tid * 8 + 4 + e] = Q[e]; }
-            } else {                             // one thread per channel quad: straight to the cells
-                unsigned long long* cell = a.pq + ((size_t)n * a.C + c) * 2 * SA_W;
+            } else {                             // one thread per channel quad: straight to this workgroup's partials
+                double* o = a.pq + (((size_t)n * gridDim.x + blockIdx.x) * a.C + c) * 2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { sa_add(cell + (2 * e) * SA_W, P[e]); sa_add(cell + (2 * e + 1) * SA_W, Q[e]); }
+                for (int e = 0; e < 4; ++e) { o[2 * e] = P[e]; o[2 * e + 1] = Q[e]; }
             }
         }
     }
@@ -173,13 +174,13 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
             const int c = i >> 1, which = i & 1, c4 = c >> 2, e = c & 3;
             double v = 0.0;
             for (int r = 0; r < PP; ++r) v += lacc[(r * C4 + c4) * 8 + which * 4 + e];
-            sa_add(a.pq + ((size_t)n * a.C * 2 + i) * SA_W, v);
+            a.pq[((size_t)n * gridDim.x + blockIdx.x) * a.C * 2 + i] = v;
         }
     }
 }
 
 // ---- kernel 2: finalize (one block per image) --------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const unsigned long long* __restrict__ pq, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __restrict__ pq, int splits, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ film,
                                                               int film_ld, double* __restrict__ sg, unsigned long long* __restrict__ dgb,
                                                               float* __restrict__ dfilm, int dfilm_ld, int C, int G,
@@ -193,7 +194,11 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const unsigned lon
     for (int i = tid; i < 2 * G * SA_W; i += 256) s12c[i] = 0ull;
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
-        const double P = sa_load(pq + (((size_t)n * C + c) * 2) * SA_W), Q = sa_load(pq + (((size_t)n * C + c) * 2 + 1) * SA_W);
+        double P = 0.0, Q = 0.0;                           // the pixel blocks of image n, in index order
+        for (int z = 0; z < splits; ++z) {
+            const double2 v = *reinterpret_cast<const double2*>(pq + (((size_t)n * splits + z) * C + c) * 2);
+            P += v.x; Q += v.y;
+        }
         const double g = gamma[c], b = beta[c];
         const double one_sc = film ? 1.0 + (double)film[(size_t)n * film_ld + c] : 1.0;
         sa_add(dgb + (size_t)(2 * c) * SA_W, one_sc * P);
@@ -334,10 +339,18 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
 
 }  // namespace
 
-// Workspace (8-byte elements): pq [N][C][2][SA_W] limb cells + dgb [C][2][SA_W] limb cells + sg [N][G][2] fp64 + coef [N][G] float4
-// (= 2 doubles each)
+// pixel blocks per image of the reduce pass (its grid.x; upper bound used by the workspace query)
+static int gn_bwd_splits(int N, int HW, int C) {
+    const int C4 = C / 4, PP = C4 <= 256 ? 256 / C4 : 1;
+    int splits = cdiv(1024, N);
+    int ppb = cdiv(HW, splits);
+    if (ppb < PP * 8) ppb = PP * 8;
+    return cdiv(HW, ppb);
+}
+// Workspace (8-byte elements): pq [N][splits <= ceil(1024 / N)][C][2] fp64 partials + dgb [C][2][SA_W] limb cells + sg [N][G][2] fp64 +
+// coef [N][G] float4 (= 2 doubles each)
 extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
-    return (size_t)N * C * 2 * SA_W + (size_t)C * 2 * SA_W + (size_t)N * G * 2 + (size_t)N * G * 2;
+    return (size_t)N * cdiv(1024, N > 0 ? N : 1) * C * 2 + (size_t)C * 2 * SA_W + (size_t)N * G * 2 + (size_t)N * G * 2;
 }
 
 extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats_, const float* gamma, const float* beta,
@@ -364,11 +377,12 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
     a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr; a.dgb = nullptr; a.dgamma = nullptr; a.dbeta = nullptr;
     const int HW = H * W;
     if (norm) {
-        unsigned long long* pq = reinterpret_cast<unsigned long long*>(ws);
-        unsigned long long* dgb = pq + (size_t)N * C * 2 * SA_W;
+        const int nsplit = gn_bwd_splits(N, HW, C);
+        double* pq = ws;
+        unsigned long long* dgb = reinterpret_cast<unsigned long long*>(pq + (size_t)N * nsplit * C * 2);
         double* sg = reinterpret_cast<double*>(dgb + (size_t)C * 2 * SA_W);
         float4* coef = reinterpret_cast<float4*>(sg + (size_t)N * G * 2);
-        bbdm_zero_async(ws, 8 * ((size_t)N * C * 2 * SA_W + (size_t)C * 2 * SA_W), st);
+        bbdm_zero_async(dgb, 8 * ((size_t)C * 2 * SA_W), st);
         a.pq = pq; a.sg = sg; a.coef = coef;
         const int C4 = C / 4;
         const int PP = C4 <= 256 ? 256 / C4 : 1;
@@ -380,7 +394,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
         if (C4 <= 256) hipLaunchKernelGGL(gn_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, a, ppb);
         else if (C4 <= 512) hipLaunchKernelGGL(gn_bwd_reduce_kernel<2>, grid, dim3(256), 0, st, a, ppb);
         else hipLaunchKernelGGL(gn_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, a, ppb);
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, pq, gamma, beta, film, film_ld, sg, dgb, dfilm,
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), 0, st, pq, splits, gamma, beta, film, film_ld, sg, dgb, dfilm,
                            dfilm_ld, C, G, stats, coef, (double)HW * (C / G), eps);
         a.dgb = dgb; a.dgamma = dgamma; a.dbeta = dbeta;
     }

@@ -25,7 +25,6 @@ inherited PyTorch modules run -- that is the reference's own path, not a fallbac
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Optional
 
 import torch
@@ -42,19 +41,16 @@ class _Flags:
     """The execution-plan switches ``_Plan``'s emitters read from their owner (``UNetModel`` for the UNet)."""
 
     def __init__(self):
-        self.winograd = int(os.environ.get("BBDM_WINOGRAD", "6"))
-        self.winograd_fuse_groupnorm = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
-        self.winograd_small = os.environ.get("BBDM_WINOGRAD_SMALL", "1") != "0"
-        self.upsample_phases = os.environ.get("BBDM_UPSAMPLE_PHASES", "1") != "0"
-        self.train_graph = False
-        self.gemm_bf3 = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
-        self.gemm_bf3p = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
-        self.fuse_groupnorm = False
-        self.fuse_stats = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
+        self.winograd = 6
+        self.winograd_fuse_groupnorm = True
+        self.winograd_small = True
+        self.upsample_phases = True
+        self.gemm_bf3 = True
+        self.gemm_bf3p = True
+        self.fuse_stats = True
         self.bf3_min_tiles = 256
-        self.conv1x1_pipe = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
-        self.conv1x1_small = os.environ.get("BBDM_CONV1X1_SMALL", "1") != "0"
-        self.gn_in_transform = int(os.environ.get("BBDM_GN_IN_TRANSFORM", "1024"))
+        self.conv1x1_small = True
+        self.gn_in_transform = 1024
         self.fp32_v_max_cout = 128
         self.upsample_f72 = True
         self.winograd_wgrad = 0             # (inference plans only)

@@ -15,7 +15,6 @@ There is no PyTorch fallback: without the HIP library, or on a non-GPU tensor, `
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -683,64 +682,52 @@ class UNetModel(nn.Module):
         self.max_cached_plans = 4
         self._freqs: Optional[torch.Tensor] = None
         self.op_profile: Optional[list] = None      # set to a list to collect per-op HIP-event timings (bench.py)
-        hg = os.environ.get("BBDM_HIP_GRAPH")       # None = automatic (small latents), True / False = force (BBDM_HIP_GRAPH=1 | 0)
-        self.hip_graph: Optional[bool] = None if hg is None else hg == "1"
-        # BBDM_TRAIN_GRAPH=1: training plans replay their forward and each backward segment as hipGraphs.  Off by default: measured on the
-        # LBBDM-f4 micro-step (C4) 74.7 vs 75.2 ms eager -- the GPU is not waiting for the host; what separates the 67 ms of plan
-        # kernels from the step is dispatch latency between ~1300 dependent launches, which a graph replay pays as well.
-        self.train_graph: bool = os.environ.get("BBDM_TRAIN_GRAPH", "0") == "1"
-        # Fold GroupNorm/FiLM/SiLU into the consuming conv's LDS staging (inference).  Measured on MI355X it trades a
-        # 2.5 % streaming pass for ~5 % more time in the MFMA-bound conv at 256^2 (VALU + coefficient loads on the
-        # staging path), so it is off by default; kept for the small-latent regime and as a tested kernel feature.
-        self.fuse_groupnorm: bool = False
-        # 3x3 convolutions of wide layers through Winograd F(4x4,3x3) / F(2x2,3x3) (csrc/winograd.hip; `winograd_tile`
-        # picks per layer).  Plans are cached per setting, so this can be changed between calls (A/B runs).
-        # BBDM_WINOGRAD: largest output tile allowed: 6 (default), 4, 2, or 0 = direct kernel everywhere.
-        self.winograd: int = int(os.environ.get("BBDM_WINOGRAD", "6"))
-        self.winograd_fuse_groupnorm: bool = os.environ.get("BBDM_WINOGRAD_FUSE_GN", "1") != "0"
-        # BBDM_WINOGRAD_SMALL=0: the small 3x3 layers (< 256 F(4x4) tiles) keep the direct f32-MFMA kernel (round-2 plan)
-        self.winograd_small: bool = os.environ.get("BBDM_WINOGRAD_SMALL", "1") != "0"
-        # BBDM_UPSAMPLE_PHASES=0: conv3x3(nearest x2 (x)) layers of inference plans transform the UPSAMPLED tensor (round-2 plan)
-        # instead of running their four phase filters on x (input transform and GEMM A operand 4x smaller)
-        self.upsample_phases: bool = os.environ.get("BBDM_UPSAMPLE_PHASES", "1") != "0"
-        # Winograd tile GEMMs on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six product terms;
-        # csrc/gemm_bf3.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  BBDM_GEMM_BF3=0: f32 MFMA.
-        self.gemm_bf3: bool = os.environ.get("BBDM_GEMM_BF3", "1") != "0"
+        # ---- planner attributes (A/B runs and tests set them on the model before the first plan of a shape is built; plans are
+        # cached per setting; nothing here reads the environment -- bench.py's --set ATTR=INT covers command-line A/Bs) ----
+        # inference plans replay their launches as ONE hipGraph (None = yes on a GPU; False = launch by launch, e.g. under rocprofv3)
+        self.hip_graph: Optional[bool] = None
+        # 3x3 convolutions of wide layers through Winograd F(m x m, 3x3) (csrc/winograd.hip; `winograd_tile` picks per layer):
+        # largest output tile allowed: 6 (default), 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B)
+        self.winograd: int = 6
+        # fold GroupNorm -> FiLM -> SiLU (and an up-sampling ResBlock's nearest x2) into the Winograd input transform
+        self.winograd_fuse_groupnorm: bool = True
+        # small 3x3 layers (128 ... 8192 F(2x2) tiles) on F(2x2,3x3) + the bf16x3 GEMM instead of the direct f32-MFMA kernel
+        self.winograd_small: bool = True
+        # conv3x3(nearest x2 (x)) of inference plans as four phase filters on x itself (input transform and GEMM A operand 4x smaller)
+        self.upsample_phases: bool = True
+        # Winograd tile GEMMs and wide 1x1 layers on the BF16 matrix core with fp32 accuracy (three-way exact operand split, six
+        # product terms; csrc/gemm_bf3*.hip) instead of the f32 MFMA, which gfx950 runs at 1/16 of the bf16 rate.  False: f32 MFMA
+        # (bench.py's strict-f32 A/B)
+        self.gemm_bf3: bool = True
         # ... with the A operand split into its three bf16 planes by the Winograd input transform (csrc/gemm_bf3p.hip: the GEMM's main
-        # loop is LDS-DMA copies + MFMAs); layers whose fp32 V the training backward re-reads keep the kernel above.  0: never.
-        self.gemm_bf3p: bool = os.environ.get("BBDM_GEMM_BF3P", "1") != "0"
-        # 1x1 layers with fewer 256x128 output tiles keep the split-K f32 kernel (one wave of tiles); BBDM_BF3_MIN_TILES for the A/B
-        self.bf3_min_tiles: int = int(os.environ.get("BBDM_BF3_MIN_TILES", "256"))
-        # wide 1x1 layers whose Cout fills 256-column tiles on the pipelined fp32-A kernel (gemm_bf3q_pipe_kernel); BBDM_CONV1X1_PIPE=0:
-        # gemm_bf3.hip everywhere (A/B; bit-equal results)
-        self.conv1x1_pipe: bool = os.environ.get("BBDM_CONV1X1_PIPE", "1") != "0"
-        # 1x1 layers BELOW bf3_min_tiles (the latent / 64^2-pixel configurations: qkv / proj_out, skip projections) on the small-problem
-        # bf16x3 kernel (csrc/gemm_bf3p.hip: gemm_bf3s_kernel, one launch, 64 channels per step) instead of the split-K f32-MFMA kernel
-        # + its reduction pass; BBDM_CONV1X1_SMALL=0: round 3's path (A/B)
-        self.conv1x1_small: bool = os.environ.get("BBDM_CONV1X1_SMALL", "1") != "0"
+        # loop is LDS-DMA copies + MFMAs).  False: gemm_bf3.hip on fp32 V (tests: the two pipelines against each other)
+        self.gemm_bf3p: bool = True
+        # 1x1 layers with fewer 256 x 128 output tiles than this leave the wide bf16x3 kernels for the small-problem kernel
+        self.bf3_min_tiles: int = 256
+        # ... csrc/gemm_bf3p.hip: gemm_bf3s_kernel (one launch, 64 channels per step); False: the split-K f32-MFMA kernel + reduction
+        self.conv1x1_small: bool = True
         # inference plans: a Winograd layer of at most this many tiles forms its fused GroupNorm coefficients INSIDE its input
         # transform (bbdm_winograd_input_bf3p_gn_f32) instead of reading what a bbdm_groupnorm_coeffs_f32 launch wrote -- one launch
-        # fewer per GroupNorm, the same bits: C5 3.25 -> 3.22 ms, C1 3.84 -> 3.80 (a coefficient launch costs ~2 us inside the replayed
-        # graph, the fold ~1 us of extra latency in its consumer); above it every thread repeating the fp64 fold costs the HBM-bound
-        # transforms more than the launch (round 4: +2.3 ms on the C2 step).  BBDM_GN_IN_TRANSFORM=0: always the separate launch (A/B)
-        self.gn_in_transform: int = int(os.environ.get("BBDM_GN_IN_TRANSFORM", "1024"))
+        # fewer per GroupNorm, the same bits (C5 3.25 -> 3.22 ms); above it every thread repeating the fp64 fold costs the HBM-bound
+        # transforms more than the launch (round 4: +2.3 ms on the C2 step).  0: always the separate launch
+        self.gn_in_transform: int = 1024
         # GroupNorm statistics accumulated by the kernel that produces the tensor (conv epilogue / Winograd output transform)
-        # instead of a separate pass that re-reads it.  BBDM_FUSE_STATS=0: stand-alone bbdm_groupnorm_stats_f32 everywhere.
-        self.fuse_stats: bool = os.environ.get("BBDM_FUSE_STATS", "1") != "0"
+        # instead of a separate pass that re-reads it.  False: stand-alone bbdm_groupnorm_stats_f32 everywhere (tests)
+        self.fuse_stats: bool = True
         # inference: Winograd layers whose tile GEMM is HBM-bound -- at most this many output channels and >= 512 MB of plane bytes, i.e.
         # the Cout = 128 layers of the 256^2 level (10 - 17 B of operands per 256 FLOP) -- keep V as fp32 rows (4 B per element instead
         # of the planes' 6; gemm_bf3.hip splits them under its idle matrix pipe): a third fewer operand bytes in both the input
-        # transform and the GEMM (round 5).  0 = planes everywhere.
+        # transform and the GEMM (round 5: C2 -1.1 ms).  0 = planes everywhere
         self.fp32_v_max_cout: int = 128
         # inference: the four phase filters of an up-sampling conv as 2 x 2 filters, F(7x7, 2x2) on the 8-point transform, where the
-        # layer would take F(6x6, 3x3) (see phase_filter_tile); False = F(6x6, 3x3) on the zero-padded 3 x 3 phase filters (A/B)
+        # layer would take F(6x6, 3x3) (see phase_filter_tile; round 5: C2 -1.7 ms); False = F(6x6, 3x3) on the zero-padded 3 x 3 filters
         self.upsample_f72: bool = True
         # training: set by dist_utils.accumulation_sync for the micro-steps whose parameter gradients no hook has to observe -- the
         # backward then adds them to the existing ``.grad`` tensors itself (bbdm_amd/autograd.py: _accumulate_in_place)
         self.grad_in_place: bool = False
-        # Training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
-        # BBDM_WINOGRAD_WGRAD=0: the direct kernel (conv_wgrad.hip) everywhere.
-        self.winograd_wgrad: int = int(os.environ.get("BBDM_WINOGRAD_WGRAD", "6"))
+        # training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
+        # 0: the direct kernel (conv_wgrad.hip) everywhere (tests)
+        self.winograd_wgrad: int = 6
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -798,9 +785,9 @@ class UNetModel(nn.Module):
 
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
-        key = (N, H, W, x.device.index, x.shape[1], training, self.fuse_groupnorm, self.winograd,
+        key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
-               self.winograd_small, self.upsample_phases, self.conv1x1_pipe, self.conv1x1_small, self.gn_in_transform,
+               self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
                self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
         if plan is None:
@@ -918,11 +905,10 @@ class _Plan:
         self.film_b = torch.empty(off, **f32)
         self._film_key = None
         # inference: the concatenated FiLM weight is also kept PACKED (csrc/embed.hip: linear_packed_kernel streams it sequentially,
-        # 51 MB at HBM rate instead of 1 TB/s); repacked whenever the weights change.  Training plans (new weights every step) and
-        # BBDM_LINEAR_PACKED=0 keep bbdm_linear_f32.
+        # 51 MB at HBM rate instead of 1 TB/s); repacked whenever the weights change.  Training plans (new weights every step) keep
+        # bbdm_linear_f32.
         self.film_wp = None
-        if (off and not training and os.environ.get("BBDM_LINEAR_PACKED", "1") != "0"
-                and self.lib.bbdm_linear_packed_supported(min(N, 32), ted, off)):
+        if off and not training and self.lib.bbdm_linear_packed_supported(min(N, 32), ted, off):
             self.film_wp = torch.empty(self.lib.bbdm_linear_packed_bytes(off, ted), dtype=torch.uint8, device=device)
 
         # ---- input / output --------------------------------------------------------------------------------------
@@ -1150,11 +1136,11 @@ class _Plan:
         Inference plans do not materialise the normalised tensor: they emit the statistics + a tiny per-(image, channel)
         coefficient kernel and return (x itself, the fused-producer arguments of bbdm_conv2d_nhwc_f32).  Training plans
         keep the explicit apply pass (the backward re-reads its output for the weight gradient).  The producer is folded
-        into the direct conv kernel only on request (``fuse_groupnorm``: it costs more MFMA stalls than the pass it
+        into the direct conv kernel only for the narrow head (``fuse_direct``; elsewhere it costs more MFMA stalls than the pass it
         removes) but always into the HBM-bound Winograd input transform of ``consumer``, where it is
         free."""
         up = 2 if upsample else 1         # (``upsample``: the consumer convolves the nearest x2 upsampling of the activated tensor)
-        fuse = fuse_direct or self.m.fuse_groupnorm or (consumer is not None and self.m.winograd_fuse_groupnorm
+        fuse = fuse_direct or (consumer is not None and self.m.winograd_fuse_groupnorm
                                                         and self._winograd_ok(consumer, up * x.H, up * x.W, x.C))
         assert not upsample or (fuse and not self.training)
         if self.training:
@@ -1351,7 +1337,7 @@ class _Plan:
             # bf16x3 GEMM with bias + residual in its epilogue (csrc/gemm_bf3.hip); small problems keep the split-K f32 kernel
             # ... on the pipelined kernel (csrc/gemm_bf3p.hip: gemm_bf3q_pipe_kernel, 200 - 214 instead of 165 - 192 TFLOP/s) where
             # Cout fills 256-column tiles; its 128-column form loses to gemm_bf3.hip's 8-wave workgroups
-            q = self.m.conv1x1_pipe and (-(-cout // 128) * 128) % 256 == 0
+            q = (-(-cout // 128) * 128) % 256 == 0
             pb = self._packed(_PackedConvBf3q if q else _PackedConvBf3, mod.weight, mod.bias, x.C)
             self.convs.append(pb)
             rec = self._op(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32") if q else "bbdm_conv1x1_bf3_f32", x, x.ld,
@@ -1723,7 +1709,7 @@ class _Plan:
             pixels = x_in.N * x_in.H * x_in.W
             if (ks == 1 and m.gemm_bf3 and x_in.C == cin and lib.bbdm_gemm_bf3_supported(pixels, dy.C, x_in.C)
                     and (pixels // 256) * -(-x_in.C // 128) >= m.bf3_min_tiles):
-                q = m.conv1x1_pipe and (-(-x_in.C // 128) * 128) % 256 == 0
+                q = (-(-x_in.C // 128) * 128) % 256 == 0
                 pk = _PackedDgradBf3(w, dy.C, planes=q)  # wide 1x1 layers: dX = dY W on the bf16x3 GEMM, like their forward
                 self.dconvs.append(pk)
                 self._bop(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32") if q else "bbdm_conv1x1_bf3_f32", dy, dy.ld,
@@ -2033,31 +2019,6 @@ class _Plan:
         ops = self.bops[lo:hi] + (self.bops_x0 if (last and need_dx) else [])
         check = _lib.check
         prof = self.m.op_profile
-        if prof is None and self._want_graph():
-            # hipGraph replay of this segment's launches; one graph per (segment, flat gradient buffer, parameter storage): the
-            # gradient plan alternates between <= 2 flat buffers (_pick_flat_grad).  The first call with a key runs eagerly
-            # (kernel attributes, caches), the second captures.
-            gkey = (k, bool(last and need_dx), self._flat_grad.data_ptr(), self._param_key)
-            if not hasattr(self, "_bgraphs"):
-                self._bgraphs, self._bwarm = {}, set()
-            g = self._bgraphs.get(gkey)
-            if g is None and gkey in self._bwarm:
-                if len(self._bgraphs) >= 4 * len(self.bsegs):          # parameter storage keeps moving: do not pile up graphs
-                    self._bgraphs.clear()
-                torch.cuda.current_stream(self.device).synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    cs = _lib.current_stream(self.device)
-                    for name, args in ops:
-                        rc = getattr(lib, getattr(name, "entry", name))(*(a.resolve() if hasattr(a, "resolve") else a for a in args), cs)
-                        if rc != 0:
-                            check(rc, name)
-                self._bgraphs[gkey] = g
-            if g is not None:
-                g.replay()
-                ops = ()
-            else:
-                self._bwarm.add(gkey)
         for name, args in ops:
             fn = getattr(lib, getattr(name, "entry", name))
             if prof is None:
@@ -2218,13 +2179,12 @@ class _Plan:
     def _want_graph(self) -> bool:
         """Inference plans replay their ~200 launches as ONE hipGraph: at the small latents it removes most of the step (launch-bound),
         at 256^2 / batch 16 -- launches of milliseconds -- still 1.4 ms of the 114 (the ~1.5 us boundaries between dependent launches and
-        the host's per-call work; measured round 3).  ``UNetModel.hip_graph`` = True / False overrides (BBDM_HIP_GRAPH=1 | 0).  Training
-        plans replay their forward and each backward segment the same way on request (``UNetModel.train_graph`` / BBDM_TRAIN_GRAPH=1;
-        measured gain on C4: 0.6 %)."""
+        the host's per-call work; measured round 3).  ``UNetModel.hip_graph`` = True / False overrides.  Training plans launch kernel by
+        kernel (replaying their forward and backward segments as graphs measured 0.6 % on C4 in round 3 and was removed in round 5)."""
         pref = self.m.hip_graph
         if pref is not None:
             return bool(pref)
-        if self.device.type != "cuda" or (self.training and not self.m.train_graph):
+        if self.device.type != "cuda" or self.training:
             return False
         return True
 

@@ -331,7 +331,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipeline", action="store_true", help="c3 / c5: skip the first-stage (VQGAN encode / decode) timing")
     ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
-    ap.add_argument("--fuse-gn", action="store_true", help="experiment: fold GroupNorm/SiLU into the conv staging")
     ap.add_argument("--set", action="append", default=[], metavar="ATTR=INT",
                     help="A/B runs: set a planner attribute of UNetModel (e.g. fp32_v_max_cout=0) before the first plan is built")
     ap.add_argument("--no-f32mfma", action="store_true", help="c2: skip the strict-f32-MFMA A/B steps after the timed region")
@@ -421,7 +420,6 @@ def run_workload(args, env):
     model = bbdm_amd.BrownianBridgeModel(cfg)
     sd = synth_state(model.denoise_fn)
     model.denoise_fn.load_state_dict(sd, strict=True)
-    model.denoise_fn.fuse_groupnorm = bool(args.fuse_gn)
     for kv in args.set:
         k, v = kv.split("=")
         if not hasattr(model.denoise_fn, k):
@@ -551,7 +549,7 @@ def run_workload(args, env):
     img = state["img"]
     if not bool(torch.isfinite(img).all()):
         raise RuntimeError("non-finite sample")
-    # the same step with the tile GEMMs / 1x1 layers on the f32 MFMA (BBDM_GEMM_BF3=0): a driver-timed number for a reader who
+    # the same step with the tile GEMMs / 1x1 layers on the f32 MFMA (UNetModel.gemm_bf3 = False): a driver-timed number for a reader who
     # does not accept the bf16x3 emulation as fp32 arithmetic (5 steps after 2 warm-ups, outside the timed region)
     f32mfma_ms = None
     if args.workload == "c2" and not training and world == 1 and not args.no_f32mfma and model.denoise_fn.gemm_bf3:
@@ -649,7 +647,7 @@ def run_workload(args, env):
     # The dominant kernel.  With the default plan the Winograd tile GEMMs run on gemm_bf3_kernel (csrc/gemm_bf3.hip): fp32
     # arithmetic emulated EXACTLY-to-fp32-rounding on the BF16 matrix core (each operand split into 3 bf16, 6 product terms,
     # fp32 accumulate).  Its roofline is the dense bf16 MFMA peak; one fp32-equivalent FLOP costs 6 bf16 FLOP, so the bound
-    # for the algorithmic (fp32) FLOPs is PEAK_BF16 / 6.  With BBDM_GEMM_BF3=0 (or where the shape gate rejects a layer)
+    # for the algorithmic (fp32) FLOPs is PEAK_BF16 / 6.  With gemm_bf3 = False (or where the shape gate rejects a layer)
     # the GEMMs run on conv_igemm_f32 (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s) together with the direct convolutions.
     all_ops = list(plan0.ops) + (list(plan0.bops) if training else [])
     entries = [getattr(nm, "entry", "") for nm, _ in all_ops if nm == "bbdm_winograd_gemm_f32"]
@@ -671,11 +669,12 @@ def run_workload(args, env):
     achieved = (flops_per_launch / (avg_launch_ms * 1e-3)) / 1e12 if avg_launch_ms > 0 else 0.0
     # whole step against the matrix peaks: time-at-peak of every MFMA kernel's work / step time
     c1x1 = both("bbdm_conv1x1_bf3_f32")                             # wide 1x1 convs / Linears on the same bf16x3 kernel
-    # the attention FORWARD issues v_mfma_f32_32x32x16_bf16 as well (csrc/attention.hip, BBDM_ATTN_BF3: 1 = Q K^T and P V -- head
+    # the attention FORWARD issues v_mfma_f32_32x32x16_bf16 as well (csrc/attention.hip, library option attn_bf3: 1 = Q K^T and P V -- head
     # widths 32 / 64 --, 2 or head width 16 = only Q K^T, 0 = f32 MFMA): its FLOPs are priced at the peak of the datatype it issues
     # (round 3 priced them at the f32 peak, which overstated frac_step by 4 points); the attention backward is on the f32 MFMA.
     attn = by.get("bbdm_attention_f32", [0, 0.0, 0.0])
-    attn_mode = int(os.environ.get("BBDM_ATTN_BF3", "1"))
+    from bbdm_amd import _lib as _bl
+    attn_mode = _bl.get_option("attn_bf3")
     attn_ch = next((oa[8] for nm, oa in plan0.ops if nm == "bbdm_attention_f32"), 64)
     attn_bf3_share = 0.0 if attn_mode == 0 else (1.0 if (attn_mode == 1 and attn_ch in (32, 64)) else 0.5)
     bf3_flops = ((wino[2] if use_bf3 else 0.0) + c1x1[2] + attn_bf3_share * attn[2]) / max(1, args.steps)

@@ -58,7 +58,7 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert wt(16, 8, 8, 1024, 1024, 6, small=False) == 0
     tiny = unet.UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
                           attention_resolutions=(), channel_mult=(1,), num_head_channels=32, condition_key="nocond")
-    assert tiny.winograd == int(__import__("os").environ.get("BBDM_WINOGRAD", "6"))      # the default cap
+    assert tiny.winograd == 6      # the default cap
     assert lib_tiles(6, 16, 64, 64) == 2048 and lib_tiles(4, 16, 64, 64) == 4096 and lib_tiles(2, 3, 8, 12) == 256
 
 

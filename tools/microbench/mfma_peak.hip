@@ -109,8 +109,13 @@ __global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __rest
         }
         if (TRAFFIC >= 3)
             __builtin_nontemporal_store(acc[it & 3][0], stream_dst + (((((size_t)it * gridDim.x + blockIdx.x) * 16 + wave) * 64 + lane) & ((1u << 29) - 1)));
-        if (TRAFFIC >= 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        // (3: the HBM copy and the store are never consumed -- up to four iterations of them stay in flight, as the real kernel's
+        // two-chunks-ahead pipeline keeps its copies; the L2-resident copies behind them are then not waited for either: this row
+        // measures what the traffic does to the MFMA rate, not a correct pipeline)
+        if (TRAFFIC == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        if (TRAFFIC >= 3) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); __syncthreads(); }
     }
+    if (TRAFFIC >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
     float s = 0.f;
 #pragma unroll

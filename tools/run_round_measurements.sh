@@ -14,17 +14,17 @@ R=$GRAFT_REPO_ROOT
 ( timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --dump-ops $O/c2_per_launch.md > $O/bench_c2.json 2> $O/bench_c2.err )
 for w in c1 c3 c5; do ( timeout 300 python bench.py --workload $w --no-cpu > $O/bench_$w.json 2> $O/bench_$w.err ); done
 ( timeout 600 python bench.py --workload c4 --no-cpu --dump-ops $O/c4_per_launch.md > $O/bench_c4.json 2> $O/bench_c4.err )
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c2 -o c2 -- env BBDM_HIP_GRAPH=0 python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/prof_c2.log 2>&1 )
-python tools/rocprof_summary.py $(find $O/prof_c2 -name "*.db" | head -1) "BBDM_HIP_GRAPH=0 python bench.py --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras (eager launches: a graph capture would run the first forward twice)" > $O/c2_kernel_stats.md 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c2 -o c2 -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/prof_c2.log 2>&1 )
+python tools/rocprof_summary.py $(find $O/prof_c2 -name "*.db" | head -1) "python bench.py --set hip_graph=0 --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras (eager launches: a graph capture would run the first forward twice)" > $O/c2_kernel_stats.md 2>&1
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c4 -o c4 -- python $R/bench.py --workload c4 --steps 4 --warmup 1 --no-cpu --no-parity > $R/$O/prof_c4.log 2>&1 )
 python tools/rocprof_summary.py $(find $O/prof_c4 -name "*.db" | head -1) "python bench.py --workload c4 --steps 4 --warmup 1 --no-cpu --no-parity (training: 4 priming + 1 warm-up + 4 timed + 4 per-op-profiled micro-steps = 13)" > $O/c4_kernel_stats.md 2>&1
-CMD="BBDM_HIP_GRAPH=0 python bench.py --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras"
-( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/$O/pmc_fetch -o pmc -- env BBDM_HIP_GRAPH=0 python $R/bench.py --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_fetch.log 2>&1 )
-( cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/$O/pmc_write -o pmc -- env BBDM_HIP_GRAPH=0 python $R/bench.py --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_write.log 2>&1 )
+CMD="python bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras"
+( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/$O/pmc_fetch -o pmc -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_fetch.log 2>&1 )
+( cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/$O/pmc_write -o pmc -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_write.log 2>&1 )
 # 2 forward passes were profiled (1 warm-up + 1 timed); SURVEY.md 8(d): 92.3 GB of algorithmic HBM traffic per C2 step
 python tools/rocprof_pmc.py $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) "$CMD" 2 92.3e9 > $O/pmc_c2_traffic.json 2> $O/pmc_err.log
-( cd /tmp && timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $R/$O/pmc_sq -o pmc -- env BBDM_HIP_GRAPH=0 python $R/bench.py --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_sq.log 2>&1 )
-( cd /tmp && timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES --kernel-trace -d $R/$O/pmc_lds -o pmc -- env BBDM_HIP_GRAPH=0 python $R/bench.py --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_lds.log 2>&1 )
+( cd /tmp && timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d $R/$O/pmc_sq -o pmc -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_sq.log 2>&1 )
+( cd /tmp && timeout 400 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES --kernel-trace -d $R/$O/pmc_lds -o pmc -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_lds.log 2>&1 )
 python tools/rocprof_counters.py --json $(find $O/pmc_sq -name "*.db" | head -1) > $O/pmc_c2_mfma_util.json 2>> $O/pmc_err.log
 python tools/rocprof_counters.py $(find $O/pmc_sq -name "*.db" | head -1) $(find $O/pmc_lds -name "*.db" | head -1) > $O/pmc_c2_counters.md 2>> $O/pmc_err.log
 rm -rf $O/prof_c2 $O/prof_c4 $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_lds
