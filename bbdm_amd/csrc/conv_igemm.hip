@@ -54,8 +54,9 @@ struct ConvArgs {
     // Winograd path (16 transformed-domain GEMMs in one launch); bias, residual and split-K are off in this mode.
     int batch;
     size_t xz, wz, oz;
-    // GroupNorm statistics of the output accumulated by this launch (VAR bit 3; see winograd.hip: StatArgs): fp64 [N][32][2]
-    // accumulators of up to two consumers, their group width and the channel offset of `out` in their tensor
+    // GroupNorm statistics of the output accumulated by this launch (VAR bit 3; see winograd.hip: StatArgs): the exact limb
+    // accumulators [N][32][2][SA_W] 64-bit words (stats_acc.h; bbdm_groupnorm_stats_bytes(N, 32) bytes each) of up to two consumers,
+    // their group width and the channel offset of `out` in their tensor
     unsigned long long* st_s[2];
     int st_cpg[2], st_coff[2];
 };

@@ -237,10 +237,13 @@ __global__ void __launch_bounds__(256) linear_packed_kernel(const float* __restr
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned st = ring0 + (unsigned)((kb % LP_NS) * LP_BLOCK);
         f32x4 wv[LP_KB / 8];
-#pragma unroll
-        for (int q = 0; q < LP_KB / 8; ++q)               // (hand-written: a plain LDS load after an LDS-DMA copy is guarded with vmcnt(0))
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wv[q]) : "v"(st), "n"(q * 1024));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]) :: "memory");
+        // (hand-written: a plain LDS load after an LDS-DMA copy is guarded with vmcnt(0).  The four reads AND their wait are ONE asm
+        // statement with early-clobber outputs: the compiler cannot place a copy or a spill of a destination register between a read and
+        // the wait it does not know about -- round-4 advisor finding)
+        static_assert(LP_KB / 8 == 4, "the fragment reads below are written out for four 16-byte pieces");
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                     "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]) : "v"(st) : "memory");
         if (kb + LP_NS - 1 < nkb) issue(kb + LP_NS - 1, ring + ((kb + LP_NS - 1) % LP_NS) * LP_BLOCK);   // the stage block kb - 1 was read from
 #pragma unroll
         for (int q = 0; q < LP_KB / 8; ++q) {

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(const float* __restrict__
 }
 
 // Scalar variant for channels-per-group not a multiple of 4 (e.g. C = 32, 96, 192 with 32 groups: only the tiny
-// test configurations; every reference template has cpg % 4 == 0).  One thread per element, LDS fp64 atomics per group.
+// test configurations; every reference template has cpg % 4 == 0).  One thread per element, LDS limb cells (integer atomics) per group.
 __global__ void __launch_bounds__(256) gn_stats_scalar_kernel(const float* __restrict__ x, int ldx,
                                                               unsigned long long* __restrict__ stats, int HW, int C, int G,
                                                               int pix_per_block) {

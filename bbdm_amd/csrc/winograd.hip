@@ -1299,9 +1299,11 @@ extern "C" int bbdm_winograd_gemm_bf3p_f32(int m, const void* Vp, const void* b_
     return bbdm_winograd_gemm_bf3p_splitk_f32(m, Vp, b_planes, M, N, H, W, CinPad, Cout, 1, stream);
 }
 
-// stats0 / stats1 (each may be NULL): fp64 [N][32][2] GroupNorm accumulators (sum, sum of squares per image and group) of up
-// to two consumers of `out`; cpg = channels per group of that consumer (a multiple of 4), coff = channel offset of `out` in
-// the consumer's tensor.  The caller zeroes them; the kernel ADDS (several producers may fill one consumer's statistics).
+// stats0 / stats1 (each may be NULL): the GroupNorm accumulators (sum, sum of squares per image and group) of up to two consumers
+// of `out`, each bbdm_groupnorm_stats_bytes(N, 32) bytes = [N][32][2][SA_W] 64-bit limb words (stats_acc.h -- NOT [N][32][2] doubles:
+// a caller sizing them as doubles would under-allocate 4x); cpg = channels per group of that consumer (a multiple of 4), coff = channel
+// offset of `out` in the consumer's tensor.  The caller zeroes them; the kernel ADDS (several producers may fill one consumer's
+// statistics).
 extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bias, const float* residual, int ldr,
                                                      float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stats0,
                                                      int cpg0, int coff0, void* stats1, int cpg1, int coff1, int splits,

@@ -1328,6 +1328,9 @@ class _Plan:
             self._emit_winograd(x, x.C, pw, pre, upsample, H, W, residual, res_ld, dest, flags)
             return
         assert not upsample
+        # (_gn_folds_into_transform mirrors the choices above; if the two ever diverge, the statistics reference a _GnPre carries in
+        # place of the coefficients must not reach a kernel that reads it as ``pre_scale`` -- round-4 advisor finding)
+        assert not isinstance(pre, _GnPre), "a coefficient-folding producer reached a layer that is not a Winograd layer on the pre-split planes"
         ks = mod.weight.shape[2] if mod.weight.dim() == 4 else 1
         pixels = self.N * x.H * x.W
         if (ks == 1 and self.m.gemm_bf3 and (pre is None or pre[0] is None) and flags == 0
