@@ -137,7 +137,7 @@ int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packe
 size_t bbdm_winograd_tiles(int m, int N, int H, int W);
 /* The four phase filters of conv3x3(nearest x2 (x)) (Upsample.forward / the up-sampling ResBlock, openaimodel.py:111-121,259-264) as one
  * 3x3 convolution Cin -> 4 Cout on the low-resolution x (see BBDM_CONV_OUT_PHASES): w4 [4 Cout][Cin][3][3] from w [Cout][Cin][3][3].
- * Per axis the taps collapse to [w0, w1 + w2, 0] (phase 0) / [0, w0 + w1, w2] (phase 1): one fp32 addition per collapsed tap. */
+ * Per axis the taps collapse to [w0, w1 + w2, 0] (phase 0) / [0, w0 + w1, w2] (phase 1): one fp32 addition per collapsed tap.
  * m = 7 (round 5) runs those four filters as the 2 x 2 filters they are, F(7x7, 2x2) on the eight transform points of F(6x6, 3x3): 49
  * outputs per 64-point tile instead of 36.  bbdm_winograd_pack_weight_f32(7, w4, packed, 4 Cout, Cin, InPad, 0),
  * bbdm_winograd_tiles(7, N, H, W) = N ceil((H + 1) / 7) ceil((W + 1) / 7) (tile t reads x rows 7 t - 1 .. 7 t + 6; phase pa writes rows
