@@ -77,9 +77,9 @@ __global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 96 * 1024 / 16; i += 1024) reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(frags)[i & 8191];
     __syncthreads();
-    bf16x8 f[12];
+    bf16x8 f[8];                     // (8 resident fragments: with 12 the 128-register budget of a 16-wave workgroup spilled)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) f[i] = *reinterpret_cast<const bf16x8*>(lds + (wave * 12 + i) * 256 % (48 * 1024) + lane * 16);
+    for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const bf16x8*>(lds + (wave * 12 + i) * 256 % (48 * 1024) + lane * 16);
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -101,14 +101,14 @@ __global__ void __launch_bounds__(1024) mfma_traffic_stream(const bf16x8* __rest
 #pragma unroll
         for (int t = 0; t < 6; ++t) {               // six term groups of four MFMAs, two fragment reloads behind each
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[(2 * t + (i >> 1)) % 12], f[(2 * t + 6 + (i & 1)) % 12], acc[i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[(2 * t + (i >> 1)) % 8], f[(2 * t + 4 + (i & 1)) % 8], acc[i], 0, 0, 0);
             if (TRAFFIC >= 1) {
-                f[2 * t] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t) * 1024) % (48 * 1024) + lane * 16);
-                f[2 * t + 1] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t + 1) * 1024) % (48 * 1024) + lane * 16);
+                f[(2 * t) % 8] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t) * 1024) % (48 * 1024) + lane * 16);
+                f[(2 * t + 1) % 8] = *reinterpret_cast<const bf16x8*>(lds + stage + ((wave * 12 + 2 * t + 1) * 1024) % (48 * 1024) + lane * 16);
             }
         }
         if (TRAFFIC >= 3)
-            __builtin_nontemporal_store(acc[it & 3][0], stream_dst + (((((size_t)it * gridDim.x + blockIdx.x) * 16 + wave) * 64 + lane) & ((1u << 29) - 1)));
+            __builtin_nontemporal_store((float)lane, stream_dst + (((((size_t)it * gridDim.x + blockIdx.x) * 16 + wave) * 64 + lane) & ((1u << 29) - 1)));
         // (3: the HBM copy and the store are never consumed -- up to four iterations of them stay in flight, as the real kernel's
         // two-chunks-ahead pipeline keeps its copies; the L2-resident copies behind them are then not waited for either: this row
         // measures what the traffic does to the MFMA rate, not a correct pipeline)
