@@ -34,7 +34,14 @@ constexpr float LOG2E = 1.44269504088896340736f, LN2 = 0.69314718055994530942f;
 // key (r & 3) + 8 (r >> 2) + 4 hi, so registers 8 ks .. 8 ks + 7 -- keys {0-3, 8-11} + 4 hi + 16 ks -- are the lane's 8 k-slots of
 // K-step ks once split and packed pairwise (lane-local: no shuffles), and the transpose reads fetch exactly those keys.
 // 6 x 2 x CH/32 MFMAs of 32 cycles per key tile instead of 16 x CH/32 of 64.
-template <int CH, bool BQ, bool BV, int NW>
+// PIPE (round 5; BQ && BV): the VALU work that does not depend on the tile's own scores is issued BETWEEN the MFMAs instead of in
+// phases of its own.  The phased loop compiled to [24 MFMAs] [~160 VALU: softmax, P split] [12 MFMAs] [34 VALU] [12 MFMAs] [~80 VALU + 12
+// ds_write: K / V split of the next tile], and the kernel's time was the SUM of its matrix-pipe time and its VALU issue time (a wave's
+// VALU instructions hide under its own or another wave's MFMAs only ~5 per 32-cycle MFMA, and only when they are there to be issued).
+// Now the split + LDS stores of tile t + 1 are dealt between the 24 Q K^T MFMAs of tile t (one stage of 3 - 8 instructions behind each
+// MFMA, fenced with sched_barrier), K / V of tile t + 2 are requested right behind them into the same registers (they land under the
+// softmax and the P V product), and the P split of the second key half is dealt between the first MFMAs of the first half's P V.  Same arithmetic, same bits (tests: attention with option "attn_pipe" 0 / 1).
+template <int CH, bool BQ, bool BV, int NW, bool PIPE = false>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
                                                        const float* __restrict__ ksrc, const float* __restrict__ vsrc, int ldkv,
                                                        int hskv, float* __restrict__ out, int ldo, float* __restrict__ lse,
@@ -49,6 +56,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
     constexpr int NTHR = NW * 64, QB = NW * 32;
     constexpr int SLOTS = (KV4 + NTHR - 1) / NTHR;
     static_assert(!BV || (BQ && CH % 32 == 0), "the bf16x3 P V path needs whole 32-channel tiles and the split K path");
+    static_assert(!PIPE || (BQ && BV), "the interleaved loop exists for the bf16x3 path");
 
     constexpr int KS = CH / 16;                    // BQ: MFMA K-steps of 16 channels
     constexpr int KROWB = CH * 2 + 16;             // BQ: bytes per key row of one bf16 plane
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
     float m_run = -INFINITY, l_run = 0.f;
 
     float4 kreg[SLOTS], vreg[SLOTS];
-    auto load_tile = [&](int tile) {
+    auto load_tile_into = [&](int tile, float4 (&kreg)[SLOTS], float4 (&vreg)[SLOTS]) {
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int f = tid + s * NTHR;
@@ -136,9 +144,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
             }
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
+    auto load_tile = [&](int tile) { load_tile_into(tile, kreg, vreg); };
+    // one slot (a float4 of K and one of V per thread) of a staged tile: split + LDS stores
+    auto store_slot = [&](int buf, int s, const float4 (&kreg)[SLOTS], const float4 (&vreg)[SLOTS]) {
+        {
             const int f = tid + s * NTHR;
             if (f < KV4) {
                 const int key = f / (CH / 4), c = (f % (CH / 4)) * 4;
@@ -166,6 +175,37 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
             }
         }
     };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) store_slot(buf, s, kreg, vreg);
+    };
+    // PIPE: the K (part 0) or V (part 1) half of slot s of the tile held in kreg / vreg, in SIX stages of 3 - 8 instructions, one behind
+    // each of the six MFMAs of a K-step (the caller fences every stage with sched_barrier: source order IS issue order)
+    uint2 hp1, hp2, hp3;
+    float hr0, hr1;
+    auto store_half_stage = [&](int buf, int s, int part, int stage) {
+        const float4 a = part == 0 ? kreg[s] : vreg[s];
+        if (stage == 0) split2_a(a.x, a.y, hp1.x, hr0, hr1);
+        else if (stage == 1) split2_b(hr0, hr1, hp2.x, hp3.x);
+        else if (stage == 2) split2_a(a.z, a.w, hp1.y, hr0, hr1);
+        else if (stage == 3) split2_b(hr0, hr1, hp2.y, hp3.y);
+        else if (stage == 5) {
+            const int f = tid + s * NTHR;
+            const int key = f / (CH / 4), c = (f % (CH / 4)) * 4;
+            if (part == 0) {
+                unsigned char* kd = reinterpret_cast<unsigned char*>(kbuf + buf * KSTAGE) + key * KROWB + c * 2;
+                *reinterpret_cast<uint2*>(kd) = hp1;
+                *reinterpret_cast<uint2*>(kd + KPLANE) = hp2;
+                *reinterpret_cast<uint2*>(kd + 2 * KPLANE) = hp3;
+            } else {
+                unsigned char* vd = reinterpret_cast<unsigned char*>(vbuf + buf * VSTAGE) + (c >> 5) * VCT + ((c >> 4) & 1) * VSUB + key * 32 +
+                                    (c & 15) * 2;
+                *reinterpret_cast<uint2*>(vd) = hp1;
+                *reinterpret_cast<uint2*>(vd + VPLANE) = hp2;
+                *reinterpret_cast<uint2*>(vd + 2 * VPLANE) = hp3;
+            }
+        }
+    };
 
     if (CH < 32) {   // rows of V^T beyond CH are read by the MFMA A operand: keep them finite
         for (int i = tid; i < 2 * VSTAGE; i += NTHR) vbuf[i] = 0.f;
@@ -175,11 +215,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
     const int ntiles = (T + KT - 1) / KT;
     load_tile(0);
     store_tile(0);
+    if (PIPE) load_tile(1);                        // (rows beyond T load as zeros: harmless when there is no tile 1)
     __syncthreads();
 
     for (int tile = 0; tile < ntiles; ++tile) {
         const int buf = tile & 1;
-        if (tile + 1 < ntiles) load_tile(tile + 1);
+        if (!PIPE && tile + 1 < ntiles) load_tile(tile + 1);     // (PIPE: kreg / vreg already hold tile + 1, requested a tile ago)
 
         // ---- S^T = K Q^T ------------------------------------------------------------------------------------
         f32x16 s;
@@ -194,8 +235,22 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
                 bf16x8 kf[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(kb + p * KPLANE + ks * 32);
+                if constexpr (PIPE) {
+                    // ... with stage t of piece ks of the NEXT tile's staging behind MFMA t (K of slot ks / 2, then its V: 2 SLOTS == KS
+                    // pieces; unconditional -- behind the last tile it rewrites a stage nobody reads again -- so that it shares the
+                    // basic block of the MFMAs).  The MFMAs of a K-step form a dependent chain: the wave would otherwise sit out ~30
+                    // cycles behind each of them with its split still to do.
+                    static_assert(!PIPE || 2 * SLOTS == KS, "one staging piece per K-step");
 #pragma unroll
-                for (int t = 0; t < 6; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t]], qb3[ks][BF3_TB[t]], s, 0, 0, 0);
+                    for (int t = 0; t < 6; ++t) {
+                        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t]], qb3[ks][BF3_TB[t]], s, 0, 0, 0);
+                        store_half_stage(buf ^ 1, ks >> 1, ks & 1, t);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t]], qb3[ks][BF3_TB[t]], s, 0, 0, 0);
+                }
             }
         } else {
             const float* kb = kbuf + buf * KSTAGE + lq * KPITCH + hi * 4;
@@ -209,6 +264,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
             }
         }
 
+        if (PIPE) load_tile(tile + 2);      // the staging registers are free again: request the tile after next (rows beyond T: zeros);
+                                            // it lands under the softmax and the P V product of this tile
         // ---- online softmax over the 32 keys of this tile (16 here, 16 in lane^32) --------------------------------
         // (scores carry the factor log2 e -- folded into the q scale above -- so that the exponentials are bare v_exp_f32; keys
         // beyond T exist only in the last tile: the 32 compare / select pairs stay out of every other iteration)
@@ -251,16 +308,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
             // word (key row i >> 2, channel quad i & 3) and receives channel i, 4 consecutive keys
             const unsigned char* vt = reinterpret_cast<const unsigned char*>(vbuf + buf * VSTAGE) + ((lane >> 4) & 1) * VSUB +
                                       (4 * hi + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
+            bf16x8 pfs[2][3];                                   // P^T planes of the lane's 8 k-slots of K-step ks: registers 8 ks .. 8 ks + 7
+            unsigned pw[3][4];
+            float pr0, pr1;
+            auto split_p = [&](int ks) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) split2(s[8 * ks + 2 * d], s[8 * ks + 2 * d + 1], pw[0][d], pw[1][d], pw[2][d]);
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pfs[ks][p] = __builtin_bit_cast(bf16x8, make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]));
+            };
+            // PIPE: the split of key half 1 in eight stages behind the first eight MFMAs of key half 0
+            auto split_p1_stage = [&](int j) {
+                if (j < 8) {
+                    const int d = j >> 1;
+                    if ((j & 1) == 0) split2_a(s[8 + 2 * d], s[8 + 2 * d + 1], pw[0][d], pr0, pr1);
+                    else split2_b(pr0, pr1, pw[1][d], pw[2][d]);
+                }
+                if (j == 8)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) pfs[1][p] = __builtin_bit_cast(bf16x8, make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]));
+            };
+            if (PIPE) split_p(0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 pf[3];                                   // P^T planes of the lane's 8 k-slots: registers 8 ks .. 8 ks + 7
-                {
-                    unsigned w[3][4];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) split2(s[8 * ks + 2 * d], s[8 * ks + 2 * d + 1], w[0][d], w[1][d], w[2][d]);
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, make_uint4(w[p][0], w[p][1], w[p][2], w[p][3]));
-                }
+                if (!PIPE) split_p(ks);
+                const bf16x8 (&pf)[3] = pfs[ks];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
                     bf16x8 vf[3];
@@ -274,8 +346,17 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
                         vf[p] = __builtin_bit_cast(bf16x8, both);
                     }
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
+                    for (int t = 0; t < 6; ++t) {
                         o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[BF3_TA[t]], pf[BF3_TB[t]], o[ct], 0, 0, 0);
+                        if (PIPE && ks == 0) {
+                            split_p1_stage(ct * 6 + t);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                if (PIPE && ks == 0 && 6 * CT < 9) {            // (one channel tile: the stages that found no MFMA)
+#pragma unroll
+                    for (int j = 6 * CT; j < 9; ++j) split_p1_stage(j);
                 }
             }
         } else {
@@ -291,7 +372,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
             }
         }
 
-        if (tile + 1 < ntiles) store_tile(buf ^ 1);
+        if (!PIPE && tile + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -321,6 +402,7 @@ static int launch_attention(const float* q, int ldq, int hsq, const float* k, co
                             hipStream_t st) {
     // Q K^T and P V on the bf16x3 path (option attn_bf3 = 0: both on the f32 MFMA; 2: only Q K^T, the round-2 kernel -- for the A/B)
     const int bq = bbdm_option(BBDM_OPT_ATTN_BF3);
+    const bool pipe = bbdm_option(BBDM_OPT_ATTN_PIPE) != 0;           // the interleaved main loop (PIPE) of the full bf16x3 path
     // 4 waves (128 queries) per workgroup, three workgroups per CU (an 8-wave / 256-query form, K / V staged once per 256 queries,
     // measured 6.55 against 6.16 ms at C2 in round 3 and is gone)
     const int nw = 4;
@@ -331,8 +413,12 @@ static int launch_attention(const float* q, int ldq, int hsq, const float* k, co
     hipLaunchKernelGGL((attn_fwd_kernel<CH, BQ, BV, NW>), grid, dim3(NW * 64), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, \
                        lse, Tq, Tk, heads, nht, qscale, kscale)
 #define BBDM_ATTN_FWD_NW(CH, BQ, BV) BBDM_ATTN_FWD(CH, BQ, BV, 4)
-    if (ch == 64) { if (bq == 1) BBDM_ATTN_FWD_NW(64, true, true); else if (bq) BBDM_ATTN_FWD_NW(64, true, false); else BBDM_ATTN_FWD_NW(64, false, false); }
-    else if (ch == 32) { if (bq == 1) BBDM_ATTN_FWD_NW(32, true, true); else if (bq) BBDM_ATTN_FWD_NW(32, true, false); else BBDM_ATTN_FWD_NW(32, false, false); }
+#define BBDM_ATTN_FWD_P(CH)                                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_kernel<CH, true, true, 4, true>), grid, dim3(4 * 64), 0, st, q, ldq, hsq, k, v, ldkv, hskv, out, ldo, \
+                       lse, Tq, Tk, heads, nht, qscale, kscale)
+    if (ch == 64) { if (bq == 1 && pipe) BBDM_ATTN_FWD_P(64); else if (bq == 1) BBDM_ATTN_FWD_NW(64, true, true); else if (bq) BBDM_ATTN_FWD_NW(64, true, false); else BBDM_ATTN_FWD_NW(64, false, false); }
+    else if (ch == 32) { if (bq == 1 && pipe) BBDM_ATTN_FWD_P(32); else if (bq == 1) BBDM_ATTN_FWD_NW(32, true, true); else if (bq) BBDM_ATTN_FWD_NW(32, true, false); else BBDM_ATTN_FWD_NW(32, false, false); }
+#undef BBDM_ATTN_FWD_P
     else { if (bq) BBDM_ATTN_FWD_NW(16, true, false); else BBDM_ATTN_FWD_NW(16, false, false); }
 #undef BBDM_ATTN_FWD_NW
 #undef BBDM_ATTN_FWD

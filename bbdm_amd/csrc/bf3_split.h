@@ -30,6 +30,17 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigne
     p3 = cvt_pk(r0 - lo_as_f32(p2), r1 - hi_as_f32(p2));
 }
 
+// split2 in two halves (the same operations: bit-equal), for loops that deal the split between their MFMAs (attention.hip)
+__device__ __forceinline__ void split2_a(float x0, float x1, unsigned& p1, float& r0, float& r1) {
+    p1 = cvt_pk(x0, x1);
+    r0 = x0 - lo_as_f32(p1);
+    r1 = x1 - hi_as_f32(p1);
+}
+__device__ __forceinline__ void split2_b(float r0, float r1, unsigned& p2, unsigned& p3) {
+    p2 = cvt_pk(r0, r1);
+    p3 = cvt_pk(r0 - lo_as_f32(p2), r1 - hi_as_f32(p2));
+}
+
 // a 4-element fp32 group -> 3 x (4 bf16 = 8 B)
 __device__ __forceinline__ void split4(float4 v, uint2& p1, uint2& p2, uint2& p3) {
     split2(v.x, v.y, p1.x, p2.x, p3.x);

@@ -178,6 +178,13 @@ __global__ void __launch_bounds__(256) linear_mfma_kernel(const float* __restric
 // output tile: a wave streams ITS tile's blocks as ONE sequential stream of 1 KB LDS-DMA copies, four blocks deep, into LDS it shares
 // with nobody (no barrier in the loop: counted vmcnt only).  Same MFMA steps in the same order as linear_mfma_kernel: the same bits.
 __device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p; }
+// four 16-byte LDS reads 1 KB apart + the wait for them, as ONE asm statement (tools/hipemu replaces it with four plain loads)
+#ifndef BBDM_LDS_READ4_1K
+#define BBDM_LDS_READ4_1K(d0, d1, d2, d3, addr)                                                                                   \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"                 \
+                 "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"                                                        \
+                 : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3) : "v"(addr) : "memory")
+#endif
 constexpr int LP_KB = 32;                      // k per block
 constexpr int LP_BLOCK = 32 * LP_KB * 4;       // bytes per block
 constexpr int LP_NS = 4;                       // blocks in the ring of one wave
@@ -241,9 +248,7 @@ __global__ void __launch_bounds__(256) linear_packed_kernel(const float* __restr
         // statement with early-clobber outputs: the compiler cannot place a copy or a spill of a destination register between a read and
         // the wait it does not know about -- round-4 advisor finding)
         static_assert(LP_KB / 8 == 4, "the fragment reads below are written out for four 16-byte pieces");
-        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
-                     "ds_read_b128 %3, %4 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(wv[0]), "=&v"(wv[1]), "=&v"(wv[2]), "=&v"(wv[3]) : "v"(st) : "memory");
+        BBDM_LDS_READ4_1K(wv[0], wv[1], wv[2], wv[3], st);
         if (kb + LP_NS - 1 < nkb) issue(kb + LP_NS - 1, ring + ((kb + LP_NS - 1) % LP_NS) * LP_BLOCK);   // the stage block kb - 1 was read from
 #pragma unroll
         for (int q = 0; q < LP_KB / 8; ++q) {

@@ -331,6 +331,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipeline", action="store_true", help="c3 / c5: skip the first-stage (VQGAN encode / decode) timing")
     ap.add_argument("--cpu-only", action="store_true", help="run only the cpu_baseline leg (no GPU; build container)")
     ap.add_argument("--dump-ops", default=None, help="write the per-launch table (name, shape, ms, TFLOP/s) here")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=INT",
+                    help="A/B runs: set a library option (include/bbdm_hip.h \"options\", e.g. attn_pipe=0) for the whole run")
     ap.add_argument("--set", action="append", default=[], metavar="ATTR=INT",
                     help="A/B runs: set a planner attribute of UNetModel (e.g. fp32_v_max_cout=0) before the first plan is built")
     ap.add_argument("--no-f32mfma", action="store_true", help="c2: skip the strict-f32-MFMA A/B steps after the timed region")
@@ -360,6 +362,10 @@ def main():
 
     import bbdm_amd
     from bbdm_amd import dist_utils
+    for kv in args.opt:
+        from bbdm_amd import _lib as _bl
+        k, v = kv.split("=")
+        _bl.call("bbdm_set_option", k.encode(), int(v))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` launches its own ranks (the reference spawns them itself too: main.py:100-104,
         # mp.spawn): re-exec under torch.distributed.run, one process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1.

@@ -145,6 +145,11 @@ def test_layernorm_and_geglu(rows, C):
     K.test_layernorm_and_geglu(CPU, rows, C)
 
 
+@pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(1, 100, 37, 2, 32), (1, 64, 160, 1, 64), (1, 33, 31, 1, 64)])
+def test_attention_interleaved_loop_is_bit_equal(N, Tq, Tk, heads, ch):
+    K.test_attention_interleaved_loop_is_bit_equal(CPU, N, Tq, Tk, heads, ch)
+
+
 def test_attention_forces_rescale():
     K.test_attention_forces_rescale(CPU)
 

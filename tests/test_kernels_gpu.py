@@ -904,6 +904,31 @@ def test_attention_forces_rescale(dev):
     assert rel_err(out.cpu().permute(0, 2, 1), ref) < TOL
 
 
+@pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(2, 160, 160, 2, 64), (1, 100, 37, 3, 32), (1, 256, 1000, 2, 64), (2, 33, 32, 1, 32),
+                                              (1, 64, 31, 2, 64)])
+def test_attention_interleaved_loop_is_bit_equal(dev, N, Tq, Tk, heads, ch):
+    """The attention forward deals its operand splits between the MFMAs (option "attn_pipe" = 1, the default) instead of running them
+    in phases of their own (0): the same arithmetic in another issue order -- same bits, incl. a single key tile, a ragged last tile
+    and the log-sum-exp the training backward reads; and option "attn_bf3" = 0 / 2 (f32 MFMA / only Q K^T on the bf16x3 path) stay
+    within the fp32 tolerance of it."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(Tq + Tk + ch)
+    C = heads * ch
+    q, k, v = (torch.randn(N, T, C, generator=g).to(dev) for T in (Tq, Tk, Tk))
+    with _lib.option("attn_pipe", 1):
+        a, la = ops.cross_attention(q, k, v, heads, return_lse=True)
+    with _lib.option("attn_pipe", 0):
+        b, lb = ops.cross_attention(q, k, v, heads, return_lse=True)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    for mode in (0, 2):
+        with _lib.option("attn_bf3", mode):
+            c = ops.cross_attention(q, k, v, heads)
+        assert rel_err(c.cpu(), a.cpu()) < TOL, mode
+
+
 @pytest.mark.parametrize("N", [1, 4, 16, 33, 70])
 def test_embedding_path(dev, N):
     import kernel_ops as ops

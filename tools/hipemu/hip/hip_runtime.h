@@ -269,6 +269,15 @@ static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu)
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// csrc/embed.hip: four LDS reads + their wait in one asm statement
+#define BBDM_LDS_READ4_1K(d0, d1, d2, d3, addr)                                                                         \
+    do {                                                                                                                \
+        const char* b__ = (const char*)hipemu::dyn_smem() + (addr);                                                     \
+        d0 = *reinterpret_cast<const __typeof__(d0)*>(b__);                                                             \
+        d1 = *reinterpret_cast<const __typeof__(d1)*>(b__ + 1024);                                                      \
+        d2 = *reinterpret_cast<const __typeof__(d2)*>(b__ + 2048);                                                      \
+        d3 = *reinterpret_cast<const __typeof__(d3)*>(b__ + 3072);                                                      \
+    } while (0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
