@@ -13,7 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 void bbdm_set_error(const char* fmt, ...);
 
 // runtime.hip: the library's few integer options (bbdm_set_option / bbdm_get_option in the public header)
-enum BbdmOption { BBDM_OPT_WGRAD1X1_BF3 = 0, BBDM_OPT_WINO_IDX64, BBDM_OPT_BF3P_KERNEL, BBDM_OPT_ATTN_BF3, BBDM_OPT_ATTN_PIPE, BBDM_OPT_COUNT };
+enum BbdmOption { BBDM_OPT_WGRAD1X1_BF3 = 0, BBDM_OPT_WINO_IDX64, BBDM_OPT_BF3P_KERNEL, BBDM_OPT_ATTN_BF3, BBDM_OPT_ATTN_PIPE, BBDM_OPT_BF3P_PAD_ROWS, BBDM_OPT_COUNT };
 int bbdm_option(int id);
 
 #define BBDM_REQUIRE(cond, ...)            \

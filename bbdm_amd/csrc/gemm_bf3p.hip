@@ -42,6 +42,7 @@ struct Bf3pArgs {
     float* M;                // [batch][T][ldo] fp32
     size_t az, bz, mz, rz;   // per-batch strides: bytes, bytes, floats (M), floats (residual)
     int T, Cout, nchunks, tilesN;
+    int rgs;                 // pipe kernel: 32-row groups the A planes are LAID OUT for (>= T / 32; the groups beyond T hold the producer's zeros)
     int tiles, batch, by_batch;
     int persist;             // pipe kernel, by_batch: workgroups walk the tiles blockIdx.x + k gridDim.x
     int ksplits, kps, P;     // split-K (pipe kernel): batch index = z * P + entry; split z walks chunks [z kps, (z+1) kps) of nchunks
@@ -124,9 +125,11 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
     const int wm = wave / WN, wn = wave % WN;
     const int tilesN = a.tilesN * 2 / WN;
     const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
-    const int rg_last = a.T / 32 - 1;                                          // a ragged last row tile (T % BM != 0) re-reads the last
-                                                                               // row group instead of running past the buffer; its
-                                                                               // rows are not stored
+    // A ragged last row tile (T % BM != 0) reads the row groups the buffer holds beyond the real rows -- zeros, written by the producer
+    // of the planes (Winograd input transform, split pass) -- and past THEM the last group again; its rows are not stored.  (Round 5:
+    // it used to re-read the last REAL group: the idle 32-row blocks then multiplied live data, and the kernel is bound by the power its
+    // operand data draws -- zeros run 1.3x faster)
+    const int rg_last = a.rgs - 1;
     // ---- the tile a (virtual) block index names; false beyond the last batch entry ----------------------------------------------
     int row0 = 0, cout0 = 0, n = 0;
     float* M = nullptr;
@@ -908,6 +911,7 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     Bf3pArgs a;
     a.A = (const unsigned char*)a_planes; a.B = (const unsigned char*)b_planes; a.M = M;
     a.T = (int)rows; a.Cout = Cout; a.nchunks = CinPad / KC;
+    a.rgs = bbdm_option(BBDM_OPT_BF3P_PAD_ROWS) ? (int)(T / 32) : (int)(rows / 32);      // (0: round 4's clamp to the last real group, A/B)
     const int CoutPad = cdiv(Cout, 128) * 128;
     a.tilesN = CoutPad / 128;
     a.az = (size_t)T * CinPad * 6; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo; a.rz = (size_t)T * ldr;
@@ -1047,6 +1051,7 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
     Bf3pArgs a;
     a.A = (const unsigned char*)at_planes; a.B = (const unsigned char*)bt_planes; a.M = C;
     a.T = M; a.Cout = N; a.nchunks = (int)(K / KC);
+    a.rgs = (M + 31) / 32;
     const int NPad = cdiv(N, 128) * 128;
     a.tilesN = NPad / 128;
     a.az = (size_t)((M + 31) / 32 * 32) * K * 6; a.bz = (size_t)NPad * K * 6; a.mz = (size_t)M * N; a.rz = 0;
@@ -1103,6 +1108,7 @@ extern "C" int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_plan
     Bf3pArgs a;
     a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = out;
     a.T = (int)pixels; a.Cout = Cout; a.nchunks = CinPad / KC;
+    a.rgs = 0;
     const int CoutPad = cdiv(Cout, 128) * 128;
     a.tilesN = CoutPad / 128;
     a.az = 0; a.bz = 0; a.mz = 0; a.rz = 0;
@@ -1131,6 +1137,7 @@ extern "C" int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_plan
     Bf3pArgs a;
     a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = out;
     a.T = (int)pixels; a.Cout = Cout; a.nchunks = CinPad / KC;
+    a.rgs = 0;
     a.tilesN = cdiv(Cout, 128);
     a.az = 0; a.bz = 0; a.mz = 0; a.rz = 0;
     a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;

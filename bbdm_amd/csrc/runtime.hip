@@ -25,6 +25,7 @@ Option g_options[BBDM_OPT_COUNT] = {
     {"bf3p_kernel", 6},       // tile shape of the pre-split GEMM: 6 = the library's choice, 4 / 5 / 7 = force 256x256 / 256x128 / 128x128
     {"attn_bf3", 1},          // attention forward: 1 = Q K^T and P V on the bf16x3 path, 2 = only Q K^T, 0 = both on the f32 MFMA (A/B)
     {"attn_pipe", 1},         // attention forward, full bf16x3 path: 1 = the loop with the splits dealt between the MFMAs, 0 = phased (A/B)
+    {"bf3p_pad_rows", 1},     // pre-split GEMM, ragged last row tile: 1 = its idle 32-row blocks read the producer's zero rows, 0 = the last real rows again (A/B)
 };
 int option_index(const char* name) {
     if (!name) return -1;

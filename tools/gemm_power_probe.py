@@ -62,6 +62,8 @@ def main():
             ts = sorted(a.elapsed_time(b) for a, b in evs)
             return ts[len(ts) // 2]
         r = {}
+        with _lib.option("bf3p_pad_rows", 0):
+            r["real b2b, idle blocks re-read live rows"] = run(False)
         r["real b2b"], r["real gaps"] = run(False), run(True)
         Vp.zero_()
         Bp.zero_()
