@@ -384,8 +384,13 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         const int f = tid + s * NW * 64, row = f >> 2, q = f & 3;
         const int grow = min(row0 + row, a.T - 1);                            // (a ragged last row tile re-reads the last row)
         asrc[s] = Af + (size_t)bz * (a.az / 4) + (size_t)grow * lda + q * 4;
-        // plane unit of row group (row >> 5): byte (k >> 3) * 512 + r * 16 + (k & 7) * 2, k = 4 q
-        adst[s] = (unsigned)(((row >> 5) * 3) * UNIT + (q >> 1) * 512 + (row & 31) * 16 + (q & 1) * 8);
+        // plane unit of row group (row >> 5): byte (k >> 3) * 512 + r' * 16 + (k & 7) * 2, k = 4 q, with the row slot of the SECOND k-half
+        // rotated by four, r' = r ^ 4 (round 5): a 16-lane group of the 8-byte stores covers 4 rows x 4 k-quads, and quads 0 and 2 of a
+        // row -- 512 B apart -- fell on the same banks (2-way: SQ_LDS_BANK_CONFLICT 16 % of this kernel's LDS cycles, round-4 counters);
+        // now quads 2 / 3 land 16 banks further.  The A fragments are read back through the same rotation (aoff below); a read group's
+        // 16 consecutive rows stay a permutation of one aligned 256-B window: conflict-free as before.  (This unit layout is private to
+        // the kernel: its own waves write and read it.)
+        adst[s] = (unsigned)(((row >> 5) * 3) * UNIT + (q >> 1) * 512 + (((row & 31) ^ ((q >> 1) << 2)) * 16) + (q & 1) * 8);
     }
     astep = KC;
     const unsigned char* bsrc[KB];
@@ -423,7 +428,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
     const unsigned lds0 = lds_address(smem);
-    const unsigned aoff = (wm * 2) * 3 * UNIT + lane * 16;
+    const unsigned aoff = (wm * 2) * 3 * UNIT + (lane >> 5) * 512 + (((lane & 31) ^ ((lane >> 5) << 2)) * 16);      // (the rotation of adst)
     const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
     // prologue: chunks 0 and 1 staged, fragments of chunk 0 in registers
     issue_b(0, smem);
