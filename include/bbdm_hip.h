@@ -524,7 +524,9 @@ int bbdm_images_to_u8_f32(const float* x_nchw, unsigned char* out_nhwc, int N, i
  *   "bf3p_kernel"  (6)  tile shape of the pre-split bf16x3 GEMM: 6 = the library's choice, 4 = 256 x 256, 5 = 256 x 128,
  *                       7 = 128 x 128 workgroup tiles (the parity tests reach every instantiation on small problems);
  *   "attn_bf3"     (1)  attention forward: 1 = Q K^T and P V on the bf16x3 path, 2 = only Q K^T, 0 = both on the f32 MFMA;
- *   "attn_pipe"    (1)  ... its main loop with the operand splits dealt between the MFMAs (1) or in phases of their own (0; same bits).
+ *   "attn_pipe"    (1)  ... its main loop with the operand splits dealt between the MFMAs (1) or in phases of their own (0; same bits);
+ *   "bf3p_pad_rows" (1) pre-split GEMM: the idle 32-row blocks of a ragged last row tile read the zero rows the producer of the A planes
+ *                       wrote behind the real ones (1) or the last real rows again (0); the stored result is the same.
  * Unknown names return BBDM_E_BADARG. */
 int bbdm_set_option(const char* name, int value);
 int bbdm_get_option(const char* name, int* value);

@@ -904,6 +904,44 @@ def test_attention_forces_rescale(dev):
     assert rel_err(out.cpu().permute(0, 2, 1), ref) < TOL
 
 
+@pytest.mark.parametrize("kernel", [4, 5, 6])
+def test_gemm_bf3p_ragged_rows_read_the_padding(dev, kernel):
+    """A ragged last row tile of the pre-split GEMM (rows % 256 != 0): option "bf3p_pad_rows" decides what its idle 32-row blocks
+    multiply -- the producer's zero rows behind the real ones (1, the default: the kernel is bound by the power its operand data draws)
+    or a re-read of the last real rows (0) -- and must not change a stored value.  The Winograd path at 12 x 20 pixels, batch 5: 40 tiles
+    of F(6x6) = 64 real rows of a 256-row layout."""
+    from bbdm_amd import _lib
+    with _lib.option("bf3p_kernel", kernel):
+        outs = []
+        for pad in (1, 0):
+            with _lib.option("bf3p_pad_rows", pad):
+                outs.append(_winograd_bf3p_M(dev, 6, 5, 12, 20, 32, 136))
+    T = 5 * 2 * 4
+    a, b = (o.view(64, -1, 136)[:, :T] for o in outs)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+
+
+def _winograd_bf3p_M(dev, m, N, H, W, Cin, Cout):
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H + W + Cin)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev)
+    st = ops._st(x)
+    P, tiles = (m + 2) ** 2, lib.bbdm_winograd_tiles(m, N, H, W)
+    pw = ops.pack_winograd_weight(w, m=m)
+    Bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(P, Cin, Cout), dtype=torch.uint8, device=dev)
+    _lib.call("bbdm_gemm_bf3p_pack_b_f32", pw.data_ptr(), Bp.data_ptr(), P, Cin, Cout, st)
+    Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
+    M = torch.zeros(P * tiles * Cout, device=dev)
+    _lib.call("bbdm_winograd_input_bf3p_f32", m, x.data_ptr(), Cin, Vp.data_ptr(), None, None, 0, 0, 0, N, H, W, Cin, st)
+    _lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cin, Cout, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    return M
+
+
 @pytest.mark.parametrize("N,Tq,Tk,heads,ch", [(2, 160, 160, 2, 64), (1, 100, 37, 3, 32), (1, 256, 1000, 2, 64), (2, 33, 32, 1, 32),
                                               (1, 64, 31, 2, 64)])
 def test_attention_interleaved_loop_is_bit_equal(dev, N, Tq, Tk, heads, ch):
