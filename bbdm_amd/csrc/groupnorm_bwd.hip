@@ -26,7 +26,8 @@ struct BwdArgs {
     const double* sg;
     const float4* coef;          // [N][G] {rstd, mean, S1/cnt, S2/cnt} in fp32, written by the finalize kernel
     double* pq;                  // [N][splits][C][2] per-workgroup partial sums of P, Q (plain stores; the finalize kernel adds the splits in order)
-    const unsigned long long* dgb;   // [C][2][SA_W] limb cells: sums over n of dgamma / dbeta (finalize kernel), folded by the apply pass
+    const double* dgb;           // [N][C][2] per-image dgamma / dbeta terms (finalize kernel, plain stores); the apply pass adds the images in order
+    int N;
     float* dgamma;
     float* dbeta;
     float* dx;
@@ -182,12 +183,12 @@ __global__ void __launch_bounds__(256) gn_bwd_reduce_kernel(const BwdArgs a, int
 // ---- kernel 2: finalize (one block per image) --------------------------------------------------------------------
 __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __restrict__ pq, int splits, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ film,
-                                                              int film_ld, double* __restrict__ sg, unsigned long long* __restrict__ dgb,
+                                                              int film_ld, double* __restrict__ sg, double* __restrict__ dgb,
                                                               float* __restrict__ dfilm, int dfilm_ld, int C, int G,
                                                               const unsigned long long* __restrict__ stats, float4* __restrict__ coef,
                                                               double cnt, float eps) {
-    // grid = N; dgb: [C][2] limb cells (zeroed by the launcher) for dgamma / dbeta over n; the group sums S1, S2 in LDS limb cells
-    // (integer atomics: order-independent)
+    // grid = N; dgb: [N][C][2] this image's dgamma / dbeta terms (the apply pass adds the images in index order: no atomics, nothing to
+    // zero); the group sums S1, S2 in LDS limb cells (integer atomics: order-independent)
     __shared__ unsigned long long s12c[64 * 2 * SA_W];
     __shared__ double s12[64 * 2];
     const int n = blockIdx.x, tid = threadIdx.x, cpg = C / G;
@@ -208,8 +209,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __re
         }
         const double g = gamma[c], b = beta[c];
         const double one_sc = film ? 1.0 + (double)film[(size_t)n * film_ld + c] : 1.0;
-        sa_add(dgb + (size_t)(2 * c) * SA_W, one_sc * P);
-        sa_add(dgb + (size_t)(2 * c + 1) * SA_W, one_sc * Q);
+        *reinterpret_cast<double2*>(dgb + ((size_t)n * C + c) * 2) = make_double2(one_sc * P, one_sc * Q);
         if (dfilm) {
             dfilm[(size_t)n * dfilm_ld + c] = (float)(g * P + b * Q);       // d scale
             dfilm[(size_t)n * dfilm_ld + C + c] = (float)Q;                 // d shift
@@ -277,10 +277,19 @@ __device__ __forceinline__ float4 apply_quad(const BwdArgs& a, const Chan4& k, f
 template <bool NORM>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int pix_per_block) {
     const int n = blockIdx.y, tid = threadIdx.x;
-    if (NORM && blockIdx.x == 0 && n == 0) {                     // dgamma / dbeta: the finalize kernel's fp64 sums over n, to fp32
+    if (NORM && blockIdx.x == 0 && n == 0) {                     // dgamma / dbeta: the finalize kernel's per-image terms, added in image order
         for (int c = tid; c < a.C; c += 256) {
-            a.dgamma[c] = (float)sa_load(a.dgb + (size_t)(2 * c) * SA_W);
-            a.dbeta[c] = (float)sa_load(a.dgb + (size_t)(2 * c + 1) * SA_W);
+            double g = 0.0, b = 0.0;
+            for (int m0 = 0; m0 < a.N; m0 += 8) {                // eight loads in flight per trip
+                double2 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(a.dgb + ((size_t)min(m0 + u, a.N - 1) * a.C + c) * 2);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (m0 + u < a.N) { g += v[u].x; b += v[u].y; }
+            }
+            a.dgamma[c] = (float)g;
+            a.dbeta[c] = (float)b;
         }
     }
     const int C4 = a.C >> 2, HW = a.H * a.W;
@@ -354,10 +363,10 @@ static int gn_bwd_splits(int N, int HW, int C) {
     if (ppb < PP * 8) ppb = PP * 8;
     return cdiv(HW, ppb);
 }
-// Workspace (8-byte elements): pq [N][splits <= ceil(1024 / N)][C][2] fp64 partials + dgb [C][2][SA_W] limb cells + sg [N][G][2] fp64 +
-// coef [N][G] float4 (= 2 doubles each)
+// Workspace (8-byte elements): pq [N][splits <= ceil(1024 / N)][C][2] fp64 partials + dgb [N][C][2] fp64 + sg [N][G][2] fp64 +
+// coef [N][G] float4 (= 2 doubles each).  Nothing in it needs zeroing (every element read is stored first).
 extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
-    return (size_t)N * cdiv(1024, N > 0 ? N : 1) * C * 2 + (size_t)C * 2 * SA_W + (size_t)N * G * 2 + (size_t)N * G * 2;
+    return (size_t)N * cdiv(1024, N > 0 ? N : 1) * C * 2 + (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)N * G * 2;
 }
 
 extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats_, const float* gamma, const float* beta,
@@ -381,15 +390,15 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.film = film; a.da = da; a.dadd = dadd; a.dx = dx;
     a.ldx = ldx; a.ldda = ldda; a.ldadd = ldadd; a.lddx = lddx; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample;
+    a.N = N;
     a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr; a.dgb = nullptr; a.dgamma = nullptr; a.dbeta = nullptr;
     const int HW = H * W;
     if (norm) {
         const int nsplit = gn_bwd_splits(N, HW, C);
         double* pq = ws;
-        unsigned long long* dgb = reinterpret_cast<unsigned long long*>(pq + (size_t)N * nsplit * C * 2);
-        double* sg = reinterpret_cast<double*>(dgb + (size_t)C * 2 * SA_W);
+        double* dgb = pq + (size_t)N * nsplit * C * 2;
+        double* sg = dgb + (size_t)N * C * 2;
         float4* coef = reinterpret_cast<float4*>(sg + (size_t)N * G * 2);
-        bbdm_zero_async(dgb, 8 * ((size_t)C * 2 * SA_W), st);
         a.pq = pq; a.sg = sg; a.coef = coef;
         const int C4 = C / 4;
         const int PP = C4 <= 256 ? 256 / C4 : 1;
