@@ -404,9 +404,13 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
     if (tg >= TG) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int TH = (int)dTH.d, TW = (int)dTW.d;
-    const int tl = lane >> 3, cp = lane & 7;
-    const unsigned tile = (unsigned)tg * 8 + tl;
-    const int c = chunk * KC + cp * 2;
+    // lane = tile x channel pair: 8 tiles x 8 pairs (one 16-channel chunk); F32: 4 tiles x 16 pairs (32 channels), so that a tile's row of
+    // the fp32 V is one full 128-B line per load and per store (64-B half lines at a pitch of 4 Cin bytes held the 640-channel layer at
+    // 3.5 TB/s); nchunks / TG / tg / chunk then count 32-channel chunks and groups of four tiles (the launcher's grid follows)
+    constexpr int TPG = F32 ? 4 : 8, CPW = F32 ? 16 : 8;
+    const int tl = lane / CPW, cp = lane % CPW;
+    const unsigned tile = (unsigned)tg * TPG + tl;
+    const int c = chunk * (2 * CPW) + cp * 2;
     {   // ---- phase A: column `wave` of the window ------------------------------------------------------------------------------
         const int jj = wave;
         float2 d[AL], col[AL];
@@ -488,7 +492,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
         for (int jj = 0; jj < AL; ++jj) t[jj] = lds[(i * AL + jj) * 64 + lane];
         bt_transform<MO>(t, row);
         if (F32) {
-            float* of = reinterpret_cast<float*>(Vp + (size_t)(i * AL) * plane) + (size_t)tile * ((size_t)nchunks * KC) + c;
+            float* of = reinterpret_cast<float*>(Vp + (size_t)(i * AL) * plane) + (size_t)tile * ((size_t)nchunks * (2 * CPW)) + c;
 #pragma unroll
             for (int jj = 0; jj < AL; ++jj) {
                 *reinterpret_cast<float2*>(of) = row[jj];
@@ -1076,9 +1080,9 @@ extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V,
     BBDM_REQUIRE(!pre_scale || (pre_ld % 4 == 0 && pre_ld >= CinPad && (((uintptr_t)pre_scale | (uintptr_t)pre_bias) & 15) == 0),
                  "winograd_input: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
-    // whole 16-channel chunks: the two-phase LDS kernel, storing fp32 rows (round 5; rows of padding tiles are written as zeros); other
+    // whole 32-channel chunks: the two-phase LDS kernel, storing fp32 rows (round 5; rows of padding tiles are written as zeros); other
     // channel counts keep the one-thread-per-window kernels below
-    if (CinPad % KC == 0 && Tp < (1ull << 31))
+    if (CinPad % 32 == 0 && Tp < (1ull << 31))
         return winograd_input_planes(m, x, ldx, V, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream,
                                      nullptr, true);
     const size_t vplane = Tp * (size_t)CinPad;
@@ -1201,7 +1205,12 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
             return BBDM_OK;
         }
         if (f32out) {                     // fp32 rows instead of planes (no transposed copy, no coefficient folding)
-            BBDM_REQUIRE(!Vt, "winograd_input: the fp32 form has no transposed copy");
+            BBDM_REQUIRE(!Vt && CinPad % 32 == 0, "winograd_input: the fp32 form has no transposed copy and takes whole 32-channel chunks");
+            // its workgroups own 4 tiles x 32 channels: re-derive the grid quantities the kernel reads
+            const int nchunks = CinPad / 32, TG = (int)(Tp / 4);
+            const FastDiv dCH = fastdiv_make((unsigned)nchunks);
+            const dim3 g((unsigned)(8ll * ((TG + 7) / 8) * nchunks));
+            BBDM_REQUIRE(8ll * ((TG + 7) / 8) * nchunks < (1ll << 31), "winograd_input: too many workgroups");
 #define BBDM_WINO_INS2_F(MO, PRE, UP, I64)                                                                                        \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, false, I64, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr, \
