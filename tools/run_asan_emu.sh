@@ -2,7 +2,7 @@
 # AddressSanitizer + UBSan pass over every kernel (CPU build of the SAME csrc/*.hip sources on tools/hipemu; no GPU sanitizers run on
 # this pool): the kernel tests and a tiny model forward / backward with exact-size torch allocations, which ASAN's malloc interposer
 # surrounds with red zones -- an out-of-bounds global read or write of a ragged-tile path aborts the run.
-#   bash tools/run_asan_emu.sh [pytest -k expression]     -> profiles/r04_asan_emu.txt (written when the run completes)
+#   bash tools/run_asan_emu.sh [pytest -k expression]     -> profiles/r05_asan_emu.txt (written when the run completes)
 set -u
 cd "$(dirname "$0")/.."
 python tools/hipemu/build.py --asan || exit 1
