@@ -15,6 +15,7 @@
 // for step r makes register r of P^T exactly the B operand of step r -- no LDS round trip, no shuffles; row
 // max / sum are 15 VALU ops + one cross-half exchange.  The running max / sum / rescale are per-lane scalars.
 #include "bf3_split.h"
+#include "lds_dma.h"
 #include <stdlib.h>
 
 namespace {
@@ -395,6 +396,229 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
     }
 }
 
+// ---- K / V pre-split (round 5): the operand planes of the key tiles are written ONCE per (image, head) instead of being split by every
+// 128-query workgroup that walks them (at T = 4096: 32 times) ---------------------------------------------------------------------------
+// With the split in the main loop the kernel issued 6.5 VALU instructions per MFMA and 32 % of its LDS cycles were bank conflicts of
+// the 8-byte plane stores (profiles/r05_pmc_c2_counters.md); a third of both was the K / V staging.  attn_kv_planes_kernel writes, per
+// (image, head) and 32-key tile, 24 "fragment units" of 1 KB -- the operand layout of gemm_bf3p.hip: a unit is one bf16 plane of a
+// 32-row x 16-k MFMA A operand in the order the lanes consume it, element (row, k) at byte (k >> 3) * 512 + row * 16 + (k & 7) * 2 --
+//   units  0 .. 11: K  [ks = 16-channel step][plane]           rows = keys, k = channels 16 ks ..        (scaled like the staged K)
+//   units 12 .. 23: V^T[ct = 32-channel tile][ks2][plane]      rows = channels, k-slot (half, j) = key 16 ks2 + 4 half + j (j < 4),
+//                                                              16 ks2 + 8 + 4 half + (j - 4) otherwise: the keys register
+//                                                              8 ks2 + j of the in-place P^T operand holds (see attn_fwd_kernel)
+// and attn_fwd_planes_kernel copies a tile's 24 KB into LDS by LDS-DMA (6 copies per wave, a tile ahead), reads every fragment with
+// one linear ds_read_b128 at lane * 16 (conflict-free by construction) and spends its VALU on the softmax and the P split alone.
+// Measured at C2 (N 16, T 4096, 16 x 64; tools/attn_bench.py, ablated builds): one launch 5.49 ms; this pair 5.06 + 0.26 ms.  Of the 5.06:
+// MFMAs alone 3.82 (1.73 PFLOP/s of bf16), + softmax / P split 0.7, + copies and the per-tile barrier 0.45, fragment reads 0 -- they add
+// up.  A touch of the planes three tiles ahead (4-byte LDS-DMAs into a junk kilobyte, to have the lines in L2) cost 0.22 ms and is gone.
+// Same split, same six terms, same MFMA order as attn_fwd_kernel<CH, true, true>: bit-equal results (tests).
+constexpr int ATTN_UNIT = 1024;
+
+template <int CH>
+__global__ void __launch_bounds__(256) attn_kv_planes_kernel(const float* __restrict__ ksrc, const float* __restrict__ vsrc, int ldkv, int hskv,
+                                                             unsigned char* __restrict__ planes, int T, int heads, float scale) {
+    constexpr int KS = CH / 16, CT = CH / 32, UNITS = 3 * KS + 6 * CT, PITCH = CH + 4;
+    __shared__ __attribute__((aligned(16))) float kt[KT * PITCH], vt[KT * PITCH];
+    const int ntiles = T / KT;
+    const int tile = (int)(blockIdx.x % (unsigned)ntiles), nh = (int)(blockIdx.x / (unsigned)ntiles);
+    const int h = nh % heads, n = nh / heads;
+    const float* kbase = ksrc + ((size_t)n * T + (size_t)tile * KT) * ldkv + h * hskv;
+    const float* vbase = vsrc + ((size_t)n * T + (size_t)tile * KT) * ldkv + h * hskv;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int f = tid; f < KT * CH / 4; f += 256) {
+        const int key = f / (CH / 4), c = (f % (CH / 4)) * 4;
+        const float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)key * ldkv + c);
+        *reinterpret_cast<float4*>(kt + key * PITCH + c) = make_float4(kv.x * scale, kv.y * scale, kv.z * scale, kv.w * scale);
+        *reinterpret_cast<float4*>(vt + key * PITCH + c) = *reinterpret_cast<const float4*>(vbase + (size_t)key * ldkv + c);
+    }
+    __syncthreads();
+    unsigned char* dst = planes + ((size_t)nh * ntiles + tile) * (size_t)(UNITS * ATTN_UNIT) + lane * 16;
+    const int row = lane & 31, half = lane >> 5;
+    for (int item = tid >> 6; item < KS + 2 * CT; item += 4) {
+        float4 v0, v1;
+        int u;
+        if (item < KS) {                          // K, step ks = item: key `row`, channels 16 ks + 8 half ..
+            const float* src = kt + row * PITCH + item * 16 + half * 8;
+            v0 = *reinterpret_cast<const float4*>(src);
+            v1 = *reinterpret_cast<const float4*>(src + 4);
+            u = item * 3;
+        } else {                                  // V^T, (ct, ks2): channel 32 ct + row, the 8 keys of this lane's k-slots
+            const int ct = (item - KS) >> 1, ks2 = (item - KS) & 1;
+            const float* src = vt + (16 * ks2 + 4 * half) * PITCH + ct * 32 + row;
+            v0 = make_float4(src[0], src[PITCH], src[2 * PITCH], src[3 * PITCH]);
+            v1 = make_float4(src[8 * PITCH], src[9 * PITCH], src[10 * PITCH], src[11 * PITCH]);
+            u = 3 * KS + ((ct * 2 + ks2) * 3);
+        }
+        uint2 a1, a2, a3, b1, b2, b3;
+        split4(v0, a1, a2, a3);
+        split4(v1, b1, b2, b3);
+        *reinterpret_cast<uint4*>(dst + (size_t)(u + 0) * ATTN_UNIT) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+        *reinterpret_cast<uint4*>(dst + (size_t)(u + 1) * ATTN_UNIT) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        *reinterpret_cast<uint4*>(dst + (size_t)(u + 2) * ATTN_UNIT) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+    }
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256, 3) attn_fwd_planes_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
+                                                                  const unsigned char* __restrict__ planes, float* __restrict__ out, int ldo,
+                                                                  float* __restrict__ lse, int T, int heads, int nheads_total, float qscale) {
+    constexpr int NW = 4, QB = NW * 32, NTHR = NW * 64;
+    constexpr int KS = CH / 16, CT = CH / 32, UNITS = 3 * KS + 6 * CT;
+    constexpr int STAGE = UNITS * ATTN_UNIT;                       // bytes per key tile
+    constexpr int OPITCH = CH + 1;
+    static_assert(UNITS % NW == 0, "the tile's units are dealt evenly to the waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // attn_planes_lds(CH) bytes: two tile stages / the epilogue's O^T
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, lq = lane & 31;
+    const int qblocks = T / QB;
+    qscale *= LOG2E;
+    const int L = (int)blockIdx.x, slot = L >> 3;                  // XCD L % 8 owns the (image, head) pairs x, x + 8, ... (see attn_fwd_kernel)
+    const int qb = slot % qblocks;
+    const int nh = (L & 7) + 8 * (slot / qblocks);
+    if (nh >= nheads_total) return;
+    const int h = nh % heads, n = nh / heads;
+    const float* qbase = qsrc + (size_t)n * T * ldq + h * hsq;
+    const int ntiles = T / KT;
+    const unsigned char* ptile = planes + (size_t)nh * ntiles * (size_t)STAGE;
+    auto issue = [&](int tile) {                                   // this wave's share of tile's 24 units -> stage tile & 1
+        const unsigned char* src = ptile + (size_t)tile * STAGE;
+        unsigned char* dstl = smem + (tile & 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < UNITS / NW; ++i) {
+            const int u = wave * (UNITS / NW) + i;
+            glds16(src + u * ATTN_UNIT, (unsigned)lane * 16, dstl + u * ATTN_UNIT);
+        }
+    };
+    issue(0);
+
+    const int q = qb * QB + wave * 32 + lq;
+    bf16x8 qb3[KS][3];                                             // lane holds q[c], c = ks*16 + hi*8 + 0..7, as three bf16 planes
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float4 v0 = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + ks * 16 + hi * 8);
+        float4 v1 = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + ks * 16 + hi * 8 + 4);
+        v0 = make_float4(v0.x * qscale, v0.y * qscale, v0.z * qscale, v0.w * qscale);
+        v1 = make_float4(v1.x * qscale, v1.y * qscale, v1.z * qscale, v1.w * qscale);
+        uint2 a1, a2, a3, b1, b2, b3;
+        split4(v0, a1, a2, a3);
+        split4(v1, b1, b2, b3);
+        qb3[ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+        qb3[ks][1] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+        qb3[ks][2] = __builtin_bit_cast(bf16x8, make_uint4(a3.x, a3.y, b3.x, b3.y));
+    }
+    f32x16 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        if (tile + 1 < ntiles) issue(tile + 1);                    // (its stage was last read a tile ago: the barrier below is behind)
+        const unsigned char* st = smem + (tile & 1) * STAGE + lane * 16;
+        // ---- S^T = K Q^T: one chain of 6 KS MFMAs (see attn_fwd_kernel) ----------------------------------------------------------
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 kf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(st + (ks * 3 + p) * ATTN_UNIT);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t]], qb3[ks][BF3_TB[t]], s, 0, 0, 0);
+        }
+        // ---- online softmax (base 2; no keys beyond T: T is a multiple of the tile) ------------------------------------------------
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        const float m_run_prev = m_run;
+        m_run = m_new;
+        if (__ballot(m_new != m_run_prev) != 0ull) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+                BBDM_KEEP_IN_BRANCH(o[ct]);
+            }
+        }
+        // ---- O^T += V^T P^T: P^T in place (registers 8 ks2 .. 8 ks2 + 7 are the lane's k-slots of step ks2); the split of key half 1
+        // is dealt between the first MFMAs of half 0 ---------------------------------------------------------------------------------
+        bf16x8 pfs[2][3];
+        unsigned pw[3][4];
+        float pr0, pr1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split2(s[2 * d], s[2 * d + 1], pw[0][d], pw[1][d], pw[2][d]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pfs[0][p] = __builtin_bit_cast(bf16x8, make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]));
+        auto split_p1_stage = [&](int j) {
+            if (j < 8) {
+                const int d = j >> 1;
+                if ((j & 1) == 0) split2_a(s[8 + 2 * d], s[8 + 2 * d + 1], pw[0][d], pr0, pr1);
+                else split2_b(pr0, pr1, pw[1][d], pw[2][d]);
+            }
+            if (j == 8)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pfs[1][p] = __builtin_bit_cast(bf16x8, make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]));
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 (&pf)[3] = pfs[ks];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                bf16x8 vf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8*>(st + (3 * KS + (ct * 2 + ks) * 3 + p) * ATTN_UNIT);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[BF3_TA[t]], pf[BF3_TB[t]], o[ct], 0, 0, 0);
+                    if (ks == 0) {
+                        split_p1_stage(ct * 6 + t);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            if (ks == 0 && 6 * CT < 9) {
+#pragma unroll
+                for (int j = 6 * CT; j < 9; ++j) split_p1_stage(j);
+            }
+        }
+        wait_vmcnt<0>();                         // my copies of tile + 1 have landed ...
+        __syncthreads();                         // ... everybody's, and everybody is done with this tile's stage
+    }
+
+    // ---- epilogue: O^T / l -> LDS [query][c] -> coalesced rows (as attn_fwd_kernel) -----------------------------------------------------
+    float* obuf = reinterpret_cast<float*>(smem);
+    const float inv = 1.0f / l_run;
+    if (lse && hi == 0) lse[((size_t)n * heads + h) * T + q] = m_run * LN2 + logf(l_run);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            obuf[(wave * 32 + lq) * OPITCH + c] = o[ct][r] * inv;
+        }
+    __syncthreads();
+    for (int i = tid; i < QB * CH; i += NTHR) {
+        const int ql = i / CH, c = i - ql * CH;
+        out[((size_t)n * T + qb * QB + ql) * ldo + h * CH + c] = obuf[ql * OPITCH + c];
+    }
+}
+
 }  // namespace
 
 static int launch_attention(const float* q, int ldq, int hsq, const float* k, const float* v, int ldkv, int hskv, float* out,
@@ -402,7 +626,7 @@ static int launch_attention(const float* q, int ldq, int hsq, const float* k, co
                             hipStream_t st) {
     // Q K^T and P V on the bf16x3 path (option attn_bf3 = 0: both on the f32 MFMA; 2: only Q K^T, the round-2 kernel -- for the A/B)
     const int bq = bbdm_option(BBDM_OPT_ATTN_BF3);
-    const bool pipe = bbdm_option(BBDM_OPT_ATTN_PIPE) != 0;           // the interleaved main loop (PIPE) of the full bf16x3 path
+    const bool pipe = bbdm_option(BBDM_OPT_ATTN_PIPE) != 0;           // the interleaved main loop (PIPE) of the full bf16x3 path (2: + the pre-split entry points)
     // 4 waves (128 queries) per workgroup, three workgroups per CU (an 8-wave / 256-query form, K / V staged once per 256 queries,
     // measured 6.55 against 6.16 ms at C2 in round 3 and is gone)
     const int nw = 4;
@@ -441,6 +665,56 @@ extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo
         launch_attention(qkv, ldq, 3 * ch, qkv + ch, qkv + 2 * ch, ldq, 3 * ch, out, ldo, lse, N, T, T, heads, ch, scale,
                          scale, (hipStream_t)stream);
     BBDM_CHECK_LAUNCH("attention");
+    return BBDM_OK;
+}
+
+// ---- the pre-split form (see attn_kv_planes_kernel): a launch that writes the K / V operand planes of every (image, head) and an
+// attention launch that reads them.  bbdm_attention_kv_planes_bytes returns 0 where the form does not apply (head channels other than
+// 64 / 32, T not a multiple of 128, sequences too short for the extra launch to pay); the results equal bbdm_attention_f32's bit for bit.
+static size_t attn_planes_lds(int ch) {
+    const size_t stages = 2 * (size_t)(3 * (ch / 16) + 6 * (ch / 32)) * 1024, epilogue = 128 * (size_t)(ch + 1) * 4;
+    return stages > epilogue ? stages : epilogue;
+}
+static bool attn_planes_ok(int N, int T, int heads, int ch) {
+    const int mode = bbdm_option(BBDM_OPT_ATTN_PIPE);               // 2: long sequences, 3: every shape the layout takes (tests)
+    return (ch == 64 || ch == 32) && T % 128 == 0 && (T >= 1024 || mode >= 3) && bbdm_option(BBDM_OPT_ATTN_BF3) == 1 && mode >= 2;
+}
+extern "C" size_t bbdm_attention_kv_planes_bytes(int N, int T, int heads, int ch) {
+    if (N <= 0 || T <= 0 || heads <= 0 || !attn_planes_ok(N, T, heads, ch)) return 0;
+    return (size_t)N * heads * (T / 32) * (size_t)((3 * (ch / 16) + 6 * (ch / 32)) * 1024);
+}
+extern "C" int bbdm_attention_kv_planes_f32(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch,
+                                            int new_order, void* stream) {
+    BBDM_REQUIRE(qkv && planes, "attention_kv_planes: null pointer");
+    const size_t need = bbdm_attention_kv_planes_bytes(N, T, heads, ch);
+    BBDM_REQUIRE(need != 0, "attention_kv_planes: N=%d T=%d heads=%d ch=%d has no pre-split form (bbdm_attention_kv_planes_bytes is 0)", N, T, heads, ch);
+    BBDM_REQUIRE(planes_bytes >= need, "attention_kv_planes: %zu bytes of planes, %zu needed", planes_bytes, need);
+    BBDM_REQUIRE(ldq % 4 == 0 && ldq >= 3 * heads * ch && (((uintptr_t)qkv | (uintptr_t)planes) & 15) == 0, "attention_kv_planes: bad pitch / alignment");
+    BBDM_REQUIRE((long long)N * heads * (T / 32) < (1ll << 31), "attention_kv_planes: too many key tiles");
+    const float scale = 1.0f / sqrtf(sqrtf((float)ch));
+    const int C = heads * ch;
+    const float* k = new_order ? qkv + C : qkv + ch;
+    const float* v = new_order ? qkv + 2 * C : qkv + 2 * ch;
+    const int hs = new_order ? ch : 3 * ch;
+    const dim3 grid((unsigned)(N * heads * (T / 32)));
+    if (ch == 64) hipLaunchKernelGGL(attn_kv_planes_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, k, v, ldq, hs, (unsigned char*)planes, T, heads, scale);
+    else hipLaunchKernelGGL(attn_kv_planes_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, k, v, ldq, hs, (unsigned char*)planes, T, heads, scale);
+    BBDM_CHECK_LAUNCH("attention_kv_planes");
+    return BBDM_OK;
+}
+extern "C" int bbdm_attention_planes_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch,
+                                         int new_order, const void* planes, void* stream) {
+    BBDM_REQUIRE(qkv && planes && out, "attention_planes: null pointer");
+    BBDM_REQUIRE(bbdm_attention_kv_planes_bytes(N, T, heads, ch) != 0, "attention_planes: N=%d T=%d heads=%d ch=%d has no pre-split form", N, T, heads, ch);
+    BBDM_REQUIRE(ldq % 4 == 0 && ldq >= 3 * heads * ch && ldo >= heads * ch && (((uintptr_t)qkv | (uintptr_t)planes) & 15) == 0,
+                 "attention_planes: bad pitch / alignment");
+    const float scale = 1.0f / sqrtf(sqrtf((float)ch));
+    const int nht = N * heads, qblocks = T / 128;
+    const dim3 grid((unsigned)(8ll * ((nht + 7) / 8) * qblocks));
+    const int hsq = new_order ? ch : 3 * ch;
+    if (ch == 64) hipLaunchKernelGGL(attn_fwd_planes_kernel<64>, grid, dim3(256), attn_planes_lds(64), (hipStream_t)stream, qkv, ldq, hsq, (const unsigned char*)planes, out, ldo, lse, T, heads, nht, scale);
+    else hipLaunchKernelGGL(attn_fwd_planes_kernel<32>, grid, dim3(256), attn_planes_lds(32), (hipStream_t)stream, qkv, ldq, hsq, (const unsigned char*)planes, out, ldo, lse, T, heads, nht, scale);
+    BBDM_CHECK_LAUNCH("attention_planes");
     return BBDM_OK;
 }
 

@@ -29,6 +29,7 @@
 // both operands by LDS-DMA two steps ahead, fp32 A split at the fragment read: round 4); the NS = 3 build of the pipe kernel for
 // small launches whose workgroups have a CU to themselves (round 4).
 #include "bf3_split.h"
+#include "lds_dma.h"
 #include <stdlib.h>
 
 namespace {
@@ -65,23 +66,6 @@ __device__ __forceinline__ int xcd_block_p(int nblk, int x, int off) {
 
 typedef int frag_t __attribute__((ext_vector_type(4)));       // one lane's 8 bf16 of an MFMA operand, as the registers it occupies
 #define BF3P_BF(x) __builtin_bit_cast(bf16x8, x)
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// one LDS-DMA: every lane fetches 16 B at unit + lane16 (unit: wave-uniform, pinned to SGPRs so that the instruction takes its
-// scalar-base + 32-bit-lane-offset form instead of a 64-bit address VGPR pair per copy), the wave's 1 KB lands at
-// lds_wave_base + lane * 16
-__device__ __forceinline__ void glds16(const unsigned char* unit, unsigned lane16, unsigned char* lds_wave_base) {
-    const unsigned long long u = (unsigned long long)(uintptr_t)unit;
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    const unsigned char* base = (const unsigned char*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane16),
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // LDS byte address of a __shared__ object (the operand of a hand-written ds_read)
 __device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)p; }

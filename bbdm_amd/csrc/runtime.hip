@@ -12,7 +12,7 @@ void bbdm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int bbdm_version(void) { return 21; }
+extern "C" int bbdm_version(void) { return 22; }
 
 // ---- options: the few integer switches tests and tools/ flip (kernel A/B inside ONE process).  Not read from the environment, not
 // latched: a launcher reads its option at every call.  Everything else the library decides from the shapes it is given.
@@ -24,7 +24,7 @@ Option g_options[BBDM_OPT_COUNT] = {
     {"wino_idx64", 0},        // 1 = force the 64-bit row-address variant of the Winograd input transform (tests)
     {"bf3p_kernel", 6},       // tile shape of the pre-split GEMM: 6 = the library's choice, 4 / 5 / 7 = force 256x256 / 256x128 / 128x128
     {"attn_bf3", 1},          // attention forward: 1 = Q K^T and P V on the bf16x3 path, 2 = only Q K^T, 0 = both on the f32 MFMA (A/B)
-    {"attn_pipe", 1},         // attention forward, full bf16x3 path: 1 = the loop with the splits dealt between the MFMAs, 0 = phased (A/B)
+    {"attn_pipe", 2},         // attention forward, full bf16x3 path: 1 = the loop with the splits dealt between the MFMAs, 0 = phased (A/B), 2 = 1 + K / V pre-split once per head for long sequences
     {"bf3p_pad_rows", 1},     // pre-split GEMM, ragged last row tile: 1 = its idle 32-row blocks read the producer's zero rows, 0 = the last real rows again (A/B)
 };
 int option_index(const char* name) {

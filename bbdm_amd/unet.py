@@ -1423,8 +1423,16 @@ class _Plan:
         lse = None
         if self.training:
             lse = _TensorRef(torch.empty(N * ab.num_heads * T, dtype=torch.float32, device=self.device))
-        self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, lse, N, T, ab.num_heads, ch,
-                 1 if ab.use_new_attention_order else 0)
+        order = 1 if ab.use_new_attention_order else 0
+        nb = int(self.lib.bbdm_attention_kv_planes_bytes(N, T, ab.num_heads, ch))
+        if nb:      # long sequences: K / V split into their bf16 operand planes once per head (in the Winograd scratch, idle here) instead
+                    # of by each of the T / 128 workgroups that walk them (csrc/attention.hip: attn_kv_planes_kernel)
+            self._wino_v_need = max(self._wino_v_need, (nb + 3) // 4)
+            self._op("bbdm_attention_kv_planes_f32", qkv, qkv.ld, self._wino_v, nb, N, T, ab.num_heads, ch, order)
+            self._op(_OpName("bbdm_attention_f32", "bbdm_attention_planes_f32"), qkv, qkv.ld, at, at.ld, lse, N, T, ab.num_heads, ch,
+                     order, self._wino_v)
+        else:
+            self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, lse, N, T, ab.num_heads, ch, order)
         out = dest if dest is not None else self._new(N, x.H, x.W, C)
         self._emit_conv(at, ab.proj_out, x, out)
         if self.training:

@@ -236,6 +236,16 @@ int bbdm_groupnorm_apply_f32(const float* x, int ldx, const bbdm_stats_t* stats,
  * lse (may be NULL): fp32 [N][heads][T] log-sum-exp of every query's score row, kept for the backward pass. */
 int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch,
                        int new_order, void* stream);
+/* The same attention in two launches for long sequences (ABI 22): bbdm_attention_kv_planes_f32 writes the bf16x3 operand planes of
+ * every (image, head)'s keys and values ONCE (K scaled; 6 bytes per element in the MFMA fragment order, csrc/attention.hip) and
+ * bbdm_attention_planes_f32 copies them tile by tile into LDS (LDS-DMA) instead of splitting K / V again in each of the T / 128
+ * workgroups that walk them.  bbdm_attention_kv_planes_bytes: size of `planes`, or 0 where the form does not apply (ch not in
+ * {32, 64}, T % 128 != 0, T < 1024, option "attn_pipe" < 2) -- callers then use bbdm_attention_f32.  Bit-equal to it. */
+size_t bbdm_attention_kv_planes_bytes(int N, int T, int heads, int ch);
+int bbdm_attention_kv_planes_f32(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch,
+                                 int new_order, void* stream);
+int bbdm_attention_planes_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch, int new_order,
+                              const void* planes, void* stream);        /* (bbdm_attention_f32's arguments, then the planes) */
 /* Backward of the above (training; the reference re-runs the block under CheckpointFunction, util.py:119-148):
  * dqkv (same layout / pitch convention as qkv, pitch lddq) from dout [N,T,heads*ch] (pitch lddo), the forward's
  * qkv, out and lse.  Two streaming kernels (dQ per query block; dK,dV per key block), no T x T tensor. */
@@ -524,7 +534,9 @@ int bbdm_images_to_u8_f32(const float* x_nchw, unsigned char* out_nhwc, int N, i
  *   "bf3p_kernel"  (6)  tile shape of the pre-split bf16x3 GEMM: 6 = the library's choice, 4 = 256 x 256, 5 = 256 x 128,
  *                       7 = 128 x 128 workgroup tiles (the parity tests reach every instantiation on small problems);
  *   "attn_bf3"     (1)  attention forward: 1 = Q K^T and P V on the bf16x3 path, 2 = only Q K^T, 0 = both on the f32 MFMA;
- *   "attn_pipe"    (1)  ... its main loop with the operand splits dealt between the MFMAs (1) or in phases of their own (0; same bits);
+ *   "attn_pipe"    (2)  ... its main loop with the operand splits dealt between the MFMAs (1, 2) or in phases of their own (0); 2 also
+ *                       enables the pre-split entry points (bbdm_attention_kv_planes_bytes > 0) from T = 1024 (3: for every T % 128 == 0, tests);
+ *                       same bits in every setting;
  *   "bf3p_pad_rows" (1) pre-split GEMM: the idle 32-row blocks of a ragged last row tile read the zero rows the producer of the A planes
  *                       wrote behind the real ones (1) or the last real rows again (0); the stored result is the same.
  * Unknown names return BBDM_E_BADARG. */

@@ -222,6 +222,28 @@ def attention(qkv: torch.Tensor, heads: int, new_order: bool = False, return_lse
     return (out, lse) if return_lse else out
 
 
+def attention_planes(qkv: torch.Tensor, heads: int, new_order: bool = False, return_lse: bool = False):
+    """:func:`attention` in its two-launch form: bbdm_attention_kv_planes_f32 (K / V operand planes once per head) +
+    bbdm_attention_planes_f32.  None where the library has no such form for the shape (bbdm_attention_kv_planes_bytes == 0)."""
+    _chk(qkv)
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    lib = _lib.load()
+    nbytes = lib.bbdm_attention_kv_planes_bytes(N, T, heads, C // heads)
+    if nbytes == 0:
+        return None
+    planes = torch.empty(nbytes + 64, dtype=torch.uint8, device=qkv.device)
+    planes[nbytes:] = 0xA5                                   # (the launch may not write behind the size it reported)
+    out = torch.empty(N, T, C, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(N, heads, T, dtype=torch.float32, device=qkv.device) if return_lse else None
+    _lib.call("bbdm_attention_kv_planes_f32", qkv.data_ptr(), C3, planes.data_ptr(), nbytes, N, T, heads, C // heads,
+              1 if new_order else 0, _st(qkv))
+    _lib.call("bbdm_attention_planes_f32", qkv.data_ptr(), C3, out.data_ptr(), C, None if lse is None else lse.data_ptr(),
+              N, T, heads, C // heads, 1 if new_order else 0, planes.data_ptr(), _st(qkv))
+    assert bool((planes[nbytes:] == 0xA5).all())
+    return (out, lse) if return_lse else out
+
+
 def attention_bwd(qkv, out, dout, lse, heads: int, new_order: bool = False) -> torch.Tensor:
     _chk(qkv, out, dout, lse)
     N, T, C3 = qkv.shape

@@ -150,6 +150,11 @@ def test_attention_interleaved_loop_is_bit_equal(N, Tq, Tk, heads, ch):
     K.test_attention_interleaved_loop_is_bit_equal(CPU, N, Tq, Tk, heads, ch)
 
 
+@pytest.mark.parametrize("N,T,heads,ch,new_order", [(1, 128, 2, 64, False), (1, 256, 1, 32, True)])
+def test_attention_presplit_form_is_bit_equal(N, T, heads, ch, new_order):
+    K.test_attention_presplit_form_is_bit_equal(CPU, N, T, heads, ch, new_order)
+
+
 @pytest.mark.parametrize("kernel", [4, 6])
 def test_gemm_bf3p_ragged_rows_read_the_padding(kernel):
     K.test_gemm_bf3p_ragged_rows_read_the_padding(CPU, kernel)

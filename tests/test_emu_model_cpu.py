@@ -315,3 +315,31 @@ def test_accumulation_in_place_matches_autograd(monkeypatch):
         return m
     monkeypatch.setattr(T, "build", build)
     T.test_accumulation_in_place_matches_autograd(CPU, "tiny_nocond")
+
+
+def test_long_sequence_attention_takes_the_presplit_form():
+    """An AttentionBlock whose sequence the pre-split K / V form accepts (library option "attn_pipe" = 3: every T % 128 == 0; by default from
+    T = 1024) is planned as bbdm_attention_kv_planes_f32 + bbdm_attention_planes_f32 on the idle Winograd scratch; the UNet output is
+    bit-equal to the one-launch plan's, and the oracle's within the step tolerance."""
+    import bbdm_amd
+    from bbdm_amd import _lib
+    import bbdm_oracle as O
+    torch.manual_seed(7)
+    params = dict(image_size=16, in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(1,),
+                  channel_mult=(1,), num_head_channels=32, use_scale_shift_norm=True, resblock_updown=True, condition_key="nocond")
+    net = bbdm_amd.UNetModel(**params).eval()
+    net.hip_graph = False
+    x, t = torch.randn(2, 3, 16, 16), torch.tensor([3, 800])
+    outs, names = [], []
+    for mode in (1, 3):
+        with _lib.option("attn_pipe", mode), torch.no_grad():
+            net._plans = {}
+            outs.append(net(x, timesteps=t).clone())
+            names.append([str(getattr(n, "entry", n)) for n, _ in next(iter(net._plans.values())).ops if "attention" in str(n)])
+    n_attn = len(names[0])                          # (input block, middle block, two output blocks)
+    assert n_attn == 4 and names[0] == ["bbdm_attention_f32"] * n_attn
+    assert names[1] == ["bbdm_attention_kv_planes_f32", "bbdm_attention_planes_f32"] * n_attn
+    assert torch.equal(outs[0], outs[1])
+    with torch.no_grad():
+        ref = O.unet_forward({k: v.detach() for k, v in net.state_dict().items()}, O.UNetSpec(**params), x, t, None)
+    assert parity_err(outs[1], ref) < M.STEP_TOL

@@ -967,6 +967,29 @@ def test_attention_interleaved_loop_is_bit_equal(dev, N, Tq, Tk, heads, ch):
         assert rel_err(c.cpu(), a.cpu()) < TOL, mode
 
 
+@pytest.mark.parametrize("N,T,heads,ch,new_order", [(2, 128, 2, 64, False), (1, 256, 3, 32, True), (2, 384, 1, 64, True), (1, 1024, 2, 64, False)])
+def test_attention_presplit_form_is_bit_equal(dev, N, T, heads, ch, new_order):
+    """bbdm_attention_kv_planes_f32 + bbdm_attention_planes_f32 (K / V split into their bf16 operand planes once per head, copied into
+    LDS by LDS-DMA) against bbdm_attention_f32 (split by every workgroup): the same split, the same MFMA order -- the same bits, output
+    and log-sum-exp; one, two and many key tiles per query block, both channel orders; shapes the form does not take report 0 bytes."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(T + ch)
+    qkv = torch.randn(N, T, 3 * heads * ch, generator=g).to(dev)
+    a, la = ops.attention(qkv, heads, new_order, return_lse=True)
+    with _lib.option("attn_pipe", 3):
+        b, lb = ops.attention_planes(qkv, heads, new_order, return_lse=True)
+        lib = _lib.load()
+        assert lib.bbdm_attention_kv_planes_bytes(N, T + 32, heads, ch) == 0 and lib.bbdm_attention_kv_planes_bytes(N, T, heads, 16) == 0
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(la, lb)
+    with _lib.option("attn_pipe", 1):
+        assert ops.attention_planes(qkv, heads, new_order) is None
+    if T < 1024:
+        assert ops.attention_planes(qkv, heads, new_order) is None          # default setting: long sequences only
+
+
 @pytest.mark.parametrize("N", [1, 4, 16, 33, 70])
 def test_embedding_path(dev, N):
     import kernel_ops as ops

@@ -279,6 +279,8 @@ static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu)
         d3 = *reinterpret_cast<const __typeof__(d3)*>(b__ + 3072);                                                      \
     } while (0)
 #define __builtin_amdgcn_sched_group_barrier(mask, size, id) ((void)0)
+// csrc/lds_dma.h: the counted wait for LDS-DMA copies
+#define BBDM_WAIT_VMCNT(N) hipemu::dma_wait(N)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_s_getreg(x) 0

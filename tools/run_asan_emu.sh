@@ -7,7 +7,7 @@ set -u
 cd "$(dirname "$0")/.."
 python tools/hipemu/build.py --asan || exit 1
 RT=$(python -c "import sys; sys.path.insert(0, 'tools/hipemu'); import build; print(build.asan_runtime())")
-FINAL=profiles/r04_asan_emu.txt
+FINAL=profiles/r05_asan_emu.txt
 OUT=$(mktemp /tmp/asan_emu.XXXXXX)      # (moved over $FINAL only when the run has finished: an interrupted run leaves the last complete report)
 K=${1:-}
 {
