@@ -702,7 +702,10 @@ __global__ void __launch_bounds__(AL * 64) winograd_output_lds_kernel(const floa
     constexpr int GL = 33;                                       // groups a 128-channel block can touch (cpg >= 4, unaligned start)
     constexpr int TAB = MO * 2 * 2 * GL * 2;                     // statistics table (doubles), parked in the transform buffer at the end
     constexpr int XF = NBUF * MO * AL * 64;
-    __shared__ float2 lds[XF > TAB ? XF : TAB];
+    constexpr bool DYN = (size_t)XF * sizeof(float2) > 65536;   // (m = 8, two buffers: 80 KB -- dynamic LDS, wino_out_lds_bytes())
+    __shared__ float2 lds_static[DYN ? 1 : (XF > TAB ? XF : TAB)];
+    extern __shared__ __attribute__((aligned(16))) float2 lds_dynamic[];
+    float2* const lds = DYN ? lds_dynamic : lds_static;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cb = (int)(blockIdx.x % (unsigned)cblocks);
     const long long tile0 = (long long)(blockIdx.x / (unsigned)cblocks) * tpw;
@@ -777,6 +780,8 @@ __global__ void __launch_bounds__(AL * 64) winograd_output_lds_kernel(const floa
                 }
             }
         }
+        if (NBUF == 1 && tpw > 1) __syncthreads();      // (one buffer, several tiles -- m = 8, whose two buffers would be 80 KB: the next
+                                                        // tile's columns may only be written once every row of this one has been read)
     }
     if (stats) {
         // Reduction in a FIXED order (run-to-run reproducible, and free of the same-address LDS atomics that cost this kernel a third
@@ -823,6 +828,9 @@ __global__ void __launch_bounds__(AL * 64) winograd_output_lds_kernel(const floa
 
 // ---- weights: U_xi[co][ci] = (G g G^T)[i][j] in the packed 1x1 layout [xi][chunk][CoutPad][16] -----------------------
 // dgrad != 0: the weights of the data-gradient convolution, g'[ci][co][r][s] = g[co][ci][2-r][2-s].
+template <int MO> struct WinoWeightT { typedef float type; };
+template <> struct WinoWeightT<8> { typedef double type; };
+
 template <int MO>
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int CoutPad,
                                        int nchunks, int dgrad) {
@@ -835,10 +843,11 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
         const int o = t % CoutPad;
         const int chunk = t / CoutPad;
         const int i = chunk * KC + k;
-        float a[AL][3];                   // a = G g   (rows of g transformed)
+        typedef typename WinoWeightT<MO>::type WT;      // (m = 8: G g G^T in fp64, rounded to fp32 once)
+        WT a[AL][3];                      // a = G g   (rows of g transformed)
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            float g[3], u[AL];
+            WT g[3], u[AL];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 float v = 0.f;
@@ -853,10 +862,10 @@ __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __res
         }
 #pragma unroll
         for (int r = 0; r < AL; ++r) {
-            float u[AL];
+            WT u[AL];
             g_transform<MO>(a[r], u);
 #pragma unroll
-            for (int s = 0; s < AL; ++s) p[(size_t)(r * AL + s) * per + idx] = u[s];
+            for (int s = 0; s < AL; ++s) p[(size_t)(r * AL + s) * per + idx] = (float)u[s];
         }
     }
 }
@@ -910,13 +919,14 @@ __global__ void winograd_weight_planes_kernel(const float* __restrict__ w, unsig
         size_t t = idx / (KC / 2);
         const int o = (int)(t % CoutPad);
         const int chunk = (int)(t / CoutPad);
-        float a[2][AL][3];
+        typedef typename WinoWeightT<MO>::type WT;
+        WT a[2][AL][3];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int i = chunk * KC + kp * 2 + e;
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx) {
-                float g[3], u[AL];
+                WT g[3], u[AL];
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     float v = 0.f;
@@ -933,13 +943,13 @@ __global__ void winograd_weight_planes_kernel(const float* __restrict__ w, unsig
                            ((kp * 2) & 7) * 2;
 #pragma unroll
         for (int r = 0; r < AL; ++r) {
-            float u0[AL], u1[AL];
+            WT u0[AL], u1[AL];
             g_transform<MO>(a[0][r], u0);
             g_transform<MO>(a[1][r], u1);
 #pragma unroll
             for (int sx = 0; sx < AL; ++sx) {
                 unsigned p1, p2, p3;
-                split2(u0[sx], u1[sx], p1, p2, p3);
+                split2((float)u0[sx], (float)u1[sx], p1, p2, p3);
                 unsigned char* q = d + (size_t)(r * AL + sx) * xi_stride;
                 *reinterpret_cast<unsigned*>(q) = p1;
                 *reinterpret_cast<unsigned*>(q + 1024) = p2;
@@ -1002,7 +1012,8 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
     // forward: conv Cin -> Cout, input tensor carries InPad >= Cin channels.
     // dgrad  : conv Cout -> Cin, its input (dY) carries InPad >= Cout channels.
     // m = 7  : w_oihw = the [Cout = 4 C][Cin][3][3] phase filters bbdm_upsample_phase_weights_f32 wrote; packed = G g2 G^T of F(7x7, 2x2)
-    BBDM_WINO_M7(m);
+    BBDM_WINO_M78(m);
+    BBDM_REQUIRE(m != 8 || !dgrad, "winograd_pack: m = 8 is a forward-only tile");
     BBDM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && InPad % 4 == 0, "winograd_pack: bad args");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack: InPad too small");
     BBDM_REQUIRE(m != 7 || (!dgrad && Cout % 4 == 0), "winograd_pack: m = 7 takes the 4 C phase filters of a forward conv");
@@ -1020,6 +1031,9 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
     else if (m == 4)
         hipLaunchKernelGGL(winograd_weight_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
                            Cin, CoutPad, nchunks, dgrad);
+    else if (m == 8)
+        hipLaunchKernelGGL(winograd_weight_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
+                           Cin, CoutPad, nchunks, dgrad);
     else
         hipLaunchKernelGGL(winograd_weight_kernel<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout,
                            Cin, CoutPad, nchunks, dgrad);
@@ -1031,7 +1045,8 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
 // b_planes: bbdm_gemm_bf3p_b_bytes((m + 2)^2, InPad, O) bytes, InPad % 16 == 0)
 extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
                                                   void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
+    BBDM_REQUIRE(m != 8 || !dgrad, "winograd_pack_bf3p: m = 8 is a forward-only tile");
     BBDM_REQUIRE(w_oihw && b_planes && Cout > 0 && Cin > 0 && InPad % KC == 0, "winograd_pack_bf3p: bad args (InPad %% 16)");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack_bf3p: InPad too small");
     BBDM_REQUIRE(((uintptr_t)b_planes & 15) == 0, "winograd_pack_bf3p: b_planes alignment");
@@ -1047,6 +1062,9 @@ extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, vo
     else if (m == 4)
         hipLaunchKernelGGL(winograd_weight_planes_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
                            CoutPad, nchunks, dgrad);
+    else if (m == 8)
+        hipLaunchKernelGGL(winograd_weight_planes_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
+                           CoutPad, nchunks, dgrad);
     else
         hipLaunchKernelGGL(winograd_weight_planes_kernel<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
                            CoutPad, nchunks, dgrad);
@@ -1055,11 +1073,11 @@ extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, vo
 }
 
 extern "C" size_t bbdm_winograd_tiles(int m, int N, int H, int W) {
-    return (m == 2 || m == 4 || m == 6 || m == 7) ? tiles_padded(N, H, W, m) : 0;
+    return (m == 2 || m == 4 || m == 6 || m == 7 || m == 8) ? tiles_padded(N, H, W, m) : 0;
 }
 
 extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int CinPad, int Cout) {
-    if (m != 2 && m != 4 && m != 6) return 0;
+    if (m != 2 && m != 4 && m != 6 && m != 8) return 0;
     return (size_t)planes(m) * tiles_padded(N, H, W, m) * ((size_t)CinPad + (size_t)Cout);
 }
 
@@ -1070,7 +1088,8 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale,
                                        const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
                                        int CinPad, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
+    BBDM_REQUIRE(m != 8 || CinPad % 32 == 0, "winograd_input: m = 8 takes whole 32-channel chunks");
     BBDM_REQUIRE(x && V && N > 0, "winograd_input: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "winograd_input: upsample needs even H, W");
@@ -1118,7 +1137,7 @@ extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V,
 
 extern "C" int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed_wino, float* M, int N, int H, int W,
                                       int CinPad, int Cout, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
     BBDM_REQUIRE(V && packed_wino && M && N > 0, "winograd_gemm: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(CinPad > 0 && CinPad % 4 == 0 && Cout % 4 == 0 && Cout > 0, "winograd_gemm: bad channel counts");
@@ -1134,7 +1153,7 @@ extern "C" int bbdm_winograd_gemm_f32(int m, const float* V, const float* packed
 // bbdm_gemm_bf3_pack_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
 extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* packed_bf3, float* M, int N, int H, int W,
                                           int CinPad, int Cout, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
     BBDM_REQUIRE(V && packed_bf3 && M && N > 0, "winograd_gemm_bf3: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     return bbdm_gemm_bf3_f32(V, packed_bf3, M, planes(m), (long long)tiles_padded(N, H, W, m), CinPad, Cout, stream);
@@ -1146,8 +1165,9 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
                                  const GnFold* fold, bool f32out) {
-    BBDM_WINO_M7(m);
+    BBDM_WINO_M78(m);
     BBDM_REQUIRE(m != 7 || (!upsample && !Vt && !fold && !f32out), "winograd_input_bf3p: m = 7 (phase filters) takes x itself, planes only");
+    BBDM_REQUIRE(m != 8 || (!Vt && !fold), "winograd_input_bf3p: m = 8 is a forward-only tile of the large layers (no transposed copy, no coefficient folding)");
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "winograd_input_bf3p: upsample needs even H, W");
@@ -1221,7 +1241,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         if (pre_scale) { if (upsample) BBDM_WINO_INS2_FI(MO, true, true); else BBDM_WINO_INS2_FI(MO, true, false); }              \
         else           { if (upsample) BBDM_WINO_INS2_FI(MO, false, true); else BBDM_WINO_INS2_FI(MO, false, false); }            \
     } while (0)
-            if (m == 2) BBDM_WINO_INS2_FM(2); else if (m == 4) BBDM_WINO_INS2_FM(4); else BBDM_WINO_INS2_FM(6);
+            if (m == 2) BBDM_WINO_INS2_FM(2); else if (m == 4) BBDM_WINO_INS2_FM(4); else if (m == 8) BBDM_WINO_INS2_FM(8); else BBDM_WINO_INS2_FM(6);
 #undef BBDM_WINO_INS2_FM
 #undef BBDM_WINO_INS2_FI
 #undef BBDM_WINO_INS2_F
@@ -1239,7 +1259,13 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         else if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true, false); else BBDM_WINO_INS2(MO, true, false, false); }   \
         else           { if (upsample) BBDM_WINO_INS2(MO, false, true, false); else BBDM_WINO_INS2(MO, false, false, false); } \
     } while (0)
-        if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else BBDM_WINO_INS2_M(6);
+#define BBDM_WINO_INS2_M8()                                                                          \
+    do {                                                                                            \
+        if (pre_scale) { if (upsample) BBDM_WINO_INS2(8, true, true, false); else BBDM_WINO_INS2(8, true, false, false); }   \
+        else           { if (upsample) BBDM_WINO_INS2(8, false, true, false); else BBDM_WINO_INS2(8, false, false, false); } \
+    } while (0)
+        if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else if (m == 8) BBDM_WINO_INS2_M8(); else BBDM_WINO_INS2_M(6);
+#undef BBDM_WINO_INS2_M8
 #undef BBDM_WINO_INS2_M
 #undef BBDM_WINO_INS2
 #undef BBDM_WINO_INS2_I
@@ -1297,7 +1323,7 @@ extern "C" int bbdm_winograd_gemm_bf3p_splits(int m, int N, int H, int W, int Ci
 }
 extern "C" int bbdm_winograd_gemm_bf3p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W,
                                                   int CinPad, int Cout, int splits, void* stream) {
-    BBDM_WINO_M7(m);
+    BBDM_WINO_M78(m);
     BBDM_REQUIRE(Vp && b_planes && M && N > 0, "winograd_gemm_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     return bbdm_gemm_bf3p_splitk_f32(Vp, b_planes, M, Cout, planes(m), (long long)tiles_padded(N, H, W, m),
@@ -1317,8 +1343,8 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
                                                      float* out, int ldo, int flags, int N, int H, int W, int Cout, void* stats0,
                                                      int cpg0, int coff0, void* stats1, int cpg1, int coff1, int splits,
                                                      void* stream) {
-    BBDM_WINO_M7(m);
-    BBDM_REQUIRE(splits >= 1 && (splits == 1 || m < 6), "winograd_output: splits=%d (m = 6 / 7 layers are never split)", splits);
+    BBDM_WINO_M78(m);
+    BBDM_REQUIRE(splits >= 1 && (splits == 1 || m < 6), "winograd_output: splits=%d (m = 6 / 7 / 8 layers are never split)", splits);
     BBDM_REQUIRE(m != 7 || ((flags & BBDM_CONV_OUT_PHASES) && Cout % 128 == 0),
                  "winograd_output: m = 7 is the phase-filter form (BBDM_CONV_OUT_PHASES, Cout %% 128 == 0)");
     BBDM_REQUIRE(M && out && N > 0, "winograd_output: null pointer / bad N");
@@ -1392,13 +1418,31 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
         if (tpw == 1) { if (residual) BBDM_WINO_OUT(MO_, true, 1); else BBDM_WINO_OUT(MO_, false, 1); }        \
         else { if (residual) BBDM_WINO_OUT(MO_, true, 2); else BBDM_WINO_OUT(MO_, false, 2); }                 \
     } while (0)
-        if (m == 6) BBDM_WINO_OUT_M(6); else if (m == 4) BBDM_WINO_OUT_M(4); else BBDM_WINO_OUT_M(2);
+        if (m == 8) {      // two buffers = 80 KB of (dynamic) LDS, two workgroups of ten waves per CU
+            constexpr size_t lds8 = (size_t)2 * 8 * 10 * 64 * sizeof(float2);
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_output_lds_kernel<8, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_output_lds_kernel<8, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess) {
+                    bbdm_set_error("winograd_output: hipFuncSetAttribute(%zu B LDS) failed", lds8);
+                    return BBDM_E_LAUNCH;
+                }
+                attr_set = true;
+            }
+            if (tpw < 2) tpw = per_image >= 2 ? 2 : 1;
+#define BBDM_WINO_OUT8(RES_)                                                                                                        \
+    hipLaunchKernelGGL((winograd_output_lds_kernel<8, RES_, 2>), dim3((unsigned)(((T + tpw - 1) / tpw) * (size_t)(Cm / 128))), dim3(640), \
+                       lds8, s_, M, Tp * (size_t)Cm, Cm, splits, bias, residual, ldr, rpi, out, ldo, N, H, W, Cout, Cm / 128, (long long)T, st, ph, tpw)
+            if (residual) BBDM_WINO_OUT8(true); else BBDM_WINO_OUT8(false);
+#undef BBDM_WINO_OUT8
+        }
+        else if (m == 6) BBDM_WINO_OUT_M(6); else if (m == 4) BBDM_WINO_OUT_M(4); else BBDM_WINO_OUT_M(2);
 #undef BBDM_WINO_OUT_M
 #undef BBDM_WINO_OUT
         BBDM_CHECK_LAUNCH("winograd_output");
         return BBDM_OK;
     }
-    BBDM_REQUIRE(m != 7, "winograd_output: m = 7 launch too large for the two-phase kernel");
+    BBDM_REQUIRE(m != 7 && m != 8, "winograd_output: m = 7 / 8 need Cout %% 128 == 0 (the two-phase kernel)");
     if (m == 6 && residual)
         hipLaunchKernelGGL(winograd_output6_kernel<true>, g, b, 0, s_, M, Tp * (size_t)Cm, Cm, bias, residual, ldr, rpi, out,
                            ldo, N, H, W, Cout, (int)iters, st, ph);
@@ -1432,7 +1476,7 @@ extern "C" int bbdm_winograd_output_f32(int m, const float* M, const float* bias
 extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const float* packed_wino, const float* bias,
                                          const float* residual, int ldr, float* out, int ldo, int flags, float* ws, int N,
                                          int H, int W, int CinPad, int Cout, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
     BBDM_REQUIRE(ws, "winograd: null workspace");
     BBDM_REQUIRE(N > 0 && H > 0 && W > 0 && CinPad > 0, "winograd: bad shape");
     float* V = ws;                                                                    // [(m+2)^2][tiles][CinPad]
@@ -1474,8 +1518,27 @@ extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int l
 // test-suite can check the hand-factored formulas against the transform matrices (tests/test_winograd_math_cpu.py).
 // which: 0 = B^T (m+2 -> m+2), 1 = A^T (m+2 -> m), 2 = G (3 -> m+2), 3 = A (m -> m+2), 4 = G^T (m+2 -> 3).
 extern "C" int bbdm_debug_winograd_transform_1d(int m, int which, const float* in, float* out) {
-    BBDM_WINO_M7(m);
+    BBDM_WINO_M78(m);
     BBDM_REQUIRE(in && out && which >= 0 && which <= 4, "winograd_transform_1d: bad args");
+    if (m == 8) {                      // F(8x8, 3x3): forward side only; G in fp64 (as the weight kernels evaluate it)
+        BBDM_REQUIRE(which <= 2, "winograd_transform_1d: m = 8 has no weight-gradient side");
+        if (which == 0) {
+            float d[10], t[10];
+            for (int i = 0; i < 10; ++i) d[i] = in[i];
+            bt_transform<8>(d, t);
+            for (int i = 0; i < 10; ++i) out[i] = t[i];
+        } else if (which == 1) {
+            float v[10], r[8];
+            for (int i = 0; i < 10; ++i) v[i] = in[i];
+            at_transform<8>(v, r);
+            for (int i = 0; i < 8; ++i) out[i] = r[i];
+        } else {
+            double g[3] = {in[0], in[1], in[2]}, u[10];
+            g_transform<8>(g, u);
+            for (int i = 0; i < 10; ++i) out[i] = (float)u[i];
+        }
+        return BBDM_OK;
+    }
     if (m == 7) {                      // F(7x7, 2x2): B^T is m = 6's (8 -> 8), A^T 8 -> 7, G 2 -> 8
         BBDM_REQUIRE(which <= 2, "winograd_transform_1d: m = 7 has no weight-gradient side");
         if (which == 0) {

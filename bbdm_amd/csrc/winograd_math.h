@@ -30,6 +30,36 @@ __host__ __device__ __forceinline__ void bt_transform(const T (&d)[MO + 2], T (&
         t[3] = 2.f * (d[3] - d[1]) + (d[4] - d[2]);
         t[4] = 2.f * (d[1] - d[3]) + (d[4] - d[2]);
         t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    } else if constexpr (MO == 8) {
+        // m = 8 (round 5): points {0, +-1/2, +-3/4, +-4/3, +-2, inf} -- the set with the smallest fp32 error of 330 candidates (the usual
+        // {0, +-1, +-2, +-1/2, +-4}: 15x more; tests/test_winograd_math_cpu.py); rows scaled so that every entry is a dyadic rational, i.e.
+        // EXACT in fp32 (and G, evaluated in fp64, carries the reciprocals): the algebra holds exactly, only the data round.
+        t[0] = 0x1.2p-3f * d[0] - 0x1.da8p-1f * d[2] + 0x1.ae1p+0f * d[4] - 0x1.da8p-1f * d[6] + 0x1.2p-3f * d[8];
+        {
+            const T ev = (-0x1.2p-1f * d[2]) + 0x1.75p+0f * d[4] - 0x1.c88p-1f * d[6] + 0x1.2p-3f * d[8];
+            const T od = (-0x1.2p-2f * d[1]) + 0x1.75p-1f * d[3] - 0x1.c88p-2f * d[5] + 0x1.2p-4f * d[7];
+            t[1] = ev + od;
+            t[2] = ev - od;
+        }
+        {
+            const T ev = (-0x1p-2f * d[2]) + 0x1.34p+0f * d[4] - 0x1.b2p-1f * d[6] + 0x1.2p-3f * d[8];
+            const T od = (-0x1.8p-3f * d[1]) + 0x1.cep-1f * d[3] - 0x1.458p-1f * d[5] + 0x1.bp-4f * d[7];
+            t[3] = ev + od;
+            t[4] = ev - od;
+        }
+        {
+            const T ev = (-0x1.bp-4f * d[2]) + 0x1.458p-1f * d[4] - 0x1.cep-1f * d[6] + 0x1.8p-3f * d[8];
+            const T od = (-0x1.2p-3f * d[1]) + 0x1.b2p-1f * d[3] - 0x1.34p+0f * d[5] + 0x1p-2f * d[7];
+            t[5] = ev + od;
+            t[6] = ev - od;
+        }
+        {
+            const T ev = (-0x1.2p-4f * d[2]) + 0x1.c88p-2f * d[4] - 0x1.75p-1f * d[6] + 0x1.2p-2f * d[8];
+            const T od = (-0x1.2p-3f * d[1]) + 0x1.c88p-1f * d[3] - 0x1.75p+0f * d[5] + 0x1.2p-1f * d[7];
+            t[7] = ev + od;
+            t[8] = ev - od;
+        }
+        t[9] = 0x1.2p-3f * d[1] - 0x1.da8p-1f * d[3] + 0x1.ae1p+0f * d[5] - 0x1.da8p-1f * d[7] + 0x1.2p-3f * d[9];
     } else {        // m = 6: points {0, 1, -1, 2, -2, 1/2, -1/2, inf} (the 8x8 transform of NNPACK / wincnn)
         const T e0 = (d[2] + d[6]) - 4.25f * d[4], o0 = (d[1] + d[5]) - 4.25f * d[3];
         const T e1 = (d[6] + 0.25f * d[2]) - 1.25f * d[4], o1 = (0.5f * d[1] + 2.f * d[5]) - 2.5f * d[3];
@@ -56,6 +86,17 @@ __host__ __device__ __forceinline__ void at_transform(const T (&m)[MO + 2], T (&
         s[1] = m12 + 2.f * m34;
         s[2] = p12 + 4.f * p34;
         s[3] = m12 + 8.f * m34 + m[5];
+    } else if constexpr (MO == 8) {
+        const T p0 = m[1] + m[2], q0 = m[1] - m[2], p1 = m[3] + m[4], q1 = m[3] - m[4], p2 = m[5] + m[6], q2 = m[5] - m[6],
+                p3 = m[7] + m[8], q3 = m[7] - m[8];
+        s[0] = m[0] + p0 + p1 + 0x1.116p-3f * p2 + 0x1p-7f * p3;
+        s[1] = 0x1p-1f * q0 + 0x1.8p-1f * q1 + 0x1.6c8p-3f * q2 + 0x1p-6f * q3;
+        s[2] = 0x1p-2f * p0 + 0x1.2p-1f * p1 + 0x1.e6p-3f * p2 + 0x1p-5f * p3;
+        s[3] = 0x1p-3f * q0 + 0x1.bp-2f * q1 + 0x1.44p-2f * q2 + 0x1p-4f * q3;
+        s[4] = 0x1p-4f * p0 + 0x1.44p-2f * p1 + 0x1.bp-2f * p2 + 0x1p-3f * p3;
+        s[5] = 0x1p-5f * q0 + 0x1.e6p-3f * q1 + 0x1.2p-1f * q2 + 0x1p-2f * q3;
+        s[6] = 0x1p-6f * p0 + 0x1.6c8p-3f * p1 + 0x1.8p-1f * p2 + 0x1p-1f * p3;
+        s[7] = 0x1p-7f * q0 + 0x1.116p-3f * q1 + q2 + q3 + m[9];
     } else {
         const T p12 = m[1] + m[2], m12 = m[1] - m[2], p34 = m[3] + m[4], m34 = m[3] - m[4], p56 = m[5] + m[6],
                 m56 = m[5] - m[6];
@@ -93,9 +134,9 @@ __host__ __device__ __forceinline__ void g_transform72(const float (&g)[2], floa
     u[7] = g[1];
 }
 
-// u = G g
-template <int MO>
-__host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float (&u)[MO + 2]) {
+// u = G g.  (m = 8 is instantiated with T = double: its G holds ninths and 4125ths, and the transformed weights are rounded to fp32 once)
+template <int MO, typename T = float>
+__host__ __device__ __forceinline__ void g_transform(const T (&g)[3], T (&u)[MO + 2]) {
     if constexpr (MO == 2) {
         u[0] = g[0];
         u[1] = 0.5f * (g[0] + g[1] + g[2]);
@@ -108,6 +149,17 @@ __host__ __device__ __forceinline__ void g_transform(const float (&g)[3], float 
         u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
         u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
         u[5] = g[2];
+    } else if constexpr (MO == 8) {
+        u[0] = (T)(64.0 / 9.0) * g[0];
+        u[1] = (T)(-32768.0 / 4125.0) * g[0] + (T)(-16384.0 / 4125.0) * g[1] + (T)(-8192.0 / 4125.0) * g[2];
+        u[2] = (T)(-32768.0 / 4125.0) * g[0] + (T)(16384.0 / 4125.0) * g[1] + (T)(-8192.0 / 4125.0) * g[2];
+        u[3] = (T)(2097152.0 / 433125.0) * g[0] + (T)(524288.0 / 144375.0) * g[1] + (T)(131072.0 / 48125.0) * g[2];
+        u[4] = (T)(2097152.0 / 433125.0) * g[0] + (T)(-524288.0 / 144375.0) * g[1] + (T)(131072.0 / 48125.0) * g[2];
+        u[5] = (T)(-131072.0 / 48125.0) * g[0] + (T)(-524288.0 / 144375.0) * g[1] + (T)(-2097152.0 / 433125.0) * g[2];
+        u[6] = (T)(-131072.0 / 48125.0) * g[0] + (T)(524288.0 / 144375.0) * g[1] + (T)(-2097152.0 / 433125.0) * g[2];
+        u[7] = (T)(8192.0 / 4125.0) * g[0] + (T)(16384.0 / 4125.0) * g[1] + (T)(32768.0 / 4125.0) * g[2];
+        u[8] = (T)(8192.0 / 4125.0) * g[0] + (T)(-16384.0 / 4125.0) * g[1] + (T)(32768.0 / 4125.0) * g[2];
+        u[9] = (T)(64.0 / 9.0) * g[2];
     } else {
         u[0] = g[0];
         u[1] = (-2.f / 9.f) * (g[0] + g[1] + g[2]);
@@ -179,7 +231,7 @@ inline size_t wino_tiles_raw(int N, int H, int W, int m) { return (size_t)N * wi
 inline size_t wino_tiles_padded(int N, int H, int W, int m) {
     return (wino_tiles_raw(N, H, W, m) + 255) / 256 * 256;      // whole 8x32 GEMM tiles
 }
-inline int wino_planes(int m) { return m == 7 ? 64 : (m + 2) * (m + 2); }
+inline int wino_planes(int m) { return m == 7 ? 64 : (m + 2) * (m + 2); }       // (m = 8: 100)
 
 }  // namespace
 
@@ -188,6 +240,11 @@ inline int wino_planes(int m) { return m == 7 ? 64 : (m + 2) * (m + 2); }
 // ... entry points of the phase-filter form also take m = 7 = F(7x7, 2x2) on the 8-point transform (see wino_tdim)
 #define BBDM_WINO_M7(m) \
     BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6 || (m) == 7, "winograd: output tile m=%d unsupported (2, 4, 6 or 7)", (m))
+// ... and the forward entry points (pack / input / tile GEMMs / output; not the gradients) m = 8 = F(8x8, 3x3) on ten points
+#define BBDM_WINO_M8(m) \
+    BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6 || (m) == 8, "winograd: output tile m=%d unsupported (2, 4, 6 or 8)", (m))
+#define BBDM_WINO_M78(m) \
+    BBDM_REQUIRE((m) == 2 || (m) == 4 || (m) == 6 || (m) == 7 || (m) == 8, "winograd: output tile m=%d unsupported (2, 4, 6, 7 or 8)", (m))
 #define BBDM_WINO_HW(m, H, W)                                                                                          \
     BBDM_REQUIRE((H) > 0 && (W) > 0 && ((m) >= 6 || ((H) % (m) == 0 && (W) % (m) == 0)),                                \
                  "winograd: H=%d, W=%d must be multiples of m=%d", H, W, m)

@@ -521,7 +521,7 @@ def phase_filter_tile(N: int, H: int, W: int, cin: int, cout4: int, max_m: int, 
     return wl
 
 
-def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True) -> int:
+def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True, forward_only: bool = False) -> int:
     """Output tile m of the Winograd F(m x m, 3x3) path for this layer, or 0 = direct implicit GEMM.
 
     Measured on MI355X (tools/wino_bench.py -> profiles/r02_wino_bench.txt): the 2.25x (m = 2) / 4x
@@ -532,6 +532,13 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, s
     if cin % 4 or cout % 4 or cout < 128:
         return 0
     hw = cin * cout / (cin + cout)
+    # m = 8 (round 5; ``forward_only``: inference forward -- the tile has no gradient side): 100 / 64 = 1.56 multiplies per output instead
+    # of m = 6's 1.78, and 64 / 128 / 256-pixel images tile without the 2 - 6 % edge waste of the 6-pixel grid: -14 ... -17 % tile GEMM work
+    # and transformed bytes.  Its fp32 error is ~7x m = 6's (tests/test_winograd_math_cpu.py): UNetModel.winograd = 8 opts in.
+    t8h, t8w = -(-H // 8), -(-W // 8)
+    if (forward_only and max_m >= 8 and cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and hw >= 64 and N * t8h * t8w >= 900
+            and (8 * t8h) * (8 * t8w) <= 1.10 * H * W):
+        return 8
     t6h, t6w = -(-H // 6), -(-W // 6)
     if (max_m >= 6 and cin >= 128 and hw >= 64 and N * t6h * t6w >= 900
             and (6 * t6h) * (6 * t6w) <= 1.10 * H * W):
@@ -687,7 +694,9 @@ class UNetModel(nn.Module):
         # inference plans replay their launches as ONE hipGraph (None = yes on a GPU; False = launch by launch, e.g. under rocprofv3)
         self.hip_graph: Optional[bool] = None
         # 3x3 convolutions of wide layers through Winograd F(m x m, 3x3) (csrc/winograd.hip; `winograd_tile` picks per layer):
-        # largest output tile allowed: 6 (default), 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B)
+        # largest output tile allowed: 8, 6, 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B).  8 = F(8x8, 3x3) on the
+        # inference forward of the large layers: -15 % tile-GEMM work and transformed bytes for ~7x the fp32 rounding error of m = 6
+        # (C2 step parity 1.6e-5 -> ~1e-4 of the 1e-3 bar; see winograd_tile)
         self.winograd: int = 6
         # fold GroupNorm -> FiLM -> SiLU (and an up-sampling ResBlock's nearest x2) into the Winograd input transform
         self.winograd_fuse_groupnorm: bool = True
@@ -1181,13 +1190,13 @@ class _Plan:
             return False
         H, W, cout = up * x.H, up * x.W, consumer.weight.shape[0]
         wm = self._winograd_ok(consumer, H, W, x.C)
-        if not wm or x.C % 16 or (x.C // self.GROUPS) % 2 or consumer.weight.shape[1] != x.C:
-            return False
+        if not wm or wm == 8 or x.C % 16 or (x.C // self.GROUPS) % 2 or consumer.weight.shape[1] != x.C:
+            return False                      # (m = 8: large layers only, no coefficient-folding input transform)
         small = bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)
         cands = [(wm, H, W, cout)]
         if up == 2 and m.upsample_phases:         # conv3x3(nearest x2 (x)) may run as four phase filters on x itself
             wl = phase_filter_tile(self.N, x.H, x.W, x.C, 4 * cout, m.winograd, small, m.upsample_f72 and not self.training)
-            if wl >= wm:
+            if wl >= min(wm, 6):
                 if wl == 7:
                     return False                  # (F(7x7, 2x2): large layers only, no coefficient-folding input transform)
                 cands = [(wl, x.H, x.W, 4 * cout)]
@@ -1211,7 +1220,8 @@ class _Plan:
         if not self.m.winograd or w.dim() != 4 or w.shape[2] != 3 or (flags & ~6) != 0:
             return 0
         return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd,
-                             small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small))
+                             small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small),
+                             forward_only=not self.training and bool(self.m.gemm_bf3))
 
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
@@ -1315,7 +1325,7 @@ class _Plan:
                                    self.m.upsample_f72 and not self.training)
             if wl == 7 and self._use_bf3(7, x.H, x.W, x.C, 4 * cout) != "p":
                 wl = 6                            # (F(7x7, 2x2) exists on the pre-split planes only)
-            if wl >= wm:
+            if wl >= min(wm, 6):               # (m = 8 at the upsampled size does not beat the phase filters' 4x smaller input transform)
                 pw = self._packed(_PackedWinograd, mod.weight, mod.bias, x.C, wl, bf3=self._use_bf3(wl, x.H, x.W, x.C, 4 * cout),
                                   phases=True)
                 self.convs.append(pw)

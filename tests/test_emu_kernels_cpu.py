@@ -155,6 +155,12 @@ def test_attention_presplit_form_is_bit_equal(N, T, heads, ch, new_order):
     K.test_attention_presplit_form_is_bit_equal(CPU, N, T, heads, ch, new_order)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,pre,up,res,f32v", [(1, 13, 11, 32, 128, 1, 0, 1, 0), (1, 8, 16, 32, 128, 1, 1, 2, 0),
+                                                             (1, 9, 8, 32, 128, 0, 0, 0, 1)])
+def test_winograd_f8_forward(N, H, W, Cin, Cout, pre, up, res, f32v):
+    K.test_winograd_f8_forward(CPU, N, H, W, Cin, Cout, pre, up, res, f32v)
+
+
 @pytest.mark.parametrize("kernel", [4, 6])
 def test_gemm_bf3p_ragged_rows_read_the_padding(kernel):
     K.test_gemm_bf3p_ragged_rows_read_the_padding(CPU, kernel)

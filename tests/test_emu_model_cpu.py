@@ -117,7 +117,7 @@ def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -151,7 +151,7 @@ def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=8, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -194,7 +194,7 @@ def test_upsampling_conv_as_f72_phase_filters(monkeypatch):
     import bbdm_amd
     import bbdm_oracle as O
     from fixture_weights import synth_weights
-    wt = lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
+    wt = lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile", wt)
     monkeypatch.setattr(bbdm_amd.unet, "phase_filter_tile",
                         lambda N, H, W, cin, cout4, max_m, small, f72=True:
@@ -233,7 +233,7 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     # the forward's tile rule wants >= 128 channels (4x the emulation time): let the 64-channel layers take F(4x4) too, so that
     # the training forward keeps their V and the gradient plan runs the staged form (dY transform -> TN GEMM -> finish) on it
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6, small=True: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -343,3 +343,49 @@ def test_long_sequence_attention_takes_the_presplit_form():
     with torch.no_grad():
         ref = O.unet_forward({k: v.detach() for k, v in net.state_dict().items()}, O.UNetSpec(**params), x, t, None)
     assert parity_err(outs[1], ref) < M.STEP_TOL
+
+
+def test_forward_on_f8_tiles(monkeypatch):
+    """UNetModel.winograd = 8: the inference forward of the large 3x3 layers on F(8x8, 3x3) (csrc/winograd_math.h: ten points; forced here
+    onto a 16x16 model with 128-channel layers).  Within the step tolerance of the oracle and of the default plan; the training plan of
+    the same model keeps the tiles that have a gradient side."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    real = bbdm_amd.unet.winograd_tile
+
+    def wt(N, H, W, cin, cout, max_m=6, small=True, forward_only=False):
+        if forward_only and max_m >= 8 and cin % 16 == 0 and cin >= 128 and cout % 128 == 0 and H >= 16:
+            return 8
+        return 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
+    monkeypatch.setattr(bbdm_amd.unet, "winograd_tile", wt)
+    up = dict(image_size=16, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 1), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 88)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.eval()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    t = torch.tensor([7, 900])
+    outs = {}
+    for cap in (8, 6):
+        m.winograd = cap
+        with torch.no_grad():
+            outs[cap] = m(x, timesteps=t, context=None).clone()
+        plan = m._plan_for(x, False)
+        tiles = sorted({a[0] for n, a in plan.ops if str(n) == "bbdm_winograd_gemm_f32"})
+        assert (8 in tiles) == (cap == 8), tiles
+    ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
+    e8, e6 = parity_err(outs[8], ref), parity_err(outs[6], ref)
+    print(f"tiny UNet on F(8x8,3x3): {e8:.2e} (default plan {e6:.2e})")
+    assert e8 < 1e-3 and e6 < M.STEP_TOL
+    m.winograd = 8
+    m.train()
+    tplan = m._plan_for(x, True)
+    assert 8 not in {a[0] for n, a in tplan.ops if str(n) == "bbdm_winograd_gemm_f32"}
+    assert real(16, 64, 64, 1024, 1024, 8, forward_only=True) == 8 and real(16, 64, 64, 1024, 1024, 8) == 6 \
+        and real(16, 64, 64, 1024, 1024, 6, forward_only=True) == 6 and real(16, 256, 256, 128, 128, 8, forward_only=True) == 8 \
+        and real(32, 32, 32, 512, 512, 8, forward_only=True) == 4

@@ -30,6 +30,101 @@ MATS = {
 }
 
 
+def cook_toom(pairs, m, r=3):
+    """Cook-Toom matrices (B^T, G, A^T) of F(m, r) on the points {0, +-p for p in pairs, inf}, in exact rational arithmetic:
+    A^T[i][j] = p_j^i, G[j][k] = p_j^k / prod_{l != j} (p_j - p_l), B^T row j = the coefficients of prod_{l != j} (x - p_l) (row inf: of
+    prod_l (x - p_l)) -- then every row of B^T and column of A^T is multiplied by the odd part of its common denominator and a power
+    of two (largest entry in [1, 2)), G taking the reciprocals: B^T and A^T become dyadic rationals, i.e. exact in fp32, as
+    csrc/winograd_math.h hard-codes them for m = 8."""
+    from fractions import Fraction as Fr
+    import math
+    pts = [Fr(0)] + [s * Fr(p) for p in pairs for s in (1, -1)]
+    n = m + r - 1
+    assert len(pts) == n - 1
+
+    def polymul(a, b):
+        c = [Fr(0)] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                c[i + j] += x * y
+        return c
+    AT = [[Fr(0)] * n for _ in range(m)]
+    G = [[Fr(0)] * r for _ in range(n)]
+    BT = [[Fr(0)] * n for _ in range(n)]
+    for j, p in enumerate(pts):
+        for i in range(m):
+            AT[i][j] = p ** i
+        Nj = math.prod([p - q for k, q in enumerate(pts) if k != j], start=Fr(1))
+        for k in range(r):
+            G[j][k] = p ** k / Nj
+        f = [Fr(1)]
+        for k, q in enumerate(pts):
+            if k != j:
+                f = polymul(f, [-q, Fr(1)])
+        BT[j][:len(f)] = f
+    AT[m - 1][n - 1] = Fr(1)
+    G[n - 1][r - 1] = Fr(1)
+    f = [Fr(1)]
+    for q in pts:
+        f = polymul(f, [-q, Fr(1)])
+    BT[n - 1][:len(f)] = f
+
+    def odd_den(vals):
+        den = 1
+        for c in vals:
+            d = c.denominator
+            while d % 2 == 0:
+                d //= 2
+            den = den * d // math.gcd(den, d)
+        return Fr(den)
+
+    def pow2_norm(vals):
+        mx, e = max(abs(c) for c in vals), 0
+        while mx >= 2:
+            mx, e = mx / 2, e - 1
+        while mx < 1:
+            mx, e = mx * 2, e + 1
+        return Fr(2) ** e
+    for j in range(n):
+        s = odd_den(BT[j])
+        s *= pow2_norm([c * s for c in BT[j]])
+        BT[j] = [c * s for c in BT[j]]
+        G[j] = [c / s for c in G[j]]
+        col = [AT[i][j] for i in range(m)]
+        s = odd_den(col)
+        s *= pow2_norm([c * s for c in col])
+        for i in range(m):
+            AT[i][j] *= s
+        G[j] = [c / s for c in G[j]]
+    t64 = lambda M_: torch.tensor([[float(c) for c in row] for row in M_], dtype=torch.float64)
+    return t64(BT), t64(G), t64(AT)
+
+
+# m = 8 (round 5, forward only): ten points {0, +-1/2, +-3/4, +-4/3, +-2, inf}; B^T and A^T exact in fp32 (checked below)
+MATS[8] = cook_toom(["1/2", "3/4", "4/3", "2"], 8)
+
+
+def test_f8_matrices_are_exact_in_fp32_and_the_point_set_is_the_accurate_one():
+    """B^T / A^T of m = 8 survive the round trip through fp32 (the algebra then holds exactly; only data round), and the point set
+    beats the textbook {0, +-1, +-2, +-1/2, +-4, inf} by an order of magnitude in fp32 (every stage of the restatement in fp32, Cin = 256,
+    post-SiLU-like data: rms 4.6e-5 against 4.6e-4; m = 6: 6.2e-6 -- the price of the larger tile is 7x m = 6's error)."""
+    BT, G, AT = MATS[8]
+    assert torch.equal(BT.float().double(), BT) and torch.equal(AT.float().double(), AT)
+    g = torch.Generator().manual_seed(8)
+    x = F.silu(torch.randn(1, 256, 24, 24, generator=g) * 1.5 + 0.3)
+    w = torch.randn(8, 256, 3, 3, generator=g) * 0.03
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    rms = lambda y: float(((y.double() - ref).pow(2).mean() / ref.pow(2).mean()).sqrt())
+    e_ours = rms(winograd_conv(x, w, 8, torch.float32))
+    MATS[80] = cook_toom(["1", "2", "1/2", "4"], 8)
+    try:
+        e_textbook = rms(_winograd_conv_mats(x, w, 8, MATS[80], torch.float32))
+    finally:
+        del MATS[80]
+    e6 = rms(winograd_conv(x, w, 6, torch.float32))
+    assert e_ours < 1e-4 and e_textbook > 4 * e_ours and e6 < e_ours, (e_ours, e_textbook, e6)     # measured: 4.6e-5, 4.6e-4, 6.2e-6
+
+
 # F(7x7, 2x2) on the same eight points (round 5: the phase filters of conv3x3(nearest x2 (x)) read 2 x 2 pixels each): B^T is m = 6's,
 # G is 8 x 2 with the same row scalings, A^T gains the x^6 row and moves the point-at-infinity column there.
 _PTS = [0, 1, -1, 2, -2, .5, -.5]
@@ -79,31 +174,39 @@ def test_f72_exact_in_fp64_and_as_upsample_phases():
 
 
 def winograd_conv(x, w, m, dtype):
-    """x [N,C,H,W], w [K,C,3,3] -> [N,K,H,W]; every stage in `dtype` (the HIP path: fp32)."""
-    BT, G, AT = (t.to(dtype) for t in MATS[m])
-    x, w = x.to(dtype), w.to(dtype)
+    """x [N,C,H,W], w [K,C,3,3] -> [N,K,H,W]; every stage in `dtype` (the HIP path: fp32; m = 8: the filter transform in fp64, rounded
+    once, as csrc/winograd.hip evaluates it)."""
+    return _winograd_conv_mats(x, w, m, MATS[m], dtype)
+
+
+def _winograd_conv_mats(x, w, m, mats, dtype):
+    BT, G, AT = (t.to(dtype) for t in mats)
+    if m == 8 and dtype == torch.float32:
+        G = mats[1]
+    x, w = x.to(dtype), w.to(G.dtype)
     a = m + 2
     N, C, H, W = x.shape
     K = w.shape[0]
     tiles = F.pad(x, (1, 1, 1, 1)).unfold(2, a, m).unfold(3, a, m)            # N, C, th, tw, a, a
     V = torch.einsum("ij,nctwjk,lk->nctwil", BT, tiles, BT)                  # input transform  B^T d B
-    U = torch.einsum("ij,kcjl,ml->kcim", G, w, G)                            # filter transform G g G^T
+    U = torch.einsum("ij,kcjl,ml->kcim", G, w, G).to(dtype)                  # filter transform G g G^T
     M = torch.einsum("nctwil,kcil->nktwil", V, U)                            # (m+2)^2 independent GEMMs over c
     Y = torch.einsum("ij,nktwjl,ml->nktwim", AT, M, AT)                      # output transform A^T m A
     return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, K, H, W)
 
 
-@pytest.mark.parametrize("m", [2, 4, 6])
+@pytest.mark.parametrize("m", [2, 4, 6, 8])
 def test_exact_in_fp64(m):
     g = torch.Generator().manual_seed(m)
-    x = torch.randn(2, 5, 12, 24, generator=g, dtype=torch.float64)
+    x = torch.randn(2, 5, 24 if m == 8 else 12, 24, generator=g, dtype=torch.float64)
     w = torch.randn(7, 5, 3, 3, generator=g, dtype=torch.float64)
     ref = F.conv2d(x, w, padding=1)
-    assert float((winograd_conv(x, w, m, torch.float64) - ref).abs().max()) < 1e-12
+    tol = 1e-11 if m == 8 else 1e-12             # (fp64 rounding amplified by the ten-point transforms: 1.5e-12 measured)
+    assert float((winograd_conv(x, w, m, torch.float64) - ref).abs().max()) < tol
     # data gradient = the same algorithm on the transposed, spatially flipped filter (winograd_weight_kernel, dgrad)
-    dy = torch.randn(2, 7, 12, 24, generator=g, dtype=torch.float64)
+    dy = torch.randn(2, 7, 24 if m == 8 else 12, 24, generator=g, dtype=torch.float64)
     wd = w.transpose(0, 1).flip(2, 3)
-    assert float((winograd_conv(dy, wd, m, torch.float64) - F.conv_transpose2d(dy, w, padding=1)).abs().max()) < 1e-12
+    assert float((winograd_conv(dy, wd, m, torch.float64) - F.conv_transpose2d(dy, w, padding=1)).abs().max()) < tol
 
 
 def winograd_wgrad(x, dy, m, dtype):
@@ -157,7 +260,7 @@ def test_fp32_rounding_levels():
     assert e2 < e4 < e6                            # each step up in tile size costs accuracy: ~10x, then ~2x
 
 
-@pytest.mark.parametrize("m", [2, 4, 6, 7])
+@pytest.mark.parametrize("m", [2, 4, 6, 7, 8])
 def test_hip_source_transforms_match_the_matrices(m):
     """csrc/winograd.hip evaluates B^T, A^T and G as hand-factored adds / multiplies; the same template code compiled
     for the host (bbdm_debug_winograd_transform_1d, an exported test hook) must agree with the matrices above on random
@@ -171,7 +274,7 @@ def test_hip_source_transforms_match_the_matrices(m):
     fn.restype = ctypes.c_int
     BT, G, AT = (t.numpy() for t in (MATS72 if m == 7 else MATS[m]))
     rng = np.random.RandomState(m)
-    sides = ((0, BT), (1, AT), (2, G)) if m == 7 else ((0, BT), (1, AT), (2, G), (3, AT.T), (4, G.T))
+    sides = ((0, BT), (1, AT), (2, G)) if m in (7, 8) else ((0, BT), (1, AT), (2, G), (3, AT.T), (4, G.T))
     for which, mat in sides:      # 3, 4: the weight-gradient side (winograd_math.h)
         rows, cols = mat.shape
         vecs = [rng.randn(cols).astype(np.float32) for _ in range(8)] + list(np.eye(cols, dtype=np.float32))
