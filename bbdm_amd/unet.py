@@ -694,10 +694,12 @@ class UNetModel(nn.Module):
         # inference plans replay their launches as ONE hipGraph (None = yes on a GPU; False = launch by launch, e.g. under rocprofv3)
         self.hip_graph: Optional[bool] = None
         # 3x3 convolutions of wide layers through Winograd F(m x m, 3x3) (csrc/winograd.hip; `winograd_tile` picks per layer):
-        # largest output tile allowed: 8, 6, 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B).  8 = F(8x8, 3x3) on the
-        # inference forward of the large layers: -15 % tile-GEMM work and transformed bytes for ~7x the fp32 rounding error of m = 6
-        # (C2 step parity 1.6e-5 -> ~1e-4 of the 1e-3 bar; see winograd_tile)
-        self.winograd: int = 6
+        # largest output tile allowed: 8 (default), 6, 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B).  8 = F(8x8, 3x3) on
+        # the inference forward of the large layers (>= 900 tiles, whole 128-channel blocks; training plans never take it): -15 % tile-GEMM
+        # work and transformed bytes for ~7x the fp32 rounding error of m = 6 -- the C2 step goes 108.0 -> 97.1 ms, its parity against the
+        # reference 1.6e-5 -> 1.1e-4 (max norm; 8.9e-6 -> 6.5e-5 in L2) of the 1e-3 bar (BASELINE.json north_star).  6 restores round 4's
+        # accuracy (the reference's own GPU path runs its convolutions in TF32 by default: ~1e-3)
+        self.winograd: int = 8
         # fold GroupNorm -> FiLM -> SiLU (and an up-sampling ResBlock's nearest x2) into the Winograd input transform
         self.winograd_fuse_groupnorm: bool = True
         # small 3x3 layers (128 ... 8192 F(2x2) tiles) on F(2x2,3x3) + the bf16x3 GEMM instead of the direct f32-MFMA kernel

@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line with, besides the contract fields,
   hip_graph    : the timed region replays the forward as one hipGraph (the product path); the per-launch events then come from an
                  eager pass of the same K steps right after it (`eager_profiled_ms_per_step`);
   f32mfma_ms_per_step : the same step with those GEMMs on the f32 MFMA (strict-fp32 A/B, 5 steps after the timed region);
+  winograd6_ms_per_step : the same step on round 4's Winograd tiles (UNetModel.winograd = 6; parity["winograd6"] = its parity sample);
   parity       : image 0 of the benchmarked batch against the CPU path (c4: loss + named gradients against the oracle's autograd);
   cpu_baseline : the oracle (kind "port": oracle/bbdm_oracle.py, the validated restatement of the reference's CPU
                  path) timed on this box's host cores on a bounded sample of the same workload.
@@ -212,7 +213,7 @@ def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
     threads = torch.get_num_threads()
     parity = None
     if parity_inputs is not None:
-        x_t, y, i_par, eps, g_a, g_b = parity_inputs
+        x_t, y, i_par, eps, g_a, g_b, alt = parity_inputs
         x_t, y, eps = x_t[:1].cpu(), y[:1].cpu(), eps[:1].cpu()
     else:
         x_t, y = make_inputs(1, ch, size)
@@ -224,6 +225,8 @@ def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
     warm = time.perf_counter() - t0
     if parity_inputs is not None:
         parity = _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
+        if alt is not None:
+            parity["winograd6"] = {k: v for k, v in _parity_record(alt[0], alt[1], a_ref, b_ref, i_par, path.kind).items() if k.startswith("rel_err")}
     n_timed = max(3, min(20, int((budget_s - warm) / max(warm, 1e-3))))
     med, ts = _time_cpu_steps(path, x_t, y, ctx, eps, n_timed)
     out = {"value": 1.0 / (med * batch), "unit": "steps/s", "cores": threads, "kind": path.kind,
@@ -259,11 +262,14 @@ def parity_only(workload, sd, parity_inputs):
     """The parity sample without the timing leg: image 0 of the benchmarked batch, one p_sample step on the CPU path."""
     desc, up, ch, size, batch, skip, sstep = WORKLOADS[workload]
     path = _CpuPath(up, skip, sstep, sd)
-    x_t, y, i_par, eps, g_a, g_b = parity_inputs
+    x_t, y, i_par, eps, g_a, g_b, alt = parity_inputs
     x_t, y, eps = x_t[:1].cpu(), y[:1].cpu(), eps[:1].cpu()
     ctx = None if up["condition_key"] == "nocond" else y
     a_ref, b_ref = path.p_sample(x_t, y, ctx, i_par, eps)
-    return _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
+    parity = _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
+    if alt is not None:
+        parity["winograd6"] = {k: v for k, v in _parity_record(alt[0], alt[1], a_ref, b_ref, i_par, path.kind).items() if k.startswith("rel_err")}
+    return parity
 
 
 def training_parity(model, sd, up, skip, sstep, x0, y, dev):
@@ -409,6 +415,10 @@ def main():
         line["summary"] = {args.workload: _brief(line, line["roofline"]["frac_step"])}
         for w, r in (line.get("workloads") or {}).items():
             line["summary"][w] = _brief(r, r["frac_step"])
+        if line.get("winograd6_ms_per_step"):        # the headline on round 4's tiles: [ms_per_step, worst parity rel_err]
+            w6 = (line.get("parity") or {}).get("winograd6") or {}
+            line["summary"][args.workload + "_winograd6"] = [round(line["winograd6_ms_per_step"], 3),
+                                                             float(f"{max(w6.values()):.2g}") if w6 else None]
         line["summary"]["units"] = "[ms_per_step, frac_step, worst parity rel_err]"
         print(json.dumps(line))
     if dist is not None:
@@ -575,6 +585,28 @@ def run_workload(args, env):
             model.denoise_fn.gemm_bf3 = True
         plan_keys = list(model.denoise_fn._plans)
         for k in plan_keys[1:]:                    # drop the A/B plan's buffers again
+            del model.denoise_fn._plans[k]
+        torch.cuda.empty_cache()
+
+    # ... and on round 4's Winograd tiles (UNetModel.winograd = 6: F(6x6, 3x3) instead of F(8x8, 3x3) on the large layers -- 7x closer
+    # to the reference, ~10 % slower): the same 2 + 5 steps; its parity sample is taken next to the headline's below
+    winograd6_ms = None
+    if args.workload in ("c2", "c3") and not training and world == 1 and not args.no_f32mfma and model.denoise_fn.winograd >= 8:
+        model.denoise_fn.winograd = 6
+        try:
+            for i in range(2):
+                state["img"] = step(i, state["img"])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5):
+                state["img"] = step(2 + i, state["img"])
+            e1.record()
+            torch.cuda.synchronize(dev)
+            winograd6_ms = e0.elapsed_time(e1) / 5
+        finally:
+            model.denoise_fn.winograd = 8
+        for k in list(model.denoise_fn._plans)[1:]:
             del model.denoise_fn._plans[k]
         torch.cuda.empty_cache()
 
@@ -798,6 +830,7 @@ def run_workload(args, env):
                          "direct_conv_peak": PEAK_FP32_MFMA_TFLOPS},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
             "f32mfma_ms_per_step": f32mfma_ms,
+            "winograd6_ms_per_step": winograd6_ms,
             "training": training_info,
         }
         if args.workload in FIRST_STAGE and not args.no_pipeline:
@@ -816,7 +849,20 @@ def run_workload(args, env):
             finally:
                 torch.randn_like = orig_rl
             torch.cuda.synchronize(dev)
-            par_in = (x_t, y, i_par, eps, g_a[0].cpu(), g_b[0].cpu())
+            alt = None
+            if winograd6_ms is not None:                 # the same sample on the F(6x6, 3x3) plan
+                model.denoise_fn.winograd = 6
+                torch.randn_like = lambda t, **k: eps
+                try:
+                    h_a, h_b = model.p_sample(x_t, y, ctx, i_par, clip_denoised=False)
+                finally:
+                    torch.randn_like = orig_rl
+                    model.denoise_fn.winograd = 8
+                torch.cuda.synchronize(dev)
+                alt = (h_a[0].cpu(), h_b[0].cpu())
+                for k in list(model.denoise_fn._plans)[1:]:
+                    del model.denoise_fn._plans[k]
+            par_in = (x_t, y, i_par, eps, g_a[0].cpu(), g_b[0].cpu(), alt)
         line["cpu_baseline"], line["parity"] = None, None
         if not args.no_cpu and world == 1:
             line["cpu_baseline"], line["parity"] = cpu_baseline(args.workload, sd, args.cpu_budget, par_in)
@@ -826,7 +872,7 @@ def run_workload(args, env):
         if training and not args.no_parity and world == 1:
             line["parity"] = training_parity(model, sd, up, skip, sstep, x_t, y, dev)
         par = line["parity"]
-        if par is not None and not all(v < par["bar"] for k, v in par.items() if k.startswith("rel_err")):
+        if par is not None and not all(v < par["bar"] for k, v in par.items() if k.startswith("rel_err") and not isinstance(v, dict)):
             raise RuntimeError(f"bench parity check failed: {par}")
         return line
     return None

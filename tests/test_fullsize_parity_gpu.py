@@ -81,7 +81,7 @@ def test_c2_256x256_step_direct_and_winograd(dev):
     i = 431
     with torch.no_grad():
         a_ref, b_ref = ora.p_sample(x_t, y, y, i, clip_denoised=False, noise=eps)
-    for wino in (0, 4, 6):
+    for wino in (0, 4, 6, 8):                             # (8, the default: F(8x8, 3x3) on the large layers, F(6x6) / F(7x7, 2x2) elsewhere)
         m.denoise_fn.winograd = wino
         m.denoise_fn._plans = {}                          # one 256^2 plan resident at a time
         for n in (N, 1):
@@ -90,6 +90,8 @@ def test_c2_256x256_step_direct_and_winograd(dev):
             if plan is not None:
                 n_wino = sum(name == "bbdm_winograd_gemm_f32" for name, _ in plan.ops)
                 assert (n_wino == 0) == (wino == 0)
+                tiles = {args[0] for name, args in plan.ops if name == "bbdm_winograd_gemm_f32"}
+                assert (8 in tiles) == (wino == 8) and (not tiles or max(tiles) <= max(wino, 7 if wino >= 6 else 0)), tiles
                 t_attn = [args[6] for name, args in plan.ops if name == "bbdm_attention_f32"]
                 assert t_attn == [4096]
             ea, eb = parity_err(a, a_ref[:n]), parity_err(b, b_ref[:n])
