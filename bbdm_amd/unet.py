@@ -536,7 +536,7 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, s
     # of m = 6's 1.78, and 64 / 128 / 256-pixel images tile without the 2 - 6 % edge waste of the 6-pixel grid: -14 ... -17 % tile GEMM work
     # and transformed bytes.  Its fp32 error is ~7x m = 6's (tests/test_winograd_math_cpu.py): UNetModel.winograd = 8 opts in.
     t8h, t8w = -(-H // 8), -(-W // 8)
-    if (forward_only and max_m >= 8 and cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and hw >= 64 and N * t8h * t8w >= 900
+    if (forward_only and max_m >= 8 and cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and hw >= 64 and N * t8h * t8w >= 512
             and (8 * t8h) * (8 * t8w) <= 1.10 * H * W):
         return 8
     t6h, t6w = -(-H // 6), -(-W // 6)
@@ -695,7 +695,7 @@ class UNetModel(nn.Module):
         self.hip_graph: Optional[bool] = None
         # 3x3 convolutions of wide layers through Winograd F(m x m, 3x3) (csrc/winograd.hip; `winograd_tile` picks per layer):
         # largest output tile allowed: 8 (default), 6, 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B).  8 = F(8x8, 3x3) on
-        # the inference forward of the large layers (>= 900 tiles, whole 128-channel blocks; training plans never take it): -15 % tile-GEMM
+        # the inference forward of the large layers (>= 512 tiles, whole 128-channel blocks; training plans never take it): -15 % tile-GEMM
         # work and transformed bytes for ~7x the fp32 rounding error of m = 6 -- the C2 step goes 108.0 -> 97.1 ms, its parity against the
         # reference 1.6e-5 -> 1.1e-4 (max norm; 8.9e-6 -> 6.5e-5 in L2) of the 1e-3 bar (BASELINE.json north_star).  6 restores round 4's
         # accuracy (the reference's own GPU path runs its convolutions in TF32 by default: ~1e-3)

@@ -388,4 +388,4 @@ def test_forward_on_f8_tiles(monkeypatch):
     assert 8 not in {a[0] for n, a in tplan.ops if str(n) == "bbdm_winograd_gemm_f32"}
     assert real(16, 64, 64, 1024, 1024, 8, forward_only=True) == 8 and real(16, 64, 64, 1024, 1024, 8) == 6 \
         and real(16, 64, 64, 1024, 1024, 6, forward_only=True) == 6 and real(16, 256, 256, 128, 128, 8, forward_only=True) == 8 \
-        and real(32, 32, 32, 512, 512, 8, forward_only=True) == 4
+        and real(32, 32, 32, 512, 512, 8, forward_only=True) == 8 and real(32, 16, 16, 1024, 1024, 8, forward_only=True) == 4

@@ -58,7 +58,11 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert wt(16, 8, 8, 1024, 1024, 6, small=False) == 0
     tiny = unet.UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
                           attention_resolutions=(), channel_mult=(1,), num_head_channels=32, condition_key="nocond")
-    assert tiny.winograd == 6      # the default cap
+    assert tiny.winograd == 8      # the default cap: F(8x8, 3x3) where an INFERENCE plan has the tiles for it (forward_only) ...
+    assert wt(16, 64, 64, 1024, 1024, 8, forward_only=True) == 8 and wt(16, 256, 256, 128, 128, 8, forward_only=True) == 8
+    assert wt(16, 64, 64, 1024, 1024, 8) == 6 and wt(16, 64, 64, 1024, 1024, 6, forward_only=True) == 6      # ... never a gradient plan / under a cap of 6
+    assert wt(16, 64, 64, 1024, 1000, 8, forward_only=True) == 6 and wt(16, 64, 64, 136, 128, 8, forward_only=True) == 6     # whole 128-channel output blocks, 16-channel chunks
+    assert wt(32, 32, 32, 512, 512, 8, forward_only=True) == 8 and wt(4, 64, 64, 512, 512, 8, forward_only=True) == 4     # 512 tiles / 256: too few
     assert lib_tiles(6, 16, 64, 64) == 2048 and lib_tiles(4, 16, 64, 64) == 4096 and lib_tiles(2, 3, 8, 12) == 256
 
 
@@ -78,7 +82,8 @@ def test_winograd_wgrad_tile_choice_follows_the_measured_crossovers():
 
 @pytest.mark.parametrize("workload,batch,training,cap", [("c1", 4, False, 4), ("c1", 16, False, 4), ("c1", 16, True, 4),
                                                          ("c5", 32, False, 4), ("c1", 16, False, 6), ("c2", 2, False, 6),
-                                                         ("c3", 32, True, 6)])
+                                                         ("c3", 32, True, 6), ("c2", 2, False, 8), ("c3", 32, False, 8),
+                                                         ("c3", 32, True, 8)])
 def test_plan_ops_are_consistent(workload, batch, training, cap):
     lib = _lib.load()
     m, plan = _plan(workload, batch, training, winograd=cap)
@@ -92,7 +97,10 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert (n2, n3) == ("bbdm_winograd_gemm_f32", "bbdm_winograd_output_f32")       # emitted as a triple
         wm = i[0]
         N, H, W, cin = i[9:13]
-        assert wm in (2, 4, 6, 7) and g[0] == wm and o[0] == wm
+        assert wm in (2, 4, 6, 7, 8) and g[0] == wm and o[0] == wm
+        # m = 8 = F(8x8, 3x3): inference forward only, >= 512 tiles, whole 16-channel chunks in, whole 128-channel blocks out, under a cap of 8
+        assert wm != 8 or (cap == 8 and not training and cin % 16 == 0 and g[8] % 128 == 0 and unet.wino_tiles(8, N, H, W) >= 512
+                           and not getattr(ops[k][0], "entry", "").endswith("_gn_f32"))
         assert (wm >= 6 or (H % wm == 0 and W % wm == 0)) and cin % 4 == 0
         phases = bool(o[7] & 8)          # conv3x3(nearest x2 (x)) as four phase filters on x: the GEMMs produce 4 Cout channels
         # m = 7 = F(7x7, 2x2): only the phase filters of an up-sampling conv, inference, on the pre-split planes, whole 128-channel
@@ -108,7 +116,8 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         if phases:
             dst = o[5]
             assert not up and not training and (dst.H, dst.W, dst.C) == (2 * H, 2 * W, cout // 4) and o[3] is None
-            assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) >= unet.winograd_tile(N, 2 * H, 2 * W, cin, cout // 4, m.winograd)
+            assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) >= min(6, unet.winograd_tile(N, 2 * H, 2 * W, cin, cout // 4, m.winograd,
+                                                                                                   forward_only=not training))
         tiles = lib.bbdm_winograd_tiles(wm, N, H, W)
         P = unet.wino_planes(wm)
         assert tiles % 256 == 0 and tiles >= unet.wino_tiles(wm, N, H, W)
