@@ -122,10 +122,25 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
     auto setup = [&](int L) -> bool {
         int bid, bz;
         if (a.by_batch) {
-            const int j = L >> 3;
-            bz = (L & 7) + 8 * (j / a.tiles);
-            if (bz >= a.batch) return false;
-            bid = j % a.tiles;
+            // XCD x = L % 8 owns the batch entries x, x + 8, ...: an entry's B planes cross the fabric into ONE L2.  A last group of 1, 2
+            // or 4 entries (batch % 8: the 36 points of F(4x4,3x3), the 100 of F(8x8,3x3)) is SHARED instead of padded -- entry
+            // 8 g + x % rem, every (8 / rem)-th of its tiles per XCD -- so that every XCD gets batch / 8 entries' worth of tiles (round 5:
+            // with whole entries four XCDs of an F(4x4) layer held 5 entries and four 4, and the layer took the time of 5: +11 %)
+            const int j = L >> 3, x = L & 7, g = j / a.tiles;
+            const int full = a.batch >> 3, rem = a.batch & 7;
+            if (g < full) {
+                bz = x + 8 * g;
+                bid = j - g * a.tiles;
+            } else if (rem == 1 || rem == 2 || rem == 4) {
+                const int t = (j - full * a.tiles) * (8 / rem) + x / rem;
+                if (t >= a.tiles) return false;
+                bz = 8 * full + x % rem;
+                bid = t;
+            } else {
+                bz = x + 8 * g;
+                if (bz >= a.batch) return false;
+                bid = j - g * a.tiles;
+            }
         } else {
             bz = (int)blockIdx.z;
             bid = xcd_block_p((int)gridDim.x, (int)blockIdx.x, (int)(((size_t)blockIdx.z * gridDim.x) % 8));
@@ -814,6 +829,12 @@ extern "C" int bbdm_gemm_bf3p_split_rows_f32(const float* x, int ldx, void* a_pl
     return BBDM_OK;
 }
 
+// tile slots per XCD of a by_batch launch (see setup() in the kernel): whole groups of 8 entries, then the last 1, 2 or 4 entries shared
+static inline long long by_batch_slots(long long blocks, int batch) {
+    const int full = batch >> 3, rem = batch & 7;
+    if (rem == 1 || rem == 2 || rem == 4) return blocks * full + (blocks + 8 / rem - 1) / (8 / rem);
+    return blocks * ((batch + 7) / 8);
+}
 template <int WM, int WN, bool RES, int NS = 2>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
@@ -830,7 +851,7 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     const long long blocks = (((long long)a.T + WM * 64 - 1) / (WM * 64)) * (a.tilesN * 2 / WN);     // (the last row tile may be ragged)
     BBDM_REQUIRE(blocks * ((batch + 7) / 8) * 8 < (1ll << 31), "gemm_bf3p: too many tiles");
     a.tiles = (int)blocks;
-    dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
+    dim3 grid = a.by_batch ? dim3((unsigned)(8 * by_batch_slots(blocks, batch))) : dim3((unsigned)blocks, 1, batch);
     a.persist = 0;
     if (a.by_batch) {
         // persistent tiles (see gemm_bf3p_pipe_kernel): as many workgroups as the chip holds at once (LDS- and wave-limited per CU), a
@@ -943,7 +964,7 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
         // profiles/r03_bf3p_tile_choice.txt).  by_batch launches quantise per XCD (32 CUs, whole batch entries).
         auto rounds = [&](int bm, int bn) {
             const long long per_entry = (long long)cdiv((int)rows, bm) * cdiv(CoutPad, bn);
-            return a.by_batch ? (double)((per_entry * ((nb + 7) / 8) + 31) / 32) : (double)((per_entry * nb + 255) / 256);
+            return a.by_batch ? (double)((by_batch_slots(per_entry, nb) + 31) / 32) : (double)((per_entry * nb + 255) / 256);
         };
         const double t44 = wide ? rounds(256, 256) : 1e30, t42 = rounds(256, 128) * 0.5 / 0.94;
         rc = t44 <= t42 ? BBDM_BF3P_GO(4, 4) : BBDM_BF3P_GO(4, 2);

@@ -161,6 +161,11 @@ def test_winograd_f8_forward(N, H, W, Cin, Cout, pre, up, res, f32v):
     K.test_winograd_f8_forward(CPU, N, H, W, Cin, Cout, pre, up, res, f32v)
 
 
+@pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(12, 512, 16, 132, 2), (9, 300, 16, 72, 1), (10, 256, 16, 40, 0), (11, 256, 16, 40, 0)])
+def test_gemm_bf3p_shared_last_group(batch, T, Cin, Cout, extra):
+    K.test_gemm_bf3p_matches_bf3_bitwise(CPU, batch, T, Cin, Cout, extra)
+
+
 @pytest.mark.parametrize("kernel", [4, 6])
 def test_gemm_bf3p_ragged_rows_read_the_padding(kernel):
     K.test_gemm_bf3p_ragged_rows_read_the_padding(CPU, kernel)

@@ -258,11 +258,15 @@ def test_gemm_bf3p_kernel_variants(dev, kernel, batch, T, Cin, Cout):
 
 
 @pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(2, 256, 48, 72, 0), (1, 512, 256, 128, 1), (3, 256, 1024, 260, 2),
-                                                    (8, 300, 64, 132, 0), (16, 768, 32, 256, 0)])
+                                                    (8, 300, 64, 132, 0), (16, 768, 32, 256, 0),
+                                                    (36, 512, 32, 256, 0), (12, 768, 32, 132, 2), (9, 300, 32, 72, 1), (10, 256, 32, 72, 0),
+                                                    (11, 256, 32, 40, 0), (100, 256, 16, 128, 0)])
 def test_gemm_bf3p_matches_bf3_bitwise(dev, batch, T, Cin, Cout, extra):
     """csrc/gemm_bf3p.hip (operands pre-split by their producers, LDS-DMA staging) must reproduce csrc/gemm_bf3.hip BIT FOR BIT --
     same exact split, same six terms in the same order -- and hence its fp32-class accuracy against an fp64 GEMM.  extra: 1 = bias,
-    2 = bias + residual (in place).  batch 8 / 16 take the each-XCD-owns-whole-entries launch; T = 300 the zero-padded rows."""
+    2 = bias + residual (in place).  batch 8 / 16 take the each-XCD-owns-whole-entries launch; T = 300 the zero-padded rows; batch 36 /
+    12 / 9 / 10 / 100 end in a group of 4 / 4 / 1 / 2 / 4 entries that the XCDs SHARE (every (8 / rem)-th tile each, one or several tiles
+    per entry), batch 11 in one of 3 that keeps whole entries."""
     import kernel_ops as ops
     g = torch.Generator().manual_seed(Cin + Cout + T)
     V = torch.randn(batch, T, Cin, generator=g) * torch.logspace(-3, 3, Cin)
