@@ -1420,7 +1420,8 @@ extern "C" int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, cons
     } while (0)
         if (m == 8) {      // two buffers = 80 KB of (dynamic) LDS, two workgroups of ten waves per CU
             constexpr size_t lds8 = (size_t)2 * 8 * 10 * 64 * sizeof(float2);
-            static bool attr_set = false;
+            static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
+            bool& attr_set = attr_set_dev[bbdm_device_slot()];
             if (!attr_set) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_output_lds_kernel<8, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess ||
                     hipFuncSetAttribute(reinterpret_cast<const void*>(winograd_output_lds_kernel<8, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) != hipSuccess) {

@@ -822,7 +822,7 @@ def run_workload(args, env):
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
                          "share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,
                          "flops_counted": "fp32-equivalent FLOPs executed: a Winograd layer's (m+2)^2 tile GEMMs = 4/9 (m=2), "
-                                          "1/4 (m=4) or 16/81 (m=6) of its direct-convolution count",
+                                          "1/4 (m=4), 16/81 (m=6) or 25/144 (m=8) of its direct-convolution count",
                          "winograd_gemm_launches_per_step": wino[0] / max(1, args.steps),
                          "winograd_gemm_tflops": (wino[2] / (wino[1] * 1e-3) / 1e12) if wino[1] > 0 else None,
                          "direct_conv_tflops": (direct[2] / (direct[1] * 1e-3) / 1e12) if direct[1] > 0 else None,
