@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)

@@ -529,6 +529,8 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
 // gemm_bf3p kernel (contraction over the tiles), in two phases through LDS like the input transform above: wave j < m transforms
 // column j of the m x m window of dY (A d), wave i < m + 2 row i (. A^T), splits, and stores through store_transposed().  The one
 // fp32 plane the bias gradient needs -- xi = (1, 1): row 1 of A is all ones, so it holds the tile sums of dY -- goes to dm11[tile][C].
+// m = 8 has no transform point 1 (winograd_math.h): there the waves of phase A leave their column sums in LDS and wave 1 adds them in
+// column order -- dm11 holds the tile sums of dY for every m.
 template <int MO>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const float* __restrict__ dy, int ld,
                                                                           unsigned char* __restrict__ dMt, float* __restrict__ dm11,
@@ -536,6 +538,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const 
                                                                           size_t plane_t, int tchunks) {
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];                 // [i][j < m][unit] intermediates; later each wave's transposition scratch
+    __shared__ float2 csum[MO == 8 ? MO * 64 : 1];       // m = 8: the column sums of the window (the bias gradient's tile sums)
     const int L = (int)blockIdx.x, q = L >> 3;
     const int chunk = q % nchunks, tg = (q / nchunks) * 8 + (L & 7);
     if (tg >= TG) return;
@@ -568,6 +571,12 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const 
         a_transform<MO>(d, col);
 #pragma unroll
         for (int i = 0; i < AL; ++i) lds[(i * AL + jj) * 64 + lane] = col[i];
+        if constexpr (MO == 8) {
+            float2 cs = d[0];
+#pragma unroll
+            for (int i = 1; i < MO; ++i) cs = cs + d[i];
+            csum[jj * 64 + lane] = cs;
+        }
     }
     __syncthreads();
     {
@@ -576,7 +585,16 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const 
 #pragma unroll
         for (int jj = 0; jj < MO; ++jj) t[jj] = lds[(i * AL + jj) * 64 + lane];
         a_transform<MO>(t, row);
-        if (i == 1 && tile < T && c < C) *reinterpret_cast<float2*>(dm11 + (size_t)tile * C + c) = row[1];
+        if constexpr (MO == 8) {
+            if (i == 1 && tile < T && c < C) {
+                float2 ts = csum[lane];
+#pragma unroll
+                for (int jj = 1; jj < MO; ++jj) ts = ts + csum[jj * 64 + lane];
+                *reinterpret_cast<float2*>(dm11 + (size_t)tile * C + c) = ts;
+            }
+        } else {
+            if (i == 1 && tile < T && c < C) *reinterpret_cast<float2*>(dm11 + (size_t)tile * C + c) = row[1];
+        }
         unsigned pl[AL][3];
 #pragma unroll
         for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
@@ -828,9 +846,6 @@ __global__ void __launch_bounds__(AL * 64) winograd_output_lds_kernel(const floa
 
 // ---- weights: U_xi[co][ci] = (G g G^T)[i][j] in the packed 1x1 layout [xi][chunk][CoutPad][16] -----------------------
 // dgrad != 0: the weights of the data-gradient convolution, g'[ci][co][r][s] = g[co][ci][2-r][2-s].
-template <int MO> struct WinoWeightT { typedef float type; };
-template <> struct WinoWeightT<8> { typedef double type; };
-
 template <int MO>
 __global__ void winograd_weight_kernel(const float* __restrict__ w, float* __restrict__ p, int Cout, int Cin, int CoutPad,
                                        int nchunks, int dgrad) {
@@ -1013,7 +1028,6 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
     // dgrad  : conv Cout -> Cin, its input (dY) carries InPad >= Cout channels.
     // m = 7  : w_oihw = the [Cout = 4 C][Cin][3][3] phase filters bbdm_upsample_phase_weights_f32 wrote; packed = G g2 G^T of F(7x7, 2x2)
     BBDM_WINO_M78(m);
-    BBDM_REQUIRE(m != 8 || !dgrad, "winograd_pack: m = 8 is a forward-only tile");
     BBDM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && InPad % 4 == 0, "winograd_pack: bad args");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack: InPad too small");
     BBDM_REQUIRE(m != 7 || (!dgrad && Cout % 4 == 0), "winograd_pack: m = 7 takes the 4 C phase filters of a forward conv");
@@ -1046,7 +1060,6 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
 extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
                                                   void* stream) {
     BBDM_WINO_M8(m);
-    BBDM_REQUIRE(m != 8 || !dgrad, "winograd_pack_bf3p: m = 8 is a forward-only tile");
     BBDM_REQUIRE(w_oihw && b_planes && Cout > 0 && Cin > 0 && InPad % KC == 0, "winograd_pack_bf3p: bad args (InPad %% 16)");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack_bf3p: InPad too small");
     BBDM_REQUIRE(((uintptr_t)b_planes & 15) == 0, "winograd_pack_bf3p: b_planes alignment");
@@ -1167,7 +1180,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
                                  const GnFold* fold, bool f32out) {
     BBDM_WINO_M78(m);
     BBDM_REQUIRE(m != 7 || (!upsample && !Vt && !fold && !f32out), "winograd_input_bf3p: m = 7 (phase filters) takes x itself, planes only");
-    BBDM_REQUIRE(m != 8 || (!Vt && !fold), "winograd_input_bf3p: m = 8 is a forward-only tile of the large layers (no transposed copy, no coefficient folding)");
+    BBDM_REQUIRE(m != 8 || !fold, "winograd_input_bf3p: m = 8 is a tile of the large layers (no coefficient folding)");
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(!upsample || (H % 2 == 0 && W % 2 == 0), "winograd_input_bf3p: upsample needs even H, W");
@@ -1259,13 +1272,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         else if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true, false); else BBDM_WINO_INS2(MO, true, false, false); }   \
         else           { if (upsample) BBDM_WINO_INS2(MO, false, true, false); else BBDM_WINO_INS2(MO, false, false, false); } \
     } while (0)
-#define BBDM_WINO_INS2_M8()                                                                          \
-    do {                                                                                            \
-        if (pre_scale) { if (upsample) BBDM_WINO_INS2(8, true, true, false); else BBDM_WINO_INS2(8, true, false, false); }   \
-        else           { if (upsample) BBDM_WINO_INS2(8, false, true, false); else BBDM_WINO_INS2(8, false, false, false); } \
-    } while (0)
-        if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else if (m == 8) BBDM_WINO_INS2_M8(); else BBDM_WINO_INS2_M(6);
-#undef BBDM_WINO_INS2_M8
+        if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else if (m == 8) BBDM_WINO_INS2_M(8); else BBDM_WINO_INS2_M(6);
 #undef BBDM_WINO_INS2_M
 #undef BBDM_WINO_INS2
 #undef BBDM_WINO_INS2_I
@@ -1493,7 +1500,7 @@ extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const f
 // the next multiple of 32 (whole fragment units) are written as zeros.
 extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W,
                                                    int Cout, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
     BBDM_REQUIRE(dy && dMt && dm11 && N > 0, "winograd_dy_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
     BBDM_REQUIRE(Cout > 0 && Cout % 2 == 0 && ld % 2 == 0 && ld >= Cout && ((uintptr_t)dy & 7) == 0 && ((uintptr_t)dMt & 15) == 0 &&
@@ -1509,7 +1516,7 @@ extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int l
 #define BBDM_WINO_DYS(MO)                                                                                                    \
     hipLaunchKernelGGL((winograd_dy_split_kernel<MO>), g, dim3((MO + 2) * 64), 0, st, dy, ld, (unsigned char*)dMt, dm11, N, H, W, \
                        Cout, nchunks, (long long)T, TG, plane_t, (int)(Tp / 16))
-    if (m == 2) BBDM_WINO_DYS(2); else if (m == 4) BBDM_WINO_DYS(4); else BBDM_WINO_DYS(6);
+    if (m == 2) BBDM_WINO_DYS(2); else if (m == 4) BBDM_WINO_DYS(4); else if (m == 8) BBDM_WINO_DYS(8); else BBDM_WINO_DYS(6);
 #undef BBDM_WINO_DYS
     BBDM_CHECK_LAUNCH("winograd_dy_bf3p");
     return BBDM_OK;
@@ -1521,9 +1528,18 @@ extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int l
 extern "C" int bbdm_debug_winograd_transform_1d(int m, int which, const float* in, float* out) {
     BBDM_WINO_M78(m);
     BBDM_REQUIRE(in && out && which >= 0 && which <= 4, "winograd_transform_1d: bad args");
-    if (m == 8) {                      // F(8x8, 3x3): forward side only; G in fp64 (as the weight kernels evaluate it)
-        BBDM_REQUIRE(which <= 2, "winograd_transform_1d: m = 8 has no weight-gradient side");
-        if (which == 0) {
+    if (m == 8) {                      // F(8x8, 3x3): G / G^T in fp64 (as the weight / finish kernels evaluate them)
+        if (which == 3) {
+            float v[8], r[10];
+            for (int i = 0; i < 8; ++i) v[i] = in[i];
+            a_transform<8>(v, r);
+            for (int i = 0; i < 10; ++i) out[i] = r[i];
+        } else if (which == 4) {
+            double u[10], g[3];
+            for (int i = 0; i < 10; ++i) u[i] = in[i];
+            gt_transform<8>(u, g);
+            for (int i = 0; i < 3; ++i) out[i] = (float)g[i];
+        } else if (which == 0) {
             float d[10], t[10];
             for (int i = 0; i < 10; ++i) d[i] = in[i];
             bt_transform<8>(d, t);

@@ -134,6 +134,10 @@ __host__ __device__ __forceinline__ void g_transform72(const float (&g)[2], floa
     u[7] = g[1];
 }
 
+// the type G / G^T are evaluated in: fp64 for m = 8, rounded to fp32 once
+template <int MO> struct WinoWeightT { typedef float type; };
+template <> struct WinoWeightT<8> { typedef double type; };
+
 // u = G g.  (m = 8 is instantiated with T = double: its G holds ninths and 4125ths, and the transformed weights are rounded to fp32 once)
 template <int MO, typename T = float>
 __host__ __device__ __forceinline__ void g_transform(const T (&g)[3], T (&u)[MO + 2]) {
@@ -188,6 +192,26 @@ __host__ __device__ __forceinline__ void a_transform(const T (&s)[MO], T (&t)[MO
         t[3] = e2 + o2;
         t[4] = e2 - o2;
         t[5] = s[3];
+    } else if constexpr (MO == 8) {
+        // the transpose of at_transform<8> (same dyadic coefficients, exact in fp32): point pairs +-1/2, +-3/4, +-4/3 (x (3/4)^7), +-2 (x 2^-7)
+        const T e0 = ((s[0] + 0x1p-2f * s[2]) + 0x1p-4f * s[4]) + 0x1p-6f * s[6];
+        const T o0 = ((0x1p-1f * s[1] + 0x1p-3f * s[3]) + 0x1p-5f * s[5]) + 0x1p-7f * s[7];
+        const T e1 = ((s[0] + 0x1.2p-1f * s[2]) + 0x1.44p-2f * s[4]) + 0x1.6c8p-3f * s[6];
+        const T o1 = ((0x1.8p-1f * s[1] + 0x1.bp-2f * s[3]) + 0x1.e6p-3f * s[5]) + 0x1.116p-3f * s[7];
+        const T e2 = ((0x1.116p-3f * s[0] + 0x1.e6p-3f * s[2]) + 0x1.bp-2f * s[4]) + 0x1.8p-1f * s[6];
+        const T o2 = ((0x1.6c8p-3f * s[1] + 0x1.44p-2f * s[3]) + 0x1.2p-1f * s[5]) + s[7];
+        const T e3 = ((0x1p-7f * s[0] + 0x1p-5f * s[2]) + 0x1p-3f * s[4]) + 0x1p-1f * s[6];
+        const T o3 = ((0x1p-6f * s[1] + 0x1p-4f * s[3]) + 0x1p-2f * s[5]) + s[7];
+        t[0] = s[0];
+        t[1] = e0 + o0;
+        t[2] = e0 - o0;
+        t[3] = e1 + o1;
+        t[4] = e1 - o1;
+        t[5] = e2 + o2;
+        t[6] = e2 - o2;
+        t[7] = e3 + o3;
+        t[8] = e3 - o3;
+        t[9] = s[7];
     } else {
         const T e1 = (s[0] + s[2]) + s[4], o1 = (s[1] + s[3]) + s[5];
         const T e2 = (s[0] + 4.f * s[2]) + 16.f * s[4], o2 = (2.f * s[1] + 8.f * s[3]) + 32.f * s[5];
@@ -203,9 +227,18 @@ __host__ __device__ __forceinline__ void a_transform(const T (&s)[MO], T (&t)[MO
     }
 }
 // g = G^T u (the transpose of g_transform: m+2 -> 3; the last step of the weight gradient, dg = G^T dU G)
-template <int MO>
-__host__ __device__ __forceinline__ void gt_transform(const float (&u)[MO + 2], float (&g)[3]) {
-    if constexpr (MO == 2) {
+// (m = 8 is instantiated with T = double, like g_transform<8>: G holds ninths and 4125ths)
+template <int MO, typename T = float>
+__host__ __device__ __forceinline__ void gt_transform(const T (&u)[MO + 2], T (&g)[3]) {
+    if constexpr (MO == 8) {
+        const T p12 = u[1] + u[2], m12 = u[2] - u[1], p34 = u[3] + u[4], m34 = u[3] - u[4], p56 = u[5] + u[6], m56 = u[6] - u[5],
+                p78 = u[7] + u[8], m78 = u[7] - u[8];
+        g[0] = (T)(64.0 / 9.0) * u[0] - (T)(32768.0 / 4125.0) * p12 + (T)(2097152.0 / 433125.0) * p34 - (T)(131072.0 / 48125.0) * p56 +
+               (T)(8192.0 / 4125.0) * p78;
+        g[1] = (T)(16384.0 / 4125.0) * (m12 + m78) + (T)(524288.0 / 144375.0) * (m34 + m56);
+        g[2] = (T)(64.0 / 9.0) * u[9] - (T)(8192.0 / 4125.0) * p12 + (T)(131072.0 / 48125.0) * p34 - (T)(2097152.0 / 433125.0) * p56 +
+               (T)(32768.0 / 4125.0) * p78;
+    } else if constexpr (MO == 2) {
         const float p = 0.5f * (u[1] + u[2]);
         g[0] = u[0] + p;
         g[1] = 0.5f * (u[1] - u[2]);

@@ -248,10 +248,11 @@ __global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restri
     const int co = co0 + col, ci = ci0 + cil;
     if (co < Cout && ci < Cin) {
         const size_t i = (size_t)ci * Cout + co;
-        float h[3][AL];                    // h[a][nu] = sum_xi G[xi][a] u[xi][nu]
+        typedef typename WinoWeightT<MO>::type WT;      // (m = 8: G^T dU G in fp64, rounded to fp32 once)
+        WT h[3][AL];                       // h[a][nu] = sum_xi G[xi][a] u[xi][nu]
 #pragma unroll
         for (int nu = 0; nu < AL; ++nu) {
-            float colv[AL], g3[3];
+            WT colv[AL], g3[3];
 #pragma unroll
             for (int xi = 0; xi < AL; ++xi) {
                 const float* p = dU + (size_t)(xi * AL + nu) * per + i;
@@ -264,11 +265,11 @@ __global__ void __launch_bounds__(256) wgrad_finish_kernel(const float* __restri
         }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            float g3[3];
+            WT g3[3];
             gt_transform<MO>(h[r], g3);
-            tile[col][cil * 9 + 3 * r + 0] = g3[0];
-            tile[col][cil * 9 + 3 * r + 1] = g3[1];
-            tile[col][cil * 9 + 3 * r + 2] = g3[2];
+            tile[col][cil * 9 + 3 * r + 0] = (float)g3[0];
+            tile[col][cil * 9 + 3 * r + 1] = (float)g3[1];
+            tile[col][cil * 9 + 3 * r + 2] = (float)g3[2];
         }
     }
     __syncthreads();
@@ -291,8 +292,10 @@ __global__ void __launch_bounds__(256) wgrad_finish_nu_kernel(const float* __res
                                                               int Cin, int Cout, const float* __restrict__ dm11, int T,
                                                               float* __restrict__ db, int bias_blocks) {
     constexpr int AL = MO + 2;
-    constexpr int FCI = 4, FCO = 32;
-    __shared__ float hbuf[FCI][FCO][3][AL + 1];
+    constexpr int NUS = AL <= 8 ? 8 : 16;               // nu slots of the thread layout (m = 8: ten of sixteen used, 2 ci per workgroup)
+    constexpr int FCI = 32 / NUS, FCO = 32;
+    typedef typename WinoWeightT<MO>::type WT;          // (m = 8: G^T dU G in fp64, rounded to fp32 once)
+    __shared__ WT hbuf[FCI][FCO][3][AL + 1];
     __shared__ float tile[FCO][FCI * 9 + 1];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < bias_blocks) {
@@ -328,7 +331,7 @@ __global__ void __launch_bounds__(256) wgrad_finish_nu_kernel(const float* __res
     const int tilesCo = (Cout + FCO - 1) / FCO;
     const int bid = (int)blockIdx.x - bias_blocks;
     const int co0 = (bid % tilesCo) * FCO, ci0 = (bid / tilesCo) * FCI;
-    const int q = tid & 7, nu = (tid >> 3) & 7, cil = tid >> 6;
+    const int q = tid & 7, nu = (tid >> 3) & (NUS - 1), cil = tid / (8 * NUS);
     if (nu < AL && co0 + 4 * q < Cout && ci0 + cil < Cin) {
         const size_t i = (size_t)(ci0 + cil) * Cout + co0 + 4 * q;
         float4 colv[AL];
@@ -344,7 +347,7 @@ __global__ void __launch_bounds__(256) wgrad_finish_nu_kernel(const float* __res
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float cv[AL], g3[3];
+            WT cv[AL], g3[3];
 #pragma unroll
             for (int xi = 0; xi < AL; ++xi) cv[xi] = e == 0 ? colv[xi].x : e == 1 ? colv[xi].y : e == 2 ? colv[xi].z : colv[xi].w;
             gt_transform<MO>(cv, g3);
@@ -356,13 +359,13 @@ __global__ void __launch_bounds__(256) wgrad_finish_nu_kernel(const float* __res
     __syncthreads();
     for (int e = tid; e < FCI * FCO * 3; e += 256) {
         const int c2 = e / (FCO * 3), rem = e - c2 * (FCO * 3), col = rem / 3, r = rem - col * 3;
-        float hv[AL], g3[3];
+        WT hv[AL], g3[3];
 #pragma unroll
         for (int k = 0; k < AL; ++k) hv[k] = hbuf[c2][col][r][k];
         gt_transform<MO>(hv, g3);
-        tile[col][c2 * 9 + 3 * r + 0] = g3[0];
-        tile[col][c2 * 9 + 3 * r + 1] = g3[1];
-        tile[col][c2 * 9 + 3 * r + 2] = g3[2];
+        tile[col][c2 * 9 + 3 * r + 0] = (float)g3[0];
+        tile[col][c2 * 9 + 3 * r + 1] = (float)g3[1];
+        tile[col][c2 * 9 + 3 * r + 2] = (float)g3[2];
     }
     __syncthreads();
     const int nci = min(FCI, Cin - ci0);
@@ -458,17 +461,18 @@ extern "C" int bbdm_winograd_dy_transform_f32(int m, const float* dy, int ld, fl
 
 static int wgrad_finish_launch(int m, const float* dU, int splits, float* dw_oihw, int Cin, int Cout, const float* dm11, int T,
                                float* dbias, void* stream) {
-    BBDM_WINO_M(m);
+    BBDM_WINO_M8(m);
     BBDM_REQUIRE(dU && dw_oihw && splits > 0 && Cin > 0 && Cout > 0, "winograd_wgrad_finish: bad args");
     hipStream_t st = (hipStream_t)stream;
     const dim3 b(256);
     if (Cout % 4 == 0 && ((uintptr_t)dU & 15) == 0 && (!dbias || ((uintptr_t)dm11 & 15) == 0)) {
         const int bias_blocks = dbias ? cdiv(Cout, 32) : 0;
-        const long long blocks = (long long)cdiv(Cout, 32) * cdiv(Cin, 4) + bias_blocks;
+        const long long blocks = (long long)cdiv(Cout, 32) * cdiv(Cin, m == 8 ? 2 : 4) + bias_blocks;     // (FCI of wgrad_finish_nu_kernel)
         BBDM_REQUIRE(blocks < (1ll << 31), "winograd_wgrad_finish: grid too large");
         const dim3 g((unsigned)blocks);
         if (m == 2) hipLaunchKernelGGL((wgrad_finish_nu_kernel<2>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
         else if (m == 4) hipLaunchKernelGGL((wgrad_finish_nu_kernel<4>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
+        else if (m == 8) hipLaunchKernelGGL((wgrad_finish_nu_kernel<8>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
         else hipLaunchKernelGGL((wgrad_finish_nu_kernel<6>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout, dm11, T, dbias, bias_blocks);
         BBDM_CHECK_LAUNCH("winograd_wgrad_finish");
         return BBDM_OK;
@@ -479,6 +483,7 @@ static int wgrad_finish_launch(int m, const float* dU, int splits, float* dw_oih
     const dim3 g((unsigned)blocks);
     if (m == 2) hipLaunchKernelGGL((wgrad_finish_kernel<2>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
     else if (m == 4) hipLaunchKernelGGL((wgrad_finish_kernel<4>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
+    else if (m == 8) hipLaunchKernelGGL((wgrad_finish_kernel<8>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
     else hipLaunchKernelGGL((wgrad_finish_kernel<6>), g, b, 0, st, dU, splits, dw_oihw, Cin, Cout);
     BBDM_CHECK_LAUNCH("winograd_wgrad_finish");
     return BBDM_OK;

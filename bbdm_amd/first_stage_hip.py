@@ -54,6 +54,7 @@ class _Flags:
         self.fp32_v_max_cout = 128
         self.upsample_f72 = True
         self.winograd_wgrad = 0             # (inference plans only)
+        self.winograd_train8 = 0
         self.hip_graph = False
         self.op_profile = None
 

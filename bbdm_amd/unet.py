@@ -521,7 +521,15 @@ def phase_filter_tile(N: int, H: int, W: int, cin: int, cout4: int, max_m: int, 
     return wl
 
 
-def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True, forward_only: bool = False) -> int:
+def _tile8_ok(N: int, H: int, W: int, cin: int, cout: int) -> bool:
+    """Does this layer earn F(8x8, 3x3)?  Large layers on the pre-split planes: whole 16-channel chunks in, whole 128-channel blocks out,
+    >= 512 tiles (fewer: 100 transform points x the weight planes become the bound), <= 10 % edge waste."""
+    t8h, t8w = -(-H // 8), -(-W // 8)
+    return (cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and cin * cout / (cin + cout) >= 64 and N * t8h * t8w >= 512
+            and (8 * t8h) * (8 * t8w) <= 1.10 * H * W)
+
+
+def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, small: bool = True, allow8: bool = False) -> int:
     """Output tile m of the Winograd F(m x m, 3x3) path for this layer, or 0 = direct implicit GEMM.
 
     Measured on MI355X (tools/wino_bench.py -> profiles/r02_wino_bench.txt): the 2.25x (m = 2) / 4x
@@ -532,12 +540,12 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, s
     if cin % 4 or cout % 4 or cout < 128:
         return 0
     hw = cin * cout / (cin + cout)
-    # m = 8 (round 5; ``forward_only``: inference forward -- the tile has no gradient side): 100 / 64 = 1.56 multiplies per output instead
-    # of m = 6's 1.78, and 64 / 128 / 256-pixel images tile without the 2 - 6 % edge waste of the 6-pixel grid: -14 ... -17 % tile GEMM work
-    # and transformed bytes.  Its fp32 error is ~7x m = 6's (tests/test_winograd_math_cpu.py): UNetModel.winograd = 8 opts in.
-    t8h, t8w = -(-H // 8), -(-W // 8)
-    if (forward_only and max_m >= 8 and cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and hw >= 64 and N * t8h * t8w >= 512
-            and (8 * t8h) * (8 * t8w) <= 1.10 * H * W):
+    # m = 8 (round 5; ``allow8``: the bf16x3 pipeline is on -- inference forward, and since the end of round 5 the training forward /
+    # data gradient / Winograd-domain weight gradient, UNetModel.winograd_train8): 100 / 64 = 1.56 multiplies per output instead
+    # of m = 6's 1.78 (m = 4: 2.25), and 64 / 128 / 256-pixel images tile without the 2 - 6 % edge waste of the 6-pixel grid: -14 ... -17 %
+    # tile GEMM work and transformed bytes (-31 % against m = 4 on 32^2 maps).  Its fp32 error is ~7x m = 6's
+    # (tests/test_winograd_math_cpu.py): UNetModel.winograd = 8 opts in.
+    if allow8 and max_m >= 8 and _tile8_ok(N, H, W, cin, cout):
         return 8
     t6h, t6w = -(-H // 6), -(-W // 6)
     if (max_m >= 6 and cin >= 128 and hw >= 64 and N * t6h * t6w >= 900
@@ -557,12 +565,15 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, s
     return 0
 
 
-def winograd_wgrad_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6) -> int:
+def winograd_wgrad_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, allow8: bool = False) -> int:
     """Tile m of the Winograd-domain WEIGHT gradient (csrc/winograd_wgrad.hip) for this 3x3 layer, or 0 = the direct
     kernel (conv_wgrad.hip).  The (m+2)^2 TN GEMMs contract over the tiles, so what matters is a long K (tiles) and
     operands wide enough for 128-wide MFMA tiles; ragged m = 6 tiles only pay while the edge waste stays small."""
     if cin % 4 or cout % 4 or cin < 64 or cout < 64:
         return 0
+    # m = 8: where the forward takes it (the gradient contracts the transposed planes of V that forward kept: same tile both ways)
+    if allow8 and max_m >= 8 and cin % 32 == 0 and _tile8_ok(N, H, W, cin, cout):
+        return 8
     t6h, t6w = -(-H // 6), -(-W // 6)
     if max_m >= 6 and N * t6h * t6w >= 900 and (6 * t6h) * (6 * t6w) <= 1.10 * H * W:
         return 6
@@ -738,7 +749,12 @@ class UNetModel(nn.Module):
         self.grad_in_place: bool = False
         # training: weight gradients of the 3x3 layers in the Winograd domain (csrc/winograd_wgrad.hip), largest tile allowed;
         # 0: the direct kernel (conv_wgrad.hip) everywhere (tests)
-        self.winograd_wgrad: int = 6
+        self.winograd_wgrad: int = 8
+        # training plans and F(8x8, 3x3) (``winograd`` = 8, the bf16x3 pipeline on): 0 = never (round 5's plans: m <= 6 both ways), 1 = the
+        # data-gradient convolutions only (they are forward convolutions of dY with the flipped filters: nothing new), 2 = also the forward
+        # and the Winograd-domain weight gradient of the layers that keep V (dY transform A (8 -> 10 points), finish G^T . G in fp64).
+        # C4: -31 % tile-GEMM work on the 32^2 maps (m = 4 before: 32 is no multiple of 6), -12 % on the 64^2 maps
+        self.winograd_train8: int = 2
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -797,7 +813,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.bf3_min_tiles,
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
                self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
@@ -1213,8 +1229,7 @@ class _Plan:
             return False
         w = consumer.weight
         wm = self._winograd_ok(consumer, x.H, x.W, x.C)
-        return bool(wm) and w.shape[1] == x.C and \
-            winograd_wgrad_tile(self.N, x.H, x.W, x.C, w.shape[0], self.m.winograd_wgrad) == wm
+        return bool(wm) and w.shape[1] == x.C and self._wgrad_tile(x.H, x.W, x.C, w.shape[0]) == wm
 
     def _winograd_ok(self, mod, H, W, cin_pad, flags=0) -> int:
         """Winograd output tile for this conv (0 = direct kernel)."""
@@ -1223,7 +1238,23 @@ class _Plan:
             return 0
         return winograd_tile(self.N, H, W, cin_pad, w.shape[0], self.m.winograd,
                              small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small),
-                             forward_only=not self.training and bool(self.m.gemm_bf3))
+                             allow8=self._allow8(2))
+
+    def _allow8(self, level: int) -> bool:
+        """F(8x8, 3x3) for this plan's forward / weight gradient (``level`` 2) or data gradient (1)?  Needs the pre-split bf16x3 pipeline."""
+        m = self.m
+        if not self.training:
+            return bool(m.gemm_bf3)
+        return bool(m.gemm_bf3 and m.gemm_bf3p) and m.winograd_train8 >= level
+
+    def _wgrad_tile(self, H, W, cin, cout) -> int:
+        """Tile of the Winograd-domain weight gradient of a 3x3 layer (0 = direct kernel); 8 only where the forward takes 8 and keeps the
+        transposed planes of V (csrc/winograd.hip: the dY transform of m = 8 exists for the bf16x3 GEMM only)."""
+        m = self.m
+        a8 = self._allow8(2) and m.winograd >= 8 and bool(self.lib.bbdm_gemm_bf3p_tn_supported(
+            self.lib.bbdm_winograd_tiles(8, self.N, H, W), cin, cout)) and bool(self.lib.bbdm_gemm_bf3p_supported(
+            self.lib.bbdm_winograd_tiles(8, self.N, H, W), cin, cout))
+        return winograd_wgrad_tile(self.N, H, W, cin, cout, m.winograd_wgrad, allow8=a8)
 
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
@@ -1245,7 +1276,7 @@ class _Plan:
     def _keeps_V(self, wm, H, W, cin_pad, cin, cout, upsample, bwd) -> bool:
         """Training forward: does this Winograd layer keep its fp32 V for the Winograd-domain weight gradient?"""
         return bool(self.training and not bwd and not upsample and cin_pad == cin and self.m.winograd_wgrad
-                    and winograd_wgrad_tile(self.N, H, W, cin_pad, cout, self.m.winograd_wgrad) == wm)
+                    and self._wgrad_tile(H, W, cin_pad, cout) == wm)
 
     def _emit_winograd(self, x, cin_pad, pw, pre, upsample, H, W, residual, res_ld, dest, flags, bwd=False):
         """input transform -> 16 batched GEMMs -> output transform (csrc/winograd.hip).  ``pw.phases``: H, W are x's; the GEMMs produce the
@@ -1669,10 +1700,14 @@ class _Plan:
                 t = torch.empty(cout, x_in.C, ks, ks, dtype=torch.float32, device=dev)
                 self._padded_wgrads.append((w, t, len(self.bops)))     # (.., index of the op that fills t: its segment copies it out)
                 dw_dst = _TensorRef(t)
-            wgm = (winograd_wgrad_tile(N, x_in.H, x_in.W, x_in.C, cout, m.winograd_wgrad)
+            wgm = (self._wgrad_tile(x_in.H, x_in.W, x_in.C, cout)
                    if (m.winograd_wgrad and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             dbias = gref(mod.bias) if mod.bias is not None else None
             saved = self._saved_V.get(id(w)) if wgm else None
+            if wgm == 8 and not (saved is not None and saved[1] == 8 and len(saved) > 2):
+                # m = 8 exists on the kept transposed planes only: a layer that did not keep them re-transforms x at m <= 6
+                wgm = winograd_wgrad_tile(N, x_in.H, x_in.W, x_in.C, cout, min(6, m.winograd_wgrad))
+                saved = None
             if saved is not None and saved[1] == wgm and len(saved) > 2:
                 # the forward kept the TRANSPOSED bf16 planes of V: dY transform (transposed planes of dM + the fp32 plane (1, 1)) ->
                 # the bf16x3 GEMM with the tiles as its K loop -> finish (csrc/gemm_bf3p.hip: bbdm_gemm_bf3p_tn_f32)
@@ -1722,7 +1757,7 @@ class _Plan:
                 return None
             dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
             wm = (winograd_tile(N, x_in.H, x_in.W, dy.C, x_in.C, m.winograd,
-                                small=bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small))
+                                small=bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small), allow8=self._allow8(1))
                   if (m.winograd and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             if wm:
                 pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=self._use_bf3(wm, x_in.H, x_in.W, dy.C, x_in.C))

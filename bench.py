@@ -272,7 +272,7 @@ def parity_only(workload, sd, parity_inputs):
     return parity
 
 
-def training_parity(model, sd, up, skip, sstep, x0, y, dev):
+def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False):
     """c4: loss and named parameter gradients of ONE micro-step on the benchmarked batch (batch 32, the benchmarked training plan)
     against autograd on the oracle (CPU, the whole batch).  l2 loss: d|t - p|/dp of the l1 loss is discontinuous, a single
     flipped sign of the 393 216 loss terms moves every gradient by ~1e-3 of its size; the loss kernel is the
@@ -289,6 +289,8 @@ def training_parity(model, sd, up, skip, sstep, x0, y, dev):
              "middle_block.2.out_layers.3.weight", "output_blocks.5.0.skip_connection.weight", "time_embed.0.weight",
              "out.2.weight", "out.2.bias"]
     names = [n for n in names if n in sd]
+    if all_grads:       # (tests/test_fullsize_parity_gpu.py: every parameter of the UNet at the benchmarked batch; ~2x the oracle time)
+        names = [n for n, _ in model.denoise_fn.named_parameters()]
     keep = model.loss_type
     model.loss_type = "l2"
     try:

@@ -100,7 +100,7 @@ int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, c
                                int N, int H, int W, int CinPad, int Cout, int ks, bbdm_stats_t* stats0, int cpg0, int coff0,
                                bbdm_stats_t* stats1, int cpg1, int coff1, void* stream);
 
-/* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2, 4, 6 or (forward only) 8 (same call sites, wide layers) */
+/* ---- 3x3 convolution through Winograd F(m x m, 3x3), m = 2, 4, 6 or 8 (same call sites, wide layers) */
 /* Y = A^T[(G g G^T) (.) (B^T d B)]A: (m+2)^2 multiplies per m^2 outputs instead of 9 m^2 -- 2.25x (m = 2) or 4x (m = 4)
  * fewer MFMA FLOP; the choice cuDNN / MIOpen make for the reference's wide 3x3 layers (openaimodel.py:207,233,524;
  * their fp32 "Winograd non-fused" is m = 4).  stride 1, padding 1, H and W multiples of m, CinPad % 4 == 0,
@@ -114,12 +114,15 @@ int bbdm_conv2d_nhwc_stats_f32(const float* x, int ldx, const float* packed_w, c
  * M[(m+2)^2][tiles][Cout]).  flags: only BBDM_CONV_RES_PER_IMAGE.
  * m = 6 (8x8 tiles, 64 transform points; H, W arbitrary -- edge tiles are masked; CinPad, Cout multiples of 4) is accepted
  * by every entry below (measured in round 2: 1.1-1.25x faster than m = 4 on layers with >= ~1000 tiles and H, W >= 64).
- * m = 8 (round 5, ABI 22: 10x10 tiles, 100 transform points {0, +-1/2, +-3/4, +-4/3, +-2, inf}; H, W arbitrary) is the FORWARD-ONLY
- * tile of the large inference layers: 1.56 multiplies per output instead of m = 6's 1.78, at ~7x its rounding error (rms 4e-5 against
+ * m = 8 (round 5, ABI 22: 10x10 tiles, 100 transform points {0, +-1/2, +-3/4, +-4/3, +-2, inf}; H, W arbitrary) is the
+ * tile of the large layers: 1.56 multiplies per output instead of m = 6's 1.78, at ~7x its rounding error (rms 4e-5 against
  * 6e-6 at Cin = 256 with every stage in fp32).  B^T and A^T are exact in fp32 by construction; the weight transform runs in fp64.
- * Accepted by pack_weight (dgrad = 0 only), pack_weight_bf3p, tiles, workspace_floats, input (CinPad % 32 == 0), input_bf3p
- * (CinPad % 16 == 0; no transposed copy, no coefficient folding), the three tile-GEMM entries and output (Cout % 128 == 0, no split-K
- * partials); the gradient entry points refuse it. */
+ * Accepted by pack_weight, pack_weight_bf3p (ABI 23: also dgrad = 1), tiles, workspace_floats, input (CinPad % 32 == 0), input_bf3p
+ * (CinPad % 16 == 0; no coefficient folding), the three tile-GEMM entries and output (Cout % 128 == 0, no split-K partials).
+ * ABI 23, the gradient side on the pre-split bf16x3 pipeline: bbdm_winograd_input_bf3p_tr_f32 (the transposed planes of V),
+ * bbdm_winograd_dy_transform_bf3p_f32 (A dY A^T on ten points; dm11 then holds the tile sums of dY directly -- the point set has no
+ * x = 1) and bbdm_winograd_wgrad_finish[_bias]_f32 (G^T dU G in fp64, rounded once) take m = 8; the fp32 gradient entry points
+ * (bbdm_winograd_dy_transform_f32, bbdm_conv3x3_winograd_wgrad_f32) keep m <= 6. */
 size_t bbdm_winograd_packed_floats(int m, int Cout, int CinPad);
 int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* packed, int Cout, int Cin, int InPad, int dgrad,
                                   void* stream);
@@ -486,7 +489,8 @@ int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bi
  *   bbdm_winograd_input_bf3p_tr_f32     : the input transform of the TRAINING forward: the planes Vp for the forward GEMM and their
  *                                         transposed copy Vt [xi][CinPad32 / 32][tiles / 16][3][1 KB] for the weight gradient
  *   bbdm_winograd_dy_transform_bf3p_f32 : dY -> dMt [xi][CoutPad128 / 32][tiles / 16][3][1 KB] (A dY A^T, transposed planes) and
- *                                         dm11 [tiles][Cout] fp32 = its plane (1, 1), whose column sums are the bias gradient
+ *                                         dm11 [tiles][Cout] fp32 = its plane (1, 1) = the tile sums of dY (m = 8: the sums themselves),
+ *                                         whose column sums are the bias gradient
  *   bbdm_gemm_bf3p_tn_at_bytes / _bt_bytes / _supported / _splits : buffer sizes, shape gate (K % 256, M % 32, N % 4), K splits
  *   bbdm_gemm_bf3p_tn_f32               : C[z][b][M][N] = sum over the K range of split z of At_b^T-as-stored . Bt_b, z < splits
  *                                         (the consumer adds the splits in order: bbdm_winograd_wgrad_finish_f32) */

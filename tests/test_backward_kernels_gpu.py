@@ -137,7 +137,10 @@ def test_winograd_wgrad(dev, m, N, H, W, Cin, Cout):
 # tile counts (zeros must enter the contraction), Cout below / not a multiple of the 128-column tile, split-K, the LBBDM-f4 layer shapes
 WINO_WGRAD_BF3P = [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 2, 12, 12, 64, 128), (6, 1, 7, 10, 32, 8), (6, 3, 16, 20, 96, 72),
                    (4, 2, 16, 16, 256, 132), (6, 2, 64, 64, 128, 128), (6, 2, 64, 64, 640, 128), (4, 2, 32, 32, 512, 512),
-                   (4, 2, 32, 32, 1536, 512), (4, 2, 16, 16, 1024, 1024), (6, 8, 64, 64, 256, 128)]
+                   (4, 2, 32, 32, 1536, 512), (4, 2, 16, 16, 1024, 1024), (6, 8, 64, 64, 256, 128),
+                   # m = 8 (round 5, UNetModel.winograd_train8): ragged / padded tiles, Cout not a multiple of 128, the C4 layer shapes
+                   (8, 2, 16, 24, 32, 24), (8, 1, 13, 18, 64, 132), (8, 2, 64, 64, 128, 128), (8, 2, 64, 64, 640, 128),
+                   (8, 2, 32, 32, 512, 512), (8, 2, 32, 32, 1536, 512), (8, 8, 64, 64, 256, 128)]
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", WINO_WGRAD_BF3P)
@@ -157,7 +160,7 @@ def test_winograd_wgrad_bf3p(dev, m, N, H, W, Cin, Cout):
         torch.cuda.synchronize()
     e = rel_err(dw.cpu(), w.grad.float())
     print(f"winograd wgrad (bf16x3 TN GEMM) m={m} N{N} {H}x{W} {Cin}->{Cout}: rel err {e:.2e}")
-    assert e < 1e-4
+    assert e < (5e-4 if m == 8 else 1e-4)       # (m = 8: ~6x m = 6's rounding, tests/test_winograd_math_cpu.py; gradient bar 1e-3)
     assert rel_err(db.cpu(), b.grad.float()) < TOL
 
 

@@ -243,7 +243,8 @@ def test_geglu_backward():
     BK.test_geglu_backward(CPU, 33, 32)
 
 
-@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 1, 7, 10, 32, 8), (6, 2, 12, 12, 64, 132)])
+@pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(2, 2, 8, 8, 32, 24), (4, 1, 8, 12, 32, 64), (6, 1, 7, 10, 32, 8), (6, 2, 12, 12, 64, 132),
+                                              (8, 1, 8, 16, 32, 8), (8, 2, 13, 18, 64, 132)])
 def test_winograd_wgrad_bf3p(m, N, H, W, Cin, Cout):
     BK.test_winograd_wgrad_bf3p(CPU, m, N, H, W, Cin, Cout)
 
@@ -297,6 +298,11 @@ def test_winograd_input_forms_groupnorm_coefficients_bitwise(m, up, silu, film, 
 @pytest.mark.parametrize("pixels,Cin,Cout,res", [(128, 256, 132, True), (96, 128, 8, False), (100, 192, 520, True), (64, 64, 64, False)])
 def test_conv1x1_bf3s_bitwise(pixels, Cin, Cout, res):
     K.test_conv1x1_bf3s_bitwise(CPU, pixels, Cin, Cout, res)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(1, 8, 16, 128, 16), (1, 13, 10, 128, 32)])
+def test_winograd_f8_dgrad(N, H, W, Cin, Cout):
+    K.test_winograd_f8_dgrad(CPU, N, H, W, Cin, Cout)
 
 
 @pytest.mark.parametrize("m,Cout,Cin,in_pad,dgrad", [(4, 96, 40, 48, False), (2, 24, 16, 32, True), (6, 40, 130, 144, False)])

@@ -117,7 +117,7 @@ def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True, allow8=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -151,7 +151,7 @@ def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):
     import bbdm_oracle as O
     from fixture_weights import synth_weights
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True, allow8=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=8, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -194,7 +194,7 @@ def test_upsampling_conv_as_f72_phase_filters(monkeypatch):
     import bbdm_amd
     import bbdm_oracle as O
     from fixture_weights import synth_weights
-    wt = lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
+    wt = lambda N, H, W, cin, cout, max_m=6, small=True, allow8=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile", wt)
     monkeypatch.setattr(bbdm_amd.unet, "phase_filter_tile",
                         lambda N, H, W, cin, cout4, max_m, small, f72=True:
@@ -233,7 +233,7 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     # the forward's tile rule wants >= 128 channels (4x the emulation time): let the 64-channel layers take F(4x4) too, so that
     # the training forward keeps their V and the gradient plan runs the staged form (dY transform -> TN GEMM -> finish) on it
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
-                        lambda N, H, W, cin, cout, max_m=6, small=True, forward_only=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+                        lambda N, H, W, cin, cout, max_m=6, small=True, allow8=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
     up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
@@ -264,6 +264,51 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
         ref = sdg[k].grad
         scale = max(float(ref.abs().max()), 1e-3 * gmax)
         assert float((p.grad - ref).abs().max()) / scale < T.GRAD_TOL, k
+
+
+def test_training_plan_on_f8_tiles(monkeypatch):
+    """UNetModel.winograd_train8 = 2 (the default): forward, data gradient and Winograd-domain weight gradient of a training plan on
+    F(8x8, 3x3) -- the transposed planes of V from the m = 8 input transform, A dY A^T on ten points with the tile sums for the bias
+    gradient, G^T dU G in fp64 -- forced onto a 128-channel 16x16 model (the real rule wants >= 512 tiles): every parameter gradient
+    against the oracle's autograd, and against the same plan on m <= 6 tiles (winograd_train8 = 0)."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    monkeypatch.setattr(bbdm_amd.unet, "_tile8_ok", lambda N, H, W, cin, cout: cin >= 128 and cin % 32 == 0 and cout % 128 == 0 and H % 8 == 0)
+    up = dict(image_size=16, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 43)
+    m.load_state_dict(sd, strict=True)
+    m.hip_graph = False
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    t = torch.arange(2) * 31 + 2
+    dout = torch.randn(2, 4, 16, 16, generator=g)
+    grads = {}
+    for level in (2, 0):
+        m.winograd_train8 = level
+        m.zero_grad(set_to_none=True)
+        (m(x, timesteps=t, context=None) * dout).sum().backward()
+        plan = m._plan_for(x, True)
+        f8 = [a for n, a in plan.ops if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8]
+        b8 = [a for n, a in plan.bops if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8]
+        w8 = [a for n, a in plan.bops if str(n) in ("bbdm_winograd_wgrad_finish_f32", "bbdm_winograd_wgrad_finish_bias_f32") and a[0] == 8]
+        assert (len(f8) >= 4 and len(b8) >= 4 and len(w8) == len(f8)) if level else not (f8 or b8 or w8), (level, len(f8), len(b8), len(w8))
+        grads[level] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    (O.unet_forward(sdg, O.UNetSpec(**up), x, t, None) * dout).sum().backward()
+    gmax = max(float(v.grad.abs().max()) for v in sdg.values())
+    worst = 0.0
+    for k in grads[2]:
+        ref = sdg[k].grad
+        scale = max(float(ref.abs().max()), 1e-3 * gmax)
+        e8, e6 = float((grads[2][k] - ref).abs().max()) / scale, float((grads[0][k] - ref).abs().max()) / scale
+        worst = max(worst, e8)
+        assert e8 < 1e-3 and e6 < T.GRAD_TOL, (k, e8, e6)
+    print(f"training plan on F(8x8): worst parameter gradient {worst:.2e} against the oracle's autograd")
 
 
 def test_first_stage_plans_on_the_emulator():
@@ -354,8 +399,8 @@ def test_forward_on_f8_tiles(monkeypatch):
     from fixture_weights import synth_weights
     real = bbdm_amd.unet.winograd_tile
 
-    def wt(N, H, W, cin, cout, max_m=6, small=True, forward_only=False):
-        if forward_only and max_m >= 8 and cin % 16 == 0 and cin >= 128 and cout % 128 == 0 and H >= 16:
+    def wt(N, H, W, cin, cout, max_m=6, small=True, allow8=False):
+        if allow8 and max_m >= 8 and cin % 16 == 0 and cin >= 128 and cout % 128 == 0 and H >= 16:
             return 8
         return 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0
     monkeypatch.setattr(bbdm_amd.unet, "winograd_tile", wt)
@@ -382,10 +427,10 @@ def test_forward_on_f8_tiles(monkeypatch):
     e8, e6 = parity_err(outs[8], ref), parity_err(outs[6], ref)
     print(f"tiny UNet on F(8x8,3x3): {e8:.2e} (default plan {e6:.2e})")
     assert e8 < 1e-3 and e6 < M.STEP_TOL
-    m.winograd = 8
+    m.winograd, m.winograd_train8 = 8, 0        # (training plans take the tile under winograd_train8: test_training_plan_on_f8_tiles)
     m.train()
     tplan = m._plan_for(x, True)
-    assert 8 not in {a[0] for n, a in tplan.ops if str(n) == "bbdm_winograd_gemm_f32"}
-    assert real(16, 64, 64, 1024, 1024, 8, forward_only=True) == 8 and real(16, 64, 64, 1024, 1024, 8) == 6 \
-        and real(16, 64, 64, 1024, 1024, 6, forward_only=True) == 6 and real(16, 256, 256, 128, 128, 8, forward_only=True) == 8 \
-        and real(32, 32, 32, 512, 512, 8, forward_only=True) == 8 and real(32, 16, 16, 1024, 1024, 8, forward_only=True) == 4
+    assert 8 not in {a[0] for n, a in list(tplan.ops) + list(tplan.bops) if str(n) == "bbdm_winograd_gemm_f32"}
+    assert real(16, 64, 64, 1024, 1024, 8, allow8=True) == 8 and real(16, 64, 64, 1024, 1024, 8) == 6 \
+        and real(16, 64, 64, 1024, 1024, 6, allow8=True) == 6 and real(16, 256, 256, 128, 128, 8, allow8=True) == 8 \
+        and real(32, 32, 32, 512, 512, 8, allow8=True) == 8 and real(32, 16, 16, 1024, 1024, 8, allow8=True) == 4

@@ -247,8 +247,8 @@ def test_benchmarked_plan_exactly(dev, workload):
 def test_c4_benchmarked_training_plan_batch32(dev):
     """BASELINE.json configs[3] at the plan bench.py times: LBBDM-f4 training, latent 3x64x64, batch 32 per GPU (the full-size gradient
     test above runs batch 2: batch 32 selects other GEMM tiles, split-K counts and Winograd weight-gradient shapes).  Loss and eight
-    named parameter gradients -- stem, a 512-channel 3x3 layer, qkv, a middle-block out conv, a 1x1 skip connection, the embedding
-    MLP, the head -- of ONE micro-step against autograd on the oracle over the whole batch (l2 loss: see the docstring above for why
+    ALL 248 parameter gradients (bench.py's line carries eight named ones: stem, a 512-channel 3x3 layer, qkv, a middle-block out conv,
+    a 1x1 skip connection, the embedding MLP, the head) of ONE micro-step against autograd on the oracle over the whole batch (l2 loss: see the docstring above for why
     the l1 gradients need a frozen sign pattern); bench.py's `parity` of the c4 line is this same comparison."""
     import bench
     desc, up, ch, size, batch, skip, sstep = bench.WORKLOADS["c4"]
@@ -256,9 +256,14 @@ def test_c4_benchmarked_training_plan_batch32(dev):
     m, sd = _model(up, bb, 3232, dev)
     m.train()
     x0, y = bench.make_inputs(batch, ch, size, seed=99)
-    par = bench.training_parity(m, sd, up, skip, sstep, x0.to(dev), y.to(dev), dev)
+    par = bench.training_parity(m, sd, up, skip, sstep, x0.to(dev), y.to(dev), dev, all_grads=True)
     plan = next(iter(m.denoise_fn._plans.values()))
-    assert plan.N == batch == 32 and plan.training
+    assert plan.N == batch == 32 and plan.training and len(par["grad_errors"]) == 248
+    # the benchmarked plan runs its 64^2 and 32^2 levels on F(8x8, 3x3) in all three directions (UNetModel.winograd_train8; batch 2 of
+    # the full-size test above has too few tiles for it)
+    for ops_, lo in ((plan.ops, 20), (plan.bops, 20)):
+        assert sum(1 for n, a in ops_ if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8) >= lo
+    assert sum(1 for n, a in plan.bops if str(n) == "bbdm_winograd_wgrad_finish_bias_f32" and a[0] == 8) >= 20
     print(f"c4 at the benchmarked training plan (batch {batch}): loss rel err {par['rel_err_loss']:.2e}, worst named gradient "
           f"{par['rel_err_grad_worst']:.2e} ({par['cpu_seconds']:.0f} s of oracle autograd)")
     assert par["rel_err_loss"] < 1e-5, par

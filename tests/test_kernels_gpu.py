@@ -499,9 +499,47 @@ def test_winograd_f8_forward(dev, N, H, W, Cin, Cout, pre, up, res, f32v):
     assert e < WINO_TOL[8]
     s_ref = o.double().reshape(N, 32, -1).sum(-1)
     assert float((ops.read_stats(stats).cpu()[:, :, 0] - s_ref).abs().max()) < 1e-3 * max(1.0, float(s_ref.abs().max()))
-    # the m = 8 entry points refuse what the tile does not have: the data-gradient packing
-    rc = lib.bbdm_winograd_pack_weight_f32(8, w.to(dev).data_ptr(), pw.data_ptr(), Cout, Cin, Cout, 1, st)
-    assert rc != 0
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 24, 128, 96), (1, 13, 18, 256, 32)])
+def test_winograd_f8_dgrad(dev, N, H, W, Cin, Cout):
+    """F(8x8, 3x3) as the data-gradient convolution of a training plan (UNetModel.winograd_train8): the flipped, transposed filters
+    straight into the bf16 planes (dgrad = 1), dY through the plane input transform, the pre-split tile GEMMs, the output transform
+    without bias / statistics.  Against the fp64 transposed convolution; ragged image in the second case."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    lib = _lib.load()
+    m, P = 8, 100
+    g = torch.Generator().manual_seed(8 * H + Cout)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    dy = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv_transpose2d(dy.double(), w.double(), padding=1)                  # dX of conv2d(x, w, padding=1): [N, Cin, H, W]
+    dyg, wg = _nhwc(dy).to(dev), w.to(dev).contiguous()
+    st = ops._st(dyg)
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    Bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(P, Cout, Cin), dtype=torch.uint8, device=dev)
+    _lib.call("bbdm_winograd_pack_weight_bf3p_f32", m, wg.data_ptr(), Bp.data_ptr(), Cout, Cin, Cout, 1, st)
+    Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(P, tiles, Cout), dtype=torch.uint8, device=dev)
+    _lib.call("bbdm_winograd_input_bf3p_f32", m, dyg.data_ptr(), Cout, Vp.data_ptr(), None, None, 0, 0, 0, N, H, W, Cout, st)
+    M = torch.full((P * tiles * Cin,), float("nan"), device=dev)
+    _lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), Bp.data_ptr(), M.data_ptr(), N, H, W, Cout, Cin, st)
+    out = torch.full((N, H, W, Cin), float("nan"), device=dev)
+    _lib.call("bbdm_winograd_output_f32", m, M.data_ptr(), None, None, 0, out.data_ptr(), Cin, 0, N, H, W, Cin, st)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    o = _nchw(out.cpu())
+    assert not bool(torch.isnan(o).any())
+    e = rel_err(o, ref.float())
+    print(f"F(8x8,3x3) data gradient N{N} {H}x{W} {Cin}<-{Cout}: rel err {e:.2e}")
+    assert e < WINO_TOL[8]
+    # ... and the fp32 packing of the same filters (the two-launch form) agrees with the fused planes
+    a = ops.winograd_weight_planes(wg, m, Cout, True, fused=True)
+    b = ops.winograd_weight_planes(wg, m, Cout, True, fused=False)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    value = lambda pl: (lambda h: (h[:, 0] + h[:, 1]) + h[:, 2])(pl.cpu().view(torch.int16).view(-1, 3, 512).view(torch.bfloat16).float())
+    va, vb = value(a), value(b)
+    assert torch.equal(va == 0, vb == 0) and float((va - vb).abs().max()) <= 2.0 ** -22 * float(vb.abs().max())
 
 
 @pytest.mark.parametrize("m,N,H,W,Cin,Cout", [(6, 2, 12, 20, 32, 40), (4, 1, 8, 16, 16, 24), (2, 3, 4, 6, 16, 8), (6, 1, 14, 10, 16, 72),

@@ -58,11 +58,12 @@ def test_winograd_tile_choice_follows_the_measured_crossovers():
     assert wt(16, 8, 8, 1024, 1024, 6, small=False) == 0
     tiny = unet.UNetModel(image_size=8, in_channels=4, model_channels=32, out_channels=4, num_res_blocks=1,
                           attention_resolutions=(), channel_mult=(1,), num_head_channels=32, condition_key="nocond")
-    assert tiny.winograd == 8      # the default cap: F(8x8, 3x3) where an INFERENCE plan has the tiles for it (forward_only) ...
-    assert wt(16, 64, 64, 1024, 1024, 8, forward_only=True) == 8 and wt(16, 256, 256, 128, 128, 8, forward_only=True) == 8
-    assert wt(16, 64, 64, 1024, 1024, 8) == 6 and wt(16, 64, 64, 1024, 1024, 6, forward_only=True) == 6      # ... never a gradient plan / under a cap of 6
-    assert wt(16, 64, 64, 1024, 1000, 8, forward_only=True) == 6 and wt(16, 64, 64, 136, 128, 8, forward_only=True) == 6     # whole 128-channel output blocks, 16-channel chunks
-    assert wt(32, 32, 32, 512, 512, 8, forward_only=True) == 8 and wt(4, 64, 64, 512, 512, 8, forward_only=True) == 4     # 512 tiles / 256: too few
+    assert tiny.winograd == 8 and tiny.winograd_train8 == 2 and tiny.winograd_wgrad == 8
+    # the default cap: F(8x8, 3x3) where a plan on the bf16x3 pipeline has the tiles for it (allow8) ...
+    assert wt(16, 64, 64, 1024, 1024, 8, allow8=True) == 8 and wt(16, 256, 256, 128, 128, 8, allow8=True) == 8
+    assert wt(16, 64, 64, 1024, 1024, 8) == 6 and wt(16, 64, 64, 1024, 1024, 6, allow8=True) == 6      # ... never without the pipeline / under a cap of 6
+    assert wt(16, 64, 64, 1024, 1000, 8, allow8=True) == 6 and wt(16, 64, 64, 136, 128, 8, allow8=True) == 6     # whole 128-channel output blocks, 16-channel chunks
+    assert wt(32, 32, 32, 512, 512, 8, allow8=True) == 8 and wt(4, 64, 64, 512, 512, 8, allow8=True) == 4     # 512 tiles / 256: too few
     assert lib_tiles(6, 16, 64, 64) == 2048 and lib_tiles(4, 16, 64, 64) == 4096 and lib_tiles(2, 3, 8, 12) == 256
 
 
@@ -78,6 +79,10 @@ def test_winograd_wgrad_tile_choice_follows_the_measured_crossovers():
     assert wt(2, 16, 16, 1024, 1024) == 0              # too few tiles for the TN GEMMs' K: direct kernel
     assert wt(32, 64, 64, 8, 128) == 0 and wt(32, 64, 64, 128, 3) == 0      # stem / head
     assert wt(32, 64, 64, 512, 512, 4) == 4 and wt(32, 64, 64, 512, 512, 0) == 0     # the cap (BBDM_WINOGRAD_WGRAD)
+    # m = 8 (allow8: the forward takes it and keeps the transposed planes): the forward's rule + whole 32-channel row groups of V^T
+    assert wt(32, 64, 64, 512, 512, 8, allow8=True) == 8 and wt(32, 32, 32, 1536, 512, 8, allow8=True) == 8
+    assert wt(32, 64, 64, 512, 512, 8) == 6 and wt(32, 64, 64, 512, 512, 6, allow8=True) == 6
+    assert wt(32, 16, 16, 2048, 1024, 8, allow8=True) == 4 and wt(32, 64, 64, 144, 128, 8, allow8=True) == 6      # 128 tiles / cin % 32
 
 
 @pytest.mark.parametrize("workload,batch,training,cap", [("c1", 4, False, 4), ("c1", 16, False, 4), ("c1", 16, True, 4),
@@ -98,8 +103,10 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         wm = i[0]
         N, H, W, cin = i[9:13]
         assert wm in (2, 4, 6, 7, 8) and g[0] == wm and o[0] == wm
-        # m = 8 = F(8x8, 3x3): inference forward only, >= 512 tiles, whole 16-channel chunks in, whole 128-channel blocks out, under a cap of 8
-        assert wm != 8 or (cap == 8 and not training and cin % 16 == 0 and g[8] % 128 == 0 and unet.wino_tiles(8, N, H, W) >= 512
+        # m = 8 = F(8x8, 3x3): >= 512 tiles, whole 16-channel chunks in, whole 128-channel blocks out, under a cap of 8 (training plans:
+        # UNetModel.winograd_train8)
+        assert wm != 8 or (cap == 8 and (not training or m.winograd_train8) and cin % 16 == 0 and g[8] % 128 == 0
+                           and unet.wino_tiles(8, N, H, W) >= 512
                            and not getattr(ops[k][0], "entry", "").endswith("_gn_f32"))
         assert (wm >= 6 or (H % wm == 0 and W % wm == 0)) and cin % 4 == 0
         phases = bool(o[7] & 8)          # conv3x3(nearest x2 (x)) as four phase filters on x: the GEMMs produce 4 Cout channels
@@ -117,7 +124,7 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             dst = o[5]
             assert not up and not training and (dst.H, dst.W, dst.C) == (2 * H, 2 * W, cout // 4) and o[3] is None
             assert unet.winograd_tile(N, H, W, cin, cout, m.winograd) >= min(6, unet.winograd_tile(N, 2 * H, 2 * W, cin, cout // 4, m.winograd,
-                                                                                                   forward_only=not training))
+                                                                                                   allow8=not training))
         tiles = lib.bbdm_winograd_tiles(wm, N, H, W)
         P = unet.wino_planes(wm)
         assert tiles % 256 == 0 and tiles >= unet.wino_tiles(wm, N, H, W)
@@ -146,7 +153,7 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             assert g[2].t.numel() == lib.bbdm_winograd_packed_floats(wm, cout, cin)
         small = bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small)
         assert (unet.phase_filter_tile(N, H, W, cin, cout, m.winograd, small) if phases else
-                unet.winograd_tile(N, H, W, cin, cout, m.winograd, small=small, forward_only=not training and not str(name).endswith(":bwd") and k < len(plan.ops))) == wm
+                unet.winograd_tile(N, H, W, cin, cout, m.winograd, small=small, allow8=plan._allow8(1 if k >= len(plan.ops) else 2))) == wm
         if entry.endswith("splitk_f32"):        # small layer: split-K partials, added by the output transform of the same count
             ks = g[-1]
             assert ks == lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin, cout) > 1
