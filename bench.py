@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line with, besides the contract fields,
                  eager pass of the same K steps right after it (`eager_profiled_ms_per_step`);
   f32mfma_ms_per_step : the same step with those GEMMs on the f32 MFMA (strict-fp32 A/B, 5 steps after the timed region);
   winograd6_ms_per_step : the same step on round 4's Winograd tiles (UNetModel.winograd = 6; parity["winograd6"] = its parity sample);
+                 c4: the training micro-step with F(8x8, 3x3) off in the training plan (UNetModel.winograd_train8 = 0; summary.c4_m6);
   parity       : image 0 of the benchmarked batch against the CPU path (c4: loss + named gradients against the oracle's autograd);
   cpu_baseline : the oracle (kind "port": oracle/bbdm_oracle.py, the validated restatement of the reference's CPU
                  path) timed on this box's host cores on a bounded sample of the same workload.
@@ -406,7 +407,8 @@ def main():
                 "hip_graph": r["hip_graph"], "frac_step": r["roofline"]["frac_step"],
                 "dominant_kernel_frac": r["roofline"]["frac"], "dominant_kernel_tflops": r["roofline"]["achieved"],
                 "kernel_ms_per_step": r["kernel_ms_per_step"], "parity": r["parity"], "pipeline": r.get("pipeline"),
-                "training": r.get("training"), "wall_s": time.perf_counter() - t0}
+                "training": r.get("training"), "winograd6_ms_per_step": r.get("winograd6_ms_per_step"),
+                "wall_s": time.perf_counter() - t0}
     if rank == 0 and line is not None:
         # LAST key of the line (the driver's stored record keeps the tail of stdout): every configuration's step time, whole-step
         # roofline fraction and worst parity error in <= 400 characters -- [ms_per_step, frac_step, worst rel_err]
@@ -421,6 +423,9 @@ def main():
             w6 = (line.get("parity") or {}).get("winograd6") or {}
             line["summary"][args.workload + "_winograd6"] = [round(line["winograd6_ms_per_step"], 3),
                                                              float(f"{max(w6.values()):.2g}") if w6 else None]
+        c4r = line if args.workload == "c4" else (line.get("workloads") or {}).get("c4") or {}
+        if c4r.get("winograd6_ms_per_step"):         # the training micro-step on the m <= 6 tiles (UNetModel.winograd_train8 = 0)
+            line["summary"]["c4_m6"] = round(c4r["winograd6_ms_per_step"], 3)
         line["summary"]["units"] = "[ms_per_step, frac_step, worst parity rel_err]"
         print(json.dumps(line))
     if dist is not None:
@@ -608,6 +613,31 @@ def run_workload(args, env):
             winograd6_ms = e0.elapsed_time(e1) / 5
         finally:
             model.denoise_fn.winograd = 8
+        for k in list(model.denoise_fn._plans)[1:]:
+            del model.denoise_fn._plans[k]
+        torch.cuda.empty_cache()
+
+    # c4: the same micro-steps with the training plan on the tiles it had before F(8x8, 3x3) got its gradient side
+    # (UNetModel.winograd_train8 = 0: m <= 6 forward, data gradient and weight gradient): one accumulation cycle to build and warm the
+    # second plan, then two cycles timed, outside the timed region
+    if training and world == 1 and not args.no_f32mfma and model.denoise_fn.winograd_train8 and model.denoise_fn.winograd >= 8:
+        keep8 = model.denoise_fn.winograd_train8
+        model.denoise_fn.winograd_train8 = 0
+        try:
+            base = prime + args.warmup + 2 * args.steps
+            base += (-base) % args.accumulate                   # (start on an accumulation boundary)
+            for i in range(args.accumulate):
+                state["img"] = step(base + i, state["img"])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(2 * args.accumulate):
+                state["img"] = step(base + args.accumulate + i, state["img"])
+            e1.record()
+            torch.cuda.synchronize(dev)
+            winograd6_ms = e0.elapsed_time(e1) / (2 * args.accumulate)
+        finally:
+            model.denoise_fn.winograd_train8 = keep8
         for k in list(model.denoise_fn._plans)[1:]:
             del model.denoise_fn._plans[k]
         torch.cuda.empty_cache()

@@ -1,6 +1,7 @@
 """Model-level paths on the CPU-emulated kernels (tools/hipemu): the execution plan, the fused bridge update, the
 autograd node and its backward plan run end to end on the golden fixtures of the real reference -- the same assertions
 as tests/test_model_gpu.py / test_training_gpu.py, before any GPU time is spent.  Not a performance path."""
+import os
 import pytest
 import torch
 
@@ -270,7 +271,7 @@ def test_training_plan_on_f8_tiles(monkeypatch):
     """UNetModel.winograd_train8 = 2 (the default): forward, data gradient and Winograd-domain weight gradient of a training plan on
     F(8x8, 3x3) -- the transposed planes of V from the m = 8 input transform, A dY A^T on ten points with the tile sums for the bias
     gradient, G^T dU G in fp64 -- forced onto a 128-channel 16x16 model (the real rule wants >= 512 tiles): every parameter gradient
-    against the oracle's autograd, and against the same plan on m <= 6 tiles (winograd_train8 = 0)."""
+    against the oracle's autograd; winograd_train8 = 0 plans the same model without the tile."""
     import bbdm_amd
     import bbdm_oracle as O
     from fixture_weights import synth_weights
@@ -287,27 +288,26 @@ def test_training_plan_on_f8_tiles(monkeypatch):
     x = torch.randn(2, 4, 16, 16, generator=g)
     t = torch.arange(2) * 31 + 2
     dout = torch.randn(2, 4, 16, 16, generator=g)
-    grads = {}
-    for level in (2, 0):
-        m.winograd_train8 = level
-        m.zero_grad(set_to_none=True)
-        (m(x, timesteps=t, context=None) * dout).sum().backward()
-        plan = m._plan_for(x, True)
-        f8 = [a for n, a in plan.ops if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8]
-        b8 = [a for n, a in plan.bops if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8]
-        w8 = [a for n, a in plan.bops if str(n) in ("bbdm_winograd_wgrad_finish_f32", "bbdm_winograd_wgrad_finish_bias_f32") and a[0] == 8]
-        assert (len(f8) >= 4 and len(b8) >= 4 and len(w8) == len(f8)) if level else not (f8 or b8 or w8), (level, len(f8), len(b8), len(w8))
-        grads[level] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    (m(x, timesteps=t, context=None) * dout).sum().backward()
+    plan = m._plan_for(x, True)
+    f8 = [a for n, a in plan.ops if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8]
+    b8 = [a for n, a in plan.bops if str(n) == "bbdm_winograd_gemm_f32" and a[0] == 8]
+    w8 = [a for n, a in plan.bops if str(n) in ("bbdm_winograd_wgrad_finish_f32", "bbdm_winograd_wgrad_finish_bias_f32") and a[0] == 8]
+    assert len(f8) >= 4 and len(b8) >= 4 and len(w8) == len(f8), (len(f8), len(b8), len(w8))
+    m.winograd_train8 = 0           # (the m <= 6 plans of the same model: no launch on the tile; their gradients are the other tests')
+    plan0 = m._plan_for(x, True)
+    assert not any(a[0] == 8 for n, a in list(plan0.ops) + list(plan0.bops) if str(n).startswith("bbdm_winograd"))
     sdg = {k: v.clone().requires_grad_() for k, v in sd.items()}
     (O.unet_forward(sdg, O.UNetSpec(**up), x, t, None) * dout).sum().backward()
     gmax = max(float(v.grad.abs().max()) for v in sdg.values())
     worst = 0.0
-    for k in grads[2]:
+    for k, p in m.named_parameters():
         ref = sdg[k].grad
-        scale = max(float(ref.abs().max()), 1e-3 * gmax)
-        e8, e6 = float((grads[2][k] - ref).abs().max()) / scale, float((grads[0][k] - ref).abs().max()) / scale
+        e8 = float((p.grad - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
         worst = max(worst, e8)
-        assert e8 < 1e-3 and e6 < T.GRAD_TOL, (k, e8, e6)
+        if os.environ.get("BBDM_TEST_VERBOSE"):
+            print(f"  {k}: {e8:.2e}")
+        assert e8 < 1e-3, (k, e8)
     print(f"training plan on F(8x8): worst parameter gradient {worst:.2e} against the oracle's autograd")
 
 
