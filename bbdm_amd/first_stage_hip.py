@@ -55,6 +55,7 @@ class _Flags:
         self.upsample_f72 = True
         self.winograd_wgrad = 0             # (inference plans only)
         self.winograd_train8 = 0
+        self.winograd8_min_tiles = 512
         self.hip_graph = False
         self.op_profile = None
 

@@ -521,11 +521,11 @@ def phase_filter_tile(N: int, H: int, W: int, cin: int, cout4: int, max_m: int, 
     return wl
 
 
-def _tile8_ok(N: int, H: int, W: int, cin: int, cout: int) -> bool:
+def _tile8_ok(N: int, H: int, W: int, cin: int, cout: int, min_tiles: int = 512) -> bool:
     """Does this layer earn F(8x8, 3x3)?  Large layers on the pre-split planes: whole 16-channel chunks in, whole 128-channel blocks out,
     >= 512 tiles (fewer: 100 transform points x the weight planes become the bound), <= 10 % edge waste."""
     t8h, t8w = -(-H // 8), -(-W // 8)
-    return (cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and cin * cout / (cin + cout) >= 64 and N * t8h * t8w >= 512
+    return (cin >= 128 and cin % 16 == 0 and cout % 128 == 0 and cin * cout / (cin + cout) >= 64 and N * t8h * t8w >= min_tiles
             and (8 * t8h) * (8 * t8w) <= 1.10 * H * W)
 
 
@@ -545,7 +545,8 @@ def winograd_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int = 6, s
     # of m = 6's 1.78 (m = 4: 2.25), and 64 / 128 / 256-pixel images tile without the 2 - 6 % edge waste of the 6-pixel grid: -14 ... -17 %
     # tile GEMM work and transformed bytes (-31 % against m = 4 on 32^2 maps).  Its fp32 error is ~7x m = 6's
     # (tests/test_winograd_math_cpu.py): UNetModel.winograd = 8 opts in.
-    if allow8 and max_m >= 8 and _tile8_ok(N, H, W, cin, cout):
+    # (``allow8``: False / True = the default threshold of 512 tiles, or the threshold itself -- UNetModel.winograd8_min_tiles)
+    if allow8 and max_m >= 8 and _tile8_ok(N, H, W, cin, cout, 512 if allow8 is True else int(allow8)):
         return 8
     t6h, t6w = -(-H // 6), -(-W // 6)
     if (max_m >= 6 and cin >= 128 and hw >= 64 and N * t6h * t6w >= 900
@@ -572,7 +573,7 @@ def winograd_wgrad_tile(N: int, H: int, W: int, cin: int, cout: int, max_m: int 
     if cin % 4 or cout % 4 or cin < 64 or cout < 64:
         return 0
     # m = 8: where the forward takes it (the gradient contracts the transposed planes of V that forward kept: same tile both ways)
-    if allow8 and max_m >= 8 and cin % 32 == 0 and _tile8_ok(N, H, W, cin, cout):
+    if allow8 and max_m >= 8 and cin % 32 == 0 and _tile8_ok(N, H, W, cin, cout, 512 if allow8 is True else int(allow8)):
         return 8
     t6h, t6w = -(-H // 6), -(-W // 6)
     if max_m >= 6 and N * t6h * t6w >= 900 and (6 * t6h) * (6 * t6w) <= 1.10 * H * W:
@@ -755,6 +756,8 @@ class UNetModel(nn.Module):
         # and the Winograd-domain weight gradient of the layers that keep V (dY transform A (8 -> 10 points), finish G^T . G in fp64).
         # C4: -31 % tile-GEMM work on the 32^2 maps (m = 4 before: 32 is no multiple of 6), -12 % on the 64^2 maps
         self.winograd_train8: int = 2
+        # least number of 8x8 tiles for a layer to take F(8x8, 3x3): below it the 100 x 6 B of weight planes per weight are the bound
+        self.winograd8_min_tiles: int = 512
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -813,7 +816,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.bf3_min_tiles,
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
                self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
@@ -1240,20 +1243,22 @@ class _Plan:
                              small=bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small),
                              allow8=self._allow8(2))
 
-    def _allow8(self, level: int) -> bool:
-        """F(8x8, 3x3) for this plan's forward / weight gradient (``level`` 2) or data gradient (1)?  Needs the pre-split bf16x3 pipeline."""
+    def _allow8(self, level: int) -> int:
+        """F(8x8, 3x3) for this plan's forward / weight gradient (``level`` 2) or data gradient (1)?  Needs the pre-split bf16x3 pipeline.
+        0 = no, else the least number of 8x8 tiles a layer needs for it (UNetModel.winograd8_min_tiles)."""
         m = self.m
-        if not self.training:
-            return bool(m.gemm_bf3)
-        return bool(m.gemm_bf3 and m.gemm_bf3p) and m.winograd_train8 >= level
+        ok = bool(m.gemm_bf3) if not self.training else (bool(m.gemm_bf3 and m.gemm_bf3p) and m.winograd_train8 >= level)
+        return int(m.winograd8_min_tiles) if ok else 0
 
     def _wgrad_tile(self, H, W, cin, cout) -> int:
         """Tile of the Winograd-domain weight gradient of a 3x3 layer (0 = direct kernel); 8 only where the forward takes 8 and keeps the
         transposed planes of V (csrc/winograd.hip: the dY transform of m = 8 exists for the bf16x3 GEMM only)."""
         m = self.m
-        a8 = self._allow8(2) and m.winograd >= 8 and bool(self.lib.bbdm_gemm_bf3p_tn_supported(
-            self.lib.bbdm_winograd_tiles(8, self.N, H, W), cin, cout)) and bool(self.lib.bbdm_gemm_bf3p_supported(
-            self.lib.bbdm_winograd_tiles(8, self.N, H, W), cin, cout))
+        a8 = self._allow8(2)
+        if a8:
+            t8 = self.lib.bbdm_winograd_tiles(8, self.N, H, W)
+            if not (m.winograd >= 8 and self.lib.bbdm_gemm_bf3p_tn_supported(t8, cin, cout) and self.lib.bbdm_gemm_bf3p_supported(t8, cin, cout)):
+                a8 = 0
         return winograd_wgrad_tile(self.N, H, W, cin, cout, m.winograd_wgrad, allow8=a8)
 
     def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
