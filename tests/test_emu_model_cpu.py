@@ -275,7 +275,7 @@ def test_training_plan_on_f8_tiles(monkeypatch):
     import bbdm_amd
     import bbdm_oracle as O
     from fixture_weights import synth_weights
-    monkeypatch.setattr(bbdm_amd.unet, "_tile8_ok", lambda N, H, W, cin, cout: cin >= 128 and cin % 32 == 0 and cout % 128 == 0 and H % 8 == 0)
+    monkeypatch.setattr(bbdm_amd.unet, "_tile8_ok", lambda N, H, W, cin, cout, min_tiles=512: cin >= 128 and cin % 32 == 0 and cout % 128 == 0 and H % 8 == 0)
     up = dict(image_size=16, in_channels=4, model_channels=128, out_channels=4, num_res_blocks=1, attention_resolutions=(),
               channel_mult=(1,), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
               resblock_updown=False, use_spatial_transformer=False, context_dim=None, condition_key="nocond")

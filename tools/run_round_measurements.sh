@@ -16,8 +16,8 @@ for w in c1 c3 c5; do ( timeout 300 python bench.py --workload $w --no-cpu > $O/
 ( timeout 600 python bench.py --workload c4 --no-cpu --dump-ops $O/c4_per_launch.md > $O/bench_c4.json 2> $O/bench_c4.err )
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c2 -o c2 -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/prof_c2.log 2>&1 )
 python tools/rocprof_summary.py $(find $O/prof_c2 -name "*.db" | head -1) "python bench.py --set hip_graph=0 --workload c2 --steps 3 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras (eager launches: a graph capture would run the first forward twice)" > $O/c2_kernel_stats.md 2>&1
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c4 -o c4 -- python $R/bench.py --workload c4 --steps 4 --warmup 1 --no-cpu --no-parity > $R/$O/prof_c4.log 2>&1 )
-python tools/rocprof_summary.py $(find $O/prof_c4 -name "*.db" | head -1) "python bench.py --workload c4 --steps 4 --warmup 1 --no-cpu --no-parity (training: 4 priming + 1 warm-up + 4 timed + 4 per-op-profiled micro-steps = 13)" > $O/c4_kernel_stats.md 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c4 -o c4 -- python $R/bench.py --workload c4 --steps 4 --warmup 1 --no-cpu --no-parity --no-f32mfma > $R/$O/prof_c4.log 2>&1 )
+python tools/rocprof_summary.py $(find $O/prof_c4 -name "*.db" | head -1) "python bench.py --workload c4 --steps 4 --warmup 1 --no-cpu --no-parity --no-f32mfma (training: 4 priming + 1 warm-up + 4 timed + 4 per-op-profiled micro-steps = 13)" > $O/c4_kernel_stats.md 2>&1
 CMD="python bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras"
 ( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/$O/pmc_fetch -o pmc -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_fetch.log 2>&1 )
 ( cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/$O/pmc_write -o pmc -- python $R/bench.py --set hip_graph=0 --workload c2 --steps 1 --warmup 1 --no-cpu --no-parity --no-f32mfma --no-extras > $R/$O/pmc_write.log 2>&1 )
