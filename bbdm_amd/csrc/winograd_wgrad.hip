@@ -16,6 +16,9 @@
 // The bias gradient = column sums of the ONE plane dM_(1,1) (row 1 of A is all ones: that plane holds the tile sums of dY).
 // fp32 throughout; rounding error of the gradient relative to fp64 (tests/test_winograd_math_cpu.py): direct 5e-7,
 // m = 2: 6e-7, m = 4: 3e-6, m = 6: 5e-6.
+// m = 8 (end of round 5; ten points, winograd_math.h): only on the bf16x3 pipeline -- the transposed planes of V from the training forward's
+// input transform, winograd_dy_split_kernel<8> (csrc/winograd.hip), bbdm_gemm_bf3p_tn_f32, and the finish kernels below with G^T . G in fp64
+// (3e-5); stages (1) - (3) of the fp32 form keep m <= 6.
 #include "winograd_math.h"
 
 namespace {
