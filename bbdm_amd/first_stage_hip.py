@@ -56,6 +56,9 @@ class _Flags:
         self.winograd_wgrad = 0             # (inference plans only)
         self.winograd_train8 = 0
         self.winograd8_min_tiles = 512
+        self.side_stream_min_macs = 0
+        self.side_stream_max_macs = 0
+        self.side_stream_max_pixels = 0
         self.hip_graph = False
         self.op_profile = None
 

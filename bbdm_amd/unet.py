@@ -758,6 +758,15 @@ class UNetModel(nn.Module):
         self.winograd_train8: int = 2
         # least number of 8x8 tiles for a layer to take F(8x8, 3x3): below it the 100 x 6 B of weight planes per weight are the bound
         self.winograd8_min_tiles: int = 512
+        # inference plans: the 1x1 skip projection of a channel-changing ResBlock on a SECOND stream of the captured graph, beside the
+        # block's first convolution, when its N H W Cin Cout lies in [min, max].  Measured at the end of round 5 (same box, ms per step,
+        # one stream -> two): C3 14.89 -> 14.51 (projections of 0.06 - 0.33 ms next to tile GEMMs that leave rounds unfilled); C5 3.10 ->
+        # 3.20 and C1 3.72 -> 3.84 (projections of 10 - 40 us: a fork and a join cost more than they hide); C2 96.9 / 97.3 -> 98.0 / 98.4 (its
+        # kernels share one power budget: running two at once lowers the clock of both; with only its one projection inside the band,
+        # 128 -> 512 at 128^2: 97.05 / 97.44 -> 97.58 / 97.55 -- hence the pixel cap).  The band admits C3's; max = 0: one stream
+        self.side_stream_min_macs: int = 4_000_000_000
+        self.side_stream_max_macs: int = 30_000_000_000
+        self.side_stream_max_pixels: int = 131072
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -816,7 +825,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.bf3_min_tiles,
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
                self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
@@ -866,6 +875,8 @@ class _Plan:
         self.tape: List[tuple] = []         # training: one record per layer, replayed in reverse by _emit_backward
         self.bops: List[tuple] = []         # training: backward op list
         self.ops: List[tuple] = []          # (fn_name, args with unresolved refs)
+        self._side_ranges: List[tuple] = []         # (first op, end op, joining op) of launches that run on the plan's second stream
+        self._side_stream = None
         self.convs: List[_PackedConv] = []
         self.bufs: List[_Buf] = []
         self._scratch: Dict[str, _Buf] = {}
@@ -1420,6 +1431,19 @@ class _Plan:
         film = rb.use_scale_shift_norm
         rs = 2 if rb.up else (1 if rb.down else 0)
         s1 = self._gn_count
+        # The 1x1 skip projection of a channel-changing block reads only x: small inference plans launch it first, on a SECOND stream of
+        # the captured graph, and join before the launch that adds it (the out conv's epilogue) -- it then runs beside the in conv's
+        # launches instead of between them (UNetModel.side_stream_min_macs / _max_macs; kernels that own no shared workspace only)
+        side, out = None, None
+        early_skip = (isinstance(rb.skip_connection, nn.Conv2d) and rs == 0 and not self.training
+                      and self.m.side_stream_min_macs <= N * x.H * x.W * x.C * rb.out_channels <= self.m.side_stream_max_macs
+                      and N * x.H * x.W <= self.m.side_stream_max_pixels)
+        if early_skip:
+            out = dest if dest is not None else self._new(N, x.H, x.W, rb.out_channels)
+            k0 = len(self.ops)
+            self._emit_conv(x, rb.skip_connection, None, out)
+            if all(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in self.ops[k0:]):
+                side = (k0, len(self.ops))
         # Up-sampling block, inference, both 3x3 convs on the Winograd path at the upsampled size: nothing is resampled explicitly.
         # GN -> SiLU -> nearest x2 folds into the input transform of in_layers[2] (index shift, csrc/winograd.hip: UP), and the skip path
         # x_upd(x) is the out conv's residual read at [h/2][w/2] (BBDM_CONV_RES_UPSAMPLE): the two gn_apply passes that wrote and
@@ -1447,10 +1471,14 @@ class _Plan:
         s2 = self._gn_count
         a2, pre2 = self._gn_input(h1, rb.out_layers[0], self.film_off[id(rb)] if film else None, silu=1, name="A2",
                                   consumer=rb.out_layers[3])
-        out = dest if dest is not None else self._new(N, oh, ow, rb.out_channels)
+        if out is None:
+            out = dest if dest is not None else self._new(N, oh, ow, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
-            self._emit_conv(xr, rb.skip_connection, None, out)
+            if not early_skip:
+                self._emit_conv(xr, rb.skip_connection, None, out)
             self._emit_conv(a2, rb.out_layers[3], out, out, pre=pre2)
+            if side is not None:
+                self._side_ranges.append((side[0], side[1], len(self.ops) - 1))      # (.., the launch that reads the projection)
         elif fold_up:
             self._emit_conv(a2, rb.out_layers[3], xr, out, pre=pre2, flags=4)        # residual = x at half resolution
         else:
@@ -2223,7 +2251,32 @@ class _Plan:
         """Enqueue one forward (statistics reset, embedding path, the op list) on ``stream``."""
         self._launch_embedding(stream)
         check = _lib.check
-        if prof is None:
+        if prof is None and self._side_ranges and self.device.type == "cuda":
+            # fork / join around the side ranges (captured into the hipGraph as parallel branches; eager launches behave the same)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side, main = self._side_stream, torch.cuda.current_stream(self.device)
+            forks = {k0: k1 for k0, k1, _ in self._side_ranges}
+            joins = {kj for _, _, kj in self._side_ranges}
+            k, n = 0, len(self._bound)
+            while k < n:
+                if k in forks:
+                    side.wait_stream(main)
+                    for j in range(k, forks[k]):
+                        fn, args = self._bound[j]
+                        rc = fn(*args, side.cuda_stream)
+                        if rc != 0:
+                            check(rc, fn.__name__)
+                    k = forks[k]
+                    continue
+                if k in joins:
+                    main.wait_stream(side)
+                fn, args = self._bound[k]
+                rc = fn(*args, stream)
+                if rc != 0:
+                    check(rc, fn.__name__)
+                k += 1
+        elif prof is None:
             for fn, args in self._bound:
                 rc = fn(*args, stream)
                 if rc != 0:

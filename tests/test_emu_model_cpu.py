@@ -33,6 +33,15 @@ def test_unet_forward_and_p_sample_match_reference_golden(name):
     with torch.no_grad():
         out = m.denoise_fn(rec["x0"], timesteps=rec["t"], context=ctx)
     assert parity_err(out, rec["unet_out"]) < M.STEP_TOL
+    # the plan that launches its 1x1 skip projections FIRST (on a GPU: on the graph's second stream, UNetModel.side_stream_*): the op
+    # order the emulator runs is a valid serialisation of it -- same bits
+    fn = m.denoise_fn
+    fn.side_stream_min_macs, fn.side_stream_max_macs, fn.side_stream_max_pixels = 0, 1 << 62, 1 << 30
+    with torch.no_grad():
+        out2 = fn(rec["x0"], timesteps=rec["t"], context=ctx)
+    plan2 = [p for p in fn._plans.values() if p._side_ranges]
+    assert len(plan2) == 1 and torch.equal(out2, out)
+    fn.side_stream_max_macs = 0
     eps = rec["p_eps"]
     orig = torch.randn_like
     torch.randn_like = lambda t, **k: eps

@@ -82,6 +82,39 @@ def test_eval_loss_matches_reference_golden(dev, name):
     assert "loss" in log
 
 
+@pytest.mark.parametrize("name", SUPPORTED)
+def test_skip_projection_on_a_second_stream_is_bit_equal(dev, name):
+    """UNetModel.side_stream_min_macs / _max_macs: the 1x1 skip projections of the channel-changing ResBlocks launched on a second stream
+    of the captured graph (fork before the block's first conv, join before the out conv's epilogue that adds them) -- same kernels, same
+    arithmetic: the step is bit-equal to the one-stream plan, as a hipGraph replay (twice) and launch by launch."""
+    rec = load_case(name)
+    m = build(rec, dev)
+    fn = m.denoise_fn
+    ctx = None if rec["unet_params"]["condition_key"] == "nocond" else rec["y"].to(dev)
+    x, t = rec["x0"].to(dev), rec["t"].to(dev)
+    outs = {}
+    for band, graph in ((0, True), (1 << 62, True), (1 << 62, False)):
+        fn.side_stream_min_macs, fn.side_stream_max_macs, fn.side_stream_max_pixels, fn.hip_graph = 0, band, 1 << 30, graph
+        with torch.no_grad():
+            a = fn(x, timesteps=t, context=ctx).clone()
+            b = fn(x, timesteps=t, context=ctx).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        plan = next(iter(fn._plans.values()))
+        n_proj = sum(1 for blk in list(fn.input_blocks) + [fn.middle_block] + list(fn.output_blocks) for l in blk
+                     if hasattr(l, "skip_connection") and isinstance(l.skip_connection, torch.nn.Conv2d) and not (l.up or l.down))
+        sides = [r for r in plan._side_ranges]
+        # (a projection that falls to the direct kernel -- odd channel counts: it owns the shared split-K workspace -- stays on the first stream)
+        assert (0 < len(sides) <= n_proj) if band else not sides, (len(sides), n_proj)
+        for k0, k1, kj in sides:          # the side launches are 1x1 projections; the joining launch reads what they wrote
+            assert k0 < k1 <= kj and all(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.ops[k0:k1])
+        outs[(band, graph)] = a
+        fn._plans = {}
+    ref = outs[(0, True)]
+    assert torch.equal(outs[(1 << 62, True)], ref) and torch.equal(outs[(1 << 62, False)], ref)
+    assert parity_err(ref.cpu(), rec["unet_out"]) < STEP_TOL
+
+
 def test_weight_updates_and_ema_swaps_are_seen(dev):
     """Packed-weight caches must follow in-place updates (optimizer) and ``param.data`` swaps (EMA.apply_shadow)."""
     rec = load_case("tiny_concat")

@@ -213,6 +213,24 @@ def test_flop_accounting_evaluates_on_every_op_of_a_training_plan():
     assert any(str(n) == "bbdm_conv_wgrad_f32" for n, _ in plan.bops)
 
 
+def test_side_stream_band_admits_the_latent_f4_projections_only():
+    """UNetModel.side_stream_min_macs / _max_macs (measured: C3 -2 %, C1 / C5 +3 %, C2 +1 %): with the defaults only the LBBDM-f4
+    sampling plan forks its 1x1 skip projections; training plans never do; every fork is joined before the launch that adds it."""
+    for workload, batch, training, want in (("c3", 32, False, True), ("c5", 32, False, False), ("c1", 4, False, False),
+                                            ("c3", 32, True, False)):
+        m, plan = _plan(workload, batch, training, winograd=8)
+        sides = plan._side_ranges
+        assert bool(sides) == want, (workload, training, len(sides))
+        last = 0
+        for k0, k1, kj in sides:
+            assert last <= k0 < k1 <= kj < len(plan.ops) and all(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.ops[k0:k1])
+            dest = plan.ops[k0][1][6]                                   # the projection's destination view ...
+            assert any(a is dest for a in plan.ops[kj][1])               # ... is the residual the joining launch adds
+            last = kj
+    m, plan = _plan("c2", 16, False, winograd=8)                         # the benchmarked C2 batch: above the band
+    assert not plan._side_ranges
+
+
 def test_first_stage_flags_cover_every_switch_the_plan_emitters_read():
     """The VQGAN plans reuse _Plan's emitters with first_stage_hip._Flags standing in for the UNetModel: every switch an emitter reads
     (``self.m.<name>`` / ``m.<name>`` in unet.py's _Plan) must exist there, or the first plan of a first stage dies on a GPU box only."""
