@@ -59,6 +59,7 @@ class _Flags:
         self.side_stream_min_macs = 0
         self.side_stream_max_macs = 0
         self.side_stream_max_pixels = 0
+        self.side_stream_train = False
         self.hip_graph = False
         self.op_profile = None
 

@@ -767,6 +767,9 @@ class UNetModel(nn.Module):
         self.side_stream_min_macs: int = 4_000_000_000
         self.side_stream_max_macs: int = 30_000_000_000
         self.side_stream_max_pixels: int = 131072
+        # ... and training plans: the projection's forward launch, and in the gradient plan its weight gradient + data gradient (a
+        # workspace of their own), forked at the top of the block's backward and joined before the GroupNorm backward that adds dX
+        self.side_stream_train: bool = True
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -825,7 +828,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.bf3_min_tiles,
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
                self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
@@ -1425,6 +1428,13 @@ class _Plan:
                        *(pre or self.NO_PRE), self.N, x.H, x.W, x.C, pc.cout, pc.ks, None, 0, 0, None, 0, 0)
         self._note_writer(dest, rec, 21 if fusable else None)
 
+    def _side_band(self, pixels: int, cin: int, cout: int) -> bool:
+        """Does a 1x1 skip projection of this size run on the plan's second stream (UNetModel.side_stream_*)?"""
+        m = self.m
+        if self.training and not m.side_stream_train:
+            return False
+        return m.side_stream_min_macs <= pixels * cin * cout <= m.side_stream_max_macs and pixels <= m.side_stream_max_pixels
+
     def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
         """ResBlock._forward (openaimodel.py:258-278)."""
         N = self.N
@@ -1435,9 +1445,7 @@ class _Plan:
         # the captured graph, and join before the launch that adds it (the out conv's epilogue) -- it then runs beside the in conv's
         # launches instead of between them (UNetModel.side_stream_min_macs / _max_macs; kernels that own no shared workspace only)
         side, out = None, None
-        early_skip = (isinstance(rb.skip_connection, nn.Conv2d) and rs == 0 and not self.training
-                      and self.m.side_stream_min_macs <= N * x.H * x.W * x.C * rb.out_channels <= self.m.side_stream_max_macs
-                      and N * x.H * x.W <= self.m.side_stream_max_pixels)
+        early_skip = isinstance(rb.skip_connection, nn.Conv2d) and rs == 0 and self._side_band(N * x.H * x.W, x.C, rb.out_channels)
         if early_skip:
             out = dest if dest is not None else self._new(N, x.H, x.W, rb.out_channels)
             k0 = len(self.ops)
@@ -1716,17 +1724,19 @@ class _Plan:
             written.add(k)
             return acc
 
-        ws_floats, ws_doubles, colsum_c = [1], [1], [1]
+        ws_floats, ws_doubles, colsum_c, ws_side_floats = [1], [1], [1], [1]
 
         def sstat(slot):
             return _Plan._StatsRef(self, slot)
 
-        def conv_bwd(mod, x_in: _View, dy: _View, need_dx: bool, dx_name: str, cin_true=None):
-            """wgrad + bias grad (+ dgrad into a scratch view).  dy: gradient of the conv output (pitch >= Cout)."""
+        def conv_bwd(mod, x_in: _View, dy: _View, need_dx: bool, dx_name: str, cin_true=None, side: bool = False):
+            """wgrad + bias grad (+ dgrad into a scratch view).  dy: gradient of the conv output (pitch >= Cout).  ``side``: a 1x1
+            layer whose launches may run on the plan's second stream -- its weight gradient takes a workspace of its own."""
             w = mod.weight
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
-            ws_floats[0] = max(ws_floats[0], lib.bbdm_conv_wgrad_workspace_floats(N, x_in.H, x_in.W, x_in.C, cout, ks))
+            wsn = ws_side_floats if side else ws_floats
+            wsn[0] = max(wsn[0], lib.bbdm_conv_wgrad_workspace_floats(N, x_in.H, x_in.W, x_in.C, cout, ks))
             if x_in.C == cin:
                 dw_dst = gref(w)
             else:                                   # padded stem input: gradient of the padding channels is dropped
@@ -1784,8 +1794,8 @@ class _Plan:
                 self._bop("bbdm_conv3x3_winograd_wgrad_f32", wgm, x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, N,
                           x_in.H, x_in.W, x_in.C, cout)
             else:
-                self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f, self._ws_f_floats, N, x_in.H,
-                          x_in.W, x_in.C, cout, ks)
+                self._bop("bbdm_conv_wgrad_f32", x_in, x_in.ld, dy, dy.ld, dw_dst, dbias, self._ws_f_side if side else self._ws_f,
+                          self._ws_f_side_floats if side else self._ws_f_floats, N, x_in.H, x_in.W, x_in.C, cout, ks)
             if not need_dx:
                 return None
             dx = self._tmp(dx_name, N, x_in.H, x_in.W, x_in.C)
@@ -1828,6 +1838,8 @@ class _Plan:
         self.dconvs: List[_PackedDgrad] = []
         self._padded_wgrads: List[tuple] = []
         self._ws_f = _LateTensor()
+        self._ws_f_side, self._ws_f_side_floats = _LateTensor(), _LateInt()
+        self._bside_ranges: List[tuple] = []        # (first op, end op, joining op) of gradient-plan launches on the second stream
         self._ws_f_floats = _LateInt()
         self._ws_d = _LateTensor()
         self._ws_d2 = _LateTensor()
@@ -1851,8 +1863,15 @@ class _Plan:
             elif kind == "res":
                 _, rb, x, a, xr, h1, a2, out, s1, s2, rs = rec
                 dout = gview(out)
+                bside = None
                 if isinstance(rb.skip_connection, nn.Conv2d):
-                    dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR")
+                    # the projection's gradients read only dOut (complete before this block's backward starts) and the block input: on the
+                    # second stream beside the block's own chain; joined before the launch that adds dXr (the last GroupNorm backward)
+                    sb = rs == 0 and self._side_band(N * xr.H * xr.W, xr.C, rb.out_channels)
+                    k0 = len(self.bops)
+                    dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR", side=sb)
+                    if sb and all(str(n) in ("bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32") for n, _ in self.bops[k0:]):
+                        bside = (k0, len(self.bops))
                 else:
                     dxr = dout
                 da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2")
@@ -1866,6 +1885,8 @@ class _Plan:
                               _TensorRef(self.dfilm, 4 * self.film_off[id(rb)]), self.film_total, N, h1.H * h1.W, h1.C)
                 da = conv_bwd(rb.in_layers[2], a, dh1, True, "DA")
                 dx = gview(x)
+                if bside is not None:
+                    self._bside_ranges.append((bside[0], bside[1], len(self.bops)))
                 gn_bwd(rb.in_layers[0], x, s1, None, da, dxr, 1, rs, dx, first_write(x))
             elif kind == "attn":
                 _, ab, x, a, qkv, at, lse, out, s0 = rec
@@ -1985,6 +2006,8 @@ class _Plan:
         self._segment_backward(rec_ends)
         self._ws_f.t = torch.empty(ws_floats[0], **f32)
         self._ws_f_floats.v = ws_floats[0]
+        self._ws_f_side.t = torch.empty(ws_side_floats[0], **f32)
+        self._ws_f_side_floats.v = ws_side_floats[0]
         self._ws_d.t = torch.empty(colsum_c[0], dtype=torch.float64, device=dev)
         self._ws_d2.t = torch.empty(ws_doubles[0], dtype=torch.float64, device=dev)
         # embedding-path backward scratch
@@ -2110,9 +2133,28 @@ class _Plan:
         ops = self.bops[lo:hi] + (self.bops_x0 if (last and need_dx) else [])
         check = _lib.check
         prof = self.m.op_profile
-        for name, args in ops:
+        # second-stream ranges of this segment (forward: _launch_forward): op index -> stream, forks and joins
+        on_side, forks, joins = {}, set(), set()
+        if prof is None and self._bside_ranges and self.device.type == "cuda":
+            for k0, k1, kj in self._bside_ranges:
+                if lo <= k0 and kj < hi:
+                    forks.add(k0 - lo)
+                    joins.add(kj - lo)
+                    for j in range(k0, k1):
+                        on_side[j - lo] = True
+            if forks:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(self.device)
+                side_s, main_s = self._side_stream, torch.cuda.current_stream(self.device)
+        for i, (name, args) in enumerate(ops):
             fn = getattr(lib, getattr(name, "entry", name))
-            if prof is None:
+            if i in forks:
+                side_s.wait_stream(main_s)
+            if i in joins:
+                main_s.wait_stream(side_s)
+            if i in on_side:
+                rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), side_s.cuda_stream)
+            elif prof is None:
                 rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
             else:                                   # per-op HIP events (bench.py's roofline leg), as in _launch_forward
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

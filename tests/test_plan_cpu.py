@@ -215,9 +215,10 @@ def test_flop_accounting_evaluates_on_every_op_of_a_training_plan():
 
 def test_side_stream_band_admits_the_latent_f4_projections_only():
     """UNetModel.side_stream_min_macs / _max_macs (measured: C3 -2 %, C1 / C5 +3 %, C2 +1 %): with the defaults only the LBBDM-f4
-    sampling plan forks its 1x1 skip projections; training plans never do; every fork is joined before the launch that adds it."""
+    plans (sampling, and training: UNetModel.side_stream_train) fork their 1x1 skip projections; every fork is joined before the launch
+    that adds it; in the gradient plan the forked launches are the projection's weight / data gradient on their own workspace."""
     for workload, batch, training, want in (("c3", 32, False, True), ("c5", 32, False, False), ("c1", 4, False, False),
-                                            ("c3", 32, True, False)):
+                                            ("c3", 32, True, True)):
         m, plan = _plan(workload, batch, training, winograd=8)
         sides = plan._side_ranges
         assert bool(sides) == want, (workload, training, len(sides))
@@ -227,6 +228,16 @@ def test_side_stream_band_admits_the_latent_f4_projections_only():
             dest = plan.ops[k0][1][6]                                   # the projection's destination view ...
             assert any(a is dest for a in plan.ops[kj][1])               # ... is the residual the joining launch adds
             last = kj
+        if training:
+            assert 0 < len(plan._bside_ranges) <= len(sides)         # (a data gradient on the direct kernel keeps its block on one stream)
+            for k0, k1, kj in plan._bside_ranges:
+                names = [str(n) for n, _ in plan.bops[k0:k1]]
+                assert names == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"] and str(plan.bops[kj][0]) == "bbdm_groupnorm_bwd_f32"
+                assert plan.bops[k0][1][6] is plan._ws_f_side                   # its own workspace, never the shared one
+                dxr = plan.bops[k1 - 1][1][6]                                    # the data gradient's destination ...
+                assert any(a is dxr for a in plan.bops[kj][1])                   # ... is what the joining GroupNorm backward adds
+            m.side_stream_train = False
+            assert not m._plan_for(torch.zeros(batch, 3, 64, 64), True)._side_ranges
     m, plan = _plan("c2", 16, False, winograd=8)                         # the benchmarked C2 batch: above the band
     assert not plan._side_ranges
 

@@ -70,6 +70,51 @@ def test_loss_and_all_parameter_gradients(dev, name):
     assert errs[0][0] < GRAD_TOL, errs[0]
 
 
+def test_skip_projection_on_a_second_stream_training_is_bit_equal(dev):
+    """UNetModel.side_stream_train: the 1x1 skip projections of a training plan -- their forward launch, and in the gradient plan their
+    weight gradient + data gradient on a workspace of their own -- run on a second stream, forked at the top of the block and joined
+    before the launch that consumes them.  Same kernels: the output and every parameter gradient are bit-equal to the one-stream plan,
+    three micro-steps in a row (a missing join shows up as a difference sooner or later).  A 64-channel UNet on 16 images of 16x16 with
+    the band forced open and the projections on the bf16x3 GEMM, as at full size (the direct kernels own a shared workspace and stay on
+    stream one)."""
+    import bbdm_amd
+    from fixture_weights import synth_weights
+    up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(16, 4, 16, 16, generator=g).to(dev)
+    t = (torch.arange(16) * 5 + 2).to(dev)
+    dout = torch.randn(16, 4, 16, 16, generator=g).to(dev)
+    runs = {}
+    for band in (0, 1 << 62):
+        m = bbdm_amd.unet.UNetModel(**up)
+        sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 44)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dev).train()
+        m.side_stream_min_macs, m.side_stream_max_macs, m.side_stream_max_pixels, m.side_stream_train = 0, band, 1 << 30, True
+        m.bf3_min_tiles = 1
+        outs = []
+        for rep in range(3):
+            m.zero_grad(set_to_none=True)
+            out = m(x, timesteps=t, context=None)
+            (out * dout).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+        plan = next(p for p in m._plans.values() if p.training)
+        assert bool(plan._side_ranges) == bool(band) and bool(plan._bside_ranges) == bool(band), (len(plan._side_ranges), len(plan._bside_ranges))
+        for k0, k1, kj in plan._bside_ranges:
+            assert k0 < k1 <= kj and [str(n) for n, _ in plan.bops[k0:k1]] == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"]
+            assert str(plan.bops[kj][0]) == "bbdm_groupnorm_bwd_f32" and plan.bops[k0][1][6] is plan._ws_f_side
+        runs[band] = outs
+    for rep in range(3):
+        oa, ga = runs[0][rep]
+        ob, gb = runs[1 << 62][rep]
+        assert torch.equal(oa, ob), rep
+        bad = [k for k in ga if not torch.equal(ga[k], gb[k])]
+        assert not bad, (rep, bad[:6])
+
+
 @pytest.mark.parametrize("name", ["tiny_concat", "tiny_xattn"])
 def test_gradient_accumulation_and_input_grad(dev, name):
     """Two backward passes accumulate into .grad (accumulate_grad_batches, BaseRunner.py:412-417); d loss / d context
