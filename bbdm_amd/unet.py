@@ -770,6 +770,10 @@ class UNetModel(nn.Module):
         # ... and training plans: the projection's forward launch, and in the gradient plan its weight gradient + data gradient (a
         # workspace of their own), forked at the top of the block's backward and joined before the GroupNorm backward that adds dX
         self.side_stream_train: bool = True
+        # ... and the Winograd-domain weight gradients of the ResBlocks' 3x3 layers (dY transform -> TN GEMM -> finish, on the side
+        # workspace) beside the data gradient of the same layer, from this many N H W Cin Cout up
+        self.side_stream_wgrad: bool = True
+        self.side_stream_wgrad_min_macs: int = 1_000_000_000
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -828,7 +832,7 @@ class UNetModel(nn.Module):
     def _plan_for(self, x, training: bool) -> "_Plan":
         N, _, H, W = x.shape
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
-               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.bf3_min_tiles,
+               self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.side_stream_wgrad, self.side_stream_wgrad_min_macs, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
                self.fp32_v_max_cout, self.upsample_f72)
         plan = self._plans.pop(key, None)
@@ -1435,6 +1439,12 @@ class _Plan:
             return False
         return m.side_stream_min_macs <= pixels * cin * cout <= m.side_stream_max_macs and pixels <= m.side_stream_max_pixels
 
+    def _side_band3(self, pixels: int, cin: int, cout: int) -> bool:
+        """Does the Winograd-domain weight gradient of a ResBlock's 3x3 layer of this size run on the gradient plan's second stream?"""
+        m = self.m
+        return bool(m.side_stream_train and m.side_stream_wgrad) and pixels * cin * cout >= m.side_stream_wgrad_min_macs \
+            and pixels <= m.side_stream_max_pixels
+
     def _emit_res(self, rb: ResBlock, x: _View, dest: Optional[_View]) -> _View:
         """ResBlock._forward (openaimodel.py:258-278)."""
         N = self.N
@@ -1725,13 +1735,16 @@ class _Plan:
             return acc
 
         ws_floats, ws_doubles, colsum_c, ws_side_floats = [1], [1], [1], [1]
+        side_chains: List[tuple] = []       # second-stream launch ranges of the block being emitted (joined at its last GroupNorm backward)
 
         def sstat(slot):
             return _Plan._StatsRef(self, slot)
 
-        def conv_bwd(mod, x_in: _View, dy: _View, need_dx: bool, dx_name: str, cin_true=None, side: bool = False):
+        def conv_bwd(mod, x_in: _View, dy: _View, need_dx: bool, dx_name: str, cin_true=None, side: bool = False,
+                     side_chain: bool = False):
             """wgrad + bias grad (+ dgrad into a scratch view).  dy: gradient of the conv output (pitch >= Cout).  ``side``: a 1x1
-            layer whose launches may run on the plan's second stream -- its weight gradient takes a workspace of its own."""
+            layer whose launches may run on the plan's second stream -- its weight gradient takes a workspace of its own;
+            ``side_chain``: a 3x3 layer whose Winograd-domain weight gradient on the kept planes may (that chain only)."""
             w = mod.weight
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
@@ -1761,8 +1774,15 @@ class _Plan:
                 o_dm11 = n_dmt
                 o_du = o_dm11 + Tp * cout
                 o_acc = (o_du + splits * P * x_in.C * cout + 1) & ~1
-                ws_floats[0] = max(ws_floats[0], o_acc + 8 * cout + 2)        # (+ the column sums' limb cells: 4 x 8 B per channel)
-                dMt, dm11, dU = _TensorRef(self._ws_f, 0), _TensorRef(self._ws_f, 4 * o_dm11), _TensorRef(self._ws_f, 4 * o_du)
+                # ``side`` (a ResBlock's 3x3 layer, UNetModel.side_stream_wgrad): the three launches of this weight gradient read dY,
+                # the kept planes and their own workspace only -- on the plan's second stream beside the data gradient of the same
+                # layer (whose tile GEMM leaves its last round half empty); joined at the end of the block
+                chain = side_chain and self._side_band3(N * x_in.H * x_in.W, x_in.C, cout)
+                wsn = ws_side_floats if chain else ws_floats
+                wsn[0] = max(wsn[0], o_acc + 8 * cout + 2)        # (+ the column sums' limb cells: 4 x 8 B per channel)
+                wsf = self._ws_f_side if chain else self._ws_f
+                dMt, dm11, dU = _TensorRef(wsf, 0), _TensorRef(wsf, 4 * o_dm11), _TensorRef(wsf, 4 * o_du)
+                k_chain = len(self.bops)
                 self._bop("bbdm_winograd_dy_transform_bf3p_f32", wgm, dy, dy.ld, dMt, dm11, N, x_in.H, x_in.W, cout)
                 self._bop("bbdm_gemm_bf3p_tn_f32", saved[0], dMt, dU, P, Tp, x_in.C, cout)
                 if dbias is not None and cout % 4 == 0:
@@ -1771,7 +1791,9 @@ class _Plan:
                 else:
                     self._bop("bbdm_winograd_wgrad_finish_f32", wgm, dU, splits, dw_dst, x_in.C, cout)
                     if dbias is not None:
-                        self._bop("bbdm_colsum_f32", dm11, cout, _TensorRef(self._ws_f, 4 * o_acc), dbias, T, cout)
+                        self._bop("bbdm_colsum_f32", dm11, cout, _TensorRef(wsf, 4 * o_acc), dbias, T, cout)
+                if chain:
+                    side_chains.append((k_chain, len(self.bops)))
             elif saved is not None and saved[1] == wgm:
                 # the forward kept this layer's V: dY transform -> TN GEMM -> finish (the stages bbdm_conv3x3_winograd_wgrad_f32 chains)
                 P, Tp = wino_planes(wgm), lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
@@ -1867,14 +1889,21 @@ class _Plan:
                 if isinstance(rb.skip_connection, nn.Conv2d):
                     # the projection's gradients read only dOut (complete before this block's backward starts) and the block input: on the
                     # second stream beside the block's own chain; joined before the launch that adds dXr (the last GroupNorm backward)
-                    sb = rs == 0 and self._side_band(N * xr.H * xr.W, xr.C, rb.out_channels)
+                    # (only where the data gradient takes the bf16x3 GEMM -- conv_bwd's rule: the direct kernel owns a shared workspace)
+                    px = N * xr.H * xr.W
+                    sb = (rs == 0 and self._side_band(px, xr.C, rb.out_channels) and bool(m.gemm_bf3)
+                          and rb.skip_connection.weight.shape[1] == xr.C and bool(lib.bbdm_gemm_bf3_supported(px, dout.C, xr.C))
+                          and (px // 256) * -(-xr.C // 128) >= m.bf3_min_tiles)
                     k0 = len(self.bops)
                     dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR", side=sb)
-                    if sb and all(str(n) in ("bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32") for n, _ in self.bops[k0:]):
+                    if sb:
+                        assert [str(n) for n, _ in self.bops[k0:]] == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"], \
+                            "second-stream projection: conv_bwd chose another kernel than this rule predicted"
                         bside = (k0, len(self.bops))
                 else:
                     dxr = dout
-                da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2")
+                side_chains.clear()
+                da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2", side_chain=True)
                 dh1 = self._tmp("DH1", N, h1.H, h1.W, h1.C)
                 if rb.use_scale_shift_norm:
                     gn_bwd(rb.out_layers[0], h1, s2, self.film_off[id(rb)], da2, None, 1, 0, dh1, 0)
@@ -1883,10 +1912,11 @@ class _Plan:
                     colsum_c[0] = max(colsum_c[0], 4 * N * h1.C)        # limb cells (csrc/stats_acc.h): 4 words per sum
                     self._bop("bbdm_colsum_batched_f32", dh1, dh1.ld, self._ws_d,
                               _TensorRef(self.dfilm, 4 * self.film_off[id(rb)]), self.film_total, N, h1.H * h1.W, h1.C)
-                da = conv_bwd(rb.in_layers[2], a, dh1, True, "DA")
+                da = conv_bwd(rb.in_layers[2], a, dh1, True, "DA", side_chain=True)
                 dx = gview(x)
-                if bside is not None:
-                    self._bside_ranges.append((bside[0], bside[1], len(self.bops)))
+                for k0, k1 in ([bside] if bside is not None else []) + side_chains:
+                    self._bside_ranges.append((k0, k1, len(self.bops)))
+                side_chains.clear()
                 gn_bwd(rb.in_layers[0], x, s1, None, da, dxr, 1, rs, dx, first_write(x))
             elif kind == "attn":
                 _, ab, x, a, qkv, at, lse, out, s0 = rec

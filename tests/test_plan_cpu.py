@@ -229,15 +229,30 @@ def test_side_stream_band_admits_the_latent_f4_projections_only():
             assert any(a is dest for a in plan.ops[kj][1])               # ... is the residual the joining launch adds
             last = kj
         if training:
-            assert 0 < len(plan._bside_ranges) <= len(sides)         # (a data gradient on the direct kernel keeps its block on one stream)
-            for k0, k1, kj in plan._bside_ranges:
+            proj = [r for r in plan._bside_ranges if str(plan.bops[r[0]][0]) == "bbdm_conv_wgrad_f32"]
+            chains = [r for r in plan._bside_ranges if str(plan.bops[r[0]][0]) == "bbdm_winograd_dy_transform_bf3p_f32"]
+            assert 0 < len(proj) <= len(sides) and len(proj) + len(chains) == len(plan._bside_ranges)
+            for k0, k1, kj in proj:       # (a data gradient on the direct kernel keeps its block's projection on one stream)
                 names = [str(n) for n, _ in plan.bops[k0:k1]]
                 assert names == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"] and str(plan.bops[kj][0]) == "bbdm_groupnorm_bwd_f32"
                 assert plan.bops[k0][1][6] is plan._ws_f_side                   # its own workspace, never the shared one
                 dxr = plan.bops[k1 - 1][1][6]                                    # the data gradient's destination ...
                 assert any(a is dxr for a in plan.bops[kj][1])                   # ... is what the joining GroupNorm backward adds
+            # the Winograd-domain weight gradients of the ResBlocks' 3x3 layers (UNetModel.side_stream_wgrad): dY transform -> TN GEMM ->
+            # finish on the side workspace; every other user of a weight-gradient workspace keeps the shared one on stream one
+            assert len(chains) >= 30
+            for k0, k1, kj in chains:
+                names = [str(n) for n, _ in plan.bops[k0:k1]]
+                assert names[:2] == ["bbdm_winograd_dy_transform_bf3p_f32", "bbdm_gemm_bf3p_tn_f32"] and names[2].startswith("bbdm_winograd_wgrad_finish")
+                assert str(plan.bops[kj][0]) == "bbdm_groupnorm_bwd_f32"
+                assert all(a.t is plan._ws_f_side for a in plan.bops[k0][1][3:5]) and plan.bops[k0 + 1][1][1].t is plan._ws_f_side
+            on_side = {j for k0, k1, _ in plan._bside_ranges for j in range(k0, k1)}
+            for j, (n, a) in enumerate(plan.bops):
+                if j not in on_side:
+                    assert not any(getattr(v, "t", None) is plan._ws_f_side or v is plan._ws_f_side for v in a), (j, str(n))
             m.side_stream_train = False
-            assert not m._plan_for(torch.zeros(batch, 3, 64, 64), True)._side_ranges
+            p1 = m._plan_for(torch.zeros(batch, 3, 64, 64), True)
+            assert not p1._side_ranges and not p1._bside_ranges
     m, plan = _plan("c2", 16, False, winograd=8)                         # the benchmarked C2 batch: above the band
     assert not plan._side_ranges
 
