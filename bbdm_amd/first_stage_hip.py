@@ -61,6 +61,7 @@ class _Flags:
         self.side_stream_max_pixels = 0
         self.side_stream_train = False
         self.side_stream_wgrad = False
+        self.side_stream_dgrad_pack = False
         self.side_stream_wgrad_min_macs = 0
         self.hip_graph = False
         self.op_profile = None

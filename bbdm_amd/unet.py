@@ -774,6 +774,9 @@ class UNetModel(nn.Module):
         # workspace) beside the data gradient of the same layer, from this many N H W Cin Cout up
         self.side_stream_wgrad: bool = True
         self.side_stream_wgrad_min_macs: int = 1_000_000_000
+        # ... and, after an optimizer step, the re-packing of the data-gradient weight operands (not read before the backward) beside
+        # the forward instead of at the start of the backward
+        self.side_stream_dgrad_pack: bool = True
 
     # reference API kept as no-ops (openaimodel.py:703-719; convert_module_to_f16 is a stub there as well)
     def convert_to_fp16(self):
@@ -2146,6 +2149,9 @@ class _Plan:
             self._flat_grad = self._pick_flat_grad()
             self.dout_nchw.copy_(dout)
             stream = _lib.current_stream(self.device)
+            if getattr(self, "_dconvs_forked", False):          # (re-packed beside the forward, see _run)
+                torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+                self._dconvs_forked = False
             for pk in self.dconvs:
                 pk.refresh(stream)
 
@@ -2390,6 +2396,17 @@ class _Plan:
         self.generation = getattr(self, "generation", 0) + 1
         stream = _lib.current_stream(self.device)
         self._refresh_weights(stream)
+        if (self.training and self.m.side_stream_train and self.m.side_stream_dgrad_pack and self.device.type == "cuda"
+                and getattr(self, "dconvs", None)):
+            # the data-gradient orientation of the weights (G g' G^T planes, packed 1x1 / direct operands) is not read before the
+            # backward: after an optimizer step it is re-packed on the second stream, beside this forward (backward_begin joins)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(self.device)
+            side = self._side_stream
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            for pk in self.dconvs:
+                pk.refresh(side.cuda_stream)
+            self._dconvs_forked = True
         # Inputs: skip the copy of a tensor this plan already holds -- the x_next the previous sampling step also wrote into x_in
         # (holds_input), the conditioning image that does not change during a sampling loop.  Identity AND version are checked and the
         # source is kept alive, so neither an in-place edit nor a recycled allocation can be mistaken for it.
