@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -109,6 +109,21 @@ SIGNATURES = {
     "bbdm_gemm_bf3p_pack_b_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "bbdm_gemm_bf3p_split_rows_f32": (c_int, [_P, c_int, _P, c_int, ctypes.c_longlong, c_int, _P]),
     "bbdm_gemm_bf3p_f32": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),
+    # the fp16-pair planes (ABI 24; csrc/h2_split.h)
+    "bbdm_gemm_h2p_a_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
+    "bbdm_gemm_h2p_b_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "bbdm_absmax_f32": (c_int, [_P, ctypes.c_longlong, _P, _P]),
+    "bbdm_gemm_h2p_pack_b_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "bbdm_gemm_h2p_split_rows_f32": (c_int, [_P, c_int, _P, _P, c_int, ctypes.c_longlong, c_int, _P]),
+    "bbdm_gemm_h2p_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),
+    "bbdm_gemm_h2p_splitk_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int, c_int, _P]),
+    "bbdm_h2_gn_bounds_f32": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
+    "bbdm_winograd_input_gain": (c_float, [c_int]),
+    "bbdm_winograd_input_h2p_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "bbdm_winograd_input_h2p_gn_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                               _P, _P, _P, c_int, c_int, c_int, ctypes.c_float, _P, _P]),
+    "bbdm_winograd_gemm_h2p_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "bbdm_winograd_gemm_h2p_splitk_f32": (c_int, [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "bbdm_conv1x1_bf3q_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_conv1x1_bf3s_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_winograd_input_bf3p_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

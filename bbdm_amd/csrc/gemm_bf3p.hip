@@ -29,6 +29,7 @@
 // both operands by LDS-DMA two steps ahead, fp32 A split at the fragment read: round 4); the NS = 3 build of the pipe kernel for
 // small launches whose workgroups have a CU to themselves (round 4).
 #include "bf3_split.h"
+#include "h2_split.h"
 #include "lds_dma.h"
 #include <stdlib.h>
 
@@ -50,6 +51,11 @@ struct Bf3pArgs {
     int ldo, ldr;
     const float* bias;       // [Cout] or null
     const float* res;        // [T][ldr] or null; may alias M
+    // h2 planes (NP = 2: two fp16 planes under a power-of-two scale, h2_split.h): the bounds the two operands were scaled by -- the
+    // epilogue multiplies the accumulators by 2^-(eA + eB), exact -- or null (bf16x3 planes carry no scale)
+    const float* hA = nullptr;
+    const float* hB = nullptr;
+    float gA = 1.f;          // *hA bounds the tensor the A planes were FORMED from; gA = the gain of that transform (Winograd: wino_input_gain)
 };
 
 __device__ __forceinline__ int xcd_block_p(int nblk, int x, int off) {
@@ -95,11 +101,13 @@ __device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uin
 // traps that cost more than the ring gained until they were removed: fragments held as <8 x bf16> across the has_next branches are
 // legalised element-wise (120 v_perm / v_lshrrev per iteration), and with the branches kept the register allocator copies the whole
 // fragment set around each of them (108 v_mov_b64 per iteration) -- hence frag_t and the unconditional reads below.
-template <int WM, int WN, bool RES, int NS = 2>
+// NP = planes per operand (round 6): 3 = the bf16x3 split, six terms; 2 = the fp16 pair of h2_split.h, three terms on
+// v_mfma_f32_32x32x16_f16 and the accumulators re-scaled by 2^-(eA + eB) in the epilogue.  Same layout with NP units per chunk.
+template <int WM, int WN, bool RES, int NS = 2, int NP = 3>
 __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) gemm_bf3p_pipe_kernel(const Bf3pArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][STAGE]
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
-    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
+    constexpr int NA = WM * 2 * NP, NB = WN * 2 * NP, NU = NA + NB, STAGE = NU * UNIT;
     constexpr int KMAX = (NU + NW - 1) / NW;
     static_assert(NS == 2 || NU % NW == 0, "counted waits need the same number of copies per wave and chunk");
     static_assert(NS >= 2 && (NS - 2) * KMAX <= 60, "vmcnt is a 6-bit counter");
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tilesN = a.tilesN * 2 / WN;
-    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
+    const size_t gstride = (size_t)a.nchunks * NP * UNIT;
     // A ragged last row tile (T % BM != 0) reads the row groups the buffer holds beyond the real rows -- zeros, written by the producer
     // of the planes (Winograd input transform, split pass) -- and past THEM the last group again; its rows are not stored.  (Round 5:
     // it used to re-read the last REAL group: the idle 32-row blocks then multiplied live data, and the kernel is bound by the power its
@@ -149,7 +157,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         row0 = m_tile * BM; cout0 = n_tile * BN;
         // split-K (the weight-gradient GEMMs: few output tiles, long contraction): entry = bz % P, split z = bz / P
         const int zs = a.ksplits > 1 ? bz / a.P : 0, ent = a.ksplits > 1 ? bz - zs * a.P : bz;
-        const size_t koff = (size_t)zs * a.kps * (3 * UNIT);
+        const size_t koff = (size_t)zs * a.kps * (NP * UNIT);
         const unsigned char* A = a.A + (size_t)ent * a.az + koff;
         const unsigned char* B = a.B + (size_t)ent * a.bz + koff + (size_t)n_tile * (WN * 2) * gstride;
         M = a.M + (size_t)bz * a.mz;
@@ -158,8 +166,8 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         for (int k = 0; k < KMAX; ++k) {
             const int u = wave + k * NW;
             const int ub = u - NA;
-            src[k] = (u < NA ? A + (size_t)min(m_tile * (WM * 2) + u / 3, rg_last) * gstride + (u % 3) * UNIT
-                             : B + (size_t)(ub / 3) * gstride + (ub % 3) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
+            src[k] = (u < NA ? A + (size_t)min(m_tile * (WM * 2) + u / NP, rg_last) * gstride + (u % NP) * UNIT
+                             : B + (size_t)(ub / NP) * gstride + (ub % NP) * UNIT);      // wave-uniform (SGPRs); + lane * 16 below
         }
         n = a.ksplits > 1 ? min(a.kps, a.nchunks - zs * a.kps) : a.nchunks;
         return true;
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int u = wave + k * NW;
-            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (3 * UNIT), lane16, st + u * UNIT);
+            if ((k + 1) * NW <= NU || u < NU) glds16(src[k] + (size_t)chunk * (NP * UNIT), lane16, st + u * UNIT);
         }
     };
     auto load_bias = [&](float (&bv)[2]) {
@@ -179,8 +187,8 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         }
     };
     const unsigned lds0 = lds_address(smem);
-    const unsigned aoff = (wm * 2) * 3 * UNIT + lane * 16;
-    const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
+    const unsigned aoff = (wm * 2) * NP * UNIT + lane * 16;
+    const unsigned boff = (NA + (wn * 2) * NP) * UNIT + lane * 16;
 
     int L = (int)blockIdx.x;
     if (!setup(L)) return;
@@ -192,28 +200,37 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
 
     // (held as 4 x 32-bit: a <8 x bf16> value that lives across the has_next branches is legalised ELEMENT-wise by the compiler --
     // 120 v_lshrrev / v_perm per iteration in the NS > 2 builds; a bit-cast at the MFMA is free)
-    frag_t fa[3][2], fb[3][2];                                                 // [plane][tile]
-#define BF3P_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
+    frag_t fa[NP][2], fb[NP][2];                                               // [plane][tile]
+#define BF3P_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * NP + (p)) * UNIT)); } while (0)
 #define BF3P_READ_A(p, base) do { BF3P_READ(fa[p][0], base, p, 0); BF3P_READ(fa[p][1], base, p, 1); } while (0)
 #define BF3P_READ_B(p, base) do { BF3P_READ(fb[p][0], base, p, 0); BF3P_READ(fb[p][1], base, p, 1); } while (0)
 #define BF3P_READS_RETURNED()                                                                                                  \
     do {                                                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),          \
-                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1])           \
-                     :: "memory");                                                                                              \
+        if constexpr (NP == 3)                                                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[NP - 1][0]), "+v"(fa[NP - 1][1]),  \
+                           "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[NP - 1][0]), "+v"(fb[NP - 1][1])   \
+                         :: "memory");                                                                                          \
+        else                                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]),                                      \
+                           "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])                                       \
+                         :: "memory");                                                                                          \
     } while (0)
 #define BF3P_ALL_LANDED()                                                                                                      \
     do {                                                                                                                        \
         wait_vmcnt<0>();                                                                                                        \
         BF3P_READS_RETURNED();                                                                                                  \
     } while (0)
+#define BF3P_MFMA(A_, B_, C_)                                                                                                   \
+    (NP == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(A_), BF3P_BF(B_), C_, 0, 0, 0)                                    \
+             : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0))
 #define BF3P_TERM(pa, pb)                                                                                                       \
     do {                                                                                                                        \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][0]), BF3P_BF(fb[pb][0]), acc[0][0], 0, 0, 0);                          \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][0]), BF3P_BF(fb[pb][1]), acc[0][1], 0, 0, 0);                          \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][1]), BF3P_BF(fb[pb][0]), acc[1][0], 0, 0, 0);                          \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[pa][1]), BF3P_BF(fb[pb][1]), acc[1][1], 0, 0, 0);                          \
+        acc[0][0] = BF3P_MFMA(fa[pa][0], fb[pb][0], acc[0][0]);                                                                 \
+        acc[0][1] = BF3P_MFMA(fa[pa][0], fb[pb][1], acc[0][1]);                                                                 \
+        acc[1][0] = BF3P_MFMA(fa[pa][1], fb[pb][0], acc[1][0]);                                                                 \
+        acc[1][1] = BF3P_MFMA(fa[pa][1], fb[pb][1], acc[1][1]);                                                                 \
     } while (0)
     for (;;) {
         f32x16 acc[2][2];
@@ -230,7 +247,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         {
             const unsigned sa = lds0 + aoff, sb = lds0 + boff;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) { BF3P_READ_A(p, sa); BF3P_READ_B(p, sb); }
+            for (int p = 0; p < NP; ++p) { BF3P_READ_A(p, sa); BF3P_READ_B(p, sb); }
         }
         BF3P_ALL_LANDED();
         asm volatile("s_barrier" ::: "memory");                                // everybody holds chunk 0: stage 0 may be overwritten
@@ -241,30 +258,47 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
             const bool has_next = NS > 2 || chunk + 1 < n;
             const unsigned nxt = lds0 + ((chunk + 1) % NS) * STAGE;
             const unsigned sa = nxt + aoff, sb = nxt + boff;
-            __builtin_amdgcn_sched_barrier(0);
-            BF3P_TERM(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (chunk + NS < n) issue(chunk + NS, smem + (chunk % NS) * STAGE);   // under the first MFMAs; stage free since the last barrier
-            __builtin_amdgcn_sched_barrier(0);
-            BF3P_TERM(0, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) BF3P_READ_B(2, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            BF3P_TERM(2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) BF3P_READ_A(2, sa);
-            __builtin_amdgcn_sched_barrier(0);
-            BF3P_TERM(0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) BF3P_READ_B(1, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            BF3P_TERM(1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) BF3P_READ_A(1, sa);
-            __builtin_amdgcn_sched_barrier(0);
-            BF3P_TERM(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+            if constexpr (NP == 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (chunk + NS < n) issue(chunk + NS, smem + (chunk % NS) * STAGE);   // under the first MFMAs; stage free since the last barrier
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) BF3P_READ_B(2, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) BF3P_READ_A(2, sa);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) BF3P_READ_B(1, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) BF3P_READ_A(1, sa);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+            } else {
+                // fp16 pair: (h1 k2) (h2 k1) (h1 k1) -- the small terms first; each fragment is re-read right after its last use
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (chunk + NS < n) issue(chunk + NS, smem + (chunk % NS) * STAGE);
+                if (has_next) BF3P_READ_B(1, sb);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) BF3P_READ_A(1, sa);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+            }
             // my copies of chunk + 2 have landed (NS > 2: those of chunks chunk + 3 .. chunk + NS, issued after them, may stay in flight;
             // in the last iterations fewer are behind them: wait for all), my reads of chunk + 1 returned
             if (NS > 2 && chunk + NS < n) wait_vmcnt<(NS - 2) * KMAX>();
@@ -277,6 +311,8 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         float* const cM = M;
         const float* const cres = res;
         const float cb0 = bv[0], cb1 = bv[1];
+        float descale = 1.f;
+        if constexpr (NP == 2) descale = h2_pow2(-(h2_exp_of_bound(*a.hA * a.gA) + h2_exp_of_bound(*a.hB)));
         L += (int)gridDim.x;
         const bool more = a.persist && setup(L);
         if (more) {
@@ -311,7 +347,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int co = ccout0 + wn * 64 + j * 32 + (lane & 31);
-                        float v = acc[i][j][r] + (j ? cb1 : cb0);
+                        float v = (NP == 2 ? acc[i][j][r] * descale : acc[i][j][r]) + (j ? cb1 : cb0);
                         if (RES) v += rv[rr][j];
 #if BBDM_NT_MSTORE
                         if (co < a.Cout && row < a.T) store_nt(dst + co, v);
@@ -324,6 +360,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         if (!more) break;
     }
 #undef BF3P_TERM
+#undef BF3P_MFMA
 #undef BF3P_ALL_LANDED
 #undef BF3P_READS_RETURNED
 #undef BF3P_READ_B
@@ -835,13 +872,13 @@ static inline long long by_batch_slots(long long blocks, int batch) {
     if (rem == 1 || rem == 2 || rem == 4) return blocks * full + (blocks + 8 / rem - 1) / (8 / rem);
     return blocks * ((batch + 7) / 8);
 }
-template <int WM, int WN, bool RES, int NS = 2>
+template <int WM, int WN, bool RES, int NS = 2, int NP = 3>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = NS * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
+    const size_t lds = NS * (size_t)(WM * 2 * NP + WN * 2 * NP) * UNIT;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES, NS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES, NS, NP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
@@ -866,7 +903,7 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
             grid = dim3(resident);
         }
     }
-    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES, NS>), grid, dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES, NS, NP>), grid, dim3(WM * WN * 64), lds, st, a);
     return BBDM_OK;
 }
 
@@ -907,9 +944,12 @@ int fwd_splits(int batch, long long rows, int CinPad, int Cout) {
 
 // rows: the rows actually computed (<= T, a multiple of 32; the tiles beyond them are neither launched nor stored); T: the row count
 // the buffers are laid out for (per-batch strides).
+// np = planes per operand: 3 (bf16x3) or 2 (the fp16 pair of h2_split.h; hA / hB = the bounds the operands were scaled by).
 int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr, float* M, int ldo,
-                 int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream) {
+                 int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream, int np = 3,
+                 const float* hA = nullptr, const float* hB = nullptr, float gA = 1.f) {
     BBDM_REQUIRE(a_planes && b_planes && M && batch > 0, "gemm_bf3p: null pointer / bad batch");
+    BBDM_REQUIRE(np == 3 || (np == 2 && hA && hB), "gemm_h2p: the fp16-pair planes need the bounds of both operands");
     BBDM_REQUIRE(bbdm_gemm_bf3p_supported(T, CinPad, Cout), "gemm_bf3p: T=%lld CinPad=%d Cout=%d unsupported (T %% 256, CinPad %% 16)",
                  T, CinPad, Cout);
     BBDM_REQUIRE(rows > 0 && rows <= T && rows % 32 == 0, "gemm_bf3p: rows=%lld of T=%lld", rows, T);
@@ -924,8 +964,9 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     a.rgs = bbdm_option(BBDM_OPT_BF3P_PAD_ROWS) ? (int)(T / 32) : (int)(rows / 32);      // (0: round 4's clamp to the last real group, A/B)
     const int CoutPad = cdiv(Cout, 128) * 128;
     a.tilesN = CoutPad / 128;
-    a.az = (size_t)T * CinPad * 6; a.bz = (size_t)CoutPad * CinPad * 6; a.mz = (size_t)T * ldo; a.rz = (size_t)T * ldr;
+    a.az = (size_t)T * CinPad * 2 * np; a.bz = (size_t)CoutPad * CinPad * 2 * np; a.mz = (size_t)T * ldo; a.rz = (size_t)T * ldr;
     a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    a.hA = hA; a.hB = hB; a.gA = gA;
     a.kps = (a.nchunks + splits - 1) / splits;
     a.ksplits = (a.nchunks + a.kps - 1) / a.kps;
     BBDM_REQUIRE(a.ksplits == splits, "gemm_bf3p: %d splits of %d chunks leave an empty split", splits, a.nchunks);
@@ -942,8 +983,10 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     const int small_wg = 200;
     auto wgs = [&](int bm, int bn) { return (long long)nb * cdiv((int)rows, bm) * cdiv(CoutPad, bn); };
     int rc;
-#define BBDM_BF3P_GO(WM, WN) (residual ? bf3p_launch<WM, WN, true>(a, nb, st) : bf3p_launch<WM, WN, false>(a, nb, st))
-#define BBDM_BF3P_GO_NS(WM, WN, NS) (residual ? bf3p_launch<WM, WN, true, NS>(a, nb, st) : bf3p_launch<WM, WN, false, NS>(a, nb, st))
+#define BBDM_BF3P_GO_NS(WM, WN, NS)                                                                                        \
+    (np == 3 ? (residual ? bf3p_launch<WM, WN, true, NS, 3>(a, nb, st) : bf3p_launch<WM, WN, false, NS, 3>(a, nb, st))     \
+             : (residual ? bf3p_launch<WM, WN, true, NS, 2>(a, nb, st) : bf3p_launch<WM, WN, false, NS, 2>(a, nb, st)))
+#define BBDM_BF3P_GO(WM, WN) BBDM_BF3P_GO_NS(WM, WN, 2)
     if (g_bf3p_variant == 4) rc = wide ? BBDM_BF3P_GO(4, 4) : BBDM_BF3P_GO(4, 2);
     else if (g_bf3p_variant == 5) rc = BBDM_BF3P_GO(4, 2);
     else if (g_bf3p_variant == 7 || wgs(256, 128) < small_wg || rows <= 128) {        // (<= 128 rows: a 256-row tile would be half padding)
@@ -994,6 +1037,114 @@ extern "C" int bbdm_gemm_bf3p_fwd_splits(int batch, long long rows, int CinPad, 
 extern "C" int bbdm_gemm_bf3p_splitk_f32(const void* a_planes, const void* b_planes, float* M, int ldo, int batch, long long T,
                                          long long rows, int CinPad, int Cout, int splits, void* stream) {
     return bf3p_forward(a_planes, b_planes, nullptr, nullptr, 0, M, ldo, batch, T, rows, CinPad, Cout, splits, stream);
+}
+
+// ---- the fp16-pair ("h2") planes: two planes per operand under a power-of-two scale (h2_split.h; round 6) ----------------------------
+// Layout as above with TWO units per chunk: A [batch][T / 32][nchunks][2][1 KB], B [batch][CoutPad / 32][nchunks][2][1 KB] -- 4 B per
+// element.  Each operand comes with a BOUND (a device float >= max |x| over the whole operand): producers scale by 2^e,
+// e = h2_exp_of_bound(bound), the GEMM's epilogue by 2^-(eA + eB).
+namespace {
+// max |x| into *bound (atomicMax on the bit pattern of a non-negative float: order-independent); *bound accumulates
+__global__ void h2_absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ bound) {
+    float m = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(m));
+}
+// bf3p_pack_b_kernel for the fp16 pair
+__global__ void h2p_pack_b_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, const float* __restrict__ bound,
+                                  size_t batch_chunks, int nchunks, int CoutPad) {
+    const float sc = h2_pow2(h2_exp_of_bound(*bound));
+    const size_t pairs = batch_chunks * CoutPad * (KC / 2);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
+        const int kp = (int)(i % (KC / 2));
+        size_t t = i / (KC / 2);
+        const int co = (int)(t % CoutPad);
+        const size_t bc = t / CoutPad;
+        const size_t b = bc / nchunks;
+        const int chunk = (int)(bc % nchunks);
+        const float2 v = *reinterpret_cast<const float2*>(src + (bc * CoutPad + co) * KC + kp * 2);
+        unsigned p1, p2;
+        h2_split2(v.x * sc, v.y * sc, p1, p2);
+        unsigned char* d = dst + (((b * (CoutPad / 32) + co / 32) * nchunks + chunk) * 2) * (size_t)UNIT + unit_off(co & 31, kp * 2);
+        *reinterpret_cast<unsigned*>(d) = p1;
+        *reinterpret_cast<unsigned*>(d + UNIT) = p2;
+    }
+}
+// bf3p_split_rows_kernel for the fp16 pair
+__global__ void __launch_bounds__(256) h2p_split_rows_kernel(const float* __restrict__ x, int ld, size_t xz, unsigned char* __restrict__ dst,
+                                                              size_t dz, const float* __restrict__ bound, int T, int nchunks) {
+    const float sc = h2_pow2(h2_exp_of_bound(*bound));
+    const int chunk = (int)blockIdx.x % nchunks, g = (int)blockIdx.x / nchunks, b = (int)blockIdx.y;
+    const int r = threadIdx.x >> 3, kp = threadIdx.x & 7;
+    const int row = g * 32 + r;
+    float2 v = make_float2(0.f, 0.f);
+    if (row < T) v = *reinterpret_cast<const float2*>(x + (size_t)b * xz + (size_t)row * ld + chunk * KC + kp * 2);
+    unsigned p1, p2;
+    h2_split2(v.x * sc, v.y * sc, p1, p2);
+    unsigned char* d = dst + (size_t)b * dz + (((size_t)g * nchunks + chunk) * 2) * UNIT + unit_off(r, kp * 2);
+    *reinterpret_cast<unsigned*>(d) = p1;
+    *reinterpret_cast<unsigned*>(d + UNIT) = p2;
+}
+}  // namespace
+
+extern "C" size_t bbdm_gemm_h2p_a_bytes(int batch, long long T, int CinPad) {
+    return (size_t)batch * (size_t)((T + 255) / 256 * 256) * (size_t)CinPad * 4;
+}
+extern "C" size_t bbdm_gemm_h2p_b_bytes(int batch, int CinPad, int Cout) {
+    return (size_t)batch * (size_t)(cdiv(Cout, 128) * 128) * (size_t)CinPad * 4;
+}
+extern "C" int bbdm_absmax_f32(const float* x, long long n, float* bound, void* stream) {
+    BBDM_REQUIRE(x && bound && n > 0, "absmax: bad args");
+    size_t blocks = ((size_t)n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, bound);
+    BBDM_CHECK_LAUNCH("absmax");
+    return BBDM_OK;
+}
+extern "C" int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, int batch, int CinPad, int Cout,
+                                        void* stream) {
+    BBDM_REQUIRE(packed_f32 && b_planes && bound && batch > 0 && CinPad > 0 && CinPad % KC == 0 && Cout > 0, "gemm_h2p_pack_b: bad args");
+    const int CoutPad = cdiv(Cout, 128) * 128, nchunks = CinPad / KC;
+    const size_t pairs = (size_t)batch * nchunks * CoutPad * (KC / 2);
+    size_t blocks = (pairs + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(h2p_pack_b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, packed_f32,
+                       (unsigned char*)b_planes, bound, (size_t)batch * nchunks, nchunks, CoutPad);
+    BBDM_CHECK_LAUNCH("gemm_h2p_pack_b");
+    return BBDM_OK;
+}
+extern "C" int bbdm_gemm_h2p_split_rows_f32(const float* x, int ldx, void* a_planes, const float* bound, int batch, long long T,
+                                            int CinPad, void* stream) {
+    BBDM_REQUIRE(x && a_planes && bound && batch > 0 && T > 0 && CinPad > 0 && CinPad % KC == 0 && ldx >= CinPad && ldx % 2 == 0,
+                 "gemm_h2p_split_rows: bad args");
+    BBDM_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)a_planes & 15) == 0, "gemm_h2p_split_rows: alignment");
+    const long long Tp = (T + 255) / 256 * 256;
+    const int nchunks = CinPad / KC;
+    BBDM_REQUIRE((Tp / 32) * nchunks < (1ll << 31) && batch < 65536, "gemm_h2p_split_rows: too large");
+    hipLaunchKernelGGL(h2p_split_rows_kernel, dim3((unsigned)((Tp / 32) * nchunks), (unsigned)batch), dim3(256), 0,
+                       (hipStream_t)stream, x, ldx, (size_t)T * ldx, (unsigned char*)a_planes, (size_t)Tp * CinPad * 4, bound, (int)T,
+                       nchunks);
+    BBDM_CHECK_LAUNCH("gemm_h2p_split_rows");
+    return BBDM_OK;
+}
+// M[b][T][ldo] = A_b . B_b (+ bias) (+ residual) on the fp16-pair planes; bound_a / bound_b: the device floats the producers scaled by
+extern "C" int bbdm_gemm_h2p_f32(const void* a_planes, const void* b_planes, const float* bound_a, const float* bound_b,
+                                 const float* bias, const float* residual, int ldr, float* M, int ldo, int batch, long long T,
+                                 int CinPad, int Cout, void* stream) {
+    return bf3p_forward(a_planes, b_planes, bias, residual, ldr, M, ldo, batch, T, T, CinPad, Cout, 1, stream, 2, bound_a, bound_b);
+}
+extern "C" int bbdm_gemm_h2p_splitk_f32(const void* a_planes, const void* b_planes, const float* bound_a, const float* bound_b, float* M,
+                                        int ldo, int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream) {
+    return bf3p_forward(a_planes, b_planes, nullptr, nullptr, 0, M, ldo, batch, T, rows, CinPad, Cout, splits, stream, 2, bound_a,
+                        bound_b);
+}
+// (winograd.hip: the A planes were scaled by the bound of the transform's INPUT times its gain)
+int bbdm_gemm_h2p_gain_splitk(const void* a_planes, const void* b_planes, const float* bound_a, float gain_a, const float* bound_b, float* M,
+                              int ldo, int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream) {
+    return bf3p_forward(a_planes, b_planes, nullptr, nullptr, 0, M, ldo, batch, T, rows, CinPad, Cout, splits, stream, 2, bound_a,
+                        bound_b, gain_a);
 }
 
 // ---- C = A^T B with the contraction over the ROWS of both operands (the Winograd-domain weight gradient dU_xi = V_xi^T dM_xi, tiles

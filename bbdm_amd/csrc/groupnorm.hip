@@ -266,6 +266,51 @@ extern "C" int bbdm_groupnorm_coeffs_f32(const void* stats, const float* gamma, 
     return BBDM_OK;
 }
 
+// ---- bounds for the fp16-pair planes (round 6; h2_split.h) -------------------------------------------------------------------------
+// A convolution input that is GroupNorm -> [FiLM] -> [SiLU] of some tensor is bounded WITHOUT looking at the tensor: a z-score over n_g
+// values cannot exceed sqrt(n_g - 1), so |GN(x)[n,c] (1 + s) + t| <= |gamma_c (1 + s_nc)| sqrt(n_g - 1) + |beta_c (1 + s_nc) + t_nc|
+// and |SiLU(v)| <= |v|.  One launch per forward evaluates that for EVERY such layer of the plan (one workgroup per layer: the maximum over
+// (n, c) needs no atomics) and multiplies by the gain of the consumer's transform: bounds[layer] >= max |V| of that layer.
+namespace {
+struct H2GnLayer {            // 32 bytes (bbdm_amd/unet.py packs it with struct 'QQiiff')
+    const float* gamma;       // [C]
+    const float* beta;        // [C]
+    int film_off;             // FiLM scale at film[n][film_off + c], shift at film[n][film_off + C + c]; < 0: none
+    int C;
+    float zmax;               // sqrt(values per (image, group) - 1)
+    float gain;               // the consumer's transform: |B^T d B| <= gain max |d| (winograd_math.h: wino_input_gain); 1 for a 1x1 conv
+};
+__global__ void __launch_bounds__(256) h2_gn_bounds_kernel(const H2GnLayer* __restrict__ table, const float* __restrict__ film, int film_ld,
+                                                           int N, float* __restrict__ bounds) {
+    const H2GnLayer L = table[blockIdx.x];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < N * L.C; i += 256) {
+        const int n = i / L.C, c = i - n * L.C;
+        float a = L.gamma[c], b = L.beta[c];
+        if (L.film_off >= 0) {
+            const float fs = film[(size_t)n * film_ld + L.film_off + c], fb = film[(size_t)n * film_ld + L.film_off + L.C + c];
+            a = a * (1.f + fs);
+            b = b * (1.f + fs) + fb;
+        }
+        m = fmaxf(m, fabsf(a) * L.zmax + fabsf(b));
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) bounds[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * L.gain;
+}
+}  // namespace
+
+extern "C" int bbdm_h2_gn_bounds_f32(const void* table, int nlayers, const float* film, int film_ld, int N, float* bounds, void* stream) {
+    BBDM_REQUIRE(table && bounds && nlayers > 0 && N > 0, "h2_gn_bounds: bad args");
+    hipLaunchKernelGGL(h2_gn_bounds_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, (const H2GnLayer*)table, film, film_ld, N,
+                       bounds);
+    BBDM_CHECK_LAUNCH("h2_gn_bounds");
+    return BBDM_OK;
+}
+
 // ---- the accumulator itself (layout: stats_acc.h) -------------------------------------------------------------------------------
 extern "C" size_t bbdm_groupnorm_stats_bytes(int N, int G) {
     return N > 0 && G > 0 ? (size_t)N * G * 2 * SA_W * sizeof(unsigned long long) : 0;

@@ -21,6 +21,7 @@
 #include "winograd_math.h"
 #include <stdlib.h>
 #include "bf3_split.h"
+#include "h2_split.h"
 #include "stats_acc.h"
 
 namespace {
@@ -386,7 +387,11 @@ struct GnFold {
 // writes 8 tiles x 64 B; the other 16-channel chunks of the tile group run on the same XCD (see below) and complete the lines in its L2.
 // ST (round 5): the tile stride.  ST = 7 with MO = 6 is the input side of F(7x7, 2x2) (the phase filters of an up-sampling conv,
 // winograd_math.h): the same 8 x 8 window and B^T, windows 7 pixels apart (window rows 7 t - 1 .. 7 t + 6).
-template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false, bool F32 = false, int ST = MO>
+// NPL (round 6): planes per value.  3 = the exact bf16 split; 2 = the fp16 pair of h2_split.h under the scale 2^e, e =
+// h2_exp_of_bound(*hbound x gain) -- hbound: a device float >= max |d| over the whole transformed tensor (after the fused producer:
+// groupnorm.hip, h2_gn_bounds_kernel), gain = wino_input_gain: |B^T d B| <= gain max |d| -- 4 B per transformed element instead of 6,
+// units [..][nchunks][2][1 KB].
+template <int MO, bool PRE, bool UP, bool TR, bool IDX64, bool GNC = false, bool F32 = false, int ST = MO, int NPL = 3>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(const float* __restrict__ x, int ldx,
                                                                               unsigned char* __restrict__ Vp,
                                                                               const float* __restrict__ sc, const float* __restrict__ bi,
@@ -394,7 +399,9 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                                                                               unsigned T, int TG, size_t plane,
                                                                               unsigned char* __restrict__ Vt, size_t plane_t,
                                                                               int tchunks, const FastDiv dTW, const FastDiv dTH,
-                                                                              const FastDiv dCH, const GnFold gn) {
+                                                                              const FastDiv dCH, const GnFold gn,
+                                                                              const float* __restrict__ hbound) {
+    static_assert(NPL == 3 || (NPL == 2 && !TR && !F32), "the fp16-pair planes have neither a transposed nor an fp32 form");
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
     const unsigned L = blockIdx.x, q = L >> 3;
@@ -501,6 +508,19 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
             return;
         }
         const int g = (int)(tile >> 5), rl = (int)(tile & 31);
+        if constexpr (NPL == 2) {
+            const float hs = h2_pow2(h2_exp_of_bound(*hbound * wino_input_gain(ST == 7 ? 7 : MO)));
+            unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 2 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
+#pragma unroll
+            for (int jj = 0; jj < AL; ++jj) {
+                unsigned p1, p2;
+                h2_split2(row[jj].x * hs, row[jj].y * hs, p1, p2);
+                *reinterpret_cast<unsigned*>(o) = p1;
+                *reinterpret_cast<unsigned*>(o + 1024) = p2;
+                o += plane;
+            }
+            return;
+        }
         // byte (k >> 3) * 512 + r * 16 + (k & 7) * 2 of the unit, k = 2 cp
         unsigned char* o = Vp + (size_t)(i * AL) * plane + ((size_t)g * nchunks + chunk) * 3 * 1024 + (cp >> 2) * 512 + rl * 16 + (cp & 3) * 4;
         unsigned pl[AL][3];
@@ -1096,7 +1116,7 @@ extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int
 
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
-                                 const GnFold* fold, bool f32out);
+                                 const GnFold* fold, bool f32out, const float* hbound = nullptr);
 
 extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale,
                                        const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
@@ -1177,8 +1197,9 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 // bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
-                                 const GnFold* fold, bool f32out) {
+                                 const GnFold* fold, bool f32out, const float* hbound) {
     BBDM_WINO_M78(m);
+    BBDM_REQUIRE(!hbound || (!Vt && !f32out), "winograd_input_h2p: the fp16-pair planes have neither a transposed nor an fp32 form");
     BBDM_REQUIRE(m != 7 || (!upsample && !Vt && !fold && !f32out), "winograd_input_bf3p: m = 7 (phase filters) takes x itself, planes only");
     BBDM_REQUIRE(m != 8 || !fold, "winograd_input_bf3p: m = 8 is a tile of the large layers (no coefficient folding)");
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
@@ -1191,7 +1212,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
                  "winograd_input_bf3p: pre_ld / alignment of the fused-producer coefficients");
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const int nchunks = CinPad / KC, TG = (int)(Tp / 8);
-    const size_t plane = Tp * (size_t)CinPad * (f32out ? 4 : 6);  // bytes of one transform point
+    const size_t plane = Tp * (size_t)CinPad * (f32out || hbound ? 4 : 6);  // bytes of one transform point
     const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * 6;       // ... of the transposed copy (whole 32-channel row groups)
     BBDM_REQUIRE(!Vt || (!upsample && ((uintptr_t)Vt & 15) == 0), "winograd_input_bf3p: the transposed copy needs upsample = 0, 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
@@ -1212,9 +1233,18 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_7(PRE, I64)                                                                                                \
     hipLaunchKernelGGL((winograd_input_split2_kernel<6, PRE, false, false, I64, false, false, 7>), g, dim3(8 * 64), 0, st, x, ldx,   \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr,  \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn)
-            if (pre_scale) { if (idx64) BBDM_WINO_INS2_7(true, true); else BBDM_WINO_INS2_7(true, false); }
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+#define BBDM_WINO_INS2_7H(PRE, I64)                                                                                               \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<6, PRE, false, false, I64, false, false, 7, 2>), g, dim3(8 * 64), 0, st, x, ldx, \
+                       (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr,  \
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+            if (hbound) {
+                if (pre_scale) { if (idx64) BBDM_WINO_INS2_7H(true, true); else BBDM_WINO_INS2_7H(true, false); }
+                else           { if (idx64) BBDM_WINO_INS2_7H(false, true); else BBDM_WINO_INS2_7H(false, false); }
+            }
+            else if (pre_scale) { if (idx64) BBDM_WINO_INS2_7(true, true); else BBDM_WINO_INS2_7(true, false); }
             else           { if (idx64) BBDM_WINO_INS2_7(false, true); else BBDM_WINO_INS2_7(false, false); }
+#undef BBDM_WINO_INS2_7H
 #undef BBDM_WINO_INS2_7
             BBDM_CHECK_LAUNCH("winograd_input_bf3p(m = 7)");
             return BBDM_OK;
@@ -1226,13 +1256,26 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         if (upsample)                                                                                                             \
             hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, true, false, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                                (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
-                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn);                                              \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                              \
         else                                                                                                                      \
             hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, false, false, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                                (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
-                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn);                                              \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                              \
     } while (0)
-            if (m == 2) BBDM_WINO_INS2_G(2); else if (m == 4) BBDM_WINO_INS2_G(4); else BBDM_WINO_INS2_G(6);
+#define BBDM_WINO_INS2_GH(MO)                                                                                                     \
+    do {                                                                                                                          \
+        if (upsample)                                                                                                             \
+            hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, true, false, false, true, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                               (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                      \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, false, false, false, true, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                               (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                      \
+    } while (0)
+            if (hbound) { if (m == 2) BBDM_WINO_INS2_GH(2); else if (m == 4) BBDM_WINO_INS2_GH(4); else BBDM_WINO_INS2_GH(6); }
+            else if (m == 2) BBDM_WINO_INS2_G(2); else if (m == 4) BBDM_WINO_INS2_G(4); else BBDM_WINO_INS2_G(6);
+#undef BBDM_WINO_INS2_GH
 #undef BBDM_WINO_INS2_G
             BBDM_CHECK_LAUNCH("winograd_input_bf3p_gn");
             return BBDM_OK;
@@ -1247,7 +1290,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_F(MO, PRE, UP, I64)                                                                                        \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, false, I64, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr, \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
 #define BBDM_WINO_INS2_FI(MO, PRE, UP) do { if (idx64) BBDM_WINO_INS2_F(MO, PRE, UP, true); else BBDM_WINO_INS2_F(MO, PRE, UP, false); } while (0)
 #define BBDM_WINO_INS2_FM(MO)                                                                                                     \
     do {                                                                                                                          \
@@ -1264,7 +1307,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_I(MO, PRE, UP, TR, I64)                                                                                    \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
                        pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, (unsigned char*)Vt,   \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
 #define BBDM_WINO_INS2(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_I(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_I(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_M(MO)                                                                        \
     do {                                                                                            \
@@ -1272,7 +1315,21 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         else if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true, false); else BBDM_WINO_INS2(MO, true, false, false); }   \
         else           { if (upsample) BBDM_WINO_INS2(MO, false, true, false); else BBDM_WINO_INS2(MO, false, false, false); } \
     } while (0)
-        if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else if (m == 8) BBDM_WINO_INS2_M(8); else BBDM_WINO_INS2_M(6);
+#define BBDM_WINO_INS2_HI(MO, PRE, UP, I64)                                                                                       \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, false, I64, false, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                       (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr, \
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+#define BBDM_WINO_INS2_H(MO, PRE, UP) do { if (idx64) BBDM_WINO_INS2_HI(MO, PRE, UP, true); else BBDM_WINO_INS2_HI(MO, PRE, UP, false); } while (0)
+#define BBDM_WINO_INS2_HM(MO)                                                                       \
+    do {                                                                                            \
+        if (pre_scale) { if (upsample) BBDM_WINO_INS2_H(MO, true, true); else BBDM_WINO_INS2_H(MO, true, false); }   \
+        else           { if (upsample) BBDM_WINO_INS2_H(MO, false, true); else BBDM_WINO_INS2_H(MO, false, false); } \
+    } while (0)
+        if (hbound) { if (m == 2) BBDM_WINO_INS2_HM(2); else if (m == 4) BBDM_WINO_INS2_HM(4); else if (m == 8) BBDM_WINO_INS2_HM(8); else BBDM_WINO_INS2_HM(6); }
+        else if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else if (m == 8) BBDM_WINO_INS2_M(8); else BBDM_WINO_INS2_M(6);
+#undef BBDM_WINO_INS2_HM
+#undef BBDM_WINO_INS2_H
+#undef BBDM_WINO_INS2_HI
 #undef BBDM_WINO_INS2_M
 #undef BBDM_WINO_INS2
 #undef BBDM_WINO_INS2_I
@@ -1318,6 +1375,47 @@ extern "C" int bbdm_winograd_input_bf3p_tr_f32(int m, const float* x, int ldx, v
                                                int CinPad, void* Vt, void* stream) {
     BBDM_REQUIRE(Vt && !upsample, "winograd_input_bf3p_tr: null pointer / upsample != 0");
     return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream, nullptr, false);
+}
+
+// ---- the same stages on the fp16-pair planes (round 6; h2_split.h, gemm_bf3p.hip "h2"): Vp holds bbdm_gemm_h2p_a_bytes((m+2)^2, tiles,
+// CinPad) bytes, b_planes = bbdm_gemm_h2p_pack_b_f32 of the buffer bbdm_winograd_pack_weight_f32 filled; vbound: a device float >=
+// max |d| of the TRANSFORMED tensor (x after the fused producer; both stages multiply it by bbdm_winograd_input_gain(m) themselves),
+// ubound: >= max |U| (bbdm_absmax_f32 of that buffer).
+extern "C" float bbdm_winograd_input_gain(int m) { return wino_input_gain(m); }
+extern "C" int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
+                                           int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad,
+                                           const float* vbound, void* stream) {
+    BBDM_REQUIRE(vbound, "winograd_input_h2p: null bound");
+    return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream, nullptr,
+                                 false, vbound);
+}
+extern "C" int bbdm_winograd_input_h2p_gn_f32(int m, const float* x, int ldx, void* Vp, const void* stats, const void* unused, int C,
+                                              int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma,
+                                              const float* beta, const float* film, int film_ld, int HW, int G, float eps,
+                                              const float* vbound, void* stream) {
+    (void)unused;
+    BBDM_REQUIRE(stats && gamma && beta && vbound, "winograd_input_h2p_gn: null pointer");
+    BBDM_REQUIRE(C == CinPad && G > 0 && C % G == 0 && (C / G) % 2 == 0 && HW > 0 && (!film || film_ld >= 2 * C),
+                 "winograd_input_h2p_gn: C=%d CinPad=%d G=%d HW=%d film_ld=%d", C, CinPad, G, HW, film_ld);
+    BBDM_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)film) & 7) == 0 && (!film || film_ld % 2 == 0),
+                 "winograd_input_h2p_gn: gamma / beta / film must be 8-byte aligned");
+    GnFold f;
+    f.stats = (const unsigned long long*)stats; f.gamma = gamma; f.beta = beta; f.film = film;
+    f.film_ld = film_ld; f.C = C; f.G = G; f.cpg = C / G; f.cnt = (double)HW * (double)(C / G); f.eps = eps;
+    return winograd_input_planes(m, x, ldx, Vp, nullptr, nullptr, nullptr, C, pre_silu, upsample, N, H, W, CinPad, stream, &f, false, vbound);
+}
+extern "C" int bbdm_winograd_gemm_h2p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
+                                                 int Cout, int splits, const float* vbound, const float* ubound, void* stream) {
+    BBDM_WINO_M78(m);
+    BBDM_REQUIRE(Vp && b_planes && M && vbound && ubound && N > 0, "winograd_gemm_h2p: null pointer / bad N");
+    BBDM_WINO_HW(m, H, W);
+    return bbdm_gemm_h2p_gain_splitk(Vp, b_planes, vbound, wino_input_gain(m), ubound, M, Cout, planes(m),
+                                     (long long)tiles_padded(N, H, W, m), (long long)((tiles_raw(N, H, W, m) + 31) / 32 * 32), CinPad, Cout,
+                                     splits, stream);
+}
+extern "C" int bbdm_winograd_gemm_h2p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad,
+                                          int Cout, const float* vbound, const float* ubound, void* stream) {
+    return bbdm_winograd_gemm_h2p_splitk_f32(m, Vp, b_planes, M, N, H, W, CinPad, Cout, 1, vbound, ubound, stream);
 }
 
 // splits > 1 (small layers, bbdm_winograd_gemm_bf3p_splits): the partial sums of split z go to M[z][(m+2)^2][tiles][Cout] and

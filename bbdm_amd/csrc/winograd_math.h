@@ -257,6 +257,12 @@ __host__ __device__ __forceinline__ void gt_transform(const T (&u)[MO + 2], T (&
     }
 }
 
+// max_i sum_j |B^T_ij| squared: |B^T d B| <= gain * max |d| for every transform point (the bound the fp16-pair planes are scaled by,
+// h2_split.h; tests/test_winograd_math_cpu.py checks the constants against the matrices).  m = 7 shares m = 6's B^T.
+__host__ __device__ inline float wino_input_gain(int m) {
+    return m == 2 ? 4.f : m == 4 ? 100.f : m == 8 ? 21.f : 225.f;      // (m = 8: 20.955)
+}
+
 // tiles along one axis.  m = 7 (the phase-filter form, F(7x7, 2x2)): tile t covers the window rows 7 t - 1 .. 7 t + 6 of x; phase 0
 // takes its 7 outputs at rows 7 t .. 7 t + 6, phase 1 at rows 7 t - 1 .. 7 t + 5 -- row H - 1 of phase 1 needs 7 t + 5 >= H - 1.
 __host__ __device__ inline int wino_tdim(int H, int m) { return m == 7 ? (H + 7) / 7 : (H + m - 1) / m; }

@@ -47,6 +47,7 @@ class _Flags:
         self.upsample_phases = True
         self.gemm_bf3 = True
         self.gemm_bf3p = True
+        self.gemm_h2 = False                # (the first stage runs once per batch; its plans launch no bound kernel)
         self.fuse_stats = True
         self.bf3_min_tiles = 256
         self.conv1x1_small = True

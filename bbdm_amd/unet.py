@@ -307,10 +307,24 @@ class _GnPre(tuple):
     (bbdm_winograd_input_bf3p_gn_f32): (stats reference, None, C, silu) in the positions of (pre_scale, pre_bias, pre_ld, pre_silu),
     the GroupNorm's parameters in ``tail`` (appended after CinPad)."""
     tail: tuple = ()
+    h2 = None          # reference of the device float that bounds the producer's output (see _Pre), or None
 
-    def __new__(cls, head, tail):
+    def __new__(cls, head, tail, h2=None):
         o = super().__new__(cls, head)
         o.tail = tuple(tail)
+        o.h2 = h2
+        return o
+
+
+class _Pre(tuple):
+    """(pre_scale, pre_bias, pre_ld, pre_silu) of a fused producer -- all None / 0 when the tensor was materialised -- plus ``h2``: the
+    reference of a device float >= max |value| of what the consumer convolves (a GroupNorm output is bounded by its coefficients alone:
+    csrc/groupnorm.hip, h2_gn_bounds_kernel), which lets the consumer's tile GEMMs run on the fp16-pair planes (csrc/h2_split.h)."""
+    h2 = None
+
+    def __new__(cls, head, h2=None):
+        o = super().__new__(cls, head)
+        o.h2 = h2
         return o
 
 
@@ -461,8 +475,14 @@ class _PackedWinograd:
         n = lib.bbdm_winograd_packed_floats(m, self.out_ch, in_pad)
         # (the planes of gemm_bf3p.hip are written directly from the weights: no fp32 G g G^T tensor -- 4x the weights at m = 4 -- is kept)
         self.fused_planes = bf3 == "p" and not phases and in_pad % 16 == 0
-        self.packed_f32 = None if self.fused_planes else torch.empty(n, dtype=torch.float32, device=weight.device)
-        if bf3 == "p":
+        # bf3 == "h": two fp16 planes under the scale of max |U| (csrc/h2_split.h); the fp32 G g G^T tensor only exists while packing
+        self.packed_f32 = None if (self.fused_planes or bf3 == "h") else torch.empty(n, dtype=torch.float32, device=weight.device)
+        self._n_f32 = n
+        self.ubound = torch.zeros(1, dtype=torch.float32, device=weight.device) if bf3 == "h" else None
+        if bf3 == "h":
+            self.packed = torch.empty(lib.bbdm_gemm_h2p_b_bytes(wino_planes(m), in_pad, self.out_ch), dtype=torch.uint8,
+                                      device=weight.device)
+        elif bf3 == "p":
             self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(wino_planes(m), in_pad, self.out_ch), dtype=torch.uint8,
                                       device=weight.device)
         elif bf3:
@@ -479,6 +499,21 @@ class _PackedWinograd:
         if key != self.key:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            if self.bf3 == "h":
+                # G g G^T in fp32 (a temporary), its exact maximum, then the two fp16 planes of U 2^e (e from the maximum)
+                tmp = torch.empty(self._n_f32, dtype=torch.float32, device=w.device)
+                src, co = w, self.cout
+                if self.phases:
+                    _lib.call("bbdm_upsample_phase_weights_f32", w.data_ptr(), self.w4.data_ptr(), self.cout, self.cin, stream)
+                    src, co = self.w4, 4 * self.cout
+                _lib.call("bbdm_winograd_pack_weight_f32", self.m, src.data_ptr(), tmp.data_ptr(), co, self.cin, self.in_pad,
+                          1 if self.dgrad else 0, stream)
+                self.ubound.zero_()
+                _lib.call("bbdm_absmax_f32", tmp.data_ptr(), tmp.numel(), self.ubound.data_ptr(), stream)
+                _lib.call("bbdm_gemm_h2p_pack_b_f32", tmp.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), wino_planes(self.m),
+                          self.in_pad, self.out_ch, stream)
+                self.key = key
+                return
             if self.phases:
                 _lib.call("bbdm_upsample_phase_weights_f32", w.data_ptr(), self.w4.data_ptr(), self.cout, self.cin, stream)
                 _lib.call("bbdm_winograd_pack_weight_f32", self.m, self.w4.data_ptr(), self.packed_f32.data_ptr(), 4 * self.cout,
@@ -725,6 +760,11 @@ class UNetModel(nn.Module):
         # ... with the A operand split into its three bf16 planes by the Winograd input transform (csrc/gemm_bf3p.hip: the GEMM's main
         # loop is LDS-DMA copies + MFMAs).  False: gemm_bf3.hip on fp32 V (tests: the two pipelines against each other)
         self.gemm_bf3p: bool = True
+        # inference: the tile GEMMs of Winograd layers whose input is bounded by its GroupNorm coefficients (every 3x3 conv inside a
+        # ResBlock) on TWO fp16 planes per operand under a provable power-of-two scale (csrc/h2_split.h; round 6): three MFMA terms
+        # instead of six, 4 B per operand element instead of 6, and half the roundings of the fp32 accumulator -- faster AND closer to
+        # the reference than the bf16x3 planes.  False: bf16x3 planes everywhere (round 5's plans; A/B)
+        self.gemm_h2: bool = True
         # 1x1 layers with fewer 256 x 128 output tiles than this leave the wide bf16x3 kernels for the small-problem kernel
         self.bf3_min_tiles: int = 256
         # ... csrc/gemm_bf3p.hip: gemm_bf3s_kernel (one launch, 64 channels per step); False: the split-K f32-MFMA kernel + reduction
@@ -837,7 +877,7 @@ class UNetModel(nn.Module):
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.side_stream_wgrad, self.side_stream_wgrad_min_macs, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
-               self.fp32_v_max_cout, self.upsample_f72)
+               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -901,6 +941,9 @@ class _Plan:
         self._conv_ws_floats = _LateInt()
         self._wino_v, self._wino_m = _LateTensor(), _LateTensor()      # Winograd V / M planes shared by every layer
         self._wino_v_need = self._wino_m_need = 0
+        self._h2_layers: List[tuple] = []            # (gamma, beta, film offset or -1, C, zmax) per bounded GroupNorm output (_gn_bound)
+        self._h2_bounds = _LateTensor()              # one float per entry, refreshed by ONE launch per forward (_launch_embedding)
+        self._h2_table = None
         self._saved_V: Dict[int, tuple] = {}         # training: id(conv weight) -> (V kept by the forward, tile m)
         self._fused_train = set()                    # training: id(conv weight) of layers whose GN->SiLU input was never materialised
         self.film, self.film_total, self.resblocks, self._film_key, self.film_wp = None, 0, [], None, None
@@ -916,6 +959,7 @@ class _Plan:
                 lt.t = torch.empty(self._coeff_need, **f32)
         self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
         self._conv_ws_floats.v = self._conv_ws_need
+        self._h2_bounds.t = torch.zeros(max(1, len(self._h2_layers)), **f32)
         self._wino_v.t = torch.empty(max(1, self._wino_v_need), **f32)
         self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
         for b in self.bufs:
@@ -1180,6 +1224,27 @@ class _Plan:
             w["used"] += 1
         self.fused_stats += 1
 
+    class _H2Ref:
+        """Address of bound slot ``k`` of the plan (a device float, csrc/h2_split.h)."""
+        __slots__ = ("plan", "k")
+
+        def __init__(self, plan, k):
+            self.plan, self.k = plan, k
+
+        def resolve(self):
+            return self.plan._h2_bounds.t.data_ptr() + 4 * self.k
+
+    def _gn_bound(self, x: _View, gn, film_off):
+        """Bound slot for GroupNorm(x) [-> FiLM] [-> SiLU] [-> average pool / nearest x2]: |value| <= |gamma (1 + s)| sqrt(n_g - 1) +
+        |beta (1 + s) + t| whatever x holds (a z-score over n_g values is at most sqrt(n_g - 1); SiLU, averaging and copying do not
+        grow it).  Inference plans only; None when the fp16-pair planes are off."""
+        if self.training or not self.m.gemm_h2 or not (self.m.gemm_bf3 and self.m.gemm_bf3p) or gn is None:
+            return None
+        n_g = x.H * x.W * (x.C // self.GROUPS)
+        self._h2_layers.append((gn.weight, gn.bias, -1 if film_off is None else int(film_off), x.C, math.sqrt(max(n_g - 1, 1))))
+        self._pref(gn.weight), self._pref(gn.bias)          # (their addresses are part of the plan's binding key)
+        return _Plan._H2Ref(self, len(self._h2_layers) - 1)
+
     def _gn_input(self, x: _View, gn, film_off, silu: int, name: str, consumer=None, fuse_direct: bool = False,
                   upsample: bool = False):
         """Input of a conv that follows GroupNorm [-> FiLM] [-> SiLU] at the same resolution.
@@ -1204,14 +1269,15 @@ class _Plan:
         elif not fuse:
             return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
         N = self.N
+        bref = self._gn_bound(x, gn, film_off) if consumer is not None else None
         ref = _Plan._StatsRef(self, self._gn_count)
         self._gn_count += 1
         self._emit_stats(x, ref)
         film = None if film_off is None else _TensorRef(self.film, 4 * film_off)
-        if self._gn_folds_into_transform(consumer, x, up):
+        if self._gn_folds_into_transform(consumer, x, up, h2=bref is not None):
             # small problem: the consumer's input transform forms the coefficients from the statistics (one launch fewer)
             return x, _GnPre((ref, None, x.C, silu), (self._pref(gn.weight), self._pref(gn.bias), film, self.film_total,
-                                                       x.H * x.W, self.GROUPS, float(gn.eps)))
+                                                       x.H * x.W, self.GROUPS, float(gn.eps)), h2=bref)
         k = self._n_coeffs
         self._n_coeffs += 1
         self._coeff_need = max(self._coeff_need, N * x.C)
@@ -1222,9 +1288,9 @@ class _Plan:
         # every size: profiles/r04_stats_tail_negative.md.)
         self._op("bbdm_groupnorm_coeffs_f32", ref, self._pref(gn.weight), self._pref(gn.bias), film, self.film_total, sc, bi,
                  x.C, N, x.H * x.W, x.C, self.GROUPS, float(gn.eps))
-        return x, (sc, bi, x.C, silu)
+        return x, _Pre((sc, bi, x.C, silu), h2=bref)
 
-    def _gn_folds_into_transform(self, consumer, x: _View, up: int) -> bool:
+    def _gn_folds_into_transform(self, consumer, x: _View, up: int, h2: bool = False) -> bool:
         """Will ``consumer`` (a 3x3 conv on GN(x), nearest-upsampled ``up`` x) run as a Winograd layer on the pre-split planes, small
         enough for its input transform to form the GroupNorm coefficients itself?  Mirrors the choices of :meth:`_emit_conv`."""
         m = self.m
@@ -1243,7 +1309,8 @@ class _Plan:
                     return False                  # (F(7x7, 2x2): large layers only, no coefficient-folding input transform)
                 cands = [(wl, x.H, x.W, 4 * cout)]
         for w_, h_, ww_, co_ in cands:
-            if self._use_bf3(w_, h_, ww_, x.C, co_) != "p" or self.lib.bbdm_winograd_tiles(w_, self.N, h_, ww_) > m.gn_in_transform:
+            if self._use_bf3(w_, h_, ww_, x.C, co_, h2=h2) not in ("p", "h") or \
+                    self.lib.bbdm_winograd_tiles(w_, self.N, h_, ww_) > m.gn_in_transform:
                 return False
         return True
 
@@ -1282,7 +1349,7 @@ class _Plan:
                 a8 = 0
         return winograd_wgrad_tile(self.N, H, W, cin, cout, m.winograd_wgrad, allow8=a8)
 
-    def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False):
+    def _use_bf3(self, wm, H, W, cin_pad, cout, keeps_V=False, h2=False):
         """Tile GEMMs of this layer on the bf16x3 kernels (fp32-accurate)?  False = f32 MFMA, True = csrc/gemm_bf3.hip (fp32 V,
         split while staged), "p" = csrc/gemm_bf3p.hip (V written pre-split by the input transform; with ``keeps_V`` -- the training
         backward contracts this layer's V again -- only where the weight-gradient GEMM takes the transposed planes too).  (Round 3
@@ -1291,6 +1358,9 @@ class _Plan:
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
+        if (h2 and not self.training and self.m.gemm_h2 and self.m.gemm_bf3p
+                and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout)):
+            return "h"          # ``h2``: the layer's input carries a bound -- two fp16 planes per operand (csrc/h2_split.h)
         if (not self.training and cout <= self.m.fp32_v_max_cout and wino_planes(wm) * tiles * cin_pad * 6 >= (512 << 20)
                 and self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout)):
             return True         # HBM-bound tile GEMM: fp32 V (see UNetModel.fp32_v_max_cout)
@@ -1314,8 +1384,12 @@ class _Plan:
             assert not bwd and not upsample and residual is None and (dest.H, dest.W) == (2 * H, 2 * W)
             flags |= 8
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
-        split = pw.bf3 == "p"          # V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
-        self._wino_v_need = max(self._wino_v_need, wino_planes(wm) * tiles * cin_pad * (3 if split else 2) // 2)
+        h2 = pw.bf3 == "h"             # V as two fp16 planes under the bound pre.h2 (4 B per element)
+        split = pw.bf3 == "p" or h2    # "p": V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
+        assert not h2 or (getattr(pre, "h2", None) is not None and not bwd and not self.training)
+        vb = (pre.h2,) if h2 else ()
+        gb = (pre.h2, _TensorRef(pw.ubound)) if h2 else ()
+        self._wino_v_need = max(self._wino_v_need, wino_planes(wm) * tiles * cin_pad * (3 if pw.bf3 == "p" else 2) // 2)
         # small layers: split-K tile GEMMs, the partial sums M[z] are added by the output transform (csrc/gemm_bf3p.hip: fwd_splits)
         ksplit = int(self.lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin_pad, cout)) if (split and not pw.phases) else 1
         self._wino_m_need = max(self._wino_m_need, ksplit * wino_planes(wm) * tiles * cout)
@@ -1339,18 +1413,20 @@ class _Plan:
                  *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt)
         elif isinstance(pre, _GnPre):
             assert split and not bwd, "the coefficient-folding input transform exists for the pre-split planes only"
-            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_gn_f32"), wm, x, x.ld, vbuf, *pre,
-                 1 if upsample else 0, N, H, W, cin_pad, *pre.tail)
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_h2p_gn_f32" if h2 else "bbdm_winograd_input_bf3p_gn_f32"),
+                 wm, x, x.ld, vbuf, *pre, 1 if upsample else 0, N, H, W, cin_pad, *pre.tail, *vb)
         else:
-            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
-                 wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad)
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_h2p_f32" if h2 else
+                         "bbdm_winograd_input_bf3p_f32" if split else "bbdm_winograd_input_f32"),
+                 wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 1 if upsample else 0, N, H, W, cin_pad, *vb)
         if ksplit > 1:
-            emit(_OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_splitk_f32"), wm, vbuf, _TensorRef(pw.packed),
-                 self._wino_m, N, H, W, cin_pad, cout, ksplit)
+            emit(_OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_h2p_splitk_f32" if h2 else "bbdm_winograd_gemm_bf3p_splitk_f32"),
+                 wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout, ksplit, *gb)
         else:
-            gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_bf3p_f32" if split else
+            gemm = _OpName("bbdm_winograd_gemm_f32", "bbdm_winograd_gemm_h2p_f32" if h2 else
+                           "bbdm_winograd_gemm_bf3p_f32" if split else
                            "bbdm_winograd_gemm_bf3_f32" if pw.bf3 else "bbdm_winograd_gemm_f32")
-            emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout)
+            emit(gemm, wm, vbuf, _TensorRef(pw.packed), self._wino_m, N, H, W, cin_pad, cout, *gb)
         ks_tail = (ksplit,) if ksplit > 1 else ()
         if bwd and ksplit == 1:
             emit("bbdm_winograd_output_f32", wm, self._wino_m, None, residual, res_ld, dest, dest.ld, flags, N, H, W, cout_y)
@@ -1375,6 +1451,7 @@ class _Plan:
             assert residual is None or residual.C == cout
             res_ld = residual.ld if residual is not None else 0
         H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+        h2 = getattr(pre, "h2", None) is not None
         wm = self._winograd_ok(mod, H, W, x.C, flags)
         if wm and upsample and self.m.upsample_phases and residual is None and flags == 0 and mod.weight.shape[1] == x.C:
             # conv3x3(nearest x2 (x)) = four phase filters on x (Cin -> 4 Cout): same GEMM work, the input transform and the GEMM's
@@ -1382,17 +1459,17 @@ class _Plan:
             wl = phase_filter_tile(self.N, x.H, x.W, x.C, 4 * cout, self.m.winograd,
                                    bool(self.m.gemm_bf3 and self.m.gemm_bf3p and self.m.winograd_small),
                                    self.m.upsample_f72 and not self.training)
-            if wl == 7 and self._use_bf3(7, x.H, x.W, x.C, 4 * cout) != "p":
+            if wl == 7 and self._use_bf3(7, x.H, x.W, x.C, 4 * cout, h2=h2) not in ("p", "h"):
                 wl = 6                            # (F(7x7, 2x2) exists on the pre-split planes only)
             if wl >= min(wm, 6):               # (m = 8 at the upsampled size does not beat the phase filters' 4x smaller input transform)
-                pw = self._packed(_PackedWinograd, mod.weight, mod.bias, x.C, wl, bf3=self._use_bf3(wl, x.H, x.W, x.C, 4 * cout),
+                pw = self._packed(_PackedWinograd, mod.weight, mod.bias, x.C, wl, bf3=self._use_bf3(wl, x.H, x.W, x.C, 4 * cout, h2=h2),
                                   phases=True)
                 self.convs.append(pw)
                 self._emit_winograd(x, x.C, pw, pre, False, x.H, x.W, None, 0, dest, 0)
                 return
         if wm:
             pw = self._packed(_PackedWinograd, mod.weight, mod.bias, x.C, wm, bf3=self._use_bf3(
-                wm, H, W, x.C, cout, keeps_V=self._keeps_V(wm, H, W, x.C, mod.weight.shape[1], cout, upsample, False)))
+                wm, H, W, x.C, cout, keeps_V=self._keeps_V(wm, H, W, x.C, mod.weight.shape[1], cout, upsample, False), h2=h2))
             self.convs.append(pw)
             self._emit_winograd(x, x.C, pw, pre, upsample, H, W, residual, res_ld, dest, flags)
             return
@@ -1479,6 +1556,8 @@ class _Plan:
             a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A", consumer=rb.in_layers[2], upsample=True)
         else:       # up / down blocks resample between the activation and the conv: explicit apply pass
             a, pre1 = self._gn_apply(x, rb.in_layers[0], None, silu=1, resample=rs, name="A"), None
+            if self._winograd_ok(rb.in_layers[2], a.H, a.W, a.C):
+                pre1 = _Pre(self.NO_PRE, h2=self._gn_bound(x, rb.in_layers[0], None))    # (pooled / copied values keep the bound)
         xr = x if (rs == 0 or fold_up) else self._gn_apply(x, None, None, 0, rs, name="XR")
         oh, ow = (2 * x.H, 2 * x.W) if fold_up else (a.H, a.W)
         h1 = self._tmp("H1", N, oh, ow, rb.out_channels)
@@ -2275,6 +2354,10 @@ class _Plan:
         self._bound_names = [str(name) for name, _ in self.ops]
         self._bound = [(getattr(lib, getattr(name, "entry", name)), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
                        for name, args in self.ops]
+        if self._h2_layers:       # csrc/groupnorm.hip: H2GnLayer {gamma, beta, film_off, C, zmax, gain}
+            import struct
+            raw = b"".join(struct.pack("QQiiff", g.data_ptr(), b.data_ptr(), fo, C, z, 1.0) for g, b, fo, C, z in self._h2_layers)
+            self._h2_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
 
     def _refresh_weights(self, stream):
         key = tuple(p.data_ptr() for p in self._params)
@@ -2324,6 +2407,10 @@ class _Plan:
             for r0 in range(0, N, 32):      # (<= 32 rows per call of the packed kernel)
                 call("bbdm_linear_packed_f32", self.emb.data_ptr() + 4 * r0 * ted, self.film_wp.data_ptr(), self.film_b.data_ptr(),
                      self.film.data_ptr() + 4 * r0 * self.film_total, min(32, N - r0), ted, self.film_total, 1, 0, stream)
+        if self._h2_layers:
+            # the bounds of every GroupNorm-fed tile GEMM on the fp16-pair planes, from gamma / beta / this step's FiLM vector
+            call("bbdm_h2_gn_bounds_f32", self._h2_table.data_ptr(), len(self._h2_layers), self.film.data_ptr() if self.film_total else None,
+                 self.film_total, N, self._h2_bounds.t.data_ptr(), stream)
 
     def _launch_forward(self, stream, prof=None):
         """Enqueue one forward (statistics reset, embedding path, the op list) on ``stream``."""

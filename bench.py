@@ -226,8 +226,8 @@ def cpu_baseline(workload, sd, budget_s=30.0, parity_inputs=None):
     warm = time.perf_counter() - t0
     if parity_inputs is not None:
         parity = _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
-        if alt is not None:
-            parity["winograd6"] = {k: v for k, v in _parity_record(alt[0], alt[1], a_ref, b_ref, i_par, path.kind).items() if k.startswith("rel_err")}
+        for name, (h_a, h_b) in (alt or {}).items():      # the same sample on the A/B plans ("winograd6", "bf16x3")
+            parity[name] = {k: v for k, v in _parity_record(h_a, h_b, a_ref, b_ref, i_par, path.kind).items() if k.startswith("rel_err")}
     n_timed = max(3, min(20, int((budget_s - warm) / max(warm, 1e-3))))
     med, ts = _time_cpu_steps(path, x_t, y, ctx, eps, n_timed)
     out = {"value": 1.0 / (med * batch), "unit": "steps/s", "cores": threads, "kind": path.kind,
@@ -268,8 +268,8 @@ def parity_only(workload, sd, parity_inputs):
     ctx = None if up["condition_key"] == "nocond" else y
     a_ref, b_ref = path.p_sample(x_t, y, ctx, i_par, eps)
     parity = _parity_record(g_a, g_b, a_ref, b_ref, i_par, path.kind)
-    if alt is not None:
-        parity["winograd6"] = {k: v for k, v in _parity_record(alt[0], alt[1], a_ref, b_ref, i_par, path.kind).items() if k.startswith("rel_err")}
+    for name, (h_a, h_b) in (alt or {}).items():
+        parity[name] = {k: v for k, v in _parity_record(h_a, h_b, a_ref, b_ref, i_par, path.kind).items() if k.startswith("rel_err")}
     return parity
 
 
@@ -423,6 +423,10 @@ def main():
             w6 = (line.get("parity") or {}).get("winograd6") or {}
             line["summary"][args.workload + "_winograd6"] = [round(line["winograd6_ms_per_step"], 3),
                                                              float(f"{max(w6.values()):.2g}") if w6 else None]
+        if line.get("bf16x3_ms_per_step"):           # the headline on round 5's six-term bf16x3 planes (UNetModel.gemm_h2 = False)
+            b3 = (line.get("parity") or {}).get("bf16x3") or {}
+            line["summary"][args.workload + "_bf16x3"] = [round(line["bf16x3_ms_per_step"], 3),
+                                                          float(f"{max(b3.values()):.2g}") if b3 else None]
         c4r = line if args.workload == "c4" else (line.get("workloads") or {}).get("c4") or {}
         if c4r.get("winograd6_ms_per_step"):         # the training micro-step on the m <= 6 tiles (UNetModel.winograd_train8 = 0)
             line["summary"]["c4_m6"] = round(c4r["winograd6_ms_per_step"], 3)
@@ -617,6 +621,27 @@ def run_workload(args, env):
             del model.denoise_fn._plans[k]
         torch.cuda.empty_cache()
 
+    # ... and on round 5's planes (UNetModel.gemm_h2 = False: every tile GEMM on the six-term bf16x3 split): the same 2 + 5 steps
+    bf16x3_ms = None
+    if args.workload in ("c2", "c3") and not training and world == 1 and not args.no_f32mfma and model.denoise_fn.gemm_h2:
+        model.denoise_fn.gemm_h2 = False
+        try:
+            for i in range(2):
+                state["img"] = step(i, state["img"])
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(5):
+                state["img"] = step(2 + i, state["img"])
+            e1.record()
+            torch.cuda.synchronize(dev)
+            bf16x3_ms = e0.elapsed_time(e1) / 5
+        finally:
+            model.denoise_fn.gemm_h2 = True
+        for k in list(model.denoise_fn._plans)[1:]:
+            del model.denoise_fn._plans[k]
+        torch.cuda.empty_cache()
+
     # c4: the same micro-steps with the training plan on the tiles it had before F(8x8, 3x3) got its gradient side
     # (UNetModel.winograd_train8 = 0: m <= 6 forward, data gradient and weight gradient): one accumulation cycle to build and warm the
     # second plan, then two cycles timed, outside the timed region
@@ -721,9 +746,22 @@ def run_workload(args, env):
     # the GEMMs run on conv_igemm_f32 (v_mfma_f32_32x32x2_f32, 157.3 TFLOP/s) together with the direct convolutions.
     all_ops = list(plan0.ops) + (list(plan0.bops) if training else [])
     entries = [getattr(nm, "entry", "") for nm, _ in all_ops if nm == "bbdm_winograd_gemm_f32"]
-    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") for e in entries), sum(e.endswith("bf3_f32") for e in entries)
-    use_bf3 = bf3p_ops + bf3_ops > 0
-    if use_bf3:
+    is_h2 = lambda e: "_h2p_" in e
+    h2_ops = sum(is_h2(e) for e in entries)
+    bf3p_ops, bf3_ops = sum(e.endswith("bf3p_f32") or "bf3p_splitk" in e for e in entries), sum(e.endswith("bf3_f32") for e in entries)
+    use_bf3 = h2_ops + bf3p_ops + bf3_ops > 0
+    # fp32-equivalent FLOPs of the tile GEMMs by the instruction they issue (round 6): the fp16-pair planes cost THREE 16-bit MFMA
+    # FLOPs per fp32-equivalent FLOP (csrc/h2_split.h), the bf16x3 planes six
+    h2_share = (sum(fl for (nm, _), fl in zip(all_ops, list(plan0.op_flops) + [0.0] * (len(all_ops) - len(plan0.op_flops)))
+                    if nm == "bbdm_winograd_gemm_f32" and is_h2(getattr(nm, "entry", ""))) /
+                max(1.0, sum(fl for (nm, _), fl in zip(plan0.ops, plan0.op_flops) if nm == "bbdm_winograd_gemm_f32"))) if not training else 0.0
+    terms = 3.0 if h2_ops > bf3p_ops + bf3_ops else 6.0
+    if use_bf3 and terms == 3.0:
+        dom, dom_name = wino, (f"gemm_bf3p_pipe_kernel<NP = 2> (v_mfma_f32_32x32x16_f16 x 3 terms on two fp16 planes per operand under a "
+                               f"provable power-of-two scale = one fp32-grade product, csrc/h2_split.h; {h2_ops} launches per pass, "
+                               f"{bf3p_ops + bf3_ops} on the bf16x3 planes)")
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0
+    elif use_bf3:
         # the tile GEMMs run on csrc/gemm_bf3p.hip (both operands pre-split by their producers, LDS-DMA + MFMA main loop) where the
         # input transform writes the planes, else on csrc/gemm_bf3.hip (fp32 V split while staged): same arithmetic, bit for bit
         kname = ("gemm_bf3p_pipe_kernel" if bf3p_ops >= bf3_ops else "gemm_bf3_kernel")
@@ -747,9 +785,10 @@ def run_workload(args, env):
     attn_mode = _bl.get_option("attn_bf3")
     attn_ch = next((oa[8] for nm, oa in plan0.ops if nm == "bbdm_attention_f32"), 64)
     attn_bf3_share = 0.0 if attn_mode == 0 else (1.0 if (attn_mode == 1 and attn_ch in (32, 64)) else 0.5)
-    bf3_flops = ((wino[2] if use_bf3 else 0.0) + c1x1[2] + attn_bf3_share * attn[2]) / max(1, args.steps)
-    t_at_peak = (executed_flops_per_step - bf3_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
-        bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12)
+    wino_h2 = (wino[2] * h2_share if use_bf3 else 0.0) / max(1, args.steps)
+    bf3_flops = ((wino[2] * (1.0 - h2_share) if use_bf3 else 0.0) + c1x1[2] + attn_bf3_share * attn[2]) / max(1, args.steps)
+    t_at_peak = (executed_flops_per_step - bf3_flops - wino_h2) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
+        bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12) + wino_h2 / (PEAK_BF16_MFMA_TFLOPS / 3.0 * 1e12)
     # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
     # rocprofv3 PMC passes of this same command (profiles/*_pmc_<workload>_traffic.json), per launch, or null.
     traffic = None
@@ -802,8 +841,9 @@ def run_workload(args, env):
             wm, gN, gH, gW, gci, gco = oa[0], *oa[4:9]
             from bbdm_amd.unet import wino_planes, wino_tiles
             P, T = wino_planes(wm), wino_tiles(wm, gN, gH, gW)
-            a_bytes = 6.0 if getattr(nm, "entry", "").endswith("bf3p_f32") else 4.0     # V as three bf16 planes / fp32
-            alg_bytes += P * T * (a_bytes * gci + 4.0 * gco) + (6.0 if use_bf3 else 4.0) * P * gci * gco
+            ent = getattr(nm, "entry", "")
+            a_bytes = 6.0 if (ent.endswith("bf3p_f32") or "bf3p_splitk" in ent) else 4.0     # V as three bf16 planes / two fp16 planes or fp32
+            alg_bytes += P * T * (a_bytes * gci + 4.0 * gco) + (4.0 if (is_h2(ent) or not use_bf3) else 6.0) * P * gci * gco
             alg_n += 1
         elif nm == "bbdm_conv2d_nhwc_f32" and not use_bf3:
             gN, gH, gW, gci, gco, gks = oa[15:21]
@@ -823,7 +863,10 @@ def run_workload(args, env):
                        f"denoise-UNet sampling steps/sec ({args.workload})"),
             "value": steps_per_s_job, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (tile GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA terms, fp32 accumulate -- fp32-accurate; "
+            "dtype": ("f32 (tile GEMMs: fp32 operands as two fp16 planes under a provable power-of-two scale, 3 fp16-MFMA terms, fp32 "
+                      "accumulate -- measured against fp64 MORE accurate than the six-term bf16x3 split and than the f32 MFMA; wide 1x1 "
+                      "layers + attention: bf16x3; all other kernels native fp32)") if (use_bf3 and terms == 3.0) else
+                     ("f32 (tile GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA terms, fp32 accumulate -- fp32-accurate; "
                       "all other kernels native fp32)") if use_bf3 else "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
             "config": {"workload": desc, "batch_per_gpu": batch, "image_size": size, "unet_params_M": nparams / 1e6,
                        "schedule_steps": nsteps_table, "parallelism": f"dp{world} (independent image-pair shards)"},
@@ -840,14 +883,16 @@ def run_workload(args, env):
             "tflops_executed": executed_flops_per_step / (ms_per_step * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "peak_note": ("fp32-equivalent bound = dense bf16 MFMA peak 2500 / 6 (six bf16 MFMA terms per fp32 "
-                                       "product); executed bf16 rate = 6 x achieved") if use_bf3 else
+                         "peak_note": (f"fp32-equivalent bound = dense 16-bit MFMA peak 2500 / {terms:.0f} ({terms:.0f} MFMA terms per "
+                                       f"fp32-grade product); executed 16-bit rate = {terms:.0f} x achieved") if use_bf3 else
                                       "fp32-input MFMA peak (MI355X_MICROARCH.md)",
-                         "executed_bf16_tflops": 6.0 * achieved if use_bf3 else None,
+                         "executed_bf16_tflops": terms * achieved if use_bf3 else None,
+                         "h2_share_of_tile_gemm_flops": h2_share if use_bf3 else None,
                          "frac_step": t_at_peak / (ms_per_step * 1e-3),
                          "frac_step_note": "whole step: time the MFMA work of every kernel would take at the matrix peak of the "
-                                           "datatype it issues (bf16 / 6 for the tile GEMMs, the wide 1x1 layers and the attention "
-                                           "forward; f32 MFMA for the rest) / step time",
+                                           "datatype it issues (2500 / 3 for tile GEMMs on the fp16-pair planes, 2500 / 6 for those on "
+                                           "the bf16x3 planes, the wide 1x1 layers and the attention forward; f32 MFMA for the rest) / "
+                                           "step time",
                          "attention_bf3_share": attn_bf3_share,
                          "traffic": traffic, "traffic_step": traffic_step, "mfma_util": mfma_util,
                          "launches_per_step": conv_launches / max(1, args.steps),
@@ -863,6 +908,7 @@ def run_workload(args, env):
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in sorted(by.items())},
             "f32mfma_ms_per_step": f32mfma_ms,
             "winograd6_ms_per_step": winograd6_ms,
+            "bf16x3_ms_per_step": bf16x3_ms,
             "training": training_info,
         }
         if args.workload in FIRST_STAGE and not args.no_pipeline:
@@ -881,17 +927,21 @@ def run_workload(args, env):
             finally:
                 torch.randn_like = orig_rl
             torch.cuda.synchronize(dev)
-            alt = None
-            if winograd6_ms is not None:                 # the same sample on the F(6x6, 3x3) plan
-                model.denoise_fn.winograd = 6
+            alt = {}
+            for ab_name, ab_attr, ab_val, ab_on in (("winograd6", "winograd", 6, winograd6_ms is not None),
+                                                    ("bf16x3", "gemm_h2", False, bf16x3_ms is not None)):
+                if not ab_on:
+                    continue
+                keep = getattr(model.denoise_fn, ab_attr)          # the same sample on the A/B plan
+                setattr(model.denoise_fn, ab_attr, ab_val)
                 torch.randn_like = lambda t, **k: eps
                 try:
                     h_a, h_b = model.p_sample(x_t, y, ctx, i_par, clip_denoised=False)
                 finally:
                     torch.randn_like = orig_rl
-                    model.denoise_fn.winograd = 8
+                    setattr(model.denoise_fn, ab_attr, keep)
                 torch.cuda.synchronize(dev)
-                alt = (h_a[0].cpu(), h_b[0].cpu())
+                alt[ab_name] = (h_a[0].cpu(), h_b[0].cpu())
                 for k in list(model.denoise_fn._plans)[1:]:
                     del model.denoise_fn._plans[k]
             par_in = (x_t, y, i_par, eps, g_a[0].cpu(), g_b[0].cpu(), alt)

@@ -482,6 +482,50 @@ int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bi
                                           int ldo, int flags, int N, int H, int W, int Cout, bbdm_stats_t* stats0, int cpg0, int coff0,
                                           bbdm_stats_t* stats1, int cpg1, int coff1, int splits, void* stream);
 
+/* ---- the same plane GEMM on TWO fp16 planes per operand ("h2"; round 6, ABI 24: csrc/h2_split.h, gemm_bf3p.hip, winograd.hip) ------- */
+/* Replaces, for the inference forward of the Winograd layers whose input is GroupNorm -> [FiLM] -> SiLU of a tensor (every 3x3
+ * convolution inside a ResBlock: openaimodel.py:205-207,229-233), the six-term bf16x3 product by x 2^e = h1 + h2 (fp16, round to
+ * nearest) and the three terms h1 k1 + h1 k2 + h2 k1 on v_mfma_f32_32x32x16_f16: half the matrix instructions, 4 B per operand element
+ * instead of 6, and HALF the roundings of the fp32 accumulator -- which, not the 2^-23 of the operands, is what bounds the accuracy of an
+ * fp32 GEMM on the matrix core (against fp64 the h2 product is more accurate than bf16x3 AND than v_mfma_f32_32x32x2_f32:
+ * tests/test_kernels_gpu.py::test_gemm_h2p_accuracy).  fp16 has 5 exponent bits, so every operand carries a BOUND -- a device float
+ * >= max |x| over the whole operand -- from which producer and consumer derive the same power-of-two scale (h2_exp_of_bound): the scaled
+ * bound lies in [2^14, 2^15), nothing can reach fp16's 65504.  A bound is measured (bbdm_absmax_f32: weights) or proved
+ * (bbdm_h2_gn_bounds_f32: a z-score over n values is at most sqrt(n - 1)), never guessed.
+ *   bbdm_gemm_h2p_a_bytes / _b_bytes   : plane buffer sizes (4 B per element; T to 256 rows, Cout to 128 columns)
+ *   bbdm_absmax_f32                    : *bound = max(*bound, max |x[i]|)  (order-independent; the caller zeroes *bound)
+ *   bbdm_gemm_h2p_pack_b_f32           : fp32 packed [batch][CinPad/16][CoutPad128][16] -> B planes scaled by `bound`
+ *   bbdm_gemm_h2p_split_rows_f32       : fp32 rows -> A planes scaled by `bound`
+ *   bbdm_gemm_h2p_f32 / _splitk_f32    : the GEMMs of bbdm_gemm_bf3p_f32 / _splitk_f32 (same shapes, tiles and split rule)
+ *   bbdm_h2_gn_bounds_f32              : bounds[l] for every GroupNorm-fed layer l of a plan in ONE launch; `table`: device array of
+ *                                        {const float* gamma, *beta; int film_off, C; float zmax, gain} (32 B each)
+ *   bbdm_winograd_input_gain           : max |B^T d B| / max |d| of tile m
+ *   bbdm_winograd_input_h2p_f32 / _gn_f32, bbdm_winograd_gemm_h2p_f32 / _splitk_f32 : stages (1) and (2) of the Winograd path on
+ *                                        these planes: the arguments of the bf3p forms, then vbound >= max |d| of the TRANSFORMED
+ *                                        tensor (x after the fused producer; both stages apply the gain themselves) and, for the
+ *                                        GEMMs, ubound >= max |U| (bbdm_absmax_f32 of bbdm_winograd_pack_weight_f32's buffer) */
+size_t bbdm_gemm_h2p_a_bytes(int batch, long long T, int CinPad);
+size_t bbdm_gemm_h2p_b_bytes(int batch, int CinPad, int Cout);
+int bbdm_absmax_f32(const float* x, long long n, float* bound, void* stream);
+int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, int batch, int CinPad, int Cout, void* stream);
+int bbdm_gemm_h2p_split_rows_f32(const float* x, int ldx, void* a_planes, const float* bound, int batch, long long T, int CinPad,
+                                 void* stream);
+int bbdm_gemm_h2p_f32(const void* a_planes, const void* b_planes, const float* bound_a, const float* bound_b, const float* bias,
+                      const float* residual, int ldr, float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
+int bbdm_gemm_h2p_splitk_f32(const void* a_planes, const void* b_planes, const float* bound_a, const float* bound_b, float* M, int ldo,
+                             int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream);
+int bbdm_h2_gn_bounds_f32(const void* table, int nlayers, const float* film, int film_ld, int N, float* bounds, void* stream);
+float bbdm_winograd_input_gain(int m);
+int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
+                                int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* vbound, void* stream);
+int bbdm_winograd_input_h2p_gn_f32(int m, const float* x, int ldx, void* Vp, const bbdm_stats_t* stats, const void* unused, int C,
+                                   int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma, const float* beta,
+                                   const float* film, int film_ld, int HW, int G, float eps, const float* vbound, void* stream);
+int bbdm_winograd_gemm_h2p_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad, int Cout,
+                               const float* vbound, const float* ubound, void* stream);
+int bbdm_winograd_gemm_h2p_splitk_f32(int m, const void* Vp, const void* b_planes, float* M, int N, int H, int W, int CinPad, int Cout,
+                                      int splits, const float* vbound, const float* ubound, void* stream);
+
 /* ---- Winograd-domain weight gradient on the same bf16x3 GEMM (training; csrc/gemm_bf3p.hip, csrc/winograd.hip) --------- */
 /* Replaces bbdm_gemm_tn_batched_f32 (f32 MFMA) in dW = G^T [ sum_tiles V_xi^T dM_xi ] G (autograd of nn.Conv2d 3x3 at
  * openaimodel.py:207,233; BaseRunner.py:412) where both operands come as bf16 planes written TRANSPOSED by their producers -- rows =

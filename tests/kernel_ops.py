@@ -618,3 +618,80 @@ def winograd_weight_planes(w: torch.Tensor, m: int, in_pad: int, dgrad: bool = F
         _lib.call("bbdm_winograd_pack_weight_f32", m, w.data_ptr(), f32.data_ptr(), cout, cin, in_pad, 1 if dgrad else 0, _st(w))
         _lib.call("bbdm_gemm_bf3p_pack_b_f32", f32.data_ptr(), planes.data_ptr(), (m + 2) ** 2, in_pad, out_ch, _st(w))
     return planes
+
+
+# ---- the fp16-pair ("h2") planes of csrc/h2_split.h (round 6) -------------------------------------------------------------------------
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """A device float holding max |x| (bbdm_absmax_f32)."""
+    _chk(x)
+    b = torch.zeros(1, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_absmax_f32", x.data_ptr(), x.numel(), b.data_ptr(), _st(x))
+    return b
+
+
+def gemm_h2p(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: int, cout: int,
+             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, bound_a: Optional[torch.Tensor] = None,
+             bound_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """:func:`gemm_bf3p` on two fp16 planes per operand: V [batch, T, cin_pad] fp32 is scaled by its bound (default: its own max) and split
+    by bbdm_gemm_h2p_split_rows_f32, the weights by bbdm_gemm_h2p_pack_b_f32."""
+    _chk(V, w_packed_f32, bias, residual)
+    T = V.shape[1]
+    Tp = (T + 255) // 256 * 256
+    lib = _lib.load()
+    ba = absmax(V) if bound_a is None else bound_a
+    bb = absmax(w_packed_f32) if bound_b is None else bound_b
+    ap = torch.empty(lib.bbdm_gemm_h2p_a_bytes(batch, T, cin_pad), dtype=torch.uint8, device=V.device)
+    bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(batch, cin_pad, cout), dtype=torch.uint8, device=V.device)
+    _lib.call("bbdm_gemm_h2p_split_rows_f32", V.data_ptr(), V.shape[2], ap.data_ptr(), ba.data_ptr(), batch, T, cin_pad, _st(V))
+    _lib.call("bbdm_gemm_h2p_pack_b_f32", w_packed_f32.data_ptr(), bp.data_ptr(), bb.data_ptr(), batch, cin_pad, cout, _st(V))
+    M = torch.empty(batch, Tp, cout, dtype=torch.float32, device=V.device)
+    if residual is not None:
+        M[:, :T] = residual
+    _lib.call("bbdm_gemm_h2p_f32", ap.data_ptr(), bp.data_ptr(), ba.data_ptr(), bb.data_ptr(), None if bias is None else bias.data_ptr(),
+              None if residual is None else M.data_ptr(), cout, M.data_ptr(), cout, batch, Tp, cin_pad, cout, _st(V))
+    return M[:, :T]
+
+
+def conv3x3_winograd_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m: int, mode: str = "bf3",
+                            pre_scale: Optional[torch.Tensor] = None, pre_bias: Optional[torch.Tensor] = None, pre_silu: bool = False,
+                            in_bound: Optional[float] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 convolution as the product's inference plans stage it -- input transform writing planes, tile GEMMs on the pipe kernel, output
+    transform -- with ``mode`` "bf3" (three bf16 planes) or "h2" (two fp16 planes; ``in_bound`` >= max |input of the transform|, default
+    the measured maximum of x, for callers without a fused producer).  x [N, H, W, Cin] NHWC, w OIHW -> [N, H, W, Cout]."""
+    _chk(x, w, bias, pre_scale, pre_bias, residual)
+    lib = _lib.load()
+    N, H, W, cin = x.shape
+    cout = w.shape[0]
+    planes = (m + 2) ** 2
+    tiles = lib.bbdm_winograd_tiles(m, N, H, W)
+    st = _st(x)
+    pf = torch.empty(lib.bbdm_winograd_packed_floats(m, cout, cin), dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_winograd_pack_weight_f32", m, w.data_ptr(), pf.data_ptr(), cout, cin, cin, 0, st)
+    Tp = (tiles + 255) // 256 * 256
+    M = torch.empty(planes * Tp * cout, dtype=torch.float32, device=x.device)
+    pre = (None if pre_scale is None else pre_scale.data_ptr(), None if pre_bias is None else pre_bias.data_ptr(),
+           0 if pre_scale is None else pre_scale.shape[-1], 1 if pre_silu else 0)
+    if mode == "h2":
+        ub = absmax(pf)
+        bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(planes, cin, cout), dtype=torch.uint8, device=x.device)
+        _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), ub.data_ptr(), planes, cin, cout, st)
+        if in_bound is None:
+            assert pre_scale is None, "a fused producer needs the caller's bound"
+            vb = absmax(x)
+        else:
+            vb = torch.full((1,), float(in_bound), dtype=torch.float32, device=x.device)
+        Vp = torch.empty(lib.bbdm_gemm_h2p_a_bytes(planes, tiles, cin), dtype=torch.uint8, device=x.device)
+        _lib.call("bbdm_winograd_input_h2p_f32", m, x.data_ptr(), cin, Vp.data_ptr(), *pre, 0, N, H, W, cin, vb.data_ptr(), st)
+        _lib.call("bbdm_winograd_gemm_h2p_f32", m, Vp.data_ptr(), bp.data_ptr(), M.data_ptr(), N, H, W, cin, cout, vb.data_ptr(),
+                  ub.data_ptr(), st)
+    else:
+        bp = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(planes, cin, cout), dtype=torch.uint8, device=x.device)
+        _lib.call("bbdm_gemm_bf3p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), planes, cin, cout, st)
+        Vp = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(planes, tiles, cin), dtype=torch.uint8, device=x.device)
+        _lib.call("bbdm_winograd_input_bf3p_f32", m, x.data_ptr(), cin, Vp.data_ptr(), *pre, 0, N, H, W, cin, st)
+        _lib.call("bbdm_winograd_gemm_bf3p_f32", m, Vp.data_ptr(), bp.data_ptr(), M.data_ptr(), N, H, W, cin, cout, st)
+    out = torch.empty(N, H, W, cout, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_winograd_output_f32", m, M.data_ptr(), None if bias is None else bias.data_ptr(),
+              None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[-1], out.data_ptr(), cout, 0,
+              N, H, W, cout, st)
+    return out

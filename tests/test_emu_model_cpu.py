@@ -135,6 +135,7 @@ def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
     sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 43)
     m.load_state_dict(sd, strict=True)
     m.hip_graph = False
+    m.gemm_h2 = False              # (the fp16-pair planes are a different product: test_sampling_plan_on_the_fp16_pair_planes)
     m.eval()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(16, 4, 16, 16, generator=g)
@@ -151,6 +152,45 @@ def test_sampling_plan_on_the_presplit_gemm_is_bit_equal(monkeypatch):
     assert torch.equal(outs[True], outs[False])
     ref = O.unet_forward(sd, O.UNetSpec(**up), x, t, None)
     assert parity_err(outs[True], ref) < M.STEP_TOL
+
+
+def test_sampling_plan_on_the_fp16_pair_planes(monkeypatch):
+    """Inference plan with the GroupNorm-fed Winograd layers on two fp16 planes per operand (csrc/h2_split.h; UNetModel.gemm_h2, the
+    default): every ResBlock convolution takes the h2 entry points with a bound slot of its own, the bounds launch fills them from
+    gamma / beta / the FiLM vector, and the step stays within the tolerance of the oracle -- also when the weights are 50x larger than the
+    initialisation (the scale follows the bound: nothing overflows fp16) and when an input pixel is a 1000x outlier."""
+    import bbdm_amd
+    import bbdm_oracle as O
+    from fixture_weights import synth_weights
+    monkeypatch.setattr(bbdm_amd.unet, "winograd_tile",
+                        lambda N, H, W, cin, cout, max_m=6, small=True, allow8=False: 4 if (max_m >= 4 and cin >= 64 and cout >= 64 and H % 4 == 0) else 0)
+    up = dict(image_size=16, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=(),
+              channel_mult=(1, 2), conv_resample=True, dims=2, num_heads=2, num_head_channels=-1, use_scale_shift_norm=True,
+              resblock_updown=True, use_spatial_transformer=False, context_dim=None, condition_key="nocond")
+    m = bbdm_amd.unet.UNetModel(**up)
+    sd = synth_weights([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 44)
+    m.hip_graph = False
+    m.eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(16, 4, 16, 16, generator=g)
+    t = torch.arange(16) * 7 + 1
+    for case in ("plain", "gain50", "outlier"):
+        sd_c = {k: (v * 50 if case == "gain50" and (".in_layers.2." in k or ".out_layers.3." in k or "norm" in k or ".in_layers.0." in k or ".out_layers.0." in k) and k.endswith("weight") else v) for k, v in sd.items()}
+        m.load_state_dict(sd_c, strict=True)
+        xc = x.clone()
+        if case == "outlier":
+            xc[:, :, 3, 5] *= 1000.0
+        with torch.no_grad():
+            out = m(xc, timesteps=t, context=None).clone()
+        plan = m._plan_for(xc, False)
+        entries = [getattr(n, "entry", str(n)) for n, _ in plan.ops]
+        n_h2 = sum(e in ("bbdm_winograd_gemm_h2p_f32", "bbdm_winograd_gemm_h2p_splitk_f32") for e in entries)
+        assert n_h2 >= 6 and n_h2 == len([1 for e in entries if e.startswith("bbdm_winograd_input_h2p")]) and len(plan._h2_layers) >= n_h2
+        bounds = plan._h2_bounds.t
+        assert bool(torch.isfinite(bounds).all()) and float(bounds[:len(plan._h2_layers)].min()) > 0
+        assert bool(torch.isfinite(out).all())
+        ref = O.unet_forward(sd_c, O.UNetSpec(**up), xc, t, None)
+        assert parity_err(out, ref) < M.STEP_TOL, (case, parity_err(out, ref))
 
 
 def test_upsampling_resblock_resamples_inside_the_transforms(monkeypatch):

@@ -113,7 +113,7 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         # m = 7 = F(7x7, 2x2): only the phase filters of an up-sampling conv, inference, on the pre-split planes, whole 128-channel
         # blocks per phase, and only where the coarser tile grid still saves GEMM work
         assert wm != 7 or (phases and not training and (g[8] // 4) % 128 == 0 and cin % 16 == 0 and
-                           "bf3p" in getattr(ops[k + 1][0], "entry", "") and
+                           ("bf3p" in getattr(ops[k + 1][0], "entry", "") or "h2p" in getattr(ops[k + 1][0], "entry", "")) and
                            unet.wino_tiles(7, N, H, W) <= 0.9 * unet.wino_tiles(6, N, H, W))
         assert tuple(g[4:8]) == (N, H, W, cin) and tuple(o[8:11]) == (N, H, W) and (4 if phases else 1) * o[11] == g[8]
         cout = g[8]
@@ -130,7 +130,20 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert tiles % 256 == 0 and tiles >= unet.wino_tiles(wm, N, H, W)
         assert plan._wino_v.t.numel() >= P * tiles * cin and plan._wino_m.t.numel() >= P * tiles * cout
         entry = getattr(ops[k + 1][0], "entry", "")
-        if "bf3p" in entry:                     # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
+        if "h2p" in entry:                      # two fp16 planes per operand under a bound (csrc/h2_split.h): inference only, 4 B per element
+            in_entry = getattr(ops[k][0], "entry", "")
+            assert not training and m.gemm_h2 and in_entry in ("bbdm_winograd_input_h2p_f32", "bbdm_winograd_input_h2p_gn_f32")
+            vb = i[-1]                          # the bound of the transformed tensor: a slot of the plan, the same one in both launches
+            assert isinstance(vb, unet._Plan._H2Ref) and 0 <= vb.k < len(plan._h2_layers) and g[-2] is vb
+            gam, bet, fo, C, z = plan._h2_layers[vb.k]
+            assert C == cin and z >= 1.0 and gam.numel() == cin and (fo == -1 or 0 <= fo <= plan.film_total - 2 * cin)
+            assert g[-1].t.numel() == 1 and g[-1].t.dtype == torch.float32          # max |U|, a device float owned by the packed weights
+            if in_entry.endswith("_gn_f32"):
+                assert tiles <= m.gn_in_transform and i[5] is None and i[6] == cin and len(i) == 21
+            assert 4 * plan._wino_v.t.numel() >= lib.bbdm_gemm_h2p_a_bytes(P, tiles, cin) and cin % 16 == 0
+            assert g[2].t.dtype == torch.uint8 and g[2].t.numel() == lib.bbdm_gemm_h2p_b_bytes(P, cin, cout)
+            assert lib.bbdm_gemm_bf3p_supported(tiles, cin, cout)
+        elif "bf3p" in entry:                   # V pre-split by the input transform (csrc/gemm_bf3p.hip): both ops, 6 B per element
             in_entry = getattr(ops[k][0], "entry", "")
             assert in_entry in ("bbdm_winograd_input_bf3p_f32", "bbdm_winograd_input_bf3p_tr_f32", "bbdm_winograd_input_bf3p_gn_f32")
             if in_entry.endswith("_gn_f32"):        # small inference layer: the transform forms the GroupNorm coefficients itself
@@ -155,12 +168,12 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         assert (unet.phase_filter_tile(N, H, W, cin, cout, m.winograd, small) if phases else
                 unet.winograd_tile(N, H, W, cin, cout, m.winograd, small=small, allow8=plan._allow8(1 if k >= len(plan.ops) else 2))) == wm
         if entry.endswith("splitk_f32"):        # small layer: split-K partials, added by the output transform of the same count
-            ks = g[-1]
+            ks = g[9]
             assert ks == lib.bbdm_winograd_gemm_bf3p_splits(wm, N, H, W, cin, cout) > 1
             assert getattr(ops[k + 2][0], "entry", "") == "bbdm_winograd_output_splitk_stats_f32" and ops[k + 2][1][-1] == ks
             assert plan._wino_m.t.numel() >= ks * (wm + 2) ** 2 * tiles * cout
     fused_gn = sum(1 for n, a in ops if n == "bbdm_winograd_input_f32" and a[4] is not None)
-    folded = sum(1 for n, a in ops if getattr(n, "entry", "") == "bbdm_winograd_input_bf3p_gn_f32")
+    folded = sum(1 for n, a in ops if getattr(n, "entry", "") in ("bbdm_winograd_input_bf3p_gn_f32", "bbdm_winograd_input_h2p_gn_f32"))
     # every fused GroupNorm has its coefficients from exactly one place: a bbdm_groupnorm_coeffs_f32 launch or its consumer's transform
     assert names["bbdm_groupnorm_coeffs_f32"] + folded >= fused_gn and (training or folded > 0 or workload in ("c2", "c3"))
     if (workload, batch, training) == ("c5", 32, False):
