@@ -156,9 +156,27 @@ def test_attention_presplit_form_is_bit_equal(N, T, heads, ch, new_order):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,pre,up,res,f32v", [(1, 13, 11, 32, 128, 1, 0, 1, 0), (1, 8, 16, 32, 128, 1, 1, 2, 0),
-                                                             (1, 9, 8, 32, 128, 0, 0, 0, 1)])
+                                                             (1, 9, 8, 32, 128, 0, 0, 0, 1), (1, 13, 11, 32, 128, 1, 0, 1, 2),
+                                                             (1, 8, 16, 32, 128, 1, 1, 2, 2)])
 def test_winograd_f8_forward(N, H, W, Cin, Cout, pre, up, res, f32v):
     K.test_winograd_f8_forward(CPU, N, H, W, Cin, Cout, pre, up, res, f32v)
+
+
+# ---- the fp16-pair planes (csrc/h2_split.h) ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("batch,T,Cin,Cout,extra,decades", [(2, 256, 48, 72, 0, 3), (1, 300, 32, 132, 2, 3), (9, 300, 16, 72, 1, 6),
+                                                            (12, 512, 16, 132, 2, 0)])
+def test_gemm_h2p_shapes_and_dynamic_range(batch, T, Cin, Cout, extra, decades):
+    K.test_gemm_h2p_shapes_and_dynamic_range(CPU, batch, T, Cin, Cout, extra, decades)
+
+
+def test_gemm_h2p_bound_is_respected():
+    K.test_gemm_h2p_bound_is_respected(CPU)
+
+
+@pytest.mark.parametrize("m,up,silu,film,N,H,W,C", [(2, 0, 1, True, 3, 4, 4, 64), (4, 1, 1, False, 2, 16, 8, 64), (6, 0, 0, True, 1, 14, 8, 64),
+                                                    (8, 0, 1, True, 1, 16, 8, 64)])
+def test_h2_bounds_and_planes_of_a_groupnorm_fed_layer(m, up, silu, film, N, H, W, C):
+    K.test_h2_bounds_and_planes_of_a_groupnorm_fed_layer(CPU, m, up, silu, film, N, H, W, C)
 
 
 @pytest.mark.parametrize("batch,T,Cin,Cout,extra", [(12, 512, 16, 132, 2), (9, 300, 16, 72, 1), (10, 256, 16, 40, 0), (11, 256, 16, 40, 0)])
