@@ -69,6 +69,18 @@ class _UNetSeg(torch.autograd.Function):
         return (None, None, None, dx, None, dctx, dtoken, *grads)
 
 
+def _observed(q) -> bool:
+    """Does anything watch gradients arrive at parameter ``q``?  Tensor hooks (``register_hook``), post-accumulate-grad hooks
+    (``register_post_accumulate_grad_hook``), and hooks registered on the parameter's AccumulateGrad node itself."""
+    if q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None):
+        return True
+    try:
+        node = q.view_as(q).grad_fn.next_functions[0][0]         # the AccumulateGrad node of q (created on demand, then cached)
+    except Exception:
+        return True
+    return bool(getattr(node, "_hooks", None) or getattr(node, "pre_hooks", lambda: {})())
+
+
 def _accumulate_in_place(plan, params, needed) -> bool:
     """Gradient accumulation without autograd's per-parameter adds (UNetModel.grad_in_place, set by dist_utils.accumulation_sync).
 
@@ -76,8 +88,9 @@ def _accumulate_in_place(plan, params, needed) -> bool:
     (autograd adopts the views :meth:`_Plan.grad_view` hands out), at the parameter's own offset; this micro-step's gradients lie at
     the same offsets of the OTHER flat buffer.  When that holds for every parameter of the segment, the segment's gradients are added
     with one ``add_`` per contiguous run of offsets (a handful per segment) and autograd receives None for them -- 248 ``AccumulateGrad``
-    launches per micro-step become ~10.  Anything else (first micro-step, a foreign ``.grad``, a parameter with tensor hooks) returns
-    False and the caller hands the views to autograd as before."""
+    launches per micro-step become ~10.  Anything else (first micro-step, a foreign ``.grad``, a parameter that ANYTHING observes: tensor
+    hooks, post-accumulate-grad hooks -- optimizer-in-backward, FSDP2 --, hooks on its AccumulateGrad node -- Horovod / apex style
+    reducers) returns False and the caller hands the views to autograd as before: returning None would silently skip those observers."""
     new = plan._flat_grad
     runs = []
     base = None
@@ -85,7 +98,7 @@ def _accumulate_in_place(plan, params, needed) -> bool:
         if not need:
             return False
         g = q.grad
-        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != q.shape or q._backward_hooks:
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != q.shape or _observed(q):
             return False
         off = plan.grad_off[id(q)]
         b = g.data_ptr() - 4 * off

@@ -103,9 +103,16 @@ __device__ __forceinline__ unsigned lds_address(void* p) { return (unsigned)(uin
 // fragment set around each of them (108 v_mov_b64 per iteration) -- hence frag_t and the unconditional reads below.
 // NP = planes per operand (round 6): 3 = the bf16x3 split, six terms; 2 = the fp16 pair of h2_split.h, three terms on
 // v_mfma_f32_32x32x16_f16 and the accumulators re-scaled by 2^-(eA + eB) in the epilogue.  Same layout with NP units per chunk.
-template <int WM, int WN, bool RES, int NS = 2, int NP = 3>
+// R4 (round 6, with NP = 2): a ring of FOUR chunk slots and TWO chunks per barrier.  With three terms instead of six a chunk is 12 MFMAs
+// per wave, so one wait + barrier per chunk weighed twice as much as on the bf16x3 planes (the first h2 build ran its MFMAs at 0.37 -
+// 0.45 of the peak against the bf16x3 kernel's 0.47 - 0.54).  Here an iteration owns chunks c, c + 1: it enters with the fragments of c in
+// registers, reads those of c + 1 (landed and visible since the last barrier: no barrier in between) under the terms of c and those
+// of c + 2 under the terms of c + 1, and issues at its top the copies of chunks c + 3 / c + 4 into the slots of c - 1 / c, which every wave
+// has finished reading before the last barrier.  A chunk's copies get a whole iteration (24 MFMAs per wave) to land, as on bf16x3.
+template <int WM, int WN, bool RES, int NS = 2, int NP = 3, bool R4 = false>
 __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) gemm_bf3p_pipe_kernel(const Bf3pArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][STAGE]
+    static_assert(!R4 || (NP == 2 && NS == 2), "the four-slot ring is the fp16-pair kernel's");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][STAGE]  (R4: [4][STAGE])
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
     constexpr int NA = WM * 2 * NP, NB = WN * 2 * NP, NU = NA + NB, STAGE = NU * UNIT;
     constexpr int KMAX = (NU + NW - 1) / NW;
@@ -192,10 +199,16 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
 
     int L = (int)blockIdx.x;
     if (!setup(L)) return;
+    // fp16-pair planes: 2^-(eA + eB), read once at the top (a wave-uniform value in an SGPR; before any hand-written LDS read is in flight)
+    float descale = 1.f;
+    if constexpr (NP == 2) {
+        const float d = h2_pow2(-(h2_exp_of_bound(*a.hA * a.gA) + h2_exp_of_bound(*a.hB)));
+        descale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(d)));
+    }
     float bv[2];
     load_bias(bv);
 #pragma unroll
-    for (int k = 0; k < NS; ++k)
+    for (int k = 0; k < (R4 ? 3 : NS); ++k)
         if (k < n) issue(k, smem + k * STAGE);
 
     // (held as 4 x 32-bit: a <8 x bf16> value that lives across the has_next branches is legalised ELEMENT-wise by the compiler --
@@ -251,6 +264,49 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         }
         BF3P_ALL_LANDED();
         asm volatile("s_barrier" ::: "memory");                                // everybody holds chunk 0: stage 0 may be overwritten
+        if constexpr (R4) {
+            for (int chunk = 0; chunk < n; chunk += 2) {
+                const bool has1 = chunk + 1 < n, has2 = chunk + 2 < n;
+                {   // ---- chunk: its fragments are in registers; read chunk + 1 (landed since the last barrier) ----------------------
+                    const unsigned nxt = lds0 + ((chunk + 1) & 3) * STAGE;
+                    const unsigned sa = nxt + aoff, sb = nxt + boff;
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (chunk + 3 < n) issue(chunk + 3, smem + ((chunk + 3) & 3) * STAGE);     // the slot of chunk - 1
+                    if (chunk + 4 < n) issue(chunk + 4, smem + (chunk & 3) * STAGE);           // the slot of chunk (in registers)
+                    if (has1) BF3P_READ_B(1, sb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has1) BF3P_READ_A(1, sa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has1) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+                }
+                if (has1) {   // ---- chunk + 1; read chunk + 2 -----------------------------------------------------------------------
+                    BF3P_READS_RETURNED();
+                    const unsigned nxt = lds0 + ((chunk + 2) & 3) * STAGE;
+                    const unsigned sa = nxt + aoff, sb = nxt + boff;
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has2) BF3P_READ_B(1, sb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has2) BF3P_READ_A(1, sa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has2) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+                }
+                wait_vmcnt<0>();
+                BF3P_READS_RETURNED();
+                asm volatile("s_barrier" ::: "memory");
+            }
+        } else
         for (int chunk = 0; chunk < n; ++chunk) {
             // (NS > 2: the reads are unconditional -- in the last iteration they fetch a stale stage into registers nobody uses; with the
             // branches the compiler, given the larger register budget of those builds, copied the whole fragment set around each of them:
@@ -311,13 +367,11 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         float* const cM = M;
         const float* const cres = res;
         const float cb0 = bv[0], cb1 = bv[1];
-        float descale = 1.f;
-        if constexpr (NP == 2) descale = h2_pow2(-(h2_exp_of_bound(*a.hA * a.gA) + h2_exp_of_bound(*a.hB)));
         L += (int)gridDim.x;
         const bool more = a.persist && setup(L);
         if (more) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k)
+            for (int k = 0; k < (R4 ? 3 : NS); ++k)
                 if (k < n) issue(k, smem + k * STAGE);
             load_bias(bv);
         }
@@ -876,9 +930,11 @@ template <int WM, int WN, bool RES, int NS = 2, int NP = 3>
 static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = NS * (size_t)(WM * 2 * NP + WN * 2 * NP) * UNIT;
+    // the fp16-pair kernel on 256 x 256 tiles: the four-slot ring (one workgroup per CU either way; 128 of the 160 KB)
+    constexpr bool R4 = NP == 2 && NS == 2 && WM == 4 && WN == 4;
+    const size_t lds = (R4 ? 4 : NS) * (size_t)(WM * 2 * NP + WN * 2 * NP) * UNIT;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES, NS, NP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3p_pipe_kernel<WM, WN, RES, NS, NP, R4>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3p: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
@@ -903,7 +959,7 @@ static int bf3p_launch(Bf3pArgs& a, int batch, hipStream_t st) {
             grid = dim3(resident);
         }
     }
-    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES, NS, NP>), grid, dim3(WM * WN * 64), lds, st, a);
+    hipLaunchKernelGGL((gemm_bf3p_pipe_kernel<WM, WN, RES, NS, NP, R4>), grid, dim3(WM * WN * 64), lds, st, a);
     return BBDM_OK;
 }
 

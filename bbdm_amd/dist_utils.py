@@ -108,6 +108,13 @@ def gather_device_info(dist=None, device: Optional[torch.device] = None):
     return out
 
 
+def _plain_modules():
+    """The model classes of this package: bare (unwrapped) modules whose gradients nobody else manages."""
+    from .model import BrownianBridgeModel
+    from .unet import UNetModel
+    return (BrownianBridgeModel, UNetModel)
+
+
 def accumulation_sync(net, micro_step: int, accumulate_grad_batches: int):
     """Context manager for one micro-step of gradient accumulation under DDP.
 
@@ -119,20 +126,26 @@ def accumulation_sync(net, micro_step: int, accumulate_grad_batches: int):
 
     Inside the context the UNet may also add a micro-step's parameter gradients to the ``.grad`` tensors IN PLACE -- one fused add
     per backward segment instead of one ``AccumulateGrad`` add per parameter (248 launches per micro-step, bbdm_amd/autograd.py) --
-    whenever no gradient hook has to observe them: every micro-step of a plain module, the non-boundary micro-steps of a DDP one
-    (under ``no_sync`` DDP's reducer ignores its hooks; on the boundary step they must fire, so that step takes autograd's path)."""
+    whenever no gradient hook has to observe them: every micro-step of a plain module, the non-boundary micro-steps of a
+    ``torch.nn.parallel.DistributedDataParallel`` one (under ``no_sync`` DDP's reducer ignores its hooks; on the boundary step they
+    must fire, so that step takes autograd's path).  Any OTHER wrapper (FSDP, Horovod, a hand-written reducer...) is unknown
+    territory: it keeps autograd's per-parameter accumulation on every micro-step (and its own ``no_sync``, when it has one) --
+    round-5 advisor finding: such a wrapper would otherwise have stopped seeing gradients after the first micro-step.  Individual
+    parameters that anything observes are excluded in any case (bbdm_amd/autograd.py: _observed)."""
     import contextlib
+    from torch.nn.parallel import DistributedDataParallel
     boundary = accumulate_grad_batches <= 1 or micro_step % accumulate_grad_batches == 0
-    ddp = hasattr(net, "no_sync")
+    ddp = isinstance(net, DistributedDataParallel)
+    bare = isinstance(net, _plain_modules())        # this package's own model, unwrapped: nobody else manages its gradients
 
     @contextlib.contextmanager
     def ctx():
         from .unet import UNetModel
-        unets = [m for m in net.modules() if isinstance(m, UNetModel)] if (not ddp or not boundary) else []
+        unets = [m for m in net.modules() if isinstance(m, UNetModel)] if (bare or (ddp and not boundary)) else []
         for m in unets:
             m.grad_in_place = True
         try:
-            if ddp and not boundary:
+            if (ddp or hasattr(net, "no_sync")) and not boundary:
                 with net.no_sync():
                     yield
             else:

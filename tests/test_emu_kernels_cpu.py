@@ -169,6 +169,11 @@ def test_gemm_h2p_shapes_and_dynamic_range(batch, T, Cin, Cout, extra, decades):
     K.test_gemm_h2p_shapes_and_dynamic_range(CPU, batch, T, Cin, Cout, extra, decades)
 
 
+@pytest.mark.parametrize("kernel,Cin", [(4, 16), (4, 32), (4, 48), (4, 64), (4, 80), (4, 112), (5, 48), (7, 48)])
+def test_gemm_h2p_kernel_variants(kernel, Cin):
+    K.test_gemm_h2p_kernel_variants(CPU, kernel, Cin)
+
+
 def test_gemm_h2p_bound_is_respected():
     K.test_gemm_h2p_bound_is_respected(CPU)
 

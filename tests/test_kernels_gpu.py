@@ -356,6 +356,29 @@ def test_gemm_h2p_shapes_and_dynamic_range(dev, batch, T, Cin, Cout, extra, deca
     assert e < (3e-6 if decades <= 3 else 1e-4)
 
 
+@pytest.mark.parametrize("kernel", [4, 5, 7])
+@pytest.mark.parametrize("Cin", [16, 32, 48, 64, 80, 112, 128, 272])
+def test_gemm_h2p_kernel_variants(dev, kernel, Cin):
+    """Every tile shape of the fp16-pair kernel (library option bf3p_kernel: 4 = 256 x 256 tiles on the FOUR-SLOT RING -- two chunks per
+    barrier: one to seventeen chunks, odd and even counts, prologue shorter than the ring --, 5 = 256 x 128, 7 = 128 x 128) against the
+    fp64 product, with a ragged row count, bias and an in-place residual; the three shapes agree bit for bit (same terms, same order)."""
+    import kernel_ops as ops
+    from bbdm_amd import _lib
+    g = torch.Generator().manual_seed(Cin)
+    batch, T, Cout = 9, 300, 256
+    V = torch.randn(batch, T, Cin, generator=g)
+    Wt = torch.randn(batch, Cout, Cin, generator=g) * 0.1
+    pk = _pack_b(Wt, Cin, Cout).to(dev)
+    bias, res = torch.randn(Cout, generator=g), torch.randn(batch, T, Cout, generator=g)
+    ref = torch.einsum("btk,bok->bto", V.double(), Wt.double()) + bias.double() + res.double()
+    with _lib.option("bf3p_kernel", kernel):
+        M = ops.gemm_h2p(V.to(dev), pk, batch, Cin, Cout, bias.to(dev), res.to(dev)).cpu()
+    M0 = ops.gemm_h2p(V.to(dev), pk, batch, Cin, Cout, bias.to(dev), res.to(dev)).cpu()
+    e = rel_err(M, ref)
+    print(f"gemm_h2p kernel variant {kernel}, {Cin // 16} chunks: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6 and torch.equal(M, M0)
+
+
 def test_gemm_h2p_bound_is_respected(dev):
     """The scale follows the BOUND, not the data: the same operands under bounds 1x ... 4096x their maximum give finite results whose
     error grows only once the second plane leaves the normal range, and a bound BELOW the maximum (a caller's bug) shows as inf / nan,

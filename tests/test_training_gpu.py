@@ -152,20 +152,26 @@ def test_gradient_accumulation_and_input_grad(dev, name):
 def test_accumulation_in_place_matches_autograd(dev, name):
     """dist_utils.accumulation_sync lets the UNet add a micro-step's gradients to the ``.grad`` tensors itself (one add per contiguous
     run of the flat gradient buffer instead of one AccumulateGrad launch per parameter): same bits as autograd's accumulation over
-    three micro-steps, ``.grad`` keeps its storage, and the boundary micro-step of a DDP-like module (``no_sync`` present) goes
-    through autograd so that reducer hooks would fire."""
+    three micro-steps and ``.grad`` keeps its storage -- for this package's own bare model (and a torch DDP under ``no_sync``:
+    tests/test_dist_cpu.py).  Everything that could be WATCHING gradients arrive keeps autograd's path (round-5 advisor finding): a
+    wrapper that is not torch's DistributedDataParallel (with or without ``no_sync``), and -- inside a bare model -- a parameter with a
+    tensor hook or a post-accumulate-grad hook, whose hook must fire on every micro-step."""
     import contextlib
     from bbdm_amd import dist_utils
     rec = load_case(name)
     x0, y, t, nz = (rec[k].to(dev) for k in ("x0", "y", "t", "noise"))
     ctx = None if rec["unet_params"]["condition_key"] == "nocond" else y
+    seen_in_place = []
 
-    def run(wrap):
+    def run(wrap, prepare=None):
         m = build(rec, dev).train()
+        if prepare is not None:
+            prepare(m)
         net = wrap(m)
         ptrs = None
         for step in (1, 2, 3):
             with dist_utils.accumulation_sync(net, step, 4) if wrap is not _plain else contextlib.nullcontext():
+                seen_in_place.append(bool(m.denoise_fn.grad_in_place))
                 loss, _ = m.p_losses(x0 * (1.0 / step), y, ctx, t, nz)
                 loss.backward()
             if step == 1:
@@ -176,26 +182,51 @@ def test_accumulation_in_place_matches_autograd(dev, name):
 
     _plain = lambda m: m
     want, _ = run(_plain)
+    assert seen_in_place == [False] * 3
 
-    class _Sync:                                   # a module without no_sync: every micro-step may accumulate in place
-        def __init__(self, m): self.m = m
-        def modules(self): return self.m.modules()
-    got, ptrs = run(_Sync)
+    del seen_in_place[:]
+    got, ptrs = run(lambda m: _Bare(m))             # the bare model: every micro-step may accumulate in place
+    assert seen_in_place == [True] * 3
     for (k, p), (_, q) in zip(got.named_parameters(), want.named_parameters()):
         assert torch.equal(p.grad, q.grad), k
         assert p.grad.data_ptr() == ptrs[k], k                 # accumulated in place: .grad never re-pointed
+
+    class _Wrapper:                                 # NOT torch DDP: its gradient handling is unknown -> autograd's path on every micro-step
+        def __init__(self, m): self.m = m
+        def modules(self): return self.m.modules()
     adds = []
 
-    class _DDPLike(_Sync):                         # has no_sync: in-place only under it (non-boundary micro-steps)
+    class _WrapperWithNoSync(_Wrapper):             # ... its no_sync is still honoured on the non-boundary micro-steps
         @contextlib.contextmanager
         def no_sync(self):
             adds.append(1)
             yield
-    got2, _ = run(_DDPLike)
+    for wrap in (_Wrapper, _WrapperWithNoSync):
+        del seen_in_place[:]
+        got2, _ = run(wrap)
+        assert seen_in_place == [False] * 3, wrap
+        for (k, p), (_, q) in zip(got2.named_parameters(), want.named_parameters()):
+            assert torch.equal(p.grad, q.grad), k
+        assert not got2.denoise_fn.grad_in_place
     assert len(adds) == 3                          # micro-steps 1..3 of 4 are non-boundary
-    for (k, p), (_, q) in zip(got2.named_parameters(), want.named_parameters()):
+
+    # observers on individual parameters of a bare model: their segment leaves the in-place path, the hooks fire every micro-step
+    fired = {"post": 0, "tensor": 0}
+
+    def prepare(m):
+        ps = list(m.denoise_fn.parameters())
+        ps[3].register_post_accumulate_grad_hook(lambda p: fired.__setitem__("post", fired["post"] + 1))
+        ps[-2].register_hook(lambda g: fired.__setitem__("tensor", fired["tensor"] + 1))
+    got3, _ = run(lambda m: _Bare(m), prepare)
+    assert fired == {"post": 3, "tensor": 3}, fired
+    for (k, p), (_, q) in zip(got3.named_parameters(), want.named_parameters()):
         assert torch.equal(p.grad, q.grad), k
-    assert not got2.denoise_fn.grad_in_place and not got.denoise_fn.grad_in_place
+    assert not got.denoise_fn.grad_in_place and not got3.denoise_fn.grad_in_place
+
+
+def _Bare(m):
+    """(the model object itself: accumulation_sync recognises this package's own classes)"""
+    return m
 
 
 def test_gradients_handed_out_are_never_overwritten(dev):
