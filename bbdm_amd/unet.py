@@ -742,10 +742,11 @@ class UNetModel(nn.Module):
         self.hip_graph: Optional[bool] = None
         # 3x3 convolutions of wide layers through Winograd F(m x m, 3x3) (csrc/winograd.hip; `winograd_tile` picks per layer):
         # largest output tile allowed: 8 (default), 6, 4, 2, or 0 = direct kernel everywhere (bit-closer parity, A/B).  8 = F(8x8, 3x3) on
-        # the inference forward of the large layers (>= 512 tiles, whole 128-channel blocks; training plans never take it): -15 % tile-GEMM
-        # work and transformed bytes for ~7x the fp32 rounding error of m = 6 -- the C2 step goes 108.0 -> 97.1 ms, its parity against the
-        # reference 1.6e-5 -> 1.1e-4 (max norm; 8.9e-6 -> 6.5e-5 in L2) of the 1e-3 bar (BASELINE.json north_star).  6 restores round 4's
-        # accuracy (the reference's own GPU path runs its convolutions in TF32 by default: ~1e-3)
+        # the large layers (>= 512 tiles, whole 128-channel blocks; inference plans, and training plans under ``winograd_train8``): -15 %
+        # tile-GEMM work and transformed bytes for ~7x the fp32 rounding error of m = 6 -- round 5, bf16x3 planes: the C2 step 108.0 -> 97.1
+        # ms, its parity against the reference 1.6e-5 -> 1.1e-4 of the 1e-3 bar (BASELINE.json north_star); round 6, fp16-pair planes
+        # (``gemm_h2``): 77.8 ms at 9.7e-5, and 85.5 ms at 1.1e-5 with ``winograd = 6`` -- the one-line opt-out for a caller who wants
+        # round 4's accuracy (the reference's own GPU path runs its convolutions in TF32 by default: ~1e-3)
         self.winograd: int = 8
         # fold GroupNorm -> FiLM -> SiLU (and an up-sampling ResBlock's nearest x2) into the Winograd input transform
         self.winograd_fuse_groupnorm: bool = True
@@ -887,6 +888,17 @@ class UNetModel(nn.Module):
             plan = _Plan(self, N, H, W, x.device, x.shape[1], training=training)
         self._plans[key] = plan                       # most recently used last
         return plan
+
+    def invalidate_inputs(self):
+        """Forget which caller tensors the cached plans already hold.
+
+        A plan skips the copy of an input it has seen before -- the conditioning image of a sampling loop, the x_next the previous step
+        wrote -- when the tensor object AND its autograd version counter are unchanged.  A write that bypasses the version counter (another
+        HIP library through a raw pointer, a DLPack consumer, ``tensor.data_ptr()`` handed to a kernel) is invisible to that check: call
+        this after such a write (or pass a fresh tensor) and the next forward copies its inputs again."""
+        for plan in self._plans.values():
+            plan._x_src = None
+            plan._ctx_src = None
 
     def _apply(self, fn, *a, **k):
         # .to(device) / .cuda() / .float(): drop compiled plans, they hold device pointers
@@ -1476,7 +1488,8 @@ class _Plan:
         assert not upsample
         # (_gn_folds_into_transform mirrors the choices above; if the two ever diverge, the statistics reference a _GnPre carries in
         # place of the coefficients must not reach a kernel that reads it as ``pre_scale`` -- round-4 advisor finding)
-        assert not isinstance(pre, _GnPre), "a coefficient-folding producer reached a layer that is not a Winograd layer on the pre-split planes"
+        if isinstance(pre, _GnPre):      # (a real error, not an assert: under python -O a statistics pointer would be read as coefficients)
+            raise RuntimeError("bbdm_amd: a coefficient-folding producer reached a layer that is not a Winograd layer on the pre-split planes")
         ks = mod.weight.shape[2] if mod.weight.dim() == 4 else 1
         pixels = self.N * x.H * x.W
         if (ks == 1 and self.m.gemm_bf3 and (pre is None or pre[0] is None) and flags == 0
@@ -1978,9 +1991,9 @@ class _Plan:
                           and (px // 256) * -(-xr.C // 128) >= m.bf3_min_tiles)
                     k0 = len(self.bops)
                     dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR", side=sb)
-                    if sb:
-                        assert [str(n) for n, _ in self.bops[k0:]] == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"], \
-                            "second-stream projection: conv_bwd chose another kernel than this rule predicted"
+                    # (checked, not assumed -- and not an assert, which python -O drops: only the workspace-free pair may leave the main
+                    # stream; if conv_bwd ever chooses other kernels than the rule above predicts, the launches simply stay in order)
+                    if sb and [str(n) for n, _ in self.bops[k0:]] == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"]:
                         bside = (k0, len(self.bops))
                 else:
                     dxr = dout

@@ -273,11 +273,14 @@ def parity_only(workload, sd, parity_inputs):
     return parity
 
 
-def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False):
+def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False, loss_type="l2"):
     """c4: loss and named parameter gradients of ONE micro-step on the benchmarked batch (batch 32, the benchmarked training plan)
-    against autograd on the oracle (CPU, the whole batch).  l2 loss: d|t - p|/dp of the l1 loss is discontinuous, a single
+    against autograd on the oracle (CPU, the whole batch).  l2 loss by default: d|t - p|/dp of the l1 loss is discontinuous, a single
     flipped sign of the 393 216 loss terms moves every gradient by ~1e-3 of its size; the loss kernel is the
-    only thing that differs between the two."""
+    only thing that differs between the two.  ``loss_type`` = "l1" (the templates' loss; tests): the oracle is differentiated with the
+    sign pattern of the HIP forward -- loss = sum(sign * (target - pred)) / count, the L1 loss with its non-differentiable sign() frozen,
+    the number of elements whose sign differs between the two forwards is returned as ``sign_flips`` -- and the loss VALUE is compared
+    unmodified."""
     odir = os.path.join(ROOT, "oracle")
     if odir not in sys.path:
         sys.path.insert(0, odir)
@@ -293,7 +296,9 @@ def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False):
     if all_grads:       # (tests/test_fullsize_parity_gpu.py: every parameter of the UNet at the benchmarked batch; ~2x the oracle time)
         names = [n for n, _ in model.denoise_fn.named_parameters()]
     keep = model.loss_type
-    model.loss_type = "l2"
+    model.loss_type = loss_type
+    seen = {}
+    hook = model.denoise_fn.register_forward_hook(lambda mod, inp, out: seen.__setitem__("pred", out.detach())) if loss_type == "l1" else None
     try:
         model.zero_grad(set_to_none=True)
         loss, _ = model.p_losses(x0, y, None, t.to(dev), noise.to(dev))
@@ -302,15 +307,30 @@ def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False):
         got = {n: dict(model.denoise_fn.named_parameters())[n].grad.detach().cpu().clone() for n in names}
         loss_gpu = float(loss.detach())
         model.zero_grad(set_to_none=True)
+        sign = None
+        if loss_type == "l1":
+            with torch.no_grad():
+                _, target_gpu = model.q_sample(x0, y, t.to(dev), noise.to(dev))
+            sign = torch.sign(target_gpu.cpu() - seen["pred"].float().cpu())
     finally:
         model.loss_type = keep
+        if hook is not None:
+            hook.remove()
     # (the timed micro-steps have stepped the optimizer: the oracle takes the model's CURRENT weights, not the initial ones)
     cur = {k: v.detach().cpu().clone() for k, v in model.denoise_fn.state_dict().items()}
     sdg = {"denoise_fn." + k: (v.requires_grad_() if k in names else v) for k, v in cur.items()}
-    ora = O.OracleBBDM(sdg, O.UNetSpec(**up), skip_sample=skip, sample_step=sstep, **dict(BB, loss_type="l2"))
+    ora = O.OracleBBDM(sdg, O.UNetSpec(**up), skip_sample=skip, sample_step=sstep, **dict(BB, loss_type=loss_type))
     t0 = time.perf_counter()
-    loss_ref, _ = ora.p_losses(x0.cpu(), y.cpu(), None, t, noise)
-    loss_ref.backward()
+    flips = None
+    if sign is None:
+        loss_ref, _ = ora.p_losses(x0.cpu(), y.cpu(), None, t, noise)
+        loss_ref.backward()
+    else:
+        x_t, target = O.q_sample(ora.bufs, x0.cpu(), y.cpu(), t, noise, ora.objective)
+        pred = ora.denoise(x_t, t, None)
+        flips = int((sign != torch.sign(target - pred.detach())).sum())
+        loss_ref = O.bb_loss(target, pred.detach(), "l1")                   # the loss VALUE: unmodified
+        ((sign * (target - pred)).sum() / pred.numel()).backward()
     secs = time.perf_counter() - t0
     gmax = max(float(sdg["denoise_fn." + n].grad.abs().max()) for n in names)
     errs = {}
@@ -319,8 +339,8 @@ def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False):
         errs[n] = float((got[n] - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
     lr = float(loss_ref.detach())
     return {"rel_err_loss": abs(loss_gpu - lr) / max(abs(lr), 1e-30), "rel_err_grad_worst": max(errs.values()), "bar": 1e-3,
-            "grad_errors": errs, "loss_gpu": loss_gpu, "loss_cpu": lr,
-            "metric": f"one training micro-step on the benchmarked batch ({batch} x {tuple(x0.shape[1:])}, l2 loss, fixed t / noise): "
+            "grad_errors": errs, "loss_gpu": loss_gpu, "loss_cpu": lr, "sign_flips": flips,
+            "metric": f"one training micro-step on the benchmarked batch ({batch} x {tuple(x0.shape[1:])}, {loss_type} loss, fixed t / noise): "
                       "|loss_gpu - loss_cpu| / |loss_cpu| and, per named parameter, max|g_gpu - g_cpu| / max(|g_cpu|max, 1e-3 x the "
                       "largest gradient magnitude)",
             "against": "port (oracle autograd)", "cpu_seconds": secs}
