@@ -113,6 +113,8 @@ SIGNATURES = {
     "bbdm_gemm_h2p_a_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
     "bbdm_gemm_h2p_b_bytes": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_absmax_f32": (c_int, [_P, ctypes.c_longlong, _P, _P]),
+    "bbdm_absmax_rows_f32": (c_int, [_P, c_int, ctypes.c_longlong, c_int, _P, _P]),
+    "bbdm_winograd_input_h2p_tr_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "bbdm_gemm_h2p_pack_b_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "bbdm_gemm_h2p_split_rows_f32": (c_int, [_P, c_int, _P, _P, c_int, ctypes.c_longlong, c_int, _P]),
     "bbdm_gemm_h2p_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),

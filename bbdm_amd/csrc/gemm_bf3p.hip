@@ -1108,6 +1108,20 @@ __global__ void h2_absmax_kernel(const float* __restrict__ x, size_t n, float* _
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(m));
 }
+// ... of a [rows][C] view with pitch ld (a channel slice of a wider NHWC buffer); C % 4 == 0, 16-byte aligned rows
+__global__ void h2_absmax_rows_kernel(const float* __restrict__ x, int ld, long long rows, int C4, float* __restrict__ bound) {
+    float m = 0.f;
+    const long long n = rows * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / C4;
+        const int c = (int)(i - r * C4);
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * c);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(m));
+}
 // bf3p_pack_b_kernel for the fp16 pair
 __global__ void h2p_pack_b_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, const float* __restrict__ bound,
                                   size_t batch_chunks, int nchunks, int CoutPad) {
@@ -1157,6 +1171,14 @@ extern "C" int bbdm_absmax_f32(const float* x, long long n, float* bound, void* 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, bound);
     BBDM_CHECK_LAUNCH("absmax");
+    return BBDM_OK;
+}
+extern "C" int bbdm_absmax_rows_f32(const float* x, int ldx, long long rows, int C, float* bound, void* stream) {
+    BBDM_REQUIRE(x && bound && rows > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "absmax_rows: bad args");
+    size_t blocks = ((size_t)rows * (C / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(h2_absmax_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C / 4, bound);
+    BBDM_CHECK_LAUNCH("absmax_rows");
     return BBDM_OK;
 }
 extern "C" int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, int batch, int CinPad, int Cout,

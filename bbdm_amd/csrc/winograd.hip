@@ -401,7 +401,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                                                                               int tchunks, const FastDiv dTW, const FastDiv dTH,
                                                                               const FastDiv dCH, const GnFold gn,
                                                                               const float* __restrict__ hbound) {
-    static_assert(NPL == 3 || (NPL == 2 && !TR && !F32), "the fp16-pair planes have neither a transposed nor an fp32 form");
+    static_assert(NPL == 3 || (NPL == 2 && !F32), "the fp16-pair planes have no fp32 form");
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
     const unsigned L = blockIdx.x, q = L >> 3;
@@ -518,6 +518,15 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                 *reinterpret_cast<unsigned*>(o) = p1;
                 *reinterpret_cast<unsigned*>(o + 1024) = p2;
                 o += plane;
+            }
+            if constexpr (TR) {
+                // training forward: the forward GEMM reads the fp16-pair planes above; the weight gradient contracts the TRANSPOSED copy
+                // with dM, whose range nothing bounds -- that GEMM stays on the exact bf16 split, and so does this copy
+                unsigned pl[AL][3];
+#pragma unroll
+                for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
+                store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane,
+                                     Vt + (size_t)(i * AL) * plane_t, plane_t, chunk, (int)(tile - tl), tchunks);
             }
             return;
         }
@@ -1199,7 +1208,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
                                  const GnFold* fold, bool f32out, const float* hbound) {
     BBDM_WINO_M78(m);
-    BBDM_REQUIRE(!hbound || (!Vt && !f32out), "winograd_input_h2p: the fp16-pair planes have neither a transposed nor an fp32 form");
+    BBDM_REQUIRE(!hbound || !f32out, "winograd_input_h2p: the fp16-pair planes have no fp32 form");
     BBDM_REQUIRE(m != 7 || (!upsample && !Vt && !fold && !f32out), "winograd_input_bf3p: m = 7 (phase filters) takes x itself, planes only");
     BBDM_REQUIRE(m != 8 || !fold, "winograd_input_bf3p: m = 8 is a tile of the large layers (no coefficient folding)");
     BBDM_REQUIRE(x && Vp && N > 0, "winograd_input_bf3p: null pointer / bad N");
@@ -1315,15 +1324,16 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         else if (pre_scale) { if (upsample) BBDM_WINO_INS2(MO, true, true, false); else BBDM_WINO_INS2(MO, true, false, false); }   \
         else           { if (upsample) BBDM_WINO_INS2(MO, false, true, false); else BBDM_WINO_INS2(MO, false, false, false); } \
     } while (0)
-#define BBDM_WINO_INS2_HI(MO, PRE, UP, I64)                                                                                       \
-    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, false, I64, false, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
-                       (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr, \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
-#define BBDM_WINO_INS2_H(MO, PRE, UP) do { if (idx64) BBDM_WINO_INS2_HI(MO, PRE, UP, true); else BBDM_WINO_INS2_HI(MO, PRE, UP, false); } while (0)
+#define BBDM_WINO_INS2_HI(MO, PRE, UP, TR, I64)                                                                                   \
+    hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64, false, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
+                       (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,           \
+                       (unsigned char*)Vt, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+#define BBDM_WINO_INS2_H(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_HI(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_HI(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_HM(MO)                                                                       \
     do {                                                                                            \
-        if (pre_scale) { if (upsample) BBDM_WINO_INS2_H(MO, true, true); else BBDM_WINO_INS2_H(MO, true, false); }   \
-        else           { if (upsample) BBDM_WINO_INS2_H(MO, false, true); else BBDM_WINO_INS2_H(MO, false, false); } \
+        if (Vt) { if (pre_scale) BBDM_WINO_INS2_H(MO, true, false, true); else BBDM_WINO_INS2_H(MO, false, false, true); }   \
+        else if (pre_scale) { if (upsample) BBDM_WINO_INS2_H(MO, true, true, false); else BBDM_WINO_INS2_H(MO, true, false, false); }   \
+        else           { if (upsample) BBDM_WINO_INS2_H(MO, false, true, false); else BBDM_WINO_INS2_H(MO, false, false, false); } \
     } while (0)
         if (hbound) { if (m == 2) BBDM_WINO_INS2_HM(2); else if (m == 4) BBDM_WINO_INS2_HM(4); else if (m == 8) BBDM_WINO_INS2_HM(8); else BBDM_WINO_INS2_HM(6); }
         else if (m == 2) BBDM_WINO_INS2_M(2); else if (m == 4) BBDM_WINO_INS2_M(4); else if (m == 8) BBDM_WINO_INS2_M(8); else BBDM_WINO_INS2_M(6);
@@ -1388,6 +1398,14 @@ extern "C" int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void*
     BBDM_REQUIRE(vbound, "winograd_input_h2p: null bound");
     return winograd_input_planes(m, x, ldx, Vp, nullptr, pre_scale, pre_bias, pre_ld, pre_silu, upsample, N, H, W, CinPad, stream, nullptr,
                                  false, vbound);
+}
+// ... and, for the training forward, ALSO the transposed planes Vt of the weight gradient -- those stay the exact bf16 split
+// (bbdm_gemm_bf3p_tn_at_bytes bytes, the layout of bbdm_winograd_input_bf3p_tr_f32: dM, their partner in that GEMM, has no bounded range)
+extern "C" int bbdm_winograd_input_h2p_tr_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
+                                              int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* Vt,
+                                              const float* vbound, void* stream) {
+    BBDM_REQUIRE(Vt && vbound && !upsample, "winograd_input_h2p_tr: null pointer / upsample != 0");
+    return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream, nullptr, false, vbound);
 }
 extern "C" int bbdm_winograd_input_h2p_gn_f32(int m, const float* x, int ldx, void* Vp, const void* stats, const void* unused, int C,
                                               int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma,

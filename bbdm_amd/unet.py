@@ -766,6 +766,13 @@ class UNetModel(nn.Module):
         # instead of six, 4 B per operand element instead of 6, and half the roundings of the fp32 accumulator -- faster AND closer to
         # the reference than the bf16x3 planes.  False: bf16x3 planes everywhere (round 5's plans; A/B)
         self.gemm_h2: bool = True
+        # ... and training plans (0 = bf16x3 planes in every direction, round 5's plans): 1 = the FORWARD tile GEMMs, whose operand is
+        # GroupNorm-bounded exactly as in sampling (the transposed copy of V the weight gradient contracts stays the exact bf16 split);
+        # 2 = also the DATA-GRADIENT tile GEMMs, dY scaled by its measured maximum (one bbdm_absmax_rows_f32 pass per layer).  A gradient
+        # tensor has no a-priori range: elements more than ~2^17 below its maximum lose bits of their second plane (their absolute
+        # error stays 2^-25 of the maximum), which the all-248-gradients tests bound at the benchmarked plan.  The Winograd-domain
+        # weight gradient keeps bf16x3 on both operands.
+        self.gemm_h2_train: int = 2
         # 1x1 layers with fewer 256 x 128 output tiles than this leave the wide bf16x3 kernels for the small-problem kernel
         self.bf3_min_tiles: int = 256
         # ... csrc/gemm_bf3p.hip: gemm_bf3s_kernel (one launch, 64 channels per step); False: the split-K f32-MFMA kernel + reduction
@@ -878,7 +885,7 @@ class UNetModel(nn.Module):
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.side_stream_wgrad, self.side_stream_wgrad_min_macs, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
-               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2)
+               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2, self.gemm_h2_train)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -956,6 +963,7 @@ class _Plan:
         self._h2_layers: List[tuple] = []            # (gamma, beta, film offset or -1, C, zmax) per bounded GroupNorm output (_gn_bound)
         self._h2_bounds = _LateTensor()              # one float per entry, refreshed by ONE launch per forward (_launch_embedding)
         self._h2_table = None
+        self._h2_dy_slots = 0                        # training: bound slots of gradient tensors (the tail of _h2_bounds, _dy_bound)
         self._saved_V: Dict[int, tuple] = {}         # training: id(conv weight) -> (V kept by the forward, tile m)
         self._fused_train = set()                    # training: id(conv weight) of layers whose GN->SiLU input was never materialised
         self.film, self.film_total, self.resblocks, self._film_key, self.film_wp = None, 0, [], None, None
@@ -971,7 +979,7 @@ class _Plan:
                 lt.t = torch.empty(self._coeff_need, **f32)
         self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
         self._conv_ws_floats.v = self._conv_ws_need
-        self._h2_bounds.t = torch.zeros(max(1, len(self._h2_layers)), **f32)
+        self._h2_bounds.t = torch.zeros(max(1, len(self._h2_layers)) + self._h2_dy_slots, **f32)
         self._wino_v.t = torch.empty(max(1, self._wino_v_need), **f32)
         self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
         for b in self.bufs:
@@ -1244,13 +1252,28 @@ class _Plan:
             self.plan, self.k = plan, k
 
         def resolve(self):
-            return self.plan._h2_bounds.t.data_ptr() + 4 * self.k
+            t = self.plan._h2_bounds.t
+            return t.data_ptr() + 4 * (self.k if self.k >= 0 else t.numel() + self.k)
+
+    def _h2_on(self, level: int) -> bool:
+        """fp16-pair planes for this plan's forward (``level`` 1) / data-gradient (2) tile GEMMs?"""
+        m = self.m
+        if not (getattr(m, "gemm_h2", False) and m.gemm_bf3 and m.gemm_bf3p):
+            return False
+        return (not self.training and level == 1) or (self.training and getattr(m, "gemm_h2_train", 0) >= level)
+
+    def _dy_bound(self, dy: _View):
+        """Bound slot for a gradient tensor: its exact maximum, measured by one pass (the slots are zeroed in backward_begin)."""
+        self._h2_dy_slots += 1
+        ref = _Plan._H2Ref(self, -self._h2_dy_slots)            # (negative: counted from the END of the bounds tensor)
+        self._bop("bbdm_absmax_rows_f32", dy, dy.ld, self.N * dy.H * dy.W, dy.C, ref)
+        return ref
 
     def _gn_bound(self, x: _View, gn, film_off):
         """Bound slot for GroupNorm(x) [-> FiLM] [-> SiLU] [-> average pool / nearest x2]: |value| <= |gamma (1 + s)| sqrt(n_g - 1) +
         |beta (1 + s) + t| whatever x holds (a z-score over n_g values is at most sqrt(n_g - 1); SiLU, averaging and copying do not
         grow it).  Inference plans only; None when the fp16-pair planes are off."""
-        if self.training or not self.m.gemm_h2 or not (self.m.gemm_bf3 and self.m.gemm_bf3p) or gn is None:
+        if not self._h2_on(1) or gn is None:
             return None
         n_g = x.H * x.W * (x.C // self.GROUPS)
         self._h2_layers.append((gn.weight, gn.bias, -1 if film_off is None else int(film_off), x.C, math.sqrt(max(n_g - 1, 1))))
@@ -1276,7 +1299,8 @@ class _Plan:
             # this layer's forward keeps (Winograd layer, same tile both ways: _emit_winograd / conv_bwd): then nothing
             # re-reads the activation and GN -> FiLM -> SiLU folds into the input transform exactly as in sampling.
             if not (self.m.winograd_fuse_groupnorm and self._train_keeps_V(consumer, x)):
-                return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
+                bref = self._gn_bound(x, gn, film_off) if (consumer is not None and self._winograd_ok(consumer, x.H, x.W, x.C)) else None
+                return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), _Pre(self.NO_PRE, h2=bref)
             self._fused_train.add(id(consumer.weight))
         elif not fuse:
             return self._gn_apply(x, gn, film_off, silu=silu, resample=0, name=name), self.NO_PRE
@@ -1370,8 +1394,8 @@ class _Plan:
         if not self.m.gemm_bf3:
             return False
         tiles = self.lib.bbdm_winograd_tiles(wm, self.N, H, W)
-        if (h2 and not self.training and self.m.gemm_h2 and self.m.gemm_bf3p
-                and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout)):
+        if (h2 and self.lib.bbdm_gemm_bf3p_supported(tiles, cin_pad, cout)
+                and (not keeps_V or self.lib.bbdm_gemm_bf3p_tn_supported(tiles, cin_pad, cout))):
             return "h"          # ``h2``: the layer's input carries a bound -- two fp16 planes per operand (csrc/h2_split.h)
         if (not self.training and cout <= self.m.fp32_v_max_cout and wino_planes(wm) * tiles * cin_pad * 6 >= (512 << 20)
                 and self.lib.bbdm_gemm_bf3_supported(tiles, cin_pad, cout)):
@@ -1398,7 +1422,7 @@ class _Plan:
         tiles = self.lib.bbdm_winograd_tiles(wm, N, H, W)
         h2 = pw.bf3 == "h"             # V as two fp16 planes under the bound pre.h2 (4 B per element)
         split = pw.bf3 == "p" or h2    # "p": V as three bf16 planes: 6 B per element of the (shared, float-typed) scratch buffer
-        assert not h2 or (getattr(pre, "h2", None) is not None and not bwd and not self.training)
+        assert not h2 or getattr(pre, "h2", None) is not None
         vb = (pre.h2,) if h2 else ()
         gb = (pre.h2, _TensorRef(pw.ubound)) if h2 else ()
         self._wino_v_need = max(self._wino_v_need, wino_planes(wm) * tiles * cin_pad * (3 if pw.bf3 == "p" else 2) // 2)
@@ -1421,8 +1445,8 @@ class _Plan:
             vt = _TensorRef(torch.empty(self.lib.bbdm_gemm_bf3p_tn_at_bytes(wino_planes(wm), tiles, cin_pad), dtype=torch.uint8,
                                         device=self.device))
             self._saved_V[id(pw.weight)] = (vt, wm, "tr")
-            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_bf3p_tr_f32"), wm, x, x.ld, vbuf,
-                 *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt)
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_h2p_tr_f32" if h2 else "bbdm_winograd_input_bf3p_tr_f32"),
+                 wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt, *vb)
         elif isinstance(pre, _GnPre):
             assert split and not bwd, "the coefficient-folding input transform exists for the pre-split planes only"
             emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_h2p_gn_f32" if h2 else "bbdm_winograd_input_bf3p_gn_f32"),
@@ -1463,7 +1487,7 @@ class _Plan:
             assert residual is None or residual.C == cout
             res_ld = residual.ld if residual is not None else 0
         H, W = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
-        h2 = getattr(pre, "h2", None) is not None
+        h2 = getattr(pre, "h2", None) is not None and self._h2_on(1)
         wm = self._winograd_ok(mod, H, W, x.C, flags)
         if wm and upsample and self.m.upsample_phases and residual is None and flags == 0 and mod.weight.shape[1] == x.C:
             # conv3x3(nearest x2 (x)) = four phase filters on x (Cin -> 4 Cout): same GEMM work, the input transform and the GEMM's
@@ -1920,9 +1944,12 @@ class _Plan:
                                 small=bool(m.gemm_bf3 and m.gemm_bf3p and m.winograd_small), allow8=self._allow8(1))
                   if (m.winograd and ks == 3 and w.dim() == 4 and x_in.C == cin) else 0)
             if wm:
-                pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=self._use_bf3(wm, x_in.H, x_in.W, dy.C, x_in.C))
+                mode = self._use_bf3(wm, x_in.H, x_in.W, dy.C, x_in.C, h2=self._h2_on(2) and dy.C % 4 == 0 and dy.ld % 4 == 0)
+                pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=mode)
                 self.dconvs.append(pk)
-                self._emit_winograd(dy, dy.C, pk, None, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
+                # fp16-pair planes: dY under its measured maximum (UNetModel.gemm_h2_train = 2)
+                pre_dy = _Pre(self.NO_PRE, h2=self._dy_bound(dy)) if mode == "h" else None
+                self._emit_winograd(dy, dy.C, pk, pre_dy, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
                 return dx
             pixels = x_in.N * x_in.H * x_in.W
             if (ks == 1 and m.gemm_bf3 and x_in.C == cin and lib.bbdm_gemm_bf3_supported(pixels, dy.C, x_in.C)
@@ -2246,6 +2273,8 @@ class _Plan:
                 self._dconvs_forked = False
             for pk in self.dconvs:
                 pk.refresh(stream)
+            if self._h2_dy_slots:                               # the measured maxima of this backward's gradient tensors accumulate from 0
+                self._h2_bounds.t[-self._h2_dy_slots:].zero_()
 
     def backward_segment(self, k: int, need_dx: bool = False):
         """Enqueue segment ``k`` of the gradient plan (0 = head side).  The last segment also runs the embedding path and,

@@ -507,6 +507,8 @@ int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bi
 size_t bbdm_gemm_h2p_a_bytes(int batch, long long T, int CinPad);
 size_t bbdm_gemm_h2p_b_bytes(int batch, int CinPad, int Cout);
 int bbdm_absmax_f32(const float* x, long long n, float* bound, void* stream);
+/* ... of a [rows][C] view with pitch ldx (a channel slice of an NHWC buffer: the dY of a data-gradient convolution); C % 4 == 0 */
+int bbdm_absmax_rows_f32(const float* x, int ldx, long long rows, int C, float* bound, void* stream);
 int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, int batch, int CinPad, int Cout, void* stream);
 int bbdm_gemm_h2p_split_rows_f32(const float* x, int ldx, void* a_planes, const float* bound, int batch, long long T, int CinPad,
                                  void* stream);
@@ -518,6 +520,11 @@ int bbdm_h2_gn_bounds_f32(const void* table, int nlayers, const float* film, int
 float bbdm_winograd_input_gain(int m);
 int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
                                 int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* vbound, void* stream);
+/* training forward: Vp as above + the TRANSPOSED planes Vt of the weight gradient, which stay the exact bf16 split (layout and size of
+ * bbdm_winograd_input_bf3p_tr_f32's: dM, their partner in bbdm_gemm_bf3p_tn_f32, has no bounded range) */
+int bbdm_winograd_input_h2p_tr_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
+                                   int pre_silu, int upsample /* 0 */, int N, int H, int W, int CinPad, void* Vt, const float* vbound,
+                                   void* stream);
 int bbdm_winograd_input_h2p_gn_f32(int m, const float* x, int ldx, void* Vp, const bbdm_stats_t* stats, const void* unused, int C,
                                    int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma, const float* beta,
                                    const float* film, int film_ld, int HW, int G, float eps, const float* vbound, void* stream);

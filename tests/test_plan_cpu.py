@@ -132,11 +132,20 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         entry = getattr(ops[k + 1][0], "entry", "")
         if "h2p" in entry:                      # two fp16 planes per operand under a bound (csrc/h2_split.h): inference only, 4 B per element
             in_entry = getattr(ops[k][0], "entry", "")
-            assert not training and m.gemm_h2 and in_entry in ("bbdm_winograd_input_h2p_f32", "bbdm_winograd_input_h2p_gn_f32")
+            assert m.gemm_h2 and (not training or m.gemm_h2_train >= (2 if k >= len(plan.ops) else 1))
+            assert in_entry in ("bbdm_winograd_input_h2p_f32", "bbdm_winograd_input_h2p_gn_f32", "bbdm_winograd_input_h2p_tr_f32")
             vb = i[-1]                          # the bound of the transformed tensor: a slot of the plan, the same one in both launches
-            assert isinstance(vb, unet._Plan._H2Ref) and 0 <= vb.k < len(plan._h2_layers) and g[-2] is vb
-            gam, bet, fo, C, z = plan._h2_layers[vb.k]
-            assert C == cin and z >= 1.0 and gam.numel() == cin and (fo == -1 or 0 <= fo <= plan.film_total - 2 * cin)
+            assert isinstance(vb, unet._Plan._H2Ref) and g[-2] is vb
+            if k >= len(plan.ops):              # data gradient: dY under its measured maximum -- the launch before the transform takes it
+                assert training and -plan._h2_dy_slots <= vb.k < 0 and i[4] is None
+                pn, pa = ops[k - 1]
+                assert pn == "bbdm_absmax_rows_f32" and pa[0] is i[1] and pa[-1] is vb and pa[3] == cin
+            else:                               # forward: the GroupNorm bound of this layer's input
+                assert 0 <= vb.k < len(plan._h2_layers)
+                gam, bet, fo, C, z = plan._h2_layers[vb.k]
+                assert C == cin and z >= 1.0 and gam.numel() == cin and (fo == -1 or 0 <= fo <= plan.film_total - 2 * cin)
+            if in_entry.endswith("_tr_f32"):    # training forward: the transposed copy stays bf16x3 (the weight gradient's operand)
+                assert training and i[8] == 0 and i[13].t.numel() == lib.bbdm_gemm_bf3p_tn_at_bytes(P, tiles, cin)
             assert g[-1].t.numel() == 1 and g[-1].t.dtype == torch.float32          # max |U|, a device float owned by the packed weights
             if in_entry.endswith("_gn_f32"):
                 assert tiles <= m.gn_in_transform and i[5] is None and i[6] == cin and len(i) == 21

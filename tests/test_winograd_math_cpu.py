@@ -100,8 +100,10 @@ def cook_toom(pairs, m, r=3):
     return t64(BT), t64(G), t64(AT)
 
 
-# m = 8 (round 5, forward only): ten points {0, +-1/2, +-3/4, +-4/3, +-2, inf}; B^T and A^T exact in fp32 (checked below)
-MATS[8] = cook_toom(["1/2", "3/4", "4/3", "2"], 8)
+# m = 8: ten points {0, +-5/4, +-9/4, +-2/5, +-4/5, inf} (round 6; round 5: {+-1/2, +-3/4, +-4/3, +-2}); B^T and A^T exact in fp32 (checked
+# below); csrc/winograd_math.h's m = 8 branches are GENERATED from this set by tools/gen_winograd8.py
+POINTS8 = ["5/4", "9/4", "2/5", "4/5"]
+MATS[8] = cook_toom(POINTS8, 8)
 
 
 def test_f8_matrices_are_exact_in_fp32_and_the_point_set_is_the_accurate_one():
@@ -122,7 +124,36 @@ def test_f8_matrices_are_exact_in_fp32_and_the_point_set_is_the_accurate_one():
     finally:
         del MATS[80]
     e6 = rms(winograd_conv(x, w, 6, torch.float32))
-    assert e_ours < 1e-4 and e_textbook > 4 * e_ours and e6 < e_ours, (e_ours, e_textbook, e6)     # measured: 4.6e-5, 4.6e-4, 6.2e-6
+    MATS[81] = cook_toom(["1/2", "3/4", "4/3", "2"], 8)
+    try:
+        e_round5 = rms(_winograd_conv_mats(x, w, 8, MATS[81], torch.float32))
+    finally:
+        del MATS[81]
+    print("fp32 restatement, rms: this set", e_ours, "round 5's", e_round5, "textbook", e_textbook, "m = 6", e6)
+    assert e_ours < 1e-4 and e_textbook > 4 * e_ours and e6 < e_ours and e_ours < 1.05 * e_round5, (e_ours, e_round5, e_textbook, e6)
+
+
+def test_f8_constants_are_the_generated_ones_and_the_gain_bounds_the_transform():
+    """tools/gen_winograd8.py regenerates the m = 8 branches of csrc/winograd_math.h from POINTS8 without changing the file, and
+    wino_input_gain(m) (the factor the fp16-pair planes' bound is multiplied by, csrc/h2_split.h) is >= max_i (sum_j |B^T_ij|)^2 and
+    within 1 % of it, for every tile."""
+    import importlib.util
+    import os
+    from bbdm_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_winograd8", os.path.join(root, "tools", "gen_winograd8.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    blocks = gen.generate(POINTS8)
+    src = open(os.path.join(root, "bbdm_amd", "csrc", "winograd_math.h")).read()
+    for key in ("bt", "at", "g", "a", "gt"):
+        assert blocks[key] in src, key
+    lib = _lib.load()
+    for m in (2, 4, 6, 8):
+        exact = float(MATS[m][0].abs().sum(1).max()) ** 2
+        got = float(lib.bbdm_winograd_input_gain(m))
+        assert exact <= got <= 1.01 * exact, (m, exact, got)
+    assert float(lib.bbdm_winograd_input_gain(7)) == float(lib.bbdm_winograd_input_gain(6))
 
 
 # F(7x7, 2x2) on the same eight points (round 5: the phase filters of conv3x3(nearest x2 (x)) read 2 x 2 pixels each): B^T is m = 6's,
