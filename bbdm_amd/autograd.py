@@ -70,15 +70,11 @@ class _UNetSeg(torch.autograd.Function):
 
 
 def _observed(q) -> bool:
-    """Does anything watch gradients arrive at parameter ``q``?  Tensor hooks (``register_hook``), post-accumulate-grad hooks
-    (``register_post_accumulate_grad_hook``), and hooks registered on the parameter's AccumulateGrad node itself."""
-    if q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None):
-        return True
-    try:
-        node = q.view_as(q).grad_fn.next_functions[0][0]         # the AccumulateGrad node of q (created on demand, then cached)
-    except Exception:
-        return True
-    return bool(getattr(node, "_hooks", None) or getattr(node, "pre_hooks", lambda: {})())
+    """Does anything registered ON THE PARAMETER watch gradients arrive?  Tensor hooks (``register_hook``) and post-accumulate-grad hooks
+    (``register_post_accumulate_grad_hook``: optimizer-in-backward, FSDP2).  Hooks on the parameter's AccumulateGrad NODE (DDP's reducer,
+    Horovod's DistributedOptimizer) cannot be seen from Python: dist_utils.accumulation_sync therefore only enables this path where it
+    knows who owns the gradients (a bare model in a single-process job, torch's DDP under ``no_sync``), or where the caller says so."""
+    return bool(q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None))
 
 
 def _accumulate_in_place(plan, params, needed) -> bool:
@@ -88,9 +84,9 @@ def _accumulate_in_place(plan, params, needed) -> bool:
     (autograd adopts the views :meth:`_Plan.grad_view` hands out), at the parameter's own offset; this micro-step's gradients lie at
     the same offsets of the OTHER flat buffer.  When that holds for every parameter of the segment, the segment's gradients are added
     with one ``add_`` per contiguous run of offsets (a handful per segment) and autograd receives None for them -- 248 ``AccumulateGrad``
-    launches per micro-step become ~10.  Anything else (first micro-step, a foreign ``.grad``, a parameter that ANYTHING observes: tensor
-    hooks, post-accumulate-grad hooks -- optimizer-in-backward, FSDP2 --, hooks on its AccumulateGrad node -- Horovod / apex style
-    reducers) returns False and the caller hands the views to autograd as before: returning None would silently skip those observers."""
+    launches per micro-step become ~10.  Anything else (first micro-step, a foreign ``.grad``, a parameter with tensor hooks or
+    post-accumulate-grad hooks -- optimizer-in-backward, FSDP2) returns False and the caller hands the views to autograd as before:
+    returning None would silently skip those observers (see _observed for what cannot be detected and who guards against it)."""
     new = plan._flat_grad
     runs = []
     base = None

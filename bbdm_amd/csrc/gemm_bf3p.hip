@@ -436,12 +436,15 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
 // Register budget: the pipe kernel's 64 accumulators + 48 fragment registers leave no room for the staging registers and the split's
 // temporaries at 128 VGPRs (a 16-wave build spilled 194 registers and ran at 20 TFLOP/s): the workgroup is 3 x WN waves -- 192-row
 // tiles, THREE waves per SIMD, up to 168 VGPRs each (WN = 4: one 12-wave workgroup per CU; WN = 2: two 6-wave workgroups).
-template <int WM, int WN, bool RES>
-__global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const Bf3pArgs a, const float* __restrict__ Af, int lda) {
+// NP = 2 (round 6): the fp16-pair planes of h2_split.h -- A scaled by 2^eA (eA from the bound *a.hA of the activation) and split into two
+// fp16 halves (7 VALU instructions per pair instead of 11), B planes packed under their own bound, three f16 MFMA terms, the accumulators
+// re-scaled in the epilogue.  32 fragment registers instead of 48: the workgroup is 4 x WN waves (256-row tiles) at 128 VGPRs.
+template <int WM, int WN, bool RES, int NP = 3>
+__global__ void __launch_bounds__(WM * WN * 64, NP == 2 && WM == 4 ? 4 : 3) gemm_bf3q_pipe_kernel(const Bf3pArgs a, const float* __restrict__ Af, int lda) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [2][STAGE]
     constexpr int NW = WM * WN, BM = WM * 64, BN = WN * 64;
     static_assert((BM * 4) % (NW * 64) == 0, "whole float4 slots of A per thread and chunk");
-    constexpr int NA = WM * 2 * 3, NB = WN * 2 * 3, NU = NA + NB, STAGE = NU * UNIT;
+    constexpr int NA = WM * 2 * NP, NB = WN * 2 * NP, NU = NA + NB, STAGE = NU * UNIT;
     constexpr int KB = (NB + NW - 1) / NW;                                    // B copies per wave and chunk
     constexpr int AS = (BM * 4 + NW * 64 - 1) / (NW * 64);                    // float4 of A per thread and chunk (1 at 16 waves, 2 at 8)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -449,7 +452,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int tilesN = a.tilesN * 2 / WN;
-    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
+    const size_t gstride = (size_t)a.nchunks * NP * UNIT;
     int bid, bz;
     if (a.by_batch) {
         const int L = (int)blockIdx.x, j = L >> 3;
@@ -480,20 +483,20 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         // now quads 2 / 3 land 16 banks further.  The A fragments are read back through the same rotation (aoff below); a read group's
         // 16 consecutive rows stay a permutation of one aligned 256-B window: conflict-free as before.  (This unit layout is private to
         // the kernel: its own waves write and read it.)
-        adst[s] = (unsigned)(((row >> 5) * 3) * UNIT + (q >> 1) * 512 + (((row & 31) ^ ((q >> 1) << 2)) * 16) + (q & 1) * 8);
+        adst[s] = (unsigned)(((row >> 5) * NP) * UNIT + (q >> 1) * 512 + (((row & 31) ^ ((q >> 1) << 2)) * 16) + (q & 1) * 8);
     }
     astep = KC;
     const unsigned char* bsrc[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
         const int u = wave + k * NW;
-        bsrc[k] = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride + (size_t)(u / 3) * gstride + (u % 3) * UNIT;
+        bsrc[k] = a.B + (size_t)bz * a.bz + (size_t)n_tile * (WN * 2) * gstride + (size_t)(u / NP) * gstride + (u % NP) * UNIT;
     }
     auto issue_b = [&](int chunk, unsigned char* st) {
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
             const int u = wave + k * NW;
-            if ((k + 1) * NW <= NB || u < NB) glds16(bsrc[k] + (size_t)chunk * (3 * UNIT), lane16, st + (NA + u) * UNIT);
+            if ((k + 1) * NW <= NB || u < NB) glds16(bsrc[k] + (size_t)chunk * (NP * UNIT), lane16, st + (NA + u) * UNIT);
         }
     };
     float4 areg[AS];
@@ -501,14 +504,28 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
 #pragma unroll
         for (int s = 0; s < AS; ++s) areg[s] = *reinterpret_cast<const float4*>(asrc[s] + (size_t)chunk * astep);
     };
+    // fp16-pair planes: the scale of A and the factor the accumulators are re-scaled by (wave-uniform; read before any LDS read is in flight)
+    float ascale = 1.f, descale = 1.f;
+    if constexpr (NP == 2) {
+        const int ea = h2_exp_of_bound(*a.hA * a.gA), eb = h2_exp_of_bound(*a.hB);
+        ascale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(h2_pow2(ea))));
+        descale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(h2_pow2(-(ea + eb)))));
+    }
     auto store_a = [&](unsigned char* st) {
 #pragma unroll
         for (int s = 0; s < AS; ++s) {
-            uint2 p1, p2, p3;
-            split4(areg[s], p1, p2, p3);
-            *reinterpret_cast<uint2*>(st + adst[s]) = p1;
-            *reinterpret_cast<uint2*>(st + adst[s] + UNIT) = p2;
-            *reinterpret_cast<uint2*>(st + adst[s] + 2 * UNIT) = p3;
+            if constexpr (NP == 2) {
+                uint2 p1, p2;
+                h2_split4(make_float4(areg[s].x * ascale, areg[s].y * ascale, areg[s].z * ascale, areg[s].w * ascale), p1, p2);
+                *reinterpret_cast<uint2*>(st + adst[s]) = p1;
+                *reinterpret_cast<uint2*>(st + adst[s] + UNIT) = p2;
+            } else {
+                uint2 p1, p2, p3;
+                split4(areg[s], p1, p2, p3);
+                *reinterpret_cast<uint2*>(st + adst[s]) = p1;
+                *reinterpret_cast<uint2*>(st + adst[s] + UNIT) = p2;
+                *reinterpret_cast<uint2*>(st + adst[s] + 2 * UNIT) = p3;
+            }
         }
     };
     float bv[2];
@@ -518,8 +535,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         bv[j] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
     }
     const unsigned lds0 = lds_address(smem);
-    const unsigned aoff = (wm * 2) * 3 * UNIT + (lane >> 5) * 512 + (((lane & 31) ^ ((lane >> 5) << 2)) * 16);      // (the rotation of adst)
-    const unsigned boff = (NA + (wn * 2) * 3) * UNIT + lane * 16;
+    const unsigned aoff = (wm * 2) * NP * UNIT + (lane >> 5) * 512 + (((lane & 31) ^ ((lane >> 5) << 2)) * 16);      // (the rotation of adst)
+    const unsigned boff = (NA + (wn * 2) * NP) * UNIT + lane * 16;
     // prologue: chunks 0 and 1 staged, fragments of chunk 0 in registers
     issue_b(0, smem);
     load_a(0);
@@ -536,24 +553,33 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 fa[3][2], fb[3][2];                                                 // [plane][tile]
-#define BF3Q_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * 3 + (p)) * UNIT)); } while (0)
+    frag_t fa[NP][2], fb[NP][2];                                               // [plane][tile] (as the registers they occupy)
+#define BF3Q_READ(dst, base, p, t) do { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(((t) * NP + (p)) * UNIT)); } while (0)
 #define BF3Q_READ_A(p, base) do { BF3Q_READ(fa[p][0], base, p, 0); BF3Q_READ(fa[p][1], base, p, 1); } while (0)
 #define BF3Q_READ_B(p, base) do { BF3Q_READ(fb[p][0], base, p, 0); BF3Q_READ(fb[p][1], base, p, 1); } while (0)
 #define BF3Q_ALL_LANDED()                                                                                                      \
     do {                                                                                                                        \
         wait_vmcnt<0>();                                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
-                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),          \
-                       "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1])           \
-                     :: "memory");                                                                                              \
+        if constexpr (NP == 3)                                                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[NP - 1][0]), "+v"(fa[NP - 1][1]),  \
+                           "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[NP - 1][0]), "+v"(fb[NP - 1][1])   \
+                         :: "memory");                                                                                          \
+        else                                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]),                                      \
+                           "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])                                       \
+                         :: "memory");                                                                                          \
     } while (0)
+#define BF3Q_MFMA(A_, B_, C_)                                                                                                   \
+    (NP == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(A_), BF3P_BF(B_), C_, 0, 0, 0)                                    \
+             : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0))
 #define BF3Q_TERM(pa, pb)                                                                                                       \
     do {                                                                                                                        \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][0], acc[0][0], 0, 0, 0);                          \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][0], fb[pb][1], acc[0][1], 0, 0, 0);                          \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][0], acc[1][0], 0, 0, 0);                          \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][1], fb[pb][1], acc[1][1], 0, 0, 0);                          \
+        acc[0][0] = BF3Q_MFMA(fa[pa][0], fb[pb][0], acc[0][0]);                                                                 \
+        acc[0][1] = BF3Q_MFMA(fa[pa][0], fb[pb][1], acc[0][1]);                                                                 \
+        acc[1][0] = BF3Q_MFMA(fa[pa][1], fb[pb][0], acc[1][0]);                                                                 \
+        acc[1][1] = BF3Q_MFMA(fa[pa][1], fb[pb][1], acc[1][1]);                                                                 \
     } while (0)
     wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -562,7 +588,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
     {
         const unsigned sa = lds0 + aoff, sb = lds0 + boff;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { BF3Q_READ_A(p, sa); BF3Q_READ_B(p, sb); }
+        for (int p = 0; p < NP; ++p) { BF3Q_READ_A(p, sa); BF3Q_READ_B(p, sb); }
     }
     BF3Q_ALL_LANDED();
     asm volatile("s_barrier" ::: "memory");                                // everybody holds chunk 0: stage 0 may be overwritten
@@ -571,35 +597,53 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
         const unsigned nxt = lds0 + ((chunk + 1) & 1) * STAGE;
         const unsigned sa = nxt + aoff, sb = nxt + boff;
         unsigned char* const st2 = smem + (chunk & 1) * STAGE;             // chunk + 2 goes where chunk was read from (one iteration ago)
-        __builtin_amdgcn_sched_barrier(0);
-        BF3Q_TERM(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (stage2) { issue_b(chunk + 2, st2); load_a(chunk + 2); }        // under the first MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        BF3Q_TERM(0, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3Q_READ_B(2, sb);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3Q_TERM(2, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3Q_READ_A(2, sa);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3Q_TERM(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3Q_READ_B(1, sb);
-        if (stage2) store_a(st2);                                          // (waits for this thread's A request; the split runs under the MFMAs)
-        __builtin_amdgcn_sched_barrier(0);
-        BF3Q_TERM(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) BF3Q_READ_A(1, sa);
-        __builtin_amdgcn_sched_barrier(0);
-        BF3Q_TERM(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) { BF3Q_READ_A(0, sa); BF3Q_READ_B(0, sb); }
+        if constexpr (NP == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stage2) { issue_b(chunk + 2, st2); load_a(chunk + 2); }        // under the first MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(0, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3Q_READ_B(2, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3Q_READ_A(2, sa);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3Q_READ_B(1, sb);
+            if (stage2) store_a(st2);                                          // (waits for this thread's A request; the split runs under the MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3Q_READ_A(1, sa);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) { BF3Q_READ_A(0, sa); BF3Q_READ_B(0, sb); }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (stage2) { issue_b(chunk + 2, st2); load_a(chunk + 2); }        // under the first MFMAs
+            if (has_next) BF3Q_READ_B(1, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) BF3Q_READ_A(1, sa);
+            if (stage2) store_a(st2);                                          // (waits for this thread's A request; the split runs under the MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+            BF3Q_TERM(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) { BF3Q_READ_A(0, sa); BF3Q_READ_B(0, sb); }
+        }
         BF3Q_ALL_LANDED();
         asm volatile("s_barrier" ::: "memory");
     }
 #undef BF3Q_TERM
+#undef BF3Q_MFMA
 #undef BF3Q_ALL_LANDED
 #undef BF3Q_READ_B
 #undef BF3Q_READ_A
@@ -630,7 +674,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 3) gemm_bf3q_pipe_kernel(const B
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int co = cout0 + wn * 64 + j * 32 + (lane & 31);
-                    float v = acc[i][j][r] + bv[j];
+                    float v = (NP == 2 ? acc[i][j][r] * descale : acc[i][j][r]) + bv[j];
                     if (RES) v += rv[rr][j];
                     if (co < a.Cout && row < a.T) dst[co] = v;
                 }
@@ -1100,27 +1144,45 @@ extern "C" int bbdm_gemm_bf3p_splitk_f32(const void* a_planes, const void* b_pla
 // element.  Each operand comes with a BOUND (a device float >= max |x| over the whole operand): producers scale by 2^e,
 // e = h2_exp_of_bound(bound), the GEMM's epilogue by 2^-(eA + eB).
 namespace {
-// max |x| into *bound (atomicMax on the bit pattern of a non-negative float: order-independent); *bound accumulates
-__global__ void h2_absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ bound) {
+// max |x| into *bound (atomicMax on the bit pattern of a non-negative float: order-independent); *bound accumulates.  ONE atomic per
+// workgroup and at most 512 workgroups: a device-scope atomic on one address retires at ~90 per microsecond (MI355X_MICROARCH.md,
+// "dequeue"), and the first version -- one per wave of 4096 workgroups -- spent 190 us per launch on them (round 6: 8.2 ms of a C4 step).
+__device__ __forceinline__ void h2_block_max_to(float m, float* bound) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(m));
+    }
+}
+__global__ void __launch_bounds__(256) h2_absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ bound) {
     float m = 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(m));
+    h2_block_max_to(m, bound);
 }
-// ... of a [rows][C] view with pitch ld (a channel slice of a wider NHWC buffer); C % 4 == 0, 16-byte aligned rows
-__global__ void h2_absmax_rows_kernel(const float* __restrict__ x, int ld, long long rows, int C4, float* __restrict__ bound) {
+// ... of a [rows][C] view with pitch ld (a channel slice of a wider NHWC buffer); C % 4 == 0, 16-byte aligned rows.  A workgroup walks
+// whole rows: thread t of a row's C / 4 float4 slots (no division in the loop)
+__global__ void __launch_bounds__(256) h2_absmax_rows_kernel(const float* __restrict__ x, int ld, long long rows, int C4, int rpb,
+                                                             float* __restrict__ bound) {
     float m = 0.f;
-    const long long n = rows * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / C4;
-        const int c = (int)(i - r * C4);
-        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * c);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const int c = threadIdx.x % C4, r0 = threadIdx.x / C4;          // rpb = 256 / C4 rows per pass (C4 <= 256), or 1 with a column loop
+    if (rpb > 0) {
+        if (r0 < rpb)
+            for (long long r = (long long)blockIdx.x * rpb + r0; r < rows; r += (long long)gridDim.x * rpb) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * c);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
+    } else {
+        for (long long r = blockIdx.x; r < rows; r += gridDim.x)
+            for (int cc = threadIdx.x; cc < C4; cc += 256) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * ld + 4 * cc);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(bound), __float_as_uint(m));
+    h2_block_max_to(m, bound);
 }
 // bf3p_pack_b_kernel for the fp16 pair
 __global__ void h2p_pack_b_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, const float* __restrict__ bound,
@@ -1167,17 +1229,19 @@ extern "C" size_t bbdm_gemm_h2p_b_bytes(int batch, int CinPad, int Cout) {
 }
 extern "C" int bbdm_absmax_f32(const float* x, long long n, float* bound, void* stream) {
     BBDM_REQUIRE(x && bound && n > 0, "absmax: bad args");
-    size_t blocks = ((size_t)n + 1023) / 1024;
-    if (blocks > 2048) blocks = 2048;
+    size_t blocks = ((size_t)n + 4095) / 4096;
+    if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(h2_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, bound);
     BBDM_CHECK_LAUNCH("absmax");
     return BBDM_OK;
 }
 extern "C" int bbdm_absmax_rows_f32(const float* x, int ldx, long long rows, int C, float* bound, void* stream) {
     BBDM_REQUIRE(x && bound && rows > 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0, "absmax_rows: bad args");
-    size_t blocks = ((size_t)rows * (C / 4) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(h2_absmax_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C / 4, bound);
+    const int C4 = C / 4, rpb = C4 <= 256 ? 256 / C4 : 0;
+    long long blocks = rpb ? (rows + 4 * rpb - 1) / (4 * rpb) : rows;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(h2_absmax_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, C4, rpb, bound);
     BBDM_CHECK_LAUNCH("absmax_rows");
     return BBDM_OK;
 }
@@ -1309,12 +1373,12 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
 
 // ---- fp32 A operand on the pipelined kernel (gemm_bf3q_pipe_kernel) ---------------------------------------------------------------------
 namespace {
-template <int WM, int WN, bool RES>
+template <int WM, int WN, bool RES, int NP = 3>
 int bf3q_launch(Bf3pArgs& a, const float* Af, int lda, int batch, hipStream_t st) {
     static bool attr_set_dev[BBDM_MAX_DEVICES] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()];
-    const size_t lds = 2 * (size_t)(WM * 2 * 3 + WN * 2 * 3) * UNIT;
-    const void* fn = reinterpret_cast<const void*>(gemm_bf3q_pipe_kernel<WM, WN, RES>);
+    const size_t lds = 2 * (size_t)(WM * 2 * NP + WN * 2 * NP) * UNIT;
+    const void* fn = reinterpret_cast<const void*>(gemm_bf3q_pipe_kernel<WM, WN, RES, NP>);
     if (!attr_set) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("gemm_bf3q: hipFuncSetAttribute(%zu B LDS) failed", lds);
@@ -1327,7 +1391,7 @@ int bf3q_launch(Bf3pArgs& a, const float* Af, int lda, int batch, hipStream_t st
     a.tiles = (int)blocks;
     a.persist = 0;
     const dim3 grid = a.by_batch ? dim3((unsigned)(8 * blocks * ((batch + 7) / 8))) : dim3((unsigned)blocks, 1, batch);
-    hipLaunchKernelGGL((gemm_bf3q_pipe_kernel<WM, WN, RES>), grid, dim3(WM * WN * 64), lds, st, a, Af, lda);
+    hipLaunchKernelGGL((gemm_bf3q_pipe_kernel<WM, WN, RES, NP>), grid, dim3(WM * WN * 64), lds, st, a, Af, lda);
     return BBDM_OK;
 }
 }  // namespace
@@ -1359,6 +1423,36 @@ extern "C" int bbdm_conv1x1_bf3q_f32(const float* x, int ldx, const void* b_plan
     else rc = residual ? bf3q_launch<3, 2, true>(a, x, ldx, 1, st) : bf3q_launch<3, 2, false>(a, x, ldx, 1, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("conv1x1_bf3q");
+    return BBDM_OK;
+}
+
+// The same product on the fp16-pair planes (round 6; h2_split.h): b_planes = bbdm_gemm_h2p_pack_b_f32(batch = 1) under wbound (the exact
+// maximum of the packed weights), xbound: a device float >= max |x| over the pixels and channels read.  256-row tiles.
+extern "C" int bbdm_conv1x1_h2q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                    float* out, int ldo, long long pixels, int CinPad, int Cout, const float* xbound, const float* wbound,
+                                    void* stream) {
+    BBDM_REQUIRE(x && b_planes && out && xbound && wbound, "conv1x1_h2q: null pointer");
+    BBDM_REQUIRE(pixels > 0 && pixels < (1ll << 31) && CinPad > 0 && CinPad % KC == 0 && Cout > 0 && Cout % 4 == 0,
+                 "conv1x1_h2q: pixels=%lld CinPad=%d Cout=%d unsupported", pixels, CinPad, Cout);
+    BBDM_REQUIRE(ldx % 4 == 0 && ldx >= CinPad && ldo >= Cout && (!residual || ldr >= Cout) &&
+                     (((uintptr_t)x | (uintptr_t)b_planes) & 15) == 0,
+                 "conv1x1_h2q: bad pitch / alignment");
+    Bf3pArgs a;
+    a.A = nullptr; a.B = (const unsigned char*)b_planes; a.M = out;
+    a.T = (int)pixels; a.Cout = Cout; a.nchunks = CinPad / KC;
+    a.rgs = 0;
+    const int CoutPad = cdiv(Cout, 128) * 128;
+    a.tilesN = CoutPad / 128;
+    a.az = 0; a.bz = 0; a.mz = 0; a.rz = 0;
+    a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
+    a.ksplits = 1; a.kps = a.nchunks; a.P = 1; a.batch = 1; a.by_batch = 0;
+    a.hA = xbound; a.hB = wbound; a.gA = 1.f;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (CoutPad % 256 == 0) rc = residual ? bf3q_launch<4, 4, true, 2>(a, x, ldx, 1, st) : bf3q_launch<4, 4, false, 2>(a, x, ldx, 1, st);
+    else rc = residual ? bf3q_launch<4, 2, true, 2>(a, x, ldx, 1, st) : bf3q_launch<4, 2, false, 2>(a, x, ldx, 1, st);
+    if (rc != BBDM_OK) return rc;
+    BBDM_CHECK_LAUNCH("conv1x1_h2q");
     return BBDM_OK;
 }
 

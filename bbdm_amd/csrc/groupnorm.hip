@@ -301,7 +301,30 @@ __global__ void __launch_bounds__(256) h2_gn_bounds_kernel(const H2GnLayer* __re
     __syncthreads();
     if (threadIdx.x == 0) bounds[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * L.gain;
 }
+// A tensor whose GroupNorm statistics exist is bounded by them: |x_i| <= sqrt(sum_j x_j^2) over its (image, group).  bound = the largest
+// such root over the N x G accumulator cells (exact sums, stats_acc.h) -- loose by up to sqrt(n_g), which the fp16 pair's 18 binades of
+// full precision absorb (h2_split.h) -- for the 1x1 convolutions that read the RAW block input (the skip projections of the ResBlocks).
+__global__ void __launch_bounds__(256) h2_stats_bound_kernel(const unsigned long long* __restrict__ stats, int cells, float* __restrict__ bound) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < cells; i += 256) {
+        const double ss = sa_load(stats + ((size_t)i * 2 + 1) * SA_W);
+        m = fmaxf(m, (float)(sqrt(ss > 0.0 ? ss : 0.0) * 1.000001));
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *bound = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
 }  // namespace
+
+extern "C" int bbdm_h2_stats_bound_f32(const void* stats, int N, int G, float* bound, void* stream) {
+    BBDM_REQUIRE(stats && bound && N > 0 && G > 0, "h2_stats_bound: bad args");
+    hipLaunchKernelGGL(h2_stats_bound_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)stats, N * G, bound);
+    BBDM_CHECK_LAUNCH("h2_stats_bound");
+    return BBDM_OK;
+}
 
 extern "C" int bbdm_h2_gn_bounds_f32(const void* table, int nlayers, const float* film, int film_ld, int N, float* bounds, void* stream) {
     BBDM_REQUIRE(table && bounds && nlayers > 0 && N > 0, "h2_gn_bounds: bad args");

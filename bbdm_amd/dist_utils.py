@@ -115,33 +115,42 @@ def _plain_modules():
     return (BrownianBridgeModel, UNetModel)
 
 
-def accumulation_sync(net, micro_step: int, accumulate_grad_batches: int):
+def accumulation_sync(net, micro_step: int, accumulate_grad_batches: int, in_place=None):
     """Context manager for one micro-step of gradient accumulation under DDP.
 
     The reference all-reduces the full 948 MB gradient on EVERY micro-step (runners/BaseRunner.py:412-417: ``loss.backward()``
     with no ``no_sync()``) although the optimizer only steps every ``accumulate_grad_batches``-th one.  Skipping the
     collective on the non-boundary micro-steps (``net.no_sync()``) and reducing the locally accumulated sum on the boundary
     step gives the same averaged gradient -- a sum of means is the mean of sums -- with 1/accumulate_grad_batches of the
-    RCCL traffic.  ``micro_step`` is the runner's 1-based ``global_step``; non-DDP modules get no ``no_sync``.
+    RCCL traffic.  ``micro_step`` is the runner's 1-based ``global_step``; modules without ``no_sync`` get none.
 
     Inside the context the UNet may also add a micro-step's parameter gradients to the ``.grad`` tensors IN PLACE -- one fused add
     per backward segment instead of one ``AccumulateGrad`` add per parameter (248 launches per micro-step, bbdm_amd/autograd.py) --
-    whenever no gradient hook has to observe them: every micro-step of a plain module, the non-boundary micro-steps of a
-    ``torch.nn.parallel.DistributedDataParallel`` one (under ``no_sync`` DDP's reducer ignores its hooks; on the boundary step they
-    must fire, so that step takes autograd's path).  Any OTHER wrapper (FSDP, Horovod, a hand-written reducer...) is unknown
-    territory: it keeps autograd's per-parameter accumulation on every micro-step (and its own ``no_sync``, when it has one) --
-    round-5 advisor finding: such a wrapper would otherwise have stopped seeing gradients after the first micro-step.  Individual
-    parameters that anything observes are excluded in any case (bbdm_amd/autograd.py: _observed)."""
+    which BYPASSES autograd's AccumulateGrad nodes, so it is only enabled where it is known that nothing hangs on them
+    (round-5 advisor finding: hooks on those nodes cannot be detected):
+      * ``in_place`` = None (default): this package's own model, unwrapped, in a job with no process group of more than one rank and
+        no Horovod loaded (nobody else can be reducing its gradients); and ``torch.nn.parallel.DistributedDataParallel`` on its
+        non-boundary micro-steps (under ``no_sync`` its reducer ignores the hooks; on the boundary step they must fire, so that step
+        takes autograd's path).  Any other wrapper (FSDP, a hand-written reducer ...) keeps autograd's accumulation on every micro-step.
+      * ``in_place`` = True / False: the caller's word -- True only if nothing observes gradient arrival on the non-boundary micro-steps.
+    Parameters with tensor hooks or post-accumulate-grad hooks are excluded in any case (bbdm_amd/autograd.py: _observed)."""
     import contextlib
+    import sys
     from torch.nn.parallel import DistributedDataParallel
     boundary = accumulate_grad_batches <= 1 or micro_step % accumulate_grad_batches == 0
     ddp = isinstance(net, DistributedDataParallel)
-    bare = isinstance(net, _plain_modules())        # this package's own model, unwrapped: nobody else manages its gradients
+    multi = (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1) \
+        or "horovod.torch" in sys.modules
+    bare = isinstance(net, _plain_modules()) and not multi      # this package's own model, unwrapped, and nobody to reduce with
+    if in_place is None:
+        allow = bare or (ddp and not boundary)
+    else:
+        allow = bool(in_place) and not (ddp and boundary)
 
     @contextlib.contextmanager
     def ctx():
         from .unet import UNetModel
-        unets = [m for m in net.modules() if isinstance(m, UNetModel)] if (bare or (ddp and not boundary)) else []
+        unets = [m for m in net.modules() if isinstance(m, UNetModel)] if allow else []
         for m in unets:
             m.grad_in_place = True
         try:

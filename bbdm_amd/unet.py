@@ -404,6 +404,32 @@ class _PackedConvBf3q(_PackedConv):
             self.key = key
 
 
+class _PackedConvH2q(_PackedConv):
+    """A 1x1 conv / Linear weight as the fp16-pair B planes of csrc/gemm_bf3p.hip under the scale of its exact maximum (``ubound``): the
+    operand of bbdm_conv1x1_h2q_f32."""
+
+    def __init__(self, weight, bias, cin_pad):
+        super().__init__(weight, bias, cin_pad)
+        self.packed_f32 = self.packed
+        self.packed = torch.empty(_lib.load().bbdm_gemm_h2p_b_bytes(1, cin_pad, self.cout), dtype=torch.uint8, device=weight.device)
+        self.packed.cin_true = self.cin
+        self.ubound = torch.zeros(1, dtype=torch.float32, device=weight.device)
+
+    def refresh(self, stream):
+        w = self.weight
+        key = (w.data_ptr(), _ver(w))
+        if key != self.key:
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
+                      self.cin_pad, 1, stream)
+            self.ubound.zero_()
+            _lib.call("bbdm_absmax_f32", self.packed_f32.data_ptr(), self.packed_f32.numel(), self.ubound.data_ptr(), stream)
+            _lib.call("bbdm_gemm_h2p_pack_b_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), 1,
+                      self.cin_pad, self.cout, stream)
+            self.key = key
+
+
 class _PackedDgradBf3:
     """The transposed weight of a 1x1 conv / Linear in the three-bf16-plane layout of csrc/gemm_bf3.hip: the data gradient
     dX = dY W as one more fp32-accurate GEMM on the BF16 matrix core (``packed``; the fp32 dgrad packing is the intermediate)."""
@@ -773,6 +799,10 @@ class UNetModel(nn.Module):
         # error stays 2^-25 of the maximum), which the all-248-gradients tests bound at the benchmarked plan.  The Winograd-domain
         # weight gradient keeps bf16x3 on both operands.
         self.gemm_h2_train: int = 2
+        # ... and the wide 1x1 convolutions whose input carries a bound -- the skip projections of the ResBlocks (their raw input is bounded
+        # by its own GroupNorm statistics: |x| <= sqrt(sum of squares) per group) and the qkv projections (a GroupNorm output) -- on
+        # bbdm_conv1x1_h2q_f32 (inference plans).  False: bbdm_conv1x1_bf3q_f32 / bbdm_conv1x1_bf3_f32
+        self.conv1x1_h2: bool = True
         # 1x1 layers with fewer 256 x 128 output tiles than this leave the wide bf16x3 kernels for the small-problem kernel
         self.bf3_min_tiles: int = 256
         # ... csrc/gemm_bf3p.hip: gemm_bf3s_kernel (one launch, 64 channels per step); False: the split-K f32-MFMA kernel + reduction
@@ -885,7 +915,7 @@ class UNetModel(nn.Module):
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.side_stream_wgrad, self.side_stream_wgrad_min_macs, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
-               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2, self.gemm_h2_train)
+               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2, self.gemm_h2_train, self.conv1x1_h2)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -964,6 +994,7 @@ class _Plan:
         self._h2_bounds = _LateTensor()              # one float per entry, refreshed by ONE launch per forward (_launch_embedding)
         self._h2_table = None
         self._h2_dy_slots = 0                        # training: bound slots of gradient tensors (the tail of _h2_bounds, _dy_bound)
+        self._h2_x_slots = 0                         # bound slots of raw block inputs (_stats_bound)
         self._saved_V: Dict[int, tuple] = {}         # training: id(conv weight) -> (V kept by the forward, tile m)
         self._fused_train = set()                    # training: id(conv weight) of layers whose GN->SiLU input was never materialised
         self.film, self.film_total, self.resblocks, self._film_key, self.film_wp = None, 0, [], None, None
@@ -979,7 +1010,7 @@ class _Plan:
                 lt.t = torch.empty(self._coeff_need, **f32)
         self._conv_ws.t = torch.empty(max(1, self._conv_ws_need), **f32)
         self._conv_ws_floats.v = self._conv_ws_need
-        self._h2_bounds.t = torch.zeros(max(1, len(self._h2_layers)) + self._h2_dy_slots, **f32)
+        self._h2_bounds.t = torch.zeros(max(1, len(self._h2_layers)) + self._h2_x_slots + self._h2_dy_slots, **f32)
         self._wino_v.t = torch.empty(max(1, self._wino_v_need), **f32)
         self._wino_m.t = torch.empty(max(1, self._wino_m_need), **f32)
         for b in self.bufs:
@@ -1245,15 +1276,18 @@ class _Plan:
         self.fused_stats += 1
 
     class _H2Ref:
-        """Address of bound slot ``k`` of the plan (a device float, csrc/h2_split.h)."""
-        __slots__ = ("plan", "k")
+        """Address of a bound slot of the plan (a device float, csrc/h2_split.h).  The plan's bounds tensor holds, in this order, the
+        GroupNorm bounds (``kind`` "gn": one launch per forward fills them all), the bounds taken from GroupNorm statistics ("x": raw
+        block inputs, bbdm_h2_stats_bound_f32) and the measured maxima of gradient tensors ("dy", training: zeroed in backward_begin)."""
+        __slots__ = ("plan", "k", "kind")
 
-        def __init__(self, plan, k):
-            self.plan, self.k = plan, k
+        def __init__(self, plan, k, kind="gn"):
+            self.plan, self.k, self.kind = plan, k, kind
 
         def resolve(self):
-            t = self.plan._h2_bounds.t
-            return t.data_ptr() + 4 * (self.k if self.k >= 0 else t.numel() + self.k)
+            p = self.plan
+            base = {"gn": 0, "x": max(1, len(p._h2_layers)), "dy": max(1, len(p._h2_layers)) + p._h2_x_slots}[self.kind]
+            return p._h2_bounds.t.data_ptr() + 4 * (base + self.k)
 
     def _h2_on(self, level: int) -> bool:
         """fp16-pair planes for this plan's forward (``level`` 1) / data-gradient (2) tile GEMMs?"""
@@ -1264,9 +1298,23 @@ class _Plan:
 
     def _dy_bound(self, dy: _View):
         """Bound slot for a gradient tensor: its exact maximum, measured by one pass (the slots are zeroed in backward_begin)."""
+        ref = _Plan._H2Ref(self, self._h2_dy_slots, "dy")
         self._h2_dy_slots += 1
-        ref = _Plan._H2Ref(self, -self._h2_dy_slots)            # (negative: counted from the END of the bounds tensor)
         self._bop("bbdm_absmax_rows_f32", dy, dy.ld, self.N * dy.H * dy.W, dy.C, ref)
+        return ref
+
+    def _conv1x1_h2_ok(self, pixels: int, cin: int, cout: int) -> bool:
+        """Would a 1x1 convolution of this size with a bounded input run on bbdm_conv1x1_h2q_f32?  (inference, wide layers: the small
+        problems keep the small-problem kernel)"""
+        return bool(not self.training and getattr(self.m, "conv1x1_h2", True) and self._h2_on(1) and cin % 16 == 0 and cout % 4 == 0
+                    and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles)
+
+    def _stats_bound(self, slot: int):
+        """Bound slot for the RAW tensor whose GroupNorm statistics are accumulator ``slot``: the largest root-sum-of-squares over its
+        (image, group) cells (csrc/groupnorm.hip: h2_stats_bound_kernel).  Emitted where the statistics are complete."""
+        ref = _Plan._H2Ref(self, self._h2_x_slots, "x")
+        self._h2_x_slots += 1
+        self._op("bbdm_h2_stats_bound_f32", _Plan._StatsRef(self, slot), self.N, self.GROUPS, ref)
         return ref
 
     def _gn_bound(self, x: _View, gn, film_off):
@@ -1516,6 +1564,15 @@ class _Plan:
             raise RuntimeError("bbdm_amd: a coefficient-folding producer reached a layer that is not a Winograd layer on the pre-split planes")
         ks = mod.weight.shape[2] if mod.weight.dim() == 4 else 1
         pixels = self.N * x.H * x.W
+        xb = getattr(pre, "h2", None)
+        if (ks == 1 and xb is not None and (pre is None or pre[0] is None) and flags == 0 and self._conv1x1_h2_ok(pixels, x.C, cout)):
+            # wide 1x1 convolution whose input carries a bound: the fp16-pair planes (csrc/gemm_bf3p.hip: gemm_bf3q_pipe_kernel<NP = 2>)
+            pb = self._packed(_PackedConvH2q, mod.weight, mod.bias, x.C)
+            self.convs.append(pb)
+            rec = self._op(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_h2q_f32"), x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
+                           residual, res_ld, dest, dest.ld, pixels, x.C, cout, xb, _TensorRef(pb.ubound))
+            self._note_writer(dest, rec, None)
+            return
         if (ks == 1 and self.m.gemm_bf3 and (pre is None or pre[0] is None) and flags == 0
                 and self.lib.bbdm_gemm_bf3_supported(pixels, x.C, cout)
                 and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles):
@@ -1573,10 +1630,16 @@ class _Plan:
         # launches instead of between them (UNetModel.side_stream_min_macs / _max_macs; kernels that own no shared workspace only)
         side, out = None, None
         early_skip = isinstance(rb.skip_connection, nn.Conv2d) and rs == 0 and self._side_band(N * x.H * x.W, x.C, rb.out_channels)
-        if early_skip:
+
+        def emit_early_skip():
+            # (after the block's first GroupNorm input has been emitted: the statistics of x are complete there, and the projection on
+            # the fp16-pair planes takes its bound from them -- the bound launch stays on the main stream, before the fork)
+            nonlocal side, out
             out = dest if dest is not None else self._new(N, x.H, x.W, rb.out_channels)
+            xbound = self._stats_bound(s1) if (rb.skip_connection.weight.shape[2] == 1
+                                               and self._conv1x1_h2_ok(N * x.H * x.W, x.C, rb.out_channels)) else None
             k0 = len(self.ops)
-            self._emit_conv(x, rb.skip_connection, None, out)
+            self._emit_conv(x, rb.skip_connection, None, out, pre=_Pre(self.NO_PRE, h2=xbound) if xbound is not None else None)
             if all(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in self.ops[k0:]):
                 side = (k0, len(self.ops))
         # Up-sampling block, inference, both 3x3 convs on the Winograd path at the upsampled size: nothing is resampled explicitly.
@@ -1589,6 +1652,8 @@ class _Plan:
                    and self._winograd_ok(rb.out_layers[3], 2 * x.H, 2 * x.W, rb.out_channels))
         if rs == 0:
             a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A", consumer=rb.in_layers[2])
+            if early_skip:
+                emit_early_skip()
         elif fold_up:
             a, pre1 = self._gn_input(x, rb.in_layers[0], None, silu=1, name="A", consumer=rb.in_layers[2], upsample=True)
         else:       # up / down blocks resample between the activation and the conv: explicit apply pass
@@ -1612,7 +1677,11 @@ class _Plan:
             out = dest if dest is not None else self._new(N, oh, ow, rb.out_channels)
         if isinstance(rb.skip_connection, nn.Conv2d):
             if not early_skip:
-                self._emit_conv(xr, rb.skip_connection, None, out)
+                # the projection reads the block input itself (pooled / copied for an up / down block: no larger): bounded by the
+                # statistics the block's first GroupNorm took of it (slot s1, complete by now)
+                xbound = self._stats_bound(s1) if (rb.skip_connection.weight.dim() == 4 and rb.skip_connection.weight.shape[2] == 1
+                                                   and self._conv1x1_h2_ok(N * xr.H * xr.W, xr.C, rb.out_channels)) else None
+                self._emit_conv(xr, rb.skip_connection, None, out, pre=_Pre(self.NO_PRE, h2=xbound) if xbound is not None else None)
             self._emit_conv(a2, rb.out_layers[3], out, out, pre=pre2)
             if side is not None:
                 self._side_ranges.append((side[0], side[1], len(self.ops) - 1))      # (.., the launch that reads the projection)
@@ -1630,6 +1699,8 @@ class _Plan:
         ch = C // ab.num_heads
         s0 = self._gn_count
         a, pre = self._gn_input(x, ab.norm, None, silu=0, name="A")
+        if (pre is None or pre[0] is None) and self._conv1x1_h2_ok(N * T, C, 3 * C):
+            pre = _Pre(self.NO_PRE, h2=self._gn_bound(x, ab.norm, None))      # (a materialised GroupNorm output: bounded by its coefficients)
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
         self._emit_conv(a, ab.qkv, None, qkv, pre=pre)
         at = self._tmp("AT", N, x.H, x.W, C)
@@ -2274,7 +2345,7 @@ class _Plan:
             for pk in self.dconvs:
                 pk.refresh(stream)
             if self._h2_dy_slots:                               # the measured maxima of this backward's gradient tensors accumulate from 0
-                self._h2_bounds.t[-self._h2_dy_slots:].zero_()
+                self._h2_bounds.t[self._h2_bounds.t.numel() - self._h2_dy_slots:].zero_()
 
     def backward_segment(self, k: int, need_dx: bool = False):
         """Enqueue segment ``k`` of the gradient plan (0 = head side).  The last segment also runs the embedding path and,

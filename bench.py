@@ -814,6 +814,10 @@ def run_workload(args, env):
     traffic = None
     traffic_step = None
     import glob
+    import hashlib
+    from bbdm_amd import _lib as _bl0
+    lib_sha = hashlib.sha256(open(_bl0.LIB_PATH, "rb").read()).hexdigest()
+    stale = []                   # committed PMC files taken on ANOTHER build of the library: their fields are withheld
     # kernel-name prefix of the dominant kernel in the rocprofv3 tables (gemm_bf3_kernel also serves the few narrow 1x1 layers: only
     # counted where it IS the tile-GEMM kernel)
     dom_prefix = ("gemm_bf3p_" if bf3p_ops >= bf3_ops else "gemm_bf3_kernel") if use_bf3 else "conv_igemm_f32"
@@ -821,6 +825,9 @@ def run_workload(args, env):
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_traffic.json")))
         if cands:
             pm = json.load(open(cands[-1]))
+            if pm.get("library_sha256") != lib_sha:
+                stale.append(os.path.basename(cands[-1]))
+                pm = {"kernels": {}}
             hits = [v for k, v in pm["kernels"].items() if k.startswith(dom_prefix)]
             if hits:                       # launch-weighted mean over the instantiations of the dominant kernel
                 nl = sum(v["launches"] for v in hits)
@@ -841,6 +848,9 @@ def run_workload(args, env):
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{args.workload}_mfma_util.json")))
         if cands:
             mu = json.load(open(cands[-1]))
+            if mu.get("library_sha256") != lib_sha:
+                stale.append(os.path.basename(cands[-1]))
+                mu = {"kernels": {}}
             hits = [v for k, v in mu["kernels"].items() if k.startswith(dom_prefix)]
             hits = [v for v in hits if v.get("MfmaUtil%") is not None]
             if hits:
@@ -915,6 +925,14 @@ def run_workload(args, env):
                                            "step time",
                          "attention_bf3_share": attn_bf3_share,
                          "traffic": traffic, "traffic_step": traffic_step, "mfma_util": mfma_util,
+                         # the same three as scalars (a record that flattens the line keeps them), or "stale" when the committed PMC
+                         # pass was taken on another build of the library than the one this process loaded
+                         "traffic_ratio_step": ((traffic_step["bytes_per_step"] / traffic_step["algorithmic_bytes_per_step"])
+                                                if (traffic_step and traffic_step.get("algorithmic_bytes_per_step")) else
+                                                ("stale" if stale else None)),
+                         "mfma_util_pct": mfma_util["percent"] if mfma_util else ("stale" if stale else None),
+                         "dom_clock_GHz": mfma_util["effective_clock_GHz"] if mfma_util else ("stale" if stale else None),
+                         "pmc_library_sha256": lib_sha[:16], "pmc_stale_files": stale or None,
                          "launches_per_step": conv_launches / max(1, args.steps),
                          "gflop_per_launch": flops_per_launch / 1e9, "avg_launch_ms": avg_launch_ms,
                          "share_of_step_time": conv_ms / (elapsed * 1e3) if elapsed > 0 else None,

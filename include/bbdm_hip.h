@@ -517,6 +517,14 @@ int bbdm_gemm_h2p_f32(const void* a_planes, const void* b_planes, const float* b
 int bbdm_gemm_h2p_splitk_f32(const void* a_planes, const void* b_planes, const float* bound_a, const float* bound_b, float* M, int ldo,
                              int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream);
 int bbdm_h2_gn_bounds_f32(const void* table, int nlayers, const float* film, int film_ld, int N, float* bounds, void* stream);
+/* *bound = max over the N x G cells of `stats` of sqrt(sum of squares): >= max |x| of the tensor the statistics were taken of (its raw
+ * values: the skip projections read the block input itself).  Launch it after the producers that fill `stats`. */
+int bbdm_h2_stats_bound_f32(const bbdm_stats_t* stats, int N, int G, float* bound, void* stream);
+/* The wide 1x1 convolutions / Linears of bbdm_conv1x1_bf3q_f32 on the fp16-pair planes (openaimodel.py:244,307; same arguments):
+ * x is read as it lies in HBM and split into two fp16 halves under xbound's scale by the waves between their MFMAs;
+ * b_planes = bbdm_gemm_h2p_pack_b_f32(batch = 1) of bbdm_conv_pack_weight_f32(ks = 1)'s buffer under wbound = its bbdm_absmax_f32. */
+int bbdm_conv1x1_h2q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr, float* out,
+                         int ldo, long long pixels, int CinPad, int Cout, const float* xbound, const float* wbound, void* stream);
 float bbdm_winograd_input_gain(int m);
 int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
                                 int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* vbound, void* stream);

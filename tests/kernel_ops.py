@@ -695,3 +695,25 @@ def conv3x3_winograd_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[tor
               None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[-1], out.data_ptr(), cout, 0,
               N, H, W, cout, st)
     return out
+
+
+def conv1x1_h2q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0, xbound: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """:func:`conv1x1_bf3q` on the fp16-pair planes (bbdm_conv1x1_h2q_f32): ``xbound`` a device float >= max |x| (default: the measured
+    maximum of the whole buffer), the weights under their exact maximum."""
+    _chk(x, w, bias, residual)
+    cout = w.shape[0]
+    cin = cin or w.shape[1]
+    lib = _lib.load()
+    pf = torch.empty(lib.bbdm_conv_packed_floats(cout, cin, 1), dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), pf.data_ptr(), cout, w.shape[1], cin, 1, _st(x))
+    wb = absmax(pf)
+    bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(1, cin, cout), dtype=torch.uint8, device=x.device)
+    _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), wb.data_ptr(), 1, cin, cout, _st(x))
+    xb = absmax(x) if xbound is None else xbound
+    if out is None:
+        out = torch.empty(x.shape[0], cout, dtype=torch.float32, device=x.device)
+    _lib.call("bbdm_conv1x1_h2q_f32", x.data_ptr() + 4 * x_off, x.shape[1], bp.data_ptr(), None if bias is None else bias.data_ptr(),
+              None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1],
+              out.data_ptr(), out.shape[1], x.shape[0], cin, cout, xb.data_ptr(), wb.data_ptr(), _st(x))
+    return out

@@ -174,6 +174,15 @@ def test_gemm_h2p_kernel_variants(kernel, Cin):
     K.test_gemm_h2p_kernel_variants(CPU, kernel, Cin)
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (300, 48, 256, True), (96, 16, 8, False)])
+def test_conv1x1_h2q(pixels, Cin, Cout, res):
+    K.test_conv1x1_h2q(CPU, pixels, Cin, Cout, res)
+
+
+def test_h2_stats_bound():
+    K.test_h2_stats_bound(CPU)
+
+
 def test_gemm_h2p_bound_is_respected():
     K.test_gemm_h2p_bound_is_respected(CPU)
 

@@ -829,6 +829,49 @@ def test_conv1x1_bf3q_bitwise(dev, pixels, Cin, Cout, res):
         assert torch.equal(out, out0), (out - out0).abs().max()
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(256, 32, 40, False), (512, 64, 132, True), (1024, 1536, 512, True), (768, 48, 256, False),
+                                                 (2080, 256, 1024, True), (96, 16, 8, False), (300, 112, 256, True)])
+def test_conv1x1_h2q(dev, pixels, Cin, Cout, res):
+    """The wide 1x1 convolutions on the fp16-pair planes (gemm_bf3q_pipe_kernel<NP = 2>: the waves scale and split the fp32 activation
+    into two fp16 halves between their MFMAs; 256-row tiles, 256- and 128-column tiles, ragged rows, K from one chunk, bias + in-place
+    residual, a channel slice of a wider buffer) against fp64, next to bbdm_conv1x1_bf3q_f32 on the same operands; and under a bound 512x
+    the measured maximum -- what the statistics bound (bbdm_h2_stats_bound_f32) may hand it."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(pixels + Cin)
+    wide = torch.randn(pixels, Cin + 16, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(pixels, Cout, generator=g) if res else None
+    ref = wide[:, 16:].double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    buf = r.clone().to(dev) if res else None
+    out = ops.conv1x1_h2q(wide.to(dev), w.to(dev), b.to(dev), residual=buf, out=buf, cin=Cin, x_off=16).cpu()
+    buf3 = r.clone().to(dev) if res else None
+    out3 = ops.conv1x1_bf3q(wide.to(dev), w.to(dev), b.to(dev), residual=buf3, out=buf3, cin=Cin, x_off=16).cpu()
+    loose = torch.full((1,), 512.0 * float(wide.abs().max()), device=dev)
+    buf2 = r.clone().to(dev) if res else None
+    out2 = ops.conv1x1_h2q(wide.to(dev), w.to(dev), b.to(dev), residual=buf2, out=buf2, cin=Cin, x_off=16, xbound=loose).cpu()
+    e, e3, e2 = rel_err(out, ref), rel_err(out3, ref), rel_err(out2, ref)
+    print(f"conv1x1 [{pixels} x {Cin} -> {Cout}]: rel err vs fp64 h2 {e:.2e} (bound 512x: {e2:.2e}), bf16x3 {e3:.2e}")
+    assert e < 3e-6 and e2 < 3e-6
+
+
+def test_h2_stats_bound(dev):
+    """bbdm_h2_stats_bound_f32: the largest root-sum-of-squares over the (image, group) cells of a GroupNorm accumulator bounds the raw
+    tensor (also with one 1000x outlier), and is at most sqrt(values per group) above its maximum."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(3)
+    N, H, W, C = 3, 12, 10, 64
+    x = torch.randn(N, H, W, C, generator=g) * 2.5 + 0.7
+    x[1, 3, 4, 17] = 3000.0
+    xd = x.to(dev)
+    stats = ops.groupnorm_stats(xd)
+    bound = torch.zeros(1, device=dev)
+    _lib.call("bbdm_h2_stats_bound_f32", stats.data_ptr(), N, 32, bound.data_ptr(), ops._st(xd))
+    want = float(x.double().reshape(N, H * W, 32, C // 32).pow(2).sum((1, 3)).max().sqrt())
+    assert float(x.abs().max()) <= float(bound) and abs(float(bound) - want) <= 1e-5 * want, (float(bound), want)
+
+
 @pytest.mark.parametrize("m,up,silu,film,N,H,W,C", [(2, 0, 1, True, 3, 4, 4, 64), (4, 0, 1, True, 2, 16, 16, 128), (4, 1, 1, False, 2, 16, 8, 64),
                                                     (6, 0, 0, True, 2, 14, 20, 192), (2, 1, 1, True, 5, 8, 8, 256)])
 def test_winograd_input_forms_groupnorm_coefficients_bitwise(dev, m, up, silu, film, N, H, W, C):

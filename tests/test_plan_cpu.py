@@ -137,11 +137,11 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             vb = i[-1]                          # the bound of the transformed tensor: a slot of the plan, the same one in both launches
             assert isinstance(vb, unet._Plan._H2Ref) and g[-2] is vb
             if k >= len(plan.ops):              # data gradient: dY under its measured maximum -- the launch before the transform takes it
-                assert training and -plan._h2_dy_slots <= vb.k < 0 and i[4] is None
+                assert training and vb.kind == "dy" and 0 <= vb.k < plan._h2_dy_slots and i[4] is None
                 pn, pa = ops[k - 1]
                 assert pn == "bbdm_absmax_rows_f32" and pa[0] is i[1] and pa[-1] is vb and pa[3] == cin
             else:                               # forward: the GroupNorm bound of this layer's input
-                assert 0 <= vb.k < len(plan._h2_layers)
+                assert vb.kind == "gn" and 0 <= vb.k < len(plan._h2_layers)
                 gam, bet, fo, C, z = plan._h2_layers[vb.k]
                 assert C == cin and z >= 1.0 and gam.numel() == cin and (fo == -1 or 0 <= fo <= plan.film_total - 2 * cin)
             if in_entry.endswith("_tr_f32"):    # training forward: the transposed copy stays bf16x3 (the weight gradient's operand)

@@ -11,6 +11,19 @@ import sqlite3
 import sys
 
 
+
+def library_stamp():
+    """sha256 of the kernel library these counters were taken on (bench.py shows the counter fields only while it matches the library it
+    loaded: a PMC file of another build is reported as "stale", round-5 verdict item 6)."""
+    import hashlib
+    import os
+    path = os.environ.get("BBDM_HIP_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bbdm_amd", "libbbdm_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def main():
     data, order = {}, []
     dur = {}
@@ -63,7 +76,7 @@ def main():
             print(f"| {k} | {n} | {us:.1f} | " + " | ".join(row + [("" if v is None else f"{v:.3g}") for v in dv]) + " |")
     if as_json:
         import json
-        json.dump({"units": "per-launch means; GRBM_GUI_ACTIVE summed over the 8 XCDs, SQ_* summed over the chip; MfmaUtil% = "
+        json.dump({"library_sha256": library_stamp(), "units": "per-launch means; GRBM_GUI_ACTIVE summed over the 8 XCDs, SQ_* summed over the chip; MfmaUtil% = "
                             "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)", "kernels": jout}, sys.stdout, indent=1)
 
 

@@ -16,6 +16,18 @@ import sqlite3
 import sys
 
 
+def library_stamp():
+    """sha256 of the kernel library these counters were taken on (bench.py shows the counter fields only while it matches the library it
+    loaded: a PMC file of another build is reported as "stale", round-5 verdict item 6)."""
+    import hashlib
+    import os
+    path = os.environ.get("BBDM_HIP_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bbdm_amd", "libbbdm_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
     out = {}
@@ -49,7 +61,7 @@ def main():
         totals = {"steps_profiled": steps, "all_kernels_bytes": allb, "one_time_weight_packing_bytes": packb,
                   "bytes_per_step_excl_packing": (allb - packb) / steps,
                   "algorithmic_bytes_per_step": float(sys.argv[5]) if len(sys.argv) > 5 else None}
-    json.dump({"command": cmd, "totals": totals,
+    json.dump({"command": cmd, "library_sha256": library_stamp(), "totals": totals,
                "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; fetch_bytes_corrected = 2 x FETCH_SIZE x 1024 (gfx950 "
                         "half-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported. They count L2<->fabric "
                         "requests: Infinity-Cache (MALL) hits are INCLUDED, so this is an upper bound on HBM bytes",
