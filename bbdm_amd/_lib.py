@@ -115,7 +115,15 @@ SIGNATURES = {
     "bbdm_absmax_f32": (c_int, [_P, ctypes.c_longlong, _P, _P]),
     "bbdm_absmax_rows_f32": (c_int, [_P, c_int, ctypes.c_longlong, c_int, _P, _P]),
     "bbdm_winograd_input_h2p_tr_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
-    "bbdm_gemm_h2p_pack_b_f32": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
+    "bbdm_winograd_input_h2p_tr2_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "bbdm_winograd_dy_transform_h2p_f32": (c_int, [c_int, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "bbdm_winograd_dy_gain": (c_float, [c_int]),
+    "bbdm_gemm_h2p_tn_at_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
+    "bbdm_gemm_h2p_tn_bt_bytes": (c_size_t, [c_int, ctypes.c_longlong, c_int]),
+    "bbdm_gemm_h2p_tn_f32": (c_int, [_P, _P, _P, c_int, ctypes.c_longlong, c_int, c_int, _P, c_float, _P, c_float, _P]),
+    "bbdm_gemm_h2p_pack_b_f32": (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, _P]),
+    "bbdm_winograd_pack_weight_h2p_f32": (c_int, [c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "bbdm_winograd_g_gain": (c_float, [c_int]),
     "bbdm_gemm_h2p_split_rows_f32": (c_int, [_P, c_int, _P, _P, c_int, ctypes.c_longlong, c_int, _P]),
     "bbdm_gemm_h2p_f32": (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, ctypes.c_longlong, c_int, c_int, _P]),
     "bbdm_gemm_h2p_splitk_f32": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, ctypes.c_longlong, ctypes.c_longlong, c_int, c_int, c_int, _P]),

@@ -112,8 +112,9 @@ extern "C" int bbdm_gemm_bf3p_f32(const void* a_planes, const void* b_planes, co
                                   float* M, int ldo, int batch, long long T, int CinPad, int Cout, void* stream);
 
 // gemm_bf3p.hip: the fp16-pair GEMM whose A planes were scaled by (bound of the transform's input) x gain_a (winograd.hip)
-int bbdm_gemm_h2p_gain_splitk(const void* a_planes, const void* b_planes, const float* bound_a, float gain_a, const float* bound_b, float* M,
-                              int ldo, int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream);
+int bbdm_gemm_h2p_gain_splitk(const void* a_planes, const void* b_planes, const float* bound_a, float gain_a, const float* bound_b,
+                              float gain_b, float* M, int ldo, int batch, long long T, long long rows, int CinPad, int Cout, int splits,
+                              void* stream);
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 // hardware v_exp_f32 + v_rcp_f32 (~2 ulp; __frcp_rn would expand to the full IEEE division sequence): for kernels where the exact-division form above would make an HBM-bound pass

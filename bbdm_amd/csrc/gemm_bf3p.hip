@@ -56,6 +56,7 @@ struct Bf3pArgs {
     const float* hA = nullptr;
     const float* hB = nullptr;
     float gA = 1.f;          // *hA bounds the tensor the A planes were FORMED from; gA = the gain of that transform (Winograd: wino_input_gain)
+    float gB = 1.f;          // ... likewise for B (the weight gradient's dM = A dY A^T under the bound of dY: wino_dy_gain)
 };
 
 __device__ __forceinline__ int xcd_block_p(int nblk, int x, int off) {
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
     // fp16-pair planes: 2^-(eA + eB), read once at the top (a wave-uniform value in an SGPR; before any hand-written LDS read is in flight)
     float descale = 1.f;
     if constexpr (NP == 2) {
-        const float d = h2_pow2(-(h2_exp_of_bound(*a.hA * a.gA) + h2_exp_of_bound(*a.hB)));
+        const float d = h2_pow2(-(h2_exp_of_bound(*a.hA * a.gA) + h2_exp_of_bound(*a.hB * a.gB)));
         descale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(d)));
     }
     float bv[2];
@@ -507,7 +508,7 @@ __global__ void __launch_bounds__(WM * WN * 64, NP == 2 && WM == 4 ? 4 : 3) gemm
     // fp16-pair planes: the scale of A and the factor the accumulators are re-scaled by (wave-uniform; read before any LDS read is in flight)
     float ascale = 1.f, descale = 1.f;
     if constexpr (NP == 2) {
-        const int ea = h2_exp_of_bound(*a.hA * a.gA), eb = h2_exp_of_bound(*a.hB);
+        const int ea = h2_exp_of_bound(*a.hA * a.gA), eb = h2_exp_of_bound(*a.hB * a.gB);
         ascale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(h2_pow2(ea))));
         descale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(h2_pow2(-(ea + eb)))));
     }
@@ -1047,7 +1048,7 @@ int fwd_splits(int batch, long long rows, int CinPad, int Cout) {
 // np = planes per operand: 3 (bf16x3) or 2 (the fp16 pair of h2_split.h; hA / hB = the bounds the operands were scaled by).
 int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, const float* residual, int ldr, float* M, int ldo,
                  int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream, int np = 3,
-                 const float* hA = nullptr, const float* hB = nullptr, float gA = 1.f) {
+                 const float* hA = nullptr, const float* hB = nullptr, float gA = 1.f, float gB = 1.f) {
     BBDM_REQUIRE(a_planes && b_planes && M && batch > 0, "gemm_bf3p: null pointer / bad batch");
     BBDM_REQUIRE(np == 3 || (np == 2 && hA && hB), "gemm_h2p: the fp16-pair planes need the bounds of both operands");
     BBDM_REQUIRE(bbdm_gemm_bf3p_supported(T, CinPad, Cout), "gemm_bf3p: T=%lld CinPad=%d Cout=%d unsupported (T %% 256, CinPad %% 16)",
@@ -1066,7 +1067,7 @@ int bf3p_forward(const void* a_planes, const void* b_planes, const float* bias, 
     a.tilesN = CoutPad / 128;
     a.az = (size_t)T * CinPad * 2 * np; a.bz = (size_t)CoutPad * CinPad * 2 * np; a.mz = (size_t)T * ldo; a.rz = (size_t)T * ldr;
     a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
-    a.hA = hA; a.hB = hB; a.gA = gA;
+    a.hA = hA; a.hB = hB; a.gA = gA; a.gB = gB;
     a.kps = (a.nchunks + splits - 1) / splits;
     a.ksplits = (a.nchunks + a.kps - 1) / a.kps;
     BBDM_REQUIRE(a.ksplits == splits, "gemm_bf3p: %d splits of %d chunks leave an empty split", splits, a.nchunks);
@@ -1186,8 +1187,8 @@ __global__ void __launch_bounds__(256) h2_absmax_rows_kernel(const float* __rest
 }
 // bf3p_pack_b_kernel for the fp16 pair
 __global__ void h2p_pack_b_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, const float* __restrict__ bound,
-                                  size_t batch_chunks, int nchunks, int CoutPad) {
-    const float sc = h2_pow2(h2_exp_of_bound(*bound));
+                                  float gain, size_t batch_chunks, int nchunks, int CoutPad) {
+    const float sc = h2_pow2(h2_exp_of_bound(*bound * gain));
     const size_t pairs = batch_chunks * CoutPad * (KC / 2);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < pairs; i += (size_t)gridDim.x * blockDim.x) {
         const int kp = (int)(i % (KC / 2));
@@ -1245,15 +1246,15 @@ extern "C" int bbdm_absmax_rows_f32(const float* x, int ldx, long long rows, int
     BBDM_CHECK_LAUNCH("absmax_rows");
     return BBDM_OK;
 }
-extern "C" int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, int batch, int CinPad, int Cout,
-                                        void* stream) {
+extern "C" int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, float gain, int batch, int CinPad,
+                                        int Cout, void* stream) {
     BBDM_REQUIRE(packed_f32 && b_planes && bound && batch > 0 && CinPad > 0 && CinPad % KC == 0 && Cout > 0, "gemm_h2p_pack_b: bad args");
     const int CoutPad = cdiv(Cout, 128) * 128, nchunks = CinPad / KC;
     const size_t pairs = (size_t)batch * nchunks * CoutPad * (KC / 2);
     size_t blocks = (pairs + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(h2p_pack_b_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, packed_f32,
-                       (unsigned char*)b_planes, bound, (size_t)batch * nchunks, nchunks, CoutPad);
+                       (unsigned char*)b_planes, bound, gain, (size_t)batch * nchunks, nchunks, CoutPad);
     BBDM_CHECK_LAUNCH("gemm_h2p_pack_b");
     return BBDM_OK;
 }
@@ -1283,10 +1284,11 @@ extern "C" int bbdm_gemm_h2p_splitk_f32(const void* a_planes, const void* b_plan
                         bound_b);
 }
 // (winograd.hip: the A planes were scaled by the bound of the transform's INPUT times its gain)
-int bbdm_gemm_h2p_gain_splitk(const void* a_planes, const void* b_planes, const float* bound_a, float gain_a, const float* bound_b, float* M,
-                              int ldo, int batch, long long T, long long rows, int CinPad, int Cout, int splits, void* stream) {
+int bbdm_gemm_h2p_gain_splitk(const void* a_planes, const void* b_planes, const float* bound_a, float gain_a, const float* bound_b,
+                              float gain_b, float* M, int ldo, int batch, long long T, long long rows, int CinPad, int Cout, int splits,
+                              void* stream) {
     return bf3p_forward(a_planes, b_planes, nullptr, nullptr, 0, M, ldo, batch, T, rows, CinPad, Cout, splits, stream, 2, bound_a,
-                        bound_b, gain_a);
+                        bound_b, gain_a, gain_b);
 }
 
 // ---- C = A^T B with the contraction over the ROWS of both operands (the Winograd-domain weight gradient dU_xi = V_xi^T dM_xi, tiles
@@ -1345,11 +1347,13 @@ extern "C" int bbdm_gemm_bf3p_tn_splits(int batch, long long K, int M, int N) {
     return tn_split(batch, K, M, N).splits;
 }
 
-extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N,
-                                     void* stream) {
+namespace {
+int bf3p_tn(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N, void* stream, int np,
+            const float* hA, float gA, const float* hB, float gB) {
     BBDM_REQUIRE(at_planes && bt_planes && C && batch > 0, "gemm_bf3p_tn: null pointer / bad batch");
     BBDM_REQUIRE(bbdm_gemm_bf3p_tn_supported(K, M, N), "gemm_bf3p_tn: K=%lld M=%d N=%d unsupported (K %% 256, M %% 32, N %% 4)", K, M, N);
     BBDM_REQUIRE((((uintptr_t)at_planes | (uintptr_t)bt_planes) & 15) == 0 && ((uintptr_t)C & 3) == 0, "gemm_bf3p_tn: alignment");
+    BBDM_REQUIRE(np == 3 || (np == 2 && hA && hB), "gemm_h2p_tn: the fp16-pair planes need the bounds of both operands");
     const TnSplit sp = tn_split(batch, K, M, N);
     Bf3pArgs a;
     a.A = (const unsigned char*)at_planes; a.B = (const unsigned char*)bt_planes; a.M = C;
@@ -1357,18 +1361,40 @@ extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_plane
     a.rgs = (M + 31) / 32;
     const int NPad = cdiv(N, 128) * 128;
     a.tilesN = NPad / 128;
-    a.az = (size_t)((M + 31) / 32 * 32) * K * 6; a.bz = (size_t)NPad * K * 6; a.mz = (size_t)M * N; a.rz = 0;
+    a.az = (size_t)((M + 31) / 32 * 32) * K * 2 * np; a.bz = (size_t)NPad * K * 2 * np; a.mz = (size_t)M * N; a.rz = 0;
     a.ldo = N; a.ldr = 0; a.bias = nullptr; a.res = nullptr;
     a.ksplits = sp.splits; a.kps = sp.kps; a.P = batch;
+    a.hA = hA; a.hB = hB; a.gA = gA; a.gB = gB;
     const int nb = batch * sp.splits;
     const int by_batch_env = 1;
     a.batch = nb;
     a.by_batch = (by_batch_env && nb >= 8) ? 1 : 0;              // (the pipe kernel returns early for the padding entries of a batch % 8 != 0)
     hipStream_t st = (hipStream_t)stream;
-    const int rc = sp.wn == 4 ? bf3p_launch<4, 4, false>(a, nb, st) : bf3p_launch<4, 2, false>(a, nb, st);
+    int rc;
+    if (np == 3) rc = sp.wn == 4 ? bf3p_launch<4, 4, false>(a, nb, st) : bf3p_launch<4, 2, false>(a, nb, st);
+    else rc = sp.wn == 4 ? bf3p_launch<4, 4, false, 2, 2>(a, nb, st) : bf3p_launch<4, 2, false, 2, 2>(a, nb, st);
     if (rc != BBDM_OK) return rc;
     BBDM_CHECK_LAUNCH("gemm_bf3p_tn");
     return BBDM_OK;
+}
+}  // namespace
+
+extern "C" int bbdm_gemm_bf3p_tn_f32(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N,
+                                     void* stream) {
+    return bf3p_tn(at_planes, bt_planes, C, batch, K, M, N, stream, 3, nullptr, 1.f, nullptr, 1.f);
+}
+// ... on the fp16-pair planes (round 6; 4 B per element: bbdm_gemm_h2p_tn_at_bytes / _bt_bytes; same split rule): the operands were
+// scaled by bound_a x gain_a and bound_b x gain_b (the Winograd-domain weight gradient: the GroupNorm bound of the layer's input x
+// bbdm_winograd_input_gain(m), the measured maximum of dY x bbdm_winograd_dy_gain(m))
+extern "C" size_t bbdm_gemm_h2p_tn_at_bytes(int batch, long long K, int M) {
+    return (size_t)batch * (size_t)((M + 31) / 32 * 32) * (size_t)((K + 255) / 256 * 256) * 4;
+}
+extern "C" size_t bbdm_gemm_h2p_tn_bt_bytes(int batch, long long K, int N) {
+    return (size_t)batch * (size_t)(cdiv(N, 128) * 128) * (size_t)((K + 255) / 256 * 256) * 4;
+}
+extern "C" int bbdm_gemm_h2p_tn_f32(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N,
+                                    const float* bound_a, float gain_a, const float* bound_b, float gain_b, void* stream) {
+    return bf3p_tn(at_planes, bt_planes, C, batch, K, M, N, stream, 2, bound_a, gain_a, bound_b, gain_b);
 }
 
 // ---- fp32 A operand on the pipelined kernel (gemm_bf3q_pipe_kernel) ---------------------------------------------------------------------

@@ -304,16 +304,16 @@ __global__ void __launch_bounds__(256) winograd_input6_kernel(const float* __res
 // LDS transpose read: the block is staged row-major ([tile][16 ch] = 32-B rows) in the wave's own scratch and a 16-lane group reads
 // it back with ds_read_b64_tr_b16 -- lane i of the group receives channel i, 4 tiles per read.  Four groups = four (xi, plane)
 // blocks per pass; AL / 2 transform points per round so that the scratch stays inside the wave's 8 x 64 x 8 B region.
-template <int AL>
-__device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][3], unsigned char* scratch, int lane, unsigned char* dst_xi0,
+template <int AL, int NPL = 3>
+__device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][NPL], unsigned char* scratch, int lane, unsigned char* dst_xi0,
                                                  size_t plane_t, int chunk, int tile0, int tchunks) {
     typedef short v4s __attribute__((ext_vector_type(4)));
-    constexpr int HALF = AL / 2, COMBOS = 3 * HALF, PITCH = 256 + 64;       // bytes between blocks (+64: stagger the bank rows)
+    constexpr int HALF = AL / 2, COMBOS = NPL * HALF, PITCH = 256 + 64;     // bytes between blocks (+64: stagger the bank rows)
     static_assert(COMBOS * PITCH <= AL * 64 * 8, "transposition scratch exceeds the wave's LDS region");
     const int grp = lane >> 4, i16 = lane & 15;
     const int c = chunk * KC + i16;                                           // this lane's channel in the transposed store
     // unit (c / 32, t / 16), k-half (t % 16) / 8, row c % 32
-    unsigned char* dst = dst_xi0 + (((size_t)(c >> 5) * tchunks + (tile0 >> 4)) * 3) * 1024 + ((tile0 >> 3) & 1) * 512 + (c & 31) * 16;
+    unsigned char* dst = dst_xi0 + (((size_t)(c >> 5) * tchunks + (tile0 >> 4)) * NPL) * 1024 + ((tile0 >> 3) & 1) * 512 + (c & 31) * 16;
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         // (the wave runs in lockstep: every lane has read its row of the intermediate / the previous round's blocks before this
@@ -322,8 +322,8 @@ __device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][3], un
 #pragma unroll
         for (int q = 0; q < HALF; ++q)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
-                *reinterpret_cast<unsigned*>(scratch + (q * 3 + p) * PITCH + lane * 4) = pl[round * HALF + q][p];
+            for (int p = 0; p < NPL; ++p)
+                *reinterpret_cast<unsigned*>(scratch + (q * NPL + p) * PITCH + lane * 4) = pl[round * HALF + q][p];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < (COMBOS + 3) / 4; ++it) {
@@ -334,7 +334,7 @@ __device__ __forceinline__ void store_transposed(const unsigned (&pl)[AL][3], un
             const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(a + 4 * 32));
             typedef short v8s __attribute__((ext_vector_type(8)));
             const v8s both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const int q = cc / 3, p = cc - 3 * q;
+            const int q = cc / NPL, p = cc - NPL * q;
             if (combo < COMBOS)
                 *reinterpret_cast<uint4*>(dst + (size_t)(round * HALF + q) * plane_t + p * 1024) = __builtin_bit_cast(uint4, both);
         }
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
                                                                               unsigned char* __restrict__ Vt, size_t plane_t,
                                                                               int tchunks, const FastDiv dTW, const FastDiv dTH,
                                                                               const FastDiv dCH, const GnFold gn,
-                                                                              const float* __restrict__ hbound) {
+                                                                              const float* __restrict__ hbound, int vt_h2 = 0) {
     static_assert(NPL == 3 || (NPL == 2 && !F32), "the fp16-pair planes have no fp32 form");
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];
@@ -521,12 +521,21 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
             }
             if constexpr (TR) {
                 // training forward: the forward GEMM reads the fp16-pair planes above; the weight gradient contracts the TRANSPOSED copy
-                // with dM, whose range nothing bounds -- that GEMM stays on the exact bf16 split, and so does this copy
-                unsigned pl[AL][3];
+                // with dM.  vt_h2 (UNetModel.gemm_h2_train = 3): that GEMM runs on the fp16 pair as well (dM under the measured maximum
+                // of dY) and the copy holds the same two planes, transposed; else it stays on the exact bf16 split, and so does the copy
+                if (vt_h2) {
+                    unsigned pl[AL][2];
 #pragma unroll
-                for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
-                store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane,
-                                     Vt + (size_t)(i * AL) * plane_t, plane_t, chunk, (int)(tile - tl), tchunks);
+                    for (int jj = 0; jj < AL; ++jj) h2_split2(row[jj].x * hs, row[jj].y * hs, pl[jj][0], pl[jj][1]);
+                    store_transposed<AL, 2>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane,
+                                            Vt + (size_t)(i * AL) * plane_t, plane_t, chunk, (int)(tile - tl), tchunks);
+                } else {
+                    unsigned pl[AL][3];
+#pragma unroll
+                    for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
+                    store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane,
+                                         Vt + (size_t)(i * AL) * plane_t, plane_t, chunk, (int)(tile - tl), tchunks);
+                }
             }
             return;
         }
@@ -560,11 +569,12 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_input_split2_kernel(co
 // fp32 plane the bias gradient needs -- xi = (1, 1): row 1 of A is all ones, so it holds the tile sums of dY -- goes to dm11[tile][C].
 // m = 8 has no transform point 1 (winograd_math.h): there the waves of phase A leave their column sums in LDS and wave 1 adds them in
 // column order -- dm11 holds the tile sums of dY for every m.
-template <int MO>
+// NPL = 2 (round 6): the fp16 pair under the scale of dybound x wino_dy_gain(m) (dybound: the measured maximum of dY).
+template <int MO, int NPL = 3>
 __global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const float* __restrict__ dy, int ld,
                                                                           unsigned char* __restrict__ dMt, float* __restrict__ dm11,
                                                                           int N, int H, int W, int C, int nchunks, long long T, int TG,
-                                                                          size_t plane_t, int tchunks) {
+                                                                          size_t plane_t, int tchunks, const float* __restrict__ dybound) {
     constexpr int AL = MO + 2;
     __shared__ float2 lds[AL * AL * 64];                 // [i][j < m][unit] intermediates; later each wave's transposition scratch
     __shared__ float2 csum[MO == 8 ? MO * 64 : 1];       // m = 8: the column sums of the window (the bias gradient's tile sums)
@@ -624,11 +634,20 @@ __global__ void __launch_bounds__((MO + 2) * 64) winograd_dy_split_kernel(const 
         } else {
             if (i == 1 && tile < T && c < C) *reinterpret_cast<float2*>(dm11 + (size_t)tile * C + c) = row[1];
         }
-        unsigned pl[AL][3];
+        if constexpr (NPL == 2) {
+            const float hs = h2_pow2(h2_exp_of_bound(*dybound * wino_dy_gain(MO)));
+            unsigned pl[AL][2];
 #pragma unroll
-        for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
-        store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane, dMt + (size_t)(i * AL) * plane_t,
-                             plane_t, chunk, (int)(tile - tl), tchunks);
+            for (int jj = 0; jj < AL; ++jj) h2_split2(row[jj].x * hs, row[jj].y * hs, pl[jj][0], pl[jj][1]);
+            store_transposed<AL, 2>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane, dMt + (size_t)(i * AL) * plane_t,
+                                    plane_t, chunk, (int)(tile - tl), tchunks);
+        } else {
+            unsigned pl[AL][3];
+#pragma unroll
+            for (int jj = 0; jj < AL; ++jj) split2(row[jj].x, row[jj].y, pl[jj][0], pl[jj][1], pl[jj][2]);
+            store_transposed<AL>(pl, reinterpret_cast<unsigned char*>(lds + (size_t)i * AL * 64), lane, dMt + (size_t)(i * AL) * plane_t,
+                                 plane_t, chunk, (int)(tile - tl), tchunks);
+        }
     }
 }
 
@@ -951,13 +970,16 @@ __global__ void winograd_weight72_kernel(const float* __restrict__ w4, float* __
 // channels per thread, each U value pair split exactly and stored as bbdm_gemm_bf3p_pack_b_f32 stores it -- the same planes (up to
 // the compiler's FMA contraction of G g G^T in this kernel body: <= 1 ulp of U) without the fp32 U tensor in between (4x the weights for m = 4, written and read once per optimizer step and direction: the two
 // launches were 6 ms of every fourth training micro-step).
-template <int MO>
+// NPL = 2 (round 6): the fp16 pair under the scale of wbound x wino_g_gain(m) -- wbound: a device float >= the filter's largest tap.
+template <int MO, int NPL = 3>
 __global__ void winograd_weight_planes_kernel(const float* __restrict__ w, unsigned char* __restrict__ dst, int Cout, int Cin,
-                                              int CoutPad, int nchunks, int dgrad) {
+                                              int CoutPad, int nchunks, int dgrad, const float* __restrict__ wbound = nullptr) {
     constexpr int AL = MO + 2;
     const int O = dgrad ? Cin : Cout, I = dgrad ? Cout : Cin;
     const size_t pairs = (size_t)nchunks * CoutPad * (KC / 2);
-    const size_t xi_stride = (size_t)(CoutPad / 32) * nchunks * 3 * 1024;
+    const size_t xi_stride = (size_t)(CoutPad / 32) * nchunks * NPL * 1024;
+    float hs = 1.f;
+    if constexpr (NPL == 2) hs = h2_pow2(h2_exp_of_bound(*wbound * wino_g_gain(MO)));
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < pairs; idx += (size_t)gridDim.x * blockDim.x) {
         const int kp = (int)(idx % (KC / 2));
         size_t t = idx / (KC / 2);
@@ -983,7 +1005,7 @@ __global__ void winograd_weight_planes_kernel(const float* __restrict__ w, unsig
                 for (int r = 0; r < AL; ++r) a[e][r][sx] = u[r];
             }
         }
-        unsigned char* d = dst + (((size_t)(o / 32) * nchunks + chunk) * 3) * 1024 + ((kp * 2) >> 3) * 512 + (o & 31) * 16 +
+        unsigned char* d = dst + (((size_t)(o / 32) * nchunks + chunk) * NPL) * 1024 + ((kp * 2) >> 3) * 512 + (o & 31) * 16 +
                            ((kp * 2) & 7) * 2;
 #pragma unroll
         for (int r = 0; r < AL; ++r) {
@@ -992,12 +1014,19 @@ __global__ void winograd_weight_planes_kernel(const float* __restrict__ w, unsig
             g_transform<MO>(a[1][r], u1);
 #pragma unroll
             for (int sx = 0; sx < AL; ++sx) {
-                unsigned p1, p2, p3;
-                split2((float)u0[sx], (float)u1[sx], p1, p2, p3);
                 unsigned char* q = d + (size_t)(r * AL + sx) * xi_stride;
-                *reinterpret_cast<unsigned*>(q) = p1;
-                *reinterpret_cast<unsigned*>(q + 1024) = p2;
-                *reinterpret_cast<unsigned*>(q + 2048) = p3;
+                if constexpr (NPL == 2) {
+                    unsigned p1, p2;
+                    h2_split2((float)u0[sx] * hs, (float)u1[sx] * hs, p1, p2);
+                    *reinterpret_cast<unsigned*>(q) = p1;
+                    *reinterpret_cast<unsigned*>(q + 1024) = p2;
+                } else {
+                    unsigned p1, p2, p3;
+                    split2((float)u0[sx], (float)u1[sx], p1, p2, p3);
+                    *reinterpret_cast<unsigned*>(q) = p1;
+                    *reinterpret_cast<unsigned*>(q + 1024) = p2;
+                    *reinterpret_cast<unsigned*>(q + 2048) = p3;
+                }
             }
         }
     }
@@ -1086,8 +1115,8 @@ extern "C" int bbdm_winograd_pack_weight_f32(int m, const float* w_oihw, float* 
 
 // ... with the B planes of gemm_bf3p.hip as the destination (= bbdm_winograd_pack_weight_f32 + bbdm_gemm_bf3p_pack_b_f32 up to FMA contraction;
 // b_planes: bbdm_gemm_bf3p_b_bytes((m + 2)^2, InPad, O) bytes, InPad % 16 == 0)
-extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
-                                                  void* stream) {
+static int winograd_pack_planes(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad, const float* wbound,
+                                void* stream) {
     BBDM_WINO_M8(m);
     BBDM_REQUIRE(w_oihw && b_planes && Cout > 0 && Cin > 0 && InPad % KC == 0, "winograd_pack_bf3p: bad args (InPad %% 16)");
     BBDM_REQUIRE(InPad >= (dgrad ? Cout : Cin), "winograd_pack_bf3p: InPad too small");
@@ -1098,21 +1127,32 @@ extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, vo
     int blocks = (int)((pairs + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     unsigned char* d = (unsigned char*)b_planes;
-    if (m == 2)
-        hipLaunchKernelGGL(winograd_weight_planes_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
-                           CoutPad, nchunks, dgrad);
-    else if (m == 4)
-        hipLaunchKernelGGL(winograd_weight_planes_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
-                           CoutPad, nchunks, dgrad);
-    else if (m == 8)
-        hipLaunchKernelGGL(winograd_weight_planes_kernel<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
-                           CoutPad, nchunks, dgrad);
-    else
-        hipLaunchKernelGGL(winograd_weight_planes_kernel<6>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, Cin,
-                           CoutPad, nchunks, dgrad);
-    BBDM_CHECK_LAUNCH("winograd_pack_bf3p");
+#define BBDM_WINO_PK(MO)                                                                                                          \
+    do {                                                                                                                          \
+        if (wbound)                                                                                                               \
+            hipLaunchKernelGGL((winograd_weight_planes_kernel<MO, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, \
+                               Cin, CoutPad, nchunks, dgrad, wbound);                                                             \
+        else                                                                                                                      \
+            hipLaunchKernelGGL((winograd_weight_planes_kernel<MO, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, d, Cout, \
+                               Cin, CoutPad, nchunks, dgrad, nullptr);                                                            \
+    } while (0)
+    if (m == 2) BBDM_WINO_PK(2); else if (m == 4) BBDM_WINO_PK(4); else if (m == 8) BBDM_WINO_PK(8); else BBDM_WINO_PK(6);
+#undef BBDM_WINO_PK
+    BBDM_CHECK_LAUNCH("winograd_pack_planes");
     return BBDM_OK;
 }
+extern "C" int bbdm_winograd_pack_weight_bf3p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
+                                                  void* stream) {
+    return winograd_pack_planes(m, w_oihw, b_planes, Cout, Cin, InPad, dgrad, nullptr, stream);
+}
+// ... as the fp16-pair planes (bbdm_gemm_h2p_b_bytes bytes) under the scale of wbound x bbdm_winograd_g_gain(m); wbound: a device float
+// >= the filter's largest tap (bbdm_absmax_f32 of the weight tensor), the same pointer bbdm_winograd_gemm_h2p_f32 takes
+extern "C" int bbdm_winograd_pack_weight_h2p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
+                                                 const float* wbound, void* stream) {
+    BBDM_REQUIRE(wbound, "winograd_pack_h2p: null bound");
+    return winograd_pack_planes(m, w_oihw, b_planes, Cout, Cin, InPad, dgrad, wbound, stream);
+}
+extern "C" float bbdm_winograd_g_gain(int m) { return wino_g_gain(m); }
 
 extern "C" size_t bbdm_winograd_tiles(int m, int N, int H, int W) {
     return (m == 2 || m == 4 || m == 6 || m == 7 || m == 8) ? tiles_padded(N, H, W, m) : 0;
@@ -1125,7 +1165,7 @@ extern "C" size_t bbdm_winograd_workspace_floats(int m, int N, int H, int W, int
 
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
-                                 const GnFold* fold, bool f32out, const float* hbound = nullptr);
+                                 const GnFold* fold, bool f32out, const float* hbound = nullptr, int vt_h2 = 0);
 
 extern "C" int bbdm_winograd_input_f32(int m, const float* x, int ldx, float* V, const float* pre_scale,
                                        const float* pre_bias, int pre_ld, int pre_silu, int upsample, int N, int H, int W,
@@ -1206,7 +1246,7 @@ extern "C" int bbdm_winograd_gemm_bf3_f32(int m, const float* V, const void* pac
 // bbdm_gemm_bf3p_pack_b_f32 applied to the buffer bbdm_winograd_pack_weight_f32 filled (batch = (m+2)^2).
 static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void* Vt, const float* pre_scale, const float* pre_bias,
                                  int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* stream,
-                                 const GnFold* fold, bool f32out, const float* hbound) {
+                                 const GnFold* fold, bool f32out, const float* hbound, int vt_h2) {
     BBDM_WINO_M78(m);
     BBDM_REQUIRE(!hbound || !f32out, "winograd_input_h2p: the fp16-pair planes have no fp32 form");
     BBDM_REQUIRE(m != 7 || (!upsample && !Vt && !fold && !f32out), "winograd_input_bf3p: m = 7 (phase filters) takes x itself, planes only");
@@ -1222,7 +1262,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const int nchunks = CinPad / KC, TG = (int)(Tp / 8);
     const size_t plane = Tp * (size_t)CinPad * (f32out || hbound ? 4 : 6);  // bytes of one transform point
-    const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * 6;       // ... of the transposed copy (whole 32-channel row groups)
+    const size_t plane_t = (size_t)((CinPad + 31) / 32 * 32) * Tp * (vt_h2 ? 4 : 6);       // ... of the transposed copy (whole 32-channel row groups)
     BBDM_REQUIRE(!Vt || (!upsample && ((uintptr_t)Vt & 15) == 0), "winograd_input_bf3p: the transposed copy needs upsample = 0, 16-B alignment");
     hipStream_t st = (hipStream_t)stream;
     {
@@ -1242,11 +1282,11 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_7(PRE, I64)                                                                                                \
     hipLaunchKernelGGL((winograd_input_split2_kernel<6, PRE, false, false, I64, false, false, 7>), g, dim3(8 * 64), 0, st, x, ldx,   \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr,  \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2)
 #define BBDM_WINO_INS2_7H(PRE, I64)                                                                                               \
     hipLaunchKernelGGL((winograd_input_split2_kernel<6, PRE, false, false, I64, false, false, 7, 2>), g, dim3(8 * 64), 0, st, x, ldx, \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr,  \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2)
             if (hbound) {
                 if (pre_scale) { if (idx64) BBDM_WINO_INS2_7H(true, true); else BBDM_WINO_INS2_7H(true, false); }
                 else           { if (idx64) BBDM_WINO_INS2_7H(false, true); else BBDM_WINO_INS2_7H(false, false); }
@@ -1265,22 +1305,22 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
         if (upsample)                                                                                                             \
             hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, true, false, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                                (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
-                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                              \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2);                                              \
         else                                                                                                                      \
             hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, false, false, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                                (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
-                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                              \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2);                                              \
     } while (0)
 #define BBDM_WINO_INS2_GH(MO)                                                                                                     \
     do {                                                                                                                          \
         if (upsample)                                                                                                             \
             hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, true, false, false, true, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                                (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
-                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                      \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2);                                      \
         else                                                                                                                      \
             hipLaunchKernelGGL((winograd_input_split2_kernel<MO, true, false, false, false, true, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                                (unsigned char*)Vp, nullptr, nullptr, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,  \
-                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound);                                      \
+                               nullptr, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2);                                      \
     } while (0)
             if (hbound) { if (m == 2) BBDM_WINO_INS2_GH(2); else if (m == 4) BBDM_WINO_INS2_GH(4); else BBDM_WINO_INS2_GH(6); }
             else if (m == 2) BBDM_WINO_INS2_G(2); else if (m == 4) BBDM_WINO_INS2_G(4); else BBDM_WINO_INS2_G(6);
@@ -1299,7 +1339,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_F(MO, PRE, UP, I64)                                                                                        \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, false, I64, false, true>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, nullptr, \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2)
 #define BBDM_WINO_INS2_FI(MO, PRE, UP) do { if (idx64) BBDM_WINO_INS2_F(MO, PRE, UP, true); else BBDM_WINO_INS2_F(MO, PRE, UP, false); } while (0)
 #define BBDM_WINO_INS2_FM(MO)                                                                                                     \
     do {                                                                                                                          \
@@ -1316,7 +1356,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_I(MO, PRE, UP, TR, I64)                                                                                    \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64>), g, dim3((MO + 2) * 64), 0, st, x, ldx, (unsigned char*)Vp, \
                        pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane, (unsigned char*)Vt,   \
-                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+                       plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2)
 #define BBDM_WINO_INS2(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_I(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_I(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_M(MO)                                                                        \
     do {                                                                                            \
@@ -1327,7 +1367,7 @@ static int winograd_input_planes(int m, const float* x, int ldx, void* Vp, void*
 #define BBDM_WINO_INS2_HI(MO, PRE, UP, TR, I64)                                                                                   \
     hipLaunchKernelGGL((winograd_input_split2_kernel<MO, PRE, UP, TR, I64, false, false, MO, 2>), g, dim3((MO + 2) * 64), 0, st, x, ldx, \
                        (unsigned char*)Vp, pre_scale, pre_bias, pre_ld, pre_silu, N, H, W, nchunks, (unsigned)T, TG, plane,           \
-                       (unsigned char*)Vt, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound)
+                       (unsigned char*)Vt, plane_t, (int)(Tp / 16), dTW, dTH, dCH, gn, hbound, vt_h2)
 #define BBDM_WINO_INS2_H(MO, PRE, UP, TR) do { if (idx64) BBDM_WINO_INS2_HI(MO, PRE, UP, TR, true); else BBDM_WINO_INS2_HI(MO, PRE, UP, TR, false); } while (0)
 #define BBDM_WINO_INS2_HM(MO)                                                                       \
     do {                                                                                            \
@@ -1390,7 +1430,7 @@ extern "C" int bbdm_winograd_input_bf3p_tr_f32(int m, const float* x, int ldx, v
 // ---- the same stages on the fp16-pair planes (round 6; h2_split.h, gemm_bf3p.hip "h2"): Vp holds bbdm_gemm_h2p_a_bytes((m+2)^2, tiles,
 // CinPad) bytes, b_planes = bbdm_gemm_h2p_pack_b_f32 of the buffer bbdm_winograd_pack_weight_f32 filled; vbound: a device float >=
 // max |d| of the TRANSFORMED tensor (x after the fused producer; both stages multiply it by bbdm_winograd_input_gain(m) themselves),
-// ubound: >= max |U| (bbdm_absmax_f32 of that buffer).
+// ubound: >= the largest TAP of the filter (bbdm_absmax_f32 of the weights; packer and GEMM multiply it by bbdm_winograd_g_gain(m)).
 extern "C" float bbdm_winograd_input_gain(int m) { return wino_input_gain(m); }
 extern "C" int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
                                            int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad,
@@ -1406,6 +1446,13 @@ extern "C" int bbdm_winograd_input_h2p_tr_f32(int m, const float* x, int ldx, vo
                                               const float* vbound, void* stream) {
     BBDM_REQUIRE(Vt && vbound && !upsample, "winograd_input_h2p_tr: null pointer / upsample != 0");
     return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream, nullptr, false, vbound);
+}
+// ... with the transposed copy on the fp16 pair as well (bbdm_gemm_h2p_tn_at_bytes bytes; the weight gradient then runs bbdm_gemm_h2p_tn_f32)
+extern "C" int bbdm_winograd_input_h2p_tr2_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias,
+                                               int pre_ld, int pre_silu, int upsample, int N, int H, int W, int CinPad, void* Vt,
+                                               const float* vbound, void* stream) {
+    BBDM_REQUIRE(Vt && vbound && !upsample, "winograd_input_h2p_tr2: null pointer / upsample != 0");
+    return winograd_input_planes(m, x, ldx, Vp, Vt, pre_scale, pre_bias, pre_ld, pre_silu, 0, N, H, W, CinPad, stream, nullptr, false, vbound, 1);
 }
 extern "C" int bbdm_winograd_input_h2p_gn_f32(int m, const float* x, int ldx, void* Vp, const void* stats, const void* unused, int C,
                                               int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma,
@@ -1427,7 +1474,7 @@ extern "C" int bbdm_winograd_gemm_h2p_splitk_f32(int m, const void* Vp, const vo
     BBDM_WINO_M78(m);
     BBDM_REQUIRE(Vp && b_planes && M && vbound && ubound && N > 0, "winograd_gemm_h2p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
-    return bbdm_gemm_h2p_gain_splitk(Vp, b_planes, vbound, wino_input_gain(m), ubound, M, Cout, planes(m),
+    return bbdm_gemm_h2p_gain_splitk(Vp, b_planes, vbound, wino_input_gain(m), ubound, wino_g_gain(m), M, Cout, planes(m),
                                      (long long)tiles_padded(N, H, W, m), (long long)((tiles_raw(N, H, W, m) + 31) / 32 * 32), CinPad, Cout,
                                      splits, stream);
 }
@@ -1614,8 +1661,21 @@ extern "C" int bbdm_conv3x3_winograd_f32(int m, const float* x, int ldx, const f
 // dY [N,H,W,Cout] (pitch ld) -> dMt = the transposed bf16 planes of A dY A^T (bbdm_gemm_bf3p_tn_bt_bytes((m+2)^2, tiles, Cout) bytes)
 // and dm11 [tiles][Cout] fp32 = its plane (1, 1), whose column sums are the bias gradient.  Cout a multiple of 4; the channels up to
 // the next multiple of 32 (whole fragment units) are written as zeros.
+static int winograd_dy_planes(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W, int Cout, const float* dybound,
+                              void* stream);
 extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W,
                                                    int Cout, void* stream) {
+    return winograd_dy_planes(m, dy, ld, dMt, dm11, N, H, W, Cout, nullptr, stream);
+}
+// ... on the fp16 pair (dMt: bbdm_gemm_h2p_tn_bt_bytes bytes) under dybound = a device float >= max |dY| (bbdm_absmax_rows_f32)
+extern "C" int bbdm_winograd_dy_transform_h2p_f32(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W,
+                                                  int Cout, const float* dybound, void* stream) {
+    BBDM_REQUIRE(dybound, "winograd_dy_h2p: null bound");
+    return winograd_dy_planes(m, dy, ld, dMt, dm11, N, H, W, Cout, dybound, stream);
+}
+extern "C" float bbdm_winograd_dy_gain(int m) { return wino_dy_gain(m); }
+static int winograd_dy_planes(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W, int Cout, const float* dybound,
+                              void* stream) {
     BBDM_WINO_M8(m);
     BBDM_REQUIRE(dy && dMt && dm11 && N > 0, "winograd_dy_bf3p: null pointer / bad N");
     BBDM_WINO_HW(m, H, W);
@@ -1624,15 +1684,16 @@ extern "C" int bbdm_winograd_dy_transform_bf3p_f32(int m, const float* dy, int l
     const size_t T = tiles_raw(N, H, W, m), Tp = tiles_padded(N, H, W, m);
     const int CoutPad = cdiv(Cout, 128) * 128;                   // the B operand of the GEMM: whole 128-column tiles
     const int nchunks = CoutPad / KC, TG = (int)(Tp / 8);
-    const size_t plane_t = (size_t)CoutPad * Tp * 6;
+    const size_t plane_t = (size_t)CoutPad * Tp * (dybound ? 4 : 6);
     const long long blocks = 8ll * ((TG + 7) / 8) * nchunks;
     BBDM_REQUIRE(blocks < (1ll << 31), "winograd_dy_bf3p: too many workgroups");
     const dim3 g((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
-#define BBDM_WINO_DYS(MO)                                                                                                    \
-    hipLaunchKernelGGL((winograd_dy_split_kernel<MO>), g, dim3((MO + 2) * 64), 0, st, dy, ld, (unsigned char*)dMt, dm11, N, H, W, \
-                       Cout, nchunks, (long long)T, TG, plane_t, (int)(Tp / 16))
-    if (m == 2) BBDM_WINO_DYS(2); else if (m == 4) BBDM_WINO_DYS(4); else if (m == 8) BBDM_WINO_DYS(8); else BBDM_WINO_DYS(6);
+#define BBDM_WINO_DYS(MO, NPL)                                                                                               \
+    hipLaunchKernelGGL((winograd_dy_split_kernel<MO, NPL>), g, dim3((MO + 2) * 64), 0, st, dy, ld, (unsigned char*)dMt, dm11, N, H, W, \
+                       Cout, nchunks, (long long)T, TG, plane_t, (int)(Tp / 16), dybound)
+    if (dybound) { if (m == 2) BBDM_WINO_DYS(2, 2); else if (m == 4) BBDM_WINO_DYS(4, 2); else if (m == 8) BBDM_WINO_DYS(8, 2); else BBDM_WINO_DYS(6, 2); }
+    else if (m == 2) BBDM_WINO_DYS(2, 3); else if (m == 4) BBDM_WINO_DYS(4, 3); else if (m == 8) BBDM_WINO_DYS(8, 3); else BBDM_WINO_DYS(6, 3);
 #undef BBDM_WINO_DYS
     BBDM_CHECK_LAUNCH("winograd_dy_bf3p");
     return BBDM_OK;

@@ -425,7 +425,7 @@ class _PackedConvH2q(_PackedConv):
                       self.cin_pad, 1, stream)
             self.ubound.zero_()
             _lib.call("bbdm_absmax_f32", self.packed_f32.data_ptr(), self.packed_f32.numel(), self.ubound.data_ptr(), stream)
-            _lib.call("bbdm_gemm_h2p_pack_b_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), 1,
+            _lib.call("bbdm_gemm_h2p_pack_b_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), 1.0, 1,
                       self.cin_pad, self.cout, stream)
             self.key = key
 
@@ -526,18 +526,21 @@ class _PackedWinograd:
             if not w.is_contiguous() or w.dtype != torch.float32:
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
             if self.bf3 == "h":
-                # G g G^T in fp32 (a temporary), its exact maximum, then the two fp16 planes of U 2^e (e from the maximum)
-                tmp = torch.empty(self._n_f32, dtype=torch.float32, device=w.device)
-                src, co = w, self.cout
+                # fp16-pair planes of U 2^e: e from ``ubound`` = the filter's largest tap (one small pass over the weights) times the gain
+                # of G . G^T, the factor the tile GEMM applies to the same pointer -- G g G^T goes straight into the planes
+                self.ubound.zero_()
                 if self.phases:
                     _lib.call("bbdm_upsample_phase_weights_f32", w.data_ptr(), self.w4.data_ptr(), self.cout, self.cin, stream)
-                    src, co = self.w4, 4 * self.cout
-                _lib.call("bbdm_winograd_pack_weight_f32", self.m, src.data_ptr(), tmp.data_ptr(), co, self.cin, self.in_pad,
-                          1 if self.dgrad else 0, stream)
-                self.ubound.zero_()
-                _lib.call("bbdm_absmax_f32", tmp.data_ptr(), tmp.numel(), self.ubound.data_ptr(), stream)
-                _lib.call("bbdm_gemm_h2p_pack_b_f32", tmp.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), wino_planes(self.m),
-                          self.in_pad, self.out_ch, stream)
+                    _lib.call("bbdm_absmax_f32", self.w4.data_ptr(), self.w4.numel(), self.ubound.data_ptr(), stream)
+                    tmp = torch.empty(self._n_f32, dtype=torch.float32, device=w.device)
+                    _lib.call("bbdm_winograd_pack_weight_f32", self.m, self.w4.data_ptr(), tmp.data_ptr(), 4 * self.cout, self.cin,
+                              self.in_pad, 0, stream)
+                    _lib.call("bbdm_gemm_h2p_pack_b_f32", tmp.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(),
+                              float(_lib.load().bbdm_winograd_g_gain(self.m)), wino_planes(self.m), self.in_pad, self.out_ch, stream)
+                else:
+                    _lib.call("bbdm_absmax_f32", w.data_ptr(), w.numel(), self.ubound.data_ptr(), stream)
+                    _lib.call("bbdm_winograd_pack_weight_h2p_f32", self.m, w.data_ptr(), self.packed.data_ptr(), self.cout, self.cin,
+                              self.in_pad, 1 if self.dgrad else 0, self.ubound.data_ptr(), stream)
                 self.key = key
                 return
             if self.phases:
@@ -794,11 +797,11 @@ class UNetModel(nn.Module):
         self.gemm_h2: bool = True
         # ... and training plans (0 = bf16x3 planes in every direction, round 5's plans): 1 = the FORWARD tile GEMMs, whose operand is
         # GroupNorm-bounded exactly as in sampling (the transposed copy of V the weight gradient contracts stays the exact bf16 split);
-        # 2 = also the DATA-GRADIENT tile GEMMs, dY scaled by its measured maximum (one bbdm_absmax_rows_f32 pass per layer).  A gradient
-        # tensor has no a-priori range: elements more than ~2^17 below its maximum lose bits of their second plane (their absolute
-        # error stays 2^-25 of the maximum), which the all-248-gradients tests bound at the benchmarked plan.  The Winograd-domain
-        # weight gradient keeps bf16x3 on both operands.
-        self.gemm_h2_train: int = 2
+        # 2 = also the DATA-GRADIENT tile GEMMs, dY scaled by its measured maximum (one bbdm_absmax_rows_f32 pass per layer); 3 = also the
+        # Winograd-domain WEIGHT gradient (the transposed copy of V and dM = A dY A^T as fp16 pairs, the TN GEMM on three terms).  A
+        # gradient tensor has no a-priori range: elements more than ~2^17 below its maximum lose bits of their second plane (their
+        # absolute error stays 2^-25 of the maximum), which the all-248-gradients tests bound at the benchmarked plan.
+        self.gemm_h2_train: int = 3
         # ... and the wide 1x1 convolutions whose input carries a bound -- the skip projections of the ResBlocks (their raw input is bounded
         # by its own GroupNorm statistics: |x| <= sqrt(sum of squares) per group) and the qkv projections (a GroupNorm output) -- on
         # bbdm_conv1x1_h2q_f32 (inference plans).  False: bbdm_conv1x1_bf3q_f32 / bbdm_conv1x1_bf3_f32
@@ -1490,10 +1493,12 @@ class _Plan:
         if keeps and split:
             # ... as bf16 planes: the forward GEMM reads the shared scratch copy, the weight gradient the TRANSPOSED copy (rows =
             # channels, contraction index = tiles) that the same input-transform launch writes -- 6 B per element kept
-            vt = _TensorRef(torch.empty(self.lib.bbdm_gemm_bf3p_tn_at_bytes(wino_planes(wm), tiles, cin_pad), dtype=torch.uint8,
-                                        device=self.device))
-            self._saved_V[id(pw.weight)] = (vt, wm, "tr")
-            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_h2p_tr_f32" if h2 else "bbdm_winograd_input_bf3p_tr_f32"),
+            vt_h2 = h2 and self._h2_on(3)         # the weight gradient's TN GEMM on the fp16 pair as well: the transposed copy likewise
+            nbytes = (self.lib.bbdm_gemm_h2p_tn_at_bytes if vt_h2 else self.lib.bbdm_gemm_bf3p_tn_at_bytes)(wino_planes(wm), tiles, cin_pad)
+            vt = _TensorRef(torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+            self._saved_V[id(pw.weight)] = (vt, wm, "tr", pre.h2) if vt_h2 else (vt, wm, "tr")
+            emit(_OpName("bbdm_winograd_input_f32", "bbdm_winograd_input_h2p_tr2_f32" if vt_h2 else
+                         "bbdm_winograd_input_h2p_tr_f32" if h2 else "bbdm_winograd_input_bf3p_tr_f32"),
                  wm, x, x.ld, vbuf, *(pre or self.NO_PRE), 0, N, H, W, cin_pad, vt, *vb)
         elif isinstance(pre, _GnPre):
             assert split and not bwd, "the coefficient-folding input transform exists for the pre-split planes only"
@@ -1938,6 +1943,7 @@ class _Plan:
             w = mod.weight
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
+            dy_ref = [None]                          # the bound slot of dY (fp16-pair planes): measured once, shared by wgrad and dgrad
             wsn = ws_side_floats if side else ws_floats
             wsn[0] = max(wsn[0], lib.bbdm_conv_wgrad_workspace_floats(N, x_in.H, x_in.W, x_in.C, cout, ks))
             if x_in.C == cin:
@@ -1960,7 +1966,10 @@ class _Plan:
                 P, Tp = wino_planes(wgm), lib.bbdm_winograd_tiles(wgm, N, x_in.H, x_in.W)
                 T = wino_tiles(wgm, N, x_in.H, x_in.W)
                 splits = lib.bbdm_gemm_bf3p_tn_splits(P, Tp, x_in.C, cout)
-                n_dmt = (lib.bbdm_gemm_bf3p_tn_bt_bytes(P, Tp, cout) + 3) // 4          # floats
+                w_h2 = len(saved) > 3                    # the forward kept V^T as fp16 pairs: dM on the pair too, under dY's measured maximum
+                if w_h2:
+                    dy_ref[0] = dy_ref[0] or self._dy_bound(dy)      # (on the main stream, before a side chain forks)
+                n_dmt = ((lib.bbdm_gemm_h2p_tn_bt_bytes if w_h2 else lib.bbdm_gemm_bf3p_tn_bt_bytes)(P, Tp, cout) + 3) // 4          # floats
                 o_dm11 = n_dmt
                 o_du = o_dm11 + Tp * cout
                 o_acc = (o_du + splits * P * x_in.C * cout + 1) & ~1
@@ -1973,8 +1982,14 @@ class _Plan:
                 wsf = self._ws_f_side if chain else self._ws_f
                 dMt, dm11, dU = _TensorRef(wsf, 0), _TensorRef(wsf, 4 * o_dm11), _TensorRef(wsf, 4 * o_du)
                 k_chain = len(self.bops)
-                self._bop("bbdm_winograd_dy_transform_bf3p_f32", wgm, dy, dy.ld, dMt, dm11, N, x_in.H, x_in.W, cout)
-                self._bop("bbdm_gemm_bf3p_tn_f32", saved[0], dMt, dU, P, Tp, x_in.C, cout)
+                if w_h2:
+                    self._bop(_OpName("bbdm_winograd_dy_transform_bf3p_f32", "bbdm_winograd_dy_transform_h2p_f32"), wgm, dy, dy.ld, dMt, dm11,
+                              N, x_in.H, x_in.W, cout, dy_ref[0])
+                    self._bop(_OpName("bbdm_gemm_bf3p_tn_f32", "bbdm_gemm_h2p_tn_f32"), saved[0], dMt, dU, P, Tp, x_in.C, cout,
+                              saved[3], float(lib.bbdm_winograd_input_gain(wgm)), dy_ref[0], float(lib.bbdm_winograd_dy_gain(wgm)))
+                else:
+                    self._bop("bbdm_winograd_dy_transform_bf3p_f32", wgm, dy, dy.ld, dMt, dm11, N, x_in.H, x_in.W, cout)
+                    self._bop("bbdm_gemm_bf3p_tn_f32", saved[0], dMt, dU, P, Tp, x_in.C, cout)
                 if dbias is not None and cout % 4 == 0:
                     # ... + the bias gradient in the same launch: column sums of dM's plane (1, 1) = the tile sums of dY
                     self._bop("bbdm_winograd_wgrad_finish_bias_f32", wgm, dU, splits, dw_dst, x_in.C, cout, dm11, T, dbias)
@@ -2019,7 +2034,7 @@ class _Plan:
                 pk = _PackedWinograd(w, None, dy.C, wm, dgrad=True, bf3=mode)
                 self.dconvs.append(pk)
                 # fp16-pair planes: dY under its measured maximum (UNetModel.gemm_h2_train = 2)
-                pre_dy = _Pre(self.NO_PRE, h2=self._dy_bound(dy)) if mode == "h" else None
+                pre_dy = _Pre(self.NO_PRE, h2=dy_ref[0] or self._dy_bound(dy)) if mode == "h" else None
                 self._emit_winograd(dy, dy.C, pk, pre_dy, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
                 return dx
             pixels = x_in.N * x_in.H * x_in.W

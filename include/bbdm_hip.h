@@ -494,7 +494,8 @@ int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bi
  * (bbdm_h2_gn_bounds_f32: a z-score over n values is at most sqrt(n - 1)), never guessed.
  *   bbdm_gemm_h2p_a_bytes / _b_bytes   : plane buffer sizes (4 B per element; T to 256 rows, Cout to 128 columns)
  *   bbdm_absmax_f32                    : *bound = max(*bound, max |x[i]|)  (order-independent; the caller zeroes *bound)
- *   bbdm_gemm_h2p_pack_b_f32           : fp32 packed [batch][CinPad/16][CoutPad128][16] -> B planes scaled by `bound`
+ *   bbdm_gemm_h2p_pack_b_f32           : fp32 packed [batch][CinPad/16][CoutPad128][16] -> B planes scaled by `bound` x `gain` (gain: 1, or
+ *                                        the factor between the bound's tensor and the packed one -- bbdm_winograd_g_gain(m))
  *   bbdm_gemm_h2p_split_rows_f32       : fp32 rows -> A planes scaled by `bound`
  *   bbdm_gemm_h2p_f32 / _splitk_f32    : the GEMMs of bbdm_gemm_bf3p_f32 / _splitk_f32 (same shapes, tiles and split rule)
  *   bbdm_h2_gn_bounds_f32              : bounds[l] for every GroupNorm-fed layer l of a plan in ONE launch; `table`: device array of
@@ -503,13 +504,20 @@ int bbdm_winograd_output_splitk_stats_f32(int m, const float* M, const float* bi
  *   bbdm_winograd_input_h2p_f32 / _gn_f32, bbdm_winograd_gemm_h2p_f32 / _splitk_f32 : stages (1) and (2) of the Winograd path on
  *                                        these planes: the arguments of the bf3p forms, then vbound >= max |d| of the TRANSFORMED
  *                                        tensor (x after the fused producer; both stages apply the gain themselves) and, for the
- *                                        GEMMs, ubound >= max |U| (bbdm_absmax_f32 of bbdm_winograd_pack_weight_f32's buffer) */
+ *                                        GEMMs, ubound >= the filter's largest tap (bbdm_absmax_f32 of the weights; the packers and
+ *                                        the GEMMs multiply it by bbdm_winograd_g_gain(m)) */
 size_t bbdm_gemm_h2p_a_bytes(int batch, long long T, int CinPad);
 size_t bbdm_gemm_h2p_b_bytes(int batch, int CinPad, int Cout);
 int bbdm_absmax_f32(const float* x, long long n, float* bound, void* stream);
 /* ... of a [rows][C] view with pitch ldx (a channel slice of an NHWC buffer: the dY of a data-gradient convolution); C % 4 == 0 */
 int bbdm_absmax_rows_f32(const float* x, int ldx, long long rows, int C, float* bound, void* stream);
-int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, int batch, int CinPad, int Cout, void* stream);
+int bbdm_gemm_h2p_pack_b_f32(const float* packed_f32, void* b_planes, const float* bound, float gain, int batch, int CinPad, int Cout,
+                             void* stream);
+/* G g G^T straight into the fp16-pair planes (bbdm_winograd_pack_weight_bf3p_f32's arguments + wbound: a device float >= the filter's
+ * largest tap; planes scaled by wbound x bbdm_winograd_g_gain(m), the factor bbdm_winograd_gemm_h2p_f32 applies to its `ubound`) */
+int bbdm_winograd_pack_weight_h2p_f32(int m, const float* w_oihw, void* b_planes, int Cout, int Cin, int InPad, int dgrad,
+                                      const float* wbound, void* stream);
+float bbdm_winograd_g_gain(int m);
 int bbdm_gemm_h2p_split_rows_f32(const float* x, int ldx, void* a_planes, const float* bound, int batch, long long T, int CinPad,
                                  void* stream);
 int bbdm_gemm_h2p_f32(const void* a_planes, const void* b_planes, const float* bound_a, const float* bound_b, const float* bias,
@@ -533,6 +541,20 @@ int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const 
 int bbdm_winograd_input_h2p_tr_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
                                    int pre_silu, int upsample /* 0 */, int N, int H, int W, int CinPad, void* Vt, const float* vbound,
                                    void* stream);
+/* ... and the Winograd-domain WEIGHT gradient on these planes (UNetModel.gemm_h2_train = 3): the transposed copy Vt as fp16 pairs
+ * (bbdm_winograd_input_h2p_tr2_f32; bbdm_gemm_h2p_tn_at_bytes bytes), dM^T = (A dY A^T)^T under the measured maximum of dY x
+ * bbdm_winograd_dy_gain(m) (bbdm_winograd_dy_transform_h2p_f32; bbdm_gemm_h2p_tn_bt_bytes bytes), and their TN product
+ * (bbdm_gemm_h2p_tn_f32: the shapes, split rule and C layout of bbdm_gemm_bf3p_tn_f32) */
+int bbdm_winograd_input_h2p_tr2_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
+                                    int pre_silu, int upsample /* 0 */, int N, int H, int W, int CinPad, void* Vt, const float* vbound,
+                                    void* stream);
+int bbdm_winograd_dy_transform_h2p_f32(int m, const float* dy, int ld, void* dMt, float* dm11, int N, int H, int W, int Cout,
+                                       const float* dybound, void* stream);
+float bbdm_winograd_dy_gain(int m);
+size_t bbdm_gemm_h2p_tn_at_bytes(int batch, long long K, int M);
+size_t bbdm_gemm_h2p_tn_bt_bytes(int batch, long long K, int N);
+int bbdm_gemm_h2p_tn_f32(const void* at_planes, const void* bt_planes, float* C, int batch, long long K, int M, int N,
+                         const float* bound_a, float gain_a, const float* bound_b, float gain_b, void* stream);
 int bbdm_winograd_input_h2p_gn_f32(int m, const float* x, int ldx, void* Vp, const bbdm_stats_t* stats, const void* unused, int C,
                                    int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* gamma, const float* beta,
                                    const float* film, int film_ld, int HW, int G, float eps, const float* vbound, void* stream);

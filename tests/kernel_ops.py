@@ -643,7 +643,7 @@ def gemm_h2p(V: torch.Tensor, w_packed_f32: torch.Tensor, batch: int, cin_pad: i
     ap = torch.empty(lib.bbdm_gemm_h2p_a_bytes(batch, T, cin_pad), dtype=torch.uint8, device=V.device)
     bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(batch, cin_pad, cout), dtype=torch.uint8, device=V.device)
     _lib.call("bbdm_gemm_h2p_split_rows_f32", V.data_ptr(), V.shape[2], ap.data_ptr(), ba.data_ptr(), batch, T, cin_pad, _st(V))
-    _lib.call("bbdm_gemm_h2p_pack_b_f32", w_packed_f32.data_ptr(), bp.data_ptr(), bb.data_ptr(), batch, cin_pad, cout, _st(V))
+    _lib.call("bbdm_gemm_h2p_pack_b_f32", w_packed_f32.data_ptr(), bp.data_ptr(), bb.data_ptr(), 1.0, batch, cin_pad, cout, _st(V))
     M = torch.empty(batch, Tp, cout, dtype=torch.float32, device=V.device)
     if residual is not None:
         M[:, :T] = residual
@@ -672,9 +672,9 @@ def conv3x3_winograd_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[tor
     pre = (None if pre_scale is None else pre_scale.data_ptr(), None if pre_bias is None else pre_bias.data_ptr(),
            0 if pre_scale is None else pre_scale.shape[-1], 1 if pre_silu else 0)
     if mode == "h2":
-        ub = absmax(pf)
+        ub = absmax(w)                      # the filter's largest tap: packer and GEMM apply the gain of G . G^T themselves
         bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(planes, cin, cout), dtype=torch.uint8, device=x.device)
-        _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), ub.data_ptr(), planes, cin, cout, st)
+        _lib.call("bbdm_winograd_pack_weight_h2p_f32", m, w.data_ptr(), bp.data_ptr(), cout, cin, cin, 0, ub.data_ptr(), st)
         if in_bound is None:
             assert pre_scale is None, "a fused producer needs the caller's bound"
             vb = absmax(x)
@@ -709,7 +709,7 @@ def conv1x1_h2q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), pf.data_ptr(), cout, w.shape[1], cin, 1, _st(x))
     wb = absmax(pf)
     bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(1, cin, cout), dtype=torch.uint8, device=x.device)
-    _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), wb.data_ptr(), 1, cin, cout, _st(x))
+    _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), bp.data_ptr(), wb.data_ptr(), 1.0, 1, cin, cout, _st(x))
     xb = absmax(x) if xbound is None else xbound
     if out is None:
         out = torch.empty(x.shape[0], cout, dtype=torch.float32, device=x.device)

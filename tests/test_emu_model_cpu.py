@@ -303,7 +303,7 @@ def test_weight_gradients_in_the_winograd_domain(monkeypatch):
     assert sum(str(n) in ("bbdm_conv3x3_winograd_wgrad_f32", "bbdm_winograd_wgrad_finish_f32", "bbdm_winograd_wgrad_finish_bias_f32") for n, _ in plan.bops) >= 4
     # ... as TRANSPOSED bf16 planes, contracted by the bf16x3 GEMM (csrc/gemm_bf3p.hip: the tiles are its K loop)
     assert sum(str(n) == "bbdm_gemm_bf3p_tn_f32" for n, _ in plan.bops) >= 1
-    assert any(getattr(n, "entry", "") in ("bbdm_winograd_input_bf3p_tr_f32", "bbdm_winograd_input_h2p_tr_f32") for n, _ in plan.ops)
+    assert any(getattr(n, "entry", "") in ("bbdm_winograd_input_bf3p_tr_f32", "bbdm_winograd_input_h2p_tr_f32", "bbdm_winograd_input_h2p_tr2_f32") for n, _ in plan.ops)
     assert len(plan._fused_train) >= 2          # ... and those layers' GN -> SiLU input was folded into the transform, not materialised
     assert sum(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.bops) >= 1 and \
         sum(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in plan.ops) >= 1

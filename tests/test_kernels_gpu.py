@@ -585,11 +585,17 @@ def test_winograd_f8_forward(dev, N, H, W, Cin, Cout, pre, up, res, f32v):
     out = torch.full((N, H, W, Cout), float("nan"), device=dev)
     pre_args = (scg.data_ptr() if pre else None, big.data_ptr() if pre else None, Cin if pre else 0, pre)
     if f32v == 2:
+        # the two-launch packing (fp32 G g G^T, then the planes under the tap bound x the gain of G . G^T) -- the fused launch
+        # (bbdm_winograd_pack_weight_h2p_f32, what ops.conv3x3_winograd_planes and the product use) must write the same planes
+        wd = w.to(dev).contiguous()
         pf = torch.empty(lib.bbdm_winograd_packed_floats(m, Cout, Cin), dtype=torch.float32, device=dev)
-        _lib.call("bbdm_winograd_pack_weight_f32", m, w.to(dev).contiguous().data_ptr(), pf.data_ptr(), Cout, Cin, Cin, 0, st)
-        ub = ops.absmax(pf)
-        Bp = torch.empty(lib.bbdm_gemm_h2p_b_bytes(P, Cin, Cout), dtype=torch.uint8, device=dev)
-        _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), Bp.data_ptr(), ub.data_ptr(), P, Cin, Cout, st)
+        _lib.call("bbdm_winograd_pack_weight_f32", m, wd.data_ptr(), pf.data_ptr(), Cout, Cin, Cin, 0, st)
+        ub = ops.absmax(wd)
+        Bp = torch.zeros(lib.bbdm_gemm_h2p_b_bytes(P, Cin, Cout), dtype=torch.uint8, device=dev)
+        _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), Bp.data_ptr(), ub.data_ptr(), float(lib.bbdm_winograd_g_gain(m)), P, Cin, Cout, st)
+        Bp2 = torch.zeros_like(Bp)
+        _lib.call("bbdm_winograd_pack_weight_h2p_f32", m, wd.data_ptr(), Bp2.data_ptr(), Cout, Cin, Cin, 0, ub.data_ptr(), st)
+        assert torch.equal(Bp.cpu(), Bp2.cpu())
         vb = torch.full((1,), float(a.abs().max()), dtype=torch.float32, device=dev)
         Vp = torch.empty(lib.bbdm_gemm_h2p_a_bytes(P, tiles, Cin), dtype=torch.uint8, device=dev)
         _lib.call("bbdm_winograd_input_h2p_f32", m, xg.data_ptr(), Cin, Vp.data_ptr(), *pre_args, up, N, H, W, Cin, vb.data_ptr(), st)

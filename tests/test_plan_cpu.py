@@ -133,13 +133,17 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
         if "h2p" in entry:                      # two fp16 planes per operand under a bound (csrc/h2_split.h): inference only, 4 B per element
             in_entry = getattr(ops[k][0], "entry", "")
             assert m.gemm_h2 and (not training or m.gemm_h2_train >= (2 if k >= len(plan.ops) else 1))
-            assert in_entry in ("bbdm_winograd_input_h2p_f32", "bbdm_winograd_input_h2p_gn_f32", "bbdm_winograd_input_h2p_tr_f32")
+            assert in_entry in ("bbdm_winograd_input_h2p_f32", "bbdm_winograd_input_h2p_gn_f32", "bbdm_winograd_input_h2p_tr_f32",
+                                "bbdm_winograd_input_h2p_tr2_f32")
+            if in_entry.endswith("_tr2_f32"):   # ... the weight gradient on the fp16 pair as well (gemm_h2_train = 3): V^T as two planes
+                assert training and m.gemm_h2_train >= 3 and i[8] == 0 and i[13].t.numel() == lib.bbdm_gemm_h2p_tn_at_bytes(P, tiles, cin)
             vb = i[-1]                          # the bound of the transformed tensor: a slot of the plan, the same one in both launches
             assert isinstance(vb, unet._Plan._H2Ref) and g[-2] is vb
             if k >= len(plan.ops):              # data gradient: dY under its measured maximum -- the launch before the transform takes it
                 assert training and vb.kind == "dy" and 0 <= vb.k < plan._h2_dy_slots and i[4] is None
-                pn, pa = ops[k - 1]
-                assert pn == "bbdm_absmax_rows_f32" and pa[0] is i[1] and pa[-1] is vb and pa[3] == cin
+                # ... measured by ONE pass earlier in the same layer's backward (right before, or ahead of its weight-gradient chain)
+                prev = [pa for pn, pa in ops[max(0, k - 8):k] if pn == "bbdm_absmax_rows_f32" and pa[-1] is vb]
+                assert len(prev) == 1 and prev[0][0] is i[1] and prev[0][3] == cin
             else:                               # forward: the GroupNorm bound of this layer's input
                 assert vb.kind == "gn" and 0 <= vb.k < len(plan._h2_layers)
                 gam, bet, fo, C, z = plan._h2_layers[vb.k]

@@ -150,10 +150,15 @@ def test_f8_constants_are_the_generated_ones_and_the_gain_bounds_the_transform()
         assert blocks[key] in src, key
     lib = _lib.load()
     for m in (2, 4, 6, 8):
-        exact = float(MATS[m][0].abs().sum(1).max()) ** 2
-        got = float(lib.bbdm_winograd_input_gain(m))
-        assert exact <= got <= 1.01 * exact, (m, exact, got)
+        BT, G, AT = MATS[m]
+        for name, fn, exact in (("input", lib.bbdm_winograd_input_gain, float(BT.abs().sum(1).max()) ** 2),
+                                ("g", lib.bbdm_winograd_g_gain, float(G.abs().sum(1).max()) ** 2),
+                                ("dy", lib.bbdm_winograd_dy_gain, float(AT.abs().sum(0).max()) ** 2)):
+            got = float(fn(m))
+            assert exact <= got <= 1.01 * exact, (m, name, exact, got)
     assert float(lib.bbdm_winograd_input_gain(7)) == float(lib.bbdm_winograd_input_gain(6))
+    g72 = float(MATS72[1].abs().sum(1).max()) ** 2
+    assert g72 <= float(lib.bbdm_winograd_g_gain(7)) <= 1.01 * g72
 
 
 # F(7x7, 2x2) on the same eight points (round 5: the phase filters of conv3x3(nearest x2 (x)) read 2 x 2 pixels each): B^T is m = 6's,

@@ -179,6 +179,8 @@ def generate(pairs):
     blocks["gt"] = "\n".join(L)
     gain = max(sum(abs(c) for c in row) for row in BT) ** 2
     blocks["gain"] = float(gain)
+    blocks["ggain"] = float(max(sum(abs(c) for c in row) for row in G) ** 2)          # |G g G^T| <= ggain max |g|
+    blocks["dygain"] = float(max(sum(abs(AT[i][j]) for i in range(m)) for j in range(n)) ** 2)      # |A dY A^T| <= dygain max |dY|
     return blocks
 
 
@@ -193,8 +195,12 @@ def patch(pairs):
         s = pat.sub(lambda mo: mo.group(1) + b[key] + mo.group(3), s, count=1)
     gain = math.ceil(b["gain"] * 100) / 100
     s = re.sub(r"m == 8 \? [0-9.]+f : 225\.f;[^\n]*", f"m == 8 ? {gain}f : 225.f;      // (m = 8, points {{0, {pts}, inf}}: {b['gain']:.4f})", s)
+    gg = math.ceil(b["ggain"] * 100) / 100
+    s = re.sub(r"m == 8 \? [0-9.]+f : 1\.55f;[^\n]*", f"m == 8 ? {gg}f : 1.55f;      // <gen8:ggain> (m = 8: {b['ggain']:.4f})", s)
+    dg = math.ceil(b["dygain"] * 10) / 10
+    s = re.sub(r"m == 8 \? [0-9.]+f : 3969\.f;[^\n]*", f"m == 8 ? {dg}f : 3969.f;      // (m = 8: {b['dygain']:.3f})", s)
     open(path, "w").write(s)
-    print("patched", path, "gain", b["gain"])
+    print("patched", path, "gains", b["gain"], b["ggain"], b["dygain"])
 
 
 if __name__ == "__main__":

@@ -63,12 +63,12 @@ def timing(dev):
         _lib.call("bbdm_winograd_pack_weight_f32", m, w.data_ptr(), pf.data_ptr(), Cout, Cin, Cin, 0, st)
         Tp = (tiles + 255) // 256 * 256
         M = torch.empty(planes * Tp * Cout, dtype=torch.float32, device=dev)
-        ub = ops.absmax(pf)
+        ub = ops.absmax(w)
         vb = torch.full((1,), 40.0, dtype=torch.float32, device=dev)
         b3 = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(planes, Cin, Cout), dtype=torch.uint8, device=dev)
         bh = torch.empty(lib.bbdm_gemm_h2p_b_bytes(planes, Cin, Cout), dtype=torch.uint8, device=dev)
         _lib.call("bbdm_gemm_bf3p_pack_b_f32", pf.data_ptr(), b3.data_ptr(), planes, Cin, Cout, st)
-        _lib.call("bbdm_gemm_h2p_pack_b_f32", pf.data_ptr(), bh.data_ptr(), ub.data_ptr(), planes, Cin, Cout, st)
+        _lib.call("bbdm_winograd_pack_weight_h2p_f32", m, w.data_ptr(), bh.data_ptr(), Cout, Cin, Cin, 0, ub.data_ptr(), st)
         V3 = torch.empty(lib.bbdm_gemm_bf3p_a_bytes(planes, tiles, Cin), dtype=torch.uint8, device=dev)
         Vh = torch.empty(lib.bbdm_gemm_h2p_a_bytes(planes, tiles, Cin), dtype=torch.uint8, device=dev)
         calls = {
