@@ -272,6 +272,14 @@ def test_side_stream_band_admits_the_latent_f4_projections_only():
                 assert names[:2] == ["bbdm_winograd_dy_transform_bf3p_f32", "bbdm_gemm_bf3p_tn_f32"] and names[2].startswith("bbdm_winograd_wgrad_finish")
                 assert str(plan.bops[kj][0]) == "bbdm_groupnorm_bwd_f32"
                 assert all(a.t is plan._ws_f_side for a in plan.bops[k0][1][3:5]) and plan.bops[k0 + 1][1][1].t is plan._ws_f_side
+            # every second-stream range of the gradient plan forks AND joins inside ONE backward segment (round-5 verdict, item 8): a
+            # segment's autograd node hands its parameter gradients to autograd -- and DDP's reducer hooks -- when its last launch has
+            # been enqueued, so a range that joined in a later segment would let the all-reduce read unfinished gradients
+            segs = [(lo, hi) for lo, hi, _ in plan.bsegs]
+            assert len(segs) >= 2 and segs[0][0] == 0 and all(a[1] == b[0] for a, b in zip(segs, segs[1:]))
+            for k0, k1, kj in plan._bside_ranges:
+                inside = [(lo, hi) for lo, hi in segs if lo <= k0 and kj < hi]
+                assert len(inside) == 1 and k0 < k1 <= kj, (k0, k1, kj, segs)
             on_side = {j for k0, k1, _ in plan._bside_ranges for j in range(k0, k1)}
             for j, (n, a) in enumerate(plan.bops):
                 if j not in on_side:
