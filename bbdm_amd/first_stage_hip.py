@@ -47,7 +47,9 @@ class _Flags:
         self.upsample_phases = True
         self.gemm_bf3 = True
         self.gemm_bf3p = True
-        self.gemm_h2 = False                # (the first stage runs once per batch; its plans launch no bound kernel)
+        self.gemm_h2 = True                 # tile GEMMs of the GroupNorm-fed 3x3 layers on the fp16-pair planes (csrc/h2_split.h), as in the UNet
+        self.gemm_h2_train = 0
+        self.conv1x1_h2 = False             # (its 1x1 layers -- the AttnBlock projections -- keep bf16x3)
         self.fuse_stats = True
         self.bf3_min_tiles = 256
         self.conv1x1_small = True
@@ -239,6 +241,9 @@ class _FSPlan(_Plan):
             self._refresh_weights(stream)
             self.x_in.copy_(x)
             self.stats.zero_()
+            if self._h2_layers:         # the GroupNorm bounds of the fp16-pair tile GEMMs (no FiLM in the first stage: gamma / beta alone)
+                _lib.call("bbdm_h2_gn_bounds_f32", self._h2_table.data_ptr(), len(self._h2_layers), None, 0, self.N,
+                          self._h2_bounds.t.data_ptr(), stream)
             check = _lib.check
             for fn, args in self._bound:
                 rc = fn(*args, stream)

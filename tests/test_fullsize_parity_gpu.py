@@ -360,3 +360,27 @@ def test_c5_real_f16_template_step(dev):
         ea, eb = parity_err(a, a_ref), parity_err(b, b_ref)
         print(f"C5 f16 template ({nparam / 1e6:.1f} M params, 6 attention blocks) step i={i}: rel err {ea:.2e} {eb:.2e}")
         assert ea < 1e-3 and eb < 1e-3
+
+
+def test_f8_template_step(dev):
+    """configs/Template-LBBDM-f8.yaml:106-129 -- the one reference template without a full-size step test (round-5 verdict, item 9): latent
+    4 x 32 x 32, in / out 4 channels, 237 M parameters, 200-step schedule.  One p_sample step at batch 2 and at batch 32 (the plans differ:
+    tile choices follow the batch) against the oracle, three schedule indices."""
+    up = dict(UNET_PIXEL, image_size=32, in_channels=4, out_channels=4, condition_key="nocond")
+    m, sd = _model(up, BB, 808, dev)
+    m.eval()
+    ora = O.OracleBBDM({"denoise_fn." + k: v for k, v in sd.items()}, O.UNetSpec(**up), **BB)
+    g = torch.Generator().manual_seed(8)
+    for N in (2, 32):
+        y = torch.randn(N, 4, 32, 32, generator=g)
+        x_t = torch.randn(N, 4, 32, 32, generator=g)
+        eps = torch.randn(N, 4, 32, 32, generator=g)
+        for i in (0, 100, 199):
+            a, b = _p_sample(m, x_t, y, None, i, eps, dev)
+            with torch.no_grad():
+                a_ref, b_ref = ora.p_sample(x_t[:2], y[:2], None, i, clip_denoised=False, noise=eps[:2])
+            ea, eb = parity_err(a[:2], a_ref), parity_err(b[:2], b_ref)
+            print(f"LBBDM-f8 template (latent 4x32x32), batch {N}, step i={i}: rel err {ea:.2e} {eb:.2e}")
+            assert ea < 1e-3 and eb < 1e-3
+    m.denoise_fn._plans = {}
+    torch.cuda.empty_cache()
