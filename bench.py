@@ -15,17 +15,23 @@ data-path collective ("weak" scaling); the timed region is bracketed by barrier 
 MAX over ranks is taken; value = steps all ranks completed / that time.
 
 Rank 0 prints ONE JSON line with, besides the contract fields,
-  roofline     : the dominant kernel -- the Winograd tile GEMMs on gemm_bf3p_pipe_kernel (fp32-accurate products on the BF16
-                 matrix core: six bf16 MFMA terms per product) -- fp32-equivalent FLOPs per launch / average launch duration
-                 measured with HIP events on the launch stream, against the dense bf16 MFMA peak / 6 (MI355X_MICROARCH.md);
-                 `frac_step` = the whole step against the matrix peaks; `traffic` / `traffic_step` / `mfma_util` from the committed
-                 rocprofv3 PMC passes of this command (profiles/*_pmc_<workload>_*.json);
+  roofline     : the dominant kernel -- the Winograd tile GEMMs on gemm_bf3p_pipe_kernel<NP = 2> (fp32-grade products on the 16-bit
+                 matrix core: two fp16 planes per operand under a provable scale, THREE f16 MFMA terms per product, csrc/h2_split.h;
+                 with UNetModel.gemm_h2 = False the six-term bf16x3 planes) -- fp32-equivalent FLOPs per launch / average launch
+                 duration measured with HIP events on the launch stream, against the dense 16-bit MFMA peak / 3 (/ 6)
+                 (MI355X_MICROARCH.md); `frac_step` = the whole step against the matrix peaks; `traffic` / `traffic_step` /
+                 `mfma_util` (+ the scalars traffic_ratio_step, mfma_util_pct, dom_clock_GHz) from the committed rocprofv3 PMC
+                 passes of this command (profiles/*_pmc_<workload>_*.json), shown only while those files carry the sha256 of the
+                 library this process loaded -- else "stale";
   hip_graph    : the timed region replays the forward as one hipGraph (the product path); the per-launch events then come from an
                  eager pass of the same K steps right after it (`eager_profiled_ms_per_step`);
   f32mfma_ms_per_step : the same step with those GEMMs on the f32 MFMA (strict-fp32 A/B, 5 steps after the timed region);
   winograd6_ms_per_step : the same step on round 4's Winograd tiles (UNetModel.winograd = 6; parity["winograd6"] = its parity sample);
+  bf16x3_ms_per_step : the same step on round 5's planes (UNetModel.gemm_h2 = False; parity["bf16x3"]);
                  c4: the training micro-step with F(8x8, 3x3) off in the training plan (UNetModel.winograd_train8 = 0; summary.c4_m6);
-  parity       : image 0 of the benchmarked batch against the CPU path (c4: loss + named gradients against the oracle's autograd);
+  parity       : image 0 of the benchmarked batch against the CPU path (c4: loss + named gradients against the oracle's autograd;
+                 c3: + `loop`: worst single step and free-running drift over the first 24 steps of the sampling loop, default plan
+                 and winograd = 6);
   cpu_baseline : the oracle (kind "port": oracle/bbdm_oracle.py, the validated restatement of the reference's CPU
                  path) timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -273,6 +279,58 @@ def parity_only(workload, sd, parity_inputs):
     return parity
 
 
+def loop_parity(model, workload, sd, y, dev, steps=24):
+    """The first ``steps`` steps of the sampling LOOP on the benchmarked batch (round-5 verdict item 1b): image 0 of the batch against
+    the CPU path's own trajectory from x_T = y with the same per-step noise -- `worst_step`: the largest single-step error when both
+    start the step from the CPU trajectory; `drift`: the free-running difference after ``steps`` steps -- on the default plan and on
+    UNetModel.winograd = 6 (max-norm and L2 form, the larger; the full 200 steps: tests/test_loop_parity_gpu.py)."""
+    desc, up, ch, size, batch, skip, sstep = WORKLOADS[workload]
+    path = _CpuPath(up, skip, sstep, sd)
+    ctx_c = None if up["condition_key"] == "nocond" else y[:1].cpu()
+    g = torch.Generator().manual_seed(2024)
+    noises = [torch.randn(y.shape, generator=g) for _ in range(steps)]
+    traj = [y[:1].cpu()]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))                     # (one small image: all host threads oversubscribe it)
+    try:
+        for i in range(steps):
+            traj.append(path.p_sample(traj[-1], y[:1].cpu(), ctx_c, i, noises[i][:1])[0])
+    finally:
+        torch.set_num_threads(threads)
+
+    def err(a, b):
+        a, b = a.double().cpu(), b.double()
+        return max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)), float((a - b).norm() / b.norm().clamp_min(1e-30)))
+    out = {"steps": steps, "against": path.kind}
+    ctx = None if up["condition_key"] == "nocond" else y
+    orig_rl = torch.randn_like
+    cur = {}
+    torch.randn_like = lambda t, **k: cur["eps"]
+    try:
+        for name, wino in (("default", None), ("winograd6", 6)):
+            keep = model.denoise_fn.winograd
+            if wino is not None:
+                model.denoise_fn.winograd = wino
+            try:
+                worst, img = 0.0, y
+                for i in range(steps):
+                    cur["eps"] = noises[i].to(dev)
+                    xin = torch.cat([traj[i].to(dev), y[1:]], 0)
+                    a, _ = model.p_sample(xin, y, ctx, i, clip_denoised=False)
+                    worst = max(worst, err(a[:1], traj[i + 1]))
+                    img, _ = model.p_sample(img, y, ctx, i, clip_denoised=False)
+                    img = img.clone()
+                torch.cuda.synchronize(dev)
+                out[name] = {"worst_step": worst, "drift": err(img[:1], traj[-1])}
+            finally:
+                model.denoise_fn.winograd = keep
+            for k in list(model.denoise_fn._plans)[1:]:
+                del model.denoise_fn._plans[k]
+    finally:
+        torch.randn_like = orig_rl
+    return out
+
+
 def training_parity(model, sd, up, skip, sstep, x0, y, dev, all_grads=False, loss_type="l2"):
     """c4: loss and named parameter gradients of ONE micro-step on the benchmarked batch (batch 32, the benchmarked training plan)
     against autograd on the oracle (CPU, the whole batch).  l2 loss by default: d|t - p|/dp of the l1 loss is discontinuous, a single
@@ -447,6 +505,10 @@ def main():
             b3 = (line.get("parity") or {}).get("bf16x3") or {}
             line["summary"][args.workload + "_bf16x3"] = [round(line["bf16x3_ms_per_step"], 3),
                                                           float(f"{max(b3.values()):.2g}") if b3 else None]
+        c3r = line if args.workload == "c3" else (line.get("workloads") or {}).get("c3") or {}
+        lp = ((c3r.get("parity") or {}).get("loop") or {})
+        if lp.get("default"):                        # the first 24 steps of the C3 sampling loop: [worst single step, free-running drift]
+            line["summary"]["c3_loop24"] = [float(f"{lp['default']['worst_step']:.2g}"), float(f"{lp['default']['drift']:.2g}")]
         c4r = line if args.workload == "c4" else (line.get("workloads") or {}).get("c4") or {}
         if c4r.get("winograd6_ms_per_step"):         # the training micro-step on the m <= 6 tiles (UNetModel.winograd_train8 = 0)
             line["summary"]["c4_m6"] = round(c4r["winograd6_ms_per_step"], 3)
@@ -989,6 +1051,8 @@ def run_workload(args, env):
             line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         elif par_in is not None:
             line["parity"] = parity_only(args.workload, sd, par_in)
+        if args.workload == "c3" and line["parity"] is not None and not training and world == 1:
+            line["parity"]["loop"] = loop_parity(model, args.workload, sd, y, dev)
         if training and not args.no_parity and world == 1:
             line["parity"] = training_parity(model, sd, up, skip, sstep, x_t, y, dev)
         par = line["parity"]
