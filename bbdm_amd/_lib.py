@@ -130,6 +130,7 @@ SIGNATURES = {
     "bbdm_h2_gn_bounds_f32": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "bbdm_h2_stats_bound_f32": (c_int, [_P, c_int, c_int, _P, _P]),
     "bbdm_conv1x1_h2q_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, ctypes.c_longlong, c_int, c_int, _P, _P, _P]),
+    "bbdm_conv1x1_h2s_f32": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, c_int, ctypes.c_longlong, c_int, c_int, _P, _P, _P]),
     "bbdm_winograd_input_gain": (c_float, [c_int]),
     "bbdm_winograd_input_h2p_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "bbdm_winograd_input_h2p_gn_f32": (c_int, [c_int, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

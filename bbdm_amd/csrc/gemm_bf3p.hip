@@ -703,12 +703,14 @@ __global__ void __launch_bounds__(WM * WN * 64, NP == 2 && WM == 4 ? 4 : 3) gemm
 //     tile, so a weight byte enters exactly one L2.
 // 120 KB of LDS, one workgroup per CU.  K a multiple of 64.  Arithmetic: the six product terms per 16-channel chunk in BF3_TA / BF3_TB
 // order, chunks in ascending order -- bit-equal to bbdm_conv1x1_bf3_f32 / bbdm_conv1x1_bf3q_f32.
-template <bool RES, int NS>
+// NP = 2 (round 6): B as fp16-pair planes (a third fewer weight bytes: these launches are bound by the weight stream), A scaled and split
+// into two fp16 halves at the fragment read, three f16 MFMA terms, the accumulator re-scaled in the epilogue (h2_split.h).
+template <bool RES, int NS, int NP = 3>
 __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, const float* __restrict__ Af, int lda) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // [NS][ASTAGE + BSTAGE]
     constexpr int CH = 4;                                                       // chunks per iteration
     constexpr int ASTAGE = 64 * CH * KC * 4;                                    // 64 rows x 64 channels fp32 = 16 KB
-    constexpr int BSTAGE = 2 * CH * 3 * UNIT;                                   // 2 row groups x 4 chunks x 3 planes x 1 KB = 24 KB
+    constexpr int BSTAGE = 2 * CH * NP * UNIT;                                  // 2 row groups x 4 chunks x NP planes x 1 KB = 24 (16) KB
     constexpr int STAGE = ASTAGE + BSTAGE;
     constexpr int KA = ASTAGE / UNIT / 4, KB = BSTAGE / UNIT / 4;               // copies per wave and iteration: 4 of A, 6 of B
     const int tid = threadIdx.x, lane = tid & 63;
@@ -728,7 +730,7 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
     if (n_tile >= tilesN) return;
     const int row0 = m_tile * 64, cout0 = n_tile * 64;
     const int n = a.nchunks / CH;                                               // iterations
-    const size_t gstride = (size_t)a.nchunks * 3 * UNIT;
+    const size_t gstride = (size_t)a.nchunks * NP * UNIT;
     // ---- A copies: copy j = wave + 4 k covers rows 4 j .. 4 j + 3 of the tile; lane = (row in copy, slot), slot holds piece slot ^ (row % 16)
     const unsigned char* asrc[KA];
 #pragma unroll
@@ -741,7 +743,7 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
     const unsigned char* bsrc[KB];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
-        const int u = wave + k * 4, g = u / (CH * 3), v = u % (CH * 3);
+        const int u = wave + k * 4, g = u / (CH * NP), v = u % (CH * NP);
         bsrc[k] = a.B + (size_t)(n_tile * 2 + g) * gstride + (size_t)v * UNIT;
     }
     auto issue = [&](int it, unsigned char* st) {
@@ -750,7 +752,7 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[k] + (size_t)it * (CH * KC * 4)),
                                              (__attribute__((address_space(3))) void*)(st + (wave + 4 * k) * UNIT), 16, 0, 0);
 #pragma unroll
-        for (int k = 0; k < KB; ++k) glds16(bsrc[k] + (size_t)it * (CH * 3 * UNIT), lane16, st + ASTAGE + (wave + k * 4) * UNIT);
+        for (int k = 0; k < KB; ++k) glds16(bsrc[k] + (size_t)it * (CH * NP * UNIT), lane16, st + ASTAGE + (wave + k * 4) * UNIT);
     };
     // ---- fragment reads: lane = (row r = lane % 32 of the wave's 32 rows, half h = lane / 32: channels 8 h .. 8 h + 7 of a chunk) ------
     const int R = wm * 32 + (lane & 31), h = lane >> 5;
@@ -761,7 +763,13 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
         aoff[c][0] = abase + (unsigned)((((4 * c + 2 * h) ^ (R & 15))) * 16);
         aoff[c][1] = abase + (unsigned)((((4 * c + 2 * h + 1) ^ (R & 15))) * 16);
     }
-    const unsigned boff = (unsigned)(ASTAGE + (wn * CH * 3) * UNIT) + lane16;
+    const unsigned boff = (unsigned)(ASTAGE + (wn * CH * NP) * UNIT) + lane16;
+    float ascale = 1.f, descale = 1.f;                                          // fp16 pair: read once, before any LDS read is in flight
+    if constexpr (NP == 2) {
+        const int ea = h2_exp_of_bound(*a.hA * a.gA), eb = h2_exp_of_bound(*a.hB * a.gB);
+        ascale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(h2_pow2(ea))));
+        descale = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(h2_pow2(-(ea + eb)))));
+    }
     float bv = 0.f;
     {
         const int co = cout0 + wn * 32 + (lane & 31);
@@ -792,39 +800,59 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
     const unsigned lds0 = lds_address(smem);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     f32x4 ra[3][2];
-    frag_t rb[3][3];
-    frag_t fa[2][3];
+    frag_t rb[3][NP];
+    frag_t fa[2][NP];
 #define BF3S_READ(set, c, base)                                                                                                 \
     do {                                                                                                                        \
         asm volatile("ds_read_b128 %0, %1" : "=v"(ra[set][0]) : "v"((base) + aoff[c][0]));                                      \
         asm volatile("ds_read_b128 %0, %1" : "=v"(ra[set][1]) : "v"((base) + aoff[c][1]));                                      \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][0]) : "v"((base) + boff), "n"(((c) * 3 + 0) * UNIT));       \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][1]) : "v"((base) + boff), "n"(((c) * 3 + 1) * UNIT));       \
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][2]) : "v"((base) + boff), "n"(((c) * 3 + 2) * UNIT));       \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][0]) : "v"((base) + boff), "n"(((c) * NP + 0) * UNIT));      \
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][1]) : "v"((base) + boff), "n"(((c) * NP + 1) * UNIT));      \
+        if constexpr (NP == 3)                                                                                                  \
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[set][NP - 1]) : "v"((base) + boff), "n"(((c) * NP + NP - 1) * UNIT)); \
     } while (0)
-    // the reads of `set` have returned; NEWER = 5: the five reads of one younger set may stay in flight (LDS returns in order)
-#define BF3S_RETURNED(set, NEWER)                                                                                               \
+    // the reads of `set` have returned; NEWER = the reads of one younger set (2 + NP) may stay in flight (LDS returns in order)
+#define BF3S_RETURNED(set, YOUNGER)                                                                                             \
     do {                                                                                                                        \
-        asm volatile("s_waitcnt lgkmcnt(" #NEWER ")"                                                                            \
-                     : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][2]) :: "memory");   \
+        if constexpr (NP == 3) {                                                                                                \
+            if (YOUNGER) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][NP - 1]) :: "memory"); \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]), "+v"(rb[set][NP - 1]) :: "memory"); \
+        } else {                                                                                                                \
+            if (YOUNGER) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) :: "memory"); \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0]), "+v"(rb[set][1]) :: "memory"); \
+        }                                                                                                                       \
     } while (0)
 #define BF3S_SPLIT(set, dst)                                                                                                    \
     do {                                                                                                                        \
-        uint2 p1, p2, p3, q1, q2, q3;                                                                                           \
-        split4(make_float4(ra[set][0][0], ra[set][0][1], ra[set][0][2], ra[set][0][3]), p1, p2, p3);                            \
-        split4(make_float4(ra[set][1][0], ra[set][1][1], ra[set][1][2], ra[set][1][3]), q1, q2, q3);                            \
-        fa[dst][0] = frag_t{(int)p1.x, (int)p1.y, (int)q1.x, (int)q1.y};                                                        \
-        fa[dst][1] = frag_t{(int)p2.x, (int)p2.y, (int)q2.x, (int)q2.y};                                                        \
-        fa[dst][2] = frag_t{(int)p3.x, (int)p3.y, (int)q3.x, (int)q3.y};                                                        \
+        if constexpr (NP == 3) {                                                                                                \
+            uint2 p1, p2, p3, q1, q2, q3;                                                                                       \
+            split4(make_float4(ra[set][0][0], ra[set][0][1], ra[set][0][2], ra[set][0][3]), p1, p2, p3);                        \
+            split4(make_float4(ra[set][1][0], ra[set][1][1], ra[set][1][2], ra[set][1][3]), q1, q2, q3);                        \
+            fa[dst][0] = frag_t{(int)p1.x, (int)p1.y, (int)q1.x, (int)q1.y};                                                    \
+            fa[dst][1] = frag_t{(int)p2.x, (int)p2.y, (int)q2.x, (int)q2.y};                                                    \
+            fa[dst][NP - 1] = frag_t{(int)p3.x, (int)p3.y, (int)q3.x, (int)q3.y};                                               \
+        } else {                                                                                                                \
+            uint2 p1, p2, q1, q2;                                                                                               \
+            h2_split4(make_float4(ra[set][0][0] * ascale, ra[set][0][1] * ascale, ra[set][0][2] * ascale, ra[set][0][3] * ascale), p1, p2); \
+            h2_split4(make_float4(ra[set][1][0] * ascale, ra[set][1][1] * ascale, ra[set][1][2] * ascale, ra[set][1][3] * ascale), q1, q2); \
+            fa[dst][0] = frag_t{(int)p1.x, (int)p1.y, (int)q1.x, (int)q1.y};                                                    \
+            fa[dst][1] = frag_t{(int)p2.x, (int)p2.y, (int)q2.x, (int)q2.y};                                                    \
+        }                                                                                                                       \
     } while (0)
 #define BF3S_MFMAS(src, set)                                                                                                    \
     do {                                                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                                           \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[src][BF3_TA[t]]), BF3P_BF(rb[set][BF3_TB[t]]), acc, 0, 0, 0); \
+        if constexpr (NP == 3) {                                                                                                \
+            _Pragma("unroll") for (int t = 0; t < 6; ++t)                                                                       \
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[src][BF3_TA[t] % NP]), BF3P_BF(rb[set][BF3_TB[t] % NP]), acc, 0, 0, 0); \
+        } else {                                                                                                                \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][0]), __builtin_bit_cast(f16x8, rb[set][1]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][1]), __builtin_bit_cast(f16x8, rb[set][0]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][0]), __builtin_bit_cast(f16x8, rb[set][0]), acc, 0, 0, 0); \
+        }                                                                                                                       \
     } while (0)
 #define BF3S_INTERLEAVE()                                                                                                       \
     do {                                                                                                                        \
-        _Pragma("unroll") for (int t = 0; t < 6; ++t) {                                                                         \
+        _Pragma("unroll") for (int t = 0; t < (NP == 3 ? 6 : 3); ++t) {                                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                  \
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                                  \
         }                                                                                                                       \
@@ -834,17 +862,17 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
         const unsigned st = lds0 + (unsigned)((i % NS) * STAGE);
         BF3S_READ(0, 0, st);
         BF3S_READ(1, 1, st);
-        BF3S_RETURNED(0, 5);
+        BF3S_RETURNED(0, 1);
         BF3S_SPLIT(0, 0);
         BF3S_READ(2, 2, st);
-        BF3S_RETURNED(1, 5);
+        BF3S_RETURNED(1, 1);
         __builtin_amdgcn_sched_barrier(0);
         BF3S_MFMAS(0, 0);                                                       // chunk 0 | split of chunk 1
         BF3S_SPLIT(1, 1);
         BF3S_INTERLEAVE();
         __builtin_amdgcn_sched_barrier(0);
         BF3S_READ(0, 3, st);
-        BF3S_RETURNED(2, 5);
+        BF3S_RETURNED(2, 1);
         __builtin_amdgcn_sched_barrier(0);
         BF3S_MFMAS(1, 1);                                                       // chunk 1 | split of chunk 2
         BF3S_SPLIT(2, 0);
@@ -873,7 +901,7 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (co < a.Cout && row < a.T) {
-            float v = acc[r] + bv;
+            float v = (NP == 2 ? acc[r] * descale : acc[r]) + bv;
             if (RES) v += res[(size_t)row * a.ldr + co];
             a.M[(size_t)row * a.ldo + co] = v;
         }
@@ -1485,8 +1513,10 @@ extern "C" int bbdm_conv1x1_h2q_f32(const float* x, int ldx, const void* b_plane
 // The same product for SMALL problems (gemm_bf3s_kernel above: 64 x 64 tiles, 64 channels per iteration, one launch, no split-K):
 // same arguments, same b_planes, same bits as bbdm_conv1x1_bf3q_f32.  The caller chooses (unet.py: below BBDM_BF3_MIN_TILES tiles of
 // 256 x 128); any pixel count, CinPad a multiple of 64.
-extern "C" int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
-                                     float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream) {
+namespace {
+template <int NP>
+int conv1x1_small(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr, float* out, int ldo,
+                  long long pixels, int CinPad, int Cout, const float* xbound, const float* wbound, void* stream) {
     BBDM_REQUIRE(x && b_planes && out, "conv1x1_bf3s: null pointer");
     BBDM_REQUIRE(pixels > 0 && pixels < (1ll << 31) && CinPad > 0 && CinPad % 64 == 0 && Cout > 0 && Cout % 4 == 0,
                  "conv1x1_bf3s: pixels=%lld CinPad=%d Cout=%d unsupported (CinPad %% 64)", pixels, CinPad, Cout);
@@ -1501,15 +1531,16 @@ extern "C" int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_plan
     a.az = 0; a.bz = 0; a.mz = 0; a.rz = 0;
     a.ldo = ldo; a.ldr = ldr; a.bias = bias; a.res = residual;
     a.ksplits = 1; a.kps = a.nchunks; a.P = 1; a.batch = 1; a.persist = 0; a.tiles = 0;
+    a.hA = xbound; a.hB = wbound;
     const int tilesM = cdiv((int)pixels, 64), tilesN = cdiv(Cout, 64);
     a.by_batch = tilesN % 8 == 0 ? 1 : 0;
     constexpr int NS = 3;      // (four stages = all 160 KB of LDS, measured: no faster -- the chain is bound by what one CU's LDS-DMA path moves,
                                // ~40 GB/s, not by the distance of the prefetch: profiles/r04_small_1x1.md)
-    const size_t lds = NS * (size_t)(64 * 64 * 4 + 2 * 4 * 3 * UNIT);
+    const size_t lds = NS * (size_t)(64 * 64 * 4 + 2 * 4 * NP * UNIT);
     static bool attr_set_dev[BBDM_MAX_DEVICES][2] = {};
     bool& attr_set = attr_set_dev[bbdm_device_slot()][residual ? 1 : 0];
     if (!attr_set) {
-        const void* fn = residual ? reinterpret_cast<const void*>(gemm_bf3s_kernel<true, NS>) : reinterpret_cast<const void*>(gemm_bf3s_kernel<false, NS>);
+        const void* fn = residual ? reinterpret_cast<const void*>(gemm_bf3s_kernel<true, NS, NP>) : reinterpret_cast<const void*>(gemm_bf3s_kernel<false, NS, NP>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             bbdm_set_error("conv1x1_bf3s: hipFuncSetAttribute(%zu B LDS) failed", lds);
             return BBDM_E_LAUNCH;
@@ -1519,8 +1550,22 @@ extern "C" int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_plan
     BBDM_REQUIRE((long long)tilesM * tilesN < (1ll << 31), "conv1x1_bf3s: too many tiles");
     const dim3 grid((unsigned)(tilesM * tilesN));
     hipStream_t st = (hipStream_t)stream;
-    if (residual) hipLaunchKernelGGL((gemm_bf3s_kernel<true, NS>), grid, dim3(256), lds, st, a, x, ldx);
-    else hipLaunchKernelGGL((gemm_bf3s_kernel<false, NS>), grid, dim3(256), lds, st, a, x, ldx);
+    if (residual) hipLaunchKernelGGL((gemm_bf3s_kernel<true, NS, NP>), grid, dim3(256), lds, st, a, x, ldx);
+    else hipLaunchKernelGGL((gemm_bf3s_kernel<false, NS, NP>), grid, dim3(256), lds, st, a, x, ldx);
     BBDM_CHECK_LAUNCH("conv1x1_bf3s");
     return BBDM_OK;
+}
+}  // namespace
+
+extern "C" int bbdm_conv1x1_bf3s_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                     float* out, int ldo, long long pixels, int CinPad, int Cout, void* stream) {
+    return conv1x1_small<3>(x, ldx, b_planes, bias, residual, ldr, out, ldo, pixels, CinPad, Cout, nullptr, nullptr, stream);
+}
+// ... on the fp16-pair planes (round 6): the arguments and bounds of bbdm_conv1x1_h2q_f32, the tile shape and size range of
+// bbdm_conv1x1_bf3s_f32 (CinPad a multiple of 64); a third fewer weight bytes for launches that are bound by the weight stream
+extern "C" int bbdm_conv1x1_h2s_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr,
+                                    float* out, int ldo, long long pixels, int CinPad, int Cout, const float* xbound, const float* wbound,
+                                    void* stream) {
+    BBDM_REQUIRE(xbound && wbound, "conv1x1_h2s: null bound");
+    return conv1x1_small<2>(x, ldx, b_planes, bias, residual, ldr, out, ldo, pixels, CinPad, Cout, xbound, wbound, stream);
 }

@@ -332,6 +332,17 @@ def _round4(c):
     return (c + 3) // 4 * 4
 
 
+def _zero_on(t: torch.Tensor, stream):
+    """``t.zero_()`` enqueued on the raw HIP stream ``stream`` -- the stream the packing launches that follow are given.  (The training
+    plans re-pack their data-gradient operands on the plan's SECOND stream: a plain ``zero_()`` would go to torch's current stream and
+    race with the maximum those launches accumulate into ``t``.)"""
+    if t.is_cuda and stream:
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=t.device)):
+            t.zero_()
+    else:
+        t.zero_()
+
+
 class _PackedConv:
     """Packed copy of one conv weight, refreshed when the parameter storage or version changes
     (EMA swaps ``param.data`` without bumping ``_version`` -- runners/base/EMA.py:31-43 -- so both are keyed)."""
@@ -423,7 +434,7 @@ class _PackedConvH2q(_PackedConv):
                 raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
             _lib.call("bbdm_conv_pack_weight_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                       self.cin_pad, 1, stream)
-            self.ubound.zero_()
+            _zero_on(self.ubound, stream)
             _lib.call("bbdm_absmax_f32", self.packed_f32.data_ptr(), self.packed_f32.numel(), self.ubound.data_ptr(), stream)
             _lib.call("bbdm_gemm_h2p_pack_b_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), 1.0, 1,
                       self.cin_pad, self.cout, stream)
@@ -528,7 +539,7 @@ class _PackedWinograd:
             if self.bf3 == "h":
                 # fp16-pair planes of U 2^e: e from ``ubound`` = the filter's largest tap (one small pass over the weights) times the gain
                 # of G . G^T, the factor the tile GEMM applies to the same pointer -- G g G^T goes straight into the planes
-                self.ubound.zero_()
+                _zero_on(self.ubound, stream)
                 if self.phases:
                     _lib.call("bbdm_upsample_phase_weights_f32", w.data_ptr(), self.w4.data_ptr(), self.cout, self.cin, stream)
                     _lib.call("bbdm_absmax_f32", self.w4.data_ptr(), self.w4.numel(), self.ubound.data_ptr(), stream)
@@ -1312,6 +1323,12 @@ class _Plan:
         return bool(not self.training and getattr(self.m, "conv1x1_h2", True) and self._h2_on(1) and cin % 16 == 0 and cout % 4 == 0
                     and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles)
 
+    def _conv1x1_h2s_ok(self, pixels: int, cin: int, cout: int) -> bool:
+        """... or, below that size, on the small-problem form bbdm_conv1x1_h2s_f32 (bound by its weight stream: a third fewer bytes)?"""
+        return bool(not self.training and getattr(self.m, "conv1x1_h2", True) and self._h2_on(1) and self.m.conv1x1_small
+                    and not self._conv1x1_h2_ok(pixels, cin, cout) and cin % 64 == 0 and cout % 4 == 0
+                    and not (self.lib.bbdm_gemm_bf3_supported(pixels, cin, cout) and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles))
+
     def _stats_bound(self, slot: int):
         """Bound slot for the RAW tensor whose GroupNorm statistics are accumulator ``slot``: the largest root-sum-of-squares over its
         (image, group) cells (csrc/groupnorm.hip: h2_stats_bound_kernel).  Emitted where the statistics are complete."""
@@ -1592,6 +1609,13 @@ class _Plan:
                            _TensorRef(pb.packed), self._pref(pb.bias), residual, res_ld, dest, dest.ld, pixels, x.C, cout)
             self._note_writer(dest, rec, None)
             return
+        if (ks == 1 and xb is not None and (pre is None or pre[0] is None) and flags == 0 and self._conv1x1_h2s_ok(pixels, x.C, cout)):
+            pb = self._packed(_PackedConvH2q, mod.weight, mod.bias, x.C)
+            self.convs.append(pb)
+            rec = self._op(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_h2s_f32"), x, x.ld, _TensorRef(pb.packed), self._pref(pb.bias),
+                           residual, res_ld, dest, dest.ld, pixels, x.C, cout, xb, _TensorRef(pb.ubound))
+            self._note_writer(dest, rec, None)
+            return
         if (ks == 1 and self.m.gemm_bf3 and self.m.conv1x1_small and (pre is None or pre[0] is None) and flags == 0
                 and x.C % 64 == 0 and cout % 4 == 0):
             # small 1x1 convolutions / Linears: bound by the length of a workgroup's chain of K steps, not by the matrix pipe -- the
@@ -1642,7 +1666,8 @@ class _Plan:
             nonlocal side, out
             out = dest if dest is not None else self._new(N, x.H, x.W, rb.out_channels)
             xbound = self._stats_bound(s1) if (rb.skip_connection.weight.shape[2] == 1
-                                               and self._conv1x1_h2_ok(N * x.H * x.W, x.C, rb.out_channels)) else None
+                                               and (self._conv1x1_h2_ok(N * x.H * x.W, x.C, rb.out_channels)
+                                                    or self._conv1x1_h2s_ok(N * x.H * x.W, x.C, rb.out_channels))) else None
             k0 = len(self.ops)
             self._emit_conv(x, rb.skip_connection, None, out, pre=_Pre(self.NO_PRE, h2=xbound) if xbound is not None else None)
             if all(str(n) == "bbdm_conv1x1_bf3_f32" for n, _ in self.ops[k0:]):
@@ -1685,7 +1710,8 @@ class _Plan:
                 # the projection reads the block input itself (pooled / copied for an up / down block: no larger): bounded by the
                 # statistics the block's first GroupNorm took of it (slot s1, complete by now)
                 xbound = self._stats_bound(s1) if (rb.skip_connection.weight.dim() == 4 and rb.skip_connection.weight.shape[2] == 1
-                                                   and self._conv1x1_h2_ok(N * xr.H * xr.W, xr.C, rb.out_channels)) else None
+                                                   and (self._conv1x1_h2_ok(N * xr.H * xr.W, xr.C, rb.out_channels)
+                                                        or self._conv1x1_h2s_ok(N * xr.H * xr.W, xr.C, rb.out_channels))) else None
                 self._emit_conv(xr, rb.skip_connection, None, out, pre=_Pre(self.NO_PRE, h2=xbound) if xbound is not None else None)
             self._emit_conv(a2, rb.out_layers[3], out, out, pre=pre2)
             if side is not None:
@@ -1704,7 +1730,7 @@ class _Plan:
         ch = C // ab.num_heads
         s0 = self._gn_count
         a, pre = self._gn_input(x, ab.norm, None, silu=0, name="A")
-        if (pre is None or pre[0] is None) and self._conv1x1_h2_ok(N * T, C, 3 * C):
+        if (pre is None or pre[0] is None) and (self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C)):
             pre = _Pre(self.NO_PRE, h2=self._gn_bound(x, ab.norm, None))      # (a materialised GroupNorm output: bounded by its coefficients)
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
         self._emit_conv(a, ab.qkv, None, qkv, pre=pre)

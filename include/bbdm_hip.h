@@ -533,6 +533,9 @@ int bbdm_h2_stats_bound_f32(const bbdm_stats_t* stats, int N, int G, float* boun
  * b_planes = bbdm_gemm_h2p_pack_b_f32(batch = 1) of bbdm_conv_pack_weight_f32(ks = 1)'s buffer under wbound = its bbdm_absmax_f32. */
 int bbdm_conv1x1_h2q_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr, float* out,
                          int ldo, long long pixels, int CinPad, int Cout, const float* xbound, const float* wbound, void* stream);
+/* ... and of bbdm_conv1x1_bf3s_f32 (the small-problem kernel: CinPad a multiple of 64), same planes and bounds */
+int bbdm_conv1x1_h2s_f32(const float* x, int ldx, const void* b_planes, const float* bias, const float* residual, int ldr, float* out,
+                         int ldo, long long pixels, int CinPad, int Cout, const float* xbound, const float* wbound, void* stream);
 float bbdm_winograd_input_gain(int m);
 int bbdm_winograd_input_h2p_f32(int m, const float* x, int ldx, void* Vp, const float* pre_scale, const float* pre_bias, int pre_ld,
                                 int pre_silu, int upsample, int N, int H, int W, int CinPad, const float* vbound, void* stream);

@@ -698,7 +698,8 @@ def conv3x3_winograd_planes(x: torch.Tensor, w: torch.Tensor, bias: Optional[tor
 
 
 def conv1x1_h2q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
-                out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0, xbound: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, cin: Optional[int] = None, x_off: int = 0, xbound: Optional[torch.Tensor] = None,
+                small: bool = False) -> torch.Tensor:
     """:func:`conv1x1_bf3q` on the fp16-pair planes (bbdm_conv1x1_h2q_f32): ``xbound`` a device float >= max |x| (default: the measured
     maximum of the whole buffer), the weights under their exact maximum."""
     _chk(x, w, bias, residual)
@@ -713,7 +714,8 @@ def conv1x1_h2q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     xb = absmax(x) if xbound is None else xbound
     if out is None:
         out = torch.empty(x.shape[0], cout, dtype=torch.float32, device=x.device)
-    _lib.call("bbdm_conv1x1_h2q_f32", x.data_ptr() + 4 * x_off, x.shape[1], bp.data_ptr(), None if bias is None else bias.data_ptr(),
+    _lib.call("bbdm_conv1x1_h2s_f32" if small else "bbdm_conv1x1_h2q_f32", x.data_ptr() + 4 * x_off, x.shape[1], bp.data_ptr(),
+              None if bias is None else bias.data_ptr(),
               None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1],
               out.data_ptr(), out.shape[1], x.shape[0], cin, cout, xb.data_ptr(), wb.data_ptr(), _st(x))
     return out

@@ -179,6 +179,11 @@ def test_conv1x1_h2q(pixels, Cin, Cout, res):
     K.test_conv1x1_h2q(CPU, pixels, Cin, Cout, res)
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(512, 64, 132, True), (96, 128, 8, False), (100, 192, 72, True), (64, 64, 64, False)])
+def test_conv1x1_h2s(pixels, Cin, Cout, res):
+    K.test_conv1x1_h2s(CPU, pixels, Cin, Cout, res)
+
+
 def test_h2_stats_bound():
     K.test_h2_stats_bound(CPU)
 

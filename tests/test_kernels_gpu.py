@@ -861,6 +861,28 @@ def test_conv1x1_h2q(dev, pixels, Cin, Cout, res):
     assert e < 3e-6 and e2 < 3e-6
 
 
+@pytest.mark.parametrize("pixels,Cin,Cout,res", [(512, 1024, 3072, False), (512, 64, 132, True), (96, 128, 8, False), (2080, 256, 1024, True),
+                                                 (100, 192, 72, True), (64, 64, 64, False)])
+def test_conv1x1_h2s(dev, pixels, Cin, Cout, res):
+    """The small-problem 1x1 kernel on the fp16-pair planes (gemm_bf3s_kernel<NP = 2>: the shapes of test_conv1x1_bf3s_bitwise -- one step
+    (K = 64) to sixteen, ragged row and column tiles, both tile orders, in-place residual): against fp64, and bit-equal to
+    bbdm_conv1x1_h2q_f32 on the same operands (same two planes, same three terms in the same order)."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(pixels + Cin)
+    wide = torch.randn(pixels, Cin + 16, generator=g)
+    w = torch.randn(Cout, Cin, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(pixels, Cout, generator=g) if res else None
+    ref = wide[:, 16:].double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    buf = r.clone().to(dev) if res else None
+    out = ops.conv1x1_h2q(wide.to(dev), w.to(dev), b.to(dev), residual=buf, out=buf, cin=Cin, x_off=16, small=True).cpu()
+    buf0 = r.clone().to(dev) if res else None
+    out0 = ops.conv1x1_h2q(wide.to(dev), w.to(dev), b.to(dev), residual=buf0, out=buf0, cin=Cin, x_off=16).cpu()
+    e = rel_err(out, ref)
+    print(f"conv1x1 small [{pixels} x {Cin} -> {Cout}] on the fp16 pair: rel err vs fp64 {e:.2e}")
+    assert e < 3e-6 and torch.equal(out, out0), (out - out0).abs().max()
+
+
 def test_h2_stats_bound(dev):
     """bbdm_h2_stats_bound_f32: the largest root-sum-of-squares over the (image, group) cells of a GroupNorm accumulator bounds the raw
     tensor (also with one 1000x outlier), and is at most sqrt(values per group) above its maximum."""

@@ -216,15 +216,20 @@ def test_1x1_layers_take_the_kernel_their_size_asks_for():
     for entry, pixels, cin, cout in layers:
         tiles = (pixels // 256) * -(-cout // 128)
         if tiles >= m.bf3_min_tiles:
-            assert entry in ("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32"), (entry, pixels, cin, cout)
-        else:
-            assert entry == "bbdm_conv1x1_bf3s_f32" and cin % 64 == 0 and cout % 4 == 0, (entry, pixels, cin, cout)
-    assert any(e == "bbdm_conv1x1_bf3s_f32" and (px, ci, co) == (512, 1024, 3072) for e, px, ci, co in layers)     # the qkv projections
+            assert entry in ("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32", "bbdm_conv1x1_h2q_f32"), (entry, pixels, cin, cout)
+        else:       # (round 6: on the fp16 pair where the input carries a bound -- skip projections, qkv; proj_out keeps bf16x3)
+            assert entry in ("bbdm_conv1x1_bf3s_f32", "bbdm_conv1x1_h2s_f32") and cin % 64 == 0 and cout % 4 == 0, (entry, pixels, cin, cout)
+    assert any(e == "bbdm_conv1x1_h2s_f32" and (px, ci, co) == (512, 1024, 3072) for e, px, ci, co in layers)     # the qkv projections
+    assert any(e == "bbdm_conv1x1_bf3s_f32" and ci == co for e, px, ci, co in layers)                              # ... proj_out
+    m1 = unet.UNetModel(**bench.WORKLOADS["c5"][1])
+    m1.winograd, m1.conv1x1_h2 = 4, False
+    layers1 = one_by_ones(m1._plan_for(torch.zeros(32, bench.WORKLOADS["c5"][1]["in_channels"], 16, 16), False))
+    assert [l[1:] for l in layers1] == [l[1:] for l in layers] and not any("h2" in str(e) for e, *_ in layers1)
     m0 = unet.UNetModel(**bench.WORKLOADS["c5"][1])
     m0.winograd, m0.conv1x1_small = 4, False
     plan0 = m0._plan_for(torch.zeros(32, bench.WORKLOADS["c5"][1]["in_channels"], 16, 16), False)
     layers0 = one_by_ones(plan0)
-    assert len(layers0) == len(layers) and not any(e == "bbdm_conv1x1_bf3s_f32" for e, *_ in layers0)
+    assert len(layers0) == len(layers) and not any(e in ("bbdm_conv1x1_bf3s_f32", "bbdm_conv1x1_h2s_f32") for e, *_ in layers0)
     assert [l[1:] for l in layers0] == [l[1:] for l in layers]
 
 
