@@ -445,15 +445,19 @@ class _PackedDgradBf3:
     """The transposed weight of a 1x1 conv / Linear in the three-bf16-plane layout of csrc/gemm_bf3.hip: the data gradient
     dX = dY W as one more fp32-accurate GEMM on the BF16 matrix core (``packed``; the fp32 dgrad packing is the intermediate)."""
 
-    def __init__(self, weight: nn.Parameter, cout_in: int, planes: bool = False):
-        """``planes``: the B planes of csrc/gemm_bf3p.hip (for bbdm_conv1x1_bf3q_f32) instead of gemm_bf3.hip's layout."""
+    def __init__(self, weight: nn.Parameter, cout_in: int, planes=False):
+        """``planes``: the B planes of csrc/gemm_bf3p.hip (for bbdm_conv1x1_bf3q_f32) instead of gemm_bf3.hip's layout; "h": the
+        fp16-pair planes under the weights' exact maximum ``ubound`` (bbdm_conv1x1_h2q_f32; round 6)."""
         self.weight = weight
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.cout_in, self.planes = cout_in, planes
         lib = _lib.load()
         self.packed_f32 = torch.empty(lib.bbdm_conv_packed_dgrad_floats(self.cout, self.cin, cout_in, 1), dtype=torch.float32,
                                       device=weight.device)
-        if planes:
+        self.ubound = torch.zeros(1, dtype=torch.float32, device=weight.device) if planes == "h" else None
+        if planes == "h":
+            self.packed = torch.empty(lib.bbdm_gemm_h2p_b_bytes(1, cout_in, self.cin), dtype=torch.uint8, device=weight.device)
+        elif planes:
             self.packed = torch.empty(lib.bbdm_gemm_bf3p_b_bytes(1, cout_in, self.cin), dtype=torch.uint8, device=weight.device)
         else:
             self.packed = torch.empty(lib.bbdm_gemm_bf3_packed_halfs(1, cout_in, self.cin), dtype=torch.int16, device=weight.device)
@@ -465,8 +469,14 @@ class _PackedDgradBf3:
         if key != self.key:
             _lib.call("bbdm_conv_pack_weight_dgrad_f32", w.data_ptr(), self.packed_f32.data_ptr(), self.cout, self.cin,
                       self.cout_in, 1, stream)
-            _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.planes else "bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(),
-                      self.packed.data_ptr(), 1, self.cout_in, self.cin, stream)
+            if self.planes == "h":
+                _zero_on(self.ubound, stream)
+                _lib.call("bbdm_absmax_f32", self.packed_f32.data_ptr(), self.packed_f32.numel(), self.ubound.data_ptr(), stream)
+                _lib.call("bbdm_gemm_h2p_pack_b_f32", self.packed_f32.data_ptr(), self.packed.data_ptr(), self.ubound.data_ptr(), 1.0, 1,
+                          self.cout_in, self.cin, stream)
+            else:
+                _lib.call("bbdm_gemm_bf3p_pack_b_f32" if self.planes else "bbdm_gemm_bf3_pack_f32", self.packed_f32.data_ptr(),
+                          self.packed.data_ptr(), 1, self.cout_in, self.cin, stream)
             self.key = key
 
 
@@ -1320,7 +1330,7 @@ class _Plan:
     def _conv1x1_h2_ok(self, pixels: int, cin: int, cout: int) -> bool:
         """Would a 1x1 convolution of this size with a bounded input run on bbdm_conv1x1_h2q_f32?  (inference, wide layers: the small
         problems keep the small-problem kernel)"""
-        return bool(not self.training and getattr(self.m, "conv1x1_h2", True) and self._h2_on(1) and cin % 16 == 0 and cout % 4 == 0
+        return bool(getattr(self.m, "conv1x1_h2", True) and self._h2_on(1) and cin % 16 == 0 and cout % 4 == 0
                     and (pixels // 256) * -(-cout // 128) >= self.m.bf3_min_tiles)
 
     def _conv1x1_h2s_ok(self, pixels: int, cin: int, cout: int) -> bool:
@@ -1962,14 +1972,15 @@ class _Plan:
             return _Plan._StatsRef(self, slot)
 
         def conv_bwd(mod, x_in: _View, dy: _View, need_dx: bool, dx_name: str, cin_true=None, side: bool = False,
-                     side_chain: bool = False):
+                     side_chain: bool = False, dy_bound=None):
             """wgrad + bias grad (+ dgrad into a scratch view).  dy: gradient of the conv output (pitch >= Cout).  ``side``: a 1x1
             layer whose launches may run on the plan's second stream -- its weight gradient takes a workspace of its own;
             ``side_chain``: a 3x3 layer whose Winograd-domain weight gradient on the kept planes may (that chain only)."""
             w = mod.weight
             cout, cin = w.shape[0], w.shape[1]
             ks = w.shape[2] if w.dim() == 4 else 1
-            dy_ref = [None]                          # the bound slot of dY (fp16-pair planes): measured once, shared by wgrad and dgrad
+            dy_ref = [dy_bound]                      # the bound slot of dY (fp16-pair planes): measured once, shared by wgrad and dgrad
+                                                     # (``dy_bound``: the caller measured it already -- a gradient two layers read)
             wsn = ws_side_floats if side else ws_floats
             wsn[0] = max(wsn[0], lib.bbdm_conv_wgrad_workspace_floats(N, x_in.H, x_in.W, x_in.C, cout, ks))
             if x_in.C == cin:
@@ -2064,6 +2075,15 @@ class _Plan:
                 self._emit_winograd(dy, dy.C, pk, pre_dy, False, x_in.H, x_in.W, None, 0, dx, 0, bwd=True)
                 return dx
             pixels = x_in.N * x_in.H * x_in.W
+            if (ks == 1 and x_in.C == cin and self._h2_on(2) and getattr(m, "conv1x1_h2", True) and dy.C % 16 == 0 and dy.ld % 4 == 0
+                    and x_in.C % 4 == 0 and (pixels // 256) * -(-x_in.C // 128) >= m.bf3_min_tiles):
+                # wide 1x1 layers on the fp16 pair: dX = dY W with dY under its measured maximum (as the 3x3 layers' data gradient)
+                pk = _PackedDgradBf3(w, dy.C, planes="h")
+                self.dconvs.append(pk)
+                dy_ref[0] = dy_ref[0] or self._dy_bound(dy)
+                self._bop(_OpName("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_h2q_f32"), dy, dy.ld, _TensorRef(pk.packed), None, None, 0, dx,
+                          dx.ld, pixels, dy.C, x_in.C, dy_ref[0], _TensorRef(pk.ubound))
+                return dx
             if (ks == 1 and m.gemm_bf3 and x_in.C == cin and lib.bbdm_gemm_bf3_supported(pixels, dy.C, x_in.C)
                     and (pixels // 256) * -(-x_in.C // 128) >= m.bf3_min_tiles):
                 q = (-(-x_in.C // 128) * 128) % 256 == 0
@@ -2120,6 +2140,8 @@ class _Plan:
                 _, rb, x, a, xr, h1, a2, out, s1, s2, rs = rec
                 dout = gview(out)
                 bside = None
+                # dOut is read by the skip projection's and by the out conv's gradients: its maximum is measured once, on the main stream
+                dref = self._dy_bound(dout) if (self._h2_on(2) and dout.C % 4 == 0 and dout.ld % 4 == 0) else None
                 if isinstance(rb.skip_connection, nn.Conv2d):
                     # the projection's gradients read only dOut (complete before this block's backward starts) and the block input: on the
                     # second stream beside the block's own chain; joined before the launch that adds dXr (the last GroupNorm backward)
@@ -2129,7 +2151,7 @@ class _Plan:
                           and rb.skip_connection.weight.shape[1] == xr.C and bool(lib.bbdm_gemm_bf3_supported(px, dout.C, xr.C))
                           and (px // 256) * -(-xr.C // 128) >= m.bf3_min_tiles)
                     k0 = len(self.bops)
-                    dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR", side=sb)
+                    dxr = conv_bwd(rb.skip_connection, xr, dout, True, "DXR", side=sb, dy_bound=dref)
                     # (checked, not assumed -- and not an assert, which python -O drops: only the workspace-free pair may leave the main
                     # stream; if conv_bwd ever chooses other kernels than the rule above predicts, the launches simply stay in order)
                     if sb and [str(n) for n, _ in self.bops[k0:]] == ["bbdm_conv_wgrad_f32", "bbdm_conv1x1_bf3_f32"]:
@@ -2137,7 +2159,7 @@ class _Plan:
                 else:
                     dxr = dout
                 side_chains.clear()
-                da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2", side_chain=True)
+                da2 = conv_bwd(rb.out_layers[3], a2, dout, True, "DA2", side_chain=True, dy_bound=dref)
                 dh1 = self._tmp("DH1", N, h1.H, h1.W, h1.C)
                 if rb.use_scale_shift_norm:
                     gn_bwd(rb.out_layers[0], h1, s2, self.film_off[id(rb)], da2, None, 1, 0, dh1, 0)

@@ -289,12 +289,14 @@ def loop_parity(model, workload, sd, y, dev, steps=24):
     ctx_c = None if up["condition_key"] == "nocond" else y[:1].cpu()
     g = torch.Generator().manual_seed(2024)
     noises = [torch.randn(y.shape, generator=g) for _ in range(steps)]
-    traj = [y[:1].cpu()]
+    traj, x0s = [y[:1].cpu()], []
     threads = torch.get_num_threads()
     torch.set_num_threads(min(threads, 32))                     # (one small image: all host threads oversubscribe it)
     try:
         for i in range(steps):
-            traj.append(path.p_sample(traj[-1], y[:1].cpu(), ctx_c, i, noises[i][:1])[0])
+            nxt, x0r = path.p_sample(traj[-1], y[:1].cpu(), ctx_c, i, noises[i][:1])
+            traj.append(nxt)
+            x0s.append(x0r)
     finally:
         torch.set_num_threads(threads)
 
@@ -316,8 +318,8 @@ def loop_parity(model, workload, sd, y, dev, steps=24):
                 for i in range(steps):
                     cur["eps"] = noises[i].to(dev)
                     xin = torch.cat([traj[i].to(dev), y[1:]], 0)
-                    a, _ = model.p_sample(xin, y, ctx, i, clip_denoised=False)
-                    worst = max(worst, err(a[:1], traj[i + 1]))
+                    a, b = model.p_sample(xin, y, ctx, i, clip_denoised=False)
+                    worst = max(worst, err(a[:1], traj[i + 1]), err(b[:1], x0s[i]))       # (x_{t-1} and x0_recon of the step)
                     img, _ = model.p_sample(img, y, ctx, i, clip_denoised=False)
                     img = img.clone()
                 torch.cuda.synchronize(dev)
