@@ -231,6 +231,11 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
                            "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1])                                       \
                          :: "memory");                                                                                          \
     } while (0)
+// the fp16-pair ring's counted waits (LDS returns in order: lgkmcnt(4) = everything but the four youngest reads, A 1 and B 0)
+#define BF3P_FIRST_READS_RETURNED()                                                                                            \
+    do { asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory"); } while (0)
+#define BF3P_LAST_READS_RETURNED()                                                                                             \
+    do { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory"); } while (0)
 #define BF3P_ALL_LANDED()                                                                                                      \
     do {                                                                                                                        \
         wait_vmcnt<0>();                                                                                                        \
@@ -268,6 +273,11 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
         if constexpr (R4) {
             for (int chunk = 0; chunk < n; chunk += 2) {
                 const bool has1 = chunk + 1 < n, has2 = chunk + 2 < n;
+                // term order (h1 k2) (h1 k1) (h2 k1): the first term of a chunk uses A plane 0 and B plane 1, whose last use in the previous
+                // chunk was its first / second term -- their reads were issued one or two term groups (4 - 8 MFMAs per wave) earlier, so the
+                // counted wait in the middle of the iteration finds them returned; the planes the LAST term frees (A 1, B 0) are read last
+                // and waited for after the first term of the next chunk.  (With (h1 k2) (h2 k1) (h1 k1) the first term needed A plane 0,
+                // freed by the last: every wave -- the four of a SIMD run in step after a barrier -- sat out an LDS round trip per chunk.)
                 {   // ---- chunk: its fragments are in registers; read chunk + 1 (landed since the last barrier) ----------------------
                     const unsigned nxt = lds0 + ((chunk + 1) & 3) * STAGE;
                     const unsigned sa = nxt + aoff, sb = nxt + boff;
@@ -278,30 +288,31 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
                     if (chunk + 4 < n) issue(chunk + 4, smem + (chunk & 3) * STAGE);           // the slot of chunk (in registers)
                     if (has1) BF3P_READ_B(1, sb);
                     __builtin_amdgcn_sched_barrier(0);
-                    BF3P_TERM(1, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (has1) BF3P_READ_A(1, sa);
-                    __builtin_amdgcn_sched_barrier(0);
                     BF3P_TERM(0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (has1) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+                    if (has1) BF3P_READ_A(0, sa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has1) { BF3P_READ_A(1, sa); BF3P_READ_B(0, sb); }
                 }
                 if (has1) {   // ---- chunk + 1; read chunk + 2 -----------------------------------------------------------------------
-                    BF3P_READS_RETURNED();
+                    BF3P_FIRST_READS_RETURNED();                               // B 1 and A 0 (the four youngest reads may be in flight)
                     const unsigned nxt = lds0 + ((chunk + 2) & 3) * STAGE;
                     const unsigned sa = nxt + aoff, sb = nxt + boff;
                     __builtin_amdgcn_sched_barrier(0);
                     BF3P_TERM(0, 1);
                     __builtin_amdgcn_sched_barrier(0);
+                    BF3P_LAST_READS_RETURNED();                                // A 1 and B 0, requested a term group ago
                     if (has2) BF3P_READ_B(1, sb);
-                    __builtin_amdgcn_sched_barrier(0);
-                    BF3P_TERM(1, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (has2) BF3P_READ_A(1, sa);
                     __builtin_amdgcn_sched_barrier(0);
                     BF3P_TERM(0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (has2) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+                    if (has2) BF3P_READ_A(0, sa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    BF3P_TERM(1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (has2) { BF3P_READ_A(1, sa); BF3P_READ_B(0, sb); }
                 }
                 wait_vmcnt<0>();
                 BF3P_READS_RETURNED();
@@ -341,20 +352,21 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
                 __builtin_amdgcn_sched_barrier(0);
                 if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
             } else {
-                // fp16 pair: (h1 k2) (h2 k1) (h1 k1) -- the small terms first; each fragment is re-read right after its last use
+                // fp16 pair: (h1 k2) (h1 k1) (h2 k1) -- the order of the ring kernel above (results are bit-equal across the tile variants);
+                // each fragment is re-read right after its last use
                 __builtin_amdgcn_sched_barrier(0);
                 BF3P_TERM(0, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (chunk + NS < n) issue(chunk + NS, smem + (chunk % NS) * STAGE);
                 if (has_next) BF3P_READ_B(1, sb);
                 __builtin_amdgcn_sched_barrier(0);
-                BF3P_TERM(1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (has_next) BF3P_READ_A(1, sa);
-                __builtin_amdgcn_sched_barrier(0);
                 BF3P_TERM(0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (has_next) { BF3P_READ_A(0, sa); BF3P_READ_B(0, sb); }
+                if (has_next) BF3P_READ_A(0, sa);
+                __builtin_amdgcn_sched_barrier(0);
+                BF3P_TERM(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) { BF3P_READ_A(1, sa); BF3P_READ_B(0, sb); }
             }
             // my copies of chunk + 2 have landed (NS > 2: those of chunks chunk + 3 .. chunk + NS, issued after them, may stay in flight;
             // in the last iterations fewer are behind them: wait for all), my reads of chunk + 1 returned
@@ -417,6 +429,8 @@ __global__ void __launch_bounds__(WM * WN * 64, NS == 2 ? 4 : NS == 3 ? 2 : 1) g
 #undef BF3P_TERM
 #undef BF3P_MFMA
 #undef BF3P_ALL_LANDED
+#undef BF3P_LAST_READS_RETURNED
+#undef BF3P_FIRST_READS_RETURNED
 #undef BF3P_READS_RETURNED
 #undef BF3P_READ_B
 #undef BF3P_READ_A
@@ -631,14 +645,14 @@ __global__ void __launch_bounds__(WM * WN * 64, NP == 2 && WM == 4 ? 4 : 3) gemm
             if (stage2) { issue_b(chunk + 2, st2); load_a(chunk + 2); }        // under the first MFMAs
             if (has_next) BF3Q_READ_B(1, sb);
             __builtin_amdgcn_sched_barrier(0);
-            BF3Q_TERM(1, 0);
+            BF3Q_TERM(0, 0);                                                   // (the term order of gemm_bf3p_pipe_kernel's fp16 pair)
             __builtin_amdgcn_sched_barrier(0);
-            if (has_next) BF3Q_READ_A(1, sa);
+            if (has_next) BF3Q_READ_A(0, sa);
             if (stage2) store_a(st2);                                          // (waits for this thread's A request; the split runs under the MFMAs)
             __builtin_amdgcn_sched_barrier(0);
-            BF3Q_TERM(0, 0);
+            BF3Q_TERM(1, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (has_next) { BF3Q_READ_A(0, sa); BF3Q_READ_B(0, sb); }
+            if (has_next) { BF3Q_READ_A(1, sa); BF3Q_READ_B(0, sb); }
         }
         BF3Q_ALL_LANDED();
         asm volatile("s_barrier" ::: "memory");
@@ -846,8 +860,8 @@ __global__ void __launch_bounds__(256, 1) gemm_bf3s_kernel(const Bf3pArgs a, con
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF3P_BF(fa[src][BF3_TA[t] % NP]), BF3P_BF(rb[set][BF3_TB[t] % NP]), acc, 0, 0, 0); \
         } else {                                                                                                                \
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][0]), __builtin_bit_cast(f16x8, rb[set][1]), acc, 0, 0, 0); \
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][1]), __builtin_bit_cast(f16x8, rb[set][0]), acc, 0, 0, 0); \
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][0]), __builtin_bit_cast(f16x8, rb[set][0]), acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[src][1]), __builtin_bit_cast(f16x8, rb[set][0]), acc, 0, 0, 0); \
         }                                                                                                                       \
     } while (0)
 #define BF3S_INTERLEAVE()                                                                                                       \
