@@ -778,7 +778,8 @@ def run_workload(args, env):
                 if str(ops_all[k][0]) != name:
                     raise RuntimeError(f"--dump-ops: profile entry {k} is {name}, the plan's op is {ops_all[k][0]}")
                 if name == "bbdm_conv1x1_bf3_f32":
-                    shp = "pixels{} {}->{} k1 (bf16x3)".format(*oargs[8:11])
+                    ent = getattr(ops_all[k][0], "entry", name)
+                    shp = "pixels{} {}->{} k1 ({})".format(*oargs[8:11], "fp16 pair" if "_h2" in ent else "bf16x3")
                 elif name == "bbdm_conv2d_nhwc_f32":
                     shp = "N{} {}x{} {}->{} k{}".format(*oargs[15:21])
                 elif name == "bbdm_winograd_gemm_f32":
@@ -958,8 +959,8 @@ def run_workload(args, env):
             "value": steps_per_s_job, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (tile GEMMs: fp32 operands as two fp16 planes under a provable power-of-two scale, 3 fp16-MFMA terms, fp32 "
-                      "accumulate -- measured against fp64 MORE accurate than the six-term bf16x3 split and than the f32 MFMA; wide 1x1 "
-                      "layers + attention: bf16x3; all other kernels native fp32)") if (use_bf3 and terms == 3.0) else
+                      "accumulate -- measured against fp64 MORE accurate than the six-term bf16x3 split and than the f32 MFMA; 1x1 layers "
+                      "whose input has a bound: the same pair; proj_out + attention: bf16x3; all other kernels native fp32)") if (use_bf3 and terms == 3.0) else
                      ("f32 (tile GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA terms, fp32 accumulate -- fp32-accurate; "
                       "all other kernels native fp32)") if use_bf3 else "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
             "config": {"workload": desc, "batch_per_gpu": batch, "image_size": size, "unet_params_M": nparams / 1e6,
