@@ -15,6 +15,7 @@
 // for step r makes register r of P^T exactly the B operand of step r -- no LDS round trip, no shuffles; row
 // max / sum are 15 VALU ops + one cross-half exchange.  The running max / sum / rescale are per-lane scalars.
 #include "bf3_split.h"
+#include "h2_split.h"
 #include "lds_dma.h"
 #include <stdlib.h>
 
@@ -414,10 +415,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) attn_fwd_kernel(cons
 // Same split, same six terms, same MFMA order as attn_fwd_kernel<CH, true, true>: bit-equal results (tests).
 constexpr int ATTN_UNIT = 1024;
 
-template <int CH>
+// NP = 2 (round 6): the fp16-pair planes of h2_split.h under ONE power-of-two scale 2^e for Q, K and V, e from `bound` >= max |qkv|
+// (the planner's provable bound of the qkv projection: GroupNorm bound x max row L1 of the weight + max |bias|; the softmax scale
+// ch^-1/4 only shrinks q and k): NP units per (step, operand) instead of three, three MFMA terms instead of six.
+template <int CH, int NP = 3>
 __global__ void __launch_bounds__(256) attn_kv_planes_kernel(const float* __restrict__ ksrc, const float* __restrict__ vsrc, int ldkv, int hskv,
-                                                             unsigned char* __restrict__ planes, int T, int heads, float scale) {
-    constexpr int KS = CH / 16, CT = CH / 32, UNITS = 3 * KS + 6 * CT, PITCH = CH + 4;
+                                                             unsigned char* __restrict__ planes, int T, int heads, float scale,
+                                                             const float* __restrict__ bound) {
+    constexpr int KS = CH / 16, CT = CH / 32, UNITS = NP * KS + 2 * NP * CT, PITCH = CH + 4;
     __shared__ __attribute__((aligned(16))) float kt[KT * PITCH], vt[KT * PITCH];
     const int ntiles = T / KT;
     const int tile = (int)(blockIdx.x % (unsigned)ntiles), nh = (int)(blockIdx.x / (unsigned)ntiles);
@@ -425,11 +430,14 @@ __global__ void __launch_bounds__(256) attn_kv_planes_kernel(const float* __rest
     const float* kbase = ksrc + ((size_t)n * T + (size_t)tile * KT) * ldkv + h * hskv;
     const float* vbase = vsrc + ((size_t)n * T + (size_t)tile * KT) * ldkv + h * hskv;
     const int tid = threadIdx.x, lane = tid & 63;
+    float up = 1.f;                                                // 2^e (exact multiplications)
+    if constexpr (NP == 2) up = h2_pow2(h2_exp_of_bound(*bound));
     for (int f = tid; f < KT * CH / 4; f += 256) {
         const int key = f / (CH / 4), c = (f % (CH / 4)) * 4;
         const float4 kv = *reinterpret_cast<const float4*>(kbase + (size_t)key * ldkv + c);
-        *reinterpret_cast<float4*>(kt + key * PITCH + c) = make_float4(kv.x * scale, kv.y * scale, kv.z * scale, kv.w * scale);
-        *reinterpret_cast<float4*>(vt + key * PITCH + c) = *reinterpret_cast<const float4*>(vbase + (size_t)key * ldkv + c);
+        const float4 vv = *reinterpret_cast<const float4*>(vbase + (size_t)key * ldkv + c);
+        *reinterpret_cast<float4*>(kt + key * PITCH + c) = make_float4(kv.x * scale * up, kv.y * scale * up, kv.z * scale * up, kv.w * scale * up);
+        *reinterpret_cast<float4*>(vt + key * PITCH + c) = make_float4(vv.x * up, vv.y * up, vv.z * up, vv.w * up);
     }
     __syncthreads();
     unsigned char* dst = planes + ((size_t)nh * ntiles + tile) * (size_t)(UNITS * ATTN_UNIT) + lane * 16;
@@ -441,33 +449,46 @@ __global__ void __launch_bounds__(256) attn_kv_planes_kernel(const float* __rest
             const float* src = kt + row * PITCH + item * 16 + half * 8;
             v0 = *reinterpret_cast<const float4*>(src);
             v1 = *reinterpret_cast<const float4*>(src + 4);
-            u = item * 3;
+            u = item * NP;
         } else {                                  // V^T, (ct, ks2): channel 32 ct + row, the 8 keys of this lane's k-slots
             const int ct = (item - KS) >> 1, ks2 = (item - KS) & 1;
             const float* src = vt + (16 * ks2 + 4 * half) * PITCH + ct * 32 + row;
             v0 = make_float4(src[0], src[PITCH], src[2 * PITCH], src[3 * PITCH]);
             v1 = make_float4(src[8 * PITCH], src[9 * PITCH], src[10 * PITCH], src[11 * PITCH]);
-            u = 3 * KS + ((ct * 2 + ks2) * 3);
+            u = NP * KS + ((ct * 2 + ks2) * NP);
         }
-        uint2 a1, a2, a3, b1, b2, b3;
-        split4(v0, a1, a2, a3);
-        split4(v1, b1, b2, b3);
-        *reinterpret_cast<uint4*>(dst + (size_t)(u + 0) * ATTN_UNIT) = make_uint4(a1.x, a1.y, b1.x, b1.y);
-        *reinterpret_cast<uint4*>(dst + (size_t)(u + 1) * ATTN_UNIT) = make_uint4(a2.x, a2.y, b2.x, b2.y);
-        *reinterpret_cast<uint4*>(dst + (size_t)(u + 2) * ATTN_UNIT) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+        if constexpr (NP == 3) {
+            uint2 a1, a2, a3, b1, b2, b3;
+            split4(v0, a1, a2, a3);
+            split4(v1, b1, b2, b3);
+            *reinterpret_cast<uint4*>(dst + (size_t)(u + 0) * ATTN_UNIT) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            *reinterpret_cast<uint4*>(dst + (size_t)(u + 1) * ATTN_UNIT) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+            *reinterpret_cast<uint4*>(dst + (size_t)(u + 2) * ATTN_UNIT) = make_uint4(a3.x, a3.y, b3.x, b3.y);
+        } else {
+            uint2 a1, a2, b1, b2;
+            h2_split4(v0, a1, a2);
+            h2_split4(v1, b1, b2);
+            *reinterpret_cast<uint4*>(dst + (size_t)(u + 0) * ATTN_UNIT) = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            *reinterpret_cast<uint4*>(dst + (size_t)(u + 1) * ATTN_UNIT) = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        }
     }
 }
 
-template <int CH>
-__global__ void __launch_bounds__(256, 3) attn_fwd_planes_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
+// NP = 2: Q (x ch^-1/4 log2 e) is scaled by the planes' 2^e and split into two fp16 halves, S = (three terms) 2^-2e; P = exp2(S - m) in
+// (0, 1] is split under ITS exact bound 1 (P 2^14 = h1 + h2); O accumulates P 2^14 V 2^e and is re-scaled once in the epilogue.  The term
+// order is gemm_bf3p.hip's (h1 k2) (h1 k1) (h2 k1).
+constexpr int H2_TA[3] = {0, 0, 1}, H2_TB[3] = {1, 0, 0};
+template <int CH, int NP = 3>
+__global__ void __launch_bounds__(256, NP == 2 ? 4 : 3) attn_fwd_planes_kernel(const float* __restrict__ qsrc, int ldq, int hsq,
                                                                   const unsigned char* __restrict__ planes, float* __restrict__ out, int ldo,
-                                                                  float* __restrict__ lse, int T, int heads, int nheads_total, float qscale) {
+                                                                  float* __restrict__ lse, int T, int heads, int nheads_total, float qscale,
+                                                                  const float* __restrict__ bound) {
     constexpr int NW = 4, QB = NW * 32, NTHR = NW * 64;
-    constexpr int KS = CH / 16, CT = CH / 32, UNITS = 3 * KS + 6 * CT;
+    constexpr int KS = CH / 16, CT = CH / 32, UNITS = NP * KS + 2 * NP * CT, NT = NP == 3 ? 6 : 3;
     constexpr int STAGE = UNITS * ATTN_UNIT;                       // bytes per key tile
     constexpr int OPITCH = CH + 1;
     static_assert(UNITS % NW == 0, "the tile's units are dealt evenly to the waves");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // attn_planes_lds(CH) bytes: two tile stages / the epilogue's O^T
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // attn_planes_lds(CH, NP) bytes: two tile stages / the epilogue's O^T
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, lq = lane & 31;
@@ -481,7 +502,16 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_planes_kernel(const float* __
     const float* qbase = qsrc + (size_t)n * T * ldq + h * hsq;
     const int ntiles = T / KT;
     const unsigned char* ptile = planes + (size_t)nh * ntiles * (size_t)STAGE;
-    auto issue = [&](int tile) {                                   // this wave's share of tile's 24 units -> stage tile & 1
+    // fp16 pair: 2^e of the planes, 2^-2e for the scores, 2^14 for P (h2_exp_of_bound(1.f)), 2^-(14 + e) for O
+    float up = 1.f, sdown = 1.f, odown = 1.f;
+    constexpr float PUP = 16384.f;
+    if constexpr (NP == 2) {
+        const int e = h2_exp_of_bound(*bound);
+        up = h2_pow2(e);
+        sdown = h2_pow2(-e) * h2_pow2(-e);
+        odown = h2_pow2(-e) * (1.f / PUP);
+    }
+    auto issue = [&](int tile) {                                   // this wave's share of tile's units -> stage tile & 1
         const unsigned char* src = ptile + (size_t)tile * STAGE;
         unsigned char* dstl = smem + (tile & 1) * STAGE;
 #pragma unroll
@@ -493,20 +523,31 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_planes_kernel(const float* __
     issue(0);
 
     const int q = qb * QB + wave * 32 + lq;
-    bf16x8 qb3[KS][3];                                             // lane holds q[c], c = ks*16 + hi*8 + 0..7, as three bf16 planes
+    uint4 qf[KS][NP];                                              // lane holds q[c], c = ks*16 + hi*8 + 0..7, as NP 16-bit planes
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         float4 v0 = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + ks * 16 + hi * 8);
         float4 v1 = *reinterpret_cast<const float4*>(qbase + (size_t)q * ldq + ks * 16 + hi * 8 + 4);
-        v0 = make_float4(v0.x * qscale, v0.y * qscale, v0.z * qscale, v0.w * qscale);
-        v1 = make_float4(v1.x * qscale, v1.y * qscale, v1.z * qscale, v1.w * qscale);
-        uint2 a1, a2, a3, b1, b2, b3;
-        split4(v0, a1, a2, a3);
-        split4(v1, b1, b2, b3);
-        qb3[ks][0] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
-        qb3[ks][1] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
-        qb3[ks][2] = __builtin_bit_cast(bf16x8, make_uint4(a3.x, a3.y, b3.x, b3.y));
+        v0 = make_float4(v0.x * qscale * up, v0.y * qscale * up, v0.z * qscale * up, v0.w * qscale * up);
+        v1 = make_float4(v1.x * qscale * up, v1.y * qscale * up, v1.z * qscale * up, v1.w * qscale * up);
+        if constexpr (NP == 3) {
+            uint2 a1, a2, a3, b1, b2, b3;
+            split4(v0, a1, a2, a3);
+            split4(v1, b1, b2, b3);
+            qf[ks][0] = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            qf[ks][1] = make_uint4(a2.x, a2.y, b2.x, b2.y);
+            qf[ks][NP - 1] = make_uint4(a3.x, a3.y, b3.x, b3.y);
+        } else {
+            uint2 a1, a2, b1, b2;
+            h2_split4(v0, a1, a2);
+            h2_split4(v1, b1, b2);
+            qf[ks][0] = make_uint4(a1.x, a1.y, b1.x, b1.y);
+            qf[ks][1] = make_uint4(a2.x, a2.y, b2.x, b2.y);
+        }
     }
+#define ATTN_MFMA(A_, B_, C_)                                                                                                    \
+    (NP == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A_), __builtin_bit_cast(bf16x8, B_), C_, 0, 0, 0)   \
+             : __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A_), __builtin_bit_cast(f16x8, B_), C_, 0, 0, 0))
     f32x16 o[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -519,29 +560,31 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_planes_kernel(const float* __
     for (int tile = 0; tile < ntiles; ++tile) {
         if (tile + 1 < ntiles) issue(tile + 1);                    // (its stage was last read a tile ago: the barrier below is behind)
         const unsigned char* st = smem + (tile & 1) * STAGE + lane * 16;
-        // ---- S^T = K Q^T: one chain of 6 KS MFMAs (see attn_fwd_kernel) ----------------------------------------------------------
+        // ---- S^T = K Q^T: one chain of NT KS MFMAs (see attn_fwd_kernel) ---------------------------------------------------------
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 kf[3];
+            uint4 kf[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const bf16x8*>(st + (ks * 3 + p) * ATTN_UNIT);
+            for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const uint4*>(st + (ks * NP + p) * ATTN_UNIT);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[BF3_TA[t]], qb3[ks][BF3_TB[t]], s, 0, 0, 0);
+            for (int t = 0; t < NT; ++t)
+                s = ATTN_MFMA(kf[NP == 3 ? BF3_TA[t] : H2_TA[t % 3]], qf[ks][NP == 3 ? BF3_TB[t] : H2_TB[t % 3]], s);
         }
         // ---- online softmax (base 2; no keys beyond T: T is a multiple of the tile) ------------------------------------------------
         float mt = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+        if constexpr (NP == 2) mt *= sdown;                        // (an exact power of two: max and scaling commute)
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(NP == 2 ? __builtin_fmaf(s[r], sdown, -m_new) : s[r] - m_new);     // (s 2^-2e is exact: one rounding either way)
             psum += s[r];
         }
         psum += __shfl_xor(psum, 32);
@@ -558,52 +601,67 @@ __global__ void __launch_bounds__(256, 3) attn_fwd_planes_kernel(const float* __
         }
         // ---- O^T += V^T P^T: P^T in place (registers 8 ks2 .. 8 ks2 + 7 are the lane's k-slots of step ks2); the split of key half 1
         // is dealt between the first MFMAs of half 0 ---------------------------------------------------------------------------------
-        bf16x8 pfs[2][3];
-        unsigned pw[3][4];
+        uint4 pfs[2][NP];
+        unsigned pw[NP][4];
         float pr0, pr1;
 #pragma unroll
-        for (int d = 0; d < 4; ++d) split2(s[2 * d], s[2 * d + 1], pw[0][d], pw[1][d], pw[2][d]);
+        for (int d = 0; d < 4; ++d) {
+            if constexpr (NP == 3) split2(s[2 * d], s[2 * d + 1], pw[0][d], pw[1][d], pw[NP - 1][d]);
+            else h2_split2(s[2 * d] * PUP, s[2 * d + 1] * PUP, pw[0][d], pw[1][d]);
+        }
 #pragma unroll
-        for (int p = 0; p < 3; ++p) pfs[0][p] = __builtin_bit_cast(bf16x8, make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]));
+        for (int p = 0; p < NP; ++p) pfs[0][p] = make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]);
         auto split_p1_stage = [&](int j) {
             if (j < 8) {
                 const int d = j >> 1;
-                if ((j & 1) == 0) split2_a(s[8 + 2 * d], s[8 + 2 * d + 1], pw[0][d], pr0, pr1);
-                else split2_b(pr0, pr1, pw[1][d], pw[2][d]);
+                if constexpr (NP == 3) {
+                    if ((j & 1) == 0) split2_a(s[8 + 2 * d], s[8 + 2 * d + 1], pw[0][d], pr0, pr1);
+                    else split2_b(pr0, pr1, pw[1][d], pw[NP - 1][d]);
+                } else {
+                    if ((j & 1) == 0) {
+                        const float x0 = s[8 + 2 * d] * PUP, x1 = s[8 + 2 * d + 1] * PUP;
+                        pw[0][d] = cvt_pk_h(x0, x1);
+                        const f16x2 hh = __builtin_bit_cast(f16x2, pw[0][d]);
+                        pr0 = x0 - (float)hh.x;
+                        pr1 = x1 - (float)hh.y;
+                    } else
+                        pw[1][d] = cvt_pk_h(pr0, pr1);
+                }
             }
             if (j == 8)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) pfs[1][p] = __builtin_bit_cast(bf16x8, make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]));
+                for (int p = 0; p < NP; ++p) pfs[1][p] = make_uint4(pw[p][0], pw[p][1], pw[p][2], pw[p][3]);
         };
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 (&pf)[3] = pfs[ks];
+            const uint4 (&pf)[NP] = pfs[ks];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                bf16x8 vf[3];
+                uint4 vf[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) vf[p] = *reinterpret_cast<const bf16x8*>(st + (3 * KS + (ct * 2 + ks) * 3 + p) * ATTN_UNIT);
+                for (int p = 0; p < NP; ++p) vf[p] = *reinterpret_cast<const uint4*>(st + (NP * KS + (ct * 2 + ks) * NP + p) * ATTN_UNIT);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[BF3_TA[t]], pf[BF3_TB[t]], o[ct], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    o[ct] = ATTN_MFMA(vf[NP == 3 ? BF3_TA[t] : H2_TA[t % 3]], pf[NP == 3 ? BF3_TB[t] : H2_TB[t % 3]], o[ct]);
                     if (ks == 0) {
-                        split_p1_stage(ct * 6 + t);
+                        split_p1_stage(ct * NT + t);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            if (ks == 0 && 6 * CT < 9) {
+            if (ks == 0 && NT * CT < 9) {
 #pragma unroll
-                for (int j = 6 * CT; j < 9; ++j) split_p1_stage(j);
+                for (int j = NT * CT; j < 9; ++j) split_p1_stage(j);
             }
         }
         wait_vmcnt<0>();                         // my copies of tile + 1 have landed ...
         __syncthreads();                         // ... everybody's, and everybody is done with this tile's stage
     }
+#undef ATTN_MFMA
 
     // ---- epilogue: O^T / l -> LDS [query][c] -> coalesced rows (as attn_fwd_kernel) -----------------------------------------------------
     float* obuf = reinterpret_cast<float*>(smem);
-    const float inv = 1.0f / l_run;
+    const float inv = (NP == 2 ? odown : 1.0f) / l_run;
     if (lse && hi == 0) lse[((size_t)n * heads + h) * T + q] = m_run * LN2 + logf(l_run);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -671,8 +729,9 @@ extern "C" int bbdm_attention_f32(const float* qkv, int ldq, float* out, int ldo
 // ---- the pre-split form (see attn_kv_planes_kernel): a launch that writes the K / V operand planes of every (image, head) and an
 // attention launch that reads them.  bbdm_attention_kv_planes_bytes returns 0 where the form does not apply (head channels other than
 // 64 / 32, T not a multiple of 128, sequences too short for the extra launch to pay); the results equal bbdm_attention_f32's bit for bit.
-static size_t attn_planes_lds(int ch) {
-    const size_t stages = 2 * (size_t)(3 * (ch / 16) + 6 * (ch / 32)) * 1024, epilogue = 128 * (size_t)(ch + 1) * 4;
+static size_t attn_planes_units(int ch, int np) { return (size_t)(np * (ch / 16) + 2 * np * (ch / 32)); }
+static size_t attn_planes_lds(int ch, int np) {
+    const size_t stages = 2 * attn_planes_units(ch, np) * 1024, epilogue = 128 * (size_t)(ch + 1) * 4;
     return stages > epilogue ? stages : epilogue;
 }
 static bool attn_planes_ok(int N, int T, int heads, int ch) {
@@ -681,12 +740,16 @@ static bool attn_planes_ok(int N, int T, int heads, int ch) {
 }
 extern "C" size_t bbdm_attention_kv_planes_bytes(int N, int T, int heads, int ch) {
     if (N <= 0 || T <= 0 || heads <= 0 || !attn_planes_ok(N, T, heads, ch)) return 0;
-    return (size_t)N * heads * (T / 32) * (size_t)((3 * (ch / 16) + 6 * (ch / 32)) * 1024);
+    return (size_t)N * heads * (T / 32) * attn_planes_units(ch, 3) * 1024;
 }
-extern "C" int bbdm_attention_kv_planes_f32(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch,
-                                            int new_order, void* stream) {
+extern "C" size_t bbdm_attention_kv_planes_h2_bytes(int N, int T, int heads, int ch) {
+    if (N <= 0 || T <= 0 || heads <= 0 || !attn_planes_ok(N, T, heads, ch)) return 0;
+    return (size_t)N * heads * (T / 32) * attn_planes_units(ch, 2) * 1024;
+}
+static int attn_kv_planes(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch, int new_order,
+                          const float* bound, void* stream) {
     BBDM_REQUIRE(qkv && planes, "attention_kv_planes: null pointer");
-    const size_t need = bbdm_attention_kv_planes_bytes(N, T, heads, ch);
+    const size_t need = bound ? bbdm_attention_kv_planes_h2_bytes(N, T, heads, ch) : bbdm_attention_kv_planes_bytes(N, T, heads, ch);
     BBDM_REQUIRE(need != 0, "attention_kv_planes: N=%d T=%d heads=%d ch=%d has no pre-split form (bbdm_attention_kv_planes_bytes is 0)", N, T, heads, ch);
     BBDM_REQUIRE(planes_bytes >= need, "attention_kv_planes: %zu bytes of planes, %zu needed", planes_bytes, need);
     BBDM_REQUIRE(ldq % 4 == 0 && ldq >= 3 * heads * ch && (((uintptr_t)qkv | (uintptr_t)planes) & 15) == 0, "attention_kv_planes: bad pitch / alignment");
@@ -697,13 +760,15 @@ extern "C" int bbdm_attention_kv_planes_f32(const float* qkv, int ldq, void* pla
     const float* v = new_order ? qkv + 2 * C : qkv + 2 * ch;
     const int hs = new_order ? ch : 3 * ch;
     const dim3 grid((unsigned)(N * heads * (T / 32)));
-    if (ch == 64) hipLaunchKernelGGL(attn_kv_planes_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, k, v, ldq, hs, (unsigned char*)planes, T, heads, scale);
-    else hipLaunchKernelGGL(attn_kv_planes_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, k, v, ldq, hs, (unsigned char*)planes, T, heads, scale);
+#define BBDM_ATTN_KV(CH, NP) hipLaunchKernelGGL((attn_kv_planes_kernel<CH, NP>), grid, dim3(256), 0, (hipStream_t)stream, k, v, ldq, hs, (unsigned char*)planes, T, heads, scale, bound)
+    if (ch == 64) { if (bound) BBDM_ATTN_KV(64, 2); else BBDM_ATTN_KV(64, 3); }
+    else { if (bound) BBDM_ATTN_KV(32, 2); else BBDM_ATTN_KV(32, 3); }
+#undef BBDM_ATTN_KV
     BBDM_CHECK_LAUNCH("attention_kv_planes");
     return BBDM_OK;
 }
-extern "C" int bbdm_attention_planes_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch,
-                                         int new_order, const void* planes, void* stream) {
+static int attn_planes(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch, int new_order,
+                       const void* planes, const float* bound, void* stream) {
     BBDM_REQUIRE(qkv && planes && out, "attention_planes: null pointer");
     BBDM_REQUIRE(bbdm_attention_kv_planes_bytes(N, T, heads, ch) != 0, "attention_planes: N=%d T=%d heads=%d ch=%d has no pre-split form", N, T, heads, ch);
     BBDM_REQUIRE(ldq % 4 == 0 && ldq >= 3 * heads * ch && ldo >= heads * ch && (((uintptr_t)qkv | (uintptr_t)planes) & 15) == 0,
@@ -712,10 +777,31 @@ extern "C" int bbdm_attention_planes_f32(const float* qkv, int ldq, float* out, 
     const int nht = N * heads, qblocks = T / 128;
     const dim3 grid((unsigned)(8ll * ((nht + 7) / 8) * qblocks));
     const int hsq = new_order ? ch : 3 * ch;
-    if (ch == 64) hipLaunchKernelGGL(attn_fwd_planes_kernel<64>, grid, dim3(256), attn_planes_lds(64), (hipStream_t)stream, qkv, ldq, hsq, (const unsigned char*)planes, out, ldo, lse, T, heads, nht, scale);
-    else hipLaunchKernelGGL(attn_fwd_planes_kernel<32>, grid, dim3(256), attn_planes_lds(32), (hipStream_t)stream, qkv, ldq, hsq, (const unsigned char*)planes, out, ldo, lse, T, heads, nht, scale);
+#define BBDM_ATTN_PL(CH, NP) hipLaunchKernelGGL((attn_fwd_planes_kernel<CH, NP>), grid, dim3(256), attn_planes_lds(CH, NP), (hipStream_t)stream, qkv, ldq, hsq, (const unsigned char*)planes, out, ldo, lse, T, heads, nht, scale, bound)
+    if (ch == 64) { if (bound) BBDM_ATTN_PL(64, 2); else BBDM_ATTN_PL(64, 3); }
+    else { if (bound) BBDM_ATTN_PL(32, 2); else BBDM_ATTN_PL(32, 3); }
+#undef BBDM_ATTN_PL
     BBDM_CHECK_LAUNCH("attention_planes");
     return BBDM_OK;
+}
+extern "C" int bbdm_attention_kv_planes_f32(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch,
+                                            int new_order, void* stream) {
+    return attn_kv_planes(qkv, ldq, planes, planes_bytes, N, T, heads, ch, new_order, nullptr, stream);
+}
+extern "C" int bbdm_attention_planes_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch,
+                                         int new_order, const void* planes, void* stream) {
+    return attn_planes(qkv, ldq, out, ldo, lse, N, T, heads, ch, new_order, planes, nullptr, stream);
+}
+// ... on the fp16-pair planes (round 6): `bound` = a device float >= max |qkv| (see attn_kv_planes_kernel); both launches take the same one.
+extern "C" int bbdm_attention_kv_planes_h2_f32(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch,
+                                               int new_order, const float* bound, void* stream) {
+    BBDM_REQUIRE(bound, "attention_kv_planes_h2: null bound");
+    return attn_kv_planes(qkv, ldq, planes, planes_bytes, N, T, heads, ch, new_order, bound, stream);
+}
+extern "C" int bbdm_attention_planes_h2_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch,
+                                            int new_order, const void* planes, const float* bound, void* stream) {
+    BBDM_REQUIRE(bound, "attention_planes_h2: null bound");
+    return attn_planes(qkv, ldq, out, ldo, lse, N, T, heads, ch, new_order, planes, bound, stream);
 }
 
 // CrossAttention.forward (model/BrownianBridge/base/modules/attention.py:170-194): q [N][Tq][heads*ch] from the image

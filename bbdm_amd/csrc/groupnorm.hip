@@ -317,7 +317,52 @@ __global__ void __launch_bounds__(256) h2_stats_bound_kernel(const unsigned long
     __syncthreads();
     if (threadIdx.x == 0) *bound = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
+// The output of a 1x1 convolution / Linear y = W x + b is bounded by max_row sum_k |W[row][k]| x max |x| + max |b|: the first and the
+// last factor are properties of the weights (h2_rowl1_kernel, at packing time), the middle one is the input's bound of every forward
+// (h2_affine_bound_kernel: one thread) -- the bound behind the attention's fp16-pair planes (csrc/attention.hip), whose operands are
+// the qkv projection of a GroupNorm output.
+__global__ void __launch_bounds__(256) h2_rowl1_kernel(const float* __restrict__ w, const float* __restrict__ bias, int rows, int cols,
+                                                       float* __restrict__ out2) {
+    // ONE workgroup (packing time: a few million elements at most): a wave per row, lanes along the row; no atomics, nothing to zero
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float l1 = 0.f, bm = 0.f;
+    for (int row = wave; row < rows; row += 4) {
+        float a = 0.f;
+        for (int k = lane; k < cols; k += 64) a += fabsf(w[(size_t)row * cols + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        l1 = fmaxf(l1, a);
+    }
+    if (bias)
+        for (int k = threadIdx.x; k < rows; k += 256) bm = fmaxf(bm, fabsf(bias[k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
+    __shared__ float red[4], redb[4];
+    if (lane == 0) { red[wave] = l1; redb[wave] = bm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (sums of non-negative fp32 terms: every rounding is below 2^-24 relative; the margin covers rows of 2^16 elements)
+        out2[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.004f;
+        out2[1] = fmaxf(fmaxf(redb[0], redb[1]), fmaxf(redb[2], redb[3]));
+    }
+}
+__global__ void h2_affine_bound_kernel(const float* __restrict__ in, const float* __restrict__ gain2, float* __restrict__ out) {
+    *out = *in * gain2[0] * 1.00001f + gain2[1];
+}
 }  // namespace
+
+extern "C" int bbdm_h2_rowl1_f32(const float* w, const float* bias, int rows, int cols, float* out2, void* stream) {
+    BBDM_REQUIRE(w && out2 && rows > 0 && cols > 0, "h2_rowl1: bad args");
+    hipLaunchKernelGGL(h2_rowl1_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, bias, rows, cols, out2);
+    BBDM_CHECK_LAUNCH("h2_rowl1");
+    return BBDM_OK;
+}
+extern "C" int bbdm_h2_affine_bound_f32(const float* in_bound, const float* gain2, float* out_bound, void* stream) {
+    BBDM_REQUIRE(in_bound && gain2 && out_bound, "h2_affine_bound: null pointer");
+    hipLaunchKernelGGL(h2_affine_bound_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, in_bound, gain2, out_bound);
+    BBDM_CHECK_LAUNCH("h2_affine_bound");
+    return BBDM_OK;
+}
 
 extern "C" int bbdm_h2_stats_bound_f32(const void* stats, int N, int G, float* bound, void* stream) {
     BBDM_REQUIRE(stats && bound && N > 0 && G > 0, "h2_stats_bound: bad args");

@@ -441,6 +441,26 @@ class _PackedConvH2q(_PackedConv):
             self.key = key
 
 
+class _RowL1Gain:
+    """(max over rows of sum |W[row, :]|, max |bias|) of a 1x1 conv / Linear as two device floats, refreshed with the weights: what
+    turns a bound of the layer's input into a bound of its output (csrc/groupnorm.hip: h2_rowl1_kernel / bbdm_h2_affine_bound_f32)."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self.gain = torch.zeros(2, dtype=torch.float32, device=weight.device)
+        self.key = None
+
+    def refresh(self, stream):
+        w, b = self.weight, self.bias
+        key = (w.data_ptr(), _ver(w), None if b is None else (b.data_ptr(), _ver(b)))
+        if key != self.key:
+            if not w.is_contiguous() or w.dtype != torch.float32:
+                raise RuntimeError("bbdm_amd: conv weights must be contiguous fp32")
+            _lib.call("bbdm_h2_rowl1_f32", w.data_ptr(), None if b is None else b.data_ptr(), w.shape[0], w[0].numel(),
+                      self.gain.data_ptr(), stream)
+            self.key = key
+
+
 class _PackedDgradBf3:
     """The transposed weight of a 1x1 conv / Linear in the three-bf16-plane layout of csrc/gemm_bf3.hip: the data gradient
     dX = dY W as one more fp32-accurate GEMM on the BF16 matrix core (``packed``; the fp32 dgrad packing is the intermediate)."""
@@ -827,6 +847,10 @@ class UNetModel(nn.Module):
         # by its own GroupNorm statistics: |x| <= sqrt(sum of squares) per group) and the qkv projections (a GroupNorm output) -- on
         # bbdm_conv1x1_h2q_f32 (inference plans).  False: bbdm_conv1x1_bf3q_f32 / bbdm_conv1x1_bf3_f32
         self.conv1x1_h2: bool = True
+        # ... and the long-sequence attention (the pre-split pair bbdm_attention_kv_planes_f32 + bbdm_attention_planes_f32) on
+        # bbdm_attention_*_h2_f32: q, k, v under the provable bound of the qkv projection (GroupNorm bound x max row L1 of its weight + max
+        # |bias|), the softmax weights under their exact bound 1 (inference plans).  False: bf16x3 planes
+        self.attn_h2: bool = True
         # 1x1 layers with fewer 256 x 128 output tiles than this leave the wide bf16x3 kernels for the small-problem kernel
         self.bf3_min_tiles: int = 256
         # ... csrc/gemm_bf3p.hip: gemm_bf3s_kernel (one launch, 64 channels per step); False: the split-K f32-MFMA kernel + reduction
@@ -939,7 +963,7 @@ class UNetModel(nn.Module):
         key = (N, H, W, x.device.index, x.shape[1], training, self.winograd,
                self.winograd_fuse_groupnorm, self.gemm_bf3, self.gemm_bf3p, self.fuse_stats, self.winograd_wgrad, self.winograd_train8, self.winograd8_min_tiles, self.side_stream_min_macs, self.side_stream_max_macs, self.side_stream_max_pixels, self.side_stream_train, self.side_stream_wgrad, self.side_stream_wgrad_min_macs, self.bf3_min_tiles,
                self.winograd_small, self.upsample_phases, self.conv1x1_small, self.gn_in_transform,
-               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2, self.gemm_h2_train, self.conv1x1_h2)
+               self.fp32_v_max_cout, self.upsample_f72, self.gemm_h2, self.gemm_h2_train, self.conv1x1_h2, self.attn_h2)
         plan = self._plans.pop(key, None)
         if plan is None:
             # a plan owns every activation (+ gradient twin when training) of its shape -- several GB at full size: keep the
@@ -1740,17 +1764,34 @@ class _Plan:
         ch = C // ab.num_heads
         s0 = self._gn_count
         a, pre = self._gn_input(x, ab.norm, None, silu=0, name="A")
-        if (pre is None or pre[0] is None) and (self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C)):
-            pre = _Pre(self.NO_PRE, h2=self._gn_bound(x, ab.norm, None))      # (a materialised GroupNorm output: bounded by its coefficients)
+        order = 1 if ab.use_new_attention_order else 0
+        nb = int(self.lib.bbdm_attention_kv_planes_bytes(N, T, ab.num_heads, ch))
+        attn_h2 = bool(nb and not self.training and getattr(self.m, "attn_h2", True) and self._h2_on(1) and (pre is None or pre[0] is None))
+        abound = None
+        if (pre is None or pre[0] is None) and (attn_h2 or self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C)):
+            abound = self._gn_bound(x, ab.norm, None)                         # (a materialised GroupNorm output: bounded by its coefficients)
+            if self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C):
+                pre = _Pre(self.NO_PRE, h2=abound)
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
         self._emit_conv(a, ab.qkv, None, qkv, pre=pre)
         at = self._tmp("AT", N, x.H, x.W, C)
         lse = None
         if self.training:
             lse = _TensorRef(torch.empty(N * ab.num_heads * T, dtype=torch.float32, device=self.device))
-        order = 1 if ab.use_new_attention_order else 0
-        nb = int(self.lib.bbdm_attention_kv_planes_bytes(N, T, ab.num_heads, ch))
-        if nb:      # long sequences: K / V split into their bf16 operand planes once per head (in the Winograd scratch, idle here) instead
+        if attn_h2 and abound is not None:
+            # ... as fp16 pairs (csrc/attention.hip, NP = 2): bound(qkv) = bound(GroupNorm output) x max row L1 of the weight + max |bias|
+            rg = _RowL1Gain(ab.qkv.weight, ab.qkv.bias)
+            self.convs.append(rg)
+            qb = _Plan._H2Ref(self, self._h2_x_slots, "x")
+            self._h2_x_slots += 1
+            self._op("bbdm_h2_affine_bound_f32", abound, _TensorRef(rg.gain), qb)
+            nb2 = int(self.lib.bbdm_attention_kv_planes_h2_bytes(N, T, ab.num_heads, ch))
+            self._wino_v_need = max(self._wino_v_need, (nb2 + 3) // 4)
+            self._op(_OpName("bbdm_attention_kv_planes_f32", "bbdm_attention_kv_planes_h2_f32"), qkv, qkv.ld, self._wino_v, nb2, N, T,
+                     ab.num_heads, ch, order, qb)
+            self._op(_OpName("bbdm_attention_f32", "bbdm_attention_planes_h2_f32"), qkv, qkv.ld, at, at.ld, lse, N, T, ab.num_heads, ch,
+                     order, self._wino_v, qb)
+        elif nb:    # long sequences: K / V split into their bf16 operand planes once per head (in the Winograd scratch, idle here) instead
                     # of by each of the T / 128 workgroups that walk them (csrc/attention.hip: attn_kv_planes_kernel)
             self._wino_v_need = max(self._wino_v_need, (nb + 3) // 4)
             self._op("bbdm_attention_kv_planes_f32", qkv, qkv.ld, self._wino_v, nb, N, T, ab.num_heads, ch, order)
@@ -2452,7 +2493,7 @@ class _Plan:
                 e0.record()
                 rc = fn(*(a.resolve() if hasattr(a, "resolve") else a for a in args), stream)
                 e1.record()
-                prof.append((str(name) + ":bwd", e0, e1, self._algorithmic_flops(str(name), args)))
+                prof.append((_OpName(str(name) + ":bwd", getattr(name, "entry", str(name))), e0, e1, self._algorithmic_flops(str(name), args)))
             if rc != 0:
                 check(rc, name)
         # weight gradients computed against a channel-padded input (stem, cross-attention to_k / to_v on a 3-channel context) live
@@ -2527,7 +2568,7 @@ class _Plan:
     # ---- execution ------------------------------------------------------------------------------------------------
     def _bind(self):
         lib = self.lib
-        self._bound_names = [str(name) for name, _ in self.ops]
+        self._bound_names = [name for name, _ in self.ops]       # (_OpName objects: bench.py reads the entry point a launch is bound to)
         self._bound = [(getattr(lib, getattr(name, "entry", name)), tuple(a.resolve() if hasattr(a, "resolve") else a for a in args))
                        for name, args in self.ops]
         if self._h2_layers:       # csrc/groupnorm.hip: H2GnLayer {gamma, beta, film_off, C, zmax, gain}

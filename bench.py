@@ -870,10 +870,27 @@ def run_workload(args, env):
     attn_mode = _bl.get_option("attn_bf3")
     attn_ch = next((oa[8] for nm, oa in plan0.ops if nm == "bbdm_attention_f32"), 64)
     attn_bf3_share = 0.0 if attn_mode == 0 else (1.0 if (attn_mode == 1 and attn_ch in (32, 64)) else 0.5)
-    wino_h2 = (wino[2] * h2_share if use_bf3 else 0.0) / max(1, args.steps)
-    bf3_flops = ((wino[2] * (1.0 - h2_share) if use_bf3 else 0.0) + c1x1[2] + attn_bf3_share * attn[2]) / max(1, args.steps)
-    t_at_peak = (executed_flops_per_step - bf3_flops - wino_h2) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
-        bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12) + wino_h2 / (PEAK_BF16_MFMA_TFLOPS / 3.0 * 1e12)
+    # executed FLOPs by the MFMA instruction that issues them, per profiled launch from the entry point the op is bound to (forward and
+    # gradient plan alike): fp16-pair planes -> 2500 / 3, bf16x3 planes -> 2500 / 6, everything else -> the f32 MFMA peak
+    cls = {"h2": 0.0, "bf3": 0.0}
+    for pname, _e0, _e1, fl in prof:
+        if not fl:
+            continue
+        base = str(pname)[:-4] if str(pname).endswith(":bwd") else str(pname)
+        ent = getattr(pname, "entry", base)
+        if base == "bbdm_attention_f32":
+            if "_h2_" in ent:
+                cls["h2"] += fl
+            else:
+                cls["bf3"] += attn_bf3_share * fl
+        elif base in ("bbdm_winograd_gemm_f32", "bbdm_conv1x1_bf3_f32"):
+            if "_h2" in ent:
+                cls["h2"] += fl
+            elif "bf3" in ent:
+                cls["bf3"] += fl
+    h2_flops, bf3_flops = cls["h2"] / max(1, args.steps), cls["bf3"] / max(1, args.steps)
+    t_at_peak = (executed_flops_per_step - bf3_flops - h2_flops) / (PEAK_FP32_MFMA_TFLOPS * 1e12) + \
+        bf3_flops / (PEAK_BF16_MFMA_TFLOPS / 6.0 * 1e12) + h2_flops / (PEAK_BF16_MFMA_TFLOPS / 3.0 * 1e12)
     # HBM-side traffic of the dominant kernel cannot be measured from inside the process: it comes from the committed
     # rocprofv3 PMC passes of this same command (profiles/*_pmc_<workload>_traffic.json), per launch, or null.
     traffic = None
@@ -985,9 +1002,11 @@ def run_workload(args, env):
                          "h2_share_of_tile_gemm_flops": h2_share if use_bf3 else None,
                          "frac_step": t_at_peak / (ms_per_step * 1e-3),
                          "frac_step_note": "whole step: time the MFMA work of every kernel would take at the matrix peak of the "
-                                           "datatype it issues (2500 / 3 for tile GEMMs on the fp16-pair planes, 2500 / 6 for those on "
-                                           "the bf16x3 planes, the wide 1x1 layers and the attention forward; f32 MFMA for the rest) / "
-                                           "step time",
+                                           "datatype it issues (2500 / 3 for launches on the fp16-pair planes -- tile GEMMs, 1x1 layers, "
+                                           "attention, forward and gradient side --, 2500 / 6 for those on the bf16x3 planes; f32 MFMA for "
+                                           "the rest) / step time",
+                         "flops_per_step_by_mfma": {"fp16_pair": h2_flops, "bf16x3": bf3_flops,
+                                                    "f32": executed_flops_per_step - bf3_flops - h2_flops},
                          "attention_bf3_share": attn_bf3_share,
                          "traffic": traffic, "traffic_step": traffic_step, "mfma_util": mfma_util,
                          # the same three as scalars (a record that flattens the line keeps them), or "stale" when the committed PMC

@@ -255,6 +255,20 @@ int bbdm_attention_kv_planes_f32(const float* qkv, int ldq, void* planes, size_t
                                  int new_order, void* stream);
 int bbdm_attention_planes_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch, int new_order,
                               const void* planes, void* stream);        /* (bbdm_attention_f32's arguments, then the planes) */
+/* ... on the fp16-pair planes (ABI 25; csrc/h2_split.h): Q, K, V under ONE power-of-two scale derived from `bound`, a device float >=
+ * max |qkv| (both launches read the same one); the softmax weights P in (0, 1] under their exact bound 1.  Three f16 MFMA terms per
+ * product instead of six, 4 bytes per K / V element instead of 6; measured against an fp64 attention at least as accurate as the bf16x3
+ * form (tests/test_kernels_gpu.py::test_attention_h2).  Same shapes as the bf16x3 pair (bbdm_attention_kv_planes_h2_bytes is 0 otherwise).
+ * The bound of a qkv PROJECTION y = W x + b needs no pass over y: max_row sum |W| x bound(x) + max |b| --
+ *   bbdm_h2_rowl1_f32       : out2[0] = max over rows of sum_k |w[row][k]| (rounded up), out2[1] = max |bias| (0 without one); w [rows][cols]
+ *   bbdm_h2_affine_bound_f32: *out_bound = *in_bound * gain2[0] + gain2[1]  (gain2 = bbdm_h2_rowl1_f32's output; one thread, every forward) */
+size_t bbdm_attention_kv_planes_h2_bytes(int N, int T, int heads, int ch);
+int bbdm_attention_kv_planes_h2_f32(const float* qkv, int ldq, void* planes, size_t planes_bytes, int N, int T, int heads, int ch,
+                                    int new_order, const float* bound, void* stream);
+int bbdm_attention_planes_h2_f32(const float* qkv, int ldq, float* out, int ldo, float* lse, int N, int T, int heads, int ch, int new_order,
+                                 const void* planes, const float* bound, void* stream);
+int bbdm_h2_rowl1_f32(const float* w, const float* bias, int rows, int cols, float* out2, void* stream);
+int bbdm_h2_affine_bound_f32(const float* in_bound, const float* gain2, float* out_bound, void* stream);
 /* Backward of the above (training; the reference re-runs the block under CheckpointFunction, util.py:119-148):
  * dqkv (same layout / pitch convention as qkv, pitch lddq) from dout [N,T,heads*ch] (pitch lddo), the forward's
  * qkv, out and lse.  Two streaming kernels (dQ per query block; dK,dV per key block), no T x T tensor. */

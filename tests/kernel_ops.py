@@ -222,16 +222,31 @@ def attention(qkv: torch.Tensor, heads: int, new_order: bool = False, return_lse
     return (out, lse) if return_lse else out
 
 
-def attention_planes(qkv: torch.Tensor, heads: int, new_order: bool = False, return_lse: bool = False):
+def attention_planes(qkv: torch.Tensor, heads: int, new_order: bool = False, return_lse: bool = False, bound=None):
     """:func:`attention` in its two-launch form: bbdm_attention_kv_planes_f32 (K / V operand planes once per head) +
-    bbdm_attention_planes_f32.  None where the library has no such form for the shape (bbdm_attention_kv_planes_bytes == 0)."""
+    bbdm_attention_planes_f32.  None where the library has no such form for the shape (bbdm_attention_kv_planes_bytes == 0).
+    ``bound`` (a float >= max |qkv|, or a one-element device tensor): the fp16-pair form, bbdm_attention_kv_planes_h2_f32 +
+    bbdm_attention_planes_h2_f32."""
     _chk(qkv)
     N, T, C3 = qkv.shape
     C = C3 // 3
     lib = _lib.load()
-    nbytes = lib.bbdm_attention_kv_planes_bytes(N, T, heads, C // heads)
+    h2 = bound is not None
+    nbytes = (lib.bbdm_attention_kv_planes_h2_bytes if h2 else lib.bbdm_attention_kv_planes_bytes)(N, T, heads, C // heads)
     if nbytes == 0:
         return None
+    if h2:
+        bt = bound if torch.is_tensor(bound) else torch.tensor([float(bound)], dtype=torch.float32, device=qkv.device)
+        planes = torch.empty(nbytes + 64, dtype=torch.uint8, device=qkv.device)
+        planes[nbytes:] = 0xA5
+        out = torch.empty(N, T, C, dtype=torch.float32, device=qkv.device)
+        lse = torch.empty(N, heads, T, dtype=torch.float32, device=qkv.device) if return_lse else None
+        _lib.call("bbdm_attention_kv_planes_h2_f32", qkv.data_ptr(), C3, planes.data_ptr(), nbytes, N, T, heads, C // heads,
+                  1 if new_order else 0, bt.data_ptr(), _st(qkv))
+        _lib.call("bbdm_attention_planes_h2_f32", qkv.data_ptr(), C3, out.data_ptr(), C, None if lse is None else lse.data_ptr(),
+                  N, T, heads, C // heads, 1 if new_order else 0, planes.data_ptr(), bt.data_ptr(), _st(qkv))
+        assert bool((planes[nbytes:] == 0xA5).all())
+        return (out, lse) if return_lse else out
     planes = torch.empty(nbytes + 64, dtype=torch.uint8, device=qkv.device)
     planes[nbytes:] = 0xA5                                   # (the launch may not write behind the size it reported)
     out = torch.empty(N, T, C, dtype=torch.float32, device=qkv.device)
@@ -718,4 +733,19 @@ def conv1x1_h2q(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
               None if bias is None else bias.data_ptr(),
               None if residual is None else residual.data_ptr(), 0 if residual is None else residual.shape[1],
               out.data_ptr(), out.shape[1], x.shape[0], cin, cout, xb.data_ptr(), wb.data_ptr(), _st(x))
+    return out
+
+
+def h2_rowl1(w: torch.Tensor, bias=None) -> torch.Tensor:
+    """bbdm_h2_rowl1_f32: (max over rows of sum |w[row, :]| rounded up, max |bias|) as a two-element device tensor."""
+    _chk(w)
+    out = torch.full((2,), -1.0, dtype=torch.float32, device=w.device)
+    _lib.call("bbdm_h2_rowl1_f32", w.data_ptr(), None if bias is None else bias.data_ptr(), w.shape[0], w[0].numel(), out.data_ptr(), _st(w))
+    return out
+
+
+def h2_affine_bound(in_bound: torch.Tensor, gain2: torch.Tensor) -> torch.Tensor:
+    """bbdm_h2_affine_bound_f32: in_bound * gain2[0] + gain2[1] as a one-element device tensor."""
+    out = torch.zeros(1, dtype=torch.float32, device=in_bound.device)
+    _lib.call("bbdm_h2_affine_bound_f32", in_bound.data_ptr(), gain2.data_ptr(), out.data_ptr(), _st(in_bound))
     return out

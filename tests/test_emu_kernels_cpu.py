@@ -155,6 +155,15 @@ def test_attention_presplit_form_is_bit_equal(N, T, heads, ch, new_order):
     K.test_attention_presplit_form_is_bit_equal(CPU, N, T, heads, ch, new_order)
 
 
+@pytest.mark.parametrize("N,T,heads,ch,new_order,slack", [(1, 128, 2, 64, False, 1.0), (1, 256, 1, 32, True, 4096.0)])
+def test_attention_h2(N, T, heads, ch, new_order, slack):
+    K.test_attention_h2(CPU, N, T, heads, ch, new_order, slack)
+
+
+def test_h2_projection_bound():
+    K.test_h2_projection_bound(CPU)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,pre,up,res,f32v", [(1, 13, 11, 32, 128, 1, 0, 1, 0), (1, 8, 16, 32, 128, 1, 1, 2, 0),
                                                              (1, 9, 8, 32, 128, 0, 0, 0, 1), (1, 13, 11, 32, 128, 1, 0, 1, 2),
                                                              (1, 8, 16, 32, 128, 1, 1, 2, 2)])

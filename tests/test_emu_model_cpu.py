@@ -425,18 +425,29 @@ def test_long_sequence_attention_takes_the_presplit_form():
     net.hip_graph = False
     x, t = torch.randn(2, 3, 16, 16), torch.tensor([3, 800])
     outs, names = [], []
-    for mode in (1, 3):
+    for mode, h2 in ((1, False), (3, False), (3, True)):
         with _lib.option("attn_pipe", mode), torch.no_grad():
             net._plans = {}
+            net.attn_h2 = h2
             outs.append(net(x, timesteps=t).clone())
-            names.append([str(getattr(n, "entry", n)) for n, _ in next(iter(net._plans.values())).ops if "attention" in str(n)])
+            names.append([str(getattr(n, "entry", n)) for n, _ in next(iter(net._plans.values())).ops
+                          if "attention" in str(n) or "affine_bound" in str(n)])
     n_attn = len(names[0])                          # (input block, middle block, two output blocks)
     assert n_attn == 4 and names[0] == ["bbdm_attention_f32"] * n_attn
     assert names[1] == ["bbdm_attention_kv_planes_f32", "bbdm_attention_planes_f32"] * n_attn
     assert torch.equal(outs[0], outs[1])
+    # the default: the pair on the fp16 planes under the projection's provable bound (GroupNorm bound x max row L1 of the qkv weight + max |bias|)
+    assert names[2] == ["bbdm_h2_affine_bound_f32", "bbdm_attention_kv_planes_h2_f32", "bbdm_attention_planes_h2_f32"] * n_attn
     with torch.no_grad():
         ref = O.unet_forward({k: v.detach() for k, v in net.state_dict().items()}, O.UNetSpec(**params), x, t, None)
-    assert parity_err(outs[1], ref) < M.STEP_TOL
+    assert parity_err(outs[1], ref) < M.STEP_TOL and parity_err(outs[2], ref) < M.STEP_TOL
+    # the bound slots the attention launches read: set, finite, and -- loose by construction (sqrt(n_g) of the GroupNorm bound times the
+    # L1 / typical ratio of a weight row) -- inside the 2^17 the pair absorbs above typical values of O(1)
+    import ctypes
+    plan = next(iter(net._plans.values()))
+    slots = [args[-1] for n, args in plan.ops if str(getattr(n, "entry", n)) == "bbdm_attention_planes_h2_f32"]
+    bounds = [ctypes.c_float.from_address(s.resolve()).value for s in slots]
+    assert len(bounds) == n_attn and all(0.0 < b < 2.0 ** 17 for b in bounds), bounds
 
 
 def test_forward_on_f8_tiles(monkeypatch):

@@ -1406,6 +1406,63 @@ def test_attention_presplit_form_is_bit_equal(dev, N, T, heads, ch, new_order):
         assert ops.attention_planes(qkv, heads, new_order) is None          # default setting: long sequences only
 
 
+@pytest.mark.parametrize("N,T,heads,ch,new_order,slack", [(2, 128, 2, 64, False, 1.0), (1, 256, 3, 32, True, 1.0), (1, 1024, 2, 64, False, 1.0),
+                                                          (2, 384, 1, 64, True, 4096.0), (1, 256, 2, 32, False, 3.0e4)])
+def test_attention_h2(dev, N, T, heads, ch, new_order, slack):
+    """The pre-split attention on the fp16-pair planes (bbdm_attention_kv_planes_h2_f32 + bbdm_attention_planes_h2_f32: q, k, v under one
+    power-of-two scale from a bound of the qkv tensor, the softmax weights under their exact bound 1, three f16 MFMA terms per product)
+    against an fp64 attention: within the bar, and no worse than the six-term bf16x3 form on the same input -- also under a bound far
+    above the data (the provable bound of a qkv projection sits ~2^13 above typical values); same log-sum-exp."""
+    from bbdm_amd import _lib
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(T + ch)
+    C = heads * ch
+    qkv = torch.randn(N, T, 3 * C, generator=g) * 1.5
+    qkv[0, 3, 5] = 11.0                                         # (an outlier: the bound sits on it)
+    x = qkv.double()
+    if new_order:
+        q, k, v = (z.reshape(N, T, heads, ch) for z in x.chunk(3, dim=2))
+    else:
+        q, k, v = x.reshape(N, T, heads, 3 * ch).split(ch, dim=3)
+    sc = ch ** -0.25
+    sim = torch.einsum("nthc,nshc->nhts", q * sc, k * sc)
+    ref = torch.einsum("nhts,nshc->nthc", sim.softmax(-1), v).reshape(N, T, C)
+    ref_lse = torch.logsumexp(sim, dim=-1)
+    qd = qkv.to(dev)
+    with _lib.option("attn_pipe", 3):
+        a = ops.attention_planes(qd, heads, new_order)
+        b, lb = ops.attention_planes(qd, heads, new_order, return_lse=True, bound=float(qkv.abs().max()) * slack)
+        lib = _lib.load()
+        assert lib.bbdm_attention_kv_planes_h2_bytes(N, T + 32, heads, ch) == 0 and lib.bbdm_attention_kv_planes_h2_bytes(N, T, heads, 16) == 0
+        assert 3 * lib.bbdm_attention_kv_planes_h2_bytes(N, T, heads, ch) == 2 * lib.bbdm_attention_kv_planes_bytes(N, T, heads, ch)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    ea, eb = rel_err(a.cpu(), ref), rel_err(b.cpu(), ref)
+    print(f"attention N{N} T{T} {heads}x{ch} bound x{slack:g}: bf16x3 {ea:.2e}, fp16 pair {eb:.2e}")
+    assert bool(torch.isfinite(b).all()) and eb < TOL and eb < 1.5 * ea + 2e-7, (ea, eb)
+    assert rel_err(lb.cpu(), ref_lse) < 1e-5
+
+
+def test_h2_projection_bound(dev):
+    """bbdm_h2_rowl1_f32 + bbdm_h2_affine_bound_f32: bound(W x + b) = bound(x) max_row sum |W| + max |b| -- never below the real maximum of
+    the projection, and close to it for the adversarial input (x = bound sign(W[row]))."""
+    import kernel_ops as ops
+    g = torch.Generator().manual_seed(5)
+    for rows, cols, has_bias in ((96, 64, True), (3072, 1024, True), (7, 2048, False)):
+        w = (torch.randn(rows, cols, 1, 1, generator=g) * 0.1).to(dev)
+        b = (torch.randn(rows, generator=g) * 0.5).to(dev) if has_bias else None
+        g2 = ops.h2_rowl1(w, b)
+        l1 = w.double().abs().sum(dim=(1, 2, 3)).max().item()
+        assert l1 <= g2[0].item() <= l1 * 1.01, (l1, g2)
+        assert g2[1].item() == (b.abs().max().item() if has_bias else 0.0)
+        xb = torch.tensor([3.25], dtype=torch.float32, device=dev)
+        ob = ops.h2_affine_bound(xb, g2).item()
+        row = int(w.double().abs().sum(dim=(1, 2, 3)).argmax())
+        x = 3.25 * torch.sign(w[row].flatten()).double()
+        y = (w.double().reshape(rows, cols) @ x.to(w.device)).cpu() + (b.double().cpu() if has_bias else 0.0)
+        assert y.abs().max().item() <= ob <= 3.25 * l1 * 1.01 + (g2[1].item() if has_bias else 0.0) + 1e-6
+
+
 @pytest.mark.parametrize("N", [1, 4, 16, 33, 70])
 def test_embedding_path(dev, N):
     import kernel_ops as ops
