@@ -1767,10 +1767,12 @@ class _Plan:
         order = 1 if ab.use_new_attention_order else 0
         nb = int(self.lib.bbdm_attention_kv_planes_bytes(N, T, ab.num_heads, ch))
         attn_h2 = bool(nb and not self.training and getattr(self.m, "attn_h2", True) and self._h2_on(1) and (pre is None or pre[0] is None))
-        abound = None
-        if (pre is None or pre[0] is None) and (attn_h2 or self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C)):
+        # proj_out reads the attention's output, a convex combination of value rows: |a| <= max |v| <= bound(qkv)
+        proj_h2 = self._conv1x1_h2_ok(N * T, C, C) or self._conv1x1_h2s_ok(N * T, C, C)
+        abound = qb = None
+        if (pre is None or pre[0] is None) and (attn_h2 or proj_h2 or self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C)):
             abound = self._gn_bound(x, ab.norm, None)                         # (a materialised GroupNorm output: bounded by its coefficients)
-            if self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C):
+            if abound is not None and (self._conv1x1_h2_ok(N * T, C, 3 * C) or self._conv1x1_h2s_ok(N * T, C, 3 * C)):
                 pre = _Pre(self.NO_PRE, h2=abound)
         qkv = self._tmp("QKV", N, x.H, x.W, 3 * C)
         self._emit_conv(a, ab.qkv, None, qkv, pre=pre)
@@ -1778,13 +1780,15 @@ class _Plan:
         lse = None
         if self.training:
             lse = _TensorRef(torch.empty(N * ab.num_heads * T, dtype=torch.float32, device=self.device))
-        if attn_h2 and abound is not None:
-            # ... as fp16 pairs (csrc/attention.hip, NP = 2): bound(qkv) = bound(GroupNorm output) x max row L1 of the weight + max |bias|
+        if abound is not None and (attn_h2 or proj_h2):
+            # bound(qkv) = bound(GroupNorm output) x max row L1 of the projection's weight + max |bias|: one thread per forward
             rg = _RowL1Gain(ab.qkv.weight, ab.qkv.bias)
             self.convs.append(rg)
             qb = _Plan._H2Ref(self, self._h2_x_slots, "x")
             self._h2_x_slots += 1
             self._op("bbdm_h2_affine_bound_f32", abound, _TensorRef(rg.gain), qb)
+        if attn_h2 and qb is not None:
+            # ... the long-sequence pair on fp16-pair planes under that bound (csrc/attention.hip, NP = 2)
             nb2 = int(self.lib.bbdm_attention_kv_planes_h2_bytes(N, T, ab.num_heads, ch))
             self._wino_v_need = max(self._wino_v_need, (nb2 + 3) // 4)
             self._op(_OpName("bbdm_attention_kv_planes_f32", "bbdm_attention_kv_planes_h2_f32"), qkv, qkv.ld, self._wino_v, nb2, N, T,
@@ -1800,7 +1804,7 @@ class _Plan:
         else:
             self._op("bbdm_attention_f32", qkv, qkv.ld, at, at.ld, lse, N, T, ab.num_heads, ch, order)
         out = dest if dest is not None else self._new(N, x.H, x.W, C)
-        self._emit_conv(at, ab.proj_out, x, out)
+        self._emit_conv(at, ab.proj_out, x, out, pre=_Pre(self.NO_PRE, h2=qb) if (qb is not None and proj_h2) else None)
         if self.training:
             self.tape.append(("attn", ab, x, a, qkv, at, lse, out, s0))
         return out

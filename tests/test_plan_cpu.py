@@ -217,10 +217,19 @@ def test_1x1_layers_take_the_kernel_their_size_asks_for():
         tiles = (pixels // 256) * -(-cout // 128)
         if tiles >= m.bf3_min_tiles:
             assert entry in ("bbdm_conv1x1_bf3_f32", "bbdm_conv1x1_bf3q_f32", "bbdm_conv1x1_h2q_f32"), (entry, pixels, cin, cout)
-        else:       # (round 6: on the fp16 pair where the input carries a bound -- skip projections, qkv; proj_out keeps bf16x3)
+        else:       # (round 6: on the fp16 pair where the input carries a bound -- skip projections, qkv, proj_out)
             assert entry in ("bbdm_conv1x1_bf3s_f32", "bbdm_conv1x1_h2s_f32") and cin % 64 == 0 and cout % 4 == 0, (entry, pixels, cin, cout)
     assert any(e == "bbdm_conv1x1_h2s_f32" and (px, ci, co) == (512, 1024, 3072) for e, px, ci, co in layers)     # the qkv projections
-    assert any(e == "bbdm_conv1x1_bf3s_f32" and ci == co for e, px, ci, co in layers)                              # ... proj_out
+    # ... proj_out: the attention's output is a convex combination of value rows, bounded by bound(qkv) = GroupNorm bound x max row L1 of
+    # the qkv weight + max |bias| -- one bbdm_h2_affine_bound_f32 launch per attention block, before its proj_out
+    assert any(e == "bbdm_conv1x1_h2s_f32" and ci == co for e, px, ci, co in layers)
+    names = [str(n) for n, _ in plan.ops]
+    assert names.count("bbdm_h2_affine_bound_f32") == names.count("bbdm_attention_f32") > 0
+    for k, n in enumerate(names):
+        if n == "bbdm_attention_f32":
+            aff = max(j for j in range(k) if names[j] == "bbdm_h2_affine_bound_f32")
+            proj = next(j for j in range(k + 1, len(names)) if names[j] == "bbdm_conv1x1_bf3_f32")
+            assert plan.ops[proj][1][-2] is plan.ops[aff][1][-1]            # proj_out's xbound is the slot that launch wrote
     m1 = unet.UNetModel(**bench.WORKLOADS["c5"][1])
     m1.winograd, m1.conv1x1_h2 = 4, False
     layers1 = one_by_ones(m1._plan_for(torch.zeros(32, bench.WORKLOADS["c5"][1]["in_channels"], 16, 16), False))
