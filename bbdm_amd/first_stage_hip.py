@@ -50,6 +50,7 @@ class _Flags:
         self.gemm_h2 = True                 # tile GEMMs of the GroupNorm-fed 3x3 layers on the fp16-pair planes (csrc/h2_split.h), as in the UNet
         self.gemm_h2_train = 0
         self.conv1x1_h2 = False             # (its 1x1 layers -- the AttnBlock projections -- keep bf16x3)
+        self.attn_h2 = False                # (... and its single-head attention the one-launch bf16x3 kernel)
         self.fuse_stats = True
         self.bf3_min_tiles = 256
         self.conv1x1_small = True
