@@ -2,12 +2,12 @@
 # AddressSanitizer + UBSan pass over every kernel (CPU build of the SAME csrc/*.hip sources on tools/hipemu; no GPU sanitizers run on
 # this pool): the kernel tests and a tiny model forward / backward with exact-size torch allocations, which ASAN's malloc interposer
 # surrounds with red zones -- an out-of-bounds global read or write of a ragged-tile path aborts the run.
-#   bash tools/run_asan_emu.sh [pytest -k expression]     -> profiles/r05_asan_emu.txt (written when the run completes)
+#   bash tools/run_asan_emu.sh [pytest -k expression]     -> profiles/r06_asan_emu.txt (written when the run completes)
 set -u
 cd "$(dirname "$0")/.."
 python tools/hipemu/build.py --asan || exit 1
 RT=$(python -c "import sys; sys.path.insert(0, 'tools/hipemu'); import build; print(build.asan_runtime())")
-FINAL=profiles/r05_asan_emu.txt
+FINAL=profiles/r06_asan_emu.txt
 OUT=$(mktemp /tmp/asan_emu.XXXXXX)      # (moved over $FINAL only when the run has finished: an interrupted run leaves the last complete report)
 K=${1:-}
 {
