@@ -35,7 +35,6 @@ struct BwdArgs {
     int H, W, C, G;
     float eps;
     int silu, resample, accumulate;
-    float* dx_bound;             // or null: max |dx| of everything this launch writes is folded into *dx_bound (atomic max of a float >= 0)
 };
 
 // silu'(v) = s (1 + v (1 - s)), s = sigmoid(v), on the hardware v_exp_f32 + v_rcp_f32 (~2 ulp each; gradient bar 1e-3): both streaming
@@ -303,12 +302,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
     float* dxb = a.dx + (size_t)n * HW * a.lddx;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     int PP, prow, c4base;
-    bool active = true;
-    if (C4 <= 256) { PP = 256 / C4; prow = tid / C4; c4base = tid - prow * C4; active = prow < PP; }
+    if (C4 <= 256) { PP = 256 / C4; prow = tid / C4; c4base = tid - prow * C4; if (prow >= PP) return; }
     else { PP = 1; prow = 0; c4base = tid; }
-    float vmax = 0.f;                                            // max |dx| this thread wrote (dx_bound)
-    auto seen = [&](const float4& o) { vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w))); };
-    for (int c4 = active ? c4base : C4; c4 < C4; c4 += 256) {
+    for (int c4 = c4base; c4 < C4; c4 += 256) {
         const int c = c4 * 4;
         Chan4 k;
         if (NORM) k = load_chan(a, n, c, cpg);
@@ -331,7 +327,6 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
                     float4 o = NORM ? apply_quad(a, k, xv[u], dz[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
                     if (addb) { o.x += ad[u].x; o.y += ad[u].y; o.z += ad[u].z; o.w += ad[u].w; }
                     if (a.accumulate) { o.x += old[u].x; o.y += old[u].y; o.z += old[u].z; o.w += old[u].w; }
-                    seen(o);
                     *reinterpret_cast<float4*>(dxb + (size_t)(p + u * PP) * a.lddx + c) = o;
                 }
             }
@@ -353,19 +348,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
                 const float4 old = *reinterpret_cast<const float4*>(op);
                 o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
-            seen(o);
             *reinterpret_cast<float4*>(op) = o;
         }
-    }
-    // The consumer of dx -- the convolution in front of this GroupNorm -- scales its fp16-pair planes by max |dY| (csrc/h2_split.h): taken
-    // here instead of by a pass of its own (bbdm_absmax_rows_f32: 44 launches, 1.0 ms of the LBBDM-f4 micro-step).  One atomic per wave, and
-    // only from waves that would raise the value (a stale read costs an unnecessary atomic, never a wrong maximum; the order of the
-    // atomics cannot change a maximum: bitwise reproducible).
-    if (a.dx_bound) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if ((tid & 63) == 0 && vmax > __builtin_nontemporal_load(a.dx_bound))
-            atomicMax(reinterpret_cast<unsigned*>(a.dx_bound), __float_as_uint(vmax));
     }
 }
 
@@ -389,7 +373,7 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
                                       const float* film, int film_ld, const float* da, int ldda, const float* dadd,
                                       int ldadd, float* dx, int lddx, int accumulate, float* dgamma, float* dbeta,
                                       float* dfilm, int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps,
-                                      int silu, int resample, float* dx_bound, void* stream) {
+                                      int silu, int resample, void* stream) {
     BBDM_REQUIRE(dx, "gn_bwd: null dx");
     const int norm = gamma != nullptr;
     BBDM_REQUIRE(norm || dadd, "gn_bwd: nothing to do (no norm, no dadd)");
@@ -407,7 +391,6 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
     a.ldx = ldx; a.ldda = ldda; a.ldadd = ldadd; a.lddx = lddx; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample;
     a.N = N;
-    a.dx_bound = dx_bound;
     a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr; a.dgb = nullptr; a.dgamma = nullptr; a.dbeta = nullptr;
     const int HW = H * W;
     if (norm) {
