@@ -977,7 +977,8 @@ def run_workload(args, env):
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (tile GEMMs: fp32 operands as two fp16 planes under a provable power-of-two scale, 3 fp16-MFMA terms, fp32 "
                       "accumulate -- measured against fp64 MORE accurate than the six-term bf16x3 split and than the f32 MFMA; 1x1 layers "
-                      "whose input has a bound: the same pair; proj_out + attention: bf16x3; all other kernels native fp32)") if (use_bf3 and terms == 3.0) else
+                      "(skip / qkv / proj_out) and the long-sequence attention: the same pair; short-sequence, cross- and training "
+                      "attention: bf16x3; all other kernels native fp32)") if (use_bf3 and terms == 3.0) else
                      ("f32 (tile GEMMs: fp32 operands split exactly into 3 bf16, 6 bf16-MFMA terms, fp32 accumulate -- fp32-accurate; "
                       "all other kernels native fp32)") if use_bf3 else "f32", "data": "synthetic (seed 1234 image pairs, random-init weights N(0,0.02))",
             "config": {"workload": desc, "batch_per_gpu": batch, "image_size": size, "unet_params_M": nparams / 1e6,

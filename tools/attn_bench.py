@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""The C2 attention (N 16, T 4096, 16 heads x 64) on bbdm_attention_f32 and on the pre-split pair (K / V planes + attention), HIP events.
+"""The C2 attention (N 16, T 4096, 16 heads x 64) on bbdm_attention_f32, on the pre-split pair (K / V planes + attention) and on the pair's
+fp16-plane form (round 6), HIP events.
     python tools/attn_bench.py [--reps 20]"""
 import argparse
 import os
@@ -48,6 +49,22 @@ def main():
         t1, t2 = timed(kv), timed(at)
         print(f"K / V planes    : {t1:6.3f} ms  ({(N * T * 2 * C * 10) / t1 / 1e6:6.1f} GB/s)")
         print(f"planes attention: {t2:6.3f} ms  {fl / t2 / 1e9:6.1f} TF/s   pair {t1 + t2:6.3f} ms   bit-equal {torch.equal(out0, out1)}")
+        # ... on the fp16-pair planes (round 6): one scale from a bound of qkv -- the exact maximum, and 2^13 above it (where the planner's
+        # provable bound of a qkv projection sits); error of all three forms against an fp64 attention of image 0, head 0
+        nb2 = lib.bbdm_attention_kv_planes_h2_bytes(N, T, heads, ch)
+        out2 = torch.empty(N, T, C, device=dev)
+        q, k, v = (z[0, :, :ch].double() for z in (qkv[..., 0:ch], qkv[..., ch:2 * ch], qkv[..., 2 * ch:3 * ch]))   # (legacy order: head 0 = q | k | v)
+        ref = torch.softmax((q @ k.t()) * ch ** -0.5, dim=-1) @ v
+        err = lambda o: float((o[0, :, :ch].double() - ref).abs().max() / ref.abs().max())
+        print(f"error vs fp64   : one launch {err(out0):.2e}, bf16x3 pair {err(out1):.2e}")
+        for slack in (1.0, 8192.0):
+            bound = (qkv.abs().max() * slack).reshape(1).float()
+            kv2 = lambda: _lib.call("bbdm_attention_kv_planes_h2_f32", qkv.data_ptr(), 3 * C, planes.data_ptr(), nb2, N, T, heads, ch, 0, bound.data_ptr(), st)
+            at2 = lambda: _lib.call("bbdm_attention_planes_h2_f32", qkv.data_ptr(), 3 * C, out2.data_ptr(), C, None, N, T, heads, ch, 0, planes.data_ptr(), bound.data_ptr(), st)
+            t3 = timed(kv2)
+            t4 = timed(at2)
+            print(f"fp16-pair form, bound = {slack:g} x max |qkv|: K / V planes {t3:6.3f} ms, attention {t4:6.3f} ms  {fl / t4 / 1e9:6.1f} TF/s   "
+                  f"pair {t3 + t4:6.3f} ms   error vs fp64 {err(out2):.2e}")
 
 
 if __name__ == "__main__":
