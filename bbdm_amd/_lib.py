@@ -12,7 +12,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # BBDM_HIP_LIB overrides the library path (A/B runs of kernel variants); the default is the in-tree build
 LIB_PATH = os.environ.get("BBDM_HIP_LIB") or os.path.join(_HERE, "libbbdm_hip.so")
-ABI_VERSION = 26
+ABI_VERSION = 25
 
 _P = c_void_p
 # name -> (restype, argtypes); must list every symbol of include/bbdm_hip.h (tests/test_abi.py checks it)
@@ -70,7 +70,7 @@ SIGNATURES = {
     "bbdm_bb_loss_bwd_f32": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
     "bbdm_groupnorm_bwd_workspace_doubles": (c_size_t, [c_int, c_int, c_int]),
     "bbdm_groupnorm_bwd_f32": (c_int, [_P, c_int, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, _P, _P,
-                                       _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P, _P]),
+                                       _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P]),
     "bbdm_timestep_embedding_f32": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "bbdm_linear_f32": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "bbdm_linear_packed_bytes": (c_size_t, [c_int, c_int]),

@@ -35,7 +35,6 @@ struct BwdArgs {
     int H, W, C, G;
     float eps;
     int silu, resample, accumulate;
-    float* wg_max;               // or null: [gridDim.y][gridDim.x] max |dx| of what each workgroup of the apply pass stored (dx_bound)
 };
 
 // silu'(v) = s (1 + v (1 - s)), s = sigmoid(v), on the hardware v_exp_f32 + v_rcp_f32 (~2 ulp each; gradient bar 1e-3): both streaming
@@ -303,12 +302,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
     float* dxb = a.dx + (size_t)n * HW * a.lddx;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
     int PP, prow, c4base;
-    bool active = true;
-    if (C4 <= 256) { PP = 256 / C4; prow = tid / C4; c4base = tid - prow * C4; active = prow < PP; }
+    if (C4 <= 256) { PP = 256 / C4; prow = tid / C4; c4base = tid - prow * C4; if (prow >= PP) return; }
     else { PP = 1; prow = 0; c4base = tid; }
-    float vmax = 0.f;                                            // max |dx| this thread wrote (dx_bound)
-    auto seen = [&](const float4& o) { vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w))); };
-    for (int c4 = active ? c4base : C4; c4 < C4; c4 += 256) {
+    for (int c4 = c4base; c4 < C4; c4 += 256) {
         const int c = c4 * 4;
         Chan4 k;
         if (NORM) k = load_chan(a, n, c, cpg);
@@ -331,7 +327,6 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
                     float4 o = NORM ? apply_quad(a, k, xv[u], dz[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
                     if (addb) { o.x += ad[u].x; o.y += ad[u].y; o.z += ad[u].z; o.w += ad[u].w; }
                     if (a.accumulate) { o.x += old[u].x; o.y += old[u].y; o.z += old[u].z; o.w += old[u].w; }
-                    seen(o);
                     *reinterpret_cast<float4*>(dxb + (size_t)(p + u * PP) * a.lddx + c) = o;
                 }
             }
@@ -353,36 +348,9 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const BwdArgs a, int 
                 const float4 old = *reinterpret_cast<const float4*>(op);
                 o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
-            seen(o);
             *reinterpret_cast<float4*>(op) = o;
         }
     }
-    // The consumer of dx -- the convolution in front of this GroupNorm -- scales its fp16-pair planes by max |dY| (csrc/h2_split.h): taken
-    // here instead of by a pass of its own (bbdm_absmax_rows_f32: 44 launches, 1.0 ms of the LBBDM-f4 micro-step).  Every workgroup
-    // STORES its maximum and gn_max_fold_kernel folds them into *dx_bound: an atomic maximum from here -- even one per wave, and only
-    // from waves that would raise the value -- made this pass 1.6x slower (the ~2000 waves resident at the start of a launch finish
-    // together and meet on one address before any of them has published a value the others could skip on).
-    if (a.wg_max) {
-        __shared__ float wmax[4];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-        if ((tid & 63) == 0) wmax[tid >> 6] = vmax;
-        __syncthreads();
-        if (tid == 0) a.wg_max[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-    }
-}
-
-// *bound = max(*bound, wg_max[0 .. n)): one workgroup, one plain store (the caller zeroes *bound once per backward pass; launches that
-// fold into the same slot are ordered by the stream)
-__global__ void __launch_bounds__(256) gn_max_fold_kernel(const float* __restrict__ wg_max, int n, float* __restrict__ bound) {
-    float m = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, wg_max[i]);
-    __shared__ float wmax[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) *bound = fmaxf(*bound, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
 }
 
 }  // namespace
@@ -396,20 +364,16 @@ static int gn_bwd_splits(int N, int HW, int C) {
     return cdiv(HW, ppb);
 }
 // Workspace (8-byte elements): pq [N][splits <= ceil(1024 / N)][C][2] fp64 partials + dgb [N][C][2] fp64 + sg [N][G][2] fp64 +
-// coef [N][G] float4 (= 2 doubles each) + the apply pass's per-workgroup maxima (dx_bound: <= N ceil(4096 / N) floats).  Nothing in it
-// needs zeroing (every element read is stored first).
-static size_t gn_bwd_norm_doubles(int N, int C, int G) {
-    return (size_t)N * cdiv(1024, N > 0 ? N : 1) * C * 2 + (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)N * G * 2;
-}
+// coef [N][G] float4 (= 2 doubles each).  Nothing in it needs zeroing (every element read is stored first).
 extern "C" size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G) {
-    return gn_bwd_norm_doubles(N, C, G) + ((size_t)N * cdiv(4096, N > 0 ? N : 1) + 1) / 2;
+    return (size_t)N * cdiv(1024, N > 0 ? N : 1) * C * 2 + (size_t)N * C * 2 + (size_t)N * G * 2 + (size_t)N * G * 2;
 }
 
 extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats_, const float* gamma, const float* beta,
                                       const float* film, int film_ld, const float* da, int ldda, const float* dadd,
                                       int ldadd, float* dx, int lddx, int accumulate, float* dgamma, float* dbeta,
                                       float* dfilm, int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps,
-                                      int silu, int resample, float* dx_bound, void* stream) {
+                                      int silu, int resample, void* stream) {
     BBDM_REQUIRE(dx, "gn_bwd: null dx");
     const int norm = gamma != nullptr;
     BBDM_REQUIRE(norm || dadd, "gn_bwd: nothing to do (no norm, no dadd)");
@@ -427,8 +391,6 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
     a.ldx = ldx; a.ldda = ldda; a.ldadd = ldadd; a.lddx = lddx; a.film_ld = film_ld;
     a.H = H; a.W = W; a.C = C; a.G = norm ? G : 1; a.eps = eps; a.silu = silu; a.resample = resample;
     a.N = N;
-    a.wg_max = nullptr;
-    BBDM_REQUIRE(!dx_bound || ws, "gn_bwd: dx_bound needs the workspace");
     a.accumulate = accumulate; a.pq = nullptr; a.sg = nullptr; a.coef = nullptr; a.dgb = nullptr; a.dgamma = nullptr; a.dbeta = nullptr;
     const int HW = H * W;
     if (norm) {
@@ -460,10 +422,8 @@ extern "C" int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const void* stats
         if (ppb < PP * 4) ppb = PP * 4;
         ppb = cdiv(ppb, PP * 4) * (PP * 4);                      // whole four-pixel trips
         splits = cdiv(HW, ppb);
-        if (dx_bound) a.wg_max = reinterpret_cast<float*>(ws + gn_bwd_norm_doubles(N, C, G > 0 ? G : 1));      // splits <= ceil(4096 / N)
         if (norm) hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, dim3((unsigned)splits, N), dim3(256), 0, st, a, ppb);
         else hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, dim3((unsigned)splits, N), dim3(256), 0, st, a, ppb);
-        if (dx_bound) hipLaunchKernelGGL(gn_max_fold_kernel, dim3(1), dim3(256), 0, st, a.wg_max, splits * N, dx_bound);
     }
     BBDM_CHECK_LAUNCH("gn_bwd");
     return BBDM_OK;

@@ -12,7 +12,7 @@ void bbdm_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int bbdm_version(void) { return 26; }
+extern "C" int bbdm_version(void) { return 25; }
 
 // ---- options: the few integer switches tests and tools/ flip (kernel A/B inside ONE process).  Not read from the environment, not
 // latched: a launcher reads its option at every call.  Everything else the library decides from the shapes it is given.

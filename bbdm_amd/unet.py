@@ -1348,16 +1348,6 @@ class _Plan:
         """Bound slot for a gradient tensor: its exact maximum, measured by one pass (the slots are zeroed in backward_begin)."""
         ref = _Plan._H2Ref(self, self._h2_dy_slots, "dy")
         self._h2_dy_slots += 1
-        last = self.bops[-1] if self.bops else None
-        if last is not None and str(last[0]) == "bbdm_groupnorm_bwd_f32" and last[1][-1] is None and last[1][18] is not None:
-            # dy is what the launch just emitted wrote (the GroupNorm behind this convolution): it takes the maximum while it stores
-            # (csrc/groupnorm_bwd.hip: dx_bound) -- no pass of its own
-            # (or a channel range of it -- the h half of a concat gradient: the maximum over the whole buffer bounds the half too)
-            dx = last[1][11]
-            if (dx.buf is dy.buf and all(getattr(dx, k) == getattr(dy, k) for k in ("ld", "N", "H", "W"))
-                    and 0 <= dy.off - dx.off and dy.off - dx.off + dy.C <= dx.C):
-                last[1][-1] = ref
-                return ref
         self._bop("bbdm_absmax_rows_f32", dy, dy.ld, self.N * dy.H * dy.W, dy.C, ref)
         return ref
 
@@ -2162,7 +2152,7 @@ class _Plan:
             self._bop("bbdm_groupnorm_bwd_f32", x, x.ld, sstat(slot), self._pref(gn.weight), self._pref(gn.bias), film,
                       self.film_total, da, da.ld, dadd, dadd.ld if dadd is not None else 0, dx, dx.ld, acc,
                       gref(gn.weight), gref(gn.bias), dfilm, self.film_total, self._ws_d2, N, x.H, x.W, x.C, G,
-                      float(gn.eps), silu, rs, None)
+                      float(gn.eps), silu, rs)
 
         f32 = dict(dtype=torch.float32, device=dev)
         self.dfilm = torch.zeros(N, self.film_total, **f32)
@@ -2259,7 +2249,7 @@ class _Plan:
 
                 def accumulate(src: _View, dst: _View, acc: int):
                     self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, src, src.ld, dst, dst.ld,
-                              acc, None, None, None, 0, None, src.N, src.H, src.W, src.C, 1, 0.0, 0, 0, None)
+                              acc, None, None, None, 0, None, src.N, src.H, src.W, src.C, 1, 0.0, 0, 0)
 
                 def ln_bwd(ln_mod, xin: _View, dy: _View, dadd: _View) -> _View:
                     ws_doubles[0] = max(ws_doubles[0], 8 * xin.C)      # [2][C] limb cells of 4 words
@@ -2317,20 +2307,20 @@ class _Plan:
                 if ds.use_conv:
                     dfull = self._tmp("DDSF", N, x.H, x.W, ds.out_channels)
                     self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, dout, dout.ld, dfull,
-                              dfull.ld, 0, None, None, None, 0, None, N, x.H, x.W, dfull.C, 1, 0.0, 0, 3, None)
+                              dfull.ld, 0, None, None, None, 0, None, N, x.H, x.W, dfull.C, 1, 0.0, 0, 3)
                     dxs = conv_bwd(ds.op, x, dfull, True, "DA")
                     self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, dxs, dxs.ld, dx, dx.ld,
-                              first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 0, None)
+                              first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 0)
                 else:
                     self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, dout, dout.ld, dx, dx.ld,
-                              first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 1, None)
+                              first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 1)
             elif kind == "up":
                 _, us, x, u, out = rec
                 dout = gview(out)
                 dx = gview(x)
                 du = conv_bwd(us.conv, u, dout, True, "DA") if us.use_conv else dout
                 self._bop("bbdm_groupnorm_bwd_f32", None, 0, None, None, None, None, 0, None, 0, du, du.ld, dx, dx.ld,
-                          first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 2, None)
+                          first_write(x), None, None, None, 0, None, N, x.H, x.W, x.C, 1, 0.0, 0, 2)
             elif kind == "stem":
                 _, conv, x, out = rec
                 dout = gview(out)

@@ -344,16 +344,13 @@ int bbdm_bb_loss_bwd_f32(const float* pred, const float* target, const float* gs
  *          this term is produced (pure resample backward)
  *   dx   : result, pitch lddx; accumulate != 0 adds to what is there (a tensor feeding two consumers)
  *   dgamma / dbeta [C] are overwritten; dfilm (may be NULL) receives [N][dfilm_ld] d scale at [c], d shift at [C+c]
- *   ws   : bbdm_groupnorm_bwd_workspace_doubles() fp64 elements of scratch.
- *   dx_bound (may be NULL; needs ws; ABI 26): *dx_bound = max(*dx_bound, max |dx| over everything this launch writes) -- the caller
- *          zeroes it once per backward pass; the convolution in front of the GroupNorm scales its fp16-pair planes by it (what
- *          bbdm_absmax_rows_f32 measures with a pass of its own; here the workgroups store their maxima and one more workgroup folds them). */
+ *   ws   : bbdm_groupnorm_bwd_workspace_doubles() fp64 elements of scratch. */
 size_t bbdm_groupnorm_bwd_workspace_doubles(int N, int C, int G);
 int bbdm_groupnorm_bwd_f32(const float* x, int ldx, const bbdm_stats_t* stats, const float* gamma, const float* beta,
                            const float* film, int film_ld, const float* da, int ldda, const float* dadd, int ldadd,
                            float* dx, int lddx, int accumulate, float* dgamma, float* dbeta, float* dfilm,
                            int dfilm_ld, double* ws, int N, int H, int W, int C, int G, float eps, int silu,
-                           int resample, float* dx_bound, void* stream);
+                           int resample, void* stream);
 
 /* ---- VQGAN first stage: the ops model/VQGAN/model.py + quantize.py need beyond the UNet's --------- */
 /* Batched GEMM with ACTIVATION operands (AttnBlock's bmm(q, k) and bmm(v, w_), model.py:166-185, one head over all channels):

@@ -412,8 +412,8 @@ def colsum(dy: torch.Tensor, C: Optional[int] = None) -> torch.Tensor:
 
 
 def groupnorm_bwd(x, stats, gamma, beta, da, film=None, dadd=None, eps=1e-5, silu=False, resample=0, groups=32,
-                  dx=None, accumulate=False, dx_bound=None):
-    """Returns (dx, dgamma, dbeta, dfilm[N, 2C] or None).  ``dx_bound``: a one-element device tensor the launch folds max |dx| into."""
+                  dx=None, accumulate=False):
+    """Returns (dx, dgamma, dbeta, dfilm[N, 2C] or None)."""
     _chk(x, stats, gamma, beta, da, film, dadd, dx)
     N, H, W, C = x.shape
     if dx is None:
@@ -428,7 +428,7 @@ def groupnorm_bwd(x, stats, gamma, beta, da, film=None, dadd=None, eps=1e-5, sil
               0 if film is None else film.shape[1], p(da), 0 if da is None else da.shape[-1], p(dadd),
               0 if dadd is None else dadd.shape[-1], dx.data_ptr(), dx.shape[-1], 1 if accumulate else 0, p(dgamma),
               p(dbeta), p(dfilm), 0 if dfilm is None else 2 * C, ws.data_ptr(), N, H, W, C, groups, float(eps),
-              1 if silu else 0, resample, p(dx_bound), _st(x))
+              1 if silu else 0, resample, _st(x))
     return dx, dgamma, dbeta, dfilm
 
 

@@ -211,22 +211,13 @@ def test_groupnorm_backward(dev, N, H, W, C, mode):
     stats = ops.groupnorm_stats(xg)
     init = torch.randn(N, H, W, C, generator=g) if mode == "silu_add_acc" else None
     dx0 = init.clone().to(dev) if init is not None else None
-    bound = torch.full((1,), 1e-3, dtype=torch.float32, device=dev)       # (a maximum taken earlier in the pass: only ever raised)
     dx, dg, dbt, dfilm = ops.groupnorm_bwd(xg, stats, gamma.detach().to(dev), beta.detach().to(dev), _nhwc(da).to(dev),
                                            film=film.detach().to(dev) if use_film else None,
                                            dadd=_nhwc(dadd).to(dev) if dadd is not None else None, silu=silu,
-                                           resample=resample, dx=dx0, accumulate=init is not None, dx_bound=bound)
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
+                                           resample=resample, dx=dx0, accumulate=init is not None)
+    torch.cuda.synchronize()
     want = x.grad + (_nchw(init) if init is not None else 0.0)
     assert rel_err(_nchw(dx.cpu()), want) < TOL
-    # dx_bound: EXACTLY the largest |dx| the launch stored (what bbdm_absmax_rows_f32 would measure) -- the scale of the fp16-pair planes
-    # the convolution in front of this GroupNorm builds of dx must cover every element
-    assert bound.item() == dx.abs().max().item()
-    big = torch.full((1,), 1e9, dtype=torch.float32, device=dev)
-    ops.groupnorm_bwd(xg, stats, gamma.detach().to(dev), beta.detach().to(dev), _nhwc(da).to(dev), film=film.detach().to(dev) if use_film else None,
-                      dadd=_nhwc(dadd).to(dev) if dadd is not None else None, silu=silu, resample=resample, dx_bound=big)
-    assert big.item() == 1e9
     assert rel_err(dg.cpu(), gamma.grad) < TOL and rel_err(dbt.cpu(), beta.grad) < TOL
     if use_film:
         assert rel_err(dfilm.cpu(), film.grad) < TOL

@@ -141,16 +141,9 @@ def test_plan_ops_are_consistent(workload, batch, training, cap):
             assert isinstance(vb, unet._Plan._H2Ref) and g[-2] is vb
             if k >= len(plan.ops):              # data gradient: dY under its measured maximum -- the launch before the transform takes it
                 assert training and vb.kind == "dy" and 0 <= vb.k < plan._h2_dy_slots and i[4] is None
-                # ... taken ONCE earlier in the same layer's backward: by the GroupNorm backward that wrote dY (its dx_bound; dY may be a
-                # channel range of that launch's dx, the h half of a concat gradient) or, where dY has another producer, by a pass of its own
+                # ... measured by ONE pass earlier in the same layer's backward (right before, or ahead of its weight-gradient chain)
                 prev = [pa for pn, pa in ops[max(0, k - 8):k] if pn == "bbdm_absmax_rows_f32" and pa[-1] is vb]
-                fused = [pa for pn, pa in ops[max(0, k - 8):k] if pn == "bbdm_groupnorm_bwd_f32" and pa[-1] is vb]
-                assert len(prev) + len(fused) == 1
-                if prev:
-                    assert prev[0][0] is i[1] and prev[0][3] == cin
-                else:
-                    dxv, dyv = fused[0][11], i[1]
-                    assert dxv.buf is dyv.buf and dxv.ld == dyv.ld and 0 <= dyv.off - dxv.off <= dxv.C - dyv.C and dyv.C == cin
+                assert len(prev) == 1 and prev[0][0] is i[1] and prev[0][3] == cin
             else:                               # forward: the GroupNorm bound of this layer's input
                 assert vb.kind == "gn" and 0 <= vb.k < len(plan._h2_layers)
                 gam, bet, fo, C, z = plan._h2_layers[vb.k]
