@@ -1407,7 +1407,7 @@ def test_attention_presplit_form_is_bit_equal(dev, N, T, heads, ch, new_order):
 
 
 @pytest.mark.parametrize("N,T,heads,ch,new_order,slack", [(2, 128, 2, 64, False, 1.0), (1, 256, 3, 32, True, 1.0), (1, 1024, 2, 64, False, 1.0),
-                                                          (2, 384, 1, 64, True, 4096.0), (1, 256, 2, 32, False, 2048.0)])
+                                                          (2, 384, 1, 64, True, 4096.0), (1, 256, 2, 32, False, 2048.0), (1, 4096, 2, 64, False, 4096.0)])     # (the last: C2's sequence length)
 def test_attention_h2(dev, N, T, heads, ch, new_order, slack):
     """The pre-split attention on the fp16-pair planes (bbdm_attention_kv_planes_h2_f32 + bbdm_attention_planes_h2_f32: q, k, v under one
     power-of-two scale from a bound of the qkv tensor, the softmax weights under their exact bound 1, three f16 MFMA terms per product)
