@@ -321,19 +321,22 @@ __global__ void __launch_bounds__(256) h2_stats_bound_kernel(const unsigned long
 // last factor are properties of the weights (h2_rowl1_kernel, at packing time), the middle one is the input's bound of every forward
 // (h2_affine_bound_kernel: one thread) -- the bound behind the attention's fp16-pair planes (csrc/attention.hip), whose operands are
 // the qkv projection of a GroupNorm output.
+__global__ void h2_zero2_kernel(float* __restrict__ out2) { out2[0] = 0.f; out2[1] = 0.f; }
 __global__ void __launch_bounds__(256) h2_rowl1_kernel(const float* __restrict__ w, const float* __restrict__ bias, int rows, int cols,
                                                        float* __restrict__ out2) {
-    // ONE workgroup (packing time: a few million elements at most): a wave per row, lanes along the row; no atomics, nothing to zero
+    // a wave per row, lanes along the row; one atomic maximum per workgroup into the zeroed pair (non-negative floats order like their
+    // bits; a maximum does not depend on the order of the atomics).  Training plans run this after every optimizer step: as ONE
+    // workgroup it took 3.8 ms for the 3072 x 1024 qkv weight of the LBBDM-f4 UNet (profiles/r06_c3_kernel_stats.md of that build)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float l1 = 0.f, bm = 0.f;
-    for (int row = wave; row < rows; row += 4) {
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         float a = 0.f;
         for (int k = lane; k < cols; k += 64) a += fabsf(w[(size_t)row * cols + k]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
         l1 = fmaxf(l1, a);
     }
-    if (bias)
+    if (bias && blockIdx.x == 0)
         for (int k = threadIdx.x; k < rows; k += 256) bm = fmaxf(bm, fabsf(bias[k]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o));
@@ -342,8 +345,8 @@ __global__ void __launch_bounds__(256) h2_rowl1_kernel(const float* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         // (sums of non-negative fp32 terms: every rounding is below 2^-24 relative; the margin covers rows of 2^16 elements)
-        out2[0] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.004f;
-        out2[1] = fmaxf(fmaxf(redb[0], redb[1]), fmaxf(redb[2], redb[3]));
+        atomicMax(reinterpret_cast<unsigned*>(out2), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.004f));
+        if (blockIdx.x == 0) out2[1] = fmaxf(fmaxf(redb[0], redb[1]), fmaxf(redb[2], redb[3]));
     }
 }
 __global__ void h2_affine_bound_kernel(const float* __restrict__ in, const float* __restrict__ gain2, float* __restrict__ out) {
@@ -353,7 +356,8 @@ __global__ void h2_affine_bound_kernel(const float* __restrict__ in, const float
 
 extern "C" int bbdm_h2_rowl1_f32(const float* w, const float* bias, int rows, int cols, float* out2, void* stream) {
     BBDM_REQUIRE(w && out2 && rows > 0 && cols > 0, "h2_rowl1: bad args");
-    hipLaunchKernelGGL(h2_rowl1_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w, bias, rows, cols, out2);
+    hipLaunchKernelGGL(h2_zero2_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out2);
+    hipLaunchKernelGGL(h2_rowl1_kernel, dim3((unsigned)min(256, cdiv(rows, 4))), dim3(256), 0, (hipStream_t)stream, w, bias, rows, cols, out2);
     BBDM_CHECK_LAUNCH("h2_rowl1");
     return BBDM_OK;
 }
